@@ -1,0 +1,112 @@
+/*
+ * szo.h -- ORACLE (test infrastructure only): a CPU restatement, in plain C, of the
+ * SZ 2.1.12 hot path (block Lorenzo / linear-regression prediction + error-bounded
+ * quantisation + Huffman coding, and the inverse) as implemented by the reference
+ * szcompressor/sz.  Every function cites the reference file:line it follows
+ * (paths relative to the reference tree).
+ *
+ * This code is NOT part of the product.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load liboracle.so, and only as the checker.
+ *
+ * PARITY PIN: the reference cannot be compiled in this image without writing a
+ * stand-in for its generated config.h (sz/src/sz.c:11, dataCompression.c:10), so no
+ * oracle/_ref build exists.  The oracle is pinned instead against the outputs of the
+ * unmodified reference recorded by the survey (SURVEY.md section 6 / BASELINE.md
+ * section 2): stream md5 + byte sizes + PSNR anchors, see tests/test_oracle_pins.py.
+ */
+#ifndef SZO_H
+#define SZO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* mirrors the fields of sz_params / sz_exedata that the hot path reads
+ * (sz/include/sz.h:164-217); defaults follow sz/src/conf.c:99-141 and example/sz.config */
+typedef struct szo_params {
+    int      sample_distance;        /* sampleDistance, default 100 */
+    float    pred_threshold;         /* predThreshold, default 0.99f */
+    unsigned max_quant_intervals;    /* default 65536 -> maxRangeRadius 32768 */
+    unsigned quantization_intervals; /* 0 = optimise (optQuantMode 1) */
+    int      with_regression;        /* SZ_WITH_LINEAR_REGRESSION (1) */
+    int      sz_mode;                /* written into the params byte; stream itself is always pre-lossless */
+    int      gzip_mode;              /* only for the params byte */
+    int      protect_value_range;
+    int      data_endian;            /* dataEndianType, 0 = little */
+    int      sol_id;                 /* 101 = SZ */
+    double   psnr;                   /* for errorBoundMode PSNR */
+    double   norm_err;               /* for errorBoundMode NORM */
+} szo_params;
+
+void szo_default_params(szo_params *p);
+
+/* intermediate products of one SZ2.1 block-regression compression, for kernel-level parity tests */
+typedef struct szo_stages {
+    size_t   num_elements, num_blocks, reg_count, total_unpred;
+    unsigned intervals;
+    int      use_mean;
+    double   mean;            /* widened copy of the T-typed mean */
+    double   eb;              /* the T-narrowed bound, widened */
+    double   dense_pos, mean_freq, sample_freq;
+    int     *codes;           /* [num_elements], block order (type array) */
+    unsigned char *indicator; /* [num_blocks], 1 = Lorenzo */
+    void    *unpred;          /* [total_unpred] of T, block order */
+    void    *reg_params;      /* [4*num_blocks] of T, SoA a|b|c|d (2-D: 3*num_blocks a|b|c) */
+    int     *coeff_codes;     /* [ncoef*reg_count] */
+    void    *coeff_dec;       /* [ncoef*reg_count] of T: decoded coefficients per regression block */
+    size_t   coeff_unpred_count[4];
+    void    *coeff_unpred[4];
+    unsigned char *code_len;  /* [2*intervals] Huffman code lengths (cout[]) */
+    size_t   tree_bytes, node_count, huff_bytes;
+} szo_stages;
+
+void szo_free_stages(szo_stages *s);
+
+/* Whole-API restatement of SZ_compress_args() for SZ_FLOAT(0)/SZ_DOUBLE(1)
+ * (sz/src/sz.c:294-391 -> sz_float.c:2811-3043 / sz_double.c:2531...).
+ * Returns a malloc'd stream in the pre-lossless ("SZ_BEST_SPEED") form; *out_size its length.
+ * If stages != NULL and the SZ2.1 path was taken, fills it (caller frees with szo_free_stages). */
+unsigned char *szo_compress_args(const szo_params *p, int data_type, const void *data, size_t *out_size,
+                                 int err_bound_mode, double abs_err, double rel_ratio,
+                                 size_t r5, size_t r4, size_t r3, size_t r2, size_t r1,
+                                 szo_stages *stages);
+
+/* Restatement of SZ_decompress() for pre-lossless streams (sz/src/sz.c:486-577 ->
+ * szd_float.c:50-183).  Returns malloc'd array of T, or NULL on error. */
+void *szo_decompress(int data_type, const unsigned char *bytes, size_t byte_len,
+                     size_t r5, size_t r4, size_t r3, size_t r2, size_t r1);
+
+/* ---- Huffman coder (sz/src/Huffman.c) ---- */
+typedef struct szo_huff {
+    int       state_num;     /* alphabet size (2*intervals) */
+    int       n_nodes;       /* nodes in pool */
+    int       root;          /* pool index of root, -1 if empty */
+    uint64_t *freq;          /* per node */
+    int      *left, *right;  /* per node, -1 for leaves */
+    unsigned *sym;           /* per node (0 for internal nodes) */
+    unsigned char *leaf;     /* per node t flag */
+    uint64_t *code;          /* per symbol, MSB-aligned in 64 bits */
+    unsigned char *len;      /* per symbol (cout[]), 0 = unused (or the single-symbol case) */
+    unsigned char *used;     /* per symbol: code[] pointer non-NULL in the reference */
+} szo_huff;
+
+szo_huff *szo_huff_from_freq(int state_num, const uint64_t *freq, size_t nfreq);
+szo_huff *szo_huff_from_symbols(int state_num, const int *s, size_t n);
+size_t    szo_huff_node_count(const szo_huff *h);                 /* 2*distinct-1 */
+size_t    szo_huff_tree_to_bytes(const szo_huff *h, unsigned char **out); /* convert_HuffTree_to_bytes_anyStates */
+szo_huff *szo_huff_tree_from_bytes(int state_num, const unsigned char *bytes, int node_count);
+size_t    szo_huff_encode(const szo_huff *h, const int *s, size_t n, unsigned char *out); /* returns bytes */
+void      szo_huff_decode(const szo_huff *h, const unsigned char *in, size_t n, int *out);
+void      szo_huff_free(szo_huff *h);
+
+/* quality metrics with the formulas of example/sz.c:558-620 */
+void szo_metrics_f32(const float *a, const float *b, size_t n, double *max_abs_err, double *psnr, double *nrmse);
+void szo_metrics_f64(const double *a, const double *b, size_t n, double *max_abs_err, double *psnr, double *nrmse);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,50 @@
+"""Synthetic test fields of SURVEY.md section 8(d) (no RNG; pure functions of the index).
+
+S-field: smooth sinusoid (reference picks Lorenzo for every block)
+L-field: slow ramp + hash noise (reference picks regression for every block)
+M-field: S for z < N/2, L for z >= N/2 (exactly 50 % regression blocks at 256^3)
+Arrays are indexed [z, y, x] with x fastest, i.e. SZ dims r1 = nx, r2 = ny, r3 = nz.
+"""
+import numpy as np
+
+
+def _grid(nz, ny, nx, z0=0):
+    z = np.arange(z0, z0 + nz, dtype=np.float64)[:, None, None]
+    y = np.arange(ny, dtype=np.float64)[None, :, None]
+    x = np.arange(nx, dtype=np.float64)[None, None, :]
+    return z, y, x
+
+
+def s_field(nz, ny, nx, dtype=np.float32, z0=0):
+    z, y, x = _grid(nz, ny, nx, z0)
+    tp = 2.0 * np.pi
+    f = np.sin(tp * x / 64.0) * np.cos(tp * y / 96.0) * np.sin(tp * z / 128.0)
+    f = f + 0.5 * np.sin(tp * (x + 2.0 * y + 3.0 * z) / 256.0)
+    return np.ascontiguousarray(f.astype(dtype))
+
+
+def l_field(nz, ny, nx, dtype=np.float32, z0=0, n_for_hash=None):
+    """`idx = (z*N + y)*N + x` with N = n_for_hash (defaults to nx, the cube edge)."""
+    N = np.uint64(n_for_hash if n_for_hash is not None else nx)
+    z, y, x = _grid(nz, ny, nx, z0)
+    tp = 2.0 * np.pi
+    f = np.sin(tp * x / 2048.0) + np.cos(tp * y / 2048.0) + np.sin(tp * z / 2048.0)
+    zi = np.arange(z0, z0 + nz, dtype=np.uint64)[:, None, None]
+    yi = np.arange(ny, dtype=np.uint64)[None, :, None]
+    xi = np.arange(nx, dtype=np.uint64)[None, None, :]
+    idx = (zi * N + yi) * N + xi
+    m32 = np.uint64(0xFFFFFFFF)
+    h = (idx * np.uint64(2654435761)) & m32
+    h = ((h ^ (h >> np.uint64(15))) * np.uint64(2246822519)) & m32
+    h = h ^ (h >> np.uint64(13))
+    u = (h & np.uint64(0xFFFFFF)).astype(np.float64) / float(1 << 24)
+    f = f + (2.0 * u - 1.0) * 5e-4
+    return np.ascontiguousarray(f.astype(dtype))
+
+
+def m_field(n, dtype=np.float32):
+    out = np.empty((n, n, n), dtype=dtype)
+    h = n // 2
+    out[:h] = s_field(h, n, n, dtype)
+    out[h:] = l_field(n - h, n, n, dtype, z0=h, n_for_hash=n)
+    return out
