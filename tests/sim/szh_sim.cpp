@@ -1,0 +1,101 @@
+// szh_sim.cpp -- TEST INFRASTRUCTURE ONLY (never linked into the product library).
+// A CPU lane simulator that instantiates the exact kernel bodies of sz_amd/csrc/szh_pencil.h with
+// NL = 64 lanes per "wavefront" and runs pencils sequentially in ticket order, so that the
+// index/shuffle/halo logic of the HIP kernel can be checked against the oracle without a GPU.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../../sz_amd/csrc/szh_pencil.h"
+
+struct SimBackend {
+    static constexpr int NL = 64;
+    static int lane(int l) { return l; }
+    template <class T> static void shfl_up(T (&dst)[64], const T (&src)[64], int d)
+    {
+        T tmp[64];
+        for (int l = 0; l < 64; ++l) tmp[l] = (l >= d) ? src[l - d] : src[l];
+        for (int l = 0; l < 64; ++l) dst[l] = tmp[l];
+    }
+    template <class T> static T readlane(const T (&src)[64], int lane) { return src[lane]; }
+    static bool all(const bool (&p)[64]) { for (int l = 0; l < 64; ++l) if (!p[l]) return false; return true; }
+    static szh_u64 ld_gran(const szh_u64 *p) { return *p; }
+    static void st_gran(szh_u64 *p, szh_u64 v) { *p = v; }
+    static void backoff() {}
+};
+
+template <class T, bool DEC>
+static int run_all(szh_qargs<T> a)
+{
+    const int r0 = a.G.g0.count, r1 = a.G.g1.count, r2 = a.G.g2.count;
+    a.nI = (r0 + 7) / 8; a.nJ = (r1 + 7) / 8;
+    const size_t ng = (size_t)a.nI * a.nJ * 8 * r2 * szh_gran<T>::NW;
+    std::vector<szh_u64> fI(ng, 0), fJ(ng, 0);
+    a.faceI = fI.data(); a.faceJ = fJ.data(); a.epoch = 7;
+    std::vector<unsigned> order((size_t)a.nI * a.nJ);
+    szh_fill_pencil_order(a.nI, a.nJ, order.data());
+    unsigned err = 0; a.err = &err;
+    for (size_t tk = 0; tk < order.size(); ++tk)
+        szh_pencil_run<T, DEC, SimBackend>(a, (int)(order[tk] >> 16), (int)(order[tk] & 0xffff));
+    return (int)err;
+}
+
+template <class T>
+static int quantize(const T *data, int r0, int r1, int r2, double eb, int cap, int use_mean, double mean,
+                    const uint8_t *blk_lor, const T *coef, uint16_t *codes_nat)
+{
+    szh_qargs<T> a; memset(&a, 0, sizeof(a));
+    a.G = szh_make_geom3(r0, r1, r2);
+    a.data = data; a.codes = codes_nat; a.blk_lor = blk_lor; a.coef = coef;
+    a.eb = (T)eb; a.recip = 1 / a.eb; a.mean = (T)mean; a.cap = cap; a.radius = cap / 2; a.use_mean = use_mean;
+    return run_all<T, false>(a);
+}
+template <class T>
+static int reconstruct(T *out, int r0, int r1, int r2, double eb, int cap, int use_mean, double mean,
+                       const uint8_t *blk_lor, const T *coef, const uint16_t *codes_nat)
+{
+    szh_qargs<T> a; memset(&a, 0, sizeof(a));
+    a.G = szh_make_geom3(r0, r1, r2);
+    a.out = out; a.codes = const_cast<uint16_t *>(codes_nat); a.blk_lor = blk_lor; a.coef = coef;
+    a.eb = (T)eb; a.recip = 1 / a.eb; a.mean = (T)mean; a.cap = cap; a.radius = cap / 2; a.use_mean = use_mean;
+    return run_all<T, true>(a);
+}
+
+extern "C" {
+int szh_sim_quantize_f32(const float *d, int r0, int r1, int r2, double eb, int cap, int um, double mean,
+                         const uint8_t *bl, const float *coef, uint16_t *codes)
+{ return quantize<float>(d, r0, r1, r2, eb, cap, um, mean, bl, coef, codes); }
+int szh_sim_quantize_f64(const double *d, int r0, int r1, int r2, double eb, int cap, int um, double mean,
+                         const uint8_t *bl, const double *coef, uint16_t *codes)
+{ return quantize<double>(d, r0, r1, r2, eb, cap, um, mean, bl, coef, codes); }
+int szh_sim_reconstruct_f32(float *o, int r0, int r1, int r2, double eb, int cap, int um, double mean,
+                            const uint8_t *bl, const float *coef, const uint16_t *codes)
+{ return reconstruct<float>(o, r0, r1, r2, eb, cap, um, mean, bl, coef, codes); }
+int szh_sim_reconstruct_f64(double *o, int r0, int r1, int r2, double eb, int cap, int um, double mean,
+                            const uint8_t *bl, const double *coef, const uint16_t *codes)
+{ return reconstruct<double>(o, r0, r1, r2, eb, cap, um, mean, bl, coef, codes); }
+
+// natural <-> block order maps (plain loops over the geometry; reference for the GPU permute kernels)
+void szh_sim_nat_to_blk_u16(const uint16_t *nat, int r0, int r1, int r2, int32_t *blk)
+{
+    szh_geom3 G = szh_make_geom3(r0, r1, r2);
+    for (int b0 = 0; b0 < G.g0.num; ++b0) for (int b1 = 0; b1 < G.g1.num; ++b1) for (int b2 = 0; b2 < G.g2.num; ++b2) {
+        int64_t p = szh_code_base(G, b0, b1, b2);
+        int o0 = szh_blk_start(G.g0, b0), o1 = szh_blk_start(G.g1, b1), o2 = szh_blk_start(G.g2, b2);
+        int s0 = szh_blk_size(G.g0, b0), s1 = szh_blk_size(G.g1, b1), s2 = szh_blk_size(G.g2, b2);
+        for (int i = 0; i < s0; ++i) for (int j = 0; j < s1; ++j) for (int k = 0; k < s2; ++k)
+            blk[p++] = nat[(int64_t)(o0 + i) * G.d0 + (int64_t)(o1 + j) * G.d1 + (o2 + k)];
+    }
+}
+void szh_sim_blk_to_nat_u16(const int32_t *blk, int r0, int r1, int r2, uint16_t *nat)
+{
+    szh_geom3 G = szh_make_geom3(r0, r1, r2);
+    for (int b0 = 0; b0 < G.g0.num; ++b0) for (int b1 = 0; b1 < G.g1.num; ++b1) for (int b2 = 0; b2 < G.g2.num; ++b2) {
+        int64_t p = szh_code_base(G, b0, b1, b2);
+        int o0 = szh_blk_start(G.g0, b0), o1 = szh_blk_start(G.g1, b1), o2 = szh_blk_start(G.g2, b2);
+        int s0 = szh_blk_size(G.g0, b0), s1 = szh_blk_size(G.g1, b1), s2 = szh_blk_size(G.g2, b2);
+        for (int i = 0; i < s0; ++i) for (int j = 0; j < s1; ++j) for (int k = 0; k < s2; ++k)
+            nat[(int64_t)(o0 + i) * G.d0 + (int64_t)(o1 + j) * G.d1 + (o2 + k)] = (uint16_t)blk[p++];
+    }
+}
+}
