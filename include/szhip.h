@@ -1,0 +1,102 @@
+/*
+ * szhip.h -- C ABI of the MI355X (gfx950) HIP layer of the SZ 2.1 hot path.
+ *
+ * Everything below is `extern "C"`, plain pointers and sizes, no globals: this is what the
+ * reference's own host code would bind instead of its CPU loops.  The reference has no FFI for
+ * this path (it is one C library); the entry points therefore replace these internal call sites:
+ *
+ *   szhip_compress()      replaces  SZ_compress_float_3D_MDQ_nonblocked_with_blocked_regression
+ *                                   (sz/src/sz_float.c:6527-7489) and the double twin
+ *                                   (sz/src/sz_double.c:5904), called from SZ_compress_args_float
+ *                                   (sz/src/sz_float.c:2974,3012) / _double
+ *   szhip_decompress()    replaces  decompressDataSeries_float_3D_nonblocked_with_blocked_regression
+ *                                   (sz/src/szd_float.c:3483-5866) / _double (szd_double.c:3316),
+ *                                   called from SZ_decompress_args_float (sz/src/szd_float.c:133)
+ *   szhip_minmax()        replaces  computeRangeSize_float/_double (sz/src/dataCompression.c:102,149)
+ *
+ * The streams produced/consumed are the reference's SZ 2.1 "raBytes" streams, byte for byte
+ * (pre-lossless, i.e. what the reference emits with szMode = SZ_BEST_SPEED).
+ */
+#ifndef SZHIP_H
+#define SZHIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SZHIP_OK            0
+#define SZHIP_ERR_NODEVICE -1   /* no HIP device / runtime failure */
+#define SZHIP_ERR_ARG      -2
+#define SZHIP_ERR_UNSUP    -3   /* valid SZ input this layer does not cover yet */
+#define SZHIP_ERR_STREAM   -4   /* malformed compressed stream */
+#define SZHIP_ERR_INTERNAL -5   /* kernel-side timeout or inconsistency */
+
+#define SZHIP_F32 0
+#define SZHIP_F64 1
+
+typedef struct szhip_ctx szhip_ctx; /* owns one HIP stream and grow-only device workspaces */
+
+/* parameters the hot path reads from sz_params / sz_exedata (sz/include/sz.h:164-217), passed by value */
+typedef struct szhip_params {
+    int      sample_distance;        /* sampleDistance */
+    float    pred_threshold;         /* predThreshold */
+    unsigned max_quant_intervals;    /* max_quant_intervals (maxRangeRadius = half of it) */
+    unsigned quantization_intervals; /* 0: optimise (optQuantMode 1); else fixed capacity */
+} szhip_params;
+
+/* per-call measurements (all times in milliseconds, device events on the ctx stream) */
+typedef struct szhip_stats {
+    double ms_total;        /* whole call, device side incl. host glue between kernels */
+    double ms_prequant;     /* fit + sampling + selection kernels */
+    double ms_quant;        /* the predict+quantise (or reconstruct) wavefront kernel alone */
+    double ms_entropy;      /* histogram/permute/encode (or decode/permute) kernels */
+    double ms_host;         /* host glue: tree build, coefficient chain, header */
+    uint64_t n_elements, n_blocks, n_reg_blocks, n_unpred;
+    unsigned intervals; int use_mean;
+    uint64_t out_bytes;
+    uint64_t quant_kernel_launches; /* launches of the wavefront kernel (1 per call) */
+} szhip_stats;
+
+int  szhip_create(szhip_ctx **ctx, int device);
+void szhip_destroy(szhip_ctx *ctx);
+const char *szhip_last_error(szhip_ctx *ctx);
+
+/* copy a host array into the context's device input buffer once, so that szhip_minmax and
+ * szhip_compress can both run on it (data_on_device = 1) without a second PCIe transfer */
+int szhip_stage_input(szhip_ctx *ctx, const void *host_data, size_t bytes, void **device_ptr);
+
+/* min / max of n values (device or host pointer) */
+int szhip_minmax(szhip_ctx *ctx, int dtype, const void *data, int data_on_device, size_t n, double *vmin, double *vmax);
+
+/*
+ * Compress a 3-D array (r0 slowest ... r2 fastest, the callee convention of sz_float.c:6527) with
+ * absolute bound `eb` (already derived from the user's mode by the caller, sz_float.c:2852-2868).
+ * `meta`/`meta_len`: the 3 version bytes + flag byte + parameter bytes the stream starts with.
+ * Output: if out_on_device, *out is a device pointer owned by ctx (valid until the next call);
+ * otherwise *out is malloc'd host memory owned by the caller (free()).
+ */
+int szhip_compress(szhip_ctx *ctx, int dtype, const void *data, int data_on_device,
+                   size_t r0, size_t r1, size_t r2, double eb, const szhip_params *params,
+                   const unsigned char *meta, size_t meta_len,
+                   int out_on_device, unsigned char **out, size_t *out_size, szhip_stats *stats);
+
+/*
+ * Decompress a SZ 2.1 regression-type stream.  `stream` points at the first byte of the whole stream
+ * (version bytes); `body_off` is the offset of the block-size field (4 + 28|36 + 8).
+ * `out`: device pointer (out_on_device) or host pointer to r0*r1*r2 values.
+ */
+int szhip_decompress(szhip_ctx *ctx, int dtype, const unsigned char *stream, int stream_on_device, size_t stream_len,
+                     size_t body_off, size_t r0, size_t r1, size_t r2,
+                     void *out, int out_on_device, szhip_stats *stats);
+
+/* test/diagnostic hook: copy the first `bytes` bytes of an internal device workspace of the LAST call to host.
+ * which: 0 coef (T SoA[4][nblocks]) 1 blk_lor (u8) 2 codes in natural order (u16) 3 codes in block order (u16)
+ *        4 code histogram (u32) 5 per-column zero counts (u32) 6 per-column unpredictable offsets (u64)
+ *        7 unpredictable values (T) 8 stream buffer */
+int szhip_debug_fetch(szhip_ctx *ctx, int which, void *dst, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,573 @@
+/* sz_api.c -- the reference's public C API (include/sz.h) on top of the MI355X HIP layer.  Host C.
+ *
+ * Mirrors, function by function (paths relative to the reference tree):
+ *   SZ_Init / SZ_Init_Params / SZ_Finalize          sz/src/sz.c:60-94, :1296-1320
+ *   computeDimension / computeDataLength / filterDimension   sz/src/sz.c:96-282
+ *   SZ_compress_args                                 sz/src/sz.c:294-391
+ *   SZ_compress_args_float / _double (dispatch)      sz/src/sz_float.c:2811-3043, sz_double.c:2531...
+ *   SZ_decompress / SZ_decompress_args_float         sz/src/sz.c:486-577, szd_float.c:50-183
+ *   sz_lossless_compress / _decompress (zstd)        sz/src/utility.c:156-214
+ * What the reference does on the CPU inside those (range scan, prediction, quantisation, Huffman)
+ * is done by szhip_* (include/szhip.h).  There is no CPU fallback: without a GPU these return NULL.
+ */
+#include <dlfcn.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "sz.h"
+#include "szhip.h"
+#include "szhost.h"
+
+int versionNumber[4] = {SZ_VER_MAJOR, SZ_VER_MINOR, SZ_VER_BUILD, SZ_VER_REVISION};
+int dataEndianType = LITTLE_ENDIAN_DATA;
+int sysEndianType = LITTLE_ENDIAN_SYSTEM;
+sz_params *confparams_cpr = NULL;
+sz_params *confparams_dec = NULL;
+sz_exedata *exe_params = NULL;
+
+int SZ_LoadConf(const char *sz_cfgFile); /* sz_conf.c */
+
+/* ---- one HIP context per process (the library is single-threaded by contract) ---- */
+static szhip_ctx *g_ctx = NULL;
+static int g_device = -1;
+static szhip_stats g_last_stats;
+
+static szhip_ctx *get_ctx(void)
+{
+    if (g_ctx) return g_ctx;
+    int dev = g_device;
+    if (dev < 0) { const char *e = getenv("SZ_HIP_DEVICE"); dev = e ? atoi(e) : 0; }
+    if (szhip_create(&g_ctx, dev) != SZHIP_OK) {
+        printf("Error: the MI355X SZ build needs a HIP device (none usable); there is no CPU fallback.\n");
+        g_ctx = NULL;
+    }
+    return g_ctx;
+}
+
+int SZ_hip_set_device(int device)
+{
+    if (g_ctx) { szhip_destroy(g_ctx); g_ctx = NULL; }
+    g_device = device;
+    return SZ_SCES;
+}
+
+int SZ_hip_last_stats(struct szhip_stats *out)
+{
+    if (!out) return SZ_NSCS;
+    *out = g_last_stats;
+    return SZ_SCES;
+}
+
+/* ---- zstd through the system library, resolved at run time (utility.c:174-214) ---- */
+typedef size_t (*zstd_compress_fn)(void *, size_t, const void *, size_t, int);
+typedef size_t (*zstd_decompress_fn)(void *, size_t, const void *, size_t);
+typedef unsigned long long (*zstd_fcs_fn)(const void *, size_t);
+typedef unsigned (*zstd_iserr_fn)(size_t);
+static struct { int tried; void *h; zstd_compress_fn compress; zstd_decompress_fn decompress; zstd_fcs_fn fcs; zstd_iserr_fn iserr; } g_zstd;
+
+static int zstd_load(void)
+{
+    if (g_zstd.tried) return g_zstd.h != NULL;
+    g_zstd.tried = 1;
+    const char *names[] = {"libzstd.so.1", "libzstd.so", NULL};
+    for (int i = 0; names[i] && !g_zstd.h; i++) g_zstd.h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+    if (!g_zstd.h) return 0;
+    g_zstd.compress = (zstd_compress_fn)dlsym(g_zstd.h, "ZSTD_compress");
+    g_zstd.decompress = (zstd_decompress_fn)dlsym(g_zstd.h, "ZSTD_decompress");
+    g_zstd.fcs = (zstd_fcs_fn)dlsym(g_zstd.h, "ZSTD_getFrameContentSize");
+    g_zstd.iserr = (zstd_iserr_fn)dlsym(g_zstd.h, "ZSTD_isError");
+    if (!g_zstd.compress || !g_zstd.decompress || !g_zstd.fcs || !g_zstd.iserr) { dlclose(g_zstd.h); g_zstd.h = NULL; return 0; }
+    return 1;
+}
+
+/* ---- init / finalize ---- */
+int SZ_Init(const char *configFilePath)
+{
+    if (confparams_cpr) { free(confparams_cpr); confparams_cpr = NULL; }
+    if (exe_params) { free(exe_params); exe_params = NULL; }
+    int r = SZ_LoadConf(configFilePath);
+    if (r == SZ_NSCS) return SZ_NSCS;
+    exe_params->SZ_SIZE_TYPE = sizeof(size_t);
+    if (confparams_cpr->szMode == SZ_TEMPORAL_COMPRESSION) {
+        printf("Error: time-step compression is outside the scope of the MI355X build.\n");
+        return SZ_NSCS;
+    }
+    return SZ_SCES;
+}
+
+int SZ_Init_Params(sz_params *params)
+{
+    SZ_Init(NULL);
+    if (params->losslessCompressor != GZIP_COMPRESSOR && params->losslessCompressor != ZSTD_COMPRESSOR)
+        params->losslessCompressor = ZSTD_COMPRESSOR;
+    if (params->max_quant_intervals > 0) params->maxRangeRadius = params->max_quant_intervals / 2;
+    memcpy(confparams_cpr, params, sizeof(sz_params));
+    if (params->quantization_intervals % 2 != 0) { printf("Error: quantization_intervals must be an even number!\n"); return SZ_NSCS; }
+    return SZ_SCES;
+}
+
+void SZ_Finalize(void)
+{
+    if (confparams_dec) { free(confparams_dec); confparams_dec = NULL; }
+    if (confparams_cpr) { free(confparams_cpr); confparams_cpr = NULL; }
+    if (exe_params) { free(exe_params); exe_params = NULL; }
+    if (g_ctx) { szhip_destroy(g_ctx); g_ctx = NULL; }
+}
+
+/* ---- dimensions ---- */
+int computeDimension(size_t r5, size_t r4, size_t r3, size_t r2, size_t r1)
+{
+    if (r1 == 0) return 0;
+    if (r2 == 0) return 1;
+    if (r3 == 0) return 2;
+    if (r4 == 0) return 3;
+    if (r5 == 0) return 4;
+    return 5;
+}
+
+size_t computeDataLength(size_t r5, size_t r4, size_t r3, size_t r2, size_t r1)
+{
+    switch (computeDimension(r5, r4, r3, r2, r1)) {
+    case 0: return 0;
+    case 1: return r1;
+    case 2: return r1 * r2;
+    case 3: return r1 * r2 * r3;
+    case 4: return r1 * r2 * r3 * r4;
+    default: return r1 * r2 * r3 * r4 * r5;
+    }
+}
+
+/* size-1 dimensions are dropped, from the slowest given dimension down (sz.c:162-282) */
+int filterDimension(size_t r5, size_t r4, size_t r3, size_t r2, size_t r1, size_t *c)
+{
+    int changed = 0;
+    int dim = computeDimension(r5, r4, r3, r2, r1);
+    c[0] = r1; c[1] = r2; c[2] = r3; c[3] = r4; c[4] = r5;
+    if (dim == 1) return r1 < 1 ? 2 : 0;
+    if (dim < 2) return 0;
+    size_t in[5] = {r1, r2, r3, r4, r5};
+    /* the slowest dimension is zeroed when 1; every other size-1 dimension shifts the tail down */
+    for (int d = dim - 1; d >= 0; d--) {
+        if (in[d] != 1) continue;
+        changed = 1;
+        if (d == dim - 1) c[d] = 0;
+        else { for (int k = d; k < 4; k++) c[k] = c[k + 1]; if (dim == 5) c[4] = 0; }
+    }
+    return changed;
+}
+
+/* ---- params bytes ---- */
+static void fill_meta(szhost_meta *m, const sz_params *p, int data_type)
+{
+    memset(m, 0, sizeof(*m));
+    m->data_type = data_type; m->err_mode = p->errorBoundMode;
+    m->abs_bound = p->absErrBound; m->rel_ratio = p->relBoundRatio; m->psnr = p->psnr;
+    m->vmin = data_type == SZ_FLOAT ? p->fmin : p->dmin; m->vmax = data_type == SZ_FLOAT ? p->fmax : p->dmax;
+    m->opt_quant_mode = exe_params->optQuantMode; m->data_endian = dataEndianType; m->sz_mode = p->szMode; m->gzip_mode = p->gzipMode;
+    m->sample_distance = p->sampleDistance; m->pred_threshold = p->predThreshold; m->sol_id = p->sol_ID;
+    m->max_quant_intervals = p->max_quant_intervals; m->quantization_intervals = p->quantization_intervals;
+    m->protect_value_range = p->protectValueRange;
+}
+
+void convertSZParamsToBytes(sz_params *params, unsigned char *result)
+{
+    unsigned char tmp[4 + MetaDataByteLength_double];
+    szhost_meta m; fill_meta(&m, params, params->dataType);
+    size_t len = szhost_write_meta(&m, 0, tmp);
+    memcpy(result, tmp + 4, len - 4);
+}
+
+void convertBytesToSZParams(unsigned char *bytes, sz_params *params)
+{
+    unsigned char flag1 = bytes[0];
+    exe_params->optQuantMode = (char)((flag1 & 0x40) >> 6);
+    dataEndianType = (flag1 & 0x20) >> 5;
+    params->szMode = (flag1 & 0x0c) >> 2;
+    switch (flag1 & 0x03) { case 0: params->gzipMode = 1; break; case 1: params->gzipMode = 0; break; case 2: params->gzipMode = 9; break; default: break; }
+    params->sampleDistance = (short)((bytes[1] << 8) | bytes[2]);
+    params->predThreshold = (float)(1.0 * (short)((bytes[3] << 8) | bytes[4]) / 10000.0);
+    params->dataType = bytes[5] & 0x07;
+    params->errorBoundMode = (bytes[5] & 0xf0) >> 4;
+    switch (params->errorBoundMode) {
+    case ABS: params->absErrBound = szhost_get_f32be(bytes + 6); break;
+    case REL: params->relBoundRatio = szhost_get_f32be(bytes + 10); break;
+    case ABS_AND_REL: case ABS_OR_REL: params->absErrBound = szhost_get_f32be(bytes + 6); params->relBoundRatio = szhost_get_f32be(bytes + 10); break;
+    case PSNR: params->psnr = szhost_get_f32be(bytes + 6); break;
+    default: break;
+    }
+    params->sol_ID = (int)bytes[14];
+    if (exe_params->optQuantMode == 1) { params->max_quant_intervals = szhost_get_u32be(bytes + 16); params->quantization_intervals = 0; }
+    else { params->max_quant_intervals = 0; params->quantization_intervals = szhost_get_u32be(bytes + 16); }
+    if (params->dataType == SZ_FLOAT) { params->fmin = szhost_get_f32be(bytes + 20); params->fmax = szhost_get_f32be(bytes + 24); }
+    else if (params->dataType == SZ_DOUBLE) { params->dmin = szhost_get_f64be(bytes + 20); params->dmax = szhost_get_f64be(bytes + 28); }
+}
+
+/* ---- compression ---- */
+static int compress_fp(int dataType, int withRegression, unsigned char **newByteData, void *oriData,
+                       size_t r5, size_t r4, size_t r3, size_t r2, size_t r1, size_t *outSize,
+                       int errBoundMode, double absErr_Bound, double relBoundRatio, double pwRelBoundRatio)
+{
+    const size_t esz = dataType == SZ_FLOAT ? 4 : 8;
+    const size_t meta_len = dataType == SZ_FLOAT ? MetaDataByteLength : MetaDataByteLength_double;
+    confparams_cpr->dataType = dataType;
+    confparams_cpr->errorBoundMode = errBoundMode;
+    if (errBoundMode == PW_REL) confparams_cpr->pw_relBoundRatio = pwRelBoundRatio;
+    *newByteData = NULL;
+    size_t dataLength = computeDataLength(r5, r4, r3, r2, r1);
+    if (dataLength <= MIN_NUM_OF_ELEMENTS) { /* SZ_skip_compress_float, sz_float.c:37 */
+        *outSize = dataLength * esz;
+        *newByteData = (unsigned char *)malloc(dataLength * esz ? dataLength * esz : 1);
+        memcpy(*newByteData, oriData, dataLength * esz);
+        return SZ_SCES;
+    }
+    if (errBoundMode >= PW_REL) { printf("Error: point-wise relative error bounds are outside the scope of the MI355X build.\n"); return SZ_BERR; }
+
+    szhip_ctx *ctx = get_ctx();
+    if (!ctx) return SZ_NSCS;
+    void *d_in = NULL;
+    if (szhip_stage_input(ctx, oriData, dataLength * esz, &d_in) != SZHIP_OK) return SZ_NSCS;
+    double vmin, vmax;
+    if (szhip_minmax(ctx, dataType == SZ_FLOAT ? SZHIP_F32 : SZHIP_F64, d_in, 1, dataLength, &vmin, &vmax) != SZHIP_OK) return SZ_NSCS;
+    double valueRangeSize;
+    if (dataType == SZ_FLOAT) { /* float arithmetic: max - min, then max = min + range (sz_float.c:2849) */
+        float fr = (float)vmax - (float)vmin; valueRangeSize = fr;
+        confparams_cpr->fmin = (float)vmin; confparams_cpr->fmax = (float)vmin + fr;
+    } else { valueRangeSize = vmax - vmin; confparams_cpr->dmin = vmin; confparams_cpr->dmax = vmin + valueRangeSize; }
+
+    int status = SZ_SCES;
+    double realPrecision = 0;
+    if (confparams_cpr->errorBoundMode == PSNR) { /* conf.c:54-60 */
+        confparams_cpr->errorBoundMode = ABS;
+        double v1 = confparams_cpr->psnr + 10 * log10(1 - 2.0 / 3.0 * (double)confparams_cpr->predThreshold);
+        realPrecision = confparams_cpr->absErrBound = valueRangeSize * pow(10, v1 / (-20));
+    } else if (confparams_cpr->errorBoundMode == NORM) { /* conf.c:62-65 */
+        confparams_cpr->errorBoundMode = ABS;
+        realPrecision = confparams_cpr->absErrBound = sqrt(3.0 / dataLength) * confparams_cpr->normErr;
+    } else { /* getRealPrecision_float/_double, dataCompression.c:288-332 */
+        if (errBoundMode == ABS) realPrecision = absErr_Bound;
+        else if (errBoundMode == REL) realPrecision = relBoundRatio * valueRangeSize;
+        else if (errBoundMode == ABS_AND_REL || errBoundMode == ABS_OR_REL) {
+            double b = relBoundRatio * valueRangeSize;
+            if (dataType == SZ_FLOAT) { /* min_f / max_f narrow both operands to float */
+                float fa = (float)absErr_Bound, fb = (float)b;
+                realPrecision = errBoundMode == ABS_AND_REL ? (fa < fb ? fa : fb) : (fa > fb ? fa : fb);
+            } else realPrecision = errBoundMode == ABS_AND_REL ? (absErr_Bound < b ? absErr_Bound : b) : (absErr_Bound > b ? absErr_Bound : b);
+        } else { printf("Error: error-bound-mode is incorrect!\n"); status = SZ_BERR; }
+        confparams_cpr->absErrBound = realPrecision;
+    }
+
+    szhost_meta m; fill_meta(&m, confparams_cpr, dataType);
+    unsigned char meta[4 + MetaDataByteLength_double];
+
+    if (valueRangeSize <= realPrecision) { /* SZ_compress_args_float_withinRange, sz_float.c:2728 */
+        unsigned char same = 0x01 | 0x40;
+        if (confparams_cpr->protectValueRange) same |= 0x04;
+        szhost_write_meta(&m, same, meta);
+        size_t tot = 4 + meta_len + 8 + esz;
+        unsigned char *o = (unsigned char *)malloc(tot);
+        memcpy(o, meta, 4 + meta_len);
+        szhost_put_u64be(o + 4 + meta_len, dataLength);
+        if (dataType == SZ_FLOAT) szhost_put_f32be(o + 4 + meta_len + 8, ((float *)oriData)[0]);
+        else szhost_put_f64be(o + 4 + meta_len + 8, ((double *)oriData)[0]);
+        *newByteData = o; *outSize = tot;
+        return status;
+    }
+
+    int dim = computeDimension(r5, r4, r3, r2, r1);
+    if (dim == 5) { printf("Error: doesn't support 5 dimensions for now.\n"); return SZ_DERR; }
+    if (!(dim == 3 || dim == 4) || withRegression == SZ_NO_REGRESSION || confparams_cpr->randomAccess) {
+        printf("Error: the MI355X build covers 3-D/4-D float/double arrays with withLinearRegression=YES; "
+               "this call (dim=%d, withRegression=%d, randomAccess=%d) is not covered yet.\n", dim, withRegression, confparams_cpr->randomAccess);
+        return SZ_NSCS;
+    }
+    unsigned char flags = 0x80 | 0x40;
+    if (confparams_cpr->protectValueRange) flags |= 0x04;
+    szhost_write_meta(&m, flags, meta);
+    szhip_params hp;
+    hp.sample_distance = confparams_cpr->sampleDistance; hp.pred_threshold = confparams_cpr->predThreshold;
+    hp.max_quant_intervals = confparams_cpr->maxRangeRadius * 2;
+    hp.quantization_intervals = exe_params->optQuantMode == 1 ? 0 : (unsigned)exe_params->intvCapacity;
+    size_t s0 = dim == 4 ? r4 * r3 : r3;
+    unsigned char *tmp = NULL; size_t tmpSize = 0;
+    int rc = szhip_compress(ctx, dataType == SZ_FLOAT ? SZHIP_F32 : SZHIP_F64, d_in, 1, s0, r2, r1, realPrecision, &hp,
+                            meta, 4 + meta_len, 0, &tmp, &tmpSize, &g_last_stats);
+    if (rc != SZHIP_OK) { printf("Error: szhip_compress failed (%d): %s\n", rc, szhip_last_error(ctx)); return SZ_NSCS; }
+    if (exe_params->optQuantMode == 1) { exe_params->intvCapacity = (int)g_last_stats.intervals; exe_params->intvRadius = exe_params->intvCapacity / 2; } /* updateQuantizationInfo */
+
+    if (tmpSize >= dataLength * esz + 3 + meta_len + exe_params->SZ_SIZE_TYPE + 1) { /* SZ_compress_args_float_StoreOriData, sz_float.c:526 */
+        size_t tot = 3 + meta_len + 8 + 1 + esz * dataLength;
+        unsigned char *o = (unsigned char *)malloc(tot);
+        memcpy(o, meta, 4 + meta_len);
+        o[3] = 80;
+        szhost_put_u64be(o + 4 + meta_len, dataLength);
+        unsigned char *q = o + 4 + meta_len + 8;
+        for (size_t i = 0; i < dataLength; i++, q += esz) {
+            if (dataType == SZ_FLOAT) szhost_put_f32be(q, ((float *)oriData)[i]); else szhost_put_f64be(q, ((double *)oriData)[i]);
+        }
+        free(tmp); tmp = o; tmpSize = tot;
+    }
+
+    if (confparams_cpr->szMode == SZ_BEST_SPEED) { *newByteData = tmp; *outSize = tmpSize; }
+    else if (confparams_cpr->szMode == SZ_BEST_COMPRESSION || confparams_cpr->szMode == SZ_DEFAULT_COMPRESSION) {
+        if (confparams_cpr->losslessCompressor == ZSTD_COMPRESSOR && zstd_load()) { /* sz_lossless_compress, utility.c:174-195 */
+            size_t est = tmpSize < 100 ? 200 : (size_t)(tmpSize * 1.2);
+            unsigned char *z = (unsigned char *)malloc(est);
+            size_t zs = g_zstd.compress(z, est, tmp, tmpSize, confparams_cpr->gzipMode);
+            if (g_zstd.iserr(zs)) { printf("Error: ZSTD_compress failed.\n"); free(z); free(tmp); return SZ_NSCS; }
+            free(tmp); *newByteData = z; *outSize = zs;
+        } else {
+            static int warned = 0;
+            if (!warned) { fprintf(stderr, "[SZ] note: lossless back-end (%s) not available in this build; returning the SZ stream without it\n",
+                                   confparams_cpr->losslessCompressor == ZSTD_COMPRESSOR ? "libzstd.so.1" : "gzip"); warned = 1; }
+            *newByteData = tmp; *outSize = tmpSize;
+        }
+    } else { printf("Error: Wrong setting of confparams_cpr->szMode in the compression.\n"); free(tmp); return SZ_MERR; }
+    return status;
+}
+
+unsigned char *SZ_compress_args(int dataType, void *data, size_t *outSize, int errBoundMode, double absErrBound,
+                                double relBoundRatio, double pwrBoundRatio, size_t r5, size_t r4, size_t r3, size_t r2, size_t r1)
+{
+    if (confparams_cpr == NULL) SZ_Init(NULL);
+    else if (exe_params == NULL) exe_params = (sz_exedata *)calloc(1, sizeof(sz_exedata));
+    if (exe_params->intvCapacity == 0) {
+        exe_params->intvCapacity = confparams_cpr->maxRangeRadius * 2;
+        exe_params->intvRadius = confparams_cpr->maxRangeRadius;
+        exe_params->optQuantMode = 1;
+    }
+    if (exe_params->SZ_SIZE_TYPE == 0) exe_params->SZ_SIZE_TYPE = sizeof(size_t);
+    size_t _r[5];
+    filterDimension(r5, r4, r3, r2, r1, _r);
+    confparams_cpr->dataType = dataType;
+    if (dataType == SZ_FLOAT || dataType == SZ_DOUBLE) {
+        unsigned char *newByteData = NULL;
+        compress_fp(dataType, confparams_cpr->withRegression, &newByteData, data, _r[4], _r[3], _r[2], _r[1], _r[0], outSize,
+                    errBoundMode, absErrBound, relBoundRatio, pwrBoundRatio);
+        return newByteData;
+    }
+    printf("Error: the MI355X build handles SZ_FLOAT and SZ_DOUBLE; integer types are outside its scope.\n");
+    return NULL;
+}
+
+int SZ_compress_args2(int dataType, void *data, unsigned char *compressed_bytes, size_t *outSize, int errBoundMode, double absErrBound,
+                      double relBoundRatio, double pwrBoundRatio, size_t r5, size_t r4, size_t r3, size_t r2, size_t r1)
+{
+    unsigned char *bytes = SZ_compress_args(dataType, data, outSize, errBoundMode, absErrBound, relBoundRatio, pwrBoundRatio, r5, r4, r3, r2, r1);
+    if (!bytes) return SZ_NSCS;
+    memcpy(compressed_bytes, bytes, *outSize);
+    free(bytes);
+    return SZ_SCES;
+}
+
+unsigned char *SZ_compress(int dataType, void *data, size_t *outSize, size_t r5, size_t r4, size_t r3, size_t r2, size_t r1)
+{
+    if (confparams_cpr == NULL) SZ_Init(NULL);
+    return SZ_compress_args(dataType, data, outSize, confparams_cpr->errorBoundMode, confparams_cpr->absErrBound,
+                            confparams_cpr->relBoundRatio, confparams_cpr->pw_relBoundRatio, r5, r4, r3, r2, r1);
+}
+
+/* ---- decompression ---- */
+static int is_zlib_format(unsigned char m1, unsigned char m2) /* callZlib.c:30-47 */
+{
+    if (m1 == 104) return m2 == 5 || m2 == 129 || m2 == 222;
+    if (m1 == 120) return m2 == 1 || m2 == 94 || m2 == 156 || m2 == 218;
+    return 0;
+}
+
+static void *decompress_fp(int dataType, unsigned char *cmpBytes, size_t cmpSize, size_t r5, size_t r4, size_t r3, size_t r2, size_t r1)
+{
+    const size_t esz = dataType == SZ_FLOAT ? 4 : 8;
+    const size_t meta_len = dataType == SZ_FLOAT ? MetaDataByteLength : MetaDataByteLength_double;
+    size_t dataLength = computeDataLength(r5, r4, r3, r2, r1);
+    unsigned char *sz = cmpBytes; size_t szlen = cmpSize; int owned = 0;
+
+    if (cmpSize != 8 + 4 + meta_len && cmpSize != 8 + 8 + meta_len) { /* szd_float.c:62-95 */
+        int lossless = -1;
+        if (zstd_load()) { if (g_zstd.fcs(cmpBytes, cmpSize) != (unsigned long long)-2) lossless = ZSTD_COMPRESSOR; } /* ZSTD_CONTENTSIZE_ERROR */
+        else if (cmpSize >= 4 && cmpBytes[0] == 0x28 && cmpBytes[1] == 0xB5 && cmpBytes[2] == 0x2F && cmpBytes[3] == 0xFD) {
+            printf("Error: zstd-wrapped stream but libzstd.so.1 is not available.\n"); return NULL;
+        }
+        if (lossless == -1 && cmpSize >= 2 && is_zlib_format(cmpBytes[0], cmpBytes[1])) {
+            printf("Error: gzip-wrapped streams are outside the scope of the MI355X build (use zstd or SZ_BEST_SPEED).\n"); return NULL;
+        }
+        confparams_dec->losslessCompressor = lossless;
+        confparams_dec->szMode = lossless != -1 ? SZ_BEST_COMPRESSION : SZ_BEST_SPEED;
+        if (lossless == ZSTD_COMPRESSOR) { /* sz_lossless_decompress, utility.c:197-214 */
+            size_t target = dataLength * esz; if (target < 1000000) target = 1000000;
+            target += 4 + meta_len + exe_params->SZ_SIZE_TYPE;
+            unsigned long long fcs = g_zstd.fcs(cmpBytes, cmpSize);
+            if (fcs != (unsigned long long)-1 && fcs > target) target = (size_t)fcs;
+            unsigned char *buf = (unsigned char *)malloc(target);
+            size_t got = g_zstd.decompress(buf, target, cmpBytes, cmpSize);
+            if (g_zstd.iserr(got)) { printf("Error: ZSTD_decompress failed.\n"); free(buf); return NULL; }
+            sz = buf; szlen = got; owned = 1;
+        }
+    }
+    if (dataLength <= MIN_NUM_OF_ELEMENTS) { /* raw copy written by SZ_skip_compress */
+        void *o = malloc(dataLength * esz ? dataLength * esz : 1);
+        memcpy(o, sz, dataLength * esz);
+        if (owned) free(sz);
+        return o;
+    }
+    if (szlen < 4 + meta_len + 8) { printf("Error: compressed stream too short.\n"); if (owned) free(sz); return NULL; }
+    /* new_TightDataPointStorageF_fromFlatBytes, TightDataPointStorageF.c:54-126 */
+    int version = sz[0] * 10000 + sz[1] * 100 + sz[2];
+    if (version < 20108 && !(sz[0] == versionNumber[0] && sz[1] == versionNumber[1] && sz[2] == versionNumber[2])) {
+        printf("Wrong version: \nCompressed-data version (%d.%d.%d)\n", sz[0], sz[1], sz[2]);
+        printf("Current sz version: (%d.%d.%d)\n", versionNumber[0], versionNumber[1], versionNumber[2]);
+        printf("Please double-check if the compressed data (or file) is correct.\n");
+        exit(0);
+    }
+    unsigned char same = sz[3];
+    exe_params->SZ_SIZE_TYPE = ((same & 0x40) >> 6) == 1 ? 8 : 4;
+    confparams_dec->protectValueRange = (same & 0x04) >> 2;
+    convertBytesToSZParams(sz + 4, confparams_dec);
+    confparams_dec->sol_ID = sz[4 + 14];
+    const size_t st = exe_params->SZ_SIZE_TYPE;
+    const unsigned char *body = sz + 4 + meta_len + st;
+    void *out = malloc(dataLength * esz);
+    int ok = 1;
+    if (same & 0x10) { /* lossless raw copy, big-endian values (szd_float.c:106-118) */
+        if (szlen < 4 + meta_len + st + dataLength * esz) ok = 0;
+        else for (size_t i = 0; i < dataLength; i++) {
+            if (dataType == SZ_FLOAT) ((float *)out)[i] = szhost_get_f32be(body + 4 * i); else ((double *)out)[i] = szhost_get_f64be(body + 8 * i);
+        }
+    } else if (same & 0x01) { /* constant */
+        for (size_t i = 0; i < dataLength; i++) {
+            if (dataType == SZ_FLOAT) ((float *)out)[i] = szhost_get_f32be(body); else ((double *)out)[i] = szhost_get_f64be(body);
+        }
+    } else {
+        int dim = computeDimension(r5, r4, r3, r2, r1);
+        if (!(same & 0x80) || !(dim == 3 || dim == 4) || st != 8 || confparams_dec->sol_ID != SZ) {
+            printf("Error: the MI355X build decodes SZ 2.1 regression-type streams of 3-D/4-D float/double arrays; this stream "
+                   "(flags 0x%02x, dim %d) is not covered yet.\n", same, dim);
+            ok = 0;
+        } else {
+            szhip_ctx *ctx = get_ctx();
+            size_t s0 = dim == 4 ? r4 * r3 : r3;
+            int rc = ctx ? szhip_decompress(ctx, dataType == SZ_FLOAT ? SZHIP_F32 : SZHIP_F64, sz, 0, szlen, 4 + meta_len + st,
+                                            s0, r2, r1, out, 0, &g_last_stats) : SZHIP_ERR_NODEVICE;
+            if (rc != SZHIP_OK) { printf("Error: szhip_decompress failed (%d): %s\n", rc, ctx ? szhip_last_error(ctx) : "no device"); ok = 0; }
+        }
+    }
+    if (ok && confparams_dec->protectValueRange) { /* szd_float.c:161-176 */
+        if (dataType == SZ_FLOAT) {
+            float *nd = (float *)out, mn = confparams_dec->fmin, mx = confparams_dec->fmax;
+            for (size_t i = 0; i < dataLength; i++) { float v = nd[i]; if (v <= mx && v >= mn) continue; if (v < mn) nd[i] = mn; else if (v > mx) nd[i] = mx; }
+        } else {
+            double *nd = (double *)out, mn = confparams_dec->dmin, mx = confparams_dec->dmax;
+            for (size_t i = 0; i < dataLength; i++) { double v = nd[i]; if (v <= mx && v >= mn) continue; if (v < mn) nd[i] = mn; else if (v > mx) nd[i] = mx; }
+        }
+    }
+    if (owned) free(sz);
+    if (!ok) { free(out); return NULL; }
+    return out;
+}
+
+void *SZ_decompress(int dataType, unsigned char *bytes, size_t byteLength, size_t r5, size_t r4, size_t r3, size_t r2, size_t r1)
+{
+    size_t _r[5];
+    filterDimension(r5, r4, r3, r2, r1, _r);
+    if (confparams_dec == NULL) confparams_dec = (sz_params *)malloc(sizeof(sz_params));
+    memset(confparams_dec, 0, sizeof(sz_params));
+    if (exe_params == NULL) exe_params = (sz_exedata *)malloc(sizeof(sz_exedata));
+    memset(exe_params, 0, sizeof(sz_exedata));
+    exe_params->SZ_SIZE_TYPE = 8;
+    sysEndianType = LITTLE_ENDIAN_SYSTEM;
+    if (dataType == SZ_FLOAT || dataType == SZ_DOUBLE) return decompress_fp(dataType, bytes, byteLength, _r[4], _r[3], _r[2], _r[1], _r[0]);
+    printf("Error: the MI355X build handles SZ_FLOAT and SZ_DOUBLE; integer types are outside its scope.\n");
+    return NULL;
+}
+
+size_t SZ_decompress_args(int dataType, unsigned char *bytes, size_t byteLength, void *decompressed_array,
+                          size_t r5, size_t r4, size_t r3, size_t r2, size_t r1)
+{
+    size_t _r[5];
+    filterDimension(r5, r4, r3, r2, r1, _r);
+    size_t nbEle = computeDataLength(_r[4], _r[3], _r[2], _r[1], _r[0]);
+    void *data = SZ_decompress(dataType, bytes, byteLength, _r[4], _r[3], _r[2], _r[1], _r[0]);
+    if (!data) return (size_t)SZ_NSCS;
+    memcpy(decompressed_array, data, nbEle * (dataType == SZ_FLOAT ? 4 : 8));
+    free(data);
+    return nbEle;
+}
+
+sz_metadata *SZ_getMetadata(unsigned char *bytes) /* sz.c:683-760 */
+{
+    if (exe_params == NULL) exe_params = (sz_exedata *)calloc(1, sizeof(sz_exedata));
+    sz_metadata *md = (sz_metadata *)calloc(1, sizeof(sz_metadata));
+    for (int i = 0; i < 3; i++) md->versionNumber[i] = bytes[i];
+    unsigned char same = bytes[3];
+    md->isConstant = same & 0x01;
+    md->isLossless = (same & 0x10) >> 4;
+    md->sizeType = ((same & 0x40) >> 6) == 1 ? 8 : 4;
+    exe_params->SZ_SIZE_TYPE = (unsigned)md->sizeType;
+    md->conf_params = (sz_params *)calloc(1, sizeof(sz_params));
+    convertBytesToSZParams(bytes + 4, md->conf_params);
+    size_t meta_len = md->conf_params->dataType == SZ_DOUBLE ? MetaDataByteLength_double : MetaDataByteLength;
+    md->dataSeriesLength = md->sizeType == 8 ? (size_t)szhost_get_u64be(bytes + 4 + meta_len) : (size_t)szhost_get_u32be(bytes + 4 + meta_len);
+    if ((same & 0x80) && !md->isConstant && !md->isLossless) { /* SZ 2.1 stream: intervals follow block size and the bound */
+        const unsigned char *q = bytes + 4 + meta_len + md->sizeType + 4 + (md->conf_params->dataType == SZ_DOUBLE ? 8 : 4);
+        md->defactoNBBins = (int)szhost_get_u32be(q);
+    }
+    return md;
+}
+
+/* ---- customised entry points (sz.c:1362-1510) ---- */
+static void maybe_init_with_user_params(sz_params *userPara, sz_params *current)
+{
+    if (userPara == NULL && current == NULL) SZ_Init(NULL);
+    else if (userPara != NULL) SZ_Init_Params(userPara);
+}
+
+unsigned char *SZ_compress_customize(const char *cmprName, void *userPara, int dataType, void *data, size_t r5, size_t r4, size_t r3,
+                                     size_t r2, size_t r1, size_t *outSize, int *status)
+{
+    unsigned char *result = NULL;
+    if (strcmp(cmprName, "SZ2.0") == 0 || strcmp(cmprName, "SZ2.1") == 0 || strcmp(cmprName, "SZ") == 0) {
+        maybe_init_with_user_params((sz_params *)userPara, confparams_cpr);
+        result = SZ_compress(dataType, data, outSize, r5, r4, r3, r2, r1);
+        *status = result ? SZ_SCES : SZ_NSCS;
+    } else {
+        printf("Error: compressor '%s' is outside the scope of the MI355X build (SZ / SZ2.0 / SZ2.1 only).\n", cmprName);
+        *status = SZ_NSCS;
+    }
+    return result;
+}
+
+unsigned char *SZ_compress_customize_threadsafe(const char *cmprName, void *userPara, int dataType, void *data, size_t r5, size_t r4,
+                                                size_t r3, size_t r2, size_t r1, size_t *outSize, int *status)
+{
+    /* the reference variant only skips SZ_Init; device state here is per process, so calls are serialised by the caller */
+    unsigned char *result = NULL;
+    if (strcmp(cmprName, "SZ2.0") == 0 || strcmp(cmprName, "SZ2.1") == 0 || strcmp(cmprName, "SZ") == 0) {
+        sz_params *para = (sz_params *)userPara;
+        if (confparams_cpr == NULL) SZ_Init(NULL);
+        size_t _r[5];
+        filterDimension(r5, r4, r3, r2, r1, _r);
+        if (dataType == SZ_FLOAT || dataType == SZ_DOUBLE)
+            compress_fp(dataType, SZ_WITH_LINEAR_REGRESSION, &result, data, _r[4], _r[3], _r[2], _r[1], _r[0], outSize,
+                        para->errorBoundMode, para->absErrBound, para->relBoundRatio, para->pw_relBoundRatio);
+        *status = result ? SZ_SCES : SZ_NSCS;
+    } else *status = SZ_NSCS;
+    return result;
+}
+
+void *SZ_decompress_customize(const char *cmprName, void *userPara, int dataType, unsigned char *bytes, size_t byteLength, size_t r5,
+                              size_t r4, size_t r3, size_t r2, size_t r1, int *status)
+{
+    (void)userPara;
+    void *result = NULL;
+    if (strcmp(cmprName, "SZ2.0") == 0 || strcmp(cmprName, "SZ2.1") == 0 || strcmp(cmprName, "SZ") == 0 || strcmp(cmprName, "SZ1.4") == 0) {
+        result = SZ_decompress(dataType, bytes, byteLength, r5, r4, r3, r2, r1);
+        *status = result ? SZ_SCES : SZ_NSCS;
+    } else *status = SZ_NSCS;
+    return result;
+}
+
+void *SZ_decompress_customize_threadsafe(const char *cmprName, void *userPara, int dataType, unsigned char *bytes, size_t byteLength,
+                                         size_t r5, size_t r4, size_t r3, size_t r2, size_t r1, int *status)
+{
+    return SZ_decompress_customize(cmprName, userPara, dataType, bytes, byteLength, r5, r4, r3, r2, r1, status);
+}

@@ -1,0 +1,797 @@
+// szhip.hip -- C-ABI HIP layer (include/szhip.h): owns device buffers, launches the kernels of
+// szhip_kernels.h in stream order and calls the short serial host pieces of szhost.c between them.
+// gfx950 only; no CPU fallback: every entry point returns an error if the HIP runtime/device is missing.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <vector>
+#include "../../include/szhip.h"
+#include "szhost.h"
+#include "szhip_kernels.h"
+
+namespace {
+
+struct DevBuf { void *p = nullptr; size_t cap = 0; };
+
+double now_ms()
+{
+    timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+} // namespace
+
+struct szhip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    char err[512] = {0};
+    unsigned epoch = 0;
+    // workspaces (grow-only)
+    DevBuf in, out, codes_nat, codes_blk, coef, blk_lor, faceI, faceJ, order, small, hist, col_zeros, col_zeros64,
+        col_off, partial, samples, unpred, stream_buf, chunk_bits, chunk_off, code_tab, len_tab, dec_tab,
+        starts, ends, counts, offs, dirty;
+    void *pinned = nullptr; size_t pinned_cap = 0;
+    int order_nI = -1, order_nJ = -1;
+};
+
+namespace {
+
+#define HIPCHK(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            snprintf(ctx->err, sizeof(ctx->err), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            fprintf(stderr, "szhip: %s\n", ctx->err);                                                  \
+            return SZHIP_ERR_NODEVICE;                                                                 \
+        }                                                                                              \
+    } while (0)
+
+#define FAIL(code, ...)                                                                                \
+    do {                                                                                               \
+        snprintf(ctx->err, sizeof(ctx->err), __VA_ARGS__);                                             \
+        fprintf(stderr, "szhip: %s\n", ctx->err);                                                      \
+        return (code);                                                                                 \
+    } while (0)
+
+int ensure(szhip_ctx *ctx, DevBuf &b, size_t bytes, bool zero_new = false)
+{
+    if (bytes == 0) bytes = 16;
+    if (b.cap >= bytes) return SZHIP_OK;
+    if (b.p) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    size_t cap = bytes + bytes / 8 + 256;
+    HIPCHK(hipMalloc(&b.p, cap));
+    b.cap = cap;
+    if (zero_new) HIPCHK(hipMemsetAsync(b.p, 0, cap, ctx->stream));
+    return SZHIP_OK;
+}
+
+int ensure_pinned(szhip_ctx *ctx, size_t bytes)
+{
+    if (ctx->pinned_cap >= bytes) return SZHIP_OK;
+    if (ctx->pinned) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipHostFree(ctx->pinned)); ctx->pinned = nullptr; ctx->pinned_cap = 0; }
+    size_t cap = bytes + bytes / 4 + 4096;
+    HIPCHK(hipHostMalloc(&ctx->pinned, cap, hipHostMallocDefault));
+    ctx->pinned_cap = cap;
+    return SZHIP_OK;
+}
+
+#define TRY(x) do { int rc_ = (x); if (rc_ != SZHIP_OK) return rc_; } while (0)
+
+// device-wide exclusive scan of u64 in[0..n) -> out; total to *total_dev (device u64)
+int scan_u64(szhip_ctx *ctx, const u64 *in, int64_t n, u64 *out, u64 *total_dev)
+{
+    const int64_t nblk = (n + SZH_SCAN_TILE - 1) / SZH_SCAN_TILE;
+    TRY(ensure(ctx, ctx->partial, (size_t)(nblk + 1) * 8));
+    u64 *partial = (u64 *)ctx->partial.p;
+    hipLaunchKernelGGL(k_scan_partials, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, in, n, partial);
+    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(256), 0, ctx->stream, partial, nblk, total_dev);
+    hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, in, n, (const u64 *)partial, out);
+    HIPCHK(hipGetLastError());
+    return SZHIP_OK;
+}
+
+// layout of the "small" device scratch (u64 slots)
+enum { SM_MINMAX = 0, SM_WITHIN = 2, SM_MEANCNT = 3, SM_TOTAL_UNPRED = 4, SM_TOTAL_BITS = 5, SM_TICKET = 6, SM_ERR = 7,
+       SM_CHANGED = 8, SM_MEANSUM = 9, SM_TOTAL_SYM = 10, SM_COUNT = 16 };
+
+int choose_segb(const szh_geom3 &G, size_t elem, size_t budget)
+{
+    const size_t rows = (size_t)G.g0.early * G.g1.early;
+    size_t per_block = rows * (size_t)G.g2.early * elem;
+    int segb = (int)(budget / (per_block ? per_block : 1));
+    if (segb < 1) segb = 1;
+    if (segb > 32) segb = 32;
+    if (segb > G.g2.num) segb = G.g2.num;
+    return segb;
+}
+size_t tile_bytes(const szh_geom3 &G, int segb, size_t elem)
+{
+    const size_t rows = (size_t)G.g0.early * G.g1.early;
+    const size_t kp = ((size_t)segb * G.g2.early) | 1;
+    return rows * kp * elem + 16;
+}
+
+int prepare_pencil(szhip_ctx *ctx, const szh_geom3 &G, int nw, int *nI_out, int *nJ_out)
+{
+    const int nI = (G.g0.count + 7) / 8, nJ = (G.g1.count + 7) / 8;
+    if (nI > 65535 || nJ > 65535) FAIL(SZHIP_ERR_UNSUP, "dimension too large for the pencil grid");
+    const size_t ng = (size_t)nI * nJ * 8 * (size_t)G.g2.count * nw * sizeof(u64);
+    TRY(ensure(ctx, ctx->faceI, ng, true));
+    TRY(ensure(ctx, ctx->faceJ, ng, true));
+    if (ctx->order_nI != nI || ctx->order_nJ != nJ) {
+        std::vector<unsigned> ord((size_t)nI * nJ);
+        szh_fill_pencil_order(nI, nJ, ord.data());
+        TRY(ensure(ctx, ctx->order, ord.size() * 4));
+        HIPCHK(hipMemcpyAsync(ctx->order.p, ord.data(), ord.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        ctx->order_nI = nI; ctx->order_nJ = nJ;
+    }
+    *nI_out = nI; *nJ_out = nJ;
+    return SZHIP_OK;
+}
+
+template <class T> double ord_dec(u64 e);
+template <> double ord_dec<float>(u64 e)
+{
+    unsigned u = (unsigned)e;
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    float f; memcpy(&f, &u, 4); return (double)f;
+}
+template <> double ord_dec<double>(u64 e)
+{
+    u64 u = (e & 0x8000000000000000ull) ? (e & 0x7fffffffffffffffull) : ~e;
+    double d; memcpy(&d, &u, 8); return d;
+}
+
+template <class T>
+int minmax_impl(szhip_ctx *ctx, const void *data, int on_dev, size_t n, double *vmin, double *vmax)
+{
+    const T *d_in = (const T *)data;
+    if (!on_dev) {
+        TRY(ensure(ctx, ctx->in, n * sizeof(T)));
+        HIPCHK(hipMemcpyAsync(ctx->in.p, data, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+        d_in = (const T *)ctx->in.p;
+    }
+    TRY(ensure(ctx, ctx->small, SM_COUNT * 8));
+    u64 *sm = (u64 *)ctx->small.p;
+    u64 init[2] = {~0ull, 0ull};
+    HIPCHK(hipMemcpyAsync(sm + SM_MINMAX, init, 16, hipMemcpyHostToDevice, ctx->stream));
+    int grid = (int)std::min<int64_t>(((int64_t)n + 255) / 256, 2048);
+    hipLaunchKernelGGL((k_minmax<T>), dim3(grid), dim3(256), 0, ctx->stream, d_in, (int64_t)n, sm + SM_MINMAX);
+    HIPCHK(hipGetLastError());
+    u64 res[2];
+    HIPCHK(hipMemcpyAsync(res, sm + SM_MINMAX, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *vmin = ord_dec<T>(res[0]); *vmax = ord_dec<T>(res[1]);
+    return SZHIP_OK;
+}
+
+template <class T>
+int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r0, size_t r1, size_t r2, double eb_in,
+                  const szhip_params *prm, const unsigned char *meta, size_t meta_len, int out_on_device,
+                  unsigned char **out, size_t *out_size, szhip_stats *stats)
+{
+    const int is_double = sizeof(T) == 8;
+    const szh_geom3 G = szh_make_geom3((int)r0, (int)r1, (int)r2);
+    const int64_t n = G.n, nb = G.nblocks;
+    const T eb = (T)eb_in;
+    const double t_begin = now_ms();
+    double host_ms = 0;
+    hipStream_t st = ctx->stream;
+    szhip_stats S; memset(&S, 0, sizeof(S));
+    S.n_elements = (uint64_t)n; S.n_blocks = (uint64_t)nb;
+
+    const T *d_in = (const T *)data;
+    if (!data_on_device) {
+        TRY(ensure(ctx, ctx->in, (size_t)n * sizeof(T)));
+        HIPCHK(hipMemcpyAsync(ctx->in.p, data, (size_t)n * sizeof(T), hipMemcpyHostToDevice, st));
+        d_in = (const T *)ctx->in.p;
+    }
+    TRY(ensure(ctx, ctx->small, SM_COUNT * 8));
+    u64 *sm = (u64 *)ctx->small.p;
+    HIPCHK(hipMemsetAsync(sm, 0, SM_COUNT * 8, st));
+    TRY(ensure(ctx, ctx->coef, (size_t)nb * 4 * sizeof(T)));
+    TRY(ensure(ctx, ctx->blk_lor, (size_t)nb));
+    T *d_coef = (T *)ctx->coef.p;
+    uint8_t *d_lor = (uint8_t *)ctx->blk_lor.p;
+    HIPCHK(hipEventRecord(ctx->ev[0], st));
+
+    // ---- regression fit of every block
+    const int ncols = G.g0.num * G.g1.num;
+    {
+        const int segb = choose_segb(G, sizeof(T), 40 * 1024);
+        const int nseg = (G.g2.num + segb - 1) / segb;
+        hipLaunchKernelGGL((k_block_stage<T, 0>), dim3(ncols, nseg), dim3(256), tile_bytes(G, segb, sizeof(T)), st,
+                           G, d_in, d_coef, d_lor, (T)0, 0, (T)0, sm + SM_MINMAX, segb);
+        HIPCHK(hipGetLastError());
+    }
+
+    // ---- interval optimiser
+    unsigned intervals = prm->quantization_intervals;
+    int use_mean = 0; T mean = 0;
+    if (intervals == 0) {
+        const unsigned max_radius = prm->max_quant_intervals / 2;
+        const int64_t md = (int64_t)(int)std::sqrt((double)n);
+        const szh_meanwalk w = szh_make_meanwalk(n, G.d0, G.g2.count, md);
+        int64_t M = 0; // number of strided samples: first m with pos >= n (positions are increasing)
+        {
+            int64_t lo = 0, hi = n / std::max<int64_t>(md - 2, 1) + 2;
+            while (szh_meanwalk_pos(w, hi) < n) hi *= 2;
+            while (lo < hi) { int64_t mid = (lo + hi) / 2; if (szh_meanwalk_pos(w, mid) >= n) hi = mid; else lo = mid + 1; }
+            M = lo;
+        }
+        TRY(ensure(ctx, ctx->samples, (size_t)M * sizeof(T)));
+        TRY(ensure_pinned(ctx, std::max<size_t>((size_t)M * sizeof(T), (size_t)(max_radius + 8192) * 4 + 64)));
+        hipLaunchKernelGGL((k_gather_mean<T>), dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, d_in, w, M, (T *)ctx->samples.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(ctx->pinned, ctx->samples.p, (size_t)M * sizeof(T), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        double h0 = now_ms();
+        const double smean = szhost_seq_mean(is_double, ctx->pinned, (size_t)M);
+        host_ms += now_ms() - h0;
+
+        TRY(ensure(ctx, ctx->hist, (size_t)(max_radius + 8192) * 4 + 64));
+        unsigned *d_rh = (unsigned *)ctx->hist.p, *d_fh = d_rh + max_radius;
+        HIPCHK(hipMemsetAsync(d_rh, 0, (size_t)(max_radius + 8192) * 4, st));
+        const int64_t nrows = szh_sample_row_limit(G, prm->sample_distance);
+        if (nrows > 0) {
+            int grid = (int)std::min<int64_t>((nrows + 255) / 256, 1024);
+            hipLaunchKernelGGL((k_sample<T>), dim3(grid), dim3(256), 0, st, G, d_in, nrows, prm->sample_distance, (double)eb,
+                               (T)smean, max_radius, d_rh, d_fh, sm + SM_WITHIN);
+            HIPCHK(hipGetLastError());
+        }
+        unsigned *h_hist = (unsigned *)ctx->pinned;
+        u64 within = 0;
+        HIPCHK(hipMemcpyAsync(h_hist, d_rh, (size_t)(max_radius + 8192) * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&within, sm + SM_WITHIN, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        h0 = now_ms();
+        u64 sample_count = 0;
+        for (unsigned i = 0; i < max_radius; ++i) sample_count += h_hist[i];
+        szhost_decision dec;
+        szhost_decide(is_double, h_hist, max_radius, h_hist + max_radius, sample_count, within, prm->pred_threshold,
+                      (double)eb, smean, &dec);
+        host_ms += now_ms() - h0;
+        intervals = dec.intervals; use_mean = dec.use_mean;
+        if (use_mean) {
+            T *d_sum = (T *)(sm + SM_MEANSUM);
+            hipLaunchKernelGGL((k_mean_seq<T>), dim3(1), dim3(64), 0, st, d_in, n, (T)dec.dense_pos, eb, d_sum, sm + SM_MEANCNT);
+            HIPCHK(hipGetLastError());
+            T hsum = 0; u64 hcnt = 0;
+            HIPCHK(hipMemcpyAsync(&hsum, d_sum, sizeof(T), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(&hcnt, sm + SM_MEANCNT, 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            if (hcnt > 0) mean = hsum / (T)hcnt; // `mean = sum / mean_count`, sz_float.c:6668
+        }
+    }
+    if (intervals > 65536 || intervals < 4) FAIL(SZHIP_ERR_UNSUP, "quantization interval count %u outside [4,65536]", intervals);
+    S.intervals = intervals; S.use_mean = use_mean;
+
+    // ---- predictor selection
+    {
+        const int segb = choose_segb(G, sizeof(T), 40 * 1024);
+        const int nseg = (G.g2.num + segb - 1) / segb;
+        const T noise = (T)((double)eb * 1.22);
+        hipLaunchKernelGGL((k_block_stage<T, 1>), dim3(ncols, nseg), dim3(256), tile_bytes(G, segb, sizeof(T)), st,
+                           G, d_in, d_coef, d_lor, noise, use_mean, mean, sm + SM_MINMAX, segb);
+        HIPCHK(hipGetLastError());
+    }
+    std::vector<unsigned char> indicator((size_t)nb);
+    HIPCHK(hipMemcpyAsync(indicator.data(), d_lor, (size_t)nb, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    size_t reg_count = 0;
+    for (int64_t b = 0; b < nb; ++b) reg_count += indicator[b] ? 0 : 1;
+    S.n_reg_blocks = reg_count;
+
+    // ---- regression coefficient chain (serial, host) and its Huffman streams
+    szhost_coeffs cf; memset(&cf, 0, sizeof(cf));
+    std::vector<unsigned char> coef_sections;
+    if (reg_count > 0) {
+        std::vector<T> hcoef((size_t)nb * 4);
+        HIPCHK(hipMemcpyAsync(hcoef.data(), d_coef, hcoef.size() * sizeof(T), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        double h0 = now_ms();
+        szhost_coeff_chain(is_double, hcoef.data(), indicator.data(), (size_t)nb, (double)eb, G.g0.late, G.g1.late, G.g2.late,
+                           use_mean, &cf);
+        for (int e = 0; e < 4; ++e) {
+            std::vector<uint32_t> h32(65536, 0);
+            for (size_t i = 0; i < reg_count; ++i) h32[(size_t)cf.codes[e][i]]++;
+            szhost_huff *ch = szhost_huff_build(131072, h32.data(), nullptr, 65536);
+            if (!ch) { szhost_coeffs_free(&cf); FAIL(SZHIP_ERR_INTERNAL, "coefficient Huffman build failed"); }
+            const size_t tb = szhost_huff_tree_size(ch);
+            const size_t enc_cap = (size_t)((ch->total_bits + 7) / 8) + 16;
+            size_t pos = coef_sections.size();
+            coef_sections.resize(pos + sizeof(T) + 12 + tb + 8 + enc_cap + 4 + cf.unpred_count[e] * sizeof(T));
+            unsigned char *q = coef_sections.data() + pos;
+            if (is_double) szhost_put_f64be(q, cf.prec[e]); else szhost_put_f32be(q, (float)cf.prec[e]);
+            q += sizeof(T);
+            szhost_put_u32be(q, 32768); q += 4;
+            szhost_put_u32be(q, (uint32_t)tb); q += 4;
+            szhost_put_u32be(q, (uint32_t)ch->n_nodes); q += 4;
+            szhost_huff_tree_write(ch, q); q += tb;
+            memset(q + 8, 0, enc_cap);
+            const size_t enc = szhost_huff_encode_i32(ch, cf.codes[e], reg_count, q + 8);
+            szhost_put_u64be(q, enc); q += 8 + enc;
+            szhost_put_u32be(q, (uint32_t)cf.unpred_count[e]); q += 4;
+            memcpy(q, cf.unpred[e], cf.unpred_count[e] * sizeof(T)); q += cf.unpred_count[e] * sizeof(T);
+            coef_sections.resize((size_t)(q - coef_sections.data()));
+            szhost_huff_free(ch);
+        }
+        host_ms += now_ms() - h0;
+        szhost_coeffs_free(&cf);
+        HIPCHK(hipMemcpyAsync(d_coef, hcoef.data(), hcoef.size() * sizeof(T), hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st)); // hcoef goes out of scope
+    }
+    HIPCHK(hipEventRecord(ctx->ev[1], st));
+
+    // ---- predict + quantise: the wavefront kernel
+    TRY(ensure(ctx, ctx->codes_nat, (size_t)n * 2 + 64));
+    TRY(ensure(ctx, ctx->codes_blk, (size_t)n * 2 + 64));
+    uint16_t *d_nat = (uint16_t *)ctx->codes_nat.p, *d_blk = (uint16_t *)ctx->codes_blk.p;
+    int nI, nJ;
+    TRY(prepare_pencil(ctx, G, szh_gran<T>::NW, &nI, &nJ));
+    {
+        szh_qargs<T> a; memset(&a, 0, sizeof(a));
+        a.G = G; a.data = d_in; a.out = nullptr; a.codes = d_nat; a.blk_lor = d_lor; a.coef = d_coef;
+        a.eb = eb; a.recip = 1 / eb; a.mean = mean; a.cap = (int)intervals; a.radius = (int)intervals / 2; a.use_mean = use_mean;
+        a.faceI = (szh_u64 *)ctx->faceI.p; a.faceJ = (szh_u64 *)ctx->faceJ.p; a.epoch = ++ctx->epoch;
+        a.nI = nI; a.nJ = nJ; a.order = (const unsigned *)ctx->order.p;
+        a.ticket = (unsigned *)(sm + SM_TICKET); a.err = (unsigned *)(sm + SM_ERR);
+        HIPCHK(hipEventRecord(ctx->ev[2], st));
+        hipLaunchKernelGGL((k_pencil<T, false>), dim3((unsigned)(nI * nJ)), dim3(64), 0, st, a);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(ctx->ev[3], st));
+        S.quant_kernel_launches = 1;
+    }
+
+    // ---- histogram, block ordering, unpredictable counts
+    TRY(ensure(ctx, ctx->hist, (size_t)(65536 + 8192) * 4 + 64));
+    unsigned *d_hist = (unsigned *)ctx->hist.p;
+    HIPCHK(hipMemsetAsync(d_hist, 0, (size_t)intervals * 4, st));
+    {
+        int rshift = 0; int use_lds = intervals <= 16384;
+        if (use_lds) { while ((intervals << (rshift + 1)) <= 16384u && rshift < 6) ++rshift; }
+        const size_t lds = use_lds ? ((size_t)intervals << rshift) * 4 : 16;
+        int grid = (int)std::min<int64_t>((n / 8 + 255) / 256 + 1, 2048);
+        hipLaunchKernelGGL(k_hist_u16, dim3(grid), dim3(256), lds, st, (const uint16_t *)d_nat, n, intervals, rshift, use_lds, d_hist);
+        HIPCHK(hipGetLastError());
+    }
+    TRY(ensure(ctx, ctx->col_zeros, (size_t)ncols * 4));
+    TRY(ensure(ctx, ctx->col_zeros64, (size_t)ncols * 8));
+    TRY(ensure(ctx, ctx->col_off, (size_t)ncols * 8));
+    HIPCHK(hipMemsetAsync(ctx->col_zeros.p, 0, (size_t)ncols * 4, st));
+    {
+        const int segb = choose_segb(G, 2, 32 * 1024);
+        const int nseg = (G.g2.num + segb - 1) / segb;
+        hipLaunchKernelGGL((k_permute<0>), dim3(ncols, nseg), dim3(256), tile_bytes(G, segb, 2), st, G, (const uint16_t *)d_nat,
+                           d_blk, (unsigned *)ctx->col_zeros.p, segb);
+        HIPCHK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_u32_to_u64, dim3((ncols + 255) / 256), dim3(256), 0, st, (const unsigned *)ctx->col_zeros.p, (int64_t)ncols,
+                       (u64 *)ctx->col_zeros64.p);
+    TRY(scan_u64(ctx, (const u64 *)ctx->col_zeros64.p, ncols, (u64 *)ctx->col_off.p, sm + SM_TOTAL_UNPRED));
+
+    TRY(ensure_pinned(ctx, (size_t)intervals * 4 + 64));
+    unsigned *h_hist = (unsigned *)ctx->pinned;
+    u64 h_small[SM_COUNT];
+    HIPCHK(hipMemcpyAsync(h_hist, d_hist, (size_t)intervals * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h_small, sm, SM_COUNT * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if ((unsigned)h_small[SM_ERR] != 0) FAIL(SZHIP_ERR_INTERNAL, "wavefront kernel: halo wait timed out");
+    const u64 total_unpred = h_small[SM_TOTAL_UNPRED];
+    S.n_unpred = total_unpred;
+
+    // ---- Huffman code book (host: heap order decides the codes) and stream header
+    double h0 = now_ms();
+    szhost_huff *hf = szhost_huff_build(2 * (int)intervals, h_hist, nullptr, intervals);
+    if (!hf) FAIL(SZHIP_ERR_INTERNAL, "Huffman build failed");
+    const size_t tree_bytes = szhost_huff_tree_size(hf);
+    const size_t ind_bytes = ((size_t)nb + 7) / 8;
+    const size_t hdr_len = meta_len + 8 + 4 + sizeof(T) + 4 + 4 + 4 + tree_bytes + 1 + sizeof(T) + ind_bytes + coef_sections.size() + 8;
+    const size_t unpred_bytes = (size_t)total_unpred * sizeof(T);
+    const size_t pay_bytes = (size_t)((hf->total_bits + 7) / 8);
+    const size_t total_len = hdr_len + unpred_bytes + pay_bytes;
+    std::vector<unsigned char> hdr(hdr_len, 0);
+    {
+        unsigned char *q = hdr.data();
+        memcpy(q, meta, meta_len); q += meta_len;
+        szhost_put_u64be(q, (uint64_t)n); q += 8;
+        szhost_put_u32be(q, SZH_BLOCK_SIZE); q += 4;
+        if (is_double) szhost_put_f64be(q, (double)eb); else szhost_put_f32be(q, (float)eb);
+        q += sizeof(T);
+        szhost_put_u32be(q, intervals); q += 4;
+        szhost_put_u32be(q, (uint32_t)tree_bytes); q += 4;
+        szhost_put_u32be(q, (uint32_t)hf->n_nodes); q += 4;
+        szhost_huff_tree_write(hf, q); q += tree_bytes;
+        *q++ = (unsigned char)use_mean;
+        memcpy(q, &mean, sizeof(T)); q += sizeof(T);
+        for (int64_t b = 0; b < nb; ++b) if (indicator[(size_t)b] == 1) q[b >> 3] |= (unsigned char)(1u << (7 - (b & 7)));
+        q += ind_bytes;
+        if (!coef_sections.empty()) { memcpy(q, coef_sections.data(), coef_sections.size()); q += coef_sections.size(); }
+        const uint64_t tu = total_unpred; memcpy(q, &tu, 8); q += 8;
+    }
+    // device code tables: right-aligned code bits + lengths, one entry per symbol < intervals
+    std::vector<u64> tab_code(intervals); std::vector<uint8_t> tab_len(intervals);
+    for (unsigned s = 0; s < intervals; ++s) { tab_code[s] = hf->code[s]; tab_len[s] = hf->len[s]; }
+    const u64 total_bits = hf->total_bits;
+    szhost_huff_free(hf);
+    host_ms += now_ms() - h0;
+
+    TRY(ensure(ctx, ctx->code_tab, (size_t)intervals * 8));
+    TRY(ensure(ctx, ctx->len_tab, (size_t)intervals));
+    HIPCHK(hipMemcpyAsync(ctx->code_tab.p, tab_code.data(), (size_t)intervals * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->len_tab.p, tab_len.data(), (size_t)intervals, hipMemcpyHostToDevice, st));
+    TRY(ensure(ctx, ctx->stream_buf, total_len + 64));
+    unsigned char *d_stream = (unsigned char *)ctx->stream_buf.p;
+    HIPCHK(hipMemsetAsync(d_stream, 0, total_len + 64, st));
+    HIPCHK(hipMemcpyAsync(d_stream, hdr.data(), hdr_len, hipMemcpyHostToDevice, st));
+    if (total_unpred > 0) {
+        TRY(ensure(ctx, ctx->unpred, unpred_bytes));
+        hipLaunchKernelGGL((k_unpred<T, 0>), dim3(ncols), dim3(256), 0, st, G, (const uint16_t *)d_blk, (const unsigned *)ctx->col_zeros.p,
+                           (const u64 *)ctx->col_off.p, d_in, (T *)ctx->unpred.p, (T *)nullptr);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(d_stream + hdr_len, ctx->unpred.p, unpred_bytes, hipMemcpyDeviceToDevice, st));
+    }
+    if (total_bits > 0) {
+        const int64_t nchunks = (n + SZH_ENC_CHUNK - 1) / SZH_ENC_CHUNK;
+        TRY(ensure(ctx, ctx->chunk_bits, (size_t)nchunks * 8));
+        TRY(ensure(ctx, ctx->chunk_off, (size_t)nchunks * 8));
+        hipLaunchKernelGGL(k_chunk_bits, dim3((unsigned)nchunks), dim3(256), 0, st, (const uint16_t *)d_blk, n, (const uint8_t *)ctx->len_tab.p,
+                           (u64 *)ctx->chunk_bits.p);
+        TRY(scan_u64(ctx, (const u64 *)ctx->chunk_bits.p, nchunks, (u64 *)ctx->chunk_off.p, sm + SM_TOTAL_BITS));
+        hipLaunchKernelGGL(k_encode, dim3((unsigned)nchunks), dim3(256), 0, st, (const uint16_t *)d_blk, n, (const u64 *)ctx->code_tab.p,
+                           (const uint8_t *)ctx->len_tab.p, (const u64 *)ctx->chunk_off.p, (u64)(hdr_len + unpred_bytes) * 8,
+                           (unsigned *)d_stream);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(ctx->ev[4], st));
+    if (out_on_device) {
+        HIPCHK(hipStreamSynchronize(st));
+        *out = d_stream;
+    } else {
+        unsigned char *h = (unsigned char *)malloc(total_len ? total_len : 1);
+        if (!h) FAIL(SZHIP_ERR_INTERNAL, "out of host memory");
+        HIPCHK(hipMemcpyAsync(h, d_stream, total_len, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        *out = h;
+    }
+    *out_size = total_len;
+    // the shuffled bit count must match what the code book predicted
+    {
+        u64 tb = 0;
+        if (total_bits > 0) { HIPCHK(hipMemcpy(&tb, sm + SM_TOTAL_BITS, 8, hipMemcpyDeviceToHost)); }
+        if (tb != total_bits) FAIL(SZHIP_ERR_INTERNAL, "encoded bit count mismatch (%llu vs %llu)", (unsigned long long)tb, (unsigned long long)total_bits);
+    }
+    float ms = 0;
+    hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); S.ms_prequant = ms;
+    hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); S.ms_quant = ms;
+    hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]); S.ms_entropy = ms;
+    S.ms_host = host_ms; S.ms_total = now_ms() - t_begin; S.out_bytes = total_len;
+    if (stats) *stats = S;
+    return SZHIP_OK;
+}
+
+template <class T>
+int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_on_device, size_t stream_len, size_t body_off,
+                    size_t r0, size_t r1, size_t r2, void *out, int out_on_device, szhip_stats *stats)
+{
+    const int is_double = sizeof(T) == 8;
+    const szh_geom3 G = szh_make_geom3((int)r0, (int)r1, (int)r2);
+    const int64_t n = G.n, nb = G.nblocks;
+    const double t_begin = now_ms();
+    double host_ms = 0;
+    hipStream_t st = ctx->stream;
+    szhip_stats S; memset(&S, 0, sizeof(S));
+    S.n_elements = (uint64_t)n; S.n_blocks = (uint64_t)nb;
+
+    // ---- stream on both sides: host copy for header parsing, device copy for the payload
+    std::vector<unsigned char> hcopy;
+    const unsigned char *hs = stream_in;
+    TRY(ensure(ctx, ctx->stream_buf, stream_len + 64));
+    unsigned char *d_stream = (unsigned char *)ctx->stream_buf.p;
+    if (stream_on_device) {
+        hcopy.resize(stream_len);
+        HIPCHK(hipMemcpyAsync(hcopy.data(), stream_in, stream_len, hipMemcpyDeviceToHost, st));
+        if (stream_in != d_stream) HIPCHK(hipMemcpyAsync(d_stream, stream_in, stream_len, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        hs = hcopy.data();
+    } else {
+        HIPCHK(hipMemcpyAsync(d_stream, stream_in, stream_len, hipMemcpyHostToDevice, st));
+    }
+    HIPCHK(hipMemsetAsync(d_stream + stream_len, 0, 64, st)); // the bit reader may look a few bytes past the end
+    HIPCHK(hipEventRecord(ctx->ev[0], st));
+
+    // ---- header (szd_float.c:3491-3587)
+    double h0 = now_ms();
+#define NEED(k) do { if ((size_t)(q - hs) + (size_t)(k) > stream_len) FAIL(SZHIP_ERR_STREAM, "truncated stream"); } while (0)
+    const unsigned char *q = hs + body_off;
+    NEED(4 + sizeof(T) + 12);
+    const unsigned block_size = szhost_get_u32be(q); q += 4;
+    if (block_size != SZH_BLOCK_SIZE) FAIL(SZHIP_ERR_UNSUP, "block size %u", block_size);
+    const T eb = is_double ? (T)szhost_get_f64be(q) : (T)szhost_get_f32be(q); q += sizeof(T);
+    const unsigned intervals = szhost_get_u32be(q); q += 4;
+    const unsigned tree_size = szhost_get_u32be(q); q += 4;
+    const int node_count = (int)szhost_get_u32be(q); q += 4;
+    if (intervals < 4 || intervals > 65536) FAIL(SZHIP_ERR_STREAM, "bad interval count %u", intervals);
+    NEED(tree_size);
+    if (node_count <= 0 || szhost_huff_serial_size(node_count) > tree_size) FAIL(SZHIP_ERR_STREAM, "bad Huffman tree size");
+    szhost_huff *hf = szhost_huff_from_bytes(2 * (int)intervals, q, node_count);
+    if (!hf) FAIL(SZHIP_ERR_STREAM, "bad Huffman tree");
+    q += tree_size;
+    NEED(1 + sizeof(T));
+    const int use_mean = *q++;
+    T mean; memcpy(&mean, q, sizeof(T)); q += sizeof(T);
+    const size_t ind_bytes = ((size_t)nb - 1) / 8 + 1;
+    NEED(ind_bytes);
+    std::vector<unsigned char> indicator((size_t)nb);
+    size_t reg_count = 0;
+    for (int64_t b = 0; b < nb; ++b) { indicator[(size_t)b] = (q[b >> 3] >> (7 - (b & 7))) & 1; reg_count += indicator[(size_t)b] ? 0 : 1; }
+    q += ind_bytes;
+    std::vector<T> hcoef;
+    if (reg_count > 0) {
+        hcoef.assign((size_t)nb * 4, (T)0);
+        std::vector<int> ccodes[4]; int *cptr[4]; int crad[4]; double cprec[4]; const unsigned char *cun[4];
+        for (int e = 0; e < 4; ++e) {
+            NEED(sizeof(T) + 12);
+            cprec[e] = is_double ? szhost_get_f64be(q) : (double)szhost_get_f32be(q); q += sizeof(T);
+            crad[e] = (int)szhost_get_u32be(q); q += 4;
+            const unsigned ts = szhost_get_u32be(q); q += 4;
+            const int cnc = (int)szhost_get_u32be(q); q += 4;
+            NEED(ts);
+            if (cnc <= 0 || crad[e] <= 0 || crad[e] > 32768 || szhost_huff_serial_size(cnc) > ts) { szhost_huff_free(hf); FAIL(SZHIP_ERR_STREAM, "bad coefficient tree size"); }
+            szhost_huff *ch = szhost_huff_from_bytes(4 * crad[e], q, cnc);
+            if (!ch) { szhost_huff_free(hf); FAIL(SZHIP_ERR_STREAM, "bad coefficient tree"); }
+            q += ts;
+            NEED(8);
+            const size_t enc = (size_t)szhost_get_u64be(q); q += 8;
+            NEED(enc);
+            ccodes[e].resize(reg_count);
+            {   // decode from a zero-padded copy so that a corrupt stream cannot run off the end
+                std::vector<unsigned char> tmp(enc + 16, 0);
+                memcpy(tmp.data(), q, enc);
+                szhost_huff_decode_i32(ch, tmp.data(), reg_count, ccodes[e].data());
+            }
+            cptr[e] = ccodes[e].data();
+            q += enc;
+            szhost_huff_free(ch);
+            NEED(4);
+            const unsigned cu = szhost_get_u32be(q); q += 4;
+            NEED((size_t)cu * sizeof(T));
+            cun[e] = q; q += (size_t)cu * sizeof(T);
+        }
+        szhost_coeff_unchain(is_double, hcoef.data(), indicator.data(), (size_t)nb, cptr, crad, cprec, cun);
+    }
+    NEED(8);
+    uint64_t total_unpred; memcpy(&total_unpred, q, 8); q += 8;
+    NEED(total_unpred * sizeof(T));
+    const size_t unpred_off = (size_t)(q - hs);
+    q += (size_t)total_unpred * sizeof(T);
+    const size_t pay_off = (size_t)(q - hs);
+    const u64 total_bits = (u64)(stream_len - pay_off) * 8;
+#undef NEED
+    S.intervals = intervals; S.use_mean = use_mean; S.n_reg_blocks = reg_count; S.n_unpred = total_unpred;
+    std::vector<uint32_t> dtab((size_t)hf->n_nodes * 2);
+    szhost_huff_decode_table(hf, dtab.data());
+    const int single_symbol = hf->t[0] ? (int)hf->C[0] : -1;
+    const int n_nodes = hf->n_nodes;
+    szhost_huff_free(hf);
+    host_ms += now_ms() - h0;
+
+    TRY(ensure(ctx, ctx->small, SM_COUNT * 8));
+    u64 *sm = (u64 *)ctx->small.p;
+    HIPCHK(hipMemsetAsync(sm, 0, SM_COUNT * 8, st));
+    TRY(ensure(ctx, ctx->codes_nat, (size_t)n * 2 + 64));
+    TRY(ensure(ctx, ctx->codes_blk, (size_t)n * 2 + 64));
+    uint16_t *d_nat = (uint16_t *)ctx->codes_nat.p, *d_blk = (uint16_t *)ctx->codes_blk.p;
+
+    // ---- Huffman decode of the type array
+    if (single_symbol >= 0) {
+        hipLaunchKernelGGL(k_fill_u16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_blk, n, (uint16_t)single_symbol);
+        HIPCHK(hipGetLastError());
+    } else {
+        const int64_t nsub = (int64_t)((total_bits + SZH_SUBSEQ_BITS - 1) / SZH_SUBSEQ_BITS);
+        if (nsub == 0) FAIL(SZHIP_ERR_STREAM, "empty Huffman payload");
+        TRY(ensure(ctx, ctx->dec_tab, dtab.size() * 4));
+        HIPCHK(hipMemcpyAsync(ctx->dec_tab.p, dtab.data(), dtab.size() * 4, hipMemcpyHostToDevice, st));
+        TRY(ensure(ctx, ctx->starts, (size_t)nsub * 8)); TRY(ensure(ctx, ctx->ends, (size_t)nsub * 8));
+        TRY(ensure(ctx, ctx->counts, (size_t)nsub * 8)); TRY(ensure(ctx, ctx->offs, (size_t)nsub * 8));
+        TRY(ensure(ctx, ctx->dirty, (size_t)nsub));
+        szh_hdec_args a;
+        a.bits = d_stream + pay_off; a.total_bits = total_bits; a.table = (const unsigned *)ctx->dec_tab.p; a.n_nodes = n_nodes;
+        a.table_in_lds = (size_t)n_nodes * 8 <= 48 * 1024; a.nsub = nsub;
+        a.starts = (u64 *)ctx->starts.p; a.ends = (u64 *)ctx->ends.p; a.counts = (u64 *)ctx->counts.p;
+        a.dirty = (unsigned char *)ctx->dirty.p; a.changed = (unsigned *)(sm + SM_CHANGED);
+        const size_t lds = a.table_in_lds ? (size_t)n_nodes * 8 : 16;
+        const unsigned gsub = (unsigned)((nsub + 255) / 256);
+        hipLaunchKernelGGL(k_hdec_init, dim3(gsub), dim3(256), 0, st, a);
+        int64_t iter = 0;
+        for (;;) {
+            hipLaunchKernelGGL(k_hdec_pass, dim3(gsub), dim3(256), lds, st, a);
+            HIPCHK(hipMemsetAsync(sm + SM_CHANGED, 0, 8, st));
+            hipLaunchKernelGGL(k_hdec_update, dim3(gsub), dim3(256), 0, st, a);
+            HIPCHK(hipGetLastError());
+            unsigned changed = 0;
+            HIPCHK(hipMemcpyAsync(&changed, sm + SM_CHANGED, 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            if (!changed) break;
+            if (++iter > nsub + 2) FAIL(SZHIP_ERR_INTERNAL, "Huffman decode did not converge");
+        }
+        TRY(scan_u64(ctx, (const u64 *)ctx->counts.p, nsub, (u64 *)ctx->offs.p, sm + SM_TOTAL_SYM));
+        u64 total_sym = 0;
+        HIPCHK(hipMemcpyAsync(&total_sym, sm + SM_TOTAL_SYM, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if ((int64_t)total_sym < n) FAIL(SZHIP_ERR_STREAM, "Huffman payload holds %llu symbols, need %lld", (unsigned long long)total_sym, (long long)n);
+        hipLaunchKernelGGL(k_hdec_write, dim3(gsub), dim3(256), lds, st, a, (const u64 *)ctx->offs.p, d_blk, n);
+        HIPCHK(hipGetLastError());
+    }
+
+    // ---- natural order, unpredictable values into the output array
+    const int ncols = G.g0.num * G.g1.num;
+    TRY(ensure(ctx, ctx->col_zeros, (size_t)ncols * 4));
+    TRY(ensure(ctx, ctx->col_zeros64, (size_t)ncols * 8));
+    TRY(ensure(ctx, ctx->col_off, (size_t)ncols * 8));
+    HIPCHK(hipMemsetAsync(ctx->col_zeros.p, 0, (size_t)ncols * 4, st));
+    {
+        const int segb = choose_segb(G, 2, 32 * 1024);
+        const int nseg = (G.g2.num + segb - 1) / segb;
+        hipLaunchKernelGGL((k_permute<1>), dim3(ncols, nseg), dim3(256), tile_bytes(G, segb, 2), st, G, (const uint16_t *)d_blk, d_nat,
+                           (unsigned *)ctx->col_zeros.p, segb);
+        HIPCHK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_u32_to_u64, dim3((ncols + 255) / 256), dim3(256), 0, st, (const unsigned *)ctx->col_zeros.p, (int64_t)ncols,
+                       (u64 *)ctx->col_zeros64.p);
+    TRY(scan_u64(ctx, (const u64 *)ctx->col_zeros64.p, ncols, (u64 *)ctx->col_off.p, sm + SM_TOTAL_UNPRED));
+    u64 zeros_found = 0;
+    HIPCHK(hipMemcpyAsync(&zeros_found, sm + SM_TOTAL_UNPRED, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (zeros_found != total_unpred) FAIL(SZHIP_ERR_STREAM, "stream lists %llu unpredictable values, codes need %llu",
+                                          (unsigned long long)total_unpred, (unsigned long long)zeros_found);
+    T *d_out = (T *)out;
+    if (!out_on_device) { TRY(ensure(ctx, ctx->out, (size_t)n * sizeof(T))); d_out = (T *)ctx->out.p; }
+    if (total_unpred > 0) {
+        TRY(ensure(ctx, ctx->unpred, (size_t)total_unpred * sizeof(T)));
+        HIPCHK(hipMemcpyAsync(ctx->unpred.p, d_stream + unpred_off, (size_t)total_unpred * sizeof(T), hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL((k_unpred<T, 1>), dim3(ncols), dim3(256), 0, st, G, (const uint16_t *)d_blk, (const unsigned *)ctx->col_zeros.p,
+                           (const u64 *)ctx->col_off.p, (const T *)nullptr, (T *)ctx->unpred.p, d_out);
+        HIPCHK(hipGetLastError());
+    }
+    TRY(ensure(ctx, ctx->coef, (size_t)nb * 4 * sizeof(T)));
+    TRY(ensure(ctx, ctx->blk_lor, (size_t)nb));
+    if (reg_count > 0) HIPCHK(hipMemcpyAsync(ctx->coef.p, hcoef.data(), hcoef.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->blk_lor.p, indicator.data(), (size_t)nb, hipMemcpyHostToDevice, st));
+    HIPCHK(hipEventRecord(ctx->ev[1], st));
+
+    // ---- reconstruct: the wavefront kernel
+    int nI, nJ;
+    TRY(prepare_pencil(ctx, G, szh_gran<T>::NW, &nI, &nJ));
+    {
+        szh_qargs<T> a; memset(&a, 0, sizeof(a));
+        a.G = G; a.data = nullptr; a.out = d_out; a.codes = d_nat; a.blk_lor = (const uint8_t *)ctx->blk_lor.p; a.coef = (const T *)ctx->coef.p;
+        a.eb = eb; a.recip = 1 / eb; a.mean = mean; a.cap = (int)intervals; a.radius = (int)intervals / 2; a.use_mean = use_mean;
+        a.faceI = (szh_u64 *)ctx->faceI.p; a.faceJ = (szh_u64 *)ctx->faceJ.p; a.epoch = ++ctx->epoch;
+        a.nI = nI; a.nJ = nJ; a.order = (const unsigned *)ctx->order.p;
+        a.ticket = (unsigned *)(sm + SM_TICKET); a.err = (unsigned *)(sm + SM_ERR);
+        HIPCHK(hipEventRecord(ctx->ev[2], st));
+        hipLaunchKernelGGL((k_pencil<T, true>), dim3((unsigned)(nI * nJ)), dim3(64), 0, st, a);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(ctx->ev[3], st));
+        S.quant_kernel_launches = 1;
+    }
+    unsigned kerr = 0;
+    HIPCHK(hipMemcpyAsync(&kerr, sm + SM_ERR, 4, hipMemcpyDeviceToHost, st));
+    if (!out_on_device) HIPCHK(hipMemcpyAsync(out, d_out, (size_t)n * sizeof(T), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(ctx->ev[4], st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (kerr) FAIL(SZHIP_ERR_INTERNAL, "wavefront kernel: halo wait timed out");
+    float ms = 0;
+    hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); S.ms_entropy = ms;
+    hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); S.ms_quant = ms;
+    S.ms_host = host_ms; S.ms_total = now_ms() - t_begin; S.out_bytes = (uint64_t)n * sizeof(T);
+    if (stats) *stats = S;
+    return SZHIP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int szhip_create(szhip_ctx **out, int device)
+{
+    if (!out) return SZHIP_ERR_ARG;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        fprintf(stderr, "szhip: no HIP device available (%s); this library has no CPU fallback\n", hipGetErrorString(e));
+        return SZHIP_ERR_NODEVICE;
+    }
+    if (device < 0 || device >= count) return SZHIP_ERR_ARG;
+    szhip_ctx *ctx = new szhip_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx; return SZHIP_ERR_NODEVICE;
+    }
+    for (int i = 0; i < 6; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return SZHIP_ERR_NODEVICE; }
+    *out = ctx;
+    return SZHIP_OK;
+}
+
+void szhip_destroy(szhip_ctx *ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    DevBuf *bufs[] = {&ctx->in, &ctx->out, &ctx->codes_nat, &ctx->codes_blk, &ctx->coef, &ctx->blk_lor, &ctx->faceI, &ctx->faceJ,
+                      &ctx->order, &ctx->small, &ctx->hist, &ctx->col_zeros, &ctx->col_zeros64, &ctx->col_off, &ctx->partial,
+                      &ctx->samples, &ctx->unpred, &ctx->stream_buf, &ctx->chunk_bits, &ctx->chunk_off, &ctx->code_tab,
+                      &ctx->len_tab, &ctx->dec_tab, &ctx->starts, &ctx->ends, &ctx->counts, &ctx->offs, &ctx->dirty};
+    for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
+    if (ctx->pinned) hipHostFree(ctx->pinned);
+    for (int i = 0; i < 6; ++i) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *szhip_last_error(szhip_ctx *ctx) { return ctx ? ctx->err : "no context"; }
+
+int szhip_stage_input(szhip_ctx *ctx, const void *host_data, size_t bytes, void **device_ptr)
+{
+    if (!ctx || !host_data || !device_ptr) return SZHIP_ERR_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
+    TRY(ensure(ctx, ctx->in, bytes));
+    HIPCHK(hipMemcpyAsync(ctx->in.p, host_data, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *device_ptr = ctx->in.p;
+    return SZHIP_OK;
+}
+
+int szhip_minmax(szhip_ctx *ctx, int dtype, const void *data, int on_dev, size_t n, double *vmin, double *vmax)
+{
+    if (!ctx || !data || !n || !vmin || !vmax) return SZHIP_ERR_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
+    return dtype == SZHIP_F32 ? minmax_impl<float>(ctx, data, on_dev, n, vmin, vmax)
+                              : minmax_impl<double>(ctx, data, on_dev, n, vmin, vmax);
+}
+
+int szhip_compress(szhip_ctx *ctx, int dtype, const void *data, int data_on_device, size_t r0, size_t r1, size_t r2, double eb,
+                   const szhip_params *params, const unsigned char *meta, size_t meta_len, int out_on_device,
+                   unsigned char **out, size_t *out_size, szhip_stats *stats)
+{
+    if (!ctx || !data || !params || !meta || !out || !out_size) return SZHIP_ERR_ARG;
+    if (r0 < 2 || r1 < 2 || r2 < 2 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff) return SZHIP_ERR_ARG;
+    if (!(eb > 0)) return SZHIP_ERR_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
+    return dtype == SZHIP_F32
+               ? compress_impl<float>(ctx, data, data_on_device, r0, r1, r2, eb, params, meta, meta_len, out_on_device, out, out_size, stats)
+               : compress_impl<double>(ctx, data, data_on_device, r0, r1, r2, eb, params, meta, meta_len, out_on_device, out, out_size, stats);
+}
+
+int szhip_decompress(szhip_ctx *ctx, int dtype, const unsigned char *stream, int stream_on_device, size_t stream_len, size_t body_off,
+                     size_t r0, size_t r1, size_t r2, void *out, int out_on_device, szhip_stats *stats)
+{
+    if (!ctx || !stream || !out || body_off >= stream_len) return SZHIP_ERR_ARG;
+    if (r0 < 2 || r1 < 2 || r2 < 2 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff) return SZHIP_ERR_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
+    return dtype == SZHIP_F32
+               ? decompress_impl<float>(ctx, stream, stream_on_device, stream_len, body_off, r0, r1, r2, out, out_on_device, stats)
+               : decompress_impl<double>(ctx, stream, stream_on_device, stream_len, body_off, r0, r1, r2, out, out_on_device, stats);
+}
+
+int szhip_debug_fetch(szhip_ctx *ctx, int which, void *dst, size_t bytes)
+{
+    if (!ctx || !dst) return SZHIP_ERR_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
+    DevBuf *bufs[] = {&ctx->coef, &ctx->blk_lor, &ctx->codes_nat, &ctx->codes_blk, &ctx->hist, &ctx->col_zeros, &ctx->col_off,
+                      &ctx->unpred, &ctx->stream_buf};
+    if (which < 0 || which >= (int)(sizeof(bufs) / sizeof(bufs[0]))) return SZHIP_ERR_ARG;
+    if (!bufs[which]->p || bufs[which]->cap < bytes) return SZHIP_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(dst, bufs[which]->p, bytes, hipMemcpyDeviceToHost));
+    return SZHIP_OK;
+}
+
+} // extern "C"

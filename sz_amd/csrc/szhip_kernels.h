@@ -1,0 +1,586 @@
+// szhip_kernels.h -- hand-written HIP kernels (gfx950 / MI355X) of the SZ 2.1 3-D hot path.
+// Included only by szhip.hip.  Wave size is 64 throughout.
+//
+// Kernel                 reference loop it replaces (paths relative to the reference tree)
+//   k_block_stage<0>     regression fit of every block          sz/src/sz_float.c:6586-6637
+//                        + min/max scan                         sz/src/dataCompression.c:102-119
+//   k_block_stage<1>     predictor selection                    sz/src/sz_float.c:7083-7123 / :6747-6786
+//   k_gather_mean        strided mean samples                   sz/src/sz_float.c:6405-6419
+//   k_sample             interval-optimiser lattice sampling    sz/src/sz_float.c:6442-6485
+//   k_mean_seq           mean of values near dense_pos          sz/src/sz_float.c:6657-6669
+//   k_pencil             predict + quantise / reconstruct       sz/src/sz_float.c:6719-7374, szd_float.c:3590-5866
+//   k_hist_u16           Huffman histogram                      sz/src/Huffman.c:165-174
+//   k_permute            type array block ordering              sz/src/sz_float.c:7064,7359
+//   k_unpred             unpredictable-value list               sz/src/sz_float.c:7280,7286 / szd_float.c
+//   k_chunk_bits/k_encode  Huffman bit packing                  sz/src/Huffman.c:205-308
+//   k_hdec_*             Huffman decoding                       sz/src/Huffman.c:310-343
+#pragma once
+#include <hip/hip_runtime.h>
+#include "szh_core.h"
+#include "szh_pencil.h"
+
+typedef unsigned long long u64;
+
+// dynamic LDS window (the test-only CPU shim provides it through a function instead of a symbol)
+#ifdef SZH_HIPSIM
+#define SZH_DYN_SMEM(name) char *name = hipsim_dyn_smem()
+#else
+#define SZH_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#endif
+
+// ------------------------------------------------------------------ small device helpers
+__device__ __forceinline__ u64 ord_enc(float v)
+{
+    unsigned u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return (u64)u;
+}
+__device__ __forceinline__ u64 ord_enc(double v)
+{
+    u64 u = (u64)__double_as_longlong(v);
+    u = (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+    return u;
+}
+
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ u64 wave_sum_u64(u64 v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ u64 wave_min_u64(u64 v)
+{
+    for (int o = 32; o > 0; o >>= 1) { u64 t = __shfl_xor(v, o, 64); v = t < v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ u64 wave_max_u64(u64 v)
+{
+    for (int o = 32; o > 0; o >>= 1) { u64 t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+    return v;
+}
+
+// exclusive prefix sum over a 256-thread block; *total receives the block sum.  `sh` needs 8 u64.
+__device__ __forceinline__ u64 block_excl_scan_256(u64 v, u64 *sh, u64 *total)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    u64 inc = v;
+    for (int o = 1; o < 64; o <<= 1) { u64 t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) sh[wid] = inc;
+    __syncthreads();
+    u64 base = 0, tot = 0;
+    for (int w = 0; w < 4; ++w) { u64 s = sh[w]; if (w < wid) base += s; tot += s; }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+// ------------------------------------------------------------------ the wavefront kernel
+struct GpuBackend {
+    static constexpr int NL = 1;
+    __device__ static int lane(int) { return (int)(threadIdx.x & 63); }
+    template <class T> __device__ static void shfl_up(T (&dst)[1], const T (&src)[1], int d) { dst[0] = __shfl_up(src[0], d, 64); }
+    template <class T> __device__ static T readlane(const T (&src)[1], int lane) { return __shfl(src[0], lane, 64); }
+    __device__ static bool all(const bool (&p)[1]) { return __all(p[0] ? 1 : 0) != 0; }
+    __device__ static szh_u64 ld_gran(const szh_u64 *p)
+    {
+        return __hip_atomic_load(const_cast<szh_u64 *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __device__ static void st_gran(szh_u64 *p, szh_u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ static void backoff() { __builtin_amdgcn_s_sleep(1); }
+};
+
+template <class T, bool DEC>
+__global__ __launch_bounds__(64) void k_pencil(szh_qargs<T> a)
+{
+    unsigned tk = 0;
+    if (threadIdx.x == 0) tk = atomicAdd(a.ticket, 1u);
+    tk = __shfl(tk, 0, 64);
+    const unsigned ij = a.order[tk];
+    szh_pencil_run<T, DEC, GpuBackend>(a, (int)(ij >> 16), (int)(ij & 0xffffu));
+}
+
+// ------------------------------------------------------------------ per-block stages (fit / select)
+template <class T> struct TileAcc {
+    const T *t; int kp, s1, koff;
+    __device__ T operator()(int i, int j, int k) const { return t[(i * s1 + j) * kp + koff + k]; }
+};
+
+// grid: (columns = nb0*nb1, segments along dim2); block 256; dynamic LDS = rows_max * kp_max * sizeof(T)
+template <class T, int MODE>
+__global__ __launch_bounds__(256) void k_block_stage(szh_geom3 G, const T *__restrict__ data, T *coef, uint8_t *blk_lor,
+                                                     T noise, int use_mean, T mean, u64 *minmax, int segb)
+{
+    SZH_DYN_SMEM(smem);
+    T *tile = reinterpret_cast<T *>(smem);
+    __shared__ u64 red[8];
+    const int col = blockIdx.x, b0 = col / G.g1.num, b1 = col - b0 * G.g1.num;
+    const int bkbeg = blockIdx.y * segb, bkend = min(bkbeg + segb, G.g2.num);
+    const int s0 = szh_blk_size(G.g0, b0), s1 = szh_blk_size(G.g1, b1);
+    const int o0 = szh_blk_start(G.g0, b0), o1 = szh_blk_start(G.g1, b1);
+    const int kbeg = szh_blk_start(G.g2, bkbeg);
+    const int kend = bkend < G.g2.num ? szh_blk_start(G.g2, bkend) : G.g2.count;
+    const int klen = kend - kbeg, kp = klen | 1, rows = s0 * s1;
+    u64 lmin = ~0ull, lmax = 0ull;
+    for (int idx = threadIdx.x; idx < rows * klen; idx += 256) {
+        const int row = idx / klen, kx = idx - row * klen;
+        const int i = row / s1, j = row - i * s1;
+        const T v = data[(int64_t)(o0 + i) * G.d0 + (int64_t)(o1 + j) * G.d1 + kbeg + kx];
+        tile[row * kp + kx] = v;
+        if (MODE == 0) { const u64 e = ord_enc(v); lmin = e < lmin ? e : lmin; lmax = e > lmax ? e : lmax; }
+    }
+    __syncthreads();
+    const int nblk = bkend - bkbeg;
+    if ((int)threadIdx.x < nblk) {
+        const int b2 = bkbeg + threadIdx.x;
+        const int s2 = szh_blk_size(G.g2, b2);
+        TileAcc<T> A{tile, kp, s1, szh_blk_start(G.g2, b2) - kbeg};
+        const int64_t b = ((int64_t)b0 * G.g1.num + b1) * G.g2.num + b2;
+        T c4[4];
+        if (MODE == 0) {
+            szh_fit_block<T>(A, s0, s1, s2, c4);
+            for (int e = 0; e < 4; ++e) coef[(int64_t)e * G.nblocks + b] = c4[e];
+        } else {
+            for (int e = 0; e < 4; ++e) c4[e] = coef[(int64_t)e * G.nblocks + b];
+            blk_lor[b] = szh_select_block<T>(A, s0, s1, s2, c4, noise, use_mean, mean) ? 0 : 1;
+        }
+    }
+    if (MODE == 0) {
+        lmin = wave_min_u64(lmin); lmax = wave_max_u64(lmax);
+        if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = lmin; red[4 + (threadIdx.x >> 6)] = lmax; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            u64 mn = red[0], mx = red[4];
+            for (int w = 1; w < 4; ++w) { mn = red[w] < mn ? red[w] : mn; mx = red[4 + w] > mx ? red[4 + w] : mx; }
+            atomicMin(&minmax[0], mn); atomicMax(&minmax[1], mx);
+        }
+    }
+}
+
+// plain min/max over a flat array (API-level range scan)
+template <class T>
+__global__ __launch_bounds__(256) void k_minmax(const T *__restrict__ data, int64_t n, u64 *minmax)
+{
+    __shared__ u64 red[8];
+    u64 lmin = ~0ull, lmax = 0ull;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const u64 e = ord_enc(data[i]); lmin = e < lmin ? e : lmin; lmax = e > lmax ? e : lmax;
+    }
+    lmin = wave_min_u64(lmin); lmax = wave_max_u64(lmax);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = lmin; red[4 + (threadIdx.x >> 6)] = lmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 mn = red[0], mx = red[4];
+        for (int w = 1; w < 4; ++w) { mn = red[w] < mn ? red[w] : mn; mx = red[4 + w] > mx ? red[4 + w] : mx; }
+        atomicMin(&minmax[0], mn); atomicMax(&minmax[1], mx);
+    }
+}
+
+// ------------------------------------------------------------------ interval optimiser sampling
+template <class T>
+__global__ __launch_bounds__(256) void k_gather_mean(const T *__restrict__ data, szh_meanwalk w, int64_t count, T *out)
+{
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m < count) out[m] = data[szh_meanwalk_pos(w, m)];
+}
+
+#define SZH_LDS_RADIUS_BINS 4096
+template <class T>
+__global__ __launch_bounds__(256) void k_sample(szh_geom3 G, const T *__restrict__ data, int64_t nrows, int sd, double ebD, T mean,
+                                                unsigned max_radius, unsigned *radius_hist, unsigned *freq_hist, u64 *within)
+{
+    __shared__ unsigned sh_r[SZH_LDS_RADIUS_BINS];
+    __shared__ unsigned sh_f[8192];
+    for (int i = threadIdx.x; i < SZH_LDS_RADIUS_BINS; i += 256) sh_r[i] = 0;
+    for (int i = threadIdx.x; i < 8192; i += 256) sh_f[i] = 0;
+    __syncthreads();
+    const int64_t rpp = G.g1.count - 1, r2 = G.g2.count;
+    unsigned w = 0;
+    for (int64_t ridx = (int64_t)blockIdx.x * 256 + threadIdx.x; ridx < nrows; ridx += (int64_t)gridDim.x * 256) {
+        const int64_t n1 = ridx / rpp + 1, n2 = ridx - (n1 - 1) * rpp + 1;
+        const int64_t c0 = sd - ((n1 + n2) % sd);
+        const int64_t origin = n1 * G.d0 + n2 * r2;
+        for (int64_t m = 0;; ++m) {
+            const int64_t col = c0 + m * sd;
+            if (m > 0 && col >= r2) break;
+            const int64_t pos = origin + col;
+            if (pos >= G.n) break;
+            unsigned ri; int fi, we;
+            szh_sample_point<T>(data, pos, r2, G.d0, ebD, mean, max_radius, &ri, &fi, &we);
+            if (ri < SZH_LDS_RADIUS_BINS) atomicAdd(&sh_r[ri], 1u); else atomicAdd(&radius_hist[ri], 1u);
+            atomicAdd(&sh_f[fi], 1u);
+            w += (unsigned)we;
+        }
+    }
+    w = wave_sum_u32(w);
+    if ((threadIdx.x & 63) == 0 && w) atomicAdd(within, (u64)w);
+    __syncthreads();
+    for (int i = threadIdx.x; i < SZH_LDS_RADIUS_BINS; i += 256) if (sh_r[i]) atomicAdd(&radius_hist[i], sh_r[i]);
+    for (int i = threadIdx.x; i < 8192; i += 256) if (sh_f[i]) atomicAdd(&freq_hist[i], sh_f[i]);
+}
+
+// sequential (order-preserving) sum of the values within eb of dense_pos: ONE wavefront, every lane
+// carries the same running sum; the additions happen in array order so the float rounding sequence
+// is the reference's.  Only launched when use_mean is decided.
+template <class T>
+__global__ __launch_bounds__(64) void k_mean_seq(const T *__restrict__ data, int64_t n, T dense, T eb, T *out_sum, u64 *out_cnt)
+{
+    const int lane = threadIdx.x;
+    T sum = 0; u64 cnt = 0;
+    for (int64_t base = 0; base < n; base += 256) {
+        T x[4]; bool q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = base + u * 64 + lane;
+            x[u] = i < n ? data[i] : (T)0;
+            q[u] = (i < n) && (szh_abs(x[u] - dense) < eb);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            u64 mask = __ballot(q[u] ? 1 : 0);
+            cnt += (u64)__popcll(mask);
+            while (mask) {
+                const int l = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                sum += __shfl(x[u], l, 64);
+            }
+        }
+    }
+    if (lane == 0) { *out_sum = sum; *out_cnt = cnt; }
+}
+
+// ------------------------------------------------------------------ code histogram (order independent)
+// LDS-privatised with R replicas per bin to spread same-symbol atomics over banks.
+__global__ __launch_bounds__(256) void k_hist_u16(const uint16_t *__restrict__ codes, int64_t n, unsigned nbins, int rshift,
+                                                  int use_lds, unsigned *hist)
+{
+    SZH_DYN_SMEM(smem);
+    unsigned *sh = reinterpret_cast<unsigned *>(smem);
+    const unsigned R = 1u << rshift;
+    if (use_lds) {
+        for (unsigned i = threadIdx.x; i < nbins * R; i += 256) sh[i] = 0;
+        __syncthreads();
+    }
+    const unsigned rep = threadIdx.x & (R - 1);
+    const int64_t nvec = n / 8;
+    const uint4 *v4 = reinterpret_cast<const uint4 *>(codes);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const uint4 v = v4[i];
+        const unsigned wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned c0 = wv[q] & 0xffffu, c1 = wv[q] >> 16;
+            if (use_lds) { atomicAdd(&sh[(c0 << rshift) + rep], 1u); atomicAdd(&sh[(c1 << rshift) + rep], 1u); }
+            else { atomicAdd(&hist[c0], 1u); atomicAdd(&hist[c1], 1u); }
+        }
+    }
+    if (blockIdx.x == 0) {
+        for (int64_t i = nvec * 8 + threadIdx.x; i < n; i += 256) {
+            const unsigned c = codes[i];
+            if (use_lds) atomicAdd(&sh[(c << rshift) + rep], 1u); else atomicAdd(&hist[c], 1u);
+        }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (unsigned b = threadIdx.x; b < nbins; b += 256) {
+            unsigned s = 0;
+            for (unsigned r = 0; r < R; ++r) s += sh[(b << rshift) + r];
+            if (s) atomicAdd(&hist[b], s);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ natural <-> block order of the code array
+// One workgroup per (block column (b0,b1), segment of `segb` blocks along dim2).  The segment is a
+// contiguous range in block order and s0*s1 contiguous row pieces in natural order, so both sides stream.
+// DIR 0: natural -> block order (compress); DIR 1: block order -> natural (decompress).
+// col_zeros[col] += number of zero codes (unpredictable points) seen.
+template <int DIR>
+__global__ __launch_bounds__(256) void k_permute(szh_geom3 G, const uint16_t *__restrict__ src, uint16_t *__restrict__ dst,
+                                                 unsigned *col_zeros, int segb)
+{
+    SZH_DYN_SMEM(smem);
+    uint16_t *tile = reinterpret_cast<uint16_t *>(smem);
+    const int col = blockIdx.x, b0 = col / G.g1.num, b1 = col - b0 * G.g1.num;
+    const int bkbeg = blockIdx.y * segb, bkend = min(bkbeg + segb, G.g2.num);
+    const int s0 = szh_blk_size(G.g0, b0), s1 = szh_blk_size(G.g1, b1);
+    const int o0 = szh_blk_start(G.g0, b0), o1 = szh_blk_start(G.g1, b1);
+    const int kbeg = szh_blk_start(G.g2, bkbeg);
+    const int kend = bkend < G.g2.num ? szh_blk_start(G.g2, bkend) : G.g2.count;
+    const int klen = kend - kbeg, kp = klen | 1, rows = s0 * s1;
+    const int total = rows * klen;
+    const int64_t base = szh_code_base(G, b0, b1, bkbeg);
+    // early-width blocks of this segment come first
+    int nE = G.g2.split - bkbeg; if (nE < 0) nE = 0; if (nE > bkend - bkbeg) nE = bkend - bkbeg;
+    const int esz = rows * G.g2.early, lsz = rows * G.g2.late, eregion = nE * esz;
+    unsigned zeros = 0;
+    if (DIR == 0) {
+        for (int idx = threadIdx.x; idx < total; idx += 256) {
+            const int row = idx / klen, kx = idx - row * klen;
+            const int i = row / s1, j = row - i * s1;
+            tile[row * kp + kx] = src[(int64_t)(o0 + i) * G.d0 + (int64_t)(o1 + j) * G.d1 + kbeg + kx];
+        }
+        __syncthreads();
+    }
+    for (int e = threadIdx.x; e < total; e += 256) {
+        int rem, s2, koff;
+        if (e < eregion) { const int bl = e / esz; rem = e - bl * esz; s2 = G.g2.early; koff = bl * G.g2.early; }
+        else { const int e2 = e - eregion; const int bl = e2 / lsz; rem = e2 - bl * lsz; s2 = G.g2.late; koff = nE * G.g2.early + bl * G.g2.late; }
+        const int row = rem / s2, kk = rem - row * s2;
+        if (DIR == 0) {
+            const uint16_t v = tile[row * kp + koff + kk];
+            dst[base + e] = v;
+            zeros += (v == 0);
+        } else {
+            const uint16_t v = src[base + e];
+            tile[row * kp + koff + kk] = v;
+            zeros += (v == 0);
+        }
+    }
+    if (DIR == 1) {
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < total; idx += 256) {
+            const int row = idx / klen, kx = idx - row * klen;
+            const int i = row / s1, j = row - i * s1;
+            dst[(int64_t)(o0 + i) * G.d0 + (int64_t)(o1 + j) * G.d1 + kbeg + kx] = tile[row * kp + kx];
+        }
+    }
+    zeros = wave_sum_u32(zeros);
+    if ((threadIdx.x & 63) == 0 && zeros) atomicAdd(&col_zeros[col], zeros);
+}
+
+// ------------------------------------------------------------------ unpredictable values, in block order
+// One workgroup per block column that contains zeros.  DIR 0: gather originals into the list
+// (compress); DIR 1: scatter the list into the output array (decompress).
+template <class T, int DIR>
+__global__ __launch_bounds__(256) void k_unpred(szh_geom3 G, const uint16_t *__restrict__ codes_blk, const unsigned *__restrict__ col_zeros,
+                                                const u64 *__restrict__ col_off, const T *data, T *unpred, T *out)
+{
+    __shared__ u64 sh[8];
+    const int col = blockIdx.x;
+    if (col_zeros[col] == 0) return;
+    const int b0 = col / G.g1.num, b1 = col - b0 * G.g1.num;
+    const int s0 = szh_blk_size(G.g0, b0), s1 = szh_blk_size(G.g1, b1);
+    const int o0 = szh_blk_start(G.g0, b0), o1 = szh_blk_start(G.g1, b1);
+    const int rows = s0 * s1;
+    const int64_t len = (int64_t)rows * G.g2.count;
+    const int64_t base = szh_code_base01(G, b0, b1);
+    const int64_t esz = (int64_t)rows * G.g2.early, lsz = (int64_t)rows * G.g2.late, eregion = (int64_t)G.g2.split * esz;
+    u64 run = col_off[col];
+    for (int64_t t0 = 0; t0 < len; t0 += 256) {
+        const int64_t e = t0 + threadIdx.x;
+        const bool z = (e < len) && (codes_blk[base + e] == 0);
+        u64 tot;
+        const u64 rank = block_excl_scan_256(z ? 1ull : 0ull, sh, &tot);
+        if (z) {
+            int64_t rem; int s2, o2;
+            if (e < eregion) { const int64_t bl = e / esz; rem = e - bl * esz; s2 = G.g2.early; o2 = (int)bl * G.g2.early; }
+            else { const int64_t e2 = e - eregion; const int64_t bl = e2 / lsz; rem = e2 - bl * lsz; s2 = G.g2.late; o2 = G.g2.split * G.g2.early + (int)bl * G.g2.late; }
+            const int row = (int)(rem / s2), kk = (int)(rem - (int64_t)row * s2);
+            const int ii = row / s1, jj = row - ii * s1;
+            const int64_t nat = (int64_t)(o0 + ii) * G.d0 + (int64_t)(o1 + jj) * G.d1 + o2 + kk;
+            if (DIR == 0) unpred[run + rank] = data[nat];
+            else out[nat] = unpred[run + rank];
+        }
+        run += tot;
+    }
+}
+
+// ------------------------------------------------------------------ device-wide exclusive scan of u64 (3 launches)
+#define SZH_SCAN_TILE 2048 /* 256 threads x 8 */
+__global__ __launch_bounds__(256) void k_scan_partials(const u64 *__restrict__ in, int64_t n, u64 *partial)
+{
+    __shared__ u64 sh[8];
+    const int64_t t0 = (int64_t)blockIdx.x * SZH_SCAN_TILE;
+    u64 s = 0;
+    for (int q = 0; q < 8; ++q) { const int64_t i = t0 + threadIdx.x * 8 + q; if (i < n) s += in[i]; }
+    s = wave_sum_u64(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+// single block: exclusive scan of partial[0..m) in place; total -> *total_out
+__global__ __launch_bounds__(256) void k_scan_single(u64 *partial, int64_t m, u64 *total_out)
+{
+    __shared__ u64 sh[8];
+    u64 carry = 0;
+    for (int64_t t0 = 0; t0 < m; t0 += 256) {
+        const int64_t i = t0 + threadIdx.x;
+        const u64 v = i < m ? partial[i] : 0;
+        u64 tot;
+        const u64 ex = block_excl_scan_256(v, sh, &tot);
+        if (i < m) partial[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) *total_out = carry;
+}
+__global__ __launch_bounds__(256) void k_scan_final(const u64 *__restrict__ in, int64_t n, const u64 *__restrict__ partial, u64 *out)
+{
+    __shared__ u64 sh[8];
+    const int64_t t0 = (int64_t)blockIdx.x * SZH_SCAN_TILE;
+    u64 v[8]; u64 s = 0;
+    for (int q = 0; q < 8; ++q) { const int64_t i = t0 + threadIdx.x * 8 + q; v[q] = i < n ? in[i] : 0; s += v[q]; }
+    u64 tot;
+    u64 ex = block_excl_scan_256(s, sh, &tot) + partial[blockIdx.x];
+    for (int q = 0; q < 8; ++q) { const int64_t i = t0 + threadIdx.x * 8 + q; if (i < n) out[i] = ex; ex += v[q]; }
+}
+__global__ __launch_bounds__(256) void k_u32_to_u64(const unsigned *__restrict__ in, int64_t n, u64 *out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+
+// ------------------------------------------------------------------ Huffman bit packing
+#define SZH_ENC_CHUNK 2048 /* symbols per workgroup: 256 threads x 8 */
+__global__ __launch_bounds__(256) void k_chunk_bits(const uint16_t *__restrict__ codes, int64_t n, const uint8_t *__restrict__ len, u64 *chunk_bits)
+{
+    __shared__ u64 sh[8];
+    const int64_t t0 = (int64_t)blockIdx.x * SZH_ENC_CHUNK + threadIdx.x * 8;
+    unsigned s = 0;
+    for (int q = 0; q < 8; ++q) { const int64_t i = t0 + q; if (i < n) s += len[codes[i]]; }
+    u64 ws = wave_sum_u64((u64)s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ws;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_bits[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// OR `nbits` (<= 64) right-aligned bits of `v` into the big-endian bit string held in 32-bit LDS words
+__device__ __forceinline__ void lds_put_bits(unsigned *buf, unsigned bitpos, u64 v, int nbits)
+{
+    while (nbits > 0) {
+        const unsigned w = bitpos >> 5, o = bitpos & 31;
+        const int room = 32 - (int)o;
+        const int take = nbits < room ? nbits : room;
+        const unsigned part = (unsigned)((v >> (nbits - take)) & ((take == 32) ? 0xffffffffull : ((1ull << take) - 1)));
+        atomicOr(&buf[w], part << (room - take));
+        bitpos += take; nbits -= take;
+    }
+}
+
+// out32: 4-byte aligned base of the stream buffer; bit0: bit position of the payload start in that buffer
+__global__ __launch_bounds__(256) void k_encode(const uint16_t *__restrict__ codes, int64_t n, const u64 *__restrict__ code,
+                                                const uint8_t *__restrict__ len, const u64 *__restrict__ chunk_off, u64 bit0,
+                                                unsigned *out32)
+{
+    __shared__ unsigned buf[SZH_ENC_CHUNK * 2 + 2];
+    __shared__ u64 sh[8];
+    for (int i = threadIdx.x; i < SZH_ENC_CHUNK * 2 + 2; i += 256) buf[i] = 0;
+    const u64 gbit = bit0 + chunk_off[blockIdx.x];
+    const unsigned lead = (unsigned)(gbit & 31);
+    const int64_t t0 = (int64_t)blockIdx.x * SZH_ENC_CHUNK + threadIdx.x * 8;
+    unsigned c[8]; unsigned l[8]; unsigned s = 0;
+    for (int q = 0; q < 8; ++q) {
+        const int64_t i = t0 + q;
+        c[q] = i < n ? codes[i] : 0;
+        l[q] = i < n ? len[c[q]] : 0;
+        s += l[q];
+    }
+    u64 tot;
+    const u64 ex = block_excl_scan_256((u64)s, sh, &tot); // also orders the LDS clear above
+    unsigned pos = lead + (unsigned)ex;
+    for (int q = 0; q < 8; ++q) {
+        if (l[q]) { lds_put_bits(buf, pos, code[c[q]], (int)l[q]); pos += l[q]; }
+    }
+    __syncthreads();
+    const unsigned nwords = (unsigned)((lead + tot + 31) >> 5);
+    const u64 w0 = gbit >> 5;
+    for (unsigned w = threadIdx.x; w < nwords; w += 256) {
+        const unsigned v = __builtin_bswap32(buf[w]);
+        if (w == 0 || w == nwords - 1) { if (v) atomicOr(&out32[w0 + w], v); }
+        else out32[w0 + w] = v;
+    }
+}
+
+// ------------------------------------------------------------------ Huffman decoding (self-synchronising)
+// The reference stream is one unbroken bit string (Huffman.c:205-308) with no index, so there are no
+// known codeword boundaries.  Every thread decodes one SUBSEQ-bit subsequence from a guessed start;
+// guesses are propagated (end of s -> start of s+1) until they stop changing -- Huffman codes
+// resynchronise after a few symbols, subsequence 0 is right by construction, and a fixed point of
+// the propagation is the sequential decode.
+#define SZH_SUBSEQ_BITS 1024
+struct szh_hdec_args {
+    const unsigned char *bits; u64 total_bits;
+    const unsigned *table; int n_nodes; int table_in_lds;
+    int64_t nsub;
+    u64 *starts; u64 *ends; u64 *counts; unsigned char *dirty; unsigned *changed;
+};
+
+__device__ __forceinline__ unsigned hdec_run(const unsigned char *__restrict__ bits, u64 total_bits, const unsigned *tab,
+                                             u64 pos, u64 limit, u64 *endpos, uint16_t *out, int64_t out_cap)
+{
+    unsigned cnt = 0, node = 0;
+    u64 p = pos, last_boundary = pos;
+    while (p < total_bits) {
+        const unsigned b = (bits[p >> 3] >> (7 - (unsigned)(p & 7))) & 1u;
+        ++p;
+        const unsigned nx = tab[2 * node + b];
+        if (nx & 0x80000000u) {
+            if (out && (int64_t)cnt < out_cap) out[cnt] = (uint16_t)(nx & 0xffffu);
+            ++cnt; node = 0; last_boundary = p;
+            if (p >= limit) break;
+        } else node = nx;
+    }
+    *endpos = last_boundary;
+    return cnt;
+}
+
+__global__ __launch_bounds__(256) void k_hdec_pass(szh_hdec_args a)
+{
+    SZH_DYN_SMEM(smem);
+    unsigned *lt = reinterpret_cast<unsigned *>(smem);
+    const unsigned *tab = a.table;
+    if (a.table_in_lds) {
+        for (int i = threadIdx.x; i < 2 * a.n_nodes; i += 256) lt[i] = a.table[i];
+        __syncthreads();
+        tab = lt;
+    }
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= a.nsub || !a.dirty[s]) return;
+    a.dirty[s] = 0;
+    const u64 limit = (u64)(s + 1) * SZH_SUBSEQ_BITS;
+    u64 endp;
+    const u64 st = a.starts[s];
+    unsigned cnt = 0;
+    if (st >= limit) endp = st; // the previous codeword swallowed this whole subsequence
+    else cnt = hdec_run(a.bits, a.total_bits, tab, st, limit, &endp, nullptr, 0);
+    a.ends[s] = endp; a.counts[s] = cnt;
+}
+__global__ __launch_bounds__(256) void k_hdec_update(szh_hdec_args a)
+{
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s < 1 || s >= a.nsub) return;
+    const u64 ns = a.ends[s - 1];
+    if (a.starts[s] != ns) { a.starts[s] = ns; a.dirty[s] = 1; *a.changed = 1u; }
+}
+__global__ __launch_bounds__(256) void k_hdec_init(szh_hdec_args a)
+{
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= a.nsub) return;
+    a.starts[s] = (u64)s * SZH_SUBSEQ_BITS; a.dirty[s] = 1; a.ends[s] = 0; a.counts[s] = 0;
+}
+__global__ __launch_bounds__(256) void k_hdec_write(szh_hdec_args a, const u64 *__restrict__ offs, uint16_t *out, int64_t n)
+{
+    SZH_DYN_SMEM(smem);
+    unsigned *lt = reinterpret_cast<unsigned *>(smem);
+    const unsigned *tab = a.table;
+    if (a.table_in_lds) {
+        for (int i = threadIdx.x; i < 2 * a.n_nodes; i += 256) lt[i] = a.table[i];
+        __syncthreads();
+        tab = lt;
+    }
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= a.nsub) return;
+    const u64 limit = (u64)(s + 1) * SZH_SUBSEQ_BITS, st = a.starts[s];
+    const int64_t o = (int64_t)offs[s];
+    if (st >= limit || o >= n) return;
+    u64 endp;
+    hdec_run(a.bits, a.total_bits, tab, st, limit, &endp, out + o, n - o);
+}
+__global__ __launch_bounds__(256) void k_fill_u16(uint16_t *p, int64_t n, uint16_t v)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}

@@ -1,0 +1,436 @@
+/* szhost.c -- host-side C of the MI355X SZ2 path (see szhost.h).  Plain C99, no GPU calls.
+ *
+ * Reference behaviour reproduced here (paths relative to the reference tree):
+ *   Huffman tree: leaves inserted in ascending symbol order into a 1-based binary min-heap whose
+ *     sift-up stops on parent<=child and whose sift-down takes the right child only on strict <
+ *     (sz/src/Huffman.c:76-114,165-185); of the two nodes removed per merge the first becomes the
+ *     RIGHT child (bit 1), the second the LEFT child (bit 0) -- gcc evaluates the arguments of
+ *     new_node(...,qremove(),qremove()) right to left (Huffman.c:181);
+ *   tree bytes: pre-order arrays L,R,C,t behind one endian byte (Huffman.c:443-585);
+ *   bit packing: MSB first, zero padded (Huffman.c:205-308);
+ *   interval decision: sz/src/sz_float.c:6486-6522,6650;
+ *   coefficient chain: sz/src/sz_float.c:7126-7152 (with mean :6790-6812), inverse szd_float.c:5809-5820;
+ *   params bytes: sz/src/ByteToolkit.c:874-972; flag byte: sz/src/dataCompression.c:686-709.
+ */
+#include "szhost.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+void szhost_put_u32be(unsigned char *b, uint32_t v) { b[0] = (unsigned char)(v >> 24); b[1] = (unsigned char)(v >> 16); b[2] = (unsigned char)(v >> 8); b[3] = (unsigned char)v; }
+void szhost_put_u64be(unsigned char *b, uint64_t v) { szhost_put_u32be(b, (uint32_t)(v >> 32)); szhost_put_u32be(b + 4, (uint32_t)v); }
+uint32_t szhost_get_u32be(const unsigned char *b) { return ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | (uint32_t)b[3]; }
+uint64_t szhost_get_u64be(const unsigned char *b) { return ((uint64_t)szhost_get_u32be(b) << 32) | szhost_get_u32be(b + 4); }
+void szhost_put_f32be(unsigned char *b, float v) { uint32_t u; memcpy(&u, &v, 4); szhost_put_u32be(b, u); }
+void szhost_put_f64be(unsigned char *b, double v) { uint64_t u; memcpy(&u, &v, 8); szhost_put_u64be(b, u); }
+float szhost_get_f32be(const unsigned char *b) { uint32_t u = szhost_get_u32be(b); float v; memcpy(&v, &u, 4); return v; }
+double szhost_get_f64be(const unsigned char *b) { uint64_t u = szhost_get_u64be(b); double v; memcpy(&v, &u, 8); return v; }
+
+/* ------------------------------------------------------------------ Huffman */
+
+typedef struct { uint64_t w; int lch, rch; uint32_t sym; } hnode; /* lch < 0: leaf */
+
+static void heap_push(int *hp, int *hn, const hnode *nd, int id)
+{
+    int i = ++(*hn);
+    while (i > 1) {
+        int par = i >> 1;
+        if (nd[hp[par]].w <= nd[id].w) break;
+        hp[i] = hp[par];
+        i = par;
+    }
+    hp[i] = id;
+}
+
+static int heap_pop(int *hp, int *hn, const hnode *nd)
+{
+    int top = hp[1];
+    int last = hp[*hn];
+    (*hn)--;
+    int n = *hn; /* valid entries 1..n after moving `last` to the root */
+    if (n >= 1) {
+        hp[1] = last;
+        int i = 1;
+        for (;;) {
+            int c = i << 1;
+            if (c > n) break;
+            if (c + 1 <= n && nd[hp[c + 1]].w < nd[hp[c]].w) c++;
+            if (nd[hp[i]].w > nd[hp[c]].w) { int t = hp[i]; hp[i] = hp[c]; hp[c] = t; i = c; }
+            else break;
+        }
+    }
+    return top;
+}
+
+static szhost_huff *huff_alloc(int state_num, int n_nodes)
+{
+    szhost_huff *h = (szhost_huff *)calloc(1, sizeof(*h));
+    h->state_num = state_num;
+    h->n_nodes = n_nodes;
+    h->code = (uint64_t *)calloc((size_t)state_num, sizeof(uint64_t));
+    h->len = (uint8_t *)calloc((size_t)state_num, 1);
+    h->L = (uint32_t *)calloc((size_t)n_nodes, 4);
+    h->R = (uint32_t *)calloc((size_t)n_nodes, 4);
+    h->C = (uint32_t *)calloc((size_t)n_nodes, 4);
+    h->t = (uint8_t *)calloc((size_t)n_nodes, 1);
+    return h;
+}
+
+void szhost_huff_free(szhost_huff *h)
+{
+    if (!h) return;
+    free(h->code); free(h->len); free(h->L); free(h->R); free(h->C); free(h->t); free(h);
+}
+
+/* assign codes by walking the serialised (pre-order) tree: left edge 0, right edge 1 */
+static int huff_codes_from_arrays(szhost_huff *h)
+{
+    int n = h->n_nodes;
+    uint32_t *stk = (uint32_t *)malloc((size_t)(n + 1) * sizeof(uint32_t));
+    uint64_t *sbits = (uint64_t *)malloc((size_t)(n + 1) * sizeof(uint64_t));
+    uint8_t *slen = (uint8_t *)malloc((size_t)(n + 1));
+    int sp = 0, ok = 1;
+    stk[0] = 0; sbits[0] = 0; slen[0] = 0; sp = 1;
+    while (sp) {
+        sp--;
+        uint32_t nd = stk[sp]; uint64_t bits = sbits[sp]; int len = slen[sp];
+        if (h->t[nd]) {
+            if (len > 64 || h->C[nd] >= (uint32_t)h->state_num) { ok = 0; break; }
+            h->code[h->C[nd]] = bits;
+            h->len[h->C[nd]] = (uint8_t)len;
+            continue;
+        }
+        if (len >= 64) { ok = 0; break; }
+        if (h->R[nd]) { stk[sp] = h->R[nd]; sbits[sp] = (bits << 1) | 1; slen[sp] = (uint8_t)(len + 1); sp++; }
+        if (h->L[nd]) { stk[sp] = h->L[nd]; sbits[sp] = bits << 1; slen[sp] = (uint8_t)(len + 1); sp++; }
+    }
+    free(stk); free(sbits); free(slen);
+    return ok;
+}
+
+szhost_huff *szhost_huff_build(int state_num, const uint32_t *hist32, const uint64_t *hist64, size_t nbins)
+{
+    size_t lim = (size_t)state_num * 2; /* the reference scans allNodes = 2*stateNum bins */
+    if (nbins < lim) lim = nbins;
+    size_t distinct = 0;
+    for (size_t s = 0; s < lim; s++) if (hist32 ? hist32[s] : hist64[s]) distinct++;
+    if (!distinct) return NULL;
+    int total = (int)(2 * distinct - 1);
+    hnode *nd = (hnode *)malloc((size_t)total * sizeof(hnode));
+    int *hp = (int *)malloc((distinct + 2) * sizeof(int));
+    int hn = 0, nn = 0;
+    uint64_t total_bits_weight = 0;
+    for (size_t s = 0; s < lim; s++) {
+        uint64_t f = hist32 ? hist32[s] : hist64[s];
+        if (!f) continue;
+        nd[nn].w = f; nd[nn].lch = -1; nd[nn].rch = -1; nd[nn].sym = (uint32_t)s;
+        heap_push(hp, &hn, nd, nn);
+        nn++;
+    }
+    while (hn > 1) {
+        int first = heap_pop(hp, &hn, nd);
+        int second = heap_pop(hp, &hn, nd);
+        nd[nn].w = nd[first].w + nd[second].w;
+        nd[nn].rch = first;   /* smallest -> right, bit 1 */
+        nd[nn].lch = second;  /* next     -> left,  bit 0 */
+        nd[nn].sym = 0;
+        heap_push(hp, &hn, nd, nn);
+        nn++;
+    }
+    int root = hp[1];
+    szhost_huff *h = huff_alloc(state_num, total);
+    /* pre-order numbering, left subtree first (pad_tree_*, Huffman.c:443-501) */
+    {
+        int *stk = (int *)malloc((size_t)(total + 1) * sizeof(int));
+        int *spar = (int *)malloc((size_t)(total + 1) * sizeof(int));
+        unsigned char *sright = (unsigned char *)malloc((size_t)(total + 1));
+        int sp = 0; uint32_t next = 0;
+        stk[0] = root; spar[0] = -1; sright[0] = 0; sp = 1;
+        while (sp) {
+            sp--;
+            int n = stk[sp], par = spar[sp]; unsigned char isr = sright[sp];
+            uint32_t idx = next++;
+            if (par >= 0) { if (isr) h->R[par] = idx; else h->L[par] = idx; }
+            h->C[idx] = nd[n].sym;
+            h->t[idx] = nd[n].lch < 0 ? 1 : 0;
+            if (nd[n].lch >= 0) {
+                stk[sp] = nd[n].rch; spar[sp] = (int)idx; sright[sp] = 1; sp++;
+                stk[sp] = nd[n].lch; spar[sp] = (int)idx; sright[sp] = 0; sp++;
+            }
+        }
+        free(stk); free(spar); free(sright);
+    }
+    free(nd); free(hp);
+    if (!huff_codes_from_arrays(h)) { fprintf(stderr, "szhost: Huffman code longer than 64 bits is not supported\n"); szhost_huff_free(h); return NULL; }
+    for (size_t s = 0; s < lim; s++) {
+        uint64_t f = hist32 ? hist32[s] : hist64[s];
+        if (f) total_bits_weight += f * h->len[s];
+    }
+    h->total_bits = total_bits_weight;
+    return h;
+}
+
+static int tree_width(int n_nodes) { return n_nodes <= 256 ? 1 : (n_nodes <= 65536 ? 2 : 4); }
+
+size_t szhost_huff_serial_size(int node_count)
+{
+    size_t n = (size_t)node_count;
+    return 1 + 2 * (size_t)tree_width(node_count) * n + 4 * n + n;
+}
+
+size_t szhost_huff_tree_size(const szhost_huff *h)
+{
+    size_t n = (size_t)h->n_nodes;
+    return 1 + 2 * (size_t)tree_width(h->n_nodes) * n + 4 * n + n;
+}
+
+void szhost_huff_tree_write(const szhost_huff *h, unsigned char *out)
+{
+    int w = tree_width(h->n_nodes);
+    size_t n = (size_t)h->n_nodes;
+    unsigned char *p = out;
+    *p++ = 0; /* little-endian system */
+    for (int pass = 0; pass < 2; pass++) {
+        const uint32_t *src = pass ? h->R : h->L;
+        for (size_t i = 0; i < n; i++) {
+            if (w == 1) p[0] = (unsigned char)src[i];
+            else if (w == 2) { uint16_t v = (uint16_t)src[i]; memcpy(p, &v, 2); }
+            else memcpy(p, &src[i], 4);
+            p += w;
+        }
+    }
+    memcpy(p, h->C, 4 * n); p += 4 * n;
+    memcpy(p, h->t, n);
+}
+
+szhost_huff *szhost_huff_from_bytes(int state_num, const unsigned char *bytes, int node_count)
+{
+    if (node_count <= 0) return NULL;
+    szhost_huff *h = huff_alloc(state_num, node_count);
+    int w = tree_width(node_count);
+    size_t n = (size_t)node_count;
+    const unsigned char *pL = bytes + 1, *pR = pL + (size_t)w * n, *pC = pR + (size_t)w * n, *pt = pC + 4 * n;
+    for (size_t i = 0; i < n; i++) {
+        uint32_t l = 0, r = 0;
+        if (w == 1) { l = pL[i]; r = pR[i]; }
+        else if (w == 2) { uint16_t a, b; memcpy(&a, pL + 2 * i, 2); memcpy(&b, pR + 2 * i, 2); l = a; r = b; }
+        else { memcpy(&l, pL + 4 * i, 4); memcpy(&r, pR + 4 * i, 4); }
+        if (l >= n || r >= n) { szhost_huff_free(h); return NULL; }
+        h->L[i] = l; h->R[i] = r;
+        memcpy(&h->C[i], pC + 4 * i, 4);
+        h->t[i] = pt[i];
+    }
+    if (node_count > 256) h->t[0] = 0; /* the reference builds the root with t=0 in the wide forms (Huffman.c:740,780) */
+    if (!huff_codes_from_arrays(h)) { szhost_huff_free(h); return NULL; }
+    return h;
+}
+
+void szhost_huff_decode_table(const szhost_huff *h, uint32_t *table)
+{
+    for (int i = 0; i < h->n_nodes; i++) {
+        uint32_t kids[2] = { h->L[i], h->R[i] };
+        for (int b = 0; b < 2; b++) {
+            uint32_t c = kids[b];
+            if (h->t[i] || c == 0) table[2 * i + b] = 0x80000000u | h->C[i]; /* leaf (only reachable for a 1-node tree) */
+            else table[2 * i + b] = h->t[c] ? (0x80000000u | h->C[c]) : c;
+        }
+    }
+}
+
+size_t szhost_huff_encode_i32(const szhost_huff *h, const int *s, size_t n, unsigned char *out)
+{
+    uint64_t acc = 0; int fill = 0; size_t o = 0;
+    for (size_t i = 0; i < n; i++) {
+        int len = h->len[s[i]];
+        uint64_t bits = h->code[s[i]];
+        while (len > 0) {
+            int room = 64 - fill;
+            int take = len < room ? len : room;
+            uint64_t part = (take == 64) ? bits : ((bits >> (len - take)) & ((((uint64_t)1) << take) - 1));
+            acc = (take == 64) ? part : ((acc << take) | part);
+            fill += take; len -= take;
+            if (fill == 64) { szhost_put_u64be(out + o, acc); o += 8; acc = 0; fill = 0; }
+        }
+    }
+    if (fill) {
+        acc <<= (64 - fill);
+        int nbytes = (fill + 7) / 8;
+        for (int b = 0; b < nbytes; b++) out[o++] = (unsigned char)(acc >> (56 - 8 * b));
+    }
+    return o;
+}
+
+void szhost_huff_decode_i32(const szhost_huff *h, const unsigned char *in, size_t n, int *out)
+{
+    if (h->t[0]) { for (size_t i = 0; i < n; i++) out[i] = (int)h->C[0]; return; }
+    size_t bit = 0, cnt = 0; uint32_t nd = 0;
+    while (cnt < n) {
+        int b = (in[bit >> 3] >> (7 - (bit & 7))) & 1; bit++;
+        nd = b ? h->R[nd] : h->L[nd];
+        if (h->t[nd]) { out[cnt++] = (int)h->C[nd]; nd = 0; }
+    }
+}
+
+/* ------------------------------------------------------------------ interval decision */
+
+static unsigned round_up_pow2(unsigned v) { v -= 1; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; return v + 1; }
+
+double szhost_seq_mean(int is_double, const void *samples, size_t count)
+{
+    if (is_double) {
+        const double *s = (const double *)samples; double m = 0.0;
+        for (size_t i = 0; i < count; i++) m += s[i];
+        if (count > 0) m /= (double)count;
+        return m;
+    } else {
+        const float *s = (const float *)samples; float m = 0.0f;
+        for (size_t i = 0; i < count; i++) m += s[i];
+        if (count > 0) m /= (float)count;
+        return (double)m;
+    }
+}
+
+void szhost_decide(int is_double, const uint32_t *radius_hist, unsigned max_radius, const uint32_t *freq_hist,
+                   uint64_t sample_count, uint64_t within_eb, float pred_threshold, double ebD, double mean,
+                   szhost_decision *out)
+{
+    double sample_freq_d = (double)within_eb * 1.0 / (double)sample_count; /* 0/0 -> NaN as in the reference */
+    uint64_t target;
+    if (is_double) target = (uint64_t)((double)sample_count * (double)pred_threshold);
+    else target = (uint64_t)((float)sample_count * pred_threshold);
+    uint64_t sum = 0; unsigned i;
+    for (i = 0; i < max_radius; i++) { sum += radius_hist[i]; if (sum > target) break; }
+    if (i >= max_radius) i = max_radius - 1;
+    unsigned p2 = round_up_pow2(2 * (i + 1));
+    if (p2 < 32) p2 = 32;
+    uint64_t max_sum = 0; size_t max_index = 0;
+    for (size_t q = 1; q < 8192 - 2; q++) {
+        uint64_t s2 = (uint64_t)freq_hist[q] + freq_hist[q + 1];
+        if (s2 > max_sum) { max_sum = s2; max_index = q; }
+    }
+    double dense = mean + ebD * (double)((int64_t)max_index + 1 - 4096);
+    double mean_freq_d = (double)max_sum * 1.0 / (double)sample_count;
+    if (is_double) { out->dense_pos = dense; out->mean_freq = mean_freq_d; out->sample_freq = sample_freq_d; }
+    else { out->dense_pos = (double)(float)dense; out->mean_freq = (double)(float)mean_freq_d; out->sample_freq = (double)(float)sample_freq_d; }
+    out->intervals = p2;
+    out->use_mean = (out->mean_freq > 0.5 || out->mean_freq > out->sample_freq) ? 1 : 0;
+}
+
+/* ------------------------------------------------------------------ coefficient chain */
+
+void szhost_coeffs_free(szhost_coeffs *c)
+{
+    for (int e = 0; e < 4; e++) { free(c->codes[e]); free(c->unpred[e]); c->codes[e] = NULL; c->unpred[e] = NULL; }
+}
+
+#define CHAIN_BODY(T, FABS, DIVIDE_IN_NOMEAN)                                                              \
+    T *cf = (T *)coef;                                                                                     \
+    T ebT = (T)eb;                                                                                         \
+    T rel = (T)0.025;                                                                                      \
+    T prec[4], rprec[4], last[4] = {0, 0, 0, 0};                                                           \
+    prec[0] = rel * ebT / late0; prec[1] = rel * ebT / late1; prec[2] = rel * ebT / late2; prec[3] = rel * ebT; \
+    for (int e = 0; e < 4; e++) { rprec[e] = 1 / prec[e]; out->prec[e] = (double)prec[e]; }                \
+    T *un[4];                                                                                              \
+    for (int e = 0; e < 4; e++) { un[e] = (T *)malloc((reg_count ? reg_count : 1) * sizeof(T)); out->unpred[e] = un[e]; } \
+    size_t ci = 0;                                                                                         \
+    for (size_t b = 0; b < nblocks; b++) {                                                                 \
+        if (indicator[b]) continue;                                                                        \
+        for (int e = 0; e < 4; e++) {                                                                      \
+            T cur = cf[(size_t)e * nblocks + b];                                                           \
+            T diff = cur - last[e];                                                                        \
+            T itv;                                                                                         \
+            if (DIVIDE_IN_NOMEAN && !use_mean) itv = FABS(diff) / prec[e] + 1;                             \
+            else itv = FABS(diff) * rprec[e] + 1;                                                          \
+            int cc = 0;                                                                                    \
+            if (itv < 65536) {                                                                             \
+                if (diff < 0) itv = -itv;                                                                  \
+                cc = (int)(itv / 2) + 32768;                                                               \
+                last[e] = last[e] + 2 * (cc - 32768) * prec[e];                                            \
+                if (FABS(cur - last[e]) > prec[e]) { cc = 0; last[e] = cur; un[e][out->unpred_count[e]++] = cur; } \
+            } else { cc = 0; last[e] = cur; un[e][out->unpred_count[e]++] = cur; }                         \
+            out->codes[e][ci] = cc;                                                                        \
+            cf[(size_t)e * nblocks + b] = last[e];                                                         \
+        }                                                                                                  \
+        ci++;                                                                                              \
+    }
+
+void szhost_coeff_chain(int is_double, void *coef, const unsigned char *indicator, size_t nblocks, double eb,
+                        int late0, int late1, int late2, int use_mean, szhost_coeffs *out)
+{
+    memset(out, 0, sizeof(*out));
+    size_t reg_count = 0;
+    for (size_t b = 0; b < nblocks; b++) if (!indicator[b]) reg_count++;
+    out->reg_count = reg_count;
+    for (int e = 0; e < 4; e++) out->codes[e] = (int *)malloc((reg_count ? reg_count : 1) * sizeof(int));
+    if (is_double) { CHAIN_BODY(double, fabs, 0) }
+    else { CHAIN_BODY(float, fabsf, 1) }
+}
+
+void szhost_coeff_unchain(int is_double, void *coef, const unsigned char *indicator, size_t nblocks,
+                          int *const codes[4], const int radius[4], const double prec[4],
+                          const unsigned char *const unpred[4])
+{
+    size_t ci = 0, un[4] = {0, 0, 0, 0};
+    if (is_double) {
+        double *cf = (double *)coef, last[4] = {0, 0, 0, 0};
+        for (size_t b = 0; b < nblocks; b++) {
+            if (indicator[b]) continue;
+            for (int e = 0; e < 4; e++) {
+                int t = codes[e][ci];
+                if (t != 0) last[e] = last[e] + 2 * (t - radius[e]) * prec[e];
+                else { memcpy(&last[e], unpred[e] + 8 * (un[e]++), 8); }
+                cf[(size_t)e * nblocks + b] = last[e];
+            }
+            ci++;
+        }
+    } else {
+        float *cf = (float *)coef, last[4] = {0, 0, 0, 0};
+        for (size_t b = 0; b < nblocks; b++) {
+            if (indicator[b]) continue;
+            for (int e = 0; e < 4; e++) {
+                int t = codes[e][ci];
+                if (t != 0) last[e] = last[e] + 2 * (t - radius[e]) * (float)prec[e];
+                else { memcpy(&last[e], unpred[e] + 4 * (un[e]++), 4); }
+                cf[(size_t)e * nblocks + b] = last[e];
+            }
+            ci++;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ stream framing */
+
+size_t szhost_write_meta(const szhost_meta *m, unsigned char flags, unsigned char *out)
+{
+    size_t plen = m->data_type == 0 ? 28 : 36;
+    memset(out, 0, 4 + plen);
+    out[0] = 2; out[1] = 1; out[2] = 12; /* versionNumber, sz/include/defines.h:13-17 */
+    out[3] = flags;
+    unsigned char *r = out + 4;
+    unsigned char buf = (unsigned char)(m->opt_quant_mode & 1);
+    buf = (unsigned char)((buf << 1) | (m->data_endian & 1));
+    buf = (unsigned char)((buf << 1) | 0); /* little-endian system */
+    buf = (unsigned char)((buf << 2) | (m->sz_mode & 3));
+    int tmp = 0;
+    if (m->gzip_mode == 1) tmp = 0; else if (m->gzip_mode == 0) tmp = 1; else if (m->gzip_mode == 9) tmp = 2;
+    buf = (unsigned char)((buf << 2) | tmp);
+    r[0] = buf;
+    r[1] = (unsigned char)((unsigned)m->sample_distance >> 8); r[2] = (unsigned char)m->sample_distance;
+    short t2 = (short)(m->pred_threshold * 10000);
+    r[3] = (unsigned char)((unsigned short)t2 >> 8); r[4] = (unsigned char)t2;
+    r[5] = (unsigned char)m->err_mode;
+    r[5] = (unsigned char)((r[5] << 4) | (m->data_type & 0x17));
+    switch (m->err_mode) {
+    case 0: szhost_put_f32be(r + 6, (float)m->abs_bound); break;
+    case 1: szhost_put_f32be(r + 10, (float)m->rel_ratio); break;
+    case 2: case 3: szhost_put_f32be(r + 6, (float)m->abs_bound); szhost_put_f32be(r + 10, (float)m->rel_ratio); break;
+    case 4: szhost_put_f32be(r + 6, (float)m->psnr); memset(r + 9, 0, 4); break;
+    default: break;
+    }
+    r[14] = (unsigned char)m->sol_id;
+    szhost_put_u32be(r + 16, m->opt_quant_mode == 1 ? m->max_quant_intervals : m->quantization_intervals);
+    if (m->data_type == 0) { szhost_put_f32be(r + 20, (float)m->vmin); szhost_put_f32be(r + 24, (float)m->vmax); }
+    else { szhost_put_f64be(r + 20, m->vmin); szhost_put_f64be(r + 28, m->vmax); }
+    return 4 + plen;
+}

@@ -7,6 +7,8 @@
 #include <cstring>
 #include <vector>
 #include "../../sz_amd/csrc/szh_pencil.h"
+#include "../../sz_amd/csrc/szh_core.h"
+#include <cmath>
 
 struct SimBackend {
     static constexpr int NL = 64;
@@ -98,4 +100,61 @@ void szh_sim_blk_to_nat_u16(const int32_t *blk, int r0, int r1, int r2, uint16_t
             nat[(int64_t)(o0 + i) * G.d0 + (int64_t)(o1 + j) * G.d1 + (o2 + k)] = (uint16_t)blk[p++];
     }
 }
+}
+
+// ---- fit / select / sampling through the shared per-block functions (global-memory accessor) ----
+template <class T> struct GAcc {
+    const T *base; int64_t d0, d1;
+    T operator()(int i, int j, int k) const { return base[(int64_t)i * d0 + (int64_t)j * d1 + k]; }
+};
+template <class T>
+static void fit_select(const T *data, int r0, int r1, int r2, double eb, int use_mean, double mean, T *coef, uint8_t *blk_lor)
+{
+    szh_geom3 G = szh_make_geom3(r0, r1, r2);
+    const T noise = (T)((T)eb * 1.22);
+    int64_t b = 0;
+    for (int b0 = 0; b0 < G.g0.num; ++b0) for (int b1 = 0; b1 < G.g1.num; ++b1) for (int b2 = 0; b2 < G.g2.num; ++b2, ++b) {
+        GAcc<T> A{data + (int64_t)szh_blk_start(G.g0, b0) * G.d0 + (int64_t)szh_blk_start(G.g1, b1) * G.d1 + szh_blk_start(G.g2, b2), G.d0, G.d1};
+        T c4[4];
+        szh_fit_block<T>(A, szh_blk_size(G.g0, b0), szh_blk_size(G.g1, b1), szh_blk_size(G.g2, b2), c4);
+        for (int e = 0; e < 4; ++e) coef[e * G.nblocks + b] = c4[e];
+        blk_lor[b] = szh_select_block<T>(A, szh_blk_size(G.g0, b0), szh_blk_size(G.g1, b1), szh_blk_size(G.g2, b2), c4, noise, use_mean, (T)mean) ? 0 : 1;
+    }
+}
+template <class T>
+static double sample(const T *data, int r0, int r1, int r2, double ebD, int sd, unsigned max_radius,
+                     uint32_t *radius_hist, uint32_t *freq_hist, uint64_t *within, uint64_t *count)
+{
+    szh_geom3 G = szh_make_geom3(r0, r1, r2);
+    // strided mean, closed-form positions, sequential sum
+    szh_meanwalk w = szh_make_meanwalk(G.n, G.d0, r2, (int64_t)(int)std::sqrt((double)G.n));
+    T mean = 0; int64_t mc = 0;
+    for (int64_t m = 0;; ++m) { int64_t p = szh_meanwalk_pos(w, m); if (p >= G.n) break; mean += data[p]; mc++; }
+    if (mc > 0) mean /= (T)mc;
+    const int64_t nrows = szh_sample_row_limit(G, sd);
+    *within = 0; *count = 0;
+    for (int64_t ridx = 0; ridx < nrows; ++ridx) {
+        const int64_t n1 = ridx / (r1 - 1) + 1, n2 = ridx % (r1 - 1) + 1;
+        const int64_t c0 = sd - ((n1 + n2) % sd);
+        for (int64_t m = 0;; ++m) {
+            const int64_t col = c0 + m * sd;
+            if (m > 0 && col >= r2) break;
+            const int64_t pos = n1 * G.d0 + n2 * r2 + col;
+            if (pos >= G.n) break;
+            unsigned ri; int fi, we;
+            szh_sample_point<T>(data, pos, r2, G.d0, ebD, mean, max_radius, &ri, &fi, &we);
+            radius_hist[ri]++; freq_hist[fi]++; *within += we; (*count)++;
+        }
+    }
+    return (double)mean;
+}
+extern "C" {
+void szh_sim_fit_select_f32(const float *d, int r0, int r1, int r2, double eb, int um, double mean, float *coef, uint8_t *bl)
+{ fit_select<float>(d, r0, r1, r2, eb, um, mean, coef, bl); }
+void szh_sim_fit_select_f64(const double *d, int r0, int r1, int r2, double eb, int um, double mean, double *coef, uint8_t *bl)
+{ fit_select<double>(d, r0, r1, r2, eb, um, mean, coef, bl); }
+double szh_sim_sample_f32(const float *d, int r0, int r1, int r2, double eb, int sd, unsigned mr, uint32_t *rh, uint32_t *fh, uint64_t *w, uint64_t *c)
+{ return sample<float>(d, r0, r1, r2, eb, sd, mr, rh, fh, w, c); }
+double szh_sim_sample_f64(const double *d, int r0, int r1, int r2, double eb, int sd, unsigned mr, uint32_t *rh, uint32_t *fh, uint64_t *w, uint64_t *c)
+{ return sample<double>(d, r0, r1, r2, eb, sd, mr, rh, fh, w, c); }
 }
