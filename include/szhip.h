@@ -73,8 +73,9 @@ int szhip_minmax(szhip_ctx *ctx, int dtype, const void *data, int data_on_device
  * Compress a 3-D array (r0 slowest ... r2 fastest, the callee convention of sz_float.c:6527) with
  * absolute bound `eb` (already derived from the user's mode by the caller, sz_float.c:2852-2868).
  * `meta`/`meta_len`: the 3 version bytes + flag byte + parameter bytes the stream starts with.
- * Output: if out_on_device, *out is a device pointer owned by ctx (valid until the next call);
- * otherwise *out is malloc'd host memory owned by the caller (free()).
+ * Output: out_on_device = 0: *out is malloc'd host memory owned by the caller (free());
+ *         out_on_device = 1: *out is a device pointer owned by ctx (valid until the next call);
+ *         out_on_device = 2: *out is the CALLER's device buffer of capacity *out_size; the stream is copied into it.
  */
 int szhip_compress(szhip_ctx *ctx, int dtype, const void *data, int data_on_device,
                    size_t r0, size_t r1, size_t r2, double eb, const szhip_params *params,

@@ -78,7 +78,7 @@ template <> struct szh_gran<double> {
 #define SZH_FORL for (int l = 0; l < NL; ++l)
 
 // B: back end. Requires: NL, lane(l), shfl_up(dst,src,d), readlane(src,lane), all(pred),
-//    ld_gran(p), st_gran(p,v), backoff().
+//    ld_gran(p), st_gran(p,v), ld_flag(p), st_flag(p,v), backoff().
 template <class T, bool DEC, class B>
 SZH_HD void szh_pencil_run(const szh_qargs<T> &a, int I, int J)
 {
@@ -200,7 +200,9 @@ SZH_UNROLL
                         ok[l] = !hact || v;
                     }
                     if (B::all(ok)) break;
-                    if (++spins > (1u << 22)) { SZH_FORL { if (!ok[l]) *a.err = 1u; } break; }
+                    // bounded wait: a lost hand-off must end the launch, not hang the GPU
+                    if (++spins > (1u << 20)) { SZH_FORL { if (!ok[l]) B::st_flag(a.err, 1u); } break; }
+                    if ((spins & 255u) == 0 && B::ld_flag(a.err) != 0) break; // another wavefront already gave up
                     B::backoff();
                     SZH_FORL {
                         if (!ok[l]) {

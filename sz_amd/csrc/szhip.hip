@@ -450,7 +450,11 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(ctx->ev[4], st));
-    if (out_on_device) {
+    if (out_on_device == 2) { // caller-provided device buffer of capacity *out_size
+        if (!*out || *out_size < total_len) FAIL(SZHIP_ERR_ARG, "caller's device buffer too small (%zu < %zu)", *out_size, total_len);
+        HIPCHK(hipMemcpyAsync(*out, d_stream, total_len, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+    } else if (out_on_device) {
         HIPCHK(hipStreamSynchronize(st));
         *out = d_stream;
     } else {

@@ -23,6 +23,8 @@ struct SimBackend {
     static bool all(const bool (&p)[64]) { for (int l = 0; l < 64; ++l) if (!p[l]) return false; return true; }
     static szh_u64 ld_gran(const szh_u64 *p) { return *p; }
     static void st_gran(szh_u64 *p, szh_u64 v) { *p = v; }
+    static unsigned ld_flag(const unsigned *p) { return *p; }
+    static void st_flag(unsigned *p, unsigned v) { *p = v; }
     static void backoff() {}
 };
 
