@@ -40,6 +40,11 @@ template <class T> struct szh_qargs {
     const unsigned *order;    // ticket -> (I<<16)|J, anti-diagonal order
     unsigned *ticket;
     unsigned *err;            // set to 1 if a halo wait timed out
+    szh_u64 *progress;        // per pencil: {epoch, steps completed}; a cheap "has my neighbour got going" word
+    int gate_steps;           // a pencil starts once both producers have completed this many steps
+    int backoff;              // sleep units between two polls of a missing granule
+    int dbg;                  // development timing experiments (results become WRONG): 1 = no hand-off at all, 2 = no publishing stores
+    szh_u64 *trace;           // optional (development): per pencil {t_start, t_gate, t_first, t_end, spins, naps, cu, 0}
 };
 
 template <class T> struct szh_gran;
@@ -69,18 +74,38 @@ template <> struct szh_gran<double> {
     }
 };
 
-#define SZH_U 8 /* steps per software-pipelined chunk */
+#define SZH_U 16 /* steps per loop trip: a trip first requests all of its inputs (values and halo granules), then steps */
 #if defined(__HIPCC__)
 #define SZH_UNROLL _Pragma("unroll")
 #else
 #define SZH_UNROLL
 #endif
 #define SZH_FORL for (int l = 0; l < NL; ++l)
+#define SZH_XC 48 /* columns of the per-wavefront LDS code ring ([column % SZH_XC][lane]) */
+
+// branch-free form of szh_quant_point (same arithmetic, same results)
+template <class T>
+SZH_HD int szh_quant_sel(T x, T pred, T eb, T recip, int capacity, int radius, T *recon)
+{
+    const T diff = x - pred;
+    T itv = szh_abs(diff) * recip + 1;
+    const bool inr = itv < (T)capacity;
+    itv = inr ? itv : (T)0;                 // keeps the int conversion in range on every back end
+    const T sitv = diff < 0 ? -itv : itv;
+    const int q = (int)(sitv / 2);
+    const T rc = pred + (T)(2 * q) * eb;
+    const bool ok = inr && !(szh_abs(x - rc) > eb);
+    *recon = ok ? rc : x;
+    return ok ? q + radius : 0;
+}
 
 // B: back end. Requires: NL, lane(l), shfl_up(dst,src,d), readlane(src,lane), all(pred),
-//    ld_gran(p), st_gran(p,v), ld_flag(p), st_flag(p,v), backoff().
-template <class T, bool DEC, class B>
-SZH_HD void szh_pencil_run(const szh_qargs<T> &a, int I, int J)
+//    ld_gran(p), st_gran(p,v), ld_flag(p), st_flag(p,v), backoff(n), nap(), clock(), where(),
+//    ld16(p, T(&)[16/sizeof T]), st16(p, const T(&)[...]) -- one 16-byte vector access (4-byte aligned for 4/8-byte T).
+// HASREG: the pencil touches at least one regression block (otherwise the block bookkeeping and the
+//         regression quantiser are compiled out); USEMEAN: the stream's use_mean flag.
+template <class T, bool DEC, bool HASREG, bool USEMEAN, class B>
+SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, uint16_t *cring)
 {
     constexpr int NL = B::NL;
     constexpr int NW = szh_gran<T>::NW;
@@ -89,12 +114,11 @@ SZH_HD void szh_pencil_run(const szh_qargs<T> &a, int I, int J)
     const int nbz = G.g2.num;
     const int cap_lor = a.cap - 2, cap_reg = a.cap, radius = a.radius;
     const T eb = a.eb, recip = a.recip, mean = a.mean;
-    const bool use_mean = a.use_mean != 0;
     const bool pubJ = (J + 1 < a.nJ), pubI = (I + 1 < a.nI);
 
     // ---- per-lane constants ----
     int il[NL], jl[NL], skew[NL], hskew[NL];
-    bool inb[NL], hrole[NL];
+    bool inb[NL], hrole[NL], pJ[NL], pI[NL];
     int64_t rowoff[NL], blkrow[NL], hoff[NL], pubJoff[NL], pubIoff[NL];
     const szh_u64 *hbuf[NL];
     T fii[NL], fjj[NL];
@@ -127,9 +151,13 @@ SZH_HD void szh_pencil_run(const szh_qargs<T> &a, int I, int J)
         }
         pubJoff[l] = (((int64_t)I * a.nJ + J) * 8 + il[l]) * r2;
         pubIoff[l] = (((int64_t)I * a.nJ + J) * 8 + jl[l]) * r2;
+        pJ[l] = pubJ && jl[l] == 7 && inb[l];
+        pI[l] = pubI && il[l] == 7 && inb[l];
+        if (a.dbg == 1) { hrole[l] = false; pJ[l] = false; pI[l] = false; }
+        if (a.dbg == 2) { pJ[l] = false; pI[l] = false; }
     }
 
-    // ---- per-lane block tracking along dim2 ----
+    // ---- per-lane block tracking along dim2 (only when the pencil touches regression blocks) ----
     int kk[NL], bz[NL], bk[NL];
     bool lor[NL], nlor[NL], nnlor[NL];
     T ca[NL], cb[NL], cc[NL], cd[NL], na[NL], nb_[NL], nc[NL], nd[NL], pbase[NL];
@@ -137,7 +165,7 @@ SZH_HD void szh_pencil_run(const szh_qargs<T> &a, int I, int J)
         bk[l] = 0; kk[l] = 0; bz[l] = szh_blk_size(G.g2, 0);
         ca[l] = cb[l] = cc[l] = cd[l] = 0; na[l] = nb_[l] = nc[l] = nd[l] = 0; pbase[l] = 0;
         lor[l] = nlor[l] = nnlor[l] = true;
-        if (inb[l]) {
+        if (HASREG && inb[l]) {
             const int64_t b = blkrow[l];
             lor[l] = a.blk_lor[b] != 0;
             if (nbz > 1) nlor[l] = a.blk_lor[b + 1] != 0;
@@ -152,25 +180,108 @@ SZH_HD void szh_pencil_run(const szh_qargs<T> &a, int I, int J)
         }
     }
 
-    // ---- software-pipelined inputs: values / codes and halo granules for SZH_U steps ----
-    T xcur[SZH_U][NL], xnext[SZH_U][NL];
-    uint16_t qcur[SZH_U][NL], qnext[SZH_U][NL];
-    szh_u64 hcur[SZH_U][NW][NL], hnext[SZH_U][NW][NL];
+    // ---- per-trip inputs.  Nothing stays in flight across the loop back-edge (hipcc guards rotated in-flight registers
+    //      with s_waitcnt vmcnt(0) = one memory round trip per STEP); a trip requests everything it needs at its top.
+    //      Memory shape: every lane moves its OWN row's next SZH_U values as 16-byte vectors (64 B contiguous per lane
+    //      instead of sixteen 4-byte requests); the 2-byte codes go through a small LDS ring and are moved between ring
+    //      and HBM as aligned 16-byte row segments (a per-step 2-byte store per lane was 134 M separate L2 write requests).
+    constexpr int VPT = 16 / (int)sizeof(T);      // values per 16-byte vector
+    constexpr int NVEC = SZH_U / VPT;             // vectors per lane per trip
+    T xr[SZH_U][NL];
+    T ov[SZH_U][NL];
+    szh_u64 hr[SZH_U][NW][NL];
+    const bool vec_codes = (r2 % 8) == 0;         // rows of the u16 code array are 16-byte aligned
 
-    auto fetch = [&](int tbase, T (&xv)[SZH_U][NL], uint16_t (&qv)[SZH_U][NL], szh_u64 (&hv)[SZH_U][NW][NL]) {
-SZH_UNROLL
-        for (int s = 0; s < SZH_U; ++s) {
-            SZH_FORL {
-                const int k = tbase + s - skew[l];
-                const bool act = inb[l] && k >= 0 && k < r2;
-                if (DEC) { qv[s][l] = act ? a.codes[rowoff[l] + k] : (uint16_t)1; xv[s][l] = 0; }
-                else { xv[s][l] = act ? a.data[rowoff[l] + k] : (T)0; qv[s][l] = 0; }
-                const int kh = tbase + s - hskew[l];
-                const bool hact = hrole[l] && kh >= 0 && kh < r2;
-SZH_UNROLL
-                for (int w = 0; w < NW; ++w)
-                    hv[s][w][l] = hact ? B::ld_gran(hbuf[l] + (hoff[l] + kh) * NW + w) : 0;
+    // this lane's row, steps t0..t0+SZH_U-1  <->  k = t0 - skew .. t0 - skew + SZH_U - 1
+    auto load_x = [&](int t0) {
+        SZH_FORL {
+            const int k0 = t0 - skew[l];
+            if (inb[l] && k0 >= 0 && k0 + SZH_U <= r2) {
+                SZH_UNROLL
+                for (int v = 0; v < NVEC; ++v) {
+                    T tmp[VPT];
+                    B::ld16(a.data + rowoff[l] + k0 + v * VPT, tmp);
+                    SZH_UNROLL
+                    for (int e = 0; e < VPT; ++e) xr[v * VPT + e][l] = tmp[e];
+                }
+            } else {
+                SZH_UNROLL
+                for (int s = 0; s < SZH_U; ++s) {
+                    const int k = k0 + s;
+                    xr[s][l] = (inb[l] && (unsigned)k < (unsigned)r2) ? a.data[rowoff[l] + k] : (T)0;
+                }
             }
+        }
+    };
+    auto store_out = [&](int t0) {
+        SZH_FORL {
+            const int k0 = t0 - skew[l];
+            if (inb[l] && k0 >= 0 && k0 + SZH_U <= r2) {
+                SZH_UNROLL
+                for (int v = 0; v < NVEC; ++v) {
+                    T tmp[VPT];
+                    SZH_UNROLL
+                    for (int e = 0; e < VPT; ++e) tmp[e] = ov[v * VPT + e][l];
+                    B::st16(a.out + rowoff[l] + k0 + v * VPT, tmp);
+                }
+            } else {
+                SZH_UNROLL
+                for (int s = 0; s < SZH_U; ++s) {
+                    const int k = k0 + s;
+                    if (inb[l] && (unsigned)k < (unsigned)r2) a.out[rowoff[l] + k] = ov[s][l];
+                }
+            }
+        }
+    };
+    // code ring <-> code array, columns [c0, c0+16) of all 64 rows of the pencil (c0 multiple of 16)
+    auto row_off = [&](int row, int64_t &off) -> bool {
+        const int i = 8 * I + (row >> 3), j = 8 * J + (row & 7);
+        off = (int64_t)i * G.d0 + (int64_t)j * G.d1;
+        return i < r0 && j < r1;
+    };
+    auto move_codes = [&](int c0) {
+        if (vec_codes && c0 + 16 <= r2) {
+            SZH_UNROLL
+            for (int q = 0; q < 2; ++q) {
+                SZH_FORL {
+                    const int lane = B::lane(l);
+                    const int row = (lane >> 1) + 32 * q, cb = c0 + 8 * (lane & 1);
+                    int64_t off;
+                    if (row_off(row, off)) {
+                        uint16_t tmp[8];
+                        if (DEC) {
+                            B::ld16(a.codes + off + cb, tmp);
+                            SZH_UNROLL
+                            for (int e = 0; e < 8; ++e) cring[((cb + e) % SZH_XC) * 64 + row] = tmp[e];
+                        } else {
+                            SZH_UNROLL
+                            for (int e = 0; e < 8; ++e) tmp[e] = cring[((cb + e) % SZH_XC) * 64 + row];
+                            B::st16(a.codes + off + cb, tmp);
+                        }
+                    }
+                }
+            }
+        } else {
+            for (int q = 0; q < 16; ++q) {
+                SZH_FORL {
+                    const int lane = B::lane(l);
+                    const int row = q * 4 + (lane >> 4), col = c0 + (lane & 15);
+                    int64_t off;
+                    if (row_off(row, off) && col < r2) {
+                        if (DEC) cring[(col % SZH_XC) * 64 + row] = a.codes[off + col];
+                        else a.codes[off + col] = cring[(col % SZH_XC) * 64 + row];
+                    }
+                }
+            }
+        }
+    };
+
+    auto load_halo = [&](int t, szh_u64 (&hv)[NW][NL]) {
+        SZH_FORL {
+            const int kh = t - hskew[l];
+            const bool hact = hrole[l] && (unsigned)kh < (unsigned)r2;
+            SZH_UNROLL
+            for (int w = 0; w < NW; ++w) hv[w][l] = hact ? B::ld_gran(hbuf[l] + (hoff[l] + kh) * NW + w) : 0;
         }
     };
 
@@ -179,46 +290,81 @@ SZH_UNROLL
     SZH_FORL { cur[l] = 0; A1[l] = 0; B1[l] = 0; C1[l] = 0; }
 
     const int tsteps = r2 + 14;
-    fetch(0, xcur, qcur, hcur);
+    int flushed = 0, filled = 0;   // code-ring columns already written back (compress) / already brought in (decompress)
+    szh_u64 tr_start = 0, tr_gate = 0, tr_first = 0, tr_spins = 0, tr_naps = 0;
+    if (a.trace) tr_start = B::clock();
+    // ---- start gate: sleep (one lane polls ONE word per producer, long naps) until the producers are under way.
+    // Thousands of queued wavefronts polling granules instead would flood the fabric and slow every hand-off.
+    {
+        const int need = a.dbg ? 0 : (a.gate_steps < tsteps ? a.gate_steps : tsteps);
+        const szh_u64 want = ((szh_u64)a.epoch << 32) | (unsigned)need;
+        unsigned naps = 0;
+        for (;;) {
+            bool ok[NL];
+            if (a.dbg) break;
+            SZH_FORL {
+                ok[l] = true;
+                const int lane = B::lane(l);
+                if (lane == 0 && J > 0) { const szh_u64 p = B::ld_gran(a.progress + ((int64_t)I * a.nJ + (J - 1))); ok[l] = (p >> 32) == a.epoch && p >= want; }
+                if (lane == 1 && I > 0) { const szh_u64 p = B::ld_gran(a.progress + ((int64_t)(I - 1) * a.nJ + J)); ok[l] = (p >> 32) == a.epoch && p >= want; }
+            }
+            if (B::all(ok)) break;
+            if (++naps > (1u << 18) || B::ld_flag(a.err) != 0) break; // bounded; the granule waits below still guard correctness
+            B::nap();
+        }
+        tr_naps = naps;
+    }
+    if (a.trace) tr_gate = B::clock();
     for (int t0 = 0; t0 < tsteps; t0 += SZH_U) {
-        if (t0 + SZH_U < tsteps) fetch(t0 + SZH_U, xnext, qnext, hnext);
-SZH_UNROLL
+        SZH_UNROLL
+        for (int s = 0; s < SZH_U; ++s) load_halo(t0 + s, hr[s]);
+        if (DEC) { while (filled < t0 + SZH_U && filled < r2) { move_codes(filled); filled += 16; } } // ring holds columns < filled
+        else load_x(t0);
+        SZH_UNROLL
         for (int s = 0; s < SZH_U; ++s) {
             const int t = t0 + s;
-            // -- halo for this step: wait until the producer's granules carry this launch's epoch --
+            // -- halo for this step.  Fast path: the granule requested at the top of the trip already carries this launch's epoch.
+            //    Slow path (cold): poll with fresh loads into a private copy; it never touches the ring registers.
             T hval[NL];
             {
-                bool ok[NL];
-                unsigned spins = 0;
-                for (;;) {
-                    SZH_FORL {
-                        const int kh = t - hskew[l];
-                        const bool hact = hrole[l] && kh >= 0 && kh < r2;
-                        bool v = true;
-SZH_UNROLL
-                        for (int w = 0; w < NW; ++w) v = v && ((unsigned)(hcur[s][w][l] >> 32) == a.epoch);
-                        ok[l] = !hact || v;
-                    }
-                    if (B::all(ok)) break;
-                    // bounded wait: a lost hand-off must end the launch, not hang the GPU
-                    if (++spins > (1u << 20)) { SZH_FORL { if (!ok[l]) B::st_flag(a.err, 1u); } break; }
-                    if ((spins & 255u) == 0 && B::ld_flag(a.err) != 0) break; // another wavefront already gave up
-                    B::backoff();
-                    SZH_FORL {
-                        if (!ok[l]) {
-                            const int kh = t - hskew[l];
-SZH_UNROLL
-                            for (int w = 0; w < NW; ++w) hcur[s][w][l] = B::ld_gran(hbuf[l] + (hoff[l] + kh) * NW + w);
-                        }
-                    }
-                }
+                szh_u64 g[NW][NL];
+                bool ok[NL], hact[NL];
                 SZH_FORL {
                     const int kh = t - hskew[l];
-                    const bool hact = hrole[l] && kh >= 0 && kh < r2;
+                    hact[l] = hrole[l] && (unsigned)kh < (unsigned)r2;
+                    bool v = true;
+                    SZH_UNROLL
+                    for (int w = 0; w < NW; ++w) { g[w][l] = hr[s][w][l]; v = v && ((unsigned)(g[w][l] >> 32) == a.epoch); }
+                    ok[l] = !hact[l] || v;
+                }
+                if (!B::all(ok) && !a.dbg) {
+                    unsigned spins = 0;
+                    for (;;) {
+                        // bounded wait: a lost hand-off must end the launch, not hang the GPU
+                        if (++spins > (1u << 20)) { SZH_FORL { if (!ok[l]) B::st_flag(a.err, 1u); } break; }
+                        if ((spins & 255u) == 0 && B::ld_flag(a.err) != 0) break; // another wavefront already gave up
+                        B::backoff(a.backoff);
+                        SZH_FORL {
+                            if (!ok[l]) {
+                                const int kh = t - hskew[l];
+                                bool v = true;
+                                SZH_UNROLL
+                                for (int w = 0; w < NW; ++w) {
+                                    g[w][l] = B::ld_gran(hbuf[l] + (hoff[l] + kh) * NW + w);
+                                    v = v && ((unsigned)(g[w][l] >> 32) == a.epoch);
+                                }
+                                ok[l] = v;
+                            }
+                        }
+                        if (B::all(ok)) break;
+                    }
+                    tr_spins += spins;
+                }
+                SZH_FORL {
                     szh_u64 w2[NW];
-SZH_UNROLL
-                    for (int w = 0; w < NW; ++w) w2[w] = hcur[s][w][l];
-                    hval[l] = hact ? szh_gran<T>::unpack(w2) : (T)0;
+                    SZH_UNROLL
+                    for (int w = 0; w < NW; ++w) w2[w] = g[w][l];
+                    hval[l] = hact[l] ? szh_gran<T>::unpack(w2) : (T)0;
                 }
             }
             // -- neighbours through cross-lane moves (values of the previous step) --
@@ -231,63 +377,66 @@ SZH_UNROLL
 
             SZH_FORL {
                 const int k = t - skew[l];
-                const bool act = inb[l] && k >= 0 && k < r2;
+                const bool act = inb[l] && (unsigned)k < (unsigned)r2;
                 const int lane = B::lane(l);
                 const T nA = jl[l] > 0 ? shA[l] : hval[l];
                 const T nB = il[l] > 0 ? shB[l] : (lane == 0 ? h63 : hval[l]);
                 const T nC = il[l] > 0 ? shCi[l] : (jl[l] > 0 ? shCj[l] : h62);
                 // [-1] + [-s1] + [-s0] - [-s1-1] - [-s0-1] - [-s0-s1] + [-s0-s1-1], left to right
                 const T pred = cur[l] + nA + nB - A1[l] - B1[l] - nC + C1[l];
-                const T fkk = (T)kk[l];
-                const T predr = pbase[l] + cc[l] * fkk + cd[l];
+                T predr = 0;
+                if (HASREG) predr = pbase[l] + cc[l] * (T)kk[l] + cd[l];
+                const bool is_lor = HASREG ? lor[l] : true;
                 T nv;
                 if (!DEC) {
-                    const T x = xcur[s][l];
-                    T rcl, rcr;
-                    int cl = szh_quant_point<T>(x, pred, eb, recip, cap_lor, radius, &rcl);
-                    const int cr = szh_quant_point<T>(x, predr, eb, recip, cap_reg, radius, &rcr);
-                    if (use_mean) {
-                        if (cl != 0 && cl <= radius) cl -= 1;               // sz_float.c:6944
-                        if (szh_abs(x - mean) <= eb) { cl = radius; rcl = mean; } // sz_float.c:6929
+                    const T x = xr[s][l];
+                    T rcl;
+                    int code = szh_quant_sel<T>(x, pred, eb, recip, cap_lor, radius, &rcl);
+                    if (USEMEAN) {
+                        if (code != 0 && code <= radius) code -= 1;                 // sz_float.c:6944
+                        if (szh_abs(x - mean) <= eb) { code = radius; rcl = mean; } // sz_float.c:6929
                     }
-                    const int code = lor[l] ? cl : cr;
-                    nv = lor[l] ? rcl : rcr;
-                    if (act) a.codes[rowoff[l] + k] = (uint16_t)code;
+                    nv = rcl;
+                    if (HASREG) {
+                        T rcr;
+                        const int cr = szh_quant_sel<T>(x, predr, eb, recip, cap_reg, radius, &rcr);
+                        code = is_lor ? code : cr;
+                        nv = is_lor ? rcl : rcr;
+                    }
+                    if (act) cring[((unsigned)k % SZH_XC) * 64 + B::lane(l)] = (uint16_t)code;
                 } else {
-                    int c = qcur[s][l];
-                    const T p = lor[l] ? pred : predr;
+                    const int c0 = act ? (int)cring[((unsigned)k % SZH_XC) * 64 + B::lane(l)] : radius;
+                    int c = c0;
+                    const T p = is_lor ? pred : predr;
                     bool is_mean = false;
-                    if (lor[l] && use_mean) {
-                        is_mean = (c == radius);
-                        if (c != 0 && c < radius) c += 1;                   // szd_float.c:3784
+                    if (USEMEAN) {
+                        is_mean = is_lor && (c == radius);
+                        if (is_lor && c != 0 && c < radius) c += 1;                 // szd_float.c:3784
                     }
                     nv = p + (T)(2 * (c - radius)) * eb;
-                    if (is_mean) nv = mean;
-                    if (act) {
-                        if (qcur[s][l] == 0) nv = a.out[rowoff[l] + k];      // pre-scattered unpredictable value
-                        else a.out[rowoff[l] + k] = nv;
-                    }
+                    if (USEMEAN && is_mean) nv = mean;
+                    if (act && c0 == 0) nv = a.out[rowoff[l] + k];                  // pre-scattered unpredictable value
+                    ov[s][l] = nv;
                 }
                 // publish faces for the pencils to the right / below
-                if (act) {
+                {
                     szh_u64 w2[NW];
                     szh_gran<T>::pack(nv, a.epoch, w2);
-                    if (pubJ && jl[l] == 7) {
-SZH_UNROLL
+                    if (act && pJ[l]) {
+                        SZH_UNROLL
                         for (int w = 0; w < NW; ++w) B::st_gran(a.faceJ + (pubJoff[l] + k) * NW + w, w2[w]);
                     }
-                    if (pubI && il[l] == 7) {
-SZH_UNROLL
+                    if (act && pI[l]) {
+                        SZH_UNROLL
                         for (int w = 0; w < NW; ++w) B::st_gran(a.faceI + (pubIoff[l] + k) * NW + w, w2[w]);
                     }
                 }
-                // roll the neighbour state; lanes outside the array or the k range carry zeros
-                cur[l] = act ? nv : (T)0;
-                A1[l] = act ? nA : (T)0;
-                B1[l] = act ? nB : (T)0;
-                C1[l] = act ? nC : (T)0;
+                // roll the neighbour state.  Lanes outside the k range see zero inputs and zero neighbours, so
+                // they produce zeros by themselves; only the mean shortcut and stale pre-scattered values need masking.
+                cur[l] = (USEMEAN || DEC) ? (act ? nv : (T)0) : nv;
+                A1[l] = nA; B1[l] = nB; C1[l] = nC;
                 // advance along dim2
-                if (act) {
+                if (HASREG && act) {
                     kk[l] += 1;
                     if (kk[l] == bz[l]) {
                         bk[l] += 1; kk[l] = 0;
@@ -307,15 +456,62 @@ SZH_UNROLL
                 }
             }
         }
-        // rotate the software pipeline
-SZH_UNROLL
-        for (int s = 0; s < SZH_U; ++s) {
-            SZH_FORL {
-                xcur[s][l] = xnext[s][l]; qcur[s][l] = qnext[s][l];
-SZH_UNROLL
-                for (int w = 0; w < NW; ++w) hcur[s][w][l] = hnext[s][w][l];
+        if (DEC) store_out(t0);
+        else {
+            // after this trip every lane is past column t0 + SZH_U - 15: flush the 16-column groups that are complete
+            while (flushed + 16 <= t0 + SZH_U - 14 && flushed < r2) { move_codes(flushed); flushed += 16; }
+        }
+        if (a.trace && t0 == 0) tr_first = B::clock();
+        // tell the consumers how far this pencil has got (one word, one lane)
+        SZH_FORL { if (B::lane(l) == 0) B::st_gran(a.progress + ((int64_t)I * a.nJ + J), ((szh_u64)a.epoch << 32) | (unsigned)(t0 + SZH_U)); }
+    }
+    if (!DEC) { for (; flushed < r2; flushed += 16) move_codes(flushed); }
+    if (a.trace) {
+        const szh_u64 tr_end = B::clock();
+        SZH_FORL {
+            if (B::lane(l) == 0) {
+                szh_u64 *tp = a.trace + ((int64_t)I * a.nJ + J) * 8;
+                tp[0] = tr_start; tp[1] = tr_gate; tp[2] = tr_first; tp[3] = tr_end; tp[4] = tr_spins; tp[5] = tr_naps; tp[6] = B::where(); tp[7] = 0;
             }
         }
+    }
+}
+
+// does pencil (I,J) touch a regression block?  (collective over the wavefront's lanes)
+template <class T, class B>
+SZH_HD bool szh_pencil_has_reg(const szh_qargs<T> &a, int I, int J)
+{
+    constexpr int NL = B::NL;
+    const szh_geom3 &G = a.G;
+    const int i0 = 8 * I, i1 = (8 * I + 7 < G.g0.count ? 8 * I + 7 : G.g0.count - 1);
+    const int j0 = 8 * J, j1 = (8 * J + 7 < G.g1.count ? 8 * J + 7 : G.g1.count - 1);
+    const int b0lo = szh_blk_of(G.g0, i0), b0hi = szh_blk_of(G.g0, i1);
+    const int b1lo = szh_blk_of(G.g1, j0), b1hi = szh_blk_of(G.g1, j1);
+    const int nbz = G.g2.num;
+    const int ncol = (b0hi - b0lo + 1) * (b1hi - b1lo + 1);
+    bool none[NL];
+    SZH_FORL {
+        none[l] = true;
+        for (int e = B::lane(l); e < ncol * nbz; e += 64) {
+            const int c = e / nbz, z = e - c * nbz;
+            const int b0 = b0lo + c / (b1hi - b1lo + 1), b1 = b1lo + c % (b1hi - b1lo + 1);
+            if (a.blk_lor[((int64_t)b0 * G.g1.num + b1) * nbz + z] == 0) none[l] = false;
+        }
+    }
+    return !B::all(none);
+}
+
+// cring: SZH_XC*64 uint16_t of LDS (HIP) / plain memory (simulator) private to this wavefront
+template <class T, bool DEC, class B>
+SZH_HD void szh_pencil_run(const szh_qargs<T> &a, int I, int J, uint16_t *cring)
+{
+    const bool hasreg = szh_pencil_has_reg<T, B>(a, I, J);
+    if (a.use_mean) {
+        if (hasreg) szh_pencil_body<T, DEC, true, true, B>(a, I, J, cring);
+        else szh_pencil_body<T, DEC, false, true, B>(a, I, J, cring);
+    } else {
+        if (hasreg) szh_pencil_body<T, DEC, true, false, B>(a, I, J, cring);
+        else szh_pencil_body<T, DEC, false, false, B>(a, I, J, cring);
     }
 }
 

@@ -32,7 +32,7 @@ struct szhip_ctx {
     char err[512] = {0};
     unsigned epoch = 0;
     // workspaces (grow-only)
-    DevBuf in, out, codes_nat, codes_blk, coef, blk_lor, faceI, faceJ, order, small, hist, col_zeros, col_zeros64,
+    DevBuf in, out, codes_nat, codes_blk, coef, blk_lor, faceI, faceJ, progress, trace, order, small, hist, col_zeros, col_zeros64,
         col_off, partial, samples, unpred, stream_buf, chunk_bits, chunk_off, code_tab, len_tab, dec_tab,
         starts, ends, counts, offs, dirty;
     void *pinned = nullptr; size_t pinned_cap = 0;
@@ -82,6 +82,13 @@ int ensure_pinned(szhip_ctx *ctx, size_t bytes)
 
 #define TRY(x) do { int rc_ = (x); if (rc_ != SZHIP_OK) return rc_; } while (0)
 
+// launch tuning knobs (development): environment overrides of the wavefront kernel's wait parameters
+int tune_int(const char *name, int def)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : def;
+}
+
 // device-wide exclusive scan of u64 in[0..n) -> out; total to *total_dev (device u64)
 int scan_u64(szhip_ctx *ctx, const u64 *in, int64_t n, u64 *out, u64 *total_dev)
 {
@@ -123,6 +130,8 @@ int prepare_pencil(szhip_ctx *ctx, const szh_geom3 &G, int nw, int *nI_out, int 
     const size_t ng = (size_t)nI * nJ * 8 * (size_t)G.g2.count * nw * sizeof(u64);
     TRY(ensure(ctx, ctx->faceI, ng, true));
     TRY(ensure(ctx, ctx->faceJ, ng, true));
+    TRY(ensure(ctx, ctx->progress, (size_t)nI * nJ * sizeof(u64), true));
+    if (tune_int("SZ_HIP_TRACE", 0)) TRY(ensure(ctx, ctx->trace, (size_t)nI * nJ * 8 * sizeof(u64), true));
     if (ctx->order_nI != nI || ctx->order_nJ != nJ) {
         std::vector<unsigned> ord((size_t)nI * nJ);
         szh_fill_pencil_order(nI, nJ, ord.data());
@@ -342,6 +351,9 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         a.faceI = (szh_u64 *)ctx->faceI.p; a.faceJ = (szh_u64 *)ctx->faceJ.p; a.epoch = ++ctx->epoch;
         a.nI = nI; a.nJ = nJ; a.order = (const unsigned *)ctx->order.p;
         a.ticket = (unsigned *)(sm + SM_TICKET); a.err = (unsigned *)(sm + SM_ERR);
+        a.progress = (szh_u64 *)ctx->progress.p; a.gate_steps = tune_int("SZ_HIP_GATE_STEPS", 16); a.backoff = tune_int("SZ_HIP_BACKOFF", 4);
+        a.trace = tune_int("SZ_HIP_TRACE", 0) ? (szh_u64 *)ctx->trace.p : nullptr;
+        a.dbg = tune_int("SZ_HIP_DBG", 0);
         HIPCHK(hipEventRecord(ctx->ev[2], st));
         hipLaunchKernelGGL((k_pencil<T, false>), dim3((unsigned)(nI * nJ)), dim3(64), 0, st, a);
         HIPCHK(hipGetLastError());
@@ -680,6 +692,9 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
         a.faceI = (szh_u64 *)ctx->faceI.p; a.faceJ = (szh_u64 *)ctx->faceJ.p; a.epoch = ++ctx->epoch;
         a.nI = nI; a.nJ = nJ; a.order = (const unsigned *)ctx->order.p;
         a.ticket = (unsigned *)(sm + SM_TICKET); a.err = (unsigned *)(sm + SM_ERR);
+        a.progress = (szh_u64 *)ctx->progress.p; a.gate_steps = tune_int("SZ_HIP_GATE_STEPS", 16); a.backoff = tune_int("SZ_HIP_BACKOFF", 4);
+        a.trace = tune_int("SZ_HIP_TRACE", 0) ? (szh_u64 *)ctx->trace.p : nullptr;
+        a.dbg = tune_int("SZ_HIP_DBG", 0);
         HIPCHK(hipEventRecord(ctx->ev[2], st));
         hipLaunchKernelGGL((k_pencil<T, true>), dim3((unsigned)(nI * nJ)), dim3(64), 0, st, a);
         HIPCHK(hipGetLastError());
@@ -729,7 +744,7 @@ void szhip_destroy(szhip_ctx *ctx)
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->in, &ctx->out, &ctx->codes_nat, &ctx->codes_blk, &ctx->coef, &ctx->blk_lor, &ctx->faceI, &ctx->faceJ,
+    DevBuf *bufs[] = {&ctx->in, &ctx->out, &ctx->codes_nat, &ctx->codes_blk, &ctx->coef, &ctx->blk_lor, &ctx->faceI, &ctx->faceJ, &ctx->progress, &ctx->trace,
                       &ctx->order, &ctx->small, &ctx->hist, &ctx->col_zeros, &ctx->col_zeros64, &ctx->col_off, &ctx->partial,
                       &ctx->samples, &ctx->unpred, &ctx->stream_buf, &ctx->chunk_bits, &ctx->chunk_off, &ctx->code_tab,
                       &ctx->len_tab, &ctx->dec_tab, &ctx->starts, &ctx->ends, &ctx->counts, &ctx->offs, &ctx->dirty};
@@ -790,7 +805,7 @@ int szhip_debug_fetch(szhip_ctx *ctx, int which, void *dst, size_t bytes)
     if (!ctx || !dst) return SZHIP_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
     DevBuf *bufs[] = {&ctx->coef, &ctx->blk_lor, &ctx->codes_nat, &ctx->codes_blk, &ctx->hist, &ctx->col_zeros, &ctx->col_off,
-                      &ctx->unpred, &ctx->stream_buf};
+                      &ctx->unpred, &ctx->stream_buf, &ctx->trace};
     if (which < 0 || which >= (int)(sizeof(bufs) / sizeof(bufs[0]))) return SZHIP_ERR_ARG;
     if (!bufs[which]->p || bufs[which]->cap < bytes) return SZHIP_ERR_ARG;
     HIPCHK(hipStreamSynchronize(ctx->stream));

@@ -92,7 +92,26 @@ struct GpuBackend {
     __device__ static void st_gran(szh_u64 *p, szh_u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     __device__ static unsigned ld_flag(const unsigned *p) { return __hip_atomic_load(const_cast<unsigned *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     __device__ static void st_flag(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    __device__ static void backoff() { __builtin_amdgcn_s_sleep(1); }
+    __device__ static void backoff(int n) { for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(2); }
+    template <class E, int N> __device__ static void ld16(const E *p, E (&v)[N])
+    {
+        static_assert(sizeof(E) * N == 16, "16-byte vector");
+        const uint4 w = *reinterpret_cast<const uint4 *>(p);
+        __builtin_memcpy(v, &w, 16);
+    }
+    template <class E, int N> __device__ static void st16(E *p, const E (&v)[N])
+    {
+        static_assert(sizeof(E) * N == 16, "16-byte vector");
+        uint4 w; __builtin_memcpy(&w, v, 16);
+        *reinterpret_cast<uint4 *>(p) = w;
+    }
+    __device__ static szh_u64 clock() { return wall_clock64(); } // 100 MHz, chip-wide
+#ifdef SZH_HIPSIM
+    __device__ static szh_u64 where() { return 0; }
+#else
+    __device__ static szh_u64 where() { unsigned x = 0; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x)); return x; }
+#endif
+    __device__ static void nap() { __builtin_amdgcn_s_sleep(40); } // ~1 us
 };
 
 template <class T, bool DEC>
@@ -102,7 +121,8 @@ __global__ __launch_bounds__(64) void k_pencil(szh_qargs<T> a)
     if (threadIdx.x == 0) tk = atomicAdd(a.ticket, 1u);
     tk = __shfl(tk, 0, 64);
     const unsigned ij = a.order[tk];
-    szh_pencil_run<T, DEC, GpuBackend>(a, (int)(ij >> 16), (int)(ij & 0xffffu));
+    __shared__ uint16_t cring[SZH_XC * 64];
+    szh_pencil_run<T, DEC, GpuBackend>(a, (int)(ij >> 16), (int)(ij & 0xffffu), cring);
 }
 
 // ------------------------------------------------------------------ per-block stages (fit / select)

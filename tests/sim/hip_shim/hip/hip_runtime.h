@@ -78,6 +78,7 @@ inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 inline long long __double_as_longlong(double d) { long long u; memcpy(&u, &d, 8); return u; }
 inline void __builtin_amdgcn_s_sleep(int) {}
+inline unsigned long long wall_clock64() { return 0; }
 inline int min(int a, int b) { return a < b ? a : b; }
 
 template <class T> inline T atomicAdd(T *p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }

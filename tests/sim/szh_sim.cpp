@@ -25,7 +25,12 @@ struct SimBackend {
     static void st_gran(szh_u64 *p, szh_u64 v) { *p = v; }
     static unsigned ld_flag(const unsigned *p) { return *p; }
     static void st_flag(unsigned *p, unsigned v) { *p = v; }
-    static void backoff() {}
+    static void backoff(int) {}
+    static void nap() {}
+    template <class E, int N> static void ld16(const E *p, E (&v)[N]) { memcpy(v, p, 16); }
+    template <class E, int N> static void st16(E *p, const E (&v)[N]) { memcpy(p, v, 16); }
+    static szh_u64 clock() { return 0; }
+    static szh_u64 where() { return 0; }
 };
 
 template <class T, bool DEC>
@@ -39,8 +44,11 @@ static int run_all(szh_qargs<T> a)
     std::vector<unsigned> order((size_t)a.nI * a.nJ);
     szh_fill_pencil_order(a.nI, a.nJ, order.data());
     unsigned err = 0; a.err = &err;
+    std::vector<szh_u64> prog((size_t)a.nI * a.nJ, 0);
+    a.progress = prog.data(); a.gate_steps = 16; a.backoff = 1;
+    std::vector<uint16_t> ring(SZH_XC * 64, 0xDEAD);
     for (size_t tk = 0; tk < order.size(); ++tk)
-        szh_pencil_run<T, DEC, SimBackend>(a, (int)(order[tk] >> 16), (int)(order[tk] & 0xffff));
+        szh_pencil_run<T, DEC, SimBackend>(a, (int)(order[tk] >> 16), (int)(order[tk] & 0xffff), ring.data());
     return (int)err;
 }
 

@@ -1,0 +1,33 @@
+"""development: per-pencil timeline of the wavefront kernel (SZ_HIP_TRACE=1)."""
+import os, sys, json
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["SZ_HIP_TRACE"] = "1"
+import sz_amd
+from sz_amd.fields import s_field
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+d = s_field(n, n, n)
+ctx = sz_amd.HipContext(0)
+meta = sz_amd.make_meta(np.float32, abs_bound=1e-4, vmin=float(d.min()), vmax=float(d.max()))
+for it in range(2):
+    b, sz, st = ctx.compress(d.ctypes.data, False, d.shape, np.float32, 1e-4, meta)
+nI = nJ = (n + 7) // 8
+tr = ctx.debug_fetch(9, nI * nJ * 8, np.uint64).reshape(nI, nJ, 8).astype(np.int64)
+t0 = tr[..., 0].min()
+us = lambda x: (x - t0) / 100.0
+print("ms_quant", st.ms_quant, "size", sz)
+np.save(os.path.join(ROOT, "gpurun_out", f"trace_{n}.npy"), tr)
+for (I, J) in [(0, 0), (0, 1), (1, 0), (1, 1), (0, 2), (2, 2), (5, 5), (nI // 2, nJ // 2), (nI - 1, nJ - 1)]:
+    r = tr[I, J]
+    print(f"pencil ({I},{J}) xcc={r[6]} start={us(r[0]):.1f} gate={us(r[1]):.1f} first_trip={us(r[2]):.1f} end={us(r[3]):.1f} spins={r[4]} naps={r[5]}")
+dur = (tr[..., 3] - tr[..., 1]) / 100.0
+print("pencil active duration us: min %.1f median %.1f max %.1f" % (dur.min(), np.median(dur), dur.max()))
+print("starts: min %.1f max %.1f ; ends: min %.1f max %.1f" % (us(tr[..., 0].min()), us(tr[..., 0].max()), us(tr[..., 3].min()), us(tr[..., 3].max())))
+# lag between a pencil's gate-pass and its J-predecessor's gate-pass
+lagJ = (tr[:, 1:, 1] - tr[:, :-1, 1]) / 100.0
+lagI = (tr[1:, :, 1] - tr[:-1, :, 1]) / 100.0
+print("gate lag vs J-pred us: median %.1f ; vs I-pred: median %.1f" % (np.median(lagJ), np.median(lagI)))
+endlagJ = (tr[:, 1:, 3] - tr[:, :-1, 3]) / 100.0
+print("end lag vs J-pred us: median %.1f" % np.median(endlagJ))
+print("spins total", tr[..., 4].sum(), "median per pencil", np.median(tr[..., 4]))
