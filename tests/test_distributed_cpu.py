@@ -1,0 +1,58 @@
+"""world_size-2 `gloo` test of the slab path's exchange steps (sz_amd/slab.py): the {min,max} all-reduce for the
+range-based bound modes and the single all-gather of variable-length sub-streams.  No GPU; the per-slab streams are
+produced by the oracle (the checker), which is exactly what each rank's GPU would produce."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_lib as O
+    from sz_amd import slab
+    from sz_amd.fields import s_field
+    dims = (40, 24, 32)
+    bounds = slab.slab_bounds(dims[0], world)
+    z0, z1 = bounds[rank]
+    mine = s_field(z1 - z0, dims[1], dims[2], np.float64, z0=z0)
+    lo, hi = slab.global_minmax(float(mine.min()), float(mine.max()))
+    eb = 1e-3 * (hi - lo)  # REL 1e-3 with the GLOBAL range, passed to every slab as an absolute bound
+    stream, _ = O.compress(mine, O.ABS, eb)
+    t = torch.frombuffer(bytearray(stream), dtype=torch.uint8)
+    parts, sizes = slab.allgather_streams(t)
+    blob = slab.pack_container(np.float64, dims, bounds, [bytes(p.numpy().tobytes()) for p in parts])
+    if rank == 0:
+        ret["blob"] = blob; ret["range"] = (lo, hi); ret["sizes"] = sizes
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.slow
+def test_slab_exchange_world2(oracle):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, 29517, ret), nprocs=world, join=True)
+    from sz_amd import slab
+    from sz_amd.fields import s_field
+    whole = s_field(40, 24, 32, np.float64)
+    lo, hi = ret["range"]
+    assert lo == float(whole.min()) and hi == float(whole.max())
+    dt, dims, bounds, streams = slab.unpack_container(ret["blob"])
+    assert dims == (40, 24, 32) and [len(s) for s in streams] == list(ret["sizes"])
+    eb = 1e-3 * (hi - lo)
+    rec = np.concatenate([oracle.decompress(bytes(s), (z1 - z0, 24, 32), np.float64) for (z0, z1), s in zip(bounds, streams)])
+    assert float(np.abs(rec - whole).max()) <= eb
+    # each sub-stream is exactly what the reference produces for that slab on its own
+    for (z0, z1), s in zip(bounds, streams):
+        ref, _ = oracle.compress(whole[z0:z1], oracle.ABS, eb)
+        assert bytes(s) == ref

@@ -1,0 +1,190 @@
+"""CPU tests of the product's host C (sz_amd/csrc/szhost.c, sz_api.c, sz_conf.c) and of the C-ABI surface.
+No compute call reaches a GPU here; the oracle is only the checker."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import sz_amd
+from sz_amd import api
+from sz_amd.fields import m_field, s_field
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L(built):
+    return sz_amd.lib()
+
+
+def test_library_exports_every_declared_symbol(L):
+    """Every function declared in include/szhip.h and include/sz.h must be exported by libszhip.so."""
+    names = set()
+    for hdr in ("szhip.h", "sz.h"):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b((?:szhip_|SZ_)[A-Za-z0-9_]+)\s*\(", text))
+        names |= set(re.findall(r"\b(computeDataLength|computeDimension|filterDimension|convertSZParamsToBytes|convertBytesToSZParams)\s*\(", text))
+    assert len(names) > 25
+    for n in sorted(names):
+        assert hasattr(L, n), f"{n} is declared but not exported"
+    for g in ("confparams_cpr", "confparams_dec", "exe_params", "dataEndianType", "sysEndianType", "versionNumber"):
+        ctypes.c_int.in_dll(L, g)
+
+
+def test_no_cpu_fallback_without_gpu(L):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(sz_amd.SZError):
+        sz_amd.HipContext(0)
+    assert sz_amd.SZ_Init(None) == 0
+    with pytest.raises(sz_amd.SZError):
+        sz_amd.SZ_compress_args(s_field(24, 24, 24), sz_amd.ABS, 1e-4)
+    sz_amd.SZ_Finalize()
+
+
+def test_conf_loader_defaults_and_file(L, tmp_path):
+    assert sz_amd.SZ_Init(None) == 0
+    p = sz_amd.conf_params()  # sz/src/conf.c:99-141
+    assert (p.max_quant_intervals, p.maxRangeRadius, p.quantization_intervals) == (65536, 32768, 0)
+    assert p.sampleDistance == 100 and abs(p.predThreshold - 0.99) < 1e-7
+    assert p.szMode == sz_amd.SZ_BEST_COMPRESSION and p.errorBoundMode == sz_amd.PSNR and p.psnr == 90
+    assert p.withRegression == 1 and p.gzipMode == 3 and p.protectValueRange == 0
+    assert sz_amd.SZ_Init(os.path.join(ROOT, "tests", "golden", "sz_speed.config")) == 0
+    p = sz_amd.conf_params()
+    assert p.szMode == sz_amd.SZ_BEST_SPEED and p.errorBoundMode == sz_amd.ABS and p.absErrBound == 1e-4
+    assert p.relBoundRatio == 1e-3 and p.gzipMode == 3 and p.withRegression == 1
+    bad = tmp_path / "bad.config"
+    bad.write_text("[ENV]\nsol_name = SZ\n[PARAMETER]\nszMode = SZ_FASTEST\nerrorBoundMode = ABS\n")
+    assert sz_amd.SZ_Init(str(bad)) == sz_amd.SZ_NSCS
+    odd = tmp_path / "odd.config"
+    odd.write_text("[ENV]\nsol_name = SZ\n[PARAMETER]\nquantization_intervals = 33\nszMode = SZ_BEST_SPEED\nerrorBoundMode = ABS\n")
+    assert sz_amd.SZ_Init(str(odd)) == sz_amd.SZ_NSCS
+    assert sz_amd.SZ_Init("/nonexistent/sz.config") == sz_amd.SZ_NSCS
+    sz_amd.SZ_Finalize()
+
+
+def _filter_model(r5, r4, r3, r2, r1):
+    """Straight restatement of the reference's filterDimension (sz/src/sz.c:162-282)."""
+    dims = [r1, r2, r3, r4, r5]
+    dim = 0
+    while dim < 5 and dims[dim] != 0:
+        dim += 1
+    c = dims[:]
+    if dim >= 2:
+        for d in range(dim - 1, -1, -1):
+            if dims[d] != 1:
+                continue
+            if d == dim - 1:
+                c[d] = 0
+            else:
+                for k in range(d, 4):
+                    c[k] = c[k + 1]
+                if dim == 5:
+                    c[4] = 0
+    return c
+
+
+def test_filter_dimension(L):
+    L.filterDimension.argtypes = [ctypes.c_size_t] * 5 + [ctypes.POINTER(ctypes.c_size_t)]
+    L.computeDataLength.restype = ctypes.c_size_t
+    L.computeDataLength.argtypes = [ctypes.c_size_t] * 5
+    import itertools
+    for ndim in range(1, 6):
+        for vals in itertools.product([1, 2, 7], repeat=ndim):
+            dims = list(vals) + [0] * (5 - ndim)  # r1..r5
+            out = (ctypes.c_size_t * 5)()
+            L.filterDimension(dims[4], dims[3], dims[2], dims[1], dims[0], out)
+            assert list(out) == _filter_model(dims[4], dims[3], dims[2], dims[1], dims[0]), dims
+    assert L.computeDataLength(0, 0, 4, 5, 6) == 120 and L.computeDataLength(0, 0, 0, 0, 9) == 9
+
+
+def test_meta_bytes_match_reference_header(oracle, c1_data):
+    ref, _ = oracle.compress(c1_data, oracle.ABS, 1e-4)
+    meta = sz_amd.make_meta(np.float32, abs_bound=1e-4, vmin=float(c1_data.min()), vmax=float(c1_data.max()))
+    assert meta == ref[:32]
+    d = s_field(10, 12, 14, np.float64)
+    ref, st = oracle.compress(d, oracle.REL, 0.0, 1e-3, want_stages=True)
+    meta = sz_amd.make_meta(np.float64, err_mode=sz_amd.REL, abs_bound=st["eb"], rel_ratio=1e-3, vmin=float(d.min()), vmax=float(d.max()))
+    assert meta == ref[:40]
+
+
+class _Huff(ctypes.Structure):
+    _fields_ = [("state_num", ctypes.c_int), ("n_nodes", ctypes.c_int), ("code", ctypes.POINTER(ctypes.c_uint64)),
+                ("len", ctypes.POINTER(ctypes.c_uint8)), ("L", ctypes.POINTER(ctypes.c_uint32)), ("R", ctypes.POINTER(ctypes.c_uint32)),
+                ("C", ctypes.POINTER(ctypes.c_uint32)), ("t", ctypes.POINTER(ctypes.c_uint8)), ("total_bits", ctypes.c_uint64)]
+
+
+@pytest.mark.parametrize("case", ["c1", "m32", "single"])
+def test_host_huffman_matches_reference_stream(L, oracle, c1_data, case):
+    """Tree bytes, code lengths and the packed payload produced by the product's host Huffman code must equal the bytes
+    inside the oracle's (reference-identical) stream; the device decode table must walk back to the same symbols."""
+    if case == "c1":
+        data, eb = c1_data, 1e-4
+    elif case == "m32":
+        data, eb = m_field(32), 1e-4
+    else:
+        data, eb = np.linspace(0, 1e-9, 24 * 24 * 24, dtype=np.float32).reshape(24, 24, 24) + np.float32(1.0), 1e-3
+        data[0, 0, 0] = 2.0  # not constant, but every point lands in one quantisation bin or is unpredictable
+    ref, st = oracle.compress(data, oracle.ABS, eb, want_stages=True)
+    codes = st["codes"]
+    hist = np.bincount(codes, minlength=st["intervals"]).astype(np.uint32)
+    L.szhost_huff_build.restype = ctypes.POINTER(_Huff)
+    L.szhost_huff_build.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    L.szhost_huff_tree_size.restype = ctypes.c_size_t
+    L.szhost_huff_tree_size.argtypes = [ctypes.c_void_p]
+    L.szhost_huff_tree_write.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    L.szhost_huff_encode_i32.restype = ctypes.c_size_t
+    L.szhost_huff_encode_i32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    L.szhost_huff_from_bytes.restype = ctypes.POINTER(_Huff)
+    L.szhost_huff_from_bytes.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    L.szhost_huff_decode_table.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    L.szhost_huff_free.argtypes = [ctypes.c_void_p]
+    h = L.szhost_huff_build(2 * st["intervals"], hist.ctypes.data, None, hist.size)
+    assert h
+    assert h.contents.n_nodes == st["node_count"]
+    tb = L.szhost_huff_tree_size(h)
+    assert tb == st["tree_bytes"]
+    tree = ctypes.create_string_buffer(tb)
+    L.szhost_huff_tree_write(h, tree)
+    esz = data.dtype.itemsize
+    off = 4 + 28 + 8 + 4 + esz + 12  # meta | N | block size | eb | intervals, treeBytes, nodeCount
+    assert tree.raw == ref[off:off + tb]
+    lens = np.ctypeslib.as_array(h.contents.len, shape=(2 * st["intervals"],))
+    assert np.array_equal(lens[:st["intervals"]], st["code_len"][:st["intervals"]])
+    payload = np.zeros(st["huff_bytes"] + 16, dtype=np.uint8)
+    c32 = np.ascontiguousarray(codes, dtype=np.int32)
+    n = L.szhost_huff_encode_i32(h, c32.ctypes.data, c32.size, payload.ctypes.data)
+    assert n == st["huff_bytes"] and bytes(payload[:n]) == ref[len(ref) - n:]
+    assert h.contents.total_bits == int(lens[codes].astype(np.uint64).sum())
+    # decode table from the serialised tree (what the GPU decoder walks)
+    h2 = L.szhost_huff_from_bytes(2 * st["intervals"], tree, st["node_count"])
+    assert h2
+    table = np.zeros(2 * st["node_count"], dtype=np.uint32)
+    L.szhost_huff_decode_table(h2, table.ctypes.data)
+    bits = np.unpackbits(payload[:n])
+    out, node, pos = [], 0, 0
+    if st["node_count"] == 1:
+        out = [int(table[0] & 0xffff)] * 50
+    else:
+        while len(out) < 50:
+            nx = int(table[2 * node + int(bits[pos])]); pos += 1
+            if nx & 0x80000000:
+                out.append(nx & 0xffff); node = 0
+            else:
+                node = nx
+    assert out == codes[:50].tolist()
+    L.szhost_huff_free(h); L.szhost_huff_free(h2)
+
+
+def test_slab_container_roundtrip():
+    from sz_amd import slab
+    b = slab.slab_bounds(1030, 8)
+    assert b[0] == (0, 129) and b[-1][1] == 1030 and all(x[1] == y[0] for x, y in zip(b, b[1:]))
+    streams = [os.urandom(10 + 7 * r) for r in range(8)]
+    blob = slab.pack_container(np.float64, (1030, 64, 32), b, streams)
+    dt, dims, bounds, got = slab.unpack_container(blob)
+    assert dt == np.float64 and dims == (1030, 64, 32) and bounds == b and [bytes(g) for g in got] == streams
