@@ -39,6 +39,9 @@ typedef struct szo_params {
     int      sol_id;                 /* 101 = SZ */
     double   psnr;                   /* for errorBoundMode PSNR */
     double   norm_err;               /* for errorBoundMode NORM */
+    double   conf_rel_bound_ratio;   /* confparams_cpr->relBoundRatio: what the parameter bytes record in the REL-type modes.
+                                        SZ_compress_args never copies its relBoundRatio ARGUMENT into the config struct
+                                        (sz_float.c:2815-2820), so the header carries the configured value. */
 } szo_params;
 
 void szo_default_params(szo_params *p);

@@ -41,6 +41,7 @@ void szo_default_params(szo_params *p)
     p->sol_id = 101;
     p->psnr = 90;
     p->norm_err = 0.05;
+    p->conf_rel_bound_ratio = 1E-4; /* conf.c:123 */
 }
 
 void szo_free_stages(szo_stages *s)
@@ -209,7 +210,7 @@ unsigned char *szo_compress_args(const szo_params *p, int data_type, const void 
     unsigned char meta[4 + SZO_META_F64];
     memset(meta, 0, sizeof(meta));
     meta[0] = 2; meta[1] = 1; meta[2] = 12;
-    szo_params_to_bytes(p, data_type, eff_mode, eb, rel_ratio, vmin, vmax, meta + 4);
+    szo_params_to_bytes(p, data_type, eff_mode, eb, p->conf_rel_bound_ratio, vmin, vmax, meta + 4);
 
     if (range <= eb) {
         /* constant data: SZ_compress_args_float_withinRange (sz_float.c:2728) -> header + first value */

@@ -16,7 +16,7 @@ class Params(ctypes.Structure):
                 ("max_quant_intervals", ctypes.c_uint), ("quantization_intervals", ctypes.c_uint),
                 ("with_regression", ctypes.c_int), ("sz_mode", ctypes.c_int), ("gzip_mode", ctypes.c_int),
                 ("protect_value_range", ctypes.c_int), ("data_endian", ctypes.c_int), ("sol_id", ctypes.c_int),
-                ("psnr", ctypes.c_double), ("norm_err", ctypes.c_double)]
+                ("psnr", ctypes.c_double), ("norm_err", ctypes.c_double), ("conf_rel_bound_ratio", ctypes.c_double)]
 
 
 class Stages(ctypes.Structure):
@@ -57,8 +57,10 @@ def lib():
 
 
 def default_params(**kw):
+    """Defaults of SZ_Init(NULL), except conf_rel_bound_ratio = 1E-3 to match tests/golden/sz_speed.config."""
     p = Params()
     lib().szo_default_params(ctypes.byref(p))
+    p.conf_rel_bound_ratio = 1e-3
     for k, v in kw.items():
         setattr(p, k, v)
     return p
