@@ -148,3 +148,22 @@ def test_baseline_size_properties(sz, anchors):
     hip.hipMemcpy(C.c_void_p(dev_copy.data_ptr()), C.c_void_p(p2), C.c_size_t(n3), 3)
     assert n2 == n3 == n and bytes(dev_copy.cpu().numpy().tobytes()) == host
     ctx.close()
+
+
+def test_config1_through_a_plain_c_caller(built, anchors, tmp_path):
+    """BASELINE configs[0] plumbing: a C program that only knows include/sz.h + include/rw.h (examples/sz_cli.c, the option
+    letters of the reference's `sz` tool) compresses example/testdata's 8x8x128 float file with ABS 1e-4 and reproduces the
+    reference's stream (md5) and quality report (PSNR to 6 decimals)."""
+    import shutil
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "examples")])
+    a = anchors["C1_testfloat_8_8_128_abs1e-4_best_speed"]
+    dat = tmp_path / "testfloat_8_8_128.dat"
+    shutil.copy(os.path.join(ROOT, "tests", "golden", "testfloat_8_8_128.dat"), dat)
+    cfg = os.path.join(ROOT, "tests", "golden", "sz_speed.config")
+    cli = os.path.join(ROOT, "examples", "sz_cli")
+    subprocess.check_call([cli, "-z", "-f", "-c", cfg, "-M", "ABS", "-A", "1e-4", "-i", str(dat), "-3", "8", "8", "128"])
+    stream = open(str(dat) + ".sz", "rb").read()
+    assert len(stream) == a["stream_bytes"] and hashlib.md5(stream).hexdigest() == a["md5"]
+    out = subprocess.check_output([cli, "-x", "-f", "-s", str(dat) + ".sz", "-i", str(dat), "-3", "8", "8", "128", "-a"]).decode()
+    assert f"PSNR = {a['psnr']:.6f}" in out and "Max absolute error = 0.0000999272" in out
