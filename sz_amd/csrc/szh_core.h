@@ -11,6 +11,9 @@
 
 // ---- regression fit of one block.  A(i,j,k) returns the original value at block-local (i,j,k).
 // The accumulation order (sum_y over k, then j, then i; fz over the whole block) is part of the result.
+// Rows are fetched into registers first (SZH_MAX_BLK independent reads in flight) and then accumulated in the reference's
+// order; fetching inside the dependent chain would pay one LDS round trip per element.
+#define SZH_MAX_BLK 12 /* widest block: a dimension of 7..11 forms a single block (sz.h:93-123) */
 template <class T, class Acc>
 SZH_HD void szh_fit_block(const Acc &A, int s0, int s1, int s2, T *coef4)
 {
@@ -18,11 +21,21 @@ SZH_HD void szh_fit_block(const Acc &A, int s0, int s1, int s2, T *coef4)
     for (int i = 0; i < s0; ++i) {
         T sum_x = 0;
         for (int j = 0; j < s1; ++j) {
+            T row[SZH_MAX_BLK];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+            for (int k = 0; k < SZH_MAX_BLK; ++k) row[k] = k < s2 ? A(i, j, k) : (T)0;
             T sum_y = 0;
-            for (int k = 0; k < s2; ++k) {
-                const T c = A(i, j, k);
-                sum_y += c;
-                fz += c * (T)k;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+            for (int k = 0; k < SZH_MAX_BLK; ++k) {
+                if (k < s2) {
+                    const T c = row[k];
+                    sum_y += c;
+                    fz += c * (T)k;
+                }
             }
             fy += sum_y * (T)j;
             sum_x += sum_y;

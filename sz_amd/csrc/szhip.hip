@@ -116,6 +116,13 @@ int choose_segb(const szh_geom3 &G, size_t elem, size_t budget)
     if (segb > G.g2.num) segb = G.g2.num;
     return segb;
 }
+// tile of k_fit_select: the dim2 range is widened to 16-byte vector boundaries on both sides
+size_t tile_bytes_vec(const szh_geom3 &G, int segb, size_t elem)
+{
+    const size_t rows = (size_t)G.g0.early * G.g1.early;
+    const size_t kp = ((size_t)segb * G.g2.early + 2 * (16 / elem)) | 1;
+    return rows * kp * elem + 16;
+}
 size_t tile_bytes(const szh_geom3 &G, int segb, size_t elem)
 {
     const size_t rows = (size_t)G.g0.early * G.g1.early;
@@ -210,15 +217,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     uint8_t *d_lor = (uint8_t *)ctx->blk_lor.p;
     HIPCHK(hipEventRecord(ctx->ev[0], st));
 
-    // ---- regression fit of every block
     const int ncols = G.g0.num * G.g1.num;
-    {
-        const int segb = choose_segb(G, sizeof(T), 40 * 1024);
-        const int nseg = (G.g2.num + segb - 1) / segb;
-        hipLaunchKernelGGL((k_block_stage<T, 0>), dim3(ncols, nseg), dim3(256), tile_bytes(G, segb, sizeof(T)), st,
-                           G, d_in, d_coef, d_lor, (T)0, 0, (T)0, sm + SM_MINMAX, segb);
-        HIPCHK(hipGetLastError());
-    }
 
     // ---- interval optimiser
     unsigned intervals = prm->quantization_intervals;
@@ -281,12 +280,12 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     if (intervals > 65536 || intervals < 4) FAIL(SZHIP_ERR_UNSUP, "quantization interval count %u outside [4,65536]", intervals);
     S.intervals = intervals; S.use_mean = use_mean;
 
-    // ---- predictor selection
+    // ---- regression fit + predictor selection, one pass (the interval decision above only needed the bound)
     {
         const int segb = choose_segb(G, sizeof(T), 40 * 1024);
         const int nseg = (G.g2.num + segb - 1) / segb;
         const T noise = (T)((double)eb * 1.22);
-        hipLaunchKernelGGL((k_block_stage<T, 1>), dim3(ncols, nseg), dim3(256), tile_bytes(G, segb, sizeof(T)), st,
+        hipLaunchKernelGGL((k_fit_select<T>), dim3(ncols, nseg), dim3(256), tile_bytes_vec(G, segb, sizeof(T)), st,
                            G, d_in, d_coef, d_lor, noise, use_mean, mean, sm + SM_MINMAX, segb);
         HIPCHK(hipGetLastError());
     }

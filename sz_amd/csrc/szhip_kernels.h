@@ -147,13 +147,17 @@ __global__ __launch_bounds__(256) void k_block_stage(szh_geom3 G, const T *__res
     const int kend = bkend < G.g2.num ? szh_blk_start(G.g2, bkend) : G.g2.count;
     const int klen = kend - kbeg, kp = klen | 1, rows = s0 * s1;
     u64 lmin = ~0ull, lmax = 0ull;
-    for (int idx = threadIdx.x; idx < rows * klen; idx += 256) {
-        const int row = idx / klen, kx = idx - row * klen;
-        const int i = row / s1, j = row - i * s1;
-        const T v = data[(int64_t)(o0 + i) * G.d0 + (int64_t)(o1 + j) * G.d1 + kbeg + kx];
-        tile[row * kp + kx] = v;
-        if (MODE == 0) { const u64 e = ord_enc(v); lmin = e < lmin ? e : lmin; lmax = e > lmax ? e : lmax; }
-    }
+    // thread = column of the segment, loop over the rows: coalesced along dim2, no index divisions
+    for (int i = 0; i < s0; ++i)
+        for (int j = 0; j < s1; ++j) {
+            const T *src = data + (int64_t)(o0 + i) * G.d0 + (int64_t)(o1 + j) * G.d1 + kbeg;
+            T *dstrow = tile + (i * s1 + j) * kp;
+            for (int kx = threadIdx.x; kx < klen; kx += 256) {
+                const T v = src[kx];
+                dstrow[kx] = v;
+                if (MODE == 0) { const u64 e = ord_enc(v); lmin = e < lmin ? e : lmin; lmax = e > lmax ? e : lmax; }
+            }
+        }
     __syncthreads();
     const int nblk = bkend - bkbeg;
     if ((int)threadIdx.x < nblk) {
@@ -179,6 +183,74 @@ __global__ __launch_bounds__(256) void k_block_stage(szh_geom3 G, const T *__res
             for (int w = 1; w < 4; ++w) { mn = red[w] < mn ? red[w] : mn; mx = red[4 + w] > mx ? red[4 + w] : mx; }
             atomicMin(&minmax[0], mn); atomicMax(&minmax[1], mx);
         }
+    }
+}
+
+// Fused regression fit + predictor selection (+ min/max): one read of the data.  Tile = one (dim0,dim1) block column x
+// `segb` blocks along dim2, fetched as 16-byte vectors (wave w takes rows w, w+4, ...; lane = vector within the row).
+template <class T>
+__global__ __launch_bounds__(256) void k_fit_select(szh_geom3 G, const T *__restrict__ data, T *coef, uint8_t *blk_lor,
+                                                    T noise, int use_mean, T mean, u64 *minmax, int segb)
+{
+    SZH_DYN_SMEM(smem);
+    T *tile = reinterpret_cast<T *>(smem);
+    __shared__ u64 red[8];
+    constexpr int VPT = 16 / (int)sizeof(T);
+    const int col = blockIdx.x, b0 = col / G.g1.num, b1 = col - b0 * G.g1.num;
+    const int bkbeg = blockIdx.y * segb, bkend = min(bkbeg + segb, G.g2.num);
+    const int s0 = szh_blk_size(G.g0, b0), s1 = szh_blk_size(G.g1, b1);
+    const int o0 = szh_blk_start(G.g0, b0), o1 = szh_blk_start(G.g1, b1);
+    const int kbeg = szh_blk_start(G.g2, bkbeg);
+    const int kend = bkend < G.g2.num ? szh_blk_start(G.g2, bkend) : G.g2.count;
+    const bool vec = (G.g2.count % VPT) == 0;          // every row starts 16-byte aligned
+    const int ka = vec ? (kbeg / VPT) * VPT : kbeg;    // tile columns [ka, kb)
+    const int kb = vec ? ((kend + VPT - 1) / VPT) * VPT : kend;
+    const int klen = kb - ka, kp = klen | 1, rows = s0 * s1;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    u64 lmin = ~0ull, lmax = 0ull;
+    for (int r = wid; r < rows; r += 4) {
+        const int i = r / s1, j = r - i * s1;
+        const T *src = data + (int64_t)(o0 + i) * G.d0 + (int64_t)(o1 + j) * G.d1 + ka;
+        T *dstrow = tile + r * kp;
+        if (vec) {
+            for (int c = lane; c < klen / VPT; c += 64) {
+                T v[VPT];
+                const uint4 w = *reinterpret_cast<const uint4 *>(src + c * VPT);
+                __builtin_memcpy(v, &w, 16);
+#pragma unroll
+                for (int e = 0; e < VPT; ++e) {
+                    dstrow[c * VPT + e] = v[e];
+                    const int k = ka + c * VPT + e;
+                    if (k >= kbeg && k < kend) { const u64 oe = ord_enc(v[e]); lmin = oe < lmin ? oe : lmin; lmax = oe > lmax ? oe : lmax; }
+                }
+            }
+        } else {
+            for (int kx = lane; kx < klen; kx += 64) {
+                const T v = src[kx];
+                dstrow[kx] = v;
+                const u64 oe = ord_enc(v); lmin = oe < lmin ? oe : lmin; lmax = oe > lmax ? oe : lmax;
+            }
+        }
+    }
+    __syncthreads();
+    const int nblk = bkend - bkbeg;
+    if ((int)threadIdx.x < nblk) {
+        const int b2 = bkbeg + threadIdx.x;
+        const int s2 = szh_blk_size(G.g2, b2);
+        TileAcc<T> A{tile, kp, s1, szh_blk_start(G.g2, b2) - ka};
+        const int64_t b = ((int64_t)b0 * G.g1.num + b1) * G.g2.num + b2;
+        T c4[4];
+        szh_fit_block<T>(A, s0, s1, s2, c4);
+        for (int e = 0; e < 4; ++e) coef[(int64_t)e * G.nblocks + b] = c4[e];
+        blk_lor[b] = szh_select_block<T>(A, s0, s1, s2, c4, noise, use_mean, mean) ? 0 : 1;
+    }
+    lmin = wave_min_u64(lmin); lmax = wave_max_u64(lmax);
+    if (lane == 0) { red[wid] = lmin; red[4 + wid] = lmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 mn = red[0], mx = red[4];
+        for (int w = 1; w < 4; ++w) { mn = red[w] < mn ? red[w] : mn; mx = red[4 + w] > mx ? red[4 + w] : mx; }
+        atomicMin(&minmax[0], mn); atomicMax(&minmax[1], mx);
     }
 }
 
@@ -339,35 +411,44 @@ __global__ __launch_bounds__(256) void k_permute(szh_geom3 G, const uint16_t *__
     int nE = G.g2.split - bkbeg; if (nE < 0) nE = 0; if (nE > bkend - bkbeg) nE = bkend - bkbeg;
     const int esz = rows * G.g2.early, lsz = rows * G.g2.late, eregion = nE * esz;
     unsigned zeros = 0;
+    (void)total; (void)esz; (void)lsz; (void)eregion;
     if (DIR == 0) {
-        for (int idx = threadIdx.x; idx < total; idx += 256) {
-            const int row = idx / klen, kx = idx - row * klen;
-            const int i = row / s1, j = row - i * s1;
-            tile[row * kp + kx] = src[(int64_t)(o0 + i) * G.d0 + (int64_t)(o1 + j) * G.d1 + kbeg + kx];
+        for (int r = 0; r < rows; ++r) {
+            const int i = r / s1, j = r - i * s1;
+            const uint16_t *srow = src + (int64_t)(o0 + i) * G.d0 + (int64_t)(o1 + j) * G.d1 + kbeg;
+            for (int kx = threadIdx.x; kx < klen; kx += 256) tile[r * kp + kx] = srow[kx];
         }
         __syncthreads();
     }
-    for (int e = threadIdx.x; e < total; e += 256) {
-        int rem, s2, koff;
-        if (e < eregion) { const int bl = e / esz; rem = e - bl * esz; s2 = G.g2.early; koff = bl * G.g2.early; }
-        else { const int e2 = e - eregion; const int bl = e2 / lsz; rem = e2 - bl * lsz; s2 = G.g2.late; koff = nE * G.g2.early + bl * G.g2.late; }
-        const int row = rem / s2, kk = rem - row * s2;
-        if (DIR == 0) {
-            const uint16_t v = tile[row * kp + koff + kk];
-            dst[base + e] = v;
-            zeros += (v == 0);
-        } else {
-            const uint16_t v = src[base + e];
-            tile[row * kp + koff + kk] = v;
-            zeros += (v == 0);
+    // block-order side: the segment's blocks are consecutive; inside a block the order is (row, kk)
+    {
+        int64_t bbase = base; int koff = 0;
+        for (int bl = 0; bl < bkend - bkbeg; ++bl) {
+            const int s2 = (bl < nE) ? G.g2.early : G.g2.late;
+            const int bsz = rows * s2;
+            for (int e = threadIdx.x; e < bsz; e += 256) {
+                int row;
+                if (s2 == 6) row = e / 6; else if (s2 == 7) row = e / 7; else row = e / s2;
+                const int kk = e - row * s2;
+                if (DIR == 0) {
+                    const uint16_t v = tile[row * kp + koff + kk];
+                    dst[bbase + e] = v;
+                    zeros += (v == 0);
+                } else {
+                    const uint16_t v = src[bbase + e];
+                    tile[row * kp + koff + kk] = v;
+                    zeros += (v == 0);
+                }
+            }
+            bbase += bsz; koff += s2;
         }
     }
     if (DIR == 1) {
         __syncthreads();
-        for (int idx = threadIdx.x; idx < total; idx += 256) {
-            const int row = idx / klen, kx = idx - row * klen;
-            const int i = row / s1, j = row - i * s1;
-            dst[(int64_t)(o0 + i) * G.d0 + (int64_t)(o1 + j) * G.d1 + kbeg + kx] = tile[row * kp + kx];
+        for (int r = 0; r < rows; ++r) {
+            const int i = r / s1, j = r - i * s1;
+            uint16_t *drow = dst + (int64_t)(o0 + i) * G.d0 + (int64_t)(o1 + j) * G.d1 + kbeg;
+            for (int kx = threadIdx.x; kx < klen; kx += 256) drow[kx] = tile[r * kp + kx];
         }
     }
     zeros = wave_sum_u32(zeros);
@@ -530,20 +611,37 @@ struct szh_hdec_args {
     u64 *starts; u64 *ends; u64 *counts; unsigned char *dirty; unsigned *changed;
 };
 
+// big-endian 64-bit window starting at byte `byte` (the stream buffer is padded, so reading a few bytes past the end is safe)
+__device__ __forceinline__ u64 hdec_window(const unsigned char *__restrict__ bits, u64 byte)
+{
+    const unsigned char *p = bits + byte;
+    const unsigned mis = (unsigned)((uintptr_t)p & 3u);
+    const unsigned *w = reinterpret_cast<const unsigned *>(p - mis);
+    const u64 a = __builtin_bswap32(w[0]), b = __builtin_bswap32(w[1]), c = __builtin_bswap32(w[2]);
+    const u64 hi = (a << 32) | b;                 // 8 bytes from the aligned address
+    return mis ? ((hi << (8 * mis)) | (c >> (32 - 8 * mis))) : hi;
+}
+
 __device__ __forceinline__ unsigned hdec_run(const unsigned char *__restrict__ bits, u64 total_bits, const unsigned *tab,
                                              u64 pos, u64 limit, u64 *endpos, uint16_t *out, int64_t out_cap)
 {
     unsigned cnt = 0, node = 0;
     u64 p = pos, last_boundary = pos;
-    while (p < total_bits) {
-        const unsigned b = (bits[p >> 3] >> (7 - (unsigned)(p & 7))) & 1u;
-        ++p;
-        const unsigned nx = tab[2 * node + b];
-        if (nx & 0x80000000u) {
-            if (out && (int64_t)cnt < out_cap) out[cnt] = (uint16_t)(nx & 0xffffu);
-            ++cnt; node = 0; last_boundary = p;
-            if (p >= limit) break;
-        } else node = nx;
+    bool done = false;
+    while (p < total_bits && !done) {
+        u64 win = hdec_window(bits, p >> 3) << (p & 7);
+        int avail = 64 - (int)(p & 7);
+        if ((u64)avail > total_bits - p) avail = (int)(total_bits - p);
+        for (; avail > 0; --avail) {
+            const unsigned b = (unsigned)(win >> 63);
+            win <<= 1; ++p;
+            const unsigned nx = tab[2 * node + b];
+            if (nx & 0x80000000u) {
+                if (out && (int64_t)cnt < out_cap) out[cnt] = (uint16_t)(nx & 0xffffu);
+                ++cnt; node = 0; last_boundary = p;
+                if (p >= limit) { done = true; break; }
+            } else node = nx;
+        }
     }
     *endpos = last_boundary;
     return cnt;
