@@ -315,7 +315,10 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, uint16_t *cring
         tr_naps = naps;
     }
     if (a.trace) tr_gate = B::clock();
+    const bool detail = a.trace && I == a.nI / 2 && J == a.nJ / 2;
+    szh_u64 *dt = a.trace ? a.trace + (int64_t)a.nI * a.nJ * 8 : nullptr;
     for (int t0 = 0; t0 < tsteps; t0 += SZH_U) {
+        if (detail && t0 / SZH_U < 64) { SZH_FORL { if (B::lane(l) == 0) dt[(t0 / SZH_U) * 4 + 0] = B::clock(); } }
         SZH_UNROLL
         for (int s = 0; s < SZH_U; ++s) load_halo(t0 + s, hr[s]);
         if (DEC) { while (filled < t0 + SZH_U && filled < r2) { move_codes(filled); filled += 16; } } // ring holds columns < filled
@@ -433,6 +436,7 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, uint16_t *cring
                 }
                 // roll the neighbour state.  Lanes outside the k range see zero inputs and zero neighbours, so
                 // they produce zeros by themselves; only the mean shortcut and stale pre-scattered values need masking.
+                if (detail && s == 0 && t0 / SZH_U < 64 && B::lane(l) == 0) dt[(t0 / SZH_U) * 4 + 1] = B::clock();
                 cur[l] = (USEMEAN || DEC) ? (act ? nv : (T)0) : nv;
                 A1[l] = nA; B1[l] = nB; C1[l] = nC;
                 // advance along dim2
@@ -456,11 +460,13 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, uint16_t *cring
                 }
             }
         }
+        if (detail && t0 / SZH_U < 64) { SZH_FORL { if (B::lane(l) == 0) dt[(t0 / SZH_U) * 4 + 2] = B::clock(); } }
         if (DEC) store_out(t0);
         else {
             // after this trip every lane is past column t0 + SZH_U - 15: flush the 16-column groups that are complete
             while (flushed + 16 <= t0 + SZH_U - 14 && flushed < r2) { move_codes(flushed); flushed += 16; }
         }
+        if (detail && t0 / SZH_U < 64) { SZH_FORL { if (B::lane(l) == 0) dt[(t0 / SZH_U) * 4 + 3] = B::clock(); } }
         if (a.trace && t0 == 0) tr_first = B::clock();
         // tell the consumers how far this pencil has got (one word, one lane)
         SZH_FORL { if (B::lane(l) == 0) B::st_gran(a.progress + ((int64_t)I * a.nJ + J), ((szh_u64)a.epoch << 32) | (unsigned)(t0 + SZH_U)); }

@@ -138,7 +138,7 @@ int prepare_pencil(szhip_ctx *ctx, const szh_geom3 &G, int nw, int *nI_out, int 
     TRY(ensure(ctx, ctx->faceI, ng, true));
     TRY(ensure(ctx, ctx->faceJ, ng, true));
     TRY(ensure(ctx, ctx->progress, (size_t)nI * nJ * sizeof(u64), true));
-    if (tune_int("SZ_HIP_TRACE", 0)) TRY(ensure(ctx, ctx->trace, (size_t)nI * nJ * 8 * sizeof(u64), true));
+    if (tune_int("SZ_HIP_TRACE", 0)) TRY(ensure(ctx, ctx->trace, ((size_t)nI * nJ * 8 + 256) * sizeof(u64), true));
     if (ctx->order_nI != nI || ctx->order_nJ != nJ) {
         std::vector<unsigned> ord((size_t)nI * nJ);
         szh_fill_pencil_order(nI, nJ, ord.data());
@@ -491,6 +491,97 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     return SZHIP_OK;
 }
 
+// everything the host reads from an SZ 2.1 regression-type stream before the unpredictable values
+template <class T> struct dec_header {
+    T eb = 0, mean = 0;
+    unsigned intervals = 0; int use_mean = 0, n_nodes = 0, single_symbol = -1;
+    size_t reg_count = 0, unpred_off = 0, pay_off = 0; uint64_t total_unpred = 0;
+    std::vector<unsigned char> indicator; std::vector<T> coef; std::vector<uint32_t> dtab;
+};
+
+// returns 0 = parsed, 1 = needs at least *need bytes of the stream on the host, < 0 = malformed (message in err)
+template <class T>
+int parse_header(const unsigned char *hs, size_t avail, size_t stream_len, size_t body_off, size_t nb, dec_header<T> &H,
+                 size_t *need, char *err, size_t errlen)
+{
+    const int is_double = sizeof(T) == 8;
+#define PFAIL(code, ...) do { snprintf(err, errlen, __VA_ARGS__); if (hf) szhost_huff_free(hf); return (code); } while (0)
+#define NEED(k) do { const size_t end_ = (size_t)(q - hs) + (size_t)(k); if (end_ > stream_len) PFAIL(SZHIP_ERR_STREAM, "truncated stream"); \
+                     if (end_ > avail) { *need = end_; if (hf) szhost_huff_free(hf); return 1; } } while (0)
+    szhost_huff *hf = nullptr;
+    const unsigned char *q = hs + body_off;
+    NEED(4 + sizeof(T) + 12);
+    const unsigned block_size = szhost_get_u32be(q); q += 4;
+    if (block_size != SZH_BLOCK_SIZE) PFAIL(SZHIP_ERR_UNSUP, "block size %u", block_size);
+    H.eb = is_double ? (T)szhost_get_f64be(q) : (T)szhost_get_f32be(q); q += sizeof(T);
+    H.intervals = szhost_get_u32be(q); q += 4;
+    const unsigned tree_size = szhost_get_u32be(q); q += 4;
+    const int node_count = (int)szhost_get_u32be(q); q += 4;
+    if (H.intervals < 4 || H.intervals > 65536) PFAIL(SZHIP_ERR_STREAM, "bad interval count %u", H.intervals);
+    NEED(tree_size);
+    if (node_count <= 0 || szhost_huff_serial_size(node_count) > tree_size) PFAIL(SZHIP_ERR_STREAM, "bad Huffman tree size");
+    hf = szhost_huff_from_bytes(2 * (int)H.intervals, q, node_count);
+    if (!hf) PFAIL(SZHIP_ERR_STREAM, "bad Huffman tree");
+    q += tree_size;
+    NEED(1 + sizeof(T));
+    H.use_mean = *q++;
+    memcpy(&H.mean, q, sizeof(T)); q += sizeof(T);
+    const size_t ind_bytes = (nb - 1) / 8 + 1;
+    NEED(ind_bytes);
+    H.indicator.resize(nb);
+    H.reg_count = 0;
+    for (size_t b = 0; b < nb; ++b) { H.indicator[b] = (q[b >> 3] >> (7 - (b & 7))) & 1; H.reg_count += H.indicator[b] ? 0 : 1; }
+    q += ind_bytes;
+    H.coef.clear();
+    if (H.reg_count > 0) {
+        std::vector<int> ccodes[4]; int *cptr[4]; int crad[4]; double cprec[4]; const unsigned char *cun[4];
+        for (int e = 0; e < 4; ++e) {
+            NEED(sizeof(T) + 12);
+            cprec[e] = is_double ? szhost_get_f64be(q) : (double)szhost_get_f32be(q); q += sizeof(T);
+            crad[e] = (int)szhost_get_u32be(q); q += 4;
+            const unsigned ts = szhost_get_u32be(q); q += 4;
+            const int cnc = (int)szhost_get_u32be(q); q += 4;
+            NEED(ts);
+            if (cnc <= 0 || crad[e] <= 0 || crad[e] > 32768 || szhost_huff_serial_size(cnc) > ts) PFAIL(SZHIP_ERR_STREAM, "bad coefficient tree size");
+            const unsigned char *tree_at = q;
+            q += ts;
+            NEED(8);
+            const size_t enc = (size_t)szhost_get_u64be(q); q += 8;
+            NEED(enc);
+            szhost_huff *ch = szhost_huff_from_bytes(4 * crad[e], tree_at, cnc);
+            if (!ch) PFAIL(SZHIP_ERR_STREAM, "bad coefficient tree");
+            ccodes[e].resize(H.reg_count);
+            {   // decode from a zero-padded copy so that a corrupt stream cannot run off the end
+                std::vector<unsigned char> tmp(enc + 16, 0);
+                memcpy(tmp.data(), q, enc);
+                szhost_huff_decode_i32(ch, tmp.data(), H.reg_count, ccodes[e].data());
+            }
+            szhost_huff_free(ch);
+            cptr[e] = ccodes[e].data();
+            q += enc;
+            NEED(4);
+            const unsigned cu = szhost_get_u32be(q); q += 4;
+            NEED((size_t)cu * sizeof(T));
+            cun[e] = q; q += (size_t)cu * sizeof(T);
+        }
+        H.coef.assign(nb * 4, (T)0);
+        szhost_coeff_unchain(is_double, H.coef.data(), H.indicator.data(), nb, cptr, crad, cprec, cun);
+    }
+    NEED(8);
+    memcpy(&H.total_unpred, q, 8); q += 8;
+    H.unpred_off = (size_t)(q - hs);
+    if (H.total_unpred > (stream_len - H.unpred_off) / sizeof(T)) PFAIL(SZHIP_ERR_STREAM, "truncated stream");
+    H.pay_off = H.unpred_off + (size_t)H.total_unpred * sizeof(T);
+    H.dtab.resize((size_t)hf->n_nodes * 2);
+    szhost_huff_decode_table(hf, H.dtab.data());
+    H.single_symbol = hf->t[0] ? (int)hf->C[0] : -1;
+    H.n_nodes = hf->n_nodes;
+    szhost_huff_free(hf);
+    return 0;
+#undef NEED
+#undef PFAIL
+}
+
 template <class T>
 int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_on_device, size_t stream_len, size_t body_off,
                     size_t r0, size_t r1, size_t r2, void *out, int out_on_device, szhip_stats *stats)
@@ -504,17 +595,16 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
     szhip_stats S; memset(&S, 0, sizeof(S));
     S.n_elements = (uint64_t)n; S.n_blocks = (uint64_t)nb;
 
-    // ---- stream on both sides: host copy for header parsing, device copy for the payload
+    // ---- stream on both sides: the device gets the whole stream; the host only needs the header (everything up to the
+    //      unpredictable values), fetched from a device-resident stream in growing prefixes
     std::vector<unsigned char> hcopy;
     const unsigned char *hs = stream_in;
+    size_t avail = stream_len;
     TRY(ensure(ctx, ctx->stream_buf, stream_len + 64));
     unsigned char *d_stream = (unsigned char *)ctx->stream_buf.p;
     if (stream_on_device) {
-        hcopy.resize(stream_len);
-        HIPCHK(hipMemcpyAsync(hcopy.data(), stream_in, stream_len, hipMemcpyDeviceToHost, st));
         if (stream_in != d_stream) HIPCHK(hipMemcpyAsync(d_stream, stream_in, stream_len, hipMemcpyDeviceToDevice, st));
-        HIPCHK(hipStreamSynchronize(st));
-        hs = hcopy.data();
+        avail = 0;
     } else {
         HIPCHK(hipMemcpyAsync(d_stream, stream_in, stream_len, hipMemcpyHostToDevice, st));
     }
@@ -523,78 +613,30 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
 
     // ---- header (szd_float.c:3491-3587)
     double h0 = now_ms();
-#define NEED(k) do { if ((size_t)(q - hs) + (size_t)(k) > stream_len) FAIL(SZHIP_ERR_STREAM, "truncated stream"); } while (0)
-    const unsigned char *q = hs + body_off;
-    NEED(4 + sizeof(T) + 12);
-    const unsigned block_size = szhost_get_u32be(q); q += 4;
-    if (block_size != SZH_BLOCK_SIZE) FAIL(SZHIP_ERR_UNSUP, "block size %u", block_size);
-    const T eb = is_double ? (T)szhost_get_f64be(q) : (T)szhost_get_f32be(q); q += sizeof(T);
-    const unsigned intervals = szhost_get_u32be(q); q += 4;
-    const unsigned tree_size = szhost_get_u32be(q); q += 4;
-    const int node_count = (int)szhost_get_u32be(q); q += 4;
-    if (intervals < 4 || intervals > 65536) FAIL(SZHIP_ERR_STREAM, "bad interval count %u", intervals);
-    NEED(tree_size);
-    if (node_count <= 0 || szhost_huff_serial_size(node_count) > tree_size) FAIL(SZHIP_ERR_STREAM, "bad Huffman tree size");
-    szhost_huff *hf = szhost_huff_from_bytes(2 * (int)intervals, q, node_count);
-    if (!hf) FAIL(SZHIP_ERR_STREAM, "bad Huffman tree");
-    q += tree_size;
-    NEED(1 + sizeof(T));
-    const int use_mean = *q++;
-    T mean; memcpy(&mean, q, sizeof(T)); q += sizeof(T);
-    const size_t ind_bytes = ((size_t)nb - 1) / 8 + 1;
-    NEED(ind_bytes);
-    std::vector<unsigned char> indicator((size_t)nb);
-    size_t reg_count = 0;
-    for (int64_t b = 0; b < nb; ++b) { indicator[(size_t)b] = (q[b >> 3] >> (7 - (b & 7))) & 1; reg_count += indicator[(size_t)b] ? 0 : 1; }
-    q += ind_bytes;
-    std::vector<T> hcoef;
-    if (reg_count > 0) {
-        hcoef.assign((size_t)nb * 4, (T)0);
-        std::vector<int> ccodes[4]; int *cptr[4]; int crad[4]; double cprec[4]; const unsigned char *cun[4];
-        for (int e = 0; e < 4; ++e) {
-            NEED(sizeof(T) + 12);
-            cprec[e] = is_double ? szhost_get_f64be(q) : (double)szhost_get_f32be(q); q += sizeof(T);
-            crad[e] = (int)szhost_get_u32be(q); q += 4;
-            const unsigned ts = szhost_get_u32be(q); q += 4;
-            const int cnc = (int)szhost_get_u32be(q); q += 4;
-            NEED(ts);
-            if (cnc <= 0 || crad[e] <= 0 || crad[e] > 32768 || szhost_huff_serial_size(cnc) > ts) { szhost_huff_free(hf); FAIL(SZHIP_ERR_STREAM, "bad coefficient tree size"); }
-            szhost_huff *ch = szhost_huff_from_bytes(4 * crad[e], q, cnc);
-            if (!ch) { szhost_huff_free(hf); FAIL(SZHIP_ERR_STREAM, "bad coefficient tree"); }
-            q += ts;
-            NEED(8);
-            const size_t enc = (size_t)szhost_get_u64be(q); q += 8;
-            NEED(enc);
-            ccodes[e].resize(reg_count);
-            {   // decode from a zero-padded copy so that a corrupt stream cannot run off the end
-                std::vector<unsigned char> tmp(enc + 16, 0);
-                memcpy(tmp.data(), q, enc);
-                szhost_huff_decode_i32(ch, tmp.data(), reg_count, ccodes[e].data());
-            }
-            cptr[e] = ccodes[e].data();
-            q += enc;
-            szhost_huff_free(ch);
-            NEED(4);
-            const unsigned cu = szhost_get_u32be(q); q += 4;
-            NEED((size_t)cu * sizeof(T));
-            cun[e] = q; q += (size_t)cu * sizeof(T);
+    dec_header<T> H;
+    for (size_t want = std::min<size_t>(stream_len, (size_t)1 << 20);;) {
+        if (stream_on_device && want > avail) {
+            TRY(ensure_pinned(ctx, want));
+            HIPCHK(hipMemcpyAsync(ctx->pinned, d_stream, want, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            hs = (const unsigned char *)ctx->pinned; avail = want;
         }
-        szhost_coeff_unchain(is_double, hcoef.data(), indicator.data(), (size_t)nb, cptr, crad, cprec, cun);
+        size_t need = 0;
+        const int rc = parse_header<T>(hs, avail, stream_len, body_off, (size_t)nb, H, &need, ctx->err, sizeof(ctx->err));
+        if (rc == 0) break;
+        if (rc < 0) { fprintf(stderr, "szhip: %s\n", ctx->err); return rc; }
+        want = std::min<size_t>(stream_len, std::max<size_t>(need, avail * 2)); // rc == 1: more bytes needed
     }
-    NEED(8);
-    uint64_t total_unpred; memcpy(&total_unpred, q, 8); q += 8;
-    NEED(total_unpred * sizeof(T));
-    const size_t unpred_off = (size_t)(q - hs);
-    q += (size_t)total_unpred * sizeof(T);
-    const size_t pay_off = (size_t)(q - hs);
+    const T eb = H.eb, mean = H.mean;
+    const unsigned intervals = H.intervals;
+    const int use_mean = H.use_mean, n_nodes = H.n_nodes, single_symbol = H.single_symbol;
+    const size_t reg_count = H.reg_count, unpred_off = H.unpred_off, pay_off = H.pay_off;
+    const uint64_t total_unpred = H.total_unpred;
+    std::vector<unsigned char> &indicator = H.indicator;
+    std::vector<T> &hcoef = H.coef;
+    std::vector<uint32_t> &dtab = H.dtab;
     const u64 total_bits = (u64)(stream_len - pay_off) * 8;
-#undef NEED
     S.intervals = intervals; S.use_mean = use_mean; S.n_reg_blocks = reg_count; S.n_unpred = total_unpred;
-    std::vector<uint32_t> dtab((size_t)hf->n_nodes * 2);
-    szhost_huff_decode_table(hf, dtab.data());
-    const int single_symbol = hf->t[0] ? (int)hf->C[0] : -1;
-    const int n_nodes = hf->n_nodes;
-    szhost_huff_free(hf);
     host_ms += now_ms() - h0;
 
     TRY(ensure(ctx, ctx->small, SM_COUNT * 8));

@@ -13,7 +13,9 @@ meta = sz_amd.make_meta(np.float32, abs_bound=1e-4, vmin=float(d.min()), vmax=fl
 for it in range(2):
     b, sz, st = ctx.compress(d.ctypes.data, False, d.shape, np.float32, 1e-4, meta)
 nI = nJ = (n + 7) // 8
-tr = ctx.debug_fetch(9, nI * nJ * 8, np.uint64).reshape(nI, nJ, 8).astype(np.int64)
+raw = ctx.debug_fetch(9, nI * nJ * 8 + 256, np.uint64).astype(np.int64)
+tr = raw[:nI * nJ * 8].reshape(nI, nJ, 8)
+det = raw[nI * nJ * 8:].reshape(64, 4)
 t0 = tr[..., 0].min()
 us = lambda x: (x - t0) / 100.0
 print("ms_quant", st.ms_quant, "size", sz)
@@ -31,3 +33,9 @@ print("gate lag vs J-pred us: median %.1f ; vs I-pred: median %.1f" % (np.median
 endlagJ = (tr[:, 1:, 3] - tr[:, :-1, 3]) / 100.0
 print("end lag vs J-pred us: median %.1f" % np.median(endlagJ))
 print("spins total", tr[..., 4].sum(), "median per pencil", np.median(tr[..., 4]))
+
+print("detail of pencil (%d,%d): per trip  wait-for-loads+step0 | remaining steps | flush  (us)" % (nI // 2, nJ // 2))
+for i in range(min(40, (n + 14 + 15) // 16)):
+    r = det[i]
+    if r[0] == 0: break
+    print("  trip %2d: top->step0 %.2f  steps %.2f  flush %.2f   (top at %.1f)" % (i, (r[1]-r[0])/100, (r[2]-r[1])/100, (r[3]-r[2])/100, us(r[0])))
