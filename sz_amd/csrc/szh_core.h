@@ -14,8 +14,10 @@
 // Rows are fetched into registers first (SZH_MAX_BLK independent reads in flight) and then accumulated in the reference's
 // order; fetching inside the dependent chain would pay one LDS round trip per element.
 #define SZH_MAX_BLK 12 /* widest block: a dimension of 7..11 forms a single block (sz.h:93-123) */
-template <class T, class Acc>
-SZH_HD void szh_fit_block(const Acc &A, int s0, int s1, int s2, T *coef4)
+struct szh_no_visit { template <class T> SZH_HD void operator()(T) const {} };
+// visit(c) sees every value of the block once (the kernel folds the array's min/max into this pass)
+template <class T, class Acc, class Visit = szh_no_visit>
+SZH_HD void szh_fit_block(const Acc &A, int s0, int s1, int s2, T *coef4, const Visit &visit = Visit())
 {
     T fx = 0, fy = 0, fz = 0, f = 0;
     for (int i = 0; i < s0; ++i) {
@@ -33,6 +35,7 @@ SZH_HD void szh_fit_block(const Acc &A, int s0, int s1, int s2, T *coef4)
             for (int k = 0; k < SZH_MAX_BLK; ++k) {
                 if (k < s2) {
                     const T c = row[k];
+                    visit(c);
                     sum_y += c;
                     fz += c * (T)k;
                 }

@@ -32,7 +32,7 @@ struct szhip_ctx {
     char err[512] = {0};
     unsigned epoch = 0;
     // workspaces (grow-only)
-    DevBuf in, out, codes_nat, codes_blk, coef, blk_lor, faceI, faceJ, progress, trace, order, small, hist, col_zeros, col_zeros64,
+    DevBuf lor_bits, in, out, codes_nat, codes_blk, coef, blk_lor, faceI, faceJ, progress, trace, order, small, hist, col_zeros, col_zeros64,
         col_off, partial, samples, unpred, stream_buf, chunk_bits, chunk_off, code_tab, len_tab, dec_tab,
         starts, ends, counts, offs, dirty;
     void *pinned = nullptr; size_t pinned_cap = 0;
@@ -104,7 +104,7 @@ int scan_u64(szhip_ctx *ctx, const u64 *in, int64_t n, u64 *out, u64 *total_dev)
 
 // layout of the "small" device scratch (u64 slots)
 enum { SM_MINMAX = 0, SM_WITHIN = 2, SM_MEANCNT = 3, SM_TOTAL_UNPRED = 4, SM_TOTAL_BITS = 5, SM_TICKET = 6, SM_ERR = 7,
-       SM_CHANGED = 8, SM_MEANSUM = 9, SM_TOTAL_SYM = 10, SM_COUNT = 16 };
+       SM_CHANGED = 8, SM_MEANSUM = 9, SM_TOTAL_SYM = 10, SM_NREG = 11, SM_COUNT = 16 };
 
 int choose_segb(const szh_geom3 &G, size_t elem, size_t budget)
 {
@@ -282,19 +282,30 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
 
     // ---- regression fit + predictor selection, one pass (the interval decision above only needed the bound)
     {
-        const int segb = choose_segb(G, sizeof(T), 40 * 1024);
-        const int nseg = (G.g2.num + segb - 1) / segb;
         const T noise = (T)((double)eb * 1.22);
-        hipLaunchKernelGGL((k_fit_select<T>), dim3(ncols, nseg), dim3(256), tile_bytes_vec(G, segb, sizeof(T)), st,
-                           G, d_in, d_coef, d_lor, noise, use_mean, mean, sm + SM_MINMAX, segb);
+        hipLaunchKernelGGL((k_fit_select<T>), dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st,
+                           G, d_in, d_coef, d_lor, noise, use_mean, mean, sm + SM_MINMAX);
         HIPCHK(hipGetLastError());
     }
-    std::vector<unsigned char> indicator((size_t)nb);
-    HIPCHK(hipMemcpyAsync(indicator.data(), d_lor, (size_t)nb, hipMemcpyDeviceToHost, st));
+    // the stream's indicator bit array and the regression-block count come from the device (no per-block host loop)
+    const size_t ind_bytes = ((size_t)nb + 7) / 8;
+    TRY(ensure(ctx, ctx->lor_bits, ind_bytes + 8));
+    hipLaunchKernelGGL(k_pack_lor, dim3((unsigned)((ind_bytes + 255) / 256)), dim3(256), 0, st, (const uint8_t *)d_lor, nb,
+                       (uint8_t *)ctx->lor_bits.p, sm + SM_NREG);
+    HIPCHK(hipGetLastError());
+    std::vector<unsigned char> ind_bits(ind_bytes);
+    u64 nreg64 = 0;
+    HIPCHK(hipMemcpyAsync(ind_bits.data(), ctx->lor_bits.p, ind_bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&nreg64, sm + SM_NREG, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    size_t reg_count = 0;
-    for (int64_t b = 0; b < nb; ++b) reg_count += indicator[b] ? 0 : 1;
+    const size_t reg_count = (size_t)nreg64;
     S.n_reg_blocks = reg_count;
+    std::vector<unsigned char> indicator;
+    if (reg_count > 0) {
+        indicator.resize((size_t)nb);
+        HIPCHK(hipMemcpyAsync(indicator.data(), d_lor, (size_t)nb, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
 
     // ---- regression coefficient chain (serial, host) and its Huffman streams
     szhost_coeffs cf; memset(&cf, 0, sizeof(cf));
@@ -402,7 +413,6 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     szhost_huff *hf = szhost_huff_build(2 * (int)intervals, h_hist, nullptr, intervals);
     if (!hf) FAIL(SZHIP_ERR_INTERNAL, "Huffman build failed");
     const size_t tree_bytes = szhost_huff_tree_size(hf);
-    const size_t ind_bytes = ((size_t)nb + 7) / 8;
     const size_t hdr_len = meta_len + 8 + 4 + sizeof(T) + 4 + 4 + 4 + tree_bytes + 1 + sizeof(T) + ind_bytes + coef_sections.size() + 8;
     const size_t unpred_bytes = (size_t)total_unpred * sizeof(T);
     const size_t pay_bytes = (size_t)((hf->total_bits + 7) / 8);
@@ -421,8 +431,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         szhost_huff_tree_write(hf, q); q += tree_bytes;
         *q++ = (unsigned char)use_mean;
         memcpy(q, &mean, sizeof(T)); q += sizeof(T);
-        for (int64_t b = 0; b < nb; ++b) if (indicator[(size_t)b] == 1) q[b >> 3] |= (unsigned char)(1u << (7 - (b & 7)));
-        q += ind_bytes;
+        memcpy(q, ind_bits.data(), ind_bytes); q += ind_bytes;
         if (!coef_sections.empty()) { memcpy(q, coef_sections.data(), coef_sections.size()); q += coef_sections.size(); }
         const uint64_t tu = total_unpred; memcpy(q, &tu, 8); q += 8;
     }
@@ -495,7 +504,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
 template <class T> struct dec_header {
     T eb = 0, mean = 0;
     unsigned intervals = 0; int use_mean = 0, n_nodes = 0, single_symbol = -1;
-    size_t reg_count = 0, unpred_off = 0, pay_off = 0; uint64_t total_unpred = 0;
+    size_t reg_count = 0, ind_off = 0, unpred_off = 0, pay_off = 0; uint64_t total_unpred = 0;
     std::vector<unsigned char> indicator; std::vector<T> coef; std::vector<uint32_t> dtab;
 };
 
@@ -528,9 +537,18 @@ int parse_header(const unsigned char *hs, size_t avail, size_t stream_len, size_
     memcpy(&H.mean, q, sizeof(T)); q += sizeof(T);
     const size_t ind_bytes = (nb - 1) / 8 + 1;
     NEED(ind_bytes);
-    H.indicator.resize(nb);
-    H.reg_count = 0;
-    for (size_t b = 0; b < nb; ++b) { H.indicator[b] = (q[b >> 3] >> (7 - (b & 7))) & 1; H.reg_count += H.indicator[b] ? 0 : 1; }
+    {   // regression blocks = zero bits among the first nb
+        size_t ones = 0, full = nb / 8;
+        for (size_t i = 0; i < full; ++i) ones += (size_t)__builtin_popcount(q[i]);
+        for (size_t b = full * 8; b < nb; ++b) ones += (q[b >> 3] >> (7 - (b & 7))) & 1;
+        H.reg_count = nb - ones;
+    }
+    H.ind_off = (size_t)(q - hs);
+    H.indicator.clear();
+    if (H.reg_count > 0) {
+        H.indicator.resize(nb);
+        for (size_t b = 0; b < nb; ++b) H.indicator[b] = (q[b >> 3] >> (7 - (b & 7))) & 1;
+    }
     q += ind_bytes;
     H.coef.clear();
     if (H.reg_count > 0) {
@@ -632,7 +650,6 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
     const int use_mean = H.use_mean, n_nodes = H.n_nodes, single_symbol = H.single_symbol;
     const size_t reg_count = H.reg_count, unpred_off = H.unpred_off, pay_off = H.pay_off;
     const uint64_t total_unpred = H.total_unpred;
-    std::vector<unsigned char> &indicator = H.indicator;
     std::vector<T> &hcoef = H.coef;
     std::vector<uint32_t> &dtab = H.dtab;
     const u64 total_bits = (u64)(stream_len - pay_off) * 8;
@@ -720,7 +737,9 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
     TRY(ensure(ctx, ctx->coef, (size_t)nb * 4 * sizeof(T)));
     TRY(ensure(ctx, ctx->blk_lor, (size_t)nb));
     if (reg_count > 0) HIPCHK(hipMemcpyAsync(ctx->coef.p, hcoef.data(), hcoef.size() * sizeof(T), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(ctx->blk_lor.p, indicator.data(), (size_t)nb, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_unpack_lor, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, (const uint8_t *)(d_stream + H.ind_off), nb,
+                       (uint8_t *)ctx->blk_lor.p);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[1], st));
 
     // ---- reconstruct: the wavefront kernel
@@ -785,7 +804,7 @@ void szhip_destroy(szhip_ctx *ctx)
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->in, &ctx->out, &ctx->codes_nat, &ctx->codes_blk, &ctx->coef, &ctx->blk_lor, &ctx->faceI, &ctx->faceJ, &ctx->progress, &ctx->trace,
+    DevBuf *bufs[] = {&ctx->lor_bits, &ctx->in, &ctx->out, &ctx->codes_nat, &ctx->codes_blk, &ctx->coef, &ctx->blk_lor, &ctx->faceI, &ctx->faceJ, &ctx->progress, &ctx->trace,
                       &ctx->order, &ctx->small, &ctx->hist, &ctx->col_zeros, &ctx->col_zeros64, &ctx->col_off, &ctx->partial,
                       &ctx->samples, &ctx->unpred, &ctx->stream_buf, &ctx->chunk_bits, &ctx->chunk_off, &ctx->code_tab,
                       &ctx->len_tab, &ctx->dec_tab, &ctx->starts, &ctx->ends, &ctx->counts, &ctx->offs, &ctx->dirty};

@@ -125,122 +125,34 @@ __global__ __launch_bounds__(64) void k_pencil(szh_qargs<T> a)
     szh_pencil_run<T, DEC, GpuBackend>(a, (int)(ij >> 16), (int)(ij & 0xffffu), cring);
 }
 
-// ------------------------------------------------------------------ per-block stages (fit / select)
-template <class T> struct TileAcc {
-    const T *t; int kp, s1, koff;
-    __device__ T operator()(int i, int j, int k) const { return t[(i * s1 + j) * kp + koff + k]; }
+// ------------------------------------------------------------------ per-block stage (fit + select)
+// One THREAD per 6x6x6 block: the reference accumulates the four moment sums of a block in one fixed serial order
+// (sz/src/sz_float.c:6732-6782), so a block is a serial chain; parallelism comes from the ~n/216 blocks.  Lanes of a
+// wavefront own neighbouring blocks along dim2, so for every (i,j) row the wavefront reads one contiguous stretch of HBM
+// straight into registers (no LDS tile; the selection pass re-reads 28 stencils, which hit in L1/L2).
+template <class T> struct GlobAcc {
+    const T *p; int64_t d0, d1;
+    __device__ T operator()(int i, int j, int k) const { return p[i * d0 + j * d1 + k]; }
 };
 
-// grid: (columns = nb0*nb1, segments along dim2); block 256; dynamic LDS = rows_max * kp_max * sizeof(T)
-template <class T, int MODE>
-__global__ __launch_bounds__(256) void k_block_stage(szh_geom3 G, const T *__restrict__ data, T *coef, uint8_t *blk_lor,
-                                                     T noise, int use_mean, T mean, u64 *minmax, int segb)
-{
-    SZH_DYN_SMEM(smem);
-    T *tile = reinterpret_cast<T *>(smem);
-    __shared__ u64 red[8];
-    const int col = blockIdx.x, b0 = col / G.g1.num, b1 = col - b0 * G.g1.num;
-    const int bkbeg = blockIdx.y * segb, bkend = min(bkbeg + segb, G.g2.num);
-    const int s0 = szh_blk_size(G.g0, b0), s1 = szh_blk_size(G.g1, b1);
-    const int o0 = szh_blk_start(G.g0, b0), o1 = szh_blk_start(G.g1, b1);
-    const int kbeg = szh_blk_start(G.g2, bkbeg);
-    const int kend = bkend < G.g2.num ? szh_blk_start(G.g2, bkend) : G.g2.count;
-    const int klen = kend - kbeg, kp = klen | 1, rows = s0 * s1;
-    u64 lmin = ~0ull, lmax = 0ull;
-    // thread = column of the segment, loop over the rows: coalesced along dim2, no index divisions
-    for (int i = 0; i < s0; ++i)
-        for (int j = 0; j < s1; ++j) {
-            const T *src = data + (int64_t)(o0 + i) * G.d0 + (int64_t)(o1 + j) * G.d1 + kbeg;
-            T *dstrow = tile + (i * s1 + j) * kp;
-            for (int kx = threadIdx.x; kx < klen; kx += 256) {
-                const T v = src[kx];
-                dstrow[kx] = v;
-                if (MODE == 0) { const u64 e = ord_enc(v); lmin = e < lmin ? e : lmin; lmax = e > lmax ? e : lmax; }
-            }
-        }
-    __syncthreads();
-    const int nblk = bkend - bkbeg;
-    if ((int)threadIdx.x < nblk) {
-        const int b2 = bkbeg + threadIdx.x;
-        const int s2 = szh_blk_size(G.g2, b2);
-        TileAcc<T> A{tile, kp, s1, szh_blk_start(G.g2, b2) - kbeg};
-        const int64_t b = ((int64_t)b0 * G.g1.num + b1) * G.g2.num + b2;
-        T c4[4];
-        if (MODE == 0) {
-            szh_fit_block<T>(A, s0, s1, s2, c4);
-            for (int e = 0; e < 4; ++e) coef[(int64_t)e * G.nblocks + b] = c4[e];
-        } else {
-            for (int e = 0; e < 4; ++e) c4[e] = coef[(int64_t)e * G.nblocks + b];
-            blk_lor[b] = szh_select_block<T>(A, s0, s1, s2, c4, noise, use_mean, mean) ? 0 : 1;
-        }
-    }
-    if (MODE == 0) {
-        lmin = wave_min_u64(lmin); lmax = wave_max_u64(lmax);
-        if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = lmin; red[4 + (threadIdx.x >> 6)] = lmax; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            u64 mn = red[0], mx = red[4];
-            for (int w = 1; w < 4; ++w) { mn = red[w] < mn ? red[w] : mn; mx = red[4 + w] > mx ? red[4 + w] : mx; }
-            atomicMin(&minmax[0], mn); atomicMax(&minmax[1], mx);
-        }
-    }
-}
-
-// Fused regression fit + predictor selection (+ min/max): one read of the data.  Tile = one (dim0,dim1) block column x
-// `segb` blocks along dim2, fetched as 16-byte vectors (wave w takes rows w, w+4, ...; lane = vector within the row).
 template <class T>
 __global__ __launch_bounds__(256) void k_fit_select(szh_geom3 G, const T *__restrict__ data, T *coef, uint8_t *blk_lor,
-                                                    T noise, int use_mean, T mean, u64 *minmax, int segb)
+                                                    T noise, int use_mean, T mean, u64 *minmax)
 {
-    SZH_DYN_SMEM(smem);
-    T *tile = reinterpret_cast<T *>(smem);
     __shared__ u64 red[8];
-    constexpr int VPT = 16 / (int)sizeof(T);
-    const int col = blockIdx.x, b0 = col / G.g1.num, b1 = col - b0 * G.g1.num;
-    const int bkbeg = blockIdx.y * segb, bkend = min(bkbeg + segb, G.g2.num);
-    const int s0 = szh_blk_size(G.g0, b0), s1 = szh_blk_size(G.g1, b1);
-    const int o0 = szh_blk_start(G.g0, b0), o1 = szh_blk_start(G.g1, b1);
-    const int kbeg = szh_blk_start(G.g2, bkbeg);
-    const int kend = bkend < G.g2.num ? szh_blk_start(G.g2, bkend) : G.g2.count;
-    const bool vec = (G.g2.count % VPT) == 0;          // every row starts 16-byte aligned
-    const int ka = vec ? (kbeg / VPT) * VPT : kbeg;    // tile columns [ka, kb)
-    const int kb = vec ? ((kend + VPT - 1) / VPT) * VPT : kend;
-    const int klen = kb - ka, kp = klen | 1, rows = s0 * s1;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
     u64 lmin = ~0ull, lmax = 0ull;
-    for (int r = wid; r < rows; r += 4) {
-        const int i = r / s1, j = r - i * s1;
-        const T *src = data + (int64_t)(o0 + i) * G.d0 + (int64_t)(o1 + j) * G.d1 + ka;
-        T *dstrow = tile + r * kp;
-        if (vec) {
-            for (int c = lane; c < klen / VPT; c += 64) {
-                T v[VPT];
-                const uint4 w = *reinterpret_cast<const uint4 *>(src + c * VPT);
-                __builtin_memcpy(v, &w, 16);
-#pragma unroll
-                for (int e = 0; e < VPT; ++e) {
-                    dstrow[c * VPT + e] = v[e];
-                    const int k = ka + c * VPT + e;
-                    if (k >= kbeg && k < kend) { const u64 oe = ord_enc(v[e]); lmin = oe < lmin ? oe : lmin; lmax = oe > lmax ? oe : lmax; }
-                }
-            }
-        } else {
-            for (int kx = lane; kx < klen; kx += 64) {
-                const T v = src[kx];
-                dstrow[kx] = v;
-                const u64 oe = ord_enc(v); lmin = oe < lmin ? oe : lmin; lmax = oe > lmax ? oe : lmax;
-            }
-        }
-    }
-    __syncthreads();
-    const int nblk = bkend - bkbeg;
-    if ((int)threadIdx.x < nblk) {
-        const int b2 = bkbeg + threadIdx.x;
-        const int s2 = szh_blk_size(G.g2, b2);
-        TileAcc<T> A{tile, kp, s1, szh_blk_start(G.g2, b2) - ka};
-        const int64_t b = ((int64_t)b0 * G.g1.num + b1) * G.g2.num + b2;
+    if (b < G.nblocks) {
+        const int nb2 = G.g2.num, nb1 = G.g1.num;
+        const int b2 = (int)(b % nb2);
+        const int64_t c = b / nb2;
+        const int b1 = (int)(c % nb1), b0 = (int)(c / nb1);
+        const int s0 = szh_blk_size(G.g0, b0), s1 = szh_blk_size(G.g1, b1), s2 = szh_blk_size(G.g2, b2);
+        const GlobAcc<T> A{data + (int64_t)szh_blk_start(G.g0, b0) * G.d0 + (int64_t)szh_blk_start(G.g1, b1) * G.d1 + szh_blk_start(G.g2, b2),
+                           G.d0, G.d1};
         T c4[4];
-        szh_fit_block<T>(A, s0, s1, s2, c4);
+        szh_fit_block<T>(A, s0, s1, s2, c4, [&](T v) { const u64 oe = ord_enc(v); lmin = oe < lmin ? oe : lmin; lmax = oe > lmax ? oe : lmax; });
         for (int e = 0; e < 4; ++e) coef[(int64_t)e * G.nblocks + b] = c4[e];
         blk_lor[b] = szh_select_block<T>(A, s0, s1, s2, c4, noise, use_mean, mean) ? 0 : 1;
     }
@@ -254,7 +166,7 @@ __global__ __launch_bounds__(256) void k_fit_select(szh_geom3 G, const T *__rest
     }
 }
 
-// plain min/max over a flat array (API-level range scan)
+// whole-array value range (szhip_minmax; computeRangeSize_float, sz/src/dataCompression.c)
 template <class T>
 __global__ __launch_bounds__(256) void k_minmax(const T *__restrict__ data, int64_t n, u64 *minmax)
 {
@@ -534,6 +446,28 @@ __global__ __launch_bounds__(256) void k_u32_to_u64(const unsigned *__restrict__
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = in[i];
+}
+
+// ------------------------------------------------------------------ predictor indicator <-> the stream's bit array
+// bit 7-(b&7) of byte b>>3 is 1 for a Lorenzo block (convertIntArray2ByteArray_fast_1b, sz/src/ByteToolkit.c:574-604)
+__global__ __launch_bounds__(256) void k_pack_lor(const uint8_t *__restrict__ lor, int64_t nb, uint8_t *bits, u64 *n_reg)
+{
+    const int64_t byte = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned v = 0, reg = 0;
+    if (byte * 8 < nb) {
+        for (int e = 0; e < 8; ++e) {
+            const int64_t b = byte * 8 + e;
+            if (b < nb) { if (lor[b]) v |= 1u << (7 - e); else ++reg; }
+        }
+        bits[byte] = (uint8_t)v;
+    }
+    for (int o = 32; o; o >>= 1) reg += __shfl_xor(reg, o, 64);
+    if ((threadIdx.x & 63) == 0 && reg) atomicAdd(n_reg, (u64)reg);
+}
+__global__ __launch_bounds__(256) void k_unpack_lor(const uint8_t *__restrict__ bits, int64_t nb, uint8_t *lor)
+{
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b < nb) lor[b] = (bits[b >> 3] >> (7 - (b & 7))) & 1;
 }
 
 // ------------------------------------------------------------------ Huffman bit packing
