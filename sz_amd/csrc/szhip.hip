@@ -116,17 +116,11 @@ int choose_segb(const szh_geom3 &G, size_t elem, size_t budget)
     if (segb > G.g2.num) segb = G.g2.num;
     return segb;
 }
-// tile of k_fit_select: the dim2 range is widened to 16-byte vector boundaries on both sides
-size_t tile_bytes_vec(const szh_geom3 &G, int segb, size_t elem)
-{
-    const size_t rows = (size_t)G.g0.early * G.g1.early;
-    const size_t kp = ((size_t)segb * G.g2.early + 2 * (16 / elem)) | 1;
-    return rows * kp * elem + 16;
-}
+// tile of k_permute: rows widened to 16-byte vector boundaries, pitch a multiple of 8 elements
 size_t tile_bytes(const szh_geom3 &G, int segb, size_t elem)
 {
     const size_t rows = (size_t)G.g0.early * G.g1.early;
-    const size_t kp = ((size_t)segb * G.g2.early) | 1;
+    const size_t kp = ((size_t)segb * G.g2.early + 31) & ~(size_t)7;
     return rows * kp * elem + 16;
 }
 

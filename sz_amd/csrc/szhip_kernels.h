@@ -316,51 +316,70 @@ __global__ __launch_bounds__(256) void k_permute(szh_geom3 G, const uint16_t *__
     const int o0 = szh_blk_start(G.g0, b0), o1 = szh_blk_start(G.g1, b1);
     const int kbeg = szh_blk_start(G.g2, bkbeg);
     const int kend = bkend < G.g2.num ? szh_blk_start(G.g2, bkend) : G.g2.count;
-    const int klen = kend - kbeg, kp = klen | 1, rows = s0 * s1;
+    // natural-order side: rows of the tile cover [ka, kb) = [kbeg, kend) widened to 16-byte vector boundaries
+    const bool vec = (G.g2.count % 8) == 0;
+    const int ka = vec ? (kbeg & ~7) : kbeg, kb = vec ? ((kend + 7) & ~7) : kend;
+    const int kp = (kb - ka + 8) & ~7, kshift = kbeg - ka;      // row pitch: a multiple of 8 elements
+    const int klen = kend - kbeg, rows = s0 * s1;
     const int total = rows * klen;
     const int64_t base = szh_code_base(G, b0, b1, bkbeg);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     // early-width blocks of this segment come first
     int nE = G.g2.split - bkbeg; if (nE < 0) nE = 0; if (nE > bkend - bkbeg) nE = bkend - bkbeg;
     const int esz = rows * G.g2.early, lsz = rows * G.g2.late, eregion = nE * esz;
+    // block-order element e of this segment -> tile index
+    auto locate = [&](int e, int &row, int &kk, int &s2, int &koff) {
+        if (e < eregion) { const int bl = e / esz; const int rem = e - bl * esz; s2 = G.g2.early; koff = bl * s2; row = rem / s2; kk = rem - row * s2; }
+        else { const int e2 = e - eregion; const int bl = e2 / lsz; const int rem = e2 - bl * lsz; s2 = G.g2.late; koff = nE * G.g2.early + bl * s2; row = rem / s2; kk = rem - row * s2; }
+    };
     unsigned zeros = 0;
-    (void)total; (void)esz; (void)lsz; (void)eregion;
     if (DIR == 0) {
-        for (int r = 0; r < rows; ++r) {
+        for (int r = wid; r < rows; r += 4) {
             const int i = r / s1, j = r - i * s1;
-            const uint16_t *srow = src + (int64_t)(o0 + i) * G.d0 + (int64_t)(o1 + j) * G.d1 + kbeg;
-            for (int kx = threadIdx.x; kx < klen; kx += 256) tile[r * kp + kx] = srow[kx];
+            const uint16_t *srow = src + (int64_t)(o0 + i) * G.d0 + (int64_t)(o1 + j) * G.d1 + ka;
+            if (vec) { for (int c = lane; c < (kb - ka) / 8; c += 64) *reinterpret_cast<uint4 *>(tile + r * kp + c * 8) = *reinterpret_cast<const uint4 *>(srow + c * 8); }
+            else { for (int kx = lane; kx < klen; kx += 64) tile[r * kp + kx] = srow[kx]; }
         }
         __syncthreads();
     }
-    // block-order side: the segment's blocks are consecutive; inside a block the order is (row, kk)
+    // block-order side: the segment is one contiguous range [base, base + total); 16-byte groups by absolute address
     {
-        int64_t bbase = base; int koff = 0;
-        for (int bl = 0; bl < bkend - bkbeg; ++bl) {
-            const int s2 = (bl < nE) ? G.g2.early : G.g2.late;
-            const int bsz = rows * s2;
-            for (int e = threadIdx.x; e < bsz; e += 256) {
-                int row;
-                if (s2 == 6) row = e / 6; else if (s2 == 7) row = e / 7; else row = e / s2;
-                const int kk = e - row * s2;
-                if (DIR == 0) {
-                    const uint16_t v = tile[row * kp + koff + kk];
-                    dst[bbase + e] = v;
-                    zeros += (v == 0);
-                } else {
-                    const uint16_t v = src[bbase + e];
-                    tile[row * kp + koff + kk] = v;
-                    zeros += (v == 0);
-                }
+        const int head = (int)(base & 7);                         // elements of the first group that belong to the previous segment
+        const int ngroups = (head + total + 7) / 8;
+        for (int g = threadIdx.x; g < ngroups; g += 256) {
+            const int e0 = g * 8 - head;                           // may be negative in the first group
+            int elo = e0 < 0 ? 0 : e0, ehi = e0 + 8 > total ? total : e0 + 8;
+            int row, kk, s2, koff;
+            locate(elo, row, kk, s2, koff);
+            uint16_t v[8];
+            if (DIR == 1) {
+                if (ehi - elo == 8) { const uint4 w = *reinterpret_cast<const uint4 *>(src + base + e0); __builtin_memcpy(v, &w, 16); }
+                else { for (int e = elo; e < ehi; ++e) v[e - e0] = src[base + e]; }
             }
-            bbase += bsz; koff += s2;
+            for (int e = elo; e < ehi; ++e) {
+                const int ti = row * kp + kshift + koff + kk;
+                if (DIR == 0) { v[e - e0] = tile[ti]; zeros += (v[e - e0] == 0); }
+                else { tile[ti] = v[e - e0]; zeros += (v[e - e0] == 0); }
+                if (++kk == s2) { kk = 0; if (++row == rows && e + 1 < ehi) locate(e + 1, row, kk, s2, koff); }
+            }
+            if (DIR == 0) {
+                if (ehi - elo == 8) { uint4 w; __builtin_memcpy(&w, v, 16); *reinterpret_cast<uint4 *>(dst + base + e0) = w; }
+                else { for (int e = elo; e < ehi; ++e) dst[base + e] = v[e - e0]; }
+            }
         }
     }
     if (DIR == 1) {
         __syncthreads();
-        for (int r = 0; r < rows; ++r) {
+        for (int r = wid; r < rows; r += 4) {
             const int i = r / s1, j = r - i * s1;
-            uint16_t *drow = dst + (int64_t)(o0 + i) * G.d0 + (int64_t)(o1 + j) * G.d1 + kbeg;
-            for (int kx = threadIdx.x; kx < klen; kx += 256) drow[kx] = tile[r * kp + kx];
+            uint16_t *drow = dst + (int64_t)(o0 + i) * G.d0 + (int64_t)(o1 + j) * G.d1 + ka;
+            if (vec) {
+                for (int c = lane; c < (kb - ka) / 8; c += 64) {
+                    const int k0 = ka + c * 8;
+                    if (k0 >= kbeg && k0 + 8 <= kend) *reinterpret_cast<uint4 *>(drow + c * 8) = *reinterpret_cast<const uint4 *>(tile + r * kp + c * 8);
+                    else { for (int e = 0; e < 8; ++e) if (k0 + e >= kbeg && k0 + e < kend) drow[c * 8 + e] = tile[r * kp + c * 8 + e]; }
+                }
+            } else { for (int kx = lane; kx < klen; kx += 64) drow[kx] = tile[r * kp + kx]; }
         }
     }
     zeros = wave_sum_u32(zeros);
@@ -385,12 +404,25 @@ __global__ __launch_bounds__(256) void k_unpred(szh_geom3 G, const uint16_t *__r
     const int64_t base = szh_code_base01(G, b0, b1);
     const int64_t esz = (int64_t)rows * G.g2.early, lsz = (int64_t)rows * G.g2.late, eregion = (int64_t)G.g2.split * esz;
     u64 run = col_off[col];
-    for (int64_t t0 = 0; t0 < len; t0 += 256) {
-        const int64_t e = t0 + threadIdx.x;
-        const bool z = (e < len) && (codes_blk[base + e] == 0);
+    // the column is one contiguous block-order range; 8 codes per thread per round (16-byte groups by absolute address)
+    const int head = (int)(base & 7);
+    const int64_t ngroups = (head + len + 7) / 8;
+    for (int64_t g0 = 0; g0 < ngroups; g0 += 256) {
+        const int64_t g = g0 + threadIdx.x;
+        const int64_t e0 = g * 8 - head;
+        uint16_t v[8];
+        unsigned zmask = 0;
+        if (g < ngroups) {
+            if (e0 >= 0 && e0 + 8 <= len) { const uint4 w = *reinterpret_cast<const uint4 *>(codes_blk + base + e0); __builtin_memcpy(v, &w, 16); }
+            else { for (int q = 0; q < 8; ++q) v[q] = (e0 + q >= 0 && e0 + q < len) ? codes_blk[base + e0 + q] : (uint16_t)1; }
+            for (int q = 0; q < 8; ++q) zmask |= (v[q] == 0 ? 1u : 0u) << q;
+        }
         u64 tot;
-        const u64 rank = block_excl_scan_256(z ? 1ull : 0ull, sh, &tot);
-        if (z) {
+        u64 rank = block_excl_scan_256((u64)__builtin_popcount(zmask), sh, &tot);
+        for (int q = 0; q < 8 && zmask; ++q) {
+            if (!(zmask >> q & 1)) continue;
+            zmask &= ~(1u << q);
+            const int64_t e = e0 + q;
             int64_t rem; int s2, o2;
             if (e < eregion) { const int64_t bl = e / esz; rem = e - bl * esz; s2 = G.g2.early; o2 = (int)bl * G.g2.early; }
             else { const int64_t e2 = e - eregion; const int64_t bl = e2 / lsz; rem = e2 - bl * lsz; s2 = G.g2.late; o2 = G.g2.split * G.g2.early + (int)bl * G.g2.late; }
@@ -399,6 +431,7 @@ __global__ __launch_bounds__(256) void k_unpred(szh_geom3 G, const uint16_t *__r
             const int64_t nat = (int64_t)(o0 + ii) * G.d0 + (int64_t)(o1 + jj) * G.d1 + o2 + kk;
             if (DIR == 0) unpred[run + rank] = data[nat];
             else out[nat] = unpred[run + rank];
+            ++rank;
         }
         run += tot;
     }
@@ -556,12 +589,24 @@ __device__ __forceinline__ u64 hdec_window(const unsigned char *__restrict__ bit
     return mis ? ((hi << (8 * mis)) | (c >> (32 - 8 * mis))) : hi;
 }
 
+// decodes from bit `pos` to the first codeword boundary at or after `limit`.  WRITE: symbols go to out[o], out[o+1], ... (< n)
+// through a 16-byte register buffer: a thread's output is a contiguous run, so apart from its ragged ends it is written as
+// aligned 8-symbol vectors (a 2-byte store per symbol per lane was 8x the memory requests).
+template <bool WRITE>
 __device__ __forceinline__ unsigned hdec_run(const unsigned char *__restrict__ bits, u64 total_bits, const unsigned *tab,
-                                             u64 pos, u64 limit, u64 *endpos, uint16_t *out, int64_t out_cap)
+                                             u64 pos, u64 limit, u64 *endpos, uint16_t *out, int64_t o, int64_t n)
 {
     unsigned cnt = 0, node = 0;
     u64 p = pos, last_boundary = pos;
     bool done = false;
+    u64 lo = 0, hi = 0;            // symbols [oi & ~7, oi) of the current 8-symbol group
+    int64_t oi = o;                // next output index
+    auto flush_partial = [&](int64_t from, int64_t to) { // scalar stores of buffered symbols [from, to), same group
+        for (int64_t i = from; i < to; ++i) {
+            const int q = (int)(i & 7);
+            out[i] = (uint16_t)(q < 4 ? (lo >> (16 * q)) : (hi >> (16 * (q - 4))));
+        }
+    };
     while (p < total_bits && !done) {
         u64 win = hdec_window(bits, p >> 3) << (p & 7);
         int avail = 64 - (int)(p & 7);
@@ -571,12 +616,24 @@ __device__ __forceinline__ unsigned hdec_run(const unsigned char *__restrict__ b
             win <<= 1; ++p;
             const unsigned nx = tab[2 * node + b];
             if (nx & 0x80000000u) {
-                if (out && (int64_t)cnt < out_cap) out[cnt] = (uint16_t)(nx & 0xffffu);
+                if (WRITE && oi < n) {
+                    const int q = (int)(oi & 7);
+                    const u64 sym = (u64)(nx & 0xffffu);
+                    if (q < 4) lo |= sym << (16 * q); else hi |= sym << (16 * (q - 4));
+                    ++oi;
+                    if (q == 7) {
+                        if (oi - 8 >= o) { uint4 w; w.x = (unsigned)lo; w.y = (unsigned)(lo >> 32); w.z = (unsigned)hi; w.w = (unsigned)(hi >> 32);
+                                           *reinterpret_cast<uint4 *>(out + oi - 8) = w; }
+                        else flush_partial(o, oi);
+                        lo = 0; hi = 0;
+                    }
+                }
                 ++cnt; node = 0; last_boundary = p;
                 if (p >= limit) { done = true; break; }
             } else node = nx;
         }
     }
+    if (WRITE && (oi & 7)) { const int64_t g0 = oi & ~(int64_t)7; flush_partial(g0 > o ? g0 : o, oi); }
     *endpos = last_boundary;
     return cnt;
 }
@@ -599,7 +656,7 @@ __global__ __launch_bounds__(256) void k_hdec_pass(szh_hdec_args a)
     const u64 st = a.starts[s];
     unsigned cnt = 0;
     if (st >= limit) endp = st; // the previous codeword swallowed this whole subsequence
-    else cnt = hdec_run(a.bits, a.total_bits, tab, st, limit, &endp, nullptr, 0);
+    else cnt = hdec_run<false>(a.bits, a.total_bits, tab, st, limit, &endp, nullptr, 0, 0);
     a.ends[s] = endp; a.counts[s] = cnt;
 }
 __global__ __launch_bounds__(256) void k_hdec_update(szh_hdec_args a)
@@ -631,7 +688,7 @@ __global__ __launch_bounds__(256) void k_hdec_write(szh_hdec_args a, const u64 *
     const int64_t o = (int64_t)offs[s];
     if (st >= limit || o >= n) return;
     u64 endp;
-    hdec_run(a.bits, a.total_bits, tab, st, limit, &endp, out + o, n - o);
+    hdec_run<true>(a.bits, a.total_bits, tab, st, limit, &endp, out, o, n);
 }
 __global__ __launch_bounds__(256) void k_fill_u16(uint16_t *p, int64_t n, uint16_t v)
 {
