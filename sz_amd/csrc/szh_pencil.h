@@ -193,22 +193,25 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, uint16_t *cring
     const bool vec_codes = (r2 % 8) == 0;         // rows of the u16 code array are 16-byte aligned
 
     // this lane's row, steps t0..t0+SZH_U-1  <->  k = t0 - skew .. t0 - skew + SZH_U - 1
+    // compress: the original values -> xr; decompress: the pre-scattered unpredictable values -> ov (overwritten step by step)
     auto load_x = [&](int t0) {
+        const T *src = DEC ? a.out : a.data;
+        T (&dst)[SZH_U][NL] = DEC ? ov : xr;
         SZH_FORL {
             const int k0 = t0 - skew[l];
             if (inb[l] && k0 >= 0 && k0 + SZH_U <= r2) {
                 SZH_UNROLL
                 for (int v = 0; v < NVEC; ++v) {
                     T tmp[VPT];
-                    B::ld16(a.data + rowoff[l] + k0 + v * VPT, tmp);
+                    B::ld16(src + rowoff[l] + k0 + v * VPT, tmp);
                     SZH_UNROLL
-                    for (int e = 0; e < VPT; ++e) xr[v * VPT + e][l] = tmp[e];
+                    for (int e = 0; e < VPT; ++e) dst[v * VPT + e][l] = tmp[e];
                 }
             } else {
                 SZH_UNROLL
                 for (int s = 0; s < SZH_U; ++s) {
                     const int k = k0 + s;
-                    xr[s][l] = (inb[l] && (unsigned)k < (unsigned)r2) ? a.data[rowoff[l] + k] : (T)0;
+                    dst[s][l] = (inb[l] && (unsigned)k < (unsigned)r2) ? src[rowoff[l] + k] : (T)0;
                 }
             }
         }
@@ -322,7 +325,7 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, uint16_t *cring
         SZH_UNROLL
         for (int s = 0; s < SZH_U; ++s) load_halo(t0 + s, hr[s]);
         if (DEC) { while (filled < t0 + SZH_U && filled < r2) { move_codes(filled); filled += 16; } } // ring holds columns < filled
-        else load_x(t0);
+        load_x(t0);
         SZH_UNROLL
         for (int s = 0; s < SZH_U; ++s) {
             const int t = t0 + s;
@@ -418,7 +421,7 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, uint16_t *cring
                     }
                     nv = p + (T)(2 * (c - radius)) * eb;
                     if (USEMEAN && is_mean) nv = mean;
-                    if (act && c0 == 0) nv = a.out[rowoff[l] + k];                  // pre-scattered unpredictable value
+                    if (act && c0 == 0) nv = ov[s][l];                              // pre-scattered unpredictable value (read at the top of the trip)
                     ov[s][l] = nv;
                 }
                 // publish faces for the pencils to the right / below

@@ -505,18 +505,6 @@ __global__ __launch_bounds__(256) void k_unpack_lor(const uint8_t *__restrict__ 
 
 // ------------------------------------------------------------------ Huffman bit packing
 #define SZH_ENC_CHUNK 2048 /* symbols per workgroup: 256 threads x 8 */
-__global__ __launch_bounds__(256) void k_chunk_bits(const uint16_t *__restrict__ codes, int64_t n, const uint8_t *__restrict__ len, u64 *chunk_bits)
-{
-    __shared__ u64 sh[8];
-    const int64_t t0 = (int64_t)blockIdx.x * SZH_ENC_CHUNK + threadIdx.x * 8;
-    unsigned s = 0;
-    for (int q = 0; q < 8; ++q) { const int64_t i = t0 + q; if (i < n) s += len[codes[i]]; }
-    u64 ws = wave_sum_u64((u64)s);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ws;
-    __syncthreads();
-    if (threadIdx.x == 0) chunk_bits[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
-}
-
 // OR `nbits` (<= 64) right-aligned bits of `v` into the big-endian bit string held in 32-bit LDS words
 __device__ __forceinline__ void lds_put_bits(unsigned *buf, unsigned bitpos, u64 v, int nbits)
 {
@@ -530,29 +518,59 @@ __device__ __forceinline__ void lds_put_bits(unsigned *buf, unsigned bitpos, u64
     }
 }
 
+// Two passes over the block-ordered codes: (1) bits per chunk of 2048 symbols, (scan), (2) pack each chunk's bits in LDS and
+// write whole 32-bit words.  (A single-pass variant with decoupled look-back was measured slower: 0.79 ms vs 0.3 ms.)
+// Code tables of up to SZH_ENC_TAB symbols are staged in LDS; codes are read as 16-byte vectors.
+#define SZH_ENC_TAB 1024
+__device__ __forceinline__ void enc_load8(const uint16_t *__restrict__ codes, int64_t t0, int64_t n, uint16_t (&c)[8])
+{
+    if (t0 + 8 <= n) { const uint4 w = *reinterpret_cast<const uint4 *>(codes + t0); __builtin_memcpy(c, &w, 16); }
+    else { for (int q = 0; q < 8; ++q) c[q] = t0 + q < n ? codes[t0 + q] : (uint16_t)0; }
+}
+__global__ __launch_bounds__(256) void k_chunk_bits(const uint16_t *__restrict__ codes, int64_t n, const uint8_t *__restrict__ len, unsigned nsym,
+                                                    u64 *chunk_bits)
+{
+    __shared__ u64 sh[8];
+    __shared__ uint8_t llen[SZH_ENC_TAB];
+    const bool tab_lds = nsym <= SZH_ENC_TAB;
+    if (tab_lds) { for (unsigned i = threadIdx.x; i < nsym; i += 256) llen[i] = len[i]; __syncthreads(); }
+    const int64_t t0 = (int64_t)blockIdx.x * SZH_ENC_CHUNK + threadIdx.x * 8;
+    uint16_t c[8];
+    enc_load8(codes, t0, n, c);
+    unsigned s = 0;
+    for (int q = 0; q < 8; ++q) if (t0 + q < n) s += tab_lds ? llen[c[q]] : len[c[q]];
+    u64 ws = wave_sum_u64((u64)s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ws;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_bits[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
 // out32: 4-byte aligned base of the stream buffer; bit0: bit position of the payload start in that buffer
 __global__ __launch_bounds__(256) void k_encode(const uint16_t *__restrict__ codes, int64_t n, const u64 *__restrict__ code,
-                                                const uint8_t *__restrict__ len, const u64 *__restrict__ chunk_off, u64 bit0,
+                                                const uint8_t *__restrict__ len, unsigned nsym, const u64 *__restrict__ chunk_off, u64 bit0,
                                                 unsigned *out32)
 {
     __shared__ unsigned buf[SZH_ENC_CHUNK * 2 + 2];
     __shared__ u64 sh[8];
+    __shared__ u64 lcode[SZH_ENC_TAB];
+    __shared__ uint8_t llen[SZH_ENC_TAB];
+    const bool tab_lds = nsym <= SZH_ENC_TAB;
     for (int i = threadIdx.x; i < SZH_ENC_CHUNK * 2 + 2; i += 256) buf[i] = 0;
+    if (tab_lds) { for (unsigned i = threadIdx.x; i < nsym; i += 256) { lcode[i] = code[i]; llen[i] = len[i]; } __syncthreads(); }
     const u64 gbit = bit0 + chunk_off[blockIdx.x];
     const unsigned lead = (unsigned)(gbit & 31);
     const int64_t t0 = (int64_t)blockIdx.x * SZH_ENC_CHUNK + threadIdx.x * 8;
-    unsigned c[8]; unsigned l[8]; unsigned s = 0;
+    uint16_t c[8]; unsigned l[8]; unsigned s = 0;
+    enc_load8(codes, t0, n, c);
     for (int q = 0; q < 8; ++q) {
-        const int64_t i = t0 + q;
-        c[q] = i < n ? codes[i] : 0;
-        l[q] = i < n ? len[c[q]] : 0;
+        l[q] = t0 + q < n ? (tab_lds ? (unsigned)llen[c[q]] : (unsigned)len[c[q]]) : 0u;
         s += l[q];
     }
     u64 tot;
     const u64 ex = block_excl_scan_256((u64)s, sh, &tot); // also orders the LDS clear above
     unsigned pos = lead + (unsigned)ex;
     for (int q = 0; q < 8; ++q) {
-        if (l[q]) { lds_put_bits(buf, pos, code[c[q]], (int)l[q]); pos += l[q]; }
+        if (l[q]) { lds_put_bits(buf, pos, tab_lds ? lcode[c[q]] : code[c[q]], (int)l[q]); pos += l[q]; }
     }
     __syncthreads();
     const unsigned nwords = (unsigned)((lead + tot + 31) >> 5);
