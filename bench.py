@@ -129,8 +129,18 @@ def main():
 
     quant_avg_ms = float(np.mean(quant_ms))
     achieved = nbytes_in / (quant_avg_ms * 1e-3) / 1e9
+    # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside the timed process);
+    # only valid for the workload it was measured on
+    traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_pencil.json")))
+        if n == EDGE:
+            traffic = pm["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     roofline = {"bound": "hbm", "kernel": "k_pencil<float,false>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "traffic_source": "profiles/r01_pmc_traffic_pencil.json (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes)",
                 "algorithmic_bytes_per_launch": nbytes_in, "avg_kernel_ms": round(quant_avg_ms, 4)}
 
     cpu = None
