@@ -437,10 +437,11 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, uint16_t *cring
                         for (int w = 0; w < NW; ++w) B::st_gran(a.faceI + (pubIoff[l] + k) * NW + w, w2[w]);
                     }
                 }
-                // roll the neighbour state.  Lanes outside the k range see zero inputs and zero neighbours, so
-                // they produce zeros by themselves; only the mean shortcut and stale pre-scattered values need masking.
+                // roll the neighbour state.  Lanes outside the k range must hand on ZEROS (the reference's zero halo).  With
+                // Lorenzo-only data they produce zeros by themselves (zero input, zero neighbours); the mean shortcut, stale
+                // pre-scattered values and a regression plane (non-zero prediction at k < 0) need the mask.
                 if (detail && s == 0 && t0 / SZH_U < 64 && B::lane(l) == 0) dt[(t0 / SZH_U) * 4 + 1] = B::clock();
-                cur[l] = (USEMEAN || DEC) ? (act ? nv : (T)0) : nv;
+                cur[l] = (USEMEAN || DEC || HASREG) ? (act ? nv : (T)0) : nv;
                 A1[l] = nA; B1[l] = nB; C1[l] = nC;
                 // advance along dim2
                 if (HASREG && act) {

@@ -48,3 +48,19 @@ def m_field(n, dtype=np.float32):
     out[:h] = s_field(h, n, n, dtype)
     out[h:] = l_field(n - h, n, n, dtype, z0=h, n_for_hash=n)
     return out
+
+
+def near_zero_planes(nz, ny, nx, dtype=np.float32, seed=5):
+    """Noisy planes close to zero: the regression predictor wins, and its plane evaluated OUTSIDE the array (k < 0) is a small,
+    quantisable value.  Next to Lorenzo blocks this checks that such values never leak into the zero halo of the array faces."""
+    z, y, x = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    rng = np.random.default_rng(seed)
+    return np.ascontiguousarray(((0.3 * z + 0.5 * y + 0.2 * x) * 2e-5 + (rng.random((nz, ny, nx)) - 0.5) * 1.2e-4).astype(dtype))
+
+
+def reg_beside_lorenzo(nz, ny, nx, dtype=np.float32):
+    """near_zero_planes for j < ny/2 - 1 (regression blocks), a scaled S-field beyond (Lorenzo blocks that read them as neighbours)."""
+    d = s_field(nz, ny, nx, dtype) * np.dtype(dtype).type(0.02)
+    h = ny // 2 - 1
+    d[:, :h, :] = near_zero_planes(nz, h, nx, dtype)
+    return np.ascontiguousarray(d)

@@ -23,7 +23,7 @@ def sz(built):
 
 
 def _fields():
-    from sz_amd.fields import l_field, m_field, s_field
+    from sz_amd.fields import l_field, m_field, reg_beside_lorenzo, s_field
     rng = np.random.default_rng(0)
     z = s_field(40, 40, 40)
     z[np.abs(z) < 0.7] = 0.0
@@ -44,6 +44,8 @@ def _fields():
         "abs-and-rel": (s_field(24, 32, 40), 2, 1e-3, 1e-4),
         "abs-or-rel": (s_field(24, 32, 40), 3, 1e-5, 1e-4),
         "4d": (s_field(12, 20, 24).reshape(3, 4, 20, 24), 0, 1e-4, 0.0),
+        "reg-beside-lorenzo": (reg_beside_lorenzo(24, 40, 32), 0, 1e-4, 0.0),
+        "reg-beside-lorenzo-f64": (reg_beside_lorenzo(48, 56, 64, np.float64), 0, 1e-4, 0.0),
         "S128": (s_field(128, 128, 128), 0, 1e-4, 0.0),
         "M128": (m_field(128), 0, 1e-4, 0.0),
     }
@@ -147,6 +149,67 @@ def test_baseline_size_properties(sz, anchors):
     hip = C.CDLL("libamdhip64.so")
     hip.hipMemcpy(C.c_void_p(dev_copy.data_ptr()), C.c_void_p(p2), C.c_size_t(n3), 3)
     assert n2 == n3 == n and bytes(dev_copy.cpu().numpy().tobytes()) == host
+    ctx.close()
+
+
+def _roundtrip_quality(sz, d, mode, abs_b, rel_b):
+    """compress + decompress through the public API on host arrays; returns (stream, decoded, psnr with the reference's formula)"""
+    stream = sz.SZ_compress_args(d, mode, abs_b, rel_b)
+    dec = sz.SZ_decompress(stream, d.shape, d.dtype)
+    err = dec.astype(np.float64) - d.astype(np.float64)
+    rng = float(d.max()) - float(d.min())
+    psnr = 20 * np.log10(rng) - 10 * np.log10(float(np.mean(err * err)))
+    return stream, dec, psnr, float(np.abs(err).max())
+
+
+def test_config3_adaptive_field_matches_recorded_reference(sz, anchors):
+    """BASELINE configs[2] at the size the survey recorded (256^3 M-field, half Lorenzo / half regression blocks, ABS 1e-4):
+    stream size, PSNR (6 decimals) and the error bound equal the unmodified reference's numbers -- no oracle involved."""
+    from sz_amd.fields import m_field
+    a = anchors["M256_f32_abs1e-4_best_speed"]
+    d = m_field(256)
+    stream, dec, psnr, maxerr = _roundtrip_quality(sz, d, sz.ABS, 1e-4, 0.0)
+    assert len(stream) == a["stream_bytes"]
+    assert f"{psnr:.6f}" == f"{a['psnr']:.6f}"
+    assert maxerr <= 1e-4
+    st = sz.SZ_hip_last_stats() if hasattr(sz, "SZ_hip_last_stats") else None
+    if st is not None and st.n_blocks:
+        assert abs(st.n_reg_blocks / st.n_blocks - a["reg_fraction"]) < 1e-3
+
+
+def test_config4_recorded_f64_rel_slab(sz, anchors):
+    """One slab of BASELINE configs[3] at the size the survey recorded (128x256x256 float64 S-field, REL 1e-3)."""
+    from sz_amd.fields import s_field
+    a = anchors["S_f64_slab_128x256x256_rel1e-3_best_speed"]
+    d = s_field(128, 256, 256, np.float64)
+    stream, dec, psnr, maxerr = _roundtrip_quality(sz, d, sz.REL, 0.0, 1e-3)
+    assert len(stream) == a["stream_bytes"]
+    assert f"{psnr:.6f}" == f"{a['psnr']:.6f}"
+    assert maxerr <= a["eb"] * (1 + 1e-12)
+
+
+@pytest.mark.slow
+def test_config4_full_size_slab_properties(sz):
+    """The per-GPU unit of BASELINE configs[3]: a 128x1024x1024 float64 slab (1 GiB) of the 1024^3 S-field, REL 1e-3 with the
+    bound taken from the GLOBAL value range (what the all-reduce of sz_amd.slab.global_minmax delivers).  Too large for the
+    CPU oracle in test time, so size-independent properties: every point within the bound, a second compress/decompress
+    generation of the decoded array stays within the bound of the first, and the stream of this smooth field beats 20:1."""
+    import torch
+    from sz_amd.fields import s_field
+    d = s_field(128, 1024, 1024, np.float64, z0=3 * 128)          # slab 3 of 8
+    eb = 1e-3 * (2 * 1.4834466)                                      # range of the full field (BASELINE.md)
+    x = torch.from_numpy(d).cuda()
+    ctx = sz.HipContext(0)
+    meta = sz.make_meta(np.float64, err_mode=sz.REL, rel_ratio=1e-3, vmin=-1.4834466, vmax=1.4834466)
+    ptr, n, stats = ctx.compress(x.data_ptr(), True, d.shape, np.float64, eb, meta, out_on_device=True)
+    assert n * 20 < d.nbytes and stats.n_blocks == 21 * 170 * 170
+    dec = torch.empty_like(x)
+    ctx.decompress(ptr, True, n, 4 + 36 + 8, d.shape, np.float64, dec.data_ptr(), True)
+    assert float((dec - x).abs().max().item()) <= eb
+    ptr2, n2, _ = ctx.compress(dec.data_ptr(), True, d.shape, np.float64, eb, meta, out_on_device=True)
+    dec2 = torch.empty_like(x)
+    ctx.decompress(ptr2, True, n2, 4 + 36 + 8, d.shape, np.float64, dec2.data_ptr(), True)
+    assert float((dec2 - dec).abs().max().item()) <= eb          # a second generation stays within the bound of the first
     ctx.close()
 
 

@@ -9,7 +9,7 @@ import pytest
 import sim_lib
 import sz_amd
 from sz_amd import api
-from sz_amd.fields import l_field, m_field, s_field
+from sz_amd.fields import l_field, m_field, reg_beside_lorenzo, s_field
 
 
 def _cases(c1):
@@ -18,7 +18,9 @@ def _cases(c1):
     z[np.abs(z) < 0.7] = 0.0
     return [("S", s_field(24, 24, 40), 1e-4), ("M", m_field(32), 1e-4), ("L", l_field(14, 19, 33), 1e-4),
             ("odd", s_field(17, 25, 38), 1e-4), ("C1", c1, 1e-4), ("M-f64", m_field(24, np.float64), 1e-5),
-            ("mean-rand", rng.random((13, 20, 17), dtype=np.float32), 1e-2), ("mean-zeros", z, 1e-3)]
+            ("mean-rand", rng.random((13, 20, 17), dtype=np.float32), 1e-2), ("mean-zeros", z, 1e-3),
+            # regression blocks whose plane is small at k < 0, next to Lorenzo blocks: nothing may leak into the zero halo
+            ("reg-beside-lorenzo", reg_beside_lorenzo(24, 40, 32), 1e-4), ("reg-beside-lorenzo-f64", reg_beside_lorenzo(24, 40, 32, np.float64), 1e-4)]
 
 
 def test_wavefront_kernel_body_codes_and_reconstruction(oracle, c1_data):
