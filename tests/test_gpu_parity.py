@@ -5,6 +5,7 @@ decoded values: the path is integer/byte work wrapped around IEEE arithmetic eva
 import ctypes
 import hashlib
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -211,6 +212,15 @@ def test_config4_full_size_slab_properties(sz):
     ctx.decompress(ptr2, True, n2, 4 + 36 + 8, d.shape, np.float64, dec2.data_ptr(), True)
     assert float((dec2 - dec).abs().max().item()) <= eb          # a second generation stays within the bound of the first
     ctx.close()
+
+
+def test_differential_fuzz_against_the_oracle(built):
+    """400 random small cases (shape, dtype, field kind, bound mode and size all random): stream byte-identical and decode
+    bit-identical to the oracle.  (7 500 cases were run once in development; tools/gpu_fuzz.py prints the failing seeds.)"""
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_fuzz.py"), "400", "11"], capture_output=True, text=True, timeout=600)
+    tail = [ln for ln in out.stdout.splitlines() if ln.startswith("fuzz:") or ln.startswith("FAIL")]
+    assert tail and tail[-1].startswith("fuzz: 400 cases, 0 failures"), "\n".join(tail[-10:]) + out.stderr[-2000:]
 
 
 def test_config1_through_a_plain_c_caller(built, anchors, tmp_path):
