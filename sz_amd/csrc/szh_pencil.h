@@ -17,6 +17,13 @@
 // "handoff-1to1"/R2).  Pencils are started in anti-diagonal order through an atomic ticket so
 // every dependency is already resident: no deadlock, no grid barrier.
 //
+// Tiles.  A workgroup owns a TILE of TPI x TPJ neighbouring pencils (float: 4 x 4 = 16 wavefronts = one whole CU;
+// double: 4 x 2), one wavefront per pencil.  Faces between pencils of the same tile never leave the CU: the producer
+// writes them into an LDS ring and bumps an LDS step counter, the consumer reads them a few hundred cycles later.
+// Only faces that cross a tile boundary travel as granules through the fabric, so the chain of slow hops across a
+// 512 x 512 cross-section is 30 long instead of 126.  The third producer of a pencil, (I-1,J-1), is not needed: its
+// corner column is the row-7 halo of (I-1,J), which forwards it as a ninth row of its I-face.
+//
 // The body is written once and instantiated by two back ends:
 //   * the HIP kernel (szh_kernels.hip): NL = 1 value per thread, collectives = DPP/bpermute;
 //   * a CPU lane simulator used ONLY by tests/ (tests/sim): NL = 64, collectives = array moves.
@@ -34,10 +41,10 @@ template <class T> struct szh_qargs {
     const T *coef;            // decoded regression coefficients, SoA [4][nblocks]
     T eb, recip, mean;
     int cap, radius, use_mean;
-    szh_u64 *faceI, *faceJ;   // granule buffers: [pencil][8 rows][r2][NW]
+    szh_u64 *faceI, *faceJ;   // granule buffers: faceJ [pencil][8 rows][r2][NW], faceI [pencil][9 rows][r2][NW] (row 8 = forwarded corner column)
     unsigned epoch;
     int nI, nJ;
-    const unsigned *order;    // ticket -> (I<<16)|J, anti-diagonal order
+    const unsigned *order;    // ticket -> (tile row << 16) | tile column, anti-diagonal order over the tiles
     unsigned *ticket;
     unsigned *err;            // set to 1 if a halo wait timed out
     szh_u64 *progress;        // per pencil: {epoch, steps completed}; a cheap "has my neighbour got going" word
@@ -74,6 +81,16 @@ template <> struct szh_gran<double> {
     }
 };
 
+// LDS of one pencil inside its tile's workgroup.  B::ring(k) maps a column to its ring slot; B::face_slot(I,J,nJ) indexes the
+// per-pencil arrays (tile-local on the GPU, global in the CPU simulator).
+template <class T> struct szh_tile_lds {
+    uint16_t *cring;          // [SZH_XC][64] this pencil's quantisation codes in flight
+    T *faces;                 // [slots][RL][SZH_FROWS] face rings of every pencil of the tile: rows 0-7 = J-face (il), 8-15 = I-face (jl),
+                              // 16 = corner column forwarded to the pencil below
+    unsigned *cstep;          // [slots] steps completed (all face values of those steps are in the ring)
+};
+#define SZH_FROWS 17
+
 #define SZH_U 16 /* steps per loop trip: a trip first requests all of its inputs (values and halo granules), then steps */
 #if defined(__HIPCC__)
 #define SZH_UNROLL _Pragma("unroll")
@@ -101,12 +118,15 @@ SZH_HD int szh_quant_sel(T x, T pred, T eb, T recip, int capacity, int radius, T
 
 // B: back end. Requires: NL, lane(l), shfl_up(dst,src,d), readlane(src,lane), all(pred),
 //    ld_gran(p), st_gran(p,v), ld_flag(p), st_flag(p,v), backoff(n), nap(), clock(), where(),
-//    ld16(p, T(&)[16/sizeof T]), st16(p, const T(&)[...]) -- one 16-byte vector access (4-byte aligned for 4/8-byte T).
+//    ld16(p, T(&)[16/sizeof T]), st16(p, const T(&)[...]) -- one 16-byte vector access (4-byte aligned for 4/8-byte T),
+//    lds_ld(p), lds_st(p,v), lds_ld_u(p) (wavefront-uniform address), lds_fence() (orders this wavefront's LDS accesses),
+//    RL / ring(k) (face-ring length), face_stride(r2) (elements per pencil slot), TPI / TPJ (tile shape), face_slot(I,J,nJ), same_tile(I,J,I2,J2).
 // HASREG: the pencil touches at least one regression block (otherwise the block bookkeeping and the
 //         regression quantiser are compiled out); USEMEAN: the stream's use_mean flag.
 template <class T, bool DEC, bool HASREG, bool USEMEAN, class B>
-SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, uint16_t *cring)
+SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_lds<T> &L)
 {
+    uint16_t *const cring = L.cring;
     constexpr int NL = B::NL;
     constexpr int NW = szh_gran<T>::NW;
     const szh_geom3 &G = a.G;
@@ -116,11 +136,20 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, uint16_t *cring
     const T eb = a.eb, recip = a.recip, mean = a.mean;
     const bool pubJ = (J + 1 < a.nJ), pubI = (I + 1 < a.nI);
 
+    // ---- this pencil's neighbours: inside the tile (LDS) or across a tile boundary (granules) ----
+    const bool predJ_lds = J > 0 && B::same_tile(I, J, I, J - 1), predI_lds = I > 0 && B::same_tile(I, J, I - 1, J);
+    const bool consJ_lds = pubJ && B::same_tile(I, J, I, J + 1), consI_lds = pubI && B::same_tile(I, J, I + 1, J);
+    const int myslot = B::face_slot(I, J, a.nJ);
+    const int slotPJ = predJ_lds ? B::face_slot(I, J - 1, a.nJ) : 0, slotPI = predI_lds ? B::face_slot(I - 1, J, a.nJ) : 0;
+    const int slotCJ = consJ_lds ? B::face_slot(I, J + 1, a.nJ) : 0, slotCI = consI_lds ? B::face_slot(I + 1, J, a.nJ) : 0;
+    T *const myface = L.faces + (int64_t)myslot * B::face_stride(r2);
+
     // ---- per-lane constants ----
-    int il[NL], jl[NL], skew[NL], hskew[NL];
-    bool inb[NL], hrole[NL], pJ[NL], pI[NL];
+    int il[NL], jl[NL], skew[NL], hskew[NL], hkind[NL], hrowl[NL];
+    bool inb[NL], pJ[NL], pI[NL], pC[NL];
     int64_t rowoff[NL], blkrow[NL], hoff[NL], pubJoff[NL], pubIoff[NL];
     const szh_u64 *hbuf[NL];
+    const T *hface[NL];
     T fii[NL], fjj[NL];
     SZH_FORL {
         const int lane = B::lane(l);
@@ -134,28 +163,33 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, uint16_t *cring
         rowoff[l] = (int64_t)ic * G.d0 + (int64_t)jc * G.d1;
         blkrow[l] = ((int64_t)b0 * G.g1.num + b1) * nbz;
         skew[l] = il[l] + jl[l];
-        // halo role: which granule row this lane fetches, and for which k = t - hskew
-        hrole[l] = false; hoff[l] = 0; hskew[l] = 0; hbuf[l] = a.faceJ;
+        // halo role: which face row this lane fetches (for k = t - hskew), and from where: hkind 0 none, 1 granules, 2 LDS ring
+        hkind[l] = 0; hoff[l] = 0; hskew[l] = 0; hbuf[l] = a.faceJ; hrowl[l] = 0; hface[l] = L.faces;
+        const int64_t pencJ = (int64_t)I * a.nJ + (J - 1), pencI = (int64_t)(I - 1) * a.nJ + J;
         if (jl[l] == 0 && J > 0 && i < r0) {           // (i, 8J-1, k): J-face of pencil (I,J-1), row il
-            hrole[l] = true; hbuf[l] = a.faceJ; hskew[l] = il[l];
-            hoff[l] = (((int64_t)I * a.nJ + (J - 1)) * 8 + il[l]) * r2;
+            hskew[l] = il[l];
+            if (predJ_lds) { hkind[l] = 2; hrowl[l] = il[l]; hface[l] = L.faces + (int64_t)slotPJ * B::face_stride(r2); }
+            else { hkind[l] = 1; hbuf[l] = a.faceJ; hoff[l] = (pencJ * 8 + il[l]) * r2; }
         } else if (il[l] == 0 && jl[l] > 0 && I > 0 && j < r1) { // (8I-1, j, k): I-face of (I-1,J), row jl
-            hrole[l] = true; hbuf[l] = a.faceI; hskew[l] = jl[l];
-            hoff[l] = (((int64_t)(I - 1) * a.nJ + J) * 8 + jl[l]) * r2;
-        } else if (lane == 63 && I > 0) {               // for lane 0: (8I-1, 8J, k)
-            hrole[l] = true; hbuf[l] = a.faceI; hskew[l] = 0;
-            hoff[l] = (((int64_t)(I - 1) * a.nJ + J) * 8 + 0) * r2;
-        } else if (lane == 62 && I > 0 && J > 0) {      // for lane 0: (8I-1, 8J-1, k)
-            hrole[l] = true; hbuf[l] = a.faceI; hskew[l] = 0;
-            hoff[l] = (((int64_t)(I - 1) * a.nJ + (J - 1)) * 8 + 7) * r2;
+            hskew[l] = jl[l];
+            if (predI_lds) { hkind[l] = 2; hrowl[l] = 8 + jl[l]; hface[l] = L.faces + (int64_t)slotPI * B::face_stride(r2); }
+            else { hkind[l] = 1; hbuf[l] = a.faceI; hoff[l] = (pencI * 9 + jl[l]) * r2; }
+        } else if (lane == 63 && I > 0) {               // for lane 0: (8I-1, 8J, k) = I-face of (I-1,J), row 0
+            if (predI_lds) { hkind[l] = 2; hrowl[l] = 8; hface[l] = L.faces + (int64_t)slotPI * B::face_stride(r2); }
+            else { hkind[l] = 1; hbuf[l] = a.faceI; hoff[l] = (pencI * 9 + 0) * r2; }
+        } else if (lane == 62 && I > 0 && J > 0) {      // for lane 0: (8I-1, 8J-1, k), forwarded by (I-1,J) as its ninth row
+            if (predI_lds) { hkind[l] = 2; hrowl[l] = 16; hface[l] = L.faces + (int64_t)slotPI * B::face_stride(r2); }
+            else { hkind[l] = 1; hbuf[l] = a.faceI; hoff[l] = (pencI * 9 + 8) * r2; }
         }
         pubJoff[l] = (((int64_t)I * a.nJ + J) * 8 + il[l]) * r2;
-        pubIoff[l] = (((int64_t)I * a.nJ + J) * 8 + jl[l]) * r2;
+        pubIoff[l] = (((int64_t)I * a.nJ + J) * 9 + jl[l]) * r2;
         pJ[l] = pubJ && jl[l] == 7 && inb[l];
         pI[l] = pubI && il[l] == 7 && inb[l];
-        if (a.dbg == 1) { hrole[l] = false; pJ[l] = false; pI[l] = false; }
-        if (a.dbg == 2) { pJ[l] = false; pI[l] = false; }
+        pC[l] = pubI && J > 0 && il[l] == 7 && jl[l] == 0 && inb[l];   // forwards its own halo value: the corner column of (I+1,J)
+        if (a.dbg == 1) { hkind[l] = 0; pJ[l] = false; pI[l] = false; pC[l] = false; }
+        if (a.dbg == 2) { pJ[l] = false; pI[l] = false; pC[l] = false; }
     }
+    const int64_t pubCoff = (((int64_t)I * a.nJ + J) * 9 + 8) * r2;
 
     // ---- per-lane block tracking along dim2 (only when the pencil touches regression blocks) ----
     int kk[NL], bz[NL], bk[NL];
@@ -279,13 +313,25 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, uint16_t *cring
         }
     };
 
-    auto load_halo = [&](int t, szh_u64 (&hv)[NW][NL]) {
+    auto load_halo = [&](int t, szh_u64 (&hv)[NW][NL]) {    // granule-sourced rows only
         SZH_FORL {
             const int kh = t - hskew[l];
-            const bool hact = hrole[l] && (unsigned)kh < (unsigned)r2;
+            const bool hact = hkind[l] == 1 && (unsigned)kh < (unsigned)r2;
             SZH_UNROLL
             for (int w = 0; w < NW; ++w) hv[w][l] = hact ? B::ld_gran(hbuf[l] + (hoff[l] + kh) * NW + w) : 0;
         }
+    };
+    // bounded wait until an LDS step counter reaches `need`; returns the value seen
+    auto wait_cstep = [&](int slot, int need) -> int {
+        int v = (int)B::lds_ld_u(L.cstep + slot);
+        unsigned spins = 0;
+        while (v < need && !a.dbg) {
+            if (++spins > (1u << 22)) { SZH_FORL { if (B::lane(l) == 0) B::st_flag(a.err, 1u); } break; }
+            if ((spins & 1023u) == 0 && B::ld_flag(a.err) != 0) break;
+            B::backoff(1);
+            v = (int)B::lds_ld_u(L.cstep + slot);
+        }
+        return v;
     };
 
     // rolling neighbour state (values at the previous step)
@@ -308,8 +354,8 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, uint16_t *cring
             SZH_FORL {
                 ok[l] = true;
                 const int lane = B::lane(l);
-                if (lane == 0 && J > 0) { const szh_u64 p = B::ld_gran(a.progress + ((int64_t)I * a.nJ + (J - 1))); ok[l] = (p >> 32) == a.epoch && p >= want; }
-                if (lane == 1 && I > 0) { const szh_u64 p = B::ld_gran(a.progress + ((int64_t)(I - 1) * a.nJ + J)); ok[l] = (p >> 32) == a.epoch && p >= want; }
+                if (lane == 0 && J > 0 && !predJ_lds) { const szh_u64 p = B::ld_gran(a.progress + ((int64_t)I * a.nJ + (J - 1))); ok[l] = (p >> 32) == a.epoch && p >= want; }
+                if (lane == 1 && I > 0 && !predI_lds) { const szh_u64 p = B::ld_gran(a.progress + ((int64_t)(I - 1) * a.nJ + J)); ok[l] = (p >> 32) == a.epoch && p >= want; }
             }
             if (B::all(ok)) break;
             if (++naps > (1u << 18) || B::ld_flag(a.err) != 0) break; // bounded; the granule waits below still guard correctness
@@ -322,6 +368,12 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, uint16_t *cring
     szh_u64 *dt = a.trace ? a.trace + (int64_t)a.nI * a.nJ * 8 : nullptr;
     for (int t0 = 0; t0 < tsteps; t0 += SZH_U) {
         if (detail && t0 / SZH_U < 64) { SZH_FORL { if (B::lane(l) == 0) dt[(t0 / SZH_U) * 4 + 0] = B::clock(); } }
+        // in-tile consumers must have read the ring slots this trip overwrites (they read column k no later than their step k+7)
+        if (consJ_lds) wait_cstep(slotCJ, t0 + SZH_U - B::RL);
+        if (consI_lds) wait_cstep(slotCI, t0 + SZH_U - B::RL);
+        // how far are the in-tile producers?  (step t needs their step t+7 finished)
+        int pstepJ = predJ_lds ? (int)B::lds_ld_u(L.cstep + slotPJ) : (1 << 30);
+        int pstepI = predI_lds ? (int)B::lds_ld_u(L.cstep + slotPI) : (1 << 30);
         SZH_UNROLL
         for (int s = 0; s < SZH_U; ++s) load_halo(t0 + s, hr[s]);
         if (DEC) { while (filled < t0 + SZH_U && filled < r2) { move_codes(filled); filled += 16; } } // ring holds columns < filled
@@ -333,15 +385,19 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, uint16_t *cring
             //    Slow path (cold): poll with fresh loads into a private copy; it never touches the ring registers.
             T hval[NL];
             {
+                // in-tile producers: their step t+7 must be complete (no halo is needed once t - hskew >= r2)
+                const int need = t + 8 < tsteps ? t + 8 : tsteps;
+                if (pstepJ < need) pstepJ = wait_cstep(slotPJ, need);
+                if (pstepI < need) pstepI = wait_cstep(slotPI, need);
                 szh_u64 g[NW][NL];
                 bool ok[NL], hact[NL];
                 SZH_FORL {
                     const int kh = t - hskew[l];
-                    hact[l] = hrole[l] && (unsigned)kh < (unsigned)r2;
+                    hact[l] = hkind[l] != 0 && (unsigned)kh < (unsigned)r2;
                     bool v = true;
                     SZH_UNROLL
                     for (int w = 0; w < NW; ++w) { g[w][l] = hr[s][w][l]; v = v && ((unsigned)(g[w][l] >> 32) == a.epoch); }
-                    ok[l] = !hact[l] || v;
+                    ok[l] = !hact[l] || hkind[l] == 2 || v;
                 }
                 if (!B::all(ok) && !a.dbg) {
                     unsigned spins = 0;
@@ -370,7 +426,10 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, uint16_t *cring
                     szh_u64 w2[NW];
                     SZH_UNROLL
                     for (int w = 0; w < NW; ++w) w2[w] = g[w][l];
-                    hval[l] = hact[l] ? szh_gran<T>::unpack(w2) : (T)0;
+                    const int kh = t - hskew[l];
+                    T hv = (T)0;
+                    if (hact[l]) hv = hkind[l] == 2 ? B::lds_ld(hface[l] + B::ring(kh) * SZH_FROWS + hrowl[l]) : szh_gran<T>::unpack(w2);
+                    hval[l] = hv;
                 }
             }
             // -- neighbours through cross-lane moves (values of the previous step) --
@@ -424,17 +483,26 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, uint16_t *cring
                     if (act && c0 == 0) nv = ov[s][l];                              // pre-scattered unpredictable value (read at the top of the trip)
                     ov[s][l] = nv;
                 }
-                // publish faces for the pencils to the right / below
+                // publish faces for the pencils to the right / below: LDS ring inside the tile, granules across a tile boundary
                 {
+                    const int slotk = B::ring(act ? k : 0) * SZH_FROWS;
                     szh_u64 w2[NW];
                     szh_gran<T>::pack(nv, a.epoch, w2);
                     if (act && pJ[l]) {
-                        SZH_UNROLL
-                        for (int w = 0; w < NW; ++w) B::st_gran(a.faceJ + (pubJoff[l] + k) * NW + w, w2[w]);
+                        if (consJ_lds) B::lds_st(myface + slotk + il[l], nv);
+                        else { SZH_UNROLL for (int w = 0; w < NW; ++w) B::st_gran(a.faceJ + (pubJoff[l] + k) * NW + w, w2[w]); }
                     }
                     if (act && pI[l]) {
-                        SZH_UNROLL
-                        for (int w = 0; w < NW; ++w) B::st_gran(a.faceI + (pubIoff[l] + k) * NW + w, w2[w]);
+                        if (consI_lds) B::lds_st(myface + slotk + 8 + jl[l], nv);
+                        else { SZH_UNROLL for (int w = 0; w < NW; ++w) B::st_gran(a.faceI + (pubIoff[l] + k) * NW + w, w2[w]); }
+                    }
+                    if (act && pC[l]) {             // lane (7,0): its halo value IS the corner column of the pencil below, same k
+                        if (consI_lds) B::lds_st(myface + slotk + 16, hval[l]);
+                        else {
+                            szh_u64 w3[NW];
+                            szh_gran<T>::pack(hval[l], a.epoch, w3);
+                            SZH_UNROLL for (int w = 0; w < NW; ++w) B::st_gran(a.faceI + (pubCoff + k) * NW + w, w3[w]);
+                        }
                     }
                 }
                 // roll the neighbour state.  Lanes outside the k range see zero inputs and zero neighbours, so
@@ -462,6 +530,11 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, uint16_t *cring
                     }
                 }
             }
+            // step t is complete: its face values are in the ring (LDS executes a wavefront's accesses in order)
+            if (consJ_lds || consI_lds || predJ_lds || predI_lds) {   // consumers wait for it; producers watch it for ring space
+                B::lds_fence();
+                SZH_FORL { if (B::lane(l) == 0) B::lds_st(L.cstep + myslot, (unsigned)(t + 1)); }
+            }
         }
         if (detail && t0 / SZH_U < 64) { SZH_FORL { if (B::lane(l) == 0) dt[(t0 / SZH_U) * 4 + 2] = B::clock(); } }
         if (DEC) store_out(t0);
@@ -472,7 +545,9 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, uint16_t *cring
         if (detail && t0 / SZH_U < 64) { SZH_FORL { if (B::lane(l) == 0) dt[(t0 / SZH_U) * 4 + 3] = B::clock(); } }
         if (a.trace && t0 == 0) tr_first = B::clock();
         // tell the consumers how far this pencil has got (one word, one lane)
-        SZH_FORL { if (B::lane(l) == 0) B::st_gran(a.progress + ((int64_t)I * a.nJ + J), ((szh_u64)a.epoch << 32) | (unsigned)(t0 + SZH_U)); }
+        if ((pubJ && !consJ_lds) || (pubI && !consI_lds)) {
+            SZH_FORL { if (B::lane(l) == 0) B::st_gran(a.progress + ((int64_t)I * a.nJ + J), ((szh_u64)a.epoch << 32) | (unsigned)(t0 + SZH_U)); }
+        }
     }
     if (!DEC) { for (; flushed < r2; flushed += 16) move_codes(flushed); }
     if (a.trace) {
@@ -510,21 +585,25 @@ SZH_HD bool szh_pencil_has_reg(const szh_qargs<T> &a, int I, int J)
     return !B::all(none);
 }
 
-// cring: SZH_XC*64 uint16_t of LDS (HIP) / plain memory (simulator) private to this wavefront
+// L: this pencil's view of its tile's LDS (HIP) / plain memory (simulator); face rings and step counters must be zero at launch
 template <class T, bool DEC, class B>
-SZH_HD void szh_pencil_run(const szh_qargs<T> &a, int I, int J, uint16_t *cring)
+SZH_HD void szh_pencil_run(const szh_qargs<T> &a, int I, int J, const szh_tile_lds<T> &L)
 {
+#ifdef SZH_EXP_NOREG
+    const bool hasreg = false;
+#else
     const bool hasreg = szh_pencil_has_reg<T, B>(a, I, J);
+#endif
     if (a.use_mean) {
-        if (hasreg) szh_pencil_body<T, DEC, true, true, B>(a, I, J, cring);
-        else szh_pencil_body<T, DEC, false, true, B>(a, I, J, cring);
+        if (hasreg) szh_pencil_body<T, DEC, true, true, B>(a, I, J, L);
+        else szh_pencil_body<T, DEC, false, true, B>(a, I, J, L);
     } else {
-        if (hasreg) szh_pencil_body<T, DEC, true, false, B>(a, I, J, cring);
-        else szh_pencil_body<T, DEC, false, false, B>(a, I, J, cring);
+        if (hasreg) szh_pencil_body<T, DEC, true, false, B>(a, I, J, L);
+        else szh_pencil_body<T, DEC, false, false, B>(a, I, J, L);
     }
 }
 
-// anti-diagonal start order of the pencils: every dependency of a pencil has a smaller ticket
+// anti-diagonal start order (of the tiles): every dependency has a smaller ticket
 inline void szh_fill_pencil_order(int nI, int nJ, unsigned *order)
 {
     int n = 0;

@@ -79,12 +79,44 @@ __device__ __forceinline__ u64 block_excl_scan_256(u64 v, u64 *sh, u64 *total)
 }
 
 // ------------------------------------------------------------------ the wavefront kernel
+// TPI x TPJ pencils per workgroup (one wavefront each); RL = columns of a face ring
+template <int TPI_, int TPJ_, int RL_>
 struct GpuBackend {
     static constexpr int NL = 1;
+    static constexpr int TPI = TPI_, TPJ = TPJ_, RL = RL_;
+    __device__ static int ring(int k) { return k & (RL - 1); }
+    __device__ static int face_stride(int) { return RL * SZH_FROWS; }
+    __device__ static int face_slot(int I, int J, int) { return (I % TPI) * TPJ + (J % TPJ); }
+    __device__ static bool same_tile(int I, int J, int I2, int J2) { return I / TPI == I2 / TPI && J / TPJ == J2 / TPJ; }
     __device__ static int lane(int) { return (int)(threadIdx.x & 63); }
     template <class T> __device__ static void shfl_up(T (&dst)[1], const T (&src)[1], int d) { dst[0] = __shfl_up(src[0], d, 64); }
     template <class T> __device__ static T readlane(const T (&src)[1], int lane) { return __shfl(src[0], lane, 64); }
     __device__ static bool all(const bool (&p)[1]) { return __all(p[0] ? 1 : 0) != 0; }
+    // LDS face rings of the tile: volatile ds_* accesses (a wavefront's LDS accesses execute in program order)
+#ifdef SZH_HIPSIM
+    template <class E> __device__ static E lds_ld(const E *p)
+    {
+        E v;
+        if (sizeof(E) == 8) { const uint64_t u = __atomic_load_n((const uint64_t *)p, __ATOMIC_RELAXED); memcpy(&v, &u, sizeof(E)); }
+        else if (sizeof(E) == 4) { const uint32_t u = __atomic_load_n((const uint32_t *)p, __ATOMIC_RELAXED); memcpy(&v, &u, sizeof(E)); }
+        else { const uint16_t u = __atomic_load_n((const uint16_t *)p, __ATOMIC_RELAXED); memcpy(&v, &u, sizeof(E)); }
+        return v;
+    }
+    template <class E> __device__ static void lds_st(E *p, E v)
+    {
+        if (sizeof(E) == 8) { uint64_t u; memcpy(&u, &v, sizeof(E)); __atomic_store_n((uint64_t *)p, u, __ATOMIC_RELAXED); }
+        else if (sizeof(E) == 4) { uint32_t u; memcpy(&u, &v, sizeof(E)); __atomic_store_n((uint32_t *)p, u, __ATOMIC_RELAXED); }
+        else { uint16_t u; memcpy(&u, &v, sizeof(E)); __atomic_store_n((uint16_t *)p, u, __ATOMIC_RELAXED); }
+    }
+    template <class E> __device__ static E lds_ld_u(const E *p) { return __shfl(lds_ld(p), 0, 64); } // one read, so every lane branches alike
+    // lanes are free-running OS threads in the shim: re-converge the wavefront, as lock-step execution would
+    __device__ static void lds_fence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); (void)__all(1); __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+#else
+    template <class E> __device__ static E lds_ld(const E *p) { return *(const volatile __attribute__((address_space(3))) E *)p; }
+    template <class E> __device__ static void lds_st(E *p, E v) { *(volatile __attribute__((address_space(3))) E *)p = v; }
+    template <class E> __device__ static E lds_ld_u(const E *p) { return (E)__builtin_amdgcn_readfirstlane((int)lds_ld(p)); } // scalar: waits on it are s_cmp/s_cbranch
+    __device__ static void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#endif
     __device__ static szh_u64 ld_gran(const szh_u64 *p)
     {
         return __hip_atomic_load(const_cast<szh_u64 *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -114,15 +146,38 @@ struct GpuBackend {
     __device__ static void nap() { __builtin_amdgcn_s_sleep(40); } // ~1 us
 };
 
+// tile shape by element type: a float tile fills a CU (16 wavefronts, <= 128 VGPRs each); double needs twice the registers
+template <class T> struct szh_tile_shape;
+template <> struct szh_tile_shape<float> { static constexpr int TPI = 4, TPJ = 4, RL = 32; };
+template <> struct szh_tile_shape<double> { static constexpr int TPI = 4, TPJ = 2, RL = 32; };
+
 template <class T, bool DEC>
-__global__ __launch_bounds__(64) void k_pencil(szh_qargs<T> a)
+__global__ __launch_bounds__(szh_tile_shape<T>::TPI * szh_tile_shape<T>::TPJ * 64) void k_pencil(szh_qargs<T> a)
 {
-    unsigned tk = 0;
-    if (threadIdx.x == 0) tk = atomicAdd(a.ticket, 1u);
-    tk = __shfl(tk, 0, 64);
-    const unsigned ij = a.order[tk];
-    __shared__ uint16_t cring[SZH_XC * 64];
-    szh_pencil_run<T, DEC, GpuBackend>(a, (int)(ij >> 16), (int)(ij & 0xffffu), cring);
+    using S = szh_tile_shape<T>;
+    using B = GpuBackend<S::TPI, S::TPJ, S::RL>;
+    constexpr int NP = S::TPI * S::TPJ;
+    __shared__ uint16_t cring[NP][SZH_XC * 64];
+    __shared__ T faces[NP * S::RL * SZH_FROWS];
+    __shared__ unsigned cstep[NP];
+    __shared__ unsigned tk_s;
+    if (threadIdx.x < NP) cstep[threadIdx.x] = 0;
+    if (threadIdx.x == 0) tk_s = atomicAdd(a.ticket, 1u);
+    __syncthreads();
+    const unsigned ij = a.order[tk_s];
+    const int w = (int)(threadIdx.x >> 6);
+    const int I = (int)(ij >> 16) * S::TPI + w / S::TPJ, J = (int)(ij & 0xffffu) * S::TPJ + w % S::TPJ;
+    if (I >= a.nI || J >= a.nJ) return;         // ragged tile: this wavefront has no pencil
+#ifndef SZH_HIPSIM
+    // the four wavefronts of a SIMD are one column of the tile (wavefront w runs on SIMD w % 4): the upstream pencil goes first,
+    // so that the chain of hand-offs advances at single-wavefront speed while the downstream pencils fill the issue gaps
+    if (a.dbg != 3) {
+        switch (w / S::TPJ) { case 0: __builtin_amdgcn_s_setprio(3); break; case 1: __builtin_amdgcn_s_setprio(2); break;
+                              case 2: __builtin_amdgcn_s_setprio(1); break; default: __builtin_amdgcn_s_setprio(0); break; }
+    }
+#endif
+    const szh_tile_lds<T> L{cring[w], faces, cstep};
+    szh_pencil_run<T, DEC, B>(a, I, J, L);
 }
 
 // ------------------------------------------------------------------ per-block stage (fit + select)

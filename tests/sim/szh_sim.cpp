@@ -20,6 +20,17 @@ struct SimBackend {
         for (int l = 0; l < 64; ++l) dst[l] = tmp[l];
     }
     template <class T> static T readlane(const T (&src)[64], int lane) { return src[lane]; }
+    // tiles of 2 x 2 pencils: some faces travel through the "LDS" rings, others through granules.  Pencils run one after
+    // the other here, so a ring must keep every column: RL covers all of dim2 and slots are global pencil indices.
+    static constexpr int TPI = 2, TPJ = 2, RL = 1 << 20;
+    static int ring(int k) { return k; }
+    static int face_stride(int r2) { return r2 * SZH_FROWS; }
+    static int face_slot(int I, int J, int nJ) { return I * nJ + J; }
+    static bool same_tile(int I, int J, int I2, int J2) { return I / TPI == I2 / TPI && J / TPJ == J2 / TPJ; }
+    template <class E> static E lds_ld(const E *p) { return *p; }
+    template <class E> static E lds_ld_u(const E *p) { return *p; }
+    template <class E> static void lds_st(E *p, E v) { *p = v; }
+    static void lds_fence() {}
     static bool all(const bool (&p)[64]) { for (int l = 0; l < 64; ++l) if (!p[l]) return false; return true; }
     static szh_u64 ld_gran(const szh_u64 *p) { return *p; }
     static void st_gran(szh_u64 *p, szh_u64 v) { *p = v; }
@@ -38,7 +49,7 @@ static int run_all(szh_qargs<T> a)
 {
     const int r0 = a.G.g0.count, r1 = a.G.g1.count, r2 = a.G.g2.count;
     a.nI = (r0 + 7) / 8; a.nJ = (r1 + 7) / 8;
-    const size_t ng = (size_t)a.nI * a.nJ * 8 * r2 * szh_gran<T>::NW;
+    const size_t ng = (size_t)a.nI * a.nJ * 9 * r2 * szh_gran<T>::NW;
     std::vector<szh_u64> fI(ng, 0), fJ(ng, 0);
     a.faceI = fI.data(); a.faceJ = fJ.data(); a.epoch = 7;
     std::vector<unsigned> order((size_t)a.nI * a.nJ);
@@ -47,8 +58,14 @@ static int run_all(szh_qargs<T> a)
     std::vector<szh_u64> prog((size_t)a.nI * a.nJ, 0);
     a.progress = prog.data(); a.gate_steps = 16; a.backoff = 1;
     std::vector<uint16_t> ring(SZH_XC * 64, 0xDEAD);
-    for (size_t tk = 0; tk < order.size(); ++tk)
-        szh_pencil_run<T, DEC, SimBackend>(a, (int)(order[tk] >> 16), (int)(order[tk] & 0xffff), ring.data());
+    // "LDS": one face array [r2][SZH_FROWS] and one step counter per pencil; poisoned so that an unwritten value shows
+    std::vector<T> faces((size_t)a.nI * a.nJ * r2 * SZH_FROWS, (T)-777);
+    std::vector<unsigned> cstep((size_t)a.nI * a.nJ, 0);
+    for (size_t tk = 0; tk < order.size(); ++tk) {
+        const int I = (int)(order[tk] >> 16), J = (int)(order[tk] & 0xffff);
+        szh_tile_lds<T> L{ring.data(), faces.data(), cstep.data()};
+        szh_pencil_run<T, DEC, SimBackend>(a, I, J, L);
+    }
     return (int)err;
 }
 

@@ -1,5 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-for dbg in 0 1 2; do
-  echo "== SZ_HIP_DBG=$dbg"; SZ_HIP_DBG=$dbg timeout 120 python tools/gpu_trace.py 256 2>&1 | grep -E "ms_quant|pencil \(0,0\)|active duration|gate lag"
+for g in 16; do
+  echo "== gate=$g"; SZ_HIP_GATE_STEPS=$g timeout 120 python tools/gpu_trace.py 512 2>&1 | grep -E "ms_quant|pencil \(32,32\)|pencil \(63,63\)|active duration|end lag|tile|^    |gate of|first_trip of"
 done

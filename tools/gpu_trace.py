@@ -39,3 +39,10 @@ for i in range(min(40, (n + 14 + 15) // 16)):
     r = det[i]
     if r[0] == 0: break
     print("  trip %2d: top->step0 %.2f  steps %.2f  flush %.2f   (top at %.1f)" % (i, (r[1]-r[0])/100, (r[2]-r[1])/100, (r[3]-r[2])/100, us(r[0])))
+
+# tile view: first-trip-end and end times of the pencils of tile (8,8) and of the first pencils of its neighbours
+if n == 512:
+    print("tile (8,8): first_trip end (us) per pencil [pi][pj]; then pencil end")
+    for pi in range(4): print("   ", " ".join("%7.1f" % us(tr[32 + pi, 32 + pj, 2]) for pj in range(4)), "  |  ", " ".join("%7.1f" % us(tr[32 + pi, 32 + pj, 3]) for pj in range(4)))
+    print("gate of (32,32) %.1f ; (32,36) %.1f ; (36,32) %.1f ; (36,36) %.1f" % (us(tr[32, 32, 1]), us(tr[32, 36, 1]), us(tr[36, 32, 1]), us(tr[36, 36, 1])))
+    print("first_trip of (35,32) %.1f (32,35) %.1f (35,35) %.1f" % (us(tr[35, 32, 2]), us(tr[32, 35, 2]), us(tr[35, 35, 2])))
