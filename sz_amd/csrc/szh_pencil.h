@@ -50,6 +50,7 @@ template <class T> struct szh_qargs {
     szh_u64 *progress;        // per pencil: {epoch, steps completed}; a cheap "has my neighbour got going" word
     int gate_steps;           // a pencil starts once both producers have completed this many steps
     int backoff;              // sleep units between two polls of a missing granule
+    int tripgate;             // 1: a tile-edge pencil sleeps at the top of a trip until its producers' progress covers the trip
     int dbg;                  // development timing experiments (results become WRONG): 1 = no hand-off at all, 2 = no publishing stores
     szh_u64 *trace;           // optional (development): per pencil {t_start, t_gate, t_first, t_end, spins, naps, cu, 0}
 };
@@ -84,9 +85,11 @@ template <> struct szh_gran<double> {
 // LDS of one pencil inside its tile's workgroup.  B::ring(k) maps a column to its ring slot; B::face_slot(I,J,nJ) indexes the
 // per-pencil arrays (tile-local on the GPU, global in the CPU simulator).
 template <class T> struct szh_tile_lds {
-    uint16_t *cring;          // [SZH_XC][64] this pencil's quantisation codes in flight
+    uint16_t *cring;          // [SZH_XC + 1][64] this pencil's quantisation codes in flight (+ trash column)
     T *faces;                 // [slots][RL][SZH_FROWS] face rings of every pencil of the tile: rows 0-7 = J-face (il), 8-15 = I-face (jl),
                               // 16 = corner column forwarded to the pencil below
+    int ftrash;               // element offset in faces[] of 64 write-only / don't-care slots (one per lane): masked-off lanes go there,
+                              // so that the ring accesses need no exec-mask juggling
     unsigned *cstep;          // [slots] steps completed (all face values of those steps are in the ring)
 };
 #define SZH_FROWS 17
@@ -98,7 +101,7 @@ template <class T> struct szh_tile_lds {
 #define SZH_UNROLL
 #endif
 #define SZH_FORL for (int l = 0; l < NL; ++l)
-#define SZH_XC 48 /* columns of the per-wavefront LDS code ring ([column % SZH_XC][lane]) */
+#define SZH_XC 32 /* columns of the per-pencil LDS code ring ([column % SZH_XC][lane]); column SZH_XC is a write-only trash column */
 
 // branch-free form of szh_quant_point (same arithmetic, same results)
 template <class T>
@@ -142,14 +145,14 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
     const int myslot = B::face_slot(I, J, a.nJ);
     const int slotPJ = predJ_lds ? B::face_slot(I, J - 1, a.nJ) : 0, slotPI = predI_lds ? B::face_slot(I - 1, J, a.nJ) : 0;
     const int slotCJ = consJ_lds ? B::face_slot(I, J + 1, a.nJ) : 0, slotCI = consI_lds ? B::face_slot(I + 1, J, a.nJ) : 0;
-    T *const myface = L.faces + (int64_t)myslot * B::face_stride(r2);
+    const int mybase = myslot * B::face_stride(r2);
+    const bool has_gran = (J > 0 && !predJ_lds) || (I > 0 && !predI_lds);    // this pencil reads granules (it sits on a tile edge)
 
     // ---- per-lane constants ----
-    int il[NL], jl[NL], skew[NL], hskew[NL], hkind[NL], hrowl[NL];
+    int il[NL], jl[NL], skew[NL], hskew[NL], hkind[NL], hlds[NL], pjb[NL], pib[NL], pcb[NL], trash[NL], ctrash[NL];
     bool inb[NL], pJ[NL], pI[NL], pC[NL];
     int64_t rowoff[NL], blkrow[NL], hoff[NL], pubJoff[NL], pubIoff[NL];
     const szh_u64 *hbuf[NL];
-    const T *hface[NL];
     T fii[NL], fjj[NL];
     SZH_FORL {
         const int lane = B::lane(l);
@@ -164,21 +167,22 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
         blkrow[l] = ((int64_t)b0 * G.g1.num + b1) * nbz;
         skew[l] = il[l] + jl[l];
         // halo role: which face row this lane fetches (for k = t - hskew), and from where: hkind 0 none, 1 granules, 2 LDS ring
-        hkind[l] = 0; hoff[l] = 0; hskew[l] = 0; hbuf[l] = a.faceJ; hrowl[l] = 0; hface[l] = L.faces;
+        hkind[l] = 0; hoff[l] = 0; hskew[l] = 0; hbuf[l] = a.faceJ; hlds[l] = -1;
+        trash[l] = L.ftrash + lane; ctrash[l] = SZH_XC * 64 + lane;
         const int64_t pencJ = (int64_t)I * a.nJ + (J - 1), pencI = (int64_t)(I - 1) * a.nJ + J;
         if (jl[l] == 0 && J > 0 && i < r0) {           // (i, 8J-1, k): J-face of pencil (I,J-1), row il
             hskew[l] = il[l];
-            if (predJ_lds) { hkind[l] = 2; hrowl[l] = il[l]; hface[l] = L.faces + (int64_t)slotPJ * B::face_stride(r2); }
+            if (predJ_lds) { hkind[l] = 2; hlds[l] = slotPJ * B::face_stride(r2) + il[l]; }
             else { hkind[l] = 1; hbuf[l] = a.faceJ; hoff[l] = (pencJ * 8 + il[l]) * r2; }
         } else if (il[l] == 0 && jl[l] > 0 && I > 0 && j < r1) { // (8I-1, j, k): I-face of (I-1,J), row jl
             hskew[l] = jl[l];
-            if (predI_lds) { hkind[l] = 2; hrowl[l] = 8 + jl[l]; hface[l] = L.faces + (int64_t)slotPI * B::face_stride(r2); }
+            if (predI_lds) { hkind[l] = 2; hlds[l] = slotPI * B::face_stride(r2) + 8 + jl[l]; }
             else { hkind[l] = 1; hbuf[l] = a.faceI; hoff[l] = (pencI * 9 + jl[l]) * r2; }
         } else if (lane == 63 && I > 0) {               // for lane 0: (8I-1, 8J, k) = I-face of (I-1,J), row 0
-            if (predI_lds) { hkind[l] = 2; hrowl[l] = 8; hface[l] = L.faces + (int64_t)slotPI * B::face_stride(r2); }
+            if (predI_lds) { hkind[l] = 2; hlds[l] = slotPI * B::face_stride(r2) + 8; }
             else { hkind[l] = 1; hbuf[l] = a.faceI; hoff[l] = (pencI * 9 + 0) * r2; }
         } else if (lane == 62 && I > 0 && J > 0) {      // for lane 0: (8I-1, 8J-1, k), forwarded by (I-1,J) as its ninth row
-            if (predI_lds) { hkind[l] = 2; hrowl[l] = 16; hface[l] = L.faces + (int64_t)slotPI * B::face_stride(r2); }
+            if (predI_lds) { hkind[l] = 2; hlds[l] = slotPI * B::face_stride(r2) + 16; }
             else { hkind[l] = 1; hbuf[l] = a.faceI; hoff[l] = (pencI * 9 + 8) * r2; }
         }
         pubJoff[l] = (((int64_t)I * a.nJ + J) * 8 + il[l]) * r2;
@@ -186,9 +190,14 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
         pJ[l] = pubJ && jl[l] == 7 && inb[l];
         pI[l] = pubI && il[l] == 7 && inb[l];
         pC[l] = pubI && J > 0 && il[l] == 7 && jl[l] == 0 && inb[l];   // forwards its own halo value: the corner column of (I+1,J)
-        if (a.dbg == 1) { hkind[l] = 0; pJ[l] = false; pI[l] = false; pC[l] = false; }
+        if (a.dbg == 1) { hkind[l] = 0; hlds[l] = -1; pJ[l] = false; pI[l] = false; pC[l] = false; }
         if (a.dbg == 2) { pJ[l] = false; pI[l] = false; pC[l] = false; }
+        // LDS ring offsets of the rows this lane publishes (-1: none)
+        pjb[l] = (pJ[l] && consJ_lds) ? mybase + il[l] : -1;
+        pib[l] = (pI[l] && consI_lds) ? mybase + 8 + jl[l] : -1;
+        pcb[l] = (pC[l] && consI_lds) ? mybase + 16 : -1;
     }
+    const bool gran_pubJ = pubJ && !consJ_lds && a.dbg == 0, gran_pubI = pubI && !consI_lds && a.dbg == 0;
     const int64_t pubCoff = (((int64_t)I * a.nJ + J) * 9 + 8) * r2;
 
     // ---- per-lane block tracking along dim2 (only when the pencil touches regression blocks) ----
@@ -270,39 +279,35 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
             }
         }
     };
-    // code ring <-> code array, columns [c0, c0+16) of all 64 rows of the pencil (c0 multiple of 16)
+    // code ring <-> code array, columns [c0, c0+8) of all 64 rows of the pencil (c0 multiple of 8): one 16-byte row segment per lane
     auto row_off = [&](int row, int64_t &off) -> bool {
         const int i = 8 * I + (row >> 3), j = 8 * J + (row & 7);
         off = (int64_t)i * G.d0 + (int64_t)j * G.d1;
         return i < r0 && j < r1;
     };
     auto move_codes = [&](int c0) {
-        if (vec_codes && c0 + 16 <= r2) {
-            SZH_UNROLL
-            for (int q = 0; q < 2; ++q) {
-                SZH_FORL {
-                    const int lane = B::lane(l);
-                    const int row = (lane >> 1) + 32 * q, cb = c0 + 8 * (lane & 1);
-                    int64_t off;
-                    if (row_off(row, off)) {
-                        uint16_t tmp[8];
-                        if (DEC) {
-                            B::ld16(a.codes + off + cb, tmp);
-                            SZH_UNROLL
-                            for (int e = 0; e < 8; ++e) cring[((cb + e) % SZH_XC) * 64 + row] = tmp[e];
-                        } else {
-                            SZH_UNROLL
-                            for (int e = 0; e < 8; ++e) tmp[e] = cring[((cb + e) % SZH_XC) * 64 + row];
-                            B::st16(a.codes + off + cb, tmp);
-                        }
+        if (vec_codes && c0 + 8 <= r2) {
+            SZH_FORL {
+                const int row = B::lane(l);
+                int64_t off;
+                if (row_off(row, off)) {
+                    uint16_t tmp[8];
+                    if (DEC) {
+                        B::ld16(a.codes + off + c0, tmp);
+                        SZH_UNROLL
+                        for (int e = 0; e < 8; ++e) cring[((c0 + e) % SZH_XC) * 64 + row] = tmp[e];
+                    } else {
+                        SZH_UNROLL
+                        for (int e = 0; e < 8; ++e) tmp[e] = cring[((c0 + e) % SZH_XC) * 64 + row];
+                        B::st16(a.codes + off + c0, tmp);
                     }
                 }
             }
         } else {
-            for (int q = 0; q < 16; ++q) {
+            for (int q = 0; q < 8; ++q) {
                 SZH_FORL {
                     const int lane = B::lane(l);
-                    const int row = q * 4 + (lane >> 4), col = c0 + (lane & 15);
+                    const int row = q * 8 + (lane >> 3), col = c0 + (lane & 7);
                     int64_t off;
                     if (row_off(row, off) && col < r2) {
                         if (DEC) cring[(col % SZH_XC) * 64 + row] = a.codes[off + col];
@@ -374,10 +379,50 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
         // how far are the in-tile producers?  (step t needs their step t+7 finished)
         int pstepJ = predJ_lds ? (int)B::lds_ld_u(L.cstep + slotPJ) : (1 << 30);
         int pstepI = predI_lds ? (int)B::lds_ld_u(L.cstep + slotPI) : (1 << 30);
-        SZH_UNROLL
-        for (int s = 0; s < SZH_U; ++s) load_halo(t0 + s, hr[s]);
-        if (DEC) { while (filled < t0 + SZH_U && filled < r2) { move_codes(filled); filled += 16; } } // ring holds columns < filled
+        if (DEC) { while (filled < t0 + SZH_U && filled < r2) { move_codes(filled); filled += 8; } } // ring holds columns < filled
         load_x(t0);
+        // granule-sourced rows (tile edge): request this trip's 16 granules per row.  If some are not there yet, this pencil
+        // has caught up with a producer in another tile: SLEEP until that producer's progress word says the whole trip is
+        // covered, and ask again.  (Polling granule by granule inside the steps costs a fabric round trip per step and
+        // throttles the whole tile behind this wavefront.)
+        if (has_gran) {
+            const int needp = t0 + SZH_U + 7 < tsteps ? t0 + SZH_U + 7 : tsteps;
+            unsigned tries = 0;
+            for (;;) {
+                szh_u64 pw[NL];
+                SZH_FORL {
+                    const int lane = B::lane(l);
+                    pw[l] = ~0ull;
+                    if (lane == 0 && J > 0 && !predJ_lds) pw[l] = B::ld_gran(a.progress + ((int64_t)I * a.nJ + (J - 1)));
+                    if (lane == 1 && I > 0 && !predI_lds) pw[l] = B::ld_gran(a.progress + ((int64_t)(I - 1) * a.nJ + J));
+                }
+                SZH_UNROLL
+                for (int s = 0; s < SZH_U; ++s) load_halo(t0 + s, hr[s]);
+                bool ok[NL];
+                SZH_FORL {
+                    ok[l] = true;
+                    if (hkind[l] == 1) {
+                        SZH_UNROLL
+                        for (int s = 0; s < SZH_U; ++s) {
+                            const int kh = t0 + s - hskew[l];
+                            if ((unsigned)kh < (unsigned)r2) {
+                                SZH_UNROLL
+                                for (int w = 0; w < NW; ++w) ok[l] = ok[l] && ((unsigned)(hr[s][w][l] >> 32) == a.epoch);
+                            }
+                        }
+                    }
+                }
+                if (B::all(ok) || a.dbg || !a.tripgate) break;
+                const szh_u64 p0 = B::readlane(pw, 0), p1 = B::readlane(pw, 1);
+                const szh_u64 want = ((szh_u64)a.epoch << 32) | (unsigned)needp;
+                const bool covered = (p0 == ~0ull || ((p0 >> 32) == a.epoch && p0 >= want)) && (p1 == ~0ull || ((p1 >> 32) == a.epoch && p1 >= want));
+                if (covered) break;          // the stragglers (stores still in flight) are picked up by the per-step wait below
+                if (++tries > (1u << 20)) { SZH_FORL { if (B::lane(l) == 0) B::st_flag(a.err, 1u); } break; }
+                if ((tries & 255u) == 0 && B::ld_flag(a.err) != 0) break;
+                B::nap();
+                ++tr_naps;
+            }
+        }
         SZH_UNROLL
         for (int s = 0; s < SZH_U; ++s) {
             const int t = t0 + s;
@@ -389,47 +434,53 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
                 const int need = t + 8 < tsteps ? t + 8 : tsteps;
                 if (pstepJ < need) pstepJ = wait_cstep(slotPJ, need);
                 if (pstepI < need) pstepI = wait_cstep(slotPI, need);
-                szh_u64 g[NW][NL];
-                bool ok[NL], hact[NL];
+                // LDS-sourced rows: every lane reads (lanes without such a row read a don't-care slot)
                 SZH_FORL {
                     const int kh = t - hskew[l];
-                    hact[l] = hkind[l] != 0 && (unsigned)kh < (unsigned)r2;
-                    bool v = true;
-                    SZH_UNROLL
-                    for (int w = 0; w < NW; ++w) { g[w][l] = hr[s][w][l]; v = v && ((unsigned)(g[w][l] >> 32) == a.epoch); }
-                    ok[l] = !hact[l] || hkind[l] == 2 || v;
+                    const bool lact = hlds[l] >= 0 && (unsigned)kh < (unsigned)r2;
+                    const T v = B::lds_ld(L.faces + (lact ? hlds[l] + B::ring(kh) * SZH_FROWS : trash[l]));
+                    hval[l] = lact ? v : (T)0;
                 }
-                if (!B::all(ok) && !a.dbg) {
-                    unsigned spins = 0;
-                    for (;;) {
-                        // bounded wait: a lost hand-off must end the launch, not hang the GPU
-                        if (++spins > (1u << 20)) { SZH_FORL { if (!ok[l]) B::st_flag(a.err, 1u); } break; }
-                        if ((spins & 255u) == 0 && B::ld_flag(a.err) != 0) break; // another wavefront already gave up
-                        B::backoff(a.backoff);
-                        SZH_FORL {
-                            if (!ok[l]) {
-                                const int kh = t - hskew[l];
-                                bool v = true;
-                                SZH_UNROLL
-                                for (int w = 0; w < NW; ++w) {
-                                    g[w][l] = B::ld_gran(hbuf[l] + (hoff[l] + kh) * NW + w);
-                                    v = v && ((unsigned)(g[w][l] >> 32) == a.epoch);
-                                }
-                                ok[l] = v;
-                            }
-                        }
-                        if (B::all(ok)) break;
+                if (has_gran) {       // granule-sourced rows (tile edge).  Fast path: the granule requested at the top of the trip is valid
+                    szh_u64 g[NW][NL];
+                    bool ok[NL], gact[NL];
+                    SZH_FORL {
+                        const int kh = t - hskew[l];
+                        gact[l] = hkind[l] == 1 && (unsigned)kh < (unsigned)r2;
+                        bool v = true;
+                        SZH_UNROLL
+                        for (int w = 0; w < NW; ++w) { g[w][l] = hr[s][w][l]; v = v && ((unsigned)(g[w][l] >> 32) == a.epoch); }
+                        ok[l] = !gact[l] || v;
                     }
-                    tr_spins += spins;
-                }
-                SZH_FORL {
-                    szh_u64 w2[NW];
-                    SZH_UNROLL
-                    for (int w = 0; w < NW; ++w) w2[w] = g[w][l];
-                    const int kh = t - hskew[l];
-                    T hv = (T)0;
-                    if (hact[l]) hv = hkind[l] == 2 ? B::lds_ld(hface[l] + B::ring(kh) * SZH_FROWS + hrowl[l]) : szh_gran<T>::unpack(w2);
-                    hval[l] = hv;
+                    if (!B::all(ok) && !a.dbg) {
+                        unsigned spins = 0;
+                        for (;;) {
+                            // bounded wait: a lost hand-off must end the launch, not hang the GPU
+                            if (++spins > (1u << 20)) { SZH_FORL { if (!ok[l]) B::st_flag(a.err, 1u); } break; }
+                            if ((spins & 255u) == 0 && B::ld_flag(a.err) != 0) break; // another wavefront already gave up
+                            B::backoff(a.backoff);
+                            SZH_FORL {
+                                if (!ok[l]) {
+                                    const int kh = t - hskew[l];
+                                    bool v = true;
+                                    SZH_UNROLL
+                                    for (int w = 0; w < NW; ++w) {
+                                        g[w][l] = B::ld_gran(hbuf[l] + (hoff[l] + kh) * NW + w);
+                                        v = v && ((unsigned)(g[w][l] >> 32) == a.epoch);
+                                    }
+                                    ok[l] = v;
+                                }
+                            }
+                            if (B::all(ok)) break;
+                        }
+                        tr_spins += spins;
+                    }
+                    SZH_FORL {
+                        szh_u64 w2[NW];
+                        SZH_UNROLL
+                        for (int w = 0; w < NW; ++w) w2[w] = g[w][l];
+                        if (gact[l]) hval[l] = szh_gran<T>::unpack(w2);
+                    }
                 }
             }
             // -- neighbours through cross-lane moves (values of the previous step) --
@@ -468,9 +519,10 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
                         code = is_lor ? code : cr;
                         nv = is_lor ? rcl : rcr;
                     }
-                    if (act) cring[((unsigned)k % SZH_XC) * 64 + B::lane(l)] = (uint16_t)code;
+                    B::lds_st(cring + (act ? ((unsigned)k % SZH_XC) * 64 + B::lane(l) : ctrash[l]), (uint16_t)code);
                 } else {
-                    const int c0 = act ? (int)cring[((unsigned)k % SZH_XC) * 64 + B::lane(l)] : radius;
+                    const int cread = (int)B::lds_ld(cring + (act ? ((unsigned)k % SZH_XC) * 64 + B::lane(l) : ctrash[l]));
+                    const int c0 = act ? cread : radius;
                     int c = c0;
                     const T p = is_lor ? pred : predr;
                     bool is_mean = false;
@@ -483,26 +535,23 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
                     if (act && c0 == 0) nv = ov[s][l];                              // pre-scattered unpredictable value (read at the top of the trip)
                     ov[s][l] = nv;
                 }
-                // publish faces for the pencils to the right / below: LDS ring inside the tile, granules across a tile boundary
-                {
-                    const int slotk = B::ring(act ? k : 0) * SZH_FROWS;
+                // publish faces for the pencils to the right / below.  Inside the tile: LDS ring, every lane stores (lanes without a
+                // face row, or outside the k range, store to their trash slot); across a tile boundary: granules
+                if (consJ_lds) B::lds_st(L.faces + ((act && pjb[l] >= 0) ? pjb[l] + B::ring(k) * SZH_FROWS : trash[l]), nv);
+                if (consI_lds) {
+                    B::lds_st(L.faces + ((act && pib[l] >= 0) ? pib[l] + B::ring(k) * SZH_FROWS : trash[l]), nv);
+                    // lane (7,0): its halo value IS the corner column of the pencil below, same k
+                    B::lds_st(L.faces + ((act && pcb[l] >= 0) ? pcb[l] + B::ring(k) * SZH_FROWS : trash[l]), hval[l]);
+                }
+                if (gran_pubJ || gran_pubI) {
                     szh_u64 w2[NW];
                     szh_gran<T>::pack(nv, a.epoch, w2);
-                    if (act && pJ[l]) {
-                        if (consJ_lds) B::lds_st(myface + slotk + il[l], nv);
-                        else { SZH_UNROLL for (int w = 0; w < NW; ++w) B::st_gran(a.faceJ + (pubJoff[l] + k) * NW + w, w2[w]); }
-                    }
-                    if (act && pI[l]) {
-                        if (consI_lds) B::lds_st(myface + slotk + 8 + jl[l], nv);
-                        else { SZH_UNROLL for (int w = 0; w < NW; ++w) B::st_gran(a.faceI + (pubIoff[l] + k) * NW + w, w2[w]); }
-                    }
-                    if (act && pC[l]) {             // lane (7,0): its halo value IS the corner column of the pencil below, same k
-                        if (consI_lds) B::lds_st(myface + slotk + 16, hval[l]);
-                        else {
-                            szh_u64 w3[NW];
-                            szh_gran<T>::pack(hval[l], a.epoch, w3);
-                            SZH_UNROLL for (int w = 0; w < NW; ++w) B::st_gran(a.faceI + (pubCoff + k) * NW + w, w3[w]);
-                        }
+                    if (gran_pubJ && act && pJ[l]) { SZH_UNROLL for (int w = 0; w < NW; ++w) B::st_gran(a.faceJ + (pubJoff[l] + k) * NW + w, w2[w]); }
+                    if (gran_pubI && act && pI[l]) { SZH_UNROLL for (int w = 0; w < NW; ++w) B::st_gran(a.faceI + (pubIoff[l] + k) * NW + w, w2[w]); }
+                    if (gran_pubI && act && pC[l]) {
+                        szh_u64 w3[NW];
+                        szh_gran<T>::pack(hval[l], a.epoch, w3);
+                        SZH_UNROLL for (int w = 0; w < NW; ++w) B::st_gran(a.faceI + (pubCoff + k) * NW + w, w3[w]);
                     }
                 }
                 // roll the neighbour state.  Lanes outside the k range see zero inputs and zero neighbours, so
@@ -533,14 +582,19 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
             // step t is complete: its face values are in the ring (LDS executes a wavefront's accesses in order)
             if (consJ_lds || consI_lds || predJ_lds || predI_lds) {   // consumers wait for it; producers watch it for ring space
                 B::lds_fence();
-                SZH_FORL { if (B::lane(l) == 0) B::lds_st(L.cstep + myslot, (unsigned)(t + 1)); }
+                SZH_FORL { B::lds_st(L.cstep + myslot, (unsigned)(t + 1)); }
+            }
+            // half-way through the trip: write back the code columns that are complete (keeps the 32-column ring from wrapping)
+            if (!DEC && s == SZH_U / 2 - 1) { while (flushed + 8 <= t + 1 - 14 && flushed < r2) { move_codes(flushed); flushed += 8; } }
+            if (s == SZH_U / 2 - 1 && (gran_pubJ || gran_pubI)) {
+                SZH_FORL { if (B::lane(l) == 0) B::st_gran(a.progress + ((int64_t)I * a.nJ + J), ((szh_u64)a.epoch << 32) | (unsigned)(t + 1)); }
             }
         }
         if (detail && t0 / SZH_U < 64) { SZH_FORL { if (B::lane(l) == 0) dt[(t0 / SZH_U) * 4 + 2] = B::clock(); } }
         if (DEC) store_out(t0);
         else {
-            // after this trip every lane is past column t0 + SZH_U - 15: flush the 16-column groups that are complete
-            while (flushed + 16 <= t0 + SZH_U - 14 && flushed < r2) { move_codes(flushed); flushed += 16; }
+            // after this trip every lane is past column t0 + SZH_U - 15: flush the 8-column groups that are complete
+            while (flushed + 8 <= t0 + SZH_U - 14 && flushed < r2) { move_codes(flushed); flushed += 8; }
         }
         if (detail && t0 / SZH_U < 64) { SZH_FORL { if (B::lane(l) == 0) dt[(t0 / SZH_U) * 4 + 3] = B::clock(); } }
         if (a.trace && t0 == 0) tr_first = B::clock();
@@ -549,7 +603,7 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
             SZH_FORL { if (B::lane(l) == 0) B::st_gran(a.progress + ((int64_t)I * a.nJ + J), ((szh_u64)a.epoch << 32) | (unsigned)(t0 + SZH_U)); }
         }
     }
-    if (!DEC) { for (; flushed < r2; flushed += 16) move_codes(flushed); }
+    if (!DEC) { for (; flushed < r2; flushed += 8) move_codes(flushed); }
     if (a.trace) {
         const szh_u64 tr_end = B::clock();
         SZH_FORL {

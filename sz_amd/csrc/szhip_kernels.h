@@ -90,7 +90,19 @@ struct GpuBackend {
     __device__ static bool same_tile(int I, int J, int I2, int J2) { return I / TPI == I2 / TPI && J / TPJ == J2 / TPJ; }
     __device__ static int lane(int) { return (int)(threadIdx.x & 63); }
     template <class T> __device__ static void shfl_up(T (&dst)[1], const T (&src)[1], int d) { dst[0] = __shfl_up(src[0], d, 64); }
+#ifdef SZH_HIPSIM
     template <class T> __device__ static T readlane(const T (&src)[1], int lane) { return __shfl(src[0], lane, 64); }
+#else
+    // lane is wavefront-uniform: v_readlane_b32 instead of a trip through the LDS crossbar
+    template <class T> __device__ static T readlane(const T (&src)[1], int lane)
+    {
+        int w[sizeof(T) / 4];
+        __builtin_memcpy(w, &src[0], sizeof(T));
+        for (unsigned i = 0; i < sizeof(T) / 4; ++i) w[i] = __builtin_amdgcn_readlane(w[i], lane);
+        T r; __builtin_memcpy(&r, w, sizeof(T));
+        return r;
+    }
+#endif
     __device__ static bool all(const bool (&p)[1]) { return __all(p[0] ? 1 : 0) != 0; }
     // LDS face rings of the tile: volatile ds_* accesses (a wavefront's LDS accesses execute in program order)
 #ifdef SZH_HIPSIM
@@ -148,8 +160,8 @@ struct GpuBackend {
 
 // tile shape by element type: a float tile fills a CU (16 wavefronts, <= 128 VGPRs each); double needs twice the registers
 template <class T> struct szh_tile_shape;
-template <> struct szh_tile_shape<float> { static constexpr int TPI = 4, TPJ = 4, RL = 32; };
-template <> struct szh_tile_shape<double> { static constexpr int TPI = 4, TPJ = 2, RL = 32; };
+template <> struct szh_tile_shape<float> { static constexpr int TPI = 4, TPJ = 4, RL = 64; };
+template <> struct szh_tile_shape<double> { static constexpr int TPI = 4, TPJ = 2, RL = 64; };
 
 template <class T, bool DEC>
 __global__ __launch_bounds__(szh_tile_shape<T>::TPI * szh_tile_shape<T>::TPJ * 64) void k_pencil(szh_qargs<T> a)
@@ -157,15 +169,21 @@ __global__ __launch_bounds__(szh_tile_shape<T>::TPI * szh_tile_shape<T>::TPJ * 6
     using S = szh_tile_shape<T>;
     using B = GpuBackend<S::TPI, S::TPJ, S::RL>;
     constexpr int NP = S::TPI * S::TPJ;
-    __shared__ uint16_t cring[NP][SZH_XC * 64];
-    __shared__ T faces[NP * S::RL * SZH_FROWS];
+    __shared__ uint16_t cring[NP][(SZH_XC + 1) * 64];
+    __shared__ T faces[NP * S::RL * SZH_FROWS + 64];
     __shared__ unsigned cstep[NP];
     __shared__ unsigned tk_s;
     if (threadIdx.x < NP) cstep[threadIdx.x] = 0;
     if (threadIdx.x == 0) tk_s = atomicAdd(a.ticket, 1u);
     __syncthreads();
+#ifdef SZH_HIPSIM
     const unsigned ij = a.order[tk_s];
     const int w = (int)(threadIdx.x >> 6);
+#else
+    // wavefront-uniform by construction; say so, so that everything derived from (I,J) lives in SGPRs and branches are scalar
+    const unsigned ij = (unsigned)__builtin_amdgcn_readfirstlane((int)a.order[tk_s]);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#endif
     const int I = (int)(ij >> 16) * S::TPI + w / S::TPJ, J = (int)(ij & 0xffffu) * S::TPJ + w % S::TPJ;
     if (I >= a.nI || J >= a.nJ) return;         // ragged tile: this wavefront has no pencil
 #ifndef SZH_HIPSIM
@@ -176,7 +194,7 @@ __global__ __launch_bounds__(szh_tile_shape<T>::TPI * szh_tile_shape<T>::TPJ * 6
                               case 2: __builtin_amdgcn_s_setprio(1); break; default: __builtin_amdgcn_s_setprio(0); break; }
     }
 #endif
-    const szh_tile_lds<T> L{cring[w], faces, cstep};
+    const szh_tile_lds<T> L{cring[w], faces, NP * S::RL * SZH_FROWS, cstep};
     szh_pencil_run<T, DEC, B>(a, I, J, L);
 }
 

@@ -56,14 +56,14 @@ static int run_all(szh_qargs<T> a)
     szh_fill_pencil_order(a.nI, a.nJ, order.data());
     unsigned err = 0; a.err = &err;
     std::vector<szh_u64> prog((size_t)a.nI * a.nJ, 0);
-    a.progress = prog.data(); a.gate_steps = 16; a.backoff = 1;
-    std::vector<uint16_t> ring(SZH_XC * 64, 0xDEAD);
+    a.progress = prog.data(); a.gate_steps = 16; a.backoff = 1; a.tripgate = 1;
+    std::vector<uint16_t> ring((SZH_XC + 1) * 64, 0xDEAD);
     // "LDS": one face array [r2][SZH_FROWS] and one step counter per pencil; poisoned so that an unwritten value shows
-    std::vector<T> faces((size_t)a.nI * a.nJ * r2 * SZH_FROWS, (T)-777);
+    std::vector<T> faces((size_t)a.nI * a.nJ * r2 * SZH_FROWS + 64, (T)-777);
     std::vector<unsigned> cstep((size_t)a.nI * a.nJ, 0);
     for (size_t tk = 0; tk < order.size(); ++tk) {
         const int I = (int)(order[tk] >> 16), J = (int)(order[tk] & 0xffff);
-        szh_tile_lds<T> L{ring.data(), faces.data(), cstep.data()};
+        szh_tile_lds<T> L{ring.data(), faces.data(), (int)((size_t)a.nI * a.nJ * r2 * SZH_FROWS), cstep.data()};
         szh_pencil_run<T, DEC, SimBackend>(a, I, J, L);
     }
     return (int)err;
