@@ -132,7 +132,7 @@ int prepare_pencil(szhip_ctx *ctx, const szh_geom3 &G, int nw, int tpi, int tpj,
     const size_t rowg = (size_t)G.g2.count * nw * sizeof(u64);
     TRY(ensure(ctx, ctx->faceI, (size_t)nI * nJ * 9 * rowg, true));
     TRY(ensure(ctx, ctx->faceJ, (size_t)nI * nJ * 8 * rowg, true));
-    TRY(ensure(ctx, ctx->progress, (size_t)nI * nJ * sizeof(u64), true));
+    TRY(ensure(ctx, ctx->progress, (size_t)nI * nJ * 2 * sizeof(u64), true));
     if (tune_int("SZ_HIP_TRACE", 0)) TRY(ensure(ctx, ctx->trace, ((size_t)nI * nJ * 8 + 256) * sizeof(u64), true));
     const int nTI = (nI + tpi - 1) / tpi, nTJ = (nJ + tpj - 1) / tpj;
     if (ctx->order_nI != nTI || ctx->order_nJ != nTJ) {
@@ -358,11 +358,11 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         a.faceI = (szh_u64 *)ctx->faceI.p; a.faceJ = (szh_u64 *)ctx->faceJ.p; a.epoch = ++ctx->epoch;
         a.nI = nI; a.nJ = nJ; a.order = (const unsigned *)ctx->order.p;
         a.ticket = (unsigned *)(sm + SM_TICKET); a.err = (unsigned *)(sm + SM_ERR);
-        a.progress = (szh_u64 *)ctx->progress.p; a.gate_steps = tune_int("SZ_HIP_GATE_STEPS", 16); a.backoff = tune_int("SZ_HIP_BACKOFF", 4); a.tripgate = tune_int("SZ_HIP_TRIPGATE", 1);
+        a.progress = (szh_u64 *)ctx->progress.p; a.gate_steps = tune_int("SZ_HIP_GATE_STEPS", 16); a.backoff = tune_int("SZ_HIP_BACKOFF", 4);
         a.trace = tune_int("SZ_HIP_TRACE", 0) ? (szh_u64 *)ctx->trace.p : nullptr;
         a.dbg = tune_int("SZ_HIP_DBG", 0);
         HIPCHK(hipEventRecord(ctx->ev[2], st));
-        hipLaunchKernelGGL((k_pencil<T, false>), dim3((unsigned)ntiles), dim3(TS::TPI * TS::TPJ * 64), 0, st, a);
+        hipLaunchKernelGGL((k_pencil<T, false>), dim3((unsigned)ntiles), dim3((TS::TPI * TS::TPJ + 2) * 64), 0, st, a);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(ctx->ev[3], st));
         S.quant_kernel_launches = 1;
@@ -750,11 +750,11 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
         a.faceI = (szh_u64 *)ctx->faceI.p; a.faceJ = (szh_u64 *)ctx->faceJ.p; a.epoch = ++ctx->epoch;
         a.nI = nI; a.nJ = nJ; a.order = (const unsigned *)ctx->order.p;
         a.ticket = (unsigned *)(sm + SM_TICKET); a.err = (unsigned *)(sm + SM_ERR);
-        a.progress = (szh_u64 *)ctx->progress.p; a.gate_steps = tune_int("SZ_HIP_GATE_STEPS", 16); a.backoff = tune_int("SZ_HIP_BACKOFF", 4); a.tripgate = tune_int("SZ_HIP_TRIPGATE", 1);
+        a.progress = (szh_u64 *)ctx->progress.p; a.gate_steps = tune_int("SZ_HIP_GATE_STEPS", 16); a.backoff = tune_int("SZ_HIP_BACKOFF", 4);
         a.trace = tune_int("SZ_HIP_TRACE", 0) ? (szh_u64 *)ctx->trace.p : nullptr;
         a.dbg = tune_int("SZ_HIP_DBG", 0);
         HIPCHK(hipEventRecord(ctx->ev[2], st));
-        hipLaunchKernelGGL((k_pencil<T, true>), dim3((unsigned)ntiles), dim3(TS::TPI * TS::TPJ * 64), 0, st, a);
+        hipLaunchKernelGGL((k_pencil<T, true>), dim3((unsigned)ntiles), dim3((TS::TPI * TS::TPJ + 2) * 64), 0, st, a);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(ctx->ev[3], st));
         S.quant_kernel_launches = 1;

@@ -86,8 +86,7 @@ struct GpuBackend {
     static constexpr int TPI = TPI_, TPJ = TPJ_, RL = RL_;
     __device__ static int ring(int k) { return k & (RL - 1); }
     __device__ static int face_stride(int) { return RL * SZH_FROWS; }
-    __device__ static int face_slot(int I, int J, int) { return (I % TPI) * TPJ + (J % TPJ); }
-    __device__ static bool same_tile(int I, int J, int I2, int J2) { return I / TPI == I2 / TPI && J / TPJ == J2 / TPJ; }
+
     __device__ static int lane(int) { return (int)(threadIdx.x & 63); }
     template <class T> __device__ static void shfl_up(T (&dst)[1], const T (&src)[1], int d) { dst[0] = __shfl_up(src[0], d, 64); }
 #ifdef SZH_HIPSIM
@@ -158,44 +157,39 @@ struct GpuBackend {
     __device__ static void nap() { __builtin_amdgcn_s_sleep(40); } // ~1 us
 };
 
-// tile shape by element type: a float tile fills a CU (16 wavefronts, <= 128 VGPRs each); double needs twice the registers
+// tile shape by element type: TPI x TPJ COMPUTE wavefronts + STORE + FILL per workgroup.  float: 14 wavefronts (<= 128 VGPRs
+// each) fill most of a CU; double needs twice the registers, so half the wavefronts
 template <class T> struct szh_tile_shape;
-template <> struct szh_tile_shape<float> { static constexpr int TPI = 4, TPJ = 4, RL = 64; };
-template <> struct szh_tile_shape<double> { static constexpr int TPI = 4, TPJ = 2, RL = 64; };
+template <> struct szh_tile_shape<float> { static constexpr int TPI = 4, TPJ = 3, RL = 64; };
+template <> struct szh_tile_shape<double> { static constexpr int TPI = 3, TPJ = 2, RL = 64; };
 
 template <class T, bool DEC>
-__global__ __launch_bounds__(szh_tile_shape<T>::TPI * szh_tile_shape<T>::TPJ * 64) void k_pencil(szh_qargs<T> a)
+__global__ __launch_bounds__((szh_tile_shape<T>::TPI * szh_tile_shape<T>::TPJ + 2) * 64) void k_pencil(szh_qargs<T> a)
 {
     using S = szh_tile_shape<T>;
     using B = GpuBackend<S::TPI, S::TPJ, S::RL>;
-    constexpr int NP = S::TPI * S::TPJ;
-    __shared__ uint16_t cring[NP][(SZH_XC + 1) * 64];
-    __shared__ T faces[NP * S::RL * SZH_FROWS + 64];
-    __shared__ unsigned cstep[NP];
+    constexpr int NP = S::TPI * S::TPJ, NV = S::TPI + S::TPJ, NT = (NP + 2) * 64;
+    __shared__ uint16_t cring[NP * (SZH_XC + 1) * 64];
+    __shared__ T faces[(NP + NV) * S::RL * SZH_FROWS + 64];
+    __shared__ unsigned cstep[NP + NV];
+    __shared__ unsigned spubJ[NP], spubI[NP];
+    __shared__ int scratch[128];
     __shared__ unsigned tk_s;
-    if (threadIdx.x < NP) cstep[threadIdx.x] = 0;
+    if (threadIdx.x < NP + NV) cstep[threadIdx.x] = 0;
+    if (threadIdx.x < NP) { spubJ[threadIdx.x] = 0; spubI[threadIdx.x] = 0; }
     if (threadIdx.x == 0) tk_s = atomicAdd(a.ticket, 1u);
     __syncthreads();
-#ifdef SZH_HIPSIM
+    (void)NT;
     const unsigned ij = a.order[tk_s];
     const int w = (int)(threadIdx.x >> 6);
-#else
-    // wavefront-uniform by construction; say so, so that everything derived from (I,J) lives in SGPRs and branches are scalar
-    const unsigned ij = (unsigned)__builtin_amdgcn_readfirstlane((int)a.order[tk_s]);
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-#endif
-    const int I = (int)(ij >> 16) * S::TPI + w / S::TPJ, J = (int)(ij & 0xffffu) * S::TPJ + w % S::TPJ;
-    if (I >= a.nI || J >= a.nJ) return;         // ragged tile: this wavefront has no pencil
-#ifndef SZH_HIPSIM
-    // the four wavefronts of a SIMD are one column of the tile (wavefront w runs on SIMD w % 4): the upstream pencil goes first,
-    // so that the chain of hand-offs advances at single-wavefront speed while the downstream pencils fill the issue gaps
-    if (a.dbg != 3) {
-        switch (w / S::TPJ) { case 0: __builtin_amdgcn_s_setprio(3); break; case 1: __builtin_amdgcn_s_setprio(2); break;
-                              case 2: __builtin_amdgcn_s_setprio(1); break; default: __builtin_amdgcn_s_setprio(0); break; }
-    }
-#endif
-    const szh_tile_lds<T> L{cring[w], faces, NP * S::RL * SZH_FROWS, cstep};
-    szh_pencil_run<T, DEC, B>(a, I, J, L);
+    const int TI = (int)(ij >> 16), TJ = (int)(ij & 0xffffu);
+    const szh_tile_lds<T> L{cring, faces, (NP + NV) * S::RL * SZH_FROWS, cstep, spubJ, spubI, scratch};
+    if (w < NP) {
+        const int I = TI * S::TPI + w / S::TPJ, J = TJ * S::TPJ + w % S::TPJ;
+        if (I >= a.nI || J >= a.nJ) return;         // ragged tile: this wavefront has no pencil
+        szh_pencil_run<T, DEC, B>(a, I, J, L);
+    } else if (w == NP) szh_tile_store<T, B>(a, TI, TJ, L);
+    else szh_tile_fill<T, B>(a, TI, TJ, L);
 }
 
 // ------------------------------------------------------------------ per-block stage (fit + select)
