@@ -184,6 +184,15 @@ __global__ __launch_bounds__((szh_tile_shape<T>::TPI * szh_tile_shape<T>::TPJ + 
     const int w = (int)(threadIdx.x >> 6);
     const int TI = (int)(ij >> 16), TJ = (int)(ij & 0xffffu);
     const szh_tile_lds<T> L{cring, faces, (NP + NV) * S::RL * SZH_FROWS, cstep, spubJ, spubI, scratch};
+#ifndef SZH_HIPSIM
+    // issue priority: the helpers (light, latency-critical) first, then the pencils in dependency order, so that the chain
+    // of hand-offs advances at single-wavefront speed while the downstream pencils fill the issue gaps
+    if (a.dbg != 4) {
+        const int d = w < NP ? (w / S::TPJ + w % S::TPJ) : 0;
+        if (d == 0) __builtin_amdgcn_s_setprio(3); else if (d == 1) __builtin_amdgcn_s_setprio(2);
+        else if (d <= 3) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+    }
+#endif
     if (w < NP) {
         const int I = TI * S::TPI + w / S::TPJ, J = TJ * S::TPJ + w % S::TPJ;
         if (I >= a.nI || J >= a.nJ) return;         // ragged tile: this wavefront has no pencil

@@ -1,5 +1,4 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-for tg in 1 0 1 0; do
-  echo "== tripgate=$tg"; SZ_HIP_TRIPGATE=$tg timeout 120 python tools/gpu_trace.py 512 2>&1 | grep -E "ms_quant|pencil \(32,32\)|pencil \(0,0\)|pencil \(63,63\)|active duration|gate of"
-done
+echo "== free run (dbg=1)"; SZ_HIP_DBG=1 timeout 120 python tools/gpu_trace.py 512 2>&1 | grep -E "ms_quant|pencil \(32,32\)|pencil \(63,63\)|active duration"
+echo "== normal"; timeout 120 python tools/gpu_trace.py 512 2>&1 | grep -E "ms_quant|pencil \(0,0\)|pencil \(32,32\)|pencil \(63,63\)|active duration|all pencils"
