@@ -306,12 +306,9 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
         }
     };
     // bounded wait until an LDS counter reaches `need`; returns the value seen.  A lost hand-off ends the launch, it must not hang the GPU
-    szh_u64 tr_spins = 0, tr_wait[3] = {0, 0, 0};   // (development) clocks spent waiting for: J-producer, I-producer, ring space
-    int tr_kind = 2;
+    szh_u64 tr_spins = 0;
     auto wait_ctr = [&](const unsigned *ctr, int need) -> int {
         int v = (int)B::lds_ld_u(ctr);
-        if (v >= need) return v;
-        const szh_u64 w0 = a.trace ? B::clock() : 0;
         unsigned spins = 0;
         while (v < need && !free_run) {
             if (++spins > (1u << 24)) { SZH_FORL { if (B::lane(l) == 0) B::st_flag(a.err, 1u); } break; }
@@ -320,7 +317,6 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
             v = (int)B::lds_ld_u(ctr);
         }
         tr_spins += spins;
-        if (a.trace) tr_wait[tr_kind] += B::clock() - w0;
         return v;
     };
 
@@ -353,9 +349,8 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
             T hval[NL];
             {
                 const int need = t + 8 < tsteps ? t + 8 : tsteps;
-                if (pstepJ < need) { tr_kind = 0; pstepJ = wait_ctr(L.cstep + slotPJ, need); }
-                if (pstepI < need) { tr_kind = 1; pstepI = wait_ctr(L.cstep + slotPI, need); }
-                tr_kind = 2;
+                if (pstepJ < need) pstepJ = wait_ctr(L.cstep + slotPJ, need);
+                if (pstepI < need) pstepI = wait_ctr(L.cstep + slotPI, need);
                 SZH_FORL {      // every lane reads (lanes without a halo row read a don't-care slot)
                     const int kh = t - hskew[l];
                     const bool lact = hlds[l] >= 0 && (unsigned)kh < (unsigned)r2;
@@ -469,7 +464,7 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
         SZH_FORL {
             if (B::lane(l) == 0) {
                 szh_u64 *tp = a.trace + ((int64_t)I * a.nJ + J) * 8;
-                tp[0] = tr_start; tp[1] = tr_start; tp[2] = tr_first; tp[3] = tr_end; tp[4] = tr_wait[0]; tp[5] = tr_wait[1]; tp[6] = B::where(); tp[7] = tr_wait[2];
+                tp[0] = tr_start; tp[1] = tr_start; tp[2] = tr_first; tp[3] = tr_end; tp[4] = tr_spins; tp[6] = B::where(); tp[7] = 0;
             }
         }
     }
@@ -555,7 +550,7 @@ SZH_HD void szh_tile_store(const szh_qargs<T> &a, int TI, int TJ, const szh_tile
 {
     constexpr int NL = B::NL;
     constexpr int NW = szh_gran<T>::NW;
-    constexpr int KP = 8;                       // columns per row per round
+    constexpr int KP = 4;                       // columns per row per round
     const int r0 = a.G.g0.count, r1 = a.G.g1.count, r2 = a.G.g2.count;
     const int stride = B::face_stride(r2);
     int pk[NL], slot[NL], rbase[NL];
@@ -639,11 +634,10 @@ SZH_HD void szh_tile_fill(const szh_qargs<T> &a, int TI, int TJ, const szh_tile_
 {
     constexpr int NL = B::NL;
     constexpr int NW = szh_gran<T>::NW;
-    constexpr int KF = 16;                      // columns per row per round
-    constexpr int SPEC = 4;                     // columns requested beyond the producer's last known progress
+    constexpr int KF = 8;                       // columns per row per round
     const int r0 = a.G.g0.count, r1 = a.G.g1.count, r2 = a.G.g2.count;
     const int stride = B::face_stride(r2);
-    int fk[NL], cslot[NL], wbase[NL], psteps[NL];
+    int fk[NL], cslot[NL], wbase[NL];
     bool en[NL];
     const szh_u64 *src[NL];
     const szh_u64 *prog[NL];
@@ -661,24 +655,20 @@ SZH_HD void szh_tile_fill(const szh_qargs<T> &a, int TI, int TJ, const szh_tile_
         const int vslot = m.isJ ? szh_vslot_left<B>(I) : szh_vslot_top<B>(J);
         wbase[l] = vslot * stride + m.ringrow;
         fk[l] = en[l] ? 0 : r2;
-        psteps[l] = 0;
     }
     unsigned idle = 0;
     for (;;) {
-        // ONE memory round trip per round: the producer's progress word and this row's next granules are requested together.
-        // Which granules: those covered by the progress seen in the PREVIOUS round plus a few speculative columns (a tag
-        // validates every granule); nothing is requested from a producer that has not started.
+        // how far have the producers got?  (every lane asks for its own row's producer: a handful of distinct words per round)
         szh_u64 g[KF][NW][NL];
         bool none[NL], fin[NL];
         int vsteps[NL];
         SZH_FORL {
             const szh_rowmap<B> m(B::lane(l));
             int avail = 0;
-            szh_u64 p = 0;
-            const bool live = en[l] && fk[l] < r2;
-            if (live) {
-                p = B::ld_gran(prog[l]);
-                avail = psteps[l] > 0 ? psteps[l] - m.sr + SPEC : 0; if (avail > r2) avail = r2;
+            if (en[l] && fk[l] < r2) {
+                const szh_u64 p = B::ld_gran(prog[l]);
+                const int ps = (unsigned)(p >> 32) == a.epoch ? (int)(unsigned)p : 0;
+                avail = ps - m.sr; if (avail > r2) avail = r2;
                 const int room = (int)B::lds_ld(L.cstep + cslot[l]) - 7 + B::RL;      // slots of columns < consumer step - 7 are free again
                 if (avail > room) avail = room;
             }
@@ -688,7 +678,6 @@ SZH_HD void szh_tile_fill(const szh_qargs<T> &a, int TI, int TJ, const szh_tile_
                 SZH_UNROLL
                 for (int w = 0; w < NW; ++w) g[e][w][l] = e < n ? B::ld_gran(src[l] + (int64_t)(fk[l] + e) * NW + w) : 0;
             }
-            if (live && (unsigned)(p >> 32) == a.epoch) psteps[l] = (int)(unsigned)p;
             int lead = 0; bool run = true;
             SZH_UNROLL
             for (int e = 0; e < KF; ++e) {
