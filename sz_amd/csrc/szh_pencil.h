@@ -17,6 +17,18 @@
 // "handoff-1to1"/R2).  Pencils are started in anti-diagonal order through an atomic ticket so
 // every dependency is already resident: no deadlock, no grid barrier.
 //
+// Tiles.  A workgroup owns a TILE of TPI x TPJ neighbouring pencils, one COMPUTE wavefront per pencil, plus two helper
+// wavefronts.  Every hand-off a compute wavefront takes part in is LDS only: it reads its producers' face rows from LDS
+// rings (waiting on an LDS step counter) and writes its own faces into its ring.  Faces between pencils of the same tile
+// never leave the CU.  Faces that cross a tile boundary travel as granules, moved by the helpers:
+//   STORE  forwards the rings of the tile's last row / last column of pencils to the granule buffers (stores only);
+//   FILL   follows the progress words of the producers in the neighbouring tiles, fetches their granules and drops them
+//          into "virtual producer" rings of this tile (loads only).
+// On gfx950 loads and stores of a wavefront share one in-order memory queue and agent-scope stores are acknowledged
+// slowly, so a wavefront that both computes and talks to the fabric pays a fabric round trip per step; the split keeps
+// the sweep at LDS latency.  The third producer of a pencil, (I-1,J-1), is not needed: its corner column is the row-7
+// halo of (I-1,J), which forwards it as a ninth row of its I-face.
+//
 // The body is written once and instantiated by two back ends:
 //   * the HIP kernel (szh_kernels.hip): NL = 1 value per thread, collectives = DPP/bpermute;
 //   * a CPU lane simulator used ONLY by tests/ (tests/sim): NL = 64, collectives = array moves.
@@ -34,13 +46,14 @@ template <class T> struct szh_qargs {
     const T *coef;            // decoded regression coefficients, SoA [4][nblocks]
     T eb, recip, mean;
     int cap, radius, use_mean;
-    szh_u64 *faceI, *faceJ;   // granule buffers: [pencil][8 rows][r2][NW]
+    szh_u64 *faceI, *faceJ;   // granule buffers: faceJ [pencil][8 rows][r2][NW], faceI [pencil][9 rows][r2][NW] (row 8 = forwarded corner column)
     unsigned epoch;
     int nI, nJ;
-    const unsigned *order;    // ticket -> (I<<16)|J, anti-diagonal order
+    const unsigned *order;    // ticket -> (tile row << 16) | tile column, anti-diagonal order over the tiles
     unsigned *ticket;
     unsigned *err;            // set to 1 if a halo wait timed out
-    szh_u64 *progress;        // per pencil: {epoch, steps completed}; a cheap "has my neighbour got going" word
+    szh_u64 *progress;        // [pencil][2] (J-face, I-face): {epoch, steps whose face values have been published}: the consumers' FILL
+                              // wavefront polls these words and then fetches only granules that exist
     int gate_steps;           // a pencil starts once both producers have completed this many steps
     int backoff;              // sleep units between two polls of a missing granule
     int dbg;                  // development timing experiments (results become WRONG): 1 = no hand-off at all, 2 = no publishing stores
@@ -74,6 +87,21 @@ template <> struct szh_gran<double> {
     }
 };
 
+// LDS of one tile (the workgroup).  Slots 0 .. NP-1 are the tile's pencils (pi * TPJ + pj); slots NP .. NP+TPI-1 are the
+// "virtual producers" left of the tile (J-faces of pencils (I, J0-1)), slots NP+TPI .. NP+TPI+TPJ-1 those above it.
+// B::ring(k) maps a column to its ring slot.
+template <class T> struct szh_tile_lds {
+    uint16_t *cring;          // [NP][(SZH_XC + 1)][64] quantisation codes in flight per pencil (+ trash column)
+    T *faces;                 // [NP + NV][RL][SZH_FROWS] face rings: rows 0-7 = J-face (il), 8-15 = I-face (jl), 16 = corner column
+                              // forwarded to the pencil below
+    int ftrash;               // element offset in faces[] of 64 write-only / don't-care slots (one per lane): masked-off lanes go there,
+                              // so that the ring accesses need no exec-mask juggling
+    unsigned *cstep;          // [NP + NV] steps completed (all face values of those steps are in the ring); virtual: same scale, by FILL
+    unsigned *spubJ, *spubI;  // [NP] columns of the J- / I-face already forwarded by STORE (ring space for the producer)
+    int *scratch;             // [2][64] helper wavefronts (STORE, FILL): per-row values for a per-slot minimum
+};
+#define SZH_FROWS 17
+
 #define SZH_U 16 /* steps per loop trip: a trip first requests all of its inputs (values and halo granules), then steps */
 #if defined(__HIPCC__)
 #define SZH_UNROLL _Pragma("unroll")
@@ -81,7 +109,7 @@ template <> struct szh_gran<double> {
 #define SZH_UNROLL
 #endif
 #define SZH_FORL for (int l = 0; l < NL; ++l)
-#define SZH_XC 48 /* columns of the per-wavefront LDS code ring ([column % SZH_XC][lane]) */
+#define SZH_XC 32 /* columns of the per-pencil LDS code ring ([column % SZH_XC][lane]); column SZH_XC is a write-only trash column */
 
 // branch-free form of szh_quant_point (same arithmetic, same results)
 template <class T>
@@ -101,26 +129,45 @@ SZH_HD int szh_quant_sel(T x, T pred, T eb, T recip, int capacity, int radius, T
 
 // B: back end. Requires: NL, lane(l), shfl_up(dst,src,d), readlane(src,lane), all(pred),
 //    ld_gran(p), st_gran(p,v), ld_flag(p), st_flag(p,v), backoff(n), nap(), clock(), where(),
-//    ld16(p, T(&)[16/sizeof T]), st16(p, const T(&)[...]) -- one 16-byte vector access (4-byte aligned for 4/8-byte T).
+//    ld16(p, T(&)[16/sizeof T]), st16(p, const T(&)[...]) -- one 16-byte vector access (4-byte aligned for 4/8-byte T),
+//    lds_ld(p), lds_st(p,v), lds_ld_u(p) (wavefront-uniform address), lds_fence() (orders this wavefront's LDS accesses),
+//    RL / ring(k) (face-ring length), face_stride(r2) (elements per ring), TPI / TPJ (tile shape).
+
+// tile-local slot numbers
+template <class B> SZH_HD int szh_slot(int I, int J) { return (I % B::TPI) * B::TPJ + (J % B::TPJ); }
+template <class B> SZH_HD int szh_vslot_left(int I) { return B::TPI * B::TPJ + (I % B::TPI); }
+template <class B> SZH_HD int szh_vslot_top(int J) { return B::TPI * B::TPJ + B::TPI + (J % B::TPJ); }
+
+// COMPUTE wavefront: the sweep of one pencil.  Memory traffic: its own rows of values and codes (plain 16-byte accesses);
+// every hand-off is LDS.
 // HASREG: the pencil touches at least one regression block (otherwise the block bookkeeping and the
 //         regression quantiser are compiled out); USEMEAN: the stream's use_mean flag.
 template <class T, bool DEC, bool HASREG, bool USEMEAN, class B>
-SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, uint16_t *cring)
+SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_lds<T> &L)
 {
     constexpr int NL = B::NL;
-    constexpr int NW = szh_gran<T>::NW;
     const szh_geom3 &G = a.G;
     const int r0 = G.g0.count, r1 = G.g1.count, r2 = G.g2.count;
     const int nbz = G.g2.num;
     const int cap_lor = a.cap - 2, cap_reg = a.cap, radius = a.radius;
     const T eb = a.eb, recip = a.recip, mean = a.mean;
-    const bool pubJ = (J + 1 < a.nJ), pubI = (I + 1 < a.nI);
+    const bool free_run = a.dbg == 1;   // development: no hand-off at all (timing only, results are wrong)
+    const bool pubJ = (J + 1 < a.nJ) && !free_run, pubI = (I + 1 < a.nI) && !free_run;
+    const int pi = I % B::TPI, pj = J % B::TPJ;
+    const int myslot = szh_slot<B>(I, J);
+    uint16_t *const cring = L.cring + (size_t)myslot * (SZH_XC + 1) * 64;
+    // producers: a pencil of this tile, or the virtual producer the FILL wavefront keeps filled
+    const bool hasPJ = J > 0 && !free_run, hasPI = I > 0 && !free_run;
+    const int slotPJ = pj > 0 ? myslot - 1 : szh_vslot_left<B>(I), slotPI = pi > 0 ? myslot - B::TPJ : szh_vslot_top<B>(J);
+    // consumers: a pencil of this tile (its step counter tells which ring slots it has read), or the STORE wavefront
+    const bool consJ_in = pubJ && pj + 1 < B::TPJ, consI_in = pubI && pi + 1 < B::TPI;
+    const int stride = B::face_stride(r2);
+    const int mybase = myslot * stride;
 
     // ---- per-lane constants ----
-    int il[NL], jl[NL], skew[NL], hskew[NL];
-    bool inb[NL], hrole[NL], pJ[NL], pI[NL];
-    int64_t rowoff[NL], blkrow[NL], hoff[NL], pubJoff[NL], pubIoff[NL];
-    const szh_u64 *hbuf[NL];
+    int il[NL], jl[NL], skew[NL], hskew[NL], hlds[NL], pjb[NL], pib[NL], pcb[NL], trash[NL], ctrash[NL];
+    bool inb[NL];
+    int64_t rowoff[NL], blkrow[NL];
     T fii[NL], fjj[NL];
     SZH_FORL {
         const int lane = B::lane(l);
@@ -134,27 +181,17 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, uint16_t *cring
         rowoff[l] = (int64_t)ic * G.d0 + (int64_t)jc * G.d1;
         blkrow[l] = ((int64_t)b0 * G.g1.num + b1) * nbz;
         skew[l] = il[l] + jl[l];
-        // halo role: which granule row this lane fetches, and for which k = t - hskew
-        hrole[l] = false; hoff[l] = 0; hskew[l] = 0; hbuf[l] = a.faceJ;
-        if (jl[l] == 0 && J > 0 && i < r0) {           // (i, 8J-1, k): J-face of pencil (I,J-1), row il
-            hrole[l] = true; hbuf[l] = a.faceJ; hskew[l] = il[l];
-            hoff[l] = (((int64_t)I * a.nJ + (J - 1)) * 8 + il[l]) * r2;
-        } else if (il[l] == 0 && jl[l] > 0 && I > 0 && j < r1) { // (8I-1, j, k): I-face of (I-1,J), row jl
-            hrole[l] = true; hbuf[l] = a.faceI; hskew[l] = jl[l];
-            hoff[l] = (((int64_t)(I - 1) * a.nJ + J) * 8 + jl[l]) * r2;
-        } else if (lane == 63 && I > 0) {               // for lane 0: (8I-1, 8J, k)
-            hrole[l] = true; hbuf[l] = a.faceI; hskew[l] = 0;
-            hoff[l] = (((int64_t)(I - 1) * a.nJ + J) * 8 + 0) * r2;
-        } else if (lane == 62 && I > 0 && J > 0) {      // for lane 0: (8I-1, 8J-1, k)
-            hrole[l] = true; hbuf[l] = a.faceI; hskew[l] = 0;
-            hoff[l] = (((int64_t)(I - 1) * a.nJ + (J - 1)) * 8 + 7) * r2;
-        }
-        pubJoff[l] = (((int64_t)I * a.nJ + J) * 8 + il[l]) * r2;
-        pubIoff[l] = (((int64_t)I * a.nJ + J) * 8 + jl[l]) * r2;
-        pJ[l] = pubJ && jl[l] == 7 && inb[l];
-        pI[l] = pubI && il[l] == 7 && inb[l];
-        if (a.dbg == 1) { hrole[l] = false; pJ[l] = false; pI[l] = false; }
-        if (a.dbg == 2) { pJ[l] = false; pI[l] = false; }
+        trash[l] = L.ftrash + lane; ctrash[l] = SZH_XC * 64 + lane;
+        // halo role: which face row this lane reads (for k = t - hskew); hlds = element offset of that row in faces[], -1: none
+        hskew[l] = 0; hlds[l] = -1;
+        if (jl[l] == 0 && hasPJ && i < r0) { hskew[l] = il[l]; hlds[l] = slotPJ * stride + il[l]; }                   // (i, 8J-1, k): J-face of (I,J-1), row il
+        else if (il[l] == 0 && jl[l] > 0 && hasPI && j < r1) { hskew[l] = jl[l]; hlds[l] = slotPI * stride + 8 + jl[l]; } // (8I-1, j, k): I-face of (I-1,J), row jl
+        else if (lane == 63 && hasPI) hlds[l] = slotPI * stride + 8;                                                   // for lane 0: (8I-1, 8J, k)
+        else if (lane == 62 && hasPI && hasPJ) hlds[l] = slotPI * stride + 16;                                         // for lane 0: (8I-1, 8J-1, k), forwarded by (I-1,J)
+        // rows of the own ring this lane writes (-1: none): J-face row il, I-face row jl, forwarded corner column
+        pjb[l] = (pubJ && jl[l] == 7 && inb[l]) ? mybase + il[l] : -1;
+        pib[l] = (pubI && il[l] == 7 && inb[l]) ? mybase + 8 + jl[l] : -1;
+        pcb[l] = (pubI && hasPJ && il[l] == 7 && jl[l] == 0 && inb[l]) ? mybase + 16 : -1;
     }
 
     // ---- per-lane block tracking along dim2 (only when the pencil touches regression blocks) ----
@@ -180,23 +217,17 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, uint16_t *cring
         }
     }
 
-    // ---- per-trip inputs.  Nothing stays in flight across the loop back-edge (hipcc guards rotated in-flight registers
-    //      with s_waitcnt vmcnt(0) = one memory round trip per STEP); a trip requests everything it needs at its top.
-    //      Memory shape: every lane moves its OWN row's next SZH_U values as 16-byte vectors (64 B contiguous per lane
-    //      instead of sixteen 4-byte requests); the 2-byte codes go through a small LDS ring and are moved between ring
-    //      and HBM as aligned 16-byte row segments (a per-step 2-byte store per lane was 134 M separate L2 write requests).
+    // ---- per-trip inputs.  Nothing stays in flight across the loop back-edge (hipcc guards rotated in-flight registers with
+    //      s_waitcnt vmcnt(0) = one memory round trip per STEP); a trip requests everything it needs at its top.
+    //      Every lane moves its OWN row's next SZH_U values as 16-byte vectors; the 2-byte codes go through a small LDS ring
+    //      and are moved between ring and HBM as aligned 16-byte row segments.
     constexpr int VPT = 16 / (int)sizeof(T);      // values per 16-byte vector
     constexpr int NVEC = SZH_U / VPT;             // vectors per lane per trip
-    T xr[SZH_U][NL];
-    T ov[SZH_U][NL];
-    szh_u64 hr[SZH_U][NW][NL];
+    T xr[SZH_U][NL];                              // compress: originals; decompress: pre-scattered values in, reconstruction out
     const bool vec_codes = (r2 % 8) == 0;         // rows of the u16 code array are 16-byte aligned
 
-    // this lane's row, steps t0..t0+SZH_U-1  <->  k = t0 - skew .. t0 - skew + SZH_U - 1
-    // compress: the original values -> xr; decompress: the pre-scattered unpredictable values -> ov (overwritten step by step)
     auto load_x = [&](int t0) {
         const T *src = DEC ? a.out : a.data;
-        T (&dst)[SZH_U][NL] = DEC ? ov : xr;
         SZH_FORL {
             const int k0 = t0 - skew[l];
             if (inb[l] && k0 >= 0 && k0 + SZH_U <= r2) {
@@ -205,13 +236,13 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, uint16_t *cring
                     T tmp[VPT];
                     B::ld16(src + rowoff[l] + k0 + v * VPT, tmp);
                     SZH_UNROLL
-                    for (int e = 0; e < VPT; ++e) dst[v * VPT + e][l] = tmp[e];
+                    for (int e = 0; e < VPT; ++e) xr[v * VPT + e][l] = tmp[e];
                 }
             } else {
                 SZH_UNROLL
                 for (int s = 0; s < SZH_U; ++s) {
                     const int k = k0 + s;
-                    dst[s][l] = (inb[l] && (unsigned)k < (unsigned)r2) ? src[rowoff[l] + k] : (T)0;
+                    xr[s][l] = (inb[l] && (unsigned)k < (unsigned)r2) ? src[rowoff[l] + k] : (T)0;
                 }
             }
         }
@@ -224,51 +255,47 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, uint16_t *cring
                 for (int v = 0; v < NVEC; ++v) {
                     T tmp[VPT];
                     SZH_UNROLL
-                    for (int e = 0; e < VPT; ++e) tmp[e] = ov[v * VPT + e][l];
+                    for (int e = 0; e < VPT; ++e) tmp[e] = xr[v * VPT + e][l];
                     B::st16(a.out + rowoff[l] + k0 + v * VPT, tmp);
                 }
             } else {
                 SZH_UNROLL
                 for (int s = 0; s < SZH_U; ++s) {
                     const int k = k0 + s;
-                    if (inb[l] && (unsigned)k < (unsigned)r2) a.out[rowoff[l] + k] = ov[s][l];
+                    if (inb[l] && (unsigned)k < (unsigned)r2) a.out[rowoff[l] + k] = xr[s][l];
                 }
             }
         }
     };
-    // code ring <-> code array, columns [c0, c0+16) of all 64 rows of the pencil (c0 multiple of 16)
+    // code ring <-> code array, columns [c0, c0+8) of all 64 rows of the pencil (c0 multiple of 8): one 16-byte row segment per lane
     auto row_off = [&](int row, int64_t &off) -> bool {
         const int i = 8 * I + (row >> 3), j = 8 * J + (row & 7);
         off = (int64_t)i * G.d0 + (int64_t)j * G.d1;
         return i < r0 && j < r1;
     };
     auto move_codes = [&](int c0) {
-        if (vec_codes && c0 + 16 <= r2) {
-            SZH_UNROLL
-            for (int q = 0; q < 2; ++q) {
-                SZH_FORL {
-                    const int lane = B::lane(l);
-                    const int row = (lane >> 1) + 32 * q, cb = c0 + 8 * (lane & 1);
-                    int64_t off;
-                    if (row_off(row, off)) {
-                        uint16_t tmp[8];
-                        if (DEC) {
-                            B::ld16(a.codes + off + cb, tmp);
-                            SZH_UNROLL
-                            for (int e = 0; e < 8; ++e) cring[((cb + e) % SZH_XC) * 64 + row] = tmp[e];
-                        } else {
-                            SZH_UNROLL
-                            for (int e = 0; e < 8; ++e) tmp[e] = cring[((cb + e) % SZH_XC) * 64 + row];
-                            B::st16(a.codes + off + cb, tmp);
-                        }
+        if (vec_codes && c0 + 8 <= r2) {
+            SZH_FORL {
+                const int row = B::lane(l);
+                int64_t off;
+                if (row_off(row, off)) {
+                    uint16_t tmp[8];
+                    if (DEC) {
+                        B::ld16(a.codes + off + c0, tmp);
+                        SZH_UNROLL
+                        for (int e = 0; e < 8; ++e) cring[((c0 + e) % SZH_XC) * 64 + row] = tmp[e];
+                    } else {
+                        SZH_UNROLL
+                        for (int e = 0; e < 8; ++e) tmp[e] = cring[((c0 + e) % SZH_XC) * 64 + row];
+                        B::st16(a.codes + off + c0, tmp);
                     }
                 }
             }
         } else {
-            for (int q = 0; q < 16; ++q) {
+            for (int q = 0; q < 8; ++q) {
                 SZH_FORL {
                     const int lane = B::lane(l);
-                    const int row = q * 4 + (lane >> 4), col = c0 + (lane & 15);
+                    const int row = q * 8 + (lane >> 3), col = c0 + (lane & 7);
                     int64_t off;
                     if (row_off(row, off) && col < r2) {
                         if (DEC) cring[(col % SZH_XC) * 64 + row] = a.codes[off + col];
@@ -278,14 +305,19 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, uint16_t *cring
             }
         }
     };
-
-    auto load_halo = [&](int t, szh_u64 (&hv)[NW][NL]) {
-        SZH_FORL {
-            const int kh = t - hskew[l];
-            const bool hact = hrole[l] && (unsigned)kh < (unsigned)r2;
-            SZH_UNROLL
-            for (int w = 0; w < NW; ++w) hv[w][l] = hact ? B::ld_gran(hbuf[l] + (hoff[l] + kh) * NW + w) : 0;
+    // bounded wait until an LDS counter reaches `need`; returns the value seen.  A lost hand-off ends the launch, it must not hang the GPU
+    szh_u64 tr_spins = 0;
+    auto wait_ctr = [&](const unsigned *ctr, int need) -> int {
+        int v = (int)B::lds_ld_u(ctr);
+        unsigned spins = 0;
+        while (v < need && !free_run) {
+            if (++spins > (1u << 24)) { SZH_FORL { if (B::lane(l) == 0) B::st_flag(a.err, 1u); } break; }
+            if ((spins & 4095u) == 0 && B::ld_flag(a.err) != 0) break;
+            B::backoff(1);
+            v = (int)B::lds_ld_u(ctr);
         }
+        tr_spins += spins;
+        return v;
     };
 
     // rolling neighbour state (values at the previous step)
@@ -294,83 +326,36 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, uint16_t *cring
 
     const int tsteps = r2 + 14;
     int flushed = 0, filled = 0;   // code-ring columns already written back (compress) / already brought in (decompress)
-    szh_u64 tr_start = 0, tr_gate = 0, tr_first = 0, tr_spins = 0, tr_naps = 0;
+    szh_u64 tr_start = 0, tr_first = 0;
     if (a.trace) tr_start = B::clock();
-    // ---- start gate: sleep (one lane polls ONE word per producer, long naps) until the producers are under way.
-    // Thousands of queued wavefronts polling granules instead would flood the fabric and slow every hand-off.
-    {
-        const int need = a.dbg ? 0 : (a.gate_steps < tsteps ? a.gate_steps : tsteps);
-        const szh_u64 want = ((szh_u64)a.epoch << 32) | (unsigned)need;
-        unsigned naps = 0;
-        for (;;) {
-            bool ok[NL];
-            if (a.dbg) break;
-            SZH_FORL {
-                ok[l] = true;
-                const int lane = B::lane(l);
-                if (lane == 0 && J > 0) { const szh_u64 p = B::ld_gran(a.progress + ((int64_t)I * a.nJ + (J - 1))); ok[l] = (p >> 32) == a.epoch && p >= want; }
-                if (lane == 1 && I > 0) { const szh_u64 p = B::ld_gran(a.progress + ((int64_t)(I - 1) * a.nJ + J)); ok[l] = (p >> 32) == a.epoch && p >= want; }
-            }
-            if (B::all(ok)) break;
-            if (++naps > (1u << 18) || B::ld_flag(a.err) != 0) break; // bounded; the granule waits below still guard correctness
-            B::nap();
-        }
-        tr_naps = naps;
-    }
-    if (a.trace) tr_gate = B::clock();
     const bool detail = a.trace && I == a.nI / 2 && J == a.nJ / 2;
     szh_u64 *dt = a.trace ? a.trace + (int64_t)a.nI * a.nJ * 8 : nullptr;
     for (int t0 = 0; t0 < tsteps; t0 += SZH_U) {
         if (detail && t0 / SZH_U < 64) { SZH_FORL { if (B::lane(l) == 0) dt[(t0 / SZH_U) * 4 + 0] = B::clock(); } }
-        SZH_UNROLL
-        for (int s = 0; s < SZH_U; ++s) load_halo(t0 + s, hr[s]);
-        if (DEC) { while (filled < t0 + SZH_U && filled < r2) { move_codes(filled); filled += 16; } } // ring holds columns < filled
+        // ring space: the consumers must have read the slots this trip overwrites.  A pencil of the tile reads column k no later
+        // than its step k+7; the STORE wavefront counts the columns it has forwarded.  (This trip writes columns <= t0 + SZH_U - 8.)
+        if (pubJ) { if (consJ_in) wait_ctr(L.cstep + myslot + 1, t0 + SZH_U - B::RL); else wait_ctr(L.spubJ + myslot, t0 + SZH_U - 7 - B::RL); }
+        if (pubI) { if (consI_in) wait_ctr(L.cstep + myslot + B::TPJ, t0 + SZH_U - B::RL); else wait_ctr(L.spubI + myslot, t0 + SZH_U - 7 - B::RL); }
+        // how far are the producers?  (step t needs their step t+7 finished)
+        int pstepJ = hasPJ ? (int)B::lds_ld_u(L.cstep + slotPJ) : (1 << 30);
+        int pstepI = hasPI ? (int)B::lds_ld_u(L.cstep + slotPI) : (1 << 30);
+        if (DEC) { while (filled < t0 + SZH_U && filled < r2) { move_codes(filled); filled += 8; } } // ring holds columns < filled
         load_x(t0);
+        if (detail && t0 / SZH_U < 64) { SZH_FORL { if (B::lane(l) == 0) dt[(t0 / SZH_U) * 4 + 1] = B::clock(); } }
         SZH_UNROLL
         for (int s = 0; s < SZH_U; ++s) {
             const int t = t0 + s;
-            // -- halo for this step.  Fast path: the granule requested at the top of the trip already carries this launch's epoch.
-            //    Slow path (cold): poll with fresh loads into a private copy; it never touches the ring registers.
+            // -- halo for this step: the producers' step t+7 must be complete (no halo is needed once t - hskew >= r2)
             T hval[NL];
             {
-                szh_u64 g[NW][NL];
-                bool ok[NL], hact[NL];
-                SZH_FORL {
+                const int need = t + 8 < tsteps ? t + 8 : tsteps;
+                if (pstepJ < need) pstepJ = wait_ctr(L.cstep + slotPJ, need);
+                if (pstepI < need) pstepI = wait_ctr(L.cstep + slotPI, need);
+                SZH_FORL {      // every lane reads (lanes without a halo row read a don't-care slot)
                     const int kh = t - hskew[l];
-                    hact[l] = hrole[l] && (unsigned)kh < (unsigned)r2;
-                    bool v = true;
-                    SZH_UNROLL
-                    for (int w = 0; w < NW; ++w) { g[w][l] = hr[s][w][l]; v = v && ((unsigned)(g[w][l] >> 32) == a.epoch); }
-                    ok[l] = !hact[l] || v;
-                }
-                if (!B::all(ok) && !a.dbg) {
-                    unsigned spins = 0;
-                    for (;;) {
-                        // bounded wait: a lost hand-off must end the launch, not hang the GPU
-                        if (++spins > (1u << 20)) { SZH_FORL { if (!ok[l]) B::st_flag(a.err, 1u); } break; }
-                        if ((spins & 255u) == 0 && B::ld_flag(a.err) != 0) break; // another wavefront already gave up
-                        B::backoff(a.backoff);
-                        SZH_FORL {
-                            if (!ok[l]) {
-                                const int kh = t - hskew[l];
-                                bool v = true;
-                                SZH_UNROLL
-                                for (int w = 0; w < NW; ++w) {
-                                    g[w][l] = B::ld_gran(hbuf[l] + (hoff[l] + kh) * NW + w);
-                                    v = v && ((unsigned)(g[w][l] >> 32) == a.epoch);
-                                }
-                                ok[l] = v;
-                            }
-                        }
-                        if (B::all(ok)) break;
-                    }
-                    tr_spins += spins;
-                }
-                SZH_FORL {
-                    szh_u64 w2[NW];
-                    SZH_UNROLL
-                    for (int w = 0; w < NW; ++w) w2[w] = g[w][l];
-                    hval[l] = hact[l] ? szh_gran<T>::unpack(w2) : (T)0;
+                    const bool lact = hlds[l] >= 0 && (unsigned)kh < (unsigned)r2;
+                    const T v = B::lds_ld(L.faces + (lact ? hlds[l] + B::ring(kh) * SZH_FROWS : trash[l]));
+                    hval[l] = lact ? v : (T)0;
                 }
             }
             // -- neighbours through cross-lane moves (values of the previous step) --
@@ -409,9 +394,10 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, uint16_t *cring
                         code = is_lor ? code : cr;
                         nv = is_lor ? rcl : rcr;
                     }
-                    if (act) cring[((unsigned)k % SZH_XC) * 64 + B::lane(l)] = (uint16_t)code;
+                    B::lds_st(cring + (act ? ((unsigned)k % SZH_XC) * 64 + lane : ctrash[l]), (uint16_t)code);
                 } else {
-                    const int c0 = act ? (int)cring[((unsigned)k % SZH_XC) * 64 + B::lane(l)] : radius;
+                    const int cread = (int)B::lds_ld(cring + (act ? ((unsigned)k % SZH_XC) * 64 + lane : ctrash[l]));
+                    const int c0 = act ? cread : radius;
                     int c = c0;
                     const T p = is_lor ? pred : predr;
                     bool is_mean = false;
@@ -421,26 +407,20 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, uint16_t *cring
                     }
                     nv = p + (T)(2 * (c - radius)) * eb;
                     if (USEMEAN && is_mean) nv = mean;
-                    if (act && c0 == 0) nv = ov[s][l];                              // pre-scattered unpredictable value (read at the top of the trip)
-                    ov[s][l] = nv;
+                    if (act && c0 == 0) nv = xr[s][l];                              // pre-scattered unpredictable value (read at the top of the trip)
+                    xr[s][l] = nv;
                 }
-                // publish faces for the pencils to the right / below
-                {
-                    szh_u64 w2[NW];
-                    szh_gran<T>::pack(nv, a.epoch, w2);
-                    if (act && pJ[l]) {
-                        SZH_UNROLL
-                        for (int w = 0; w < NW; ++w) B::st_gran(a.faceJ + (pubJoff[l] + k) * NW + w, w2[w]);
-                    }
-                    if (act && pI[l]) {
-                        SZH_UNROLL
-                        for (int w = 0; w < NW; ++w) B::st_gran(a.faceI + (pubIoff[l] + k) * NW + w, w2[w]);
-                    }
+                // faces for the pencils to the right / below (in this tile or, through the STORE wavefront, in the next one):
+                // every lane stores; lanes without a face row, or outside the k range, store to their trash slot
+                if (pubJ) B::lds_st(L.faces + ((act && pjb[l] >= 0) ? pjb[l] + B::ring(k) * SZH_FROWS : trash[l]), nv);
+                if (pubI) {
+                    B::lds_st(L.faces + ((act && pib[l] >= 0) ? pib[l] + B::ring(k) * SZH_FROWS : trash[l]), nv);
+                    // lane (7,0): its halo value IS the corner column of the pencil below, same k
+                    B::lds_st(L.faces + ((act && pcb[l] >= 0) ? pcb[l] + B::ring(k) * SZH_FROWS : trash[l]), hval[l]);
                 }
                 // roll the neighbour state.  Lanes outside the k range must hand on ZEROS (the reference's zero halo).  With
                 // Lorenzo-only data they produce zeros by themselves (zero input, zero neighbours); the mean shortcut, stale
                 // pre-scattered values and a regression plane (non-zero prediction at k < 0) need the mask.
-                if (detail && s == 0 && t0 / SZH_U < 64 && B::lane(l) == 0) dt[(t0 / SZH_U) * 4 + 1] = B::clock();
                 cur[l] = (USEMEAN || DEC || HASREG) ? (act ? nv : (T)0) : nv;
                 A1[l] = nA; B1[l] = nB; C1[l] = nC;
                 // advance along dim2
@@ -463,25 +443,28 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, uint16_t *cring
                     }
                 }
             }
+            // step t is complete: its face values are in the ring (LDS executes a wavefront's accesses in order)
+            B::lds_fence();
+            SZH_FORL { B::lds_st(L.cstep + myslot, (unsigned)(t + 1)); }
+            // half-way through the trip: write back the code columns that are complete (keeps the 32-column ring from wrapping)
+            if (!DEC && s == SZH_U / 2 - 1) { while (flushed + 8 <= t + 1 - 14 && flushed < r2) { move_codes(flushed); flushed += 8; } }
         }
         if (detail && t0 / SZH_U < 64) { SZH_FORL { if (B::lane(l) == 0) dt[(t0 / SZH_U) * 4 + 2] = B::clock(); } }
         if (DEC) store_out(t0);
         else {
-            // after this trip every lane is past column t0 + SZH_U - 15: flush the 16-column groups that are complete
-            while (flushed + 16 <= t0 + SZH_U - 14 && flushed < r2) { move_codes(flushed); flushed += 16; }
+            // after this trip every lane is past column t0 + SZH_U - 15: flush the 8-column groups that are complete
+            while (flushed + 8 <= t0 + SZH_U - 14 && flushed < r2) { move_codes(flushed); flushed += 8; }
         }
         if (detail && t0 / SZH_U < 64) { SZH_FORL { if (B::lane(l) == 0) dt[(t0 / SZH_U) * 4 + 3] = B::clock(); } }
         if (a.trace && t0 == 0) tr_first = B::clock();
-        // tell the consumers how far this pencil has got (one word, one lane)
-        SZH_FORL { if (B::lane(l) == 0) B::st_gran(a.progress + ((int64_t)I * a.nJ + J), ((szh_u64)a.epoch << 32) | (unsigned)(t0 + SZH_U)); }
     }
-    if (!DEC) { for (; flushed < r2; flushed += 16) move_codes(flushed); }
+    if (!DEC) { for (; flushed < r2; flushed += 8) move_codes(flushed); }
     if (a.trace) {
         const szh_u64 tr_end = B::clock();
         SZH_FORL {
             if (B::lane(l) == 0) {
                 szh_u64 *tp = a.trace + ((int64_t)I * a.nJ + J) * 8;
-                tp[0] = tr_start; tp[1] = tr_gate; tp[2] = tr_first; tp[3] = tr_end; tp[4] = tr_spins; tp[5] = tr_naps; tp[6] = B::where(); tp[7] = 0;
+                tp[0] = tr_start; tp[1] = tr_start; tp[2] = tr_first; tp[3] = tr_end; tp[4] = tr_spins; tp[6] = B::where(); tp[7] = 0;
             }
         }
     }
@@ -511,21 +494,226 @@ SZH_HD bool szh_pencil_has_reg(const szh_qargs<T> &a, int I, int J)
     return !B::all(none);
 }
 
-// cring: SZH_XC*64 uint16_t of LDS (HIP) / plain memory (simulator) private to this wavefront
+// L: this pencil's view of its tile's LDS (HIP) / plain memory (simulator); face rings and step counters must be zero at launch
 template <class T, bool DEC, class B>
-SZH_HD void szh_pencil_run(const szh_qargs<T> &a, int I, int J, uint16_t *cring)
+SZH_HD void szh_pencil_run(const szh_qargs<T> &a, int I, int J, const szh_tile_lds<T> &L)
 {
+#ifdef SZH_EXP_NOREG
+    const bool hasreg = false;
+#else
     const bool hasreg = szh_pencil_has_reg<T, B>(a, I, J);
+#endif
     if (a.use_mean) {
-        if (hasreg) szh_pencil_body<T, DEC, true, true, B>(a, I, J, cring);
-        else szh_pencil_body<T, DEC, false, true, B>(a, I, J, cring);
+        if (hasreg) szh_pencil_body<T, DEC, true, true, B>(a, I, J, L);
+        else szh_pencil_body<T, DEC, false, true, B>(a, I, J, L);
     } else {
-        if (hasreg) szh_pencil_body<T, DEC, true, false, B>(a, I, J, cring);
-        else szh_pencil_body<T, DEC, false, false, B>(a, I, J, cring);
+        if (hasreg) szh_pencil_body<T, DEC, true, false, B>(a, I, J, L);
+        else szh_pencil_body<T, DEC, false, false, B>(a, I, J, L);
     }
 }
 
-// anti-diagonal start order of the pencils: every dependency of a pencil has a smaller ticket
+// ---------------------------------------------------------------------------------------------------------------------
+// Helper wavefronts of a tile (TI, TJ) = pencils [TI*TPI, ...) x [TJ*TPJ, ...).  One ROW of a face per lane:
+//   lanes 0 .. 8*TPI-1          J-face rows: pencil row pi = lane / 8, face row il = lane % 8
+//   lanes 8*TPI .. 8*TPI+9*TPJ-1  I-face rows: pencil column pj = (lane - 8*TPI) / 9, face row r = (lane - 8*TPI) % 9 (8 = corner column)
+// sr = the step offset at which the PRODUCING pencil finishes column k of that row (k + sr); hs = the step offset at which
+// the CONSUMING pencil reads it (k + hs).
+template <class B> struct szh_rowmap {
+    bool isJ, valid; int pp, r, ringrow, sr, hs;
+    SZH_HD explicit szh_rowmap(int lane)
+    {
+        constexpr int NJ = 8 * B::TPI, NI = 9 * B::TPJ;
+        valid = lane < NJ + NI; isJ = lane < NJ;
+        if (isJ) { pp = lane >> 3; r = lane & 7; ringrow = r; sr = r + 7; hs = r; }
+        else { const int q = valid ? lane - NJ : 0; pp = q / 9; r = q - pp * 9; ringrow = 8 + r; sr = r < 8 ? 7 + r : 7; hs = r < 8 ? r : 0; }
+    }
+};
+// minimum of v over the lanes of each pencil group; result returned to every lane of the group (through the LDS scratch row)
+template <class B> SZH_HD void szh_group_min(int *scratch, const int (&v)[B::NL], int (&out)[B::NL])
+{
+    constexpr int NL = B::NL;
+    SZH_FORL { B::lds_st(scratch + B::lane(l), v[l]); }
+    B::lds_fence();
+    SZH_FORL {
+        const szh_rowmap<B> m(B::lane(l));
+        const int base = m.isJ ? m.pp * 8 : 8 * B::TPI + m.pp * 9, cnt = m.isJ ? 8 : 9;
+        int mn = 1 << 30;
+        if (m.valid) { for (int e = 0; e < cnt; ++e) { const int x = B::lds_ld(scratch + base + e); mn = x < mn ? x : mn; } }
+        out[l] = mn;
+    }
+    B::lds_fence();
+}
+
+// STORE wavefront (stores only): forwards the face rings of the tile's last column / last row of pencils to the granule buffers.
+template <class T, class B>
+SZH_HD void szh_tile_store(const szh_qargs<T> &a, int TI, int TJ, const szh_tile_lds<T> &L)
+{
+    constexpr int NL = B::NL;
+    constexpr int NW = szh_gran<T>::NW;
+    constexpr int KP = 4;                       // columns per row per round
+    const int r0 = a.G.g0.count, r1 = a.G.g1.count, r2 = a.G.g2.count;
+    const int stride = B::face_stride(r2);
+    int pk[NL], slot[NL], rbase[NL];
+    bool en[NL];
+    szh_u64 *dst[NL];
+    int64_t penc[NL];
+    SZH_FORL {
+        const szh_rowmap<B> m(B::lane(l));
+        // J-face rows come from the pencils of the tile's LAST column, I-face rows from its LAST row
+        const int I = m.isJ ? TI * B::TPI + m.pp : TI * B::TPI + B::TPI - 1, J = m.isJ ? TJ * B::TPJ + B::TPJ - 1 : TJ * B::TPJ + m.pp;
+        en[l] = m.valid && I < a.nI && J < a.nJ && a.dbg != 1;
+        if (m.isJ) en[l] = en[l] && J + 1 < a.nJ && 8 * I + m.r < r0;
+        else en[l] = en[l] && I + 1 < a.nI && (m.r < 8 ? 8 * J + m.r < r1 : J > 0);
+        penc[l] = (int64_t)I * a.nJ + J;
+        slot[l] = en[l] ? szh_slot<B>(I, J) : 0;
+        rbase[l] = slot[l] * stride + m.ringrow;
+        dst[l] = m.isJ ? a.faceJ + (penc[l] * 8 + m.r) * (int64_t)r2 * NW : a.faceI + (penc[l] * 9 + m.r) * (int64_t)r2 * NW;
+        pk[l] = en[l] ? 0 : r2;
+    }
+    int reported[NL];
+    SZH_FORL reported[l] = -1;
+    unsigned idle = 0;
+    for (;;) {
+        bool none[NL], fin[NL];
+        int steps[NL];
+        SZH_FORL {
+            const szh_rowmap<B> m(B::lane(l));
+            const int cs = (int)B::lds_ld(L.cstep + slot[l]);
+            int avail = cs - m.sr; if (avail > r2) avail = r2;
+            int n = avail - pk[l]; if (n > KP) n = KP; if (n < 0 || !en[l]) n = 0;
+            SZH_UNROLL
+            for (int e = 0; e < KP; ++e) {
+                if (e < n) {
+                    const int k = pk[l] + e;
+                    const T v = B::lds_ld(L.faces + rbase[l] + B::ring(k) * SZH_FROWS);
+                    szh_u64 w2[NW];
+                    szh_gran<T>::pack(v, a.epoch, w2);
+                    SZH_UNROLL
+                    for (int w = 0; w < NW; ++w) B::st_gran(dst[l] + (int64_t)k * NW + w, w2[w]);
+                }
+            }
+            pk[l] += n;
+            none[l] = n == 0; fin[l] = pk[l] >= r2;
+            steps[l] = en[l] ? (pk[l] >= r2 ? (1 << 29) : pk[l] + m.sr) : (1 << 30);
+        }
+        // per pencil: ring space for the producer (columns forwarded on every row) and the progress word for the consumers' FILL
+        int cols[NL], gcols[NL], gsteps[NL];
+        SZH_FORL cols[l] = en[l] ? pk[l] : (1 << 30);
+        szh_group_min<B>(L.scratch, cols, gcols);
+        szh_group_min<B>(L.scratch, steps, gsteps);
+        SZH_FORL {
+            const szh_rowmap<B> m(B::lane(l));
+            const bool leader = m.valid && m.r == 0 && gcols[l] < (1 << 30);
+            if (leader) {
+                const int I = m.isJ ? TI * B::TPI + m.pp : TI * B::TPI + B::TPI - 1, J = m.isJ ? TJ * B::TPJ + B::TPJ - 1 : TJ * B::TPJ + m.pp;
+                if (I < a.nI && J < a.nJ) B::lds_st((m.isJ ? L.spubJ : L.spubI) + szh_slot<B>(I, J), (unsigned)gcols[l]);
+            }
+        }
+        // progress words (one per pencil and face: [pencil][0] J-face, [pencil][1] I-face)
+        SZH_FORL {
+            const szh_rowmap<B> m(B::lane(l));
+            if (m.valid && m.r == 0 && gsteps[l] < (1 << 30)) {
+                int v = gsteps[l]; if (v > r2 + 14) v = r2 + 14;
+                if (v != reported[l]) { reported[l] = v; B::st_gran(a.progress + penc[l] * 2 + (m.isJ ? 0 : 1), ((szh_u64)a.epoch << 32) | (unsigned)v); }
+            }
+        }
+        if (B::all(fin)) break;
+        if (B::all(none)) {
+            if (++idle > (1u << 24)) { SZH_FORL { if (B::lane(l) == 0) B::st_flag(a.err, 1u); } break; }
+            if ((idle & 4095u) == 0 && B::ld_flag(a.err) != 0) break;
+            B::backoff(1);
+        } else idle = 0;
+    }
+}
+
+// FILL wavefront (loads only): follows the progress words of the producing pencils in the neighbouring tiles, fetches their
+// granules and delivers them to this tile's virtual-producer rings.  Only granules that the progress word covers are
+// requested (polling the granules themselves from every waiting tile floods the fabric); every granule is validated by its tag.
+template <class T, class B>
+SZH_HD void szh_tile_fill(const szh_qargs<T> &a, int TI, int TJ, const szh_tile_lds<T> &L)
+{
+    constexpr int NL = B::NL;
+    constexpr int NW = szh_gran<T>::NW;
+    constexpr int KF = 8;                       // columns per row per round
+    const int r0 = a.G.g0.count, r1 = a.G.g1.count, r2 = a.G.g2.count;
+    const int stride = B::face_stride(r2);
+    int fk[NL], cslot[NL], wbase[NL];
+    bool en[NL];
+    const szh_u64 *src[NL];
+    const szh_u64 *prog[NL];
+    SZH_FORL {
+        const szh_rowmap<B> m(B::lane(l));
+        // J-face rows feed the pencils of the tile's FIRST column (from the tile to the left), I-face rows its FIRST row (from above)
+        const int I = m.isJ ? TI * B::TPI + m.pp : TI * B::TPI, J = m.isJ ? TJ * B::TPJ : TJ * B::TPJ + m.pp;
+        en[l] = m.valid && I < a.nI && J < a.nJ && a.dbg != 1;
+        if (m.isJ) en[l] = en[l] && J > 0 && 8 * I + m.r < r0;
+        else en[l] = en[l] && I > 0 && (m.r < 8 ? 8 * J + m.r < r1 : J > 0);
+        const int64_t pp = m.isJ ? (int64_t)I * a.nJ + (J - 1) : (int64_t)(I - 1) * a.nJ + J;   // the producing pencil
+        src[l] = en[l] ? (m.isJ ? a.faceJ + (pp * 8 + m.r) * (int64_t)r2 * NW : a.faceI + (pp * 9 + m.r) * (int64_t)r2 * NW) : a.faceJ;
+        prog[l] = a.progress + (en[l] ? pp * 2 + (m.isJ ? 0 : 1) : 0);
+        cslot[l] = en[l] ? szh_slot<B>(I, J) : 0;
+        const int vslot = m.isJ ? szh_vslot_left<B>(I) : szh_vslot_top<B>(J);
+        wbase[l] = vslot * stride + m.ringrow;
+        fk[l] = en[l] ? 0 : r2;
+    }
+    unsigned idle = 0;
+    for (;;) {
+        // how far have the producers got?  (every lane asks for its own row's producer: a handful of distinct words per round)
+        szh_u64 g[KF][NW][NL];
+        bool none[NL], fin[NL];
+        int vsteps[NL];
+        SZH_FORL {
+            const szh_rowmap<B> m(B::lane(l));
+            int avail = 0;
+            if (en[l] && fk[l] < r2) {
+                const szh_u64 p = B::ld_gran(prog[l]);
+                const int ps = (unsigned)(p >> 32) == a.epoch ? (int)(unsigned)p : 0;
+                avail = ps - m.sr; if (avail > r2) avail = r2;
+                const int room = (int)B::lds_ld(L.cstep + cslot[l]) - 7 + B::RL;      // slots of columns < consumer step - 7 are free again
+                if (avail > room) avail = room;
+            }
+            int n = avail - fk[l]; if (n > KF) n = KF; if (n < 0) n = 0;
+            SZH_UNROLL
+            for (int e = 0; e < KF; ++e) {
+                SZH_UNROLL
+                for (int w = 0; w < NW; ++w) g[e][w][l] = e < n ? B::ld_gran(src[l] + (int64_t)(fk[l] + e) * NW + w) : 0;
+            }
+            int lead = 0; bool run = true;
+            SZH_UNROLL
+            for (int e = 0; e < KF; ++e) {
+                bool v = e < n;
+                szh_u64 w2[NW];
+                SZH_UNROLL
+                for (int w = 0; w < NW; ++w) { w2[w] = g[e][w][l]; v = v && ((unsigned)(w2[w] >> 32) == a.epoch); }
+                run = run && v;                    // a row advances by its run of leading delivered columns
+                if (run) { B::lds_st(L.faces + wbase[l] + B::ring(fk[l] + e) * SZH_FROWS, szh_gran<T>::unpack(w2)); ++lead; }
+            }
+            fk[l] += lead;
+            none[l] = lead == 0; fin[l] = fk[l] >= r2;
+            // the consumer reads column k of this row at its step k + hs: "steps covered" on the scale of the step counters (+7)
+            vsteps[l] = en[l] ? (fk[l] >= r2 ? (1 << 29) : fk[l] + m.hs + 7) : (1 << 30);
+        }
+        B::lds_fence();          // the values are in the ring before the counter says so
+        int gv[NL];
+        szh_group_min<B>(L.scratch + 64, vsteps, gv);
+        SZH_FORL {
+            const szh_rowmap<B> m(B::lane(l));
+            if (m.valid && m.r == 0) {
+                const int I = m.isJ ? TI * B::TPI + m.pp : TI * B::TPI, J = m.isJ ? TJ * B::TPJ : TJ * B::TPJ + m.pp;
+                const int vslot = m.isJ ? szh_vslot_left<B>(I) : szh_vslot_top<B>(J);
+                B::lds_st(L.cstep + vslot, (unsigned)gv[l]);
+            }
+        }
+        if (B::all(fin)) break;
+        if (B::all(none)) {
+            if (++idle > (1u << 22)) { SZH_FORL { if (B::lane(l) == 0) B::st_flag(a.err, 1u); } break; }
+            if ((idle & 1023u) == 0 && B::ld_flag(a.err) != 0) break;
+            B::backoff(a.backoff);
+        } else idle = 0;
+    }
+}
+
+// anti-diagonal start order (of the tiles): every dependency has a smaller ticket
 inline void szh_fill_pencil_order(int nI, int nJ, unsigned *order)
 {
     int n = 0;

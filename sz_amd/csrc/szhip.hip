@@ -124,24 +124,26 @@ size_t tile_bytes(const szh_geom3 &G, int segb, size_t elem)
     return rows * kp * elem + 16;
 }
 
-int prepare_pencil(szhip_ctx *ctx, const szh_geom3 &G, int nw, int *nI_out, int *nJ_out)
+// buffers of the wavefront kernel: granule faces, progress words, start order of the tiles (tpi x tpj pencils each)
+int prepare_pencil(szhip_ctx *ctx, const szh_geom3 &G, int nw, int tpi, int tpj, int *nI_out, int *nJ_out, int *ntiles_out)
 {
     const int nI = (G.g0.count + 7) / 8, nJ = (G.g1.count + 7) / 8;
     if (nI > 65535 || nJ > 65535) FAIL(SZHIP_ERR_UNSUP, "dimension too large for the pencil grid");
-    const size_t ng = (size_t)nI * nJ * 8 * (size_t)G.g2.count * nw * sizeof(u64);
-    TRY(ensure(ctx, ctx->faceI, ng, true));
-    TRY(ensure(ctx, ctx->faceJ, ng, true));
-    TRY(ensure(ctx, ctx->progress, (size_t)nI * nJ * sizeof(u64), true));
+    const size_t rowg = (size_t)G.g2.count * nw * sizeof(u64);
+    TRY(ensure(ctx, ctx->faceI, (size_t)nI * nJ * 9 * rowg, true));
+    TRY(ensure(ctx, ctx->faceJ, (size_t)nI * nJ * 8 * rowg, true));
+    TRY(ensure(ctx, ctx->progress, (size_t)nI * nJ * 2 * sizeof(u64), true));
     if (tune_int("SZ_HIP_TRACE", 0)) TRY(ensure(ctx, ctx->trace, ((size_t)nI * nJ * 8 + 256) * sizeof(u64), true));
-    if (ctx->order_nI != nI || ctx->order_nJ != nJ) {
-        std::vector<unsigned> ord((size_t)nI * nJ);
-        szh_fill_pencil_order(nI, nJ, ord.data());
+    const int nTI = (nI + tpi - 1) / tpi, nTJ = (nJ + tpj - 1) / tpj;
+    if (ctx->order_nI != nTI || ctx->order_nJ != nTJ) {
+        std::vector<unsigned> ord((size_t)nTI * nTJ);
+        szh_fill_pencil_order(nTI, nTJ, ord.data());
         TRY(ensure(ctx, ctx->order, ord.size() * 4));
         HIPCHK(hipMemcpyAsync(ctx->order.p, ord.data(), ord.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
-        ctx->order_nI = nI; ctx->order_nJ = nJ;
+        ctx->order_nI = nTI; ctx->order_nJ = nTJ;
     }
-    *nI_out = nI; *nJ_out = nJ;
+    *nI_out = nI; *nJ_out = nJ; *ntiles_out = nTI * nTJ;
     return SZHIP_OK;
 }
 
@@ -346,8 +348,9 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     TRY(ensure(ctx, ctx->codes_nat, (size_t)n * 2 + 64));
     TRY(ensure(ctx, ctx->codes_blk, (size_t)n * 2 + 64));
     uint16_t *d_nat = (uint16_t *)ctx->codes_nat.p, *d_blk = (uint16_t *)ctx->codes_blk.p;
-    int nI, nJ;
-    TRY(prepare_pencil(ctx, G, szh_gran<T>::NW, &nI, &nJ));
+    int nI, nJ, ntiles;
+    using TS = szh_tile_shape<T>;
+    TRY(prepare_pencil(ctx, G, szh_gran<T>::NW, TS::TPI, TS::TPJ, &nI, &nJ, &ntiles));
     {
         szh_qargs<T> a; memset(&a, 0, sizeof(a));
         a.G = G; a.data = d_in; a.out = nullptr; a.codes = d_nat; a.blk_lor = d_lor; a.coef = d_coef;
@@ -359,7 +362,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         a.trace = tune_int("SZ_HIP_TRACE", 0) ? (szh_u64 *)ctx->trace.p : nullptr;
         a.dbg = tune_int("SZ_HIP_DBG", 0);
         HIPCHK(hipEventRecord(ctx->ev[2], st));
-        hipLaunchKernelGGL((k_pencil<T, false>), dim3((unsigned)(nI * nJ)), dim3(64), 0, st, a);
+        hipLaunchKernelGGL((k_pencil<T, false>), dim3((unsigned)ntiles), dim3((TS::TPI * TS::TPJ + 2) * 64), 0, st, a);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(ctx->ev[3], st));
         S.quant_kernel_launches = 1;
@@ -737,8 +740,9 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
     HIPCHK(hipEventRecord(ctx->ev[1], st));
 
     // ---- reconstruct: the wavefront kernel
-    int nI, nJ;
-    TRY(prepare_pencil(ctx, G, szh_gran<T>::NW, &nI, &nJ));
+    int nI, nJ, ntiles;
+    using TS = szh_tile_shape<T>;
+    TRY(prepare_pencil(ctx, G, szh_gran<T>::NW, TS::TPI, TS::TPJ, &nI, &nJ, &ntiles));
     {
         szh_qargs<T> a; memset(&a, 0, sizeof(a));
         a.G = G; a.data = nullptr; a.out = d_out; a.codes = d_nat; a.blk_lor = (const uint8_t *)ctx->blk_lor.p; a.coef = (const T *)ctx->coef.p;
@@ -750,7 +754,7 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
         a.trace = tune_int("SZ_HIP_TRACE", 0) ? (szh_u64 *)ctx->trace.p : nullptr;
         a.dbg = tune_int("SZ_HIP_DBG", 0);
         HIPCHK(hipEventRecord(ctx->ev[2], st));
-        hipLaunchKernelGGL((k_pencil<T, true>), dim3((unsigned)(nI * nJ)), dim3(64), 0, st, a);
+        hipLaunchKernelGGL((k_pencil<T, true>), dim3((unsigned)ntiles), dim3((TS::TPI * TS::TPJ + 2) * 64), 0, st, a);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(ctx->ev[3], st));
         S.quant_kernel_launches = 1;

@@ -79,12 +79,55 @@ __device__ __forceinline__ u64 block_excl_scan_256(u64 v, u64 *sh, u64 *total)
 }
 
 // ------------------------------------------------------------------ the wavefront kernel
+// TPI x TPJ pencils per workgroup (one wavefront each); RL = columns of a face ring
+template <int TPI_, int TPJ_, int RL_>
 struct GpuBackend {
     static constexpr int NL = 1;
+    static constexpr int TPI = TPI_, TPJ = TPJ_, RL = RL_;
+    __device__ static int ring(int k) { return k & (RL - 1); }
+    __device__ static int face_stride(int) { return RL * SZH_FROWS; }
+
     __device__ static int lane(int) { return (int)(threadIdx.x & 63); }
     template <class T> __device__ static void shfl_up(T (&dst)[1], const T (&src)[1], int d) { dst[0] = __shfl_up(src[0], d, 64); }
+#ifdef SZH_HIPSIM
     template <class T> __device__ static T readlane(const T (&src)[1], int lane) { return __shfl(src[0], lane, 64); }
+#else
+    // lane is wavefront-uniform: v_readlane_b32 instead of a trip through the LDS crossbar
+    template <class T> __device__ static T readlane(const T (&src)[1], int lane)
+    {
+        int w[sizeof(T) / 4];
+        __builtin_memcpy(w, &src[0], sizeof(T));
+        for (unsigned i = 0; i < sizeof(T) / 4; ++i) w[i] = __builtin_amdgcn_readlane(w[i], lane);
+        T r; __builtin_memcpy(&r, w, sizeof(T));
+        return r;
+    }
+#endif
     __device__ static bool all(const bool (&p)[1]) { return __all(p[0] ? 1 : 0) != 0; }
+    // LDS face rings of the tile: volatile ds_* accesses (a wavefront's LDS accesses execute in program order)
+#ifdef SZH_HIPSIM
+    template <class E> __device__ static E lds_ld(const E *p)
+    {
+        E v;
+        if (sizeof(E) == 8) { const uint64_t u = __atomic_load_n((const uint64_t *)p, __ATOMIC_RELAXED); memcpy(&v, &u, sizeof(E)); }
+        else if (sizeof(E) == 4) { const uint32_t u = __atomic_load_n((const uint32_t *)p, __ATOMIC_RELAXED); memcpy(&v, &u, sizeof(E)); }
+        else { const uint16_t u = __atomic_load_n((const uint16_t *)p, __ATOMIC_RELAXED); memcpy(&v, &u, sizeof(E)); }
+        return v;
+    }
+    template <class E> __device__ static void lds_st(E *p, E v)
+    {
+        if (sizeof(E) == 8) { uint64_t u; memcpy(&u, &v, sizeof(E)); __atomic_store_n((uint64_t *)p, u, __ATOMIC_RELAXED); }
+        else if (sizeof(E) == 4) { uint32_t u; memcpy(&u, &v, sizeof(E)); __atomic_store_n((uint32_t *)p, u, __ATOMIC_RELAXED); }
+        else { uint16_t u; memcpy(&u, &v, sizeof(E)); __atomic_store_n((uint16_t *)p, u, __ATOMIC_RELAXED); }
+    }
+    template <class E> __device__ static E lds_ld_u(const E *p) { return __shfl(lds_ld(p), 0, 64); } // one read, so every lane branches alike
+    // lanes are free-running OS threads in the shim: re-converge the wavefront, as lock-step execution would
+    __device__ static void lds_fence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); (void)__all(1); __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+#else
+    template <class E> __device__ static E lds_ld(const E *p) { return *(const volatile __attribute__((address_space(3))) E *)p; }
+    template <class E> __device__ static void lds_st(E *p, E v) { *(volatile __attribute__((address_space(3))) E *)p = v; }
+    template <class E> __device__ static E lds_ld_u(const E *p) { return (E)__builtin_amdgcn_readfirstlane((int)lds_ld(p)); } // scalar: waits on it are s_cmp/s_cbranch
+    __device__ static void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#endif
     __device__ static szh_u64 ld_gran(const szh_u64 *p)
     {
         return __hip_atomic_load(const_cast<szh_u64 *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -114,15 +157,48 @@ struct GpuBackend {
     __device__ static void nap() { __builtin_amdgcn_s_sleep(40); } // ~1 us
 };
 
+// tile shape by element type: TPI x TPJ COMPUTE wavefronts + STORE + FILL per workgroup.  float: 14 wavefronts (<= 128 VGPRs
+// each) fill most of a CU; double needs twice the registers, so half the wavefronts
+template <class T> struct szh_tile_shape;
+template <> struct szh_tile_shape<float> { static constexpr int TPI = 4, TPJ = 3, RL = 64; };
+template <> struct szh_tile_shape<double> { static constexpr int TPI = 3, TPJ = 2, RL = 64; };
+
 template <class T, bool DEC>
-__global__ __launch_bounds__(64) void k_pencil(szh_qargs<T> a)
+__global__ __launch_bounds__((szh_tile_shape<T>::TPI * szh_tile_shape<T>::TPJ + 2) * 64) void k_pencil(szh_qargs<T> a)
 {
-    unsigned tk = 0;
-    if (threadIdx.x == 0) tk = atomicAdd(a.ticket, 1u);
-    tk = __shfl(tk, 0, 64);
-    const unsigned ij = a.order[tk];
-    __shared__ uint16_t cring[SZH_XC * 64];
-    szh_pencil_run<T, DEC, GpuBackend>(a, (int)(ij >> 16), (int)(ij & 0xffffu), cring);
+    using S = szh_tile_shape<T>;
+    using B = GpuBackend<S::TPI, S::TPJ, S::RL>;
+    constexpr int NP = S::TPI * S::TPJ, NV = S::TPI + S::TPJ, NT = (NP + 2) * 64;
+    __shared__ uint16_t cring[NP * (SZH_XC + 1) * 64];
+    __shared__ T faces[(NP + NV) * S::RL * SZH_FROWS + 64];
+    __shared__ unsigned cstep[NP + NV];
+    __shared__ unsigned spubJ[NP], spubI[NP];
+    __shared__ int scratch[128];
+    __shared__ unsigned tk_s;
+    if (threadIdx.x < NP + NV) cstep[threadIdx.x] = 0;
+    if (threadIdx.x < NP) { spubJ[threadIdx.x] = 0; spubI[threadIdx.x] = 0; }
+    if (threadIdx.x == 0) tk_s = atomicAdd(a.ticket, 1u);
+    __syncthreads();
+    (void)NT;
+    const unsigned ij = a.order[tk_s];
+    const int w = (int)(threadIdx.x >> 6);
+    const int TI = (int)(ij >> 16), TJ = (int)(ij & 0xffffu);
+    const szh_tile_lds<T> L{cring, faces, (NP + NV) * S::RL * SZH_FROWS, cstep, spubJ, spubI, scratch};
+#ifndef SZH_HIPSIM
+    // issue priority: the helpers (light, latency-critical) first, then the pencils in dependency order, so that the chain
+    // of hand-offs advances at single-wavefront speed while the downstream pencils fill the issue gaps
+    if (a.dbg != 4) {
+        const int d = w < NP ? (w / S::TPJ + w % S::TPJ) : 0;
+        if (d == 0) __builtin_amdgcn_s_setprio(3); else if (d == 1) __builtin_amdgcn_s_setprio(2);
+        else if (d <= 3) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+    }
+#endif
+    if (w < NP) {
+        const int I = TI * S::TPI + w / S::TPJ, J = TJ * S::TPJ + w % S::TPJ;
+        if (I >= a.nI || J >= a.nJ) return;         // ragged tile: this wavefront has no pencil
+        szh_pencil_run<T, DEC, B>(a, I, J, L);
+    } else if (w == NP) szh_tile_store<T, B>(a, TI, TJ, L);
+    else szh_tile_fill<T, B>(a, TI, TJ, L);
 }
 
 // ------------------------------------------------------------------ per-block stage (fit + select)

@@ -5,6 +5,7 @@
 // stream assembly); it says nothing about the GPU memory model or performance.
 #pragma once
 #include <pthread.h>
+#include <sched.h>
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
@@ -77,7 +78,7 @@ inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 inline long long __double_as_longlong(double d) { long long u; memcpy(&u, &d, 8); return u; }
-inline void __builtin_amdgcn_s_sleep(int) {}
+inline void __builtin_amdgcn_s_sleep(int) { sched_yield(); } // waiting "wavefronts" are OS threads here
 inline unsigned long long wall_clock64() { return 0; }
 inline int min(int a, int b) { return a < b ? a : b; }
 

@@ -23,7 +23,7 @@ struct Barrier {
         else cv.wait(lk, [&] { return gen != g; });
     }
 };
-constexpr int MAXT = 256;
+constexpr int MAXT = 1024;
 Barrier g_block_bar, g_wave_bar[MAXT / 64], g_start, g_done;
 alignas(16) unsigned char g_xbuf[MAXT / 64][64][16];
 int g_nthreads = 0;

@@ -20,6 +20,15 @@ struct SimBackend {
         for (int l = 0; l < 64; ++l) dst[l] = tmp[l];
     }
     template <class T> static T readlane(const T (&src)[64], int lane) { return src[lane]; }
+    // tiles of 2 x 3 pencils.  The simulator runs a tile's FILL, its pencils and its STORE one after the other, so a ring must
+    // keep every column: RL covers all of dim2.
+    static constexpr int TPI = 2, TPJ = 3, RL = 1 << 20;
+    static int ring(int k) { return k; }
+    static int face_stride(int r2) { return r2 * SZH_FROWS; }
+    template <class E> static E lds_ld(const E *p) { return *p; }
+    template <class E> static E lds_ld_u(const E *p) { return *p; }
+    template <class E> static void lds_st(E *p, E v) { *p = v; }
+    static void lds_fence() {}
     static bool all(const bool (&p)[64]) { for (int l = 0; l < 64; ++l) if (!p[l]) return false; return true; }
     static szh_u64 ld_gran(const szh_u64 *p) { return *p; }
     static void st_gran(szh_u64 *p, szh_u64 v) { *p = v; }
@@ -38,17 +47,37 @@ static int run_all(szh_qargs<T> a)
 {
     const int r0 = a.G.g0.count, r1 = a.G.g1.count, r2 = a.G.g2.count;
     a.nI = (r0 + 7) / 8; a.nJ = (r1 + 7) / 8;
-    const size_t ng = (size_t)a.nI * a.nJ * 8 * r2 * szh_gran<T>::NW;
+    const size_t ng = (size_t)a.nI * a.nJ * 9 * r2 * szh_gran<T>::NW;
     std::vector<szh_u64> fI(ng, 0), fJ(ng, 0);
     a.faceI = fI.data(); a.faceJ = fJ.data(); a.epoch = 7;
-    std::vector<unsigned> order((size_t)a.nI * a.nJ);
-    szh_fill_pencil_order(a.nI, a.nJ, order.data());
+    using B = SimBackend;
+    const int nTI = (a.nI + B::TPI - 1) / B::TPI, nTJ = (a.nJ + B::TPJ - 1) / B::TPJ;
+    std::vector<unsigned> order((size_t)nTI * nTJ);
+    szh_fill_pencil_order(nTI, nTJ, order.data());
     unsigned err = 0; a.err = &err;
-    std::vector<szh_u64> prog((size_t)a.nI * a.nJ, 0);
+    std::vector<szh_u64> prog((size_t)a.nI * a.nJ * 2, 0);
     a.progress = prog.data(); a.gate_steps = 16; a.backoff = 1;
-    std::vector<uint16_t> ring(SZH_XC * 64, 0xDEAD);
-    for (size_t tk = 0; tk < order.size(); ++tk)
-        szh_pencil_run<T, DEC, SimBackend>(a, (int)(order[tk] >> 16), (int)(order[tk] & 0xffff), ring.data());
+    constexpr int NP = B::TPI * B::TPJ, NV = B::TPI + B::TPJ;
+    std::vector<uint16_t> ring((size_t)NP * (SZH_XC + 1) * 64);
+    // "LDS" of one tile: face arrays [r2][SZH_FROWS] per slot, poisoned so that a value used before it is written shows
+    const size_t fsz = (size_t)(NP + NV) * r2 * SZH_FROWS;
+    std::vector<T> faces(fsz + 64);
+    std::vector<unsigned> cstep(NP + NV), spubJ(NP), spubI(NP);
+    std::vector<int> scratch(128);
+    for (size_t tk = 0; tk < order.size(); ++tk) {
+        const int TI = (int)(order[tk] >> 16), TJ = (int)(order[tk] & 0xffff);
+        std::fill(ring.begin(), ring.end(), (uint16_t)0xDEAD);
+        std::fill(faces.begin(), faces.end(), (T)-777);
+        std::fill(cstep.begin(), cstep.end(), 0u); std::fill(spubJ.begin(), spubJ.end(), 0u); std::fill(spubI.begin(), spubI.end(), 0u);
+        szh_tile_lds<T> L{ring.data(), faces.data(), (int)fsz, cstep.data(), spubJ.data(), spubI.data(), scratch.data()};
+        szh_tile_fill<T, B>(a, TI, TJ, L);
+        for (int pi = 0; pi < B::TPI; ++pi)
+            for (int pj = 0; pj < B::TPJ; ++pj) {
+                const int I = TI * B::TPI + pi, J = TJ * B::TPJ + pj;
+                if (I < a.nI && J < a.nJ) szh_pencil_run<T, DEC, B>(a, I, J, L);
+            }
+        szh_tile_store<T, B>(a, TI, TJ, L);
+    }
     return (int)err;
 }
 
