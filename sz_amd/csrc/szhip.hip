@@ -32,7 +32,7 @@ struct szhip_ctx {
     char err[512] = {0};
     unsigned epoch = 0;
     // workspaces (grow-only)
-    DevBuf lor_bits, in, out, codes_nat, codes_blk, coef, blk_lor, faceI, faceJ, progress, trace, order, small, hist, col_zeros, col_zeros64,
+    DevBuf lor_bits, reg_flags, reg_rank, coef_compact, in, out, codes_nat, codes_blk, coef, blk_lor, faceI, faceJ, progress, trace, order, small, hist, col_zeros, col_zeros64,
         col_off, partial, samples, unpred, stream_buf, chunk_bits, chunk_off, code_tab, len_tab, dec_tab,
         starts, ends, counts, offs, dirty;
     void *pinned = nullptr; size_t pinned_cap = 0;
@@ -104,7 +104,7 @@ int scan_u64(szhip_ctx *ctx, const u64 *in, int64_t n, u64 *out, u64 *total_dev)
 
 // layout of the "small" device scratch (u64 slots)
 enum { SM_MINMAX = 0, SM_WITHIN = 2, SM_MEANCNT = 3, SM_TOTAL_UNPRED = 4, SM_TOTAL_BITS = 5, SM_TICKET = 6, SM_ERR = 7,
-       SM_CHANGED = 8, SM_MEANSUM = 9, SM_TOTAL_SYM = 10, SM_NREG = 11, SM_COUNT = 16 };
+       SM_CHANGED = 8, SM_MEANSUM = 9, SM_TOTAL_SYM = 10, SM_NREG = 11, SM_SCRATCH = 12, SM_COUNT = 16 };
 
 int choose_segb(const szh_geom3 &G, size_t elem, size_t budget)
 {
@@ -296,22 +296,26 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     HIPCHK(hipStreamSynchronize(st));
     const size_t reg_count = (size_t)nreg64;
     S.n_reg_blocks = reg_count;
-    std::vector<unsigned char> indicator;
-    if (reg_count > 0) {
-        indicator.resize((size_t)nb);
-        HIPCHK(hipMemcpyAsync(indicator.data(), d_lor, (size_t)nb, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-    }
-
     // ---- regression coefficient chain (serial, host) and its Huffman streams
     szhost_coeffs cf; memset(&cf, 0, sizeof(cf));
     std::vector<unsigned char> coef_sections;
     if (reg_count > 0) {
-        std::vector<T> hcoef((size_t)nb * 4);
-        HIPCHK(hipMemcpyAsync(hcoef.data(), d_coef, hcoef.size() * sizeof(T), hipMemcpyDeviceToHost, st));
+        // only the regression blocks' coefficients travel: rank them in scan order, gather [4][reg_count], chain on the host
+        // (the compact arrays are "all regression blocks" to szhost_coeff_chain), scatter the decoded values back
+        TRY(ensure(ctx, ctx->reg_flags, (size_t)nb * 8));
+        TRY(ensure(ctx, ctx->reg_rank, (size_t)nb * 8));
+        TRY(ensure(ctx, ctx->coef_compact, reg_count * 4 * sizeof(T)));
+        hipLaunchKernelGGL(k_reg_flags, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, (const uint8_t *)d_lor, nb, (u64 *)ctx->reg_flags.p);
+        TRY(scan_u64(ctx, (const u64 *)ctx->reg_flags.p, nb, (u64 *)ctx->reg_rank.p, sm + SM_SCRATCH));
+        hipLaunchKernelGGL((k_move_coef<T, 0>), dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, (const uint8_t *)d_lor,
+                           (const u64 *)ctx->reg_rank.p, nb, (int64_t)reg_count, d_coef, (T *)ctx->coef_compact.p);
+        HIPCHK(hipGetLastError());
+        std::vector<T> hcoef(reg_count * 4);
+        HIPCHK(hipMemcpyAsync(hcoef.data(), ctx->coef_compact.p, hcoef.size() * sizeof(T), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         double h0 = now_ms();
-        szhost_coeff_chain(is_double, hcoef.data(), indicator.data(), (size_t)nb, (double)eb, G.g0.late, G.g1.late, G.g2.late,
+        const std::vector<unsigned char> all_reg(reg_count, 0);
+        szhost_coeff_chain(is_double, hcoef.data(), all_reg.data(), reg_count, (double)eb, G.g0.late, G.g1.late, G.g2.late,
                            use_mean, &cf);
         for (int e = 0; e < 4; ++e) {
             std::vector<uint32_t> h32(65536, 0);
@@ -339,7 +343,10 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         }
         host_ms += now_ms() - h0;
         szhost_coeffs_free(&cf);
-        HIPCHK(hipMemcpyAsync(d_coef, hcoef.data(), hcoef.size() * sizeof(T), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(ctx->coef_compact.p, hcoef.data(), hcoef.size() * sizeof(T), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL((k_move_coef<T, 1>), dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, (const uint8_t *)d_lor,
+                           (const u64 *)ctx->reg_rank.p, nb, (int64_t)reg_count, d_coef, (T *)ctx->coef_compact.p);
+        HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(st)); // hcoef goes out of scope
     }
     HIPCHK(hipEventRecord(ctx->ev[1], st));
@@ -502,7 +509,7 @@ template <class T> struct dec_header {
     T eb = 0, mean = 0;
     unsigned intervals = 0; int use_mean = 0, n_nodes = 0, single_symbol = -1;
     size_t reg_count = 0, ind_off = 0, unpred_off = 0, pay_off = 0; uint64_t total_unpred = 0;
-    std::vector<unsigned char> indicator; std::vector<T> coef; std::vector<uint32_t> dtab;
+    std::vector<T> coef; std::vector<uint32_t> dtab;   // coef: decoded regression coefficients, compact [4][reg_count]
 };
 
 // returns 0 = parsed, 1 = needs at least *need bytes of the stream on the host, < 0 = malformed (message in err)
@@ -541,11 +548,6 @@ int parse_header(const unsigned char *hs, size_t avail, size_t stream_len, size_
         H.reg_count = nb - ones;
     }
     H.ind_off = (size_t)(q - hs);
-    H.indicator.clear();
-    if (H.reg_count > 0) {
-        H.indicator.resize(nb);
-        for (size_t b = 0; b < nb; ++b) H.indicator[b] = (q[b >> 3] >> (7 - (b & 7))) & 1;
-    }
     q += ind_bytes;
     H.coef.clear();
     if (H.reg_count > 0) {
@@ -579,8 +581,10 @@ int parse_header(const unsigned char *hs, size_t avail, size_t stream_len, size_
             NEED((size_t)cu * sizeof(T));
             cun[e] = q; q += (size_t)cu * sizeof(T);
         }
-        H.coef.assign(nb * 4, (T)0);
-        szhost_coeff_unchain(is_double, H.coef.data(), H.indicator.data(), nb, cptr, crad, cprec, cun);
+        // compact [4][reg_count] in scan order; the device scatters them to the blocks (k_move_coef)
+        H.coef.assign(H.reg_count * 4, (T)0);
+        const std::vector<unsigned char> all_reg(H.reg_count, 0);
+        szhost_coeff_unchain(is_double, H.coef.data(), all_reg.data(), H.reg_count, cptr, crad, cprec, cun);
     }
     NEED(8);
     memcpy(&H.total_unpred, q, 8); q += 8;
@@ -733,10 +737,21 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
     }
     TRY(ensure(ctx, ctx->coef, (size_t)nb * 4 * sizeof(T)));
     TRY(ensure(ctx, ctx->blk_lor, (size_t)nb));
-    if (reg_count > 0) HIPCHK(hipMemcpyAsync(ctx->coef.p, hcoef.data(), hcoef.size() * sizeof(T), hipMemcpyHostToDevice, st));
+
     hipLaunchKernelGGL(k_unpack_lor, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, (const uint8_t *)(d_stream + H.ind_off), nb,
                        (uint8_t *)ctx->blk_lor.p);
     HIPCHK(hipGetLastError());
+    if (reg_count > 0) {
+        TRY(ensure(ctx, ctx->reg_flags, (size_t)nb * 8));
+        TRY(ensure(ctx, ctx->reg_rank, (size_t)nb * 8));
+        TRY(ensure(ctx, ctx->coef_compact, reg_count * 4 * sizeof(T)));
+        HIPCHK(hipMemcpyAsync(ctx->coef_compact.p, hcoef.data(), hcoef.size() * sizeof(T), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_reg_flags, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, (const uint8_t *)ctx->blk_lor.p, nb, (u64 *)ctx->reg_flags.p);
+        TRY(scan_u64(ctx, (const u64 *)ctx->reg_flags.p, nb, (u64 *)ctx->reg_rank.p, sm + SM_SCRATCH));
+        hipLaunchKernelGGL((k_move_coef<T, 1>), dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, (const uint8_t *)ctx->blk_lor.p,
+                           (const u64 *)ctx->reg_rank.p, nb, (int64_t)reg_count, (T *)ctx->coef.p, (T *)ctx->coef_compact.p);
+        HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipEventRecord(ctx->ev[1], st));
 
     // ---- reconstruct: the wavefront kernel
@@ -802,7 +817,7 @@ void szhip_destroy(szhip_ctx *ctx)
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->lor_bits, &ctx->in, &ctx->out, &ctx->codes_nat, &ctx->codes_blk, &ctx->coef, &ctx->blk_lor, &ctx->faceI, &ctx->faceJ, &ctx->progress, &ctx->trace,
+    DevBuf *bufs[] = {&ctx->lor_bits, &ctx->reg_flags, &ctx->reg_rank, &ctx->coef_compact, &ctx->in, &ctx->out, &ctx->codes_nat, &ctx->codes_blk, &ctx->coef, &ctx->blk_lor, &ctx->faceI, &ctx->faceJ, &ctx->progress, &ctx->trace,
                       &ctx->order, &ctx->small, &ctx->hist, &ctx->col_zeros, &ctx->col_zeros64, &ctx->col_off, &ctx->partial,
                       &ctx->samples, &ctx->unpred, &ctx->stream_buf, &ctx->chunk_bits, &ctx->chunk_off, &ctx->code_tab,
                       &ctx->len_tab, &ctx->dec_tab, &ctx->starts, &ctx->ends, &ctx->counts, &ctx->offs, &ctx->dirty};

@@ -161,7 +161,7 @@ struct GpuBackend {
 // each) fill most of a CU; double needs twice the registers, so half the wavefronts
 template <class T> struct szh_tile_shape;
 template <> struct szh_tile_shape<float> { static constexpr int TPI = 4, TPJ = 3, RL = 64; };
-template <> struct szh_tile_shape<double> { static constexpr int TPI = 3, TPJ = 2, RL = 64; };
+template <> struct szh_tile_shape<double> { static constexpr int TPI = 3, TPJ = 3, RL = 32; };
 
 template <class T, bool DEC>
 __global__ __launch_bounds__((szh_tile_shape<T>::TPI * szh_tile_shape<T>::TPJ + 2) * 64) void k_pencil(szh_qargs<T> a)
@@ -577,6 +577,26 @@ __global__ __launch_bounds__(256) void k_unpack_lor(const uint8_t *__restrict__ 
 {
     const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (b < nb) lor[b] = (bits[b >> 3] >> (7 - (b & 7))) & 1;
+}
+
+// regression blocks in scan order: flags for the rank scan, and the coefficient gather / scatter between the SoA-by-block
+// arrays [4][nblocks] and the compact arrays [4][reg_count] the serial chain on the host works on
+__global__ __launch_bounds__(256) void k_reg_flags(const uint8_t *__restrict__ lor, int64_t nb, u64 *flags)
+{
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b < nb) flags[b] = lor[b] ? 0ull : 1ull;
+}
+template <class T, int DIR>
+__global__ __launch_bounds__(256) void k_move_coef(const uint8_t *__restrict__ lor, const u64 *__restrict__ rank, int64_t nb, int64_t nreg,
+                                                   T *coef, T *compact)
+{
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= nb || lor[b]) return;
+    const int64_t r = (int64_t)rank[b];
+    for (int e = 0; e < 4; ++e) {
+        if (DIR == 0) compact[(int64_t)e * nreg + r] = coef[(int64_t)e * nb + b];
+        else coef[(int64_t)e * nb + b] = compact[(int64_t)e * nreg + r];
+    }
 }
 
 // ------------------------------------------------------------------ Huffman bit packing
