@@ -54,9 +54,8 @@ template <class T> struct szh_qargs {
     unsigned *err;            // set to 1 if a halo wait timed out
     szh_u64 *progress;        // [pencil][2] (J-face, I-face): {epoch, steps whose face values have been published}: the consumers' FILL
                               // wavefront polls these words and then fetches only granules that exist
-    int gate_steps;           // a pencil starts once both producers have completed this many steps
-    int backoff;              // sleep units between two polls of a missing granule
-    int dbg;                  // development timing experiments (results become WRONG): 1 = no hand-off at all, 2 = no publishing stores
+    int backoff;              // FILL wavefront: sleep units between two rounds that delivered nothing
+    int dbg;                  // development: 1 = no hand-off at all (timing only, results become WRONG), 4 = no issue priorities
     szh_u64 *trace;           // optional (development): per pencil {t_start, t_gate, t_first, t_end, spins, naps, cu, 0}
 };
 
