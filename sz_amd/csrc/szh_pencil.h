@@ -91,7 +91,8 @@ template <> struct szh_gran<double> {
 // B::ring(k) maps a column to its ring slot.
 template <class T> struct szh_tile_lds {
     uint16_t *cring;          // [NP][(SZH_XC + 1)][64] quantisation codes in flight per pencil (+ trash column)
-    T *faces;                 // [NP + NV][RL][SZH_FROWS] face rings: rows 0-7 = J-face (il), 8-15 = I-face (jl), 16 = corner column
+    T *faces;                 // [NP + NV][SZH_FROWS][row stride] face rings: rows 0-7 = J-face (il), 8-15 = I-face (jl), 16 = corner column;
+                              // the row stride (RL + 2) spreads the skewed columns of neighbouring rows over different LDS banks
                               // forwarded to the pencil below
     int ftrash;               // element offset in faces[] of 64 write-only / don't-care slots (one per lane): masked-off lanes go there,
                               // so that the ring accesses need no exec-mask juggling
@@ -160,7 +161,7 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
     const int slotPJ = pj > 0 ? myslot - 1 : szh_vslot_left<B>(I), slotPI = pi > 0 ? myslot - B::TPJ : szh_vslot_top<B>(J);
     // consumers: a pencil of this tile (its step counter tells which ring slots it has read), or the STORE wavefront
     const bool consJ_in = pubJ && pj + 1 < B::TPJ, consI_in = pubI && pi + 1 < B::TPI;
-    const int stride = B::face_stride(r2);
+    const int stride = B::face_stride(r2), RS = B::face_rowstride(r2);
     const int mybase = myslot * stride;
 
     // ---- per-lane constants ----
@@ -183,14 +184,14 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
         trash[l] = L.ftrash + lane; ctrash[l] = SZH_XC * 64 + lane;
         // halo role: which face row this lane reads (for k = t - hskew); hlds = element offset of that row in faces[], -1: none
         hskew[l] = 0; hlds[l] = -1;
-        if (jl[l] == 0 && hasPJ && i < r0) { hskew[l] = il[l]; hlds[l] = slotPJ * stride + il[l]; }                   // (i, 8J-1, k): J-face of (I,J-1), row il
-        else if (il[l] == 0 && jl[l] > 0 && hasPI && j < r1) { hskew[l] = jl[l]; hlds[l] = slotPI * stride + 8 + jl[l]; } // (8I-1, j, k): I-face of (I-1,J), row jl
-        else if (lane == 63 && hasPI) hlds[l] = slotPI * stride + 8;                                                   // for lane 0: (8I-1, 8J, k)
-        else if (lane == 62 && hasPI && hasPJ) hlds[l] = slotPI * stride + 16;                                         // for lane 0: (8I-1, 8J-1, k), forwarded by (I-1,J)
+        if (jl[l] == 0 && hasPJ && i < r0) { hskew[l] = il[l]; hlds[l] = slotPJ * stride + il[l] * RS; }                   // (i, 8J-1, k): J-face of (I,J-1), row il
+        else if (il[l] == 0 && jl[l] > 0 && hasPI && j < r1) { hskew[l] = jl[l]; hlds[l] = slotPI * stride + (8 + jl[l]) * RS; } // (8I-1, j, k): I-face of (I-1,J), row jl
+        else if (lane == 63 && hasPI) hlds[l] = slotPI * stride + 8 * RS;                                                   // for lane 0: (8I-1, 8J, k)
+        else if (lane == 62 && hasPI && hasPJ) hlds[l] = slotPI * stride + 16 * RS;                                         // for lane 0: (8I-1, 8J-1, k), forwarded by (I-1,J)
         // rows of the own ring this lane writes (-1: none): J-face row il, I-face row jl, forwarded corner column
-        pjb[l] = (pubJ && jl[l] == 7 && inb[l]) ? mybase + il[l] : -1;
-        pib[l] = (pubI && il[l] == 7 && inb[l]) ? mybase + 8 + jl[l] : -1;
-        pcb[l] = (pubI && hasPJ && il[l] == 7 && jl[l] == 0 && inb[l]) ? mybase + 16 : -1;
+        pjb[l] = (pubJ && jl[l] == 7 && inb[l]) ? mybase + il[l] * RS : -1;
+        pib[l] = (pubI && il[l] == 7 && inb[l]) ? mybase + (8 + jl[l]) * RS : -1;
+        pcb[l] = (pubI && hasPJ && il[l] == 7 && jl[l] == 0 && inb[l]) ? mybase + 16 * RS : -1;
     }
 
     // ---- per-lane block tracking along dim2 (only when the pencil touches regression blocks) ----
@@ -353,7 +354,7 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
                 SZH_FORL {      // every lane reads (lanes without a halo row read a don't-care slot)
                     const int kh = t - hskew[l];
                     const bool lact = hlds[l] >= 0 && (unsigned)kh < (unsigned)r2;
-                    const T v = B::lds_ld(L.faces + (lact ? hlds[l] + B::ring(kh) * SZH_FROWS : trash[l]));
+                    const T v = B::lds_ld(L.faces + (lact ? hlds[l] + B::ring(kh) : trash[l]));
                     hval[l] = lact ? v : (T)0;
                 }
             }
@@ -411,11 +412,11 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
                 }
                 // faces for the pencils to the right / below (in this tile or, through the STORE wavefront, in the next one):
                 // every lane stores; lanes without a face row, or outside the k range, store to their trash slot
-                if (pubJ) B::lds_st(L.faces + ((act && pjb[l] >= 0) ? pjb[l] + B::ring(k) * SZH_FROWS : trash[l]), nv);
+                if (pubJ) B::lds_st(L.faces + ((act && pjb[l] >= 0) ? pjb[l] + B::ring(k) : trash[l]), nv);
                 if (pubI) {
-                    B::lds_st(L.faces + ((act && pib[l] >= 0) ? pib[l] + B::ring(k) * SZH_FROWS : trash[l]), nv);
+                    B::lds_st(L.faces + ((act && pib[l] >= 0) ? pib[l] + B::ring(k) : trash[l]), nv);
                     // lane (7,0): its halo value IS the corner column of the pencil below, same k
-                    B::lds_st(L.faces + ((act && pcb[l] >= 0) ? pcb[l] + B::ring(k) * SZH_FROWS : trash[l]), hval[l]);
+                    B::lds_st(L.faces + ((act && pcb[l] >= 0) ? pcb[l] + B::ring(k) : trash[l]), hval[l]);
                 }
                 // roll the neighbour state.  Lanes outside the k range must hand on ZEROS (the reference's zero halo).  With
                 // Lorenzo-only data they produce zeros by themselves (zero input, zero neighbours); the mean shortcut, stale
@@ -565,7 +566,7 @@ SZH_HD void szh_tile_store(const szh_qargs<T> &a, int TI, int TJ, const szh_tile
         else en[l] = en[l] && I + 1 < a.nI && (m.r < 8 ? 8 * J + m.r < r1 : J > 0);
         penc[l] = (int64_t)I * a.nJ + J;
         slot[l] = en[l] ? szh_slot<B>(I, J) : 0;
-        rbase[l] = slot[l] * stride + m.ringrow;
+        rbase[l] = slot[l] * stride + m.ringrow * B::face_rowstride(r2);
         dst[l] = m.isJ ? a.faceJ + (penc[l] * 8 + m.r) * (int64_t)r2 * NW : a.faceI + (penc[l] * 9 + m.r) * (int64_t)r2 * NW;
         pk[l] = en[l] ? 0 : r2;
     }
@@ -584,7 +585,7 @@ SZH_HD void szh_tile_store(const szh_qargs<T> &a, int TI, int TJ, const szh_tile
             for (int e = 0; e < KP; ++e) {
                 if (e < n) {
                     const int k = pk[l] + e;
-                    const T v = B::lds_ld(L.faces + rbase[l] + B::ring(k) * SZH_FROWS);
+                    const T v = B::lds_ld(L.faces + rbase[l] + B::ring(k));
                     szh_u64 w2[NW];
                     szh_gran<T>::pack(v, a.epoch, w2);
                     SZH_UNROLL
@@ -652,7 +653,7 @@ SZH_HD void szh_tile_fill(const szh_qargs<T> &a, int TI, int TJ, const szh_tile_
         prog[l] = a.progress + (en[l] ? pp * 2 + (m.isJ ? 0 : 1) : 0);
         cslot[l] = en[l] ? szh_slot<B>(I, J) : 0;
         const int vslot = m.isJ ? szh_vslot_left<B>(I) : szh_vslot_top<B>(J);
-        wbase[l] = vslot * stride + m.ringrow;
+        wbase[l] = vslot * stride + m.ringrow * B::face_rowstride(r2);
         fk[l] = en[l] ? 0 : r2;
     }
     unsigned idle = 0;
@@ -685,7 +686,7 @@ SZH_HD void szh_tile_fill(const szh_qargs<T> &a, int TI, int TJ, const szh_tile_
                 SZH_UNROLL
                 for (int w = 0; w < NW; ++w) { w2[w] = g[e][w][l]; v = v && ((unsigned)(w2[w] >> 32) == a.epoch); }
                 run = run && v;                    // a row advances by its run of leading delivered columns
-                if (run) { B::lds_st(L.faces + wbase[l] + B::ring(fk[l] + e) * SZH_FROWS, szh_gran<T>::unpack(w2)); ++lead; }
+                if (run) { B::lds_st(L.faces + wbase[l] + B::ring(fk[l] + e), szh_gran<T>::unpack(w2)); ++lead; }
             }
             fk[l] += lead;
             none[l] = lead == 0; fin[l] = fk[l] >= r2;

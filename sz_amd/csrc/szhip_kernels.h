@@ -85,7 +85,8 @@ struct GpuBackend {
     static constexpr int NL = 1;
     static constexpr int TPI = TPI_, TPJ = TPJ_, RL = RL_;
     __device__ static int ring(int k) { return k & (RL - 1); }
-    __device__ static int face_stride(int) { return RL * SZH_FROWS; }
+    __device__ static int face_rowstride(int) { return RL + 2; }   // +2: neighbouring rows' skewed columns fall into different banks
+    __device__ static int face_stride(int) { return (RL + 2) * SZH_FROWS; }
 
     __device__ static int lane(int) { return (int)(threadIdx.x & 63); }
     template <class T> __device__ static void shfl_up(T (&dst)[1], const T (&src)[1], int d) { dst[0] = __shfl_up(src[0], d, 64); }
@@ -170,7 +171,7 @@ __global__ __launch_bounds__((szh_tile_shape<T>::TPI * szh_tile_shape<T>::TPJ + 
     using B = GpuBackend<S::TPI, S::TPJ, S::RL>;
     constexpr int NP = S::TPI * S::TPJ, NV = S::TPI + S::TPJ, NT = (NP + 2) * 64;
     __shared__ uint16_t cring[NP * (SZH_XC + 1) * 64];
-    __shared__ T faces[(NP + NV) * S::RL * SZH_FROWS + 64];
+    __shared__ T faces[(NP + NV) * (S::RL + 2) * SZH_FROWS + 64];
     __shared__ unsigned cstep[NP + NV];
     __shared__ unsigned spubJ[NP], spubI[NP];
     __shared__ int scratch[128];
@@ -183,7 +184,7 @@ __global__ __launch_bounds__((szh_tile_shape<T>::TPI * szh_tile_shape<T>::TPJ + 
     const unsigned ij = a.order[tk_s];
     const int w = (int)(threadIdx.x >> 6);
     const int TI = (int)(ij >> 16), TJ = (int)(ij & 0xffffu);
-    const szh_tile_lds<T> L{cring, faces, (NP + NV) * S::RL * SZH_FROWS, cstep, spubJ, spubI, scratch};
+    const szh_tile_lds<T> L{cring, faces, (NP + NV) * (S::RL + 2) * SZH_FROWS, cstep, spubJ, spubI, scratch};
 #ifndef SZH_HIPSIM
     // issue priority: the helpers (light, latency-critical) first, then the pencils in dependency order, so that the chain
     // of hand-offs advances at single-wavefront speed while the downstream pencils fill the issue gaps

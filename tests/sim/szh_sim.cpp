@@ -24,6 +24,7 @@ struct SimBackend {
     // keep every column: RL covers all of dim2.
     static constexpr int TPI = 2, TPJ = 3, RL = 1 << 20;
     static int ring(int k) { return k; }
+    static int face_rowstride(int r2) { return r2; }
     static int face_stride(int r2) { return r2 * SZH_FROWS; }
     template <class E> static E lds_ld(const E *p) { return *p; }
     template <class E> static E lds_ld_u(const E *p) { return *p; }
