@@ -55,7 +55,6 @@ template <class T> struct szh_qargs {
     szh_u64 *progress;        // [pencil][2] (J-face, I-face): {epoch, steps whose face values have been published}: the consumers' FILL
                               // wavefront polls these words and then fetches only granules that exist
     int backoff;              // FILL wavefront: sleep units between two rounds that delivered nothing
-    int slack;                // a pencil starts once its producers are 8 + slack steps in: slack absorbs the jitter of the hand-offs
     int dbg;                  // development: 1 = no hand-off at all (timing only, results become WRONG), 4 = no issue priorities
     szh_u64 *trace;           // optional (development): per pencil {t_start, t_gate, t_first, t_end, spins, naps, cu, 0}
 };
@@ -331,12 +330,6 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
     if (a.trace) tr_start = B::clock();
     const bool detail = a.trace && I == a.nI / 2 && J == a.nJ / 2;
     szh_u64 *dt = a.trace ? a.trace + (int64_t)a.nI * a.nJ * 8 : nullptr;
-    // start with some slack behind the producers (a pencil that runs exactly 7 steps behind stalls on every hiccup of either producer)
-    if (a.slack > 0) {
-        const int need0 = 8 + a.slack < tsteps ? 8 + a.slack : tsteps;
-        if (hasPJ) wait_ctr(L.cstep + slotPJ, need0);
-        if (hasPI) wait_ctr(L.cstep + slotPI, need0);
-    }
     for (int t0 = 0; t0 < tsteps; t0 += SZH_U) {
         if (detail && t0 / SZH_U < 64) { SZH_FORL { if (B::lane(l) == 0) dt[(t0 / SZH_U) * 4 + 0] = B::clock(); } }
         // ring space: the consumers must have read the slots this trip overwrites.  A pencil of the tile reads column k no later

@@ -365,7 +365,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         a.faceI = (szh_u64 *)ctx->faceI.p; a.faceJ = (szh_u64 *)ctx->faceJ.p; a.epoch = ++ctx->epoch;
         a.nI = nI; a.nJ = nJ; a.order = (const unsigned *)ctx->order.p;
         a.ticket = (unsigned *)(sm + SM_TICKET); a.err = (unsigned *)(sm + SM_ERR);
-        a.progress = (szh_u64 *)ctx->progress.p; a.backoff = tune_int("SZ_HIP_BACKOFF", 4); a.slack = tune_int("SZ_HIP_SLACK", 0);
+        a.progress = (szh_u64 *)ctx->progress.p; a.backoff = tune_int("SZ_HIP_BACKOFF", 4);
         a.trace = tune_int("SZ_HIP_TRACE", 0) ? (szh_u64 *)ctx->trace.p : nullptr;
         a.dbg = tune_int("SZ_HIP_DBG", 0);
         HIPCHK(hipEventRecord(ctx->ev[2], st));
@@ -765,7 +765,7 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
         a.faceI = (szh_u64 *)ctx->faceI.p; a.faceJ = (szh_u64 *)ctx->faceJ.p; a.epoch = ++ctx->epoch;
         a.nI = nI; a.nJ = nJ; a.order = (const unsigned *)ctx->order.p;
         a.ticket = (unsigned *)(sm + SM_TICKET); a.err = (unsigned *)(sm + SM_ERR);
-        a.progress = (szh_u64 *)ctx->progress.p; a.backoff = tune_int("SZ_HIP_BACKOFF", 4); a.slack = tune_int("SZ_HIP_SLACK", 0);
+        a.progress = (szh_u64 *)ctx->progress.p; a.backoff = tune_int("SZ_HIP_BACKOFF", 4);
         a.trace = tune_int("SZ_HIP_TRACE", 0) ? (szh_u64 *)ctx->trace.p : nullptr;
         a.dbg = tune_int("SZ_HIP_DBG", 0);
         HIPCHK(hipEventRecord(ctx->ev[2], st));

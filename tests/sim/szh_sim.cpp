@@ -57,7 +57,7 @@ static int run_all(szh_qargs<T> a)
     szh_fill_pencil_order(nTI, nTJ, order.data());
     unsigned err = 0; a.err = &err;
     std::vector<szh_u64> prog((size_t)a.nI * a.nJ * 2, 0);
-    a.progress = prog.data(); a.backoff = 1; a.slack = 5;
+    a.progress = prog.data(); a.backoff = 1;
     constexpr int NP = B::TPI * B::TPJ, NV = B::TPI + B::TPJ;
     std::vector<uint16_t> ring((size_t)NP * (SZH_XC + 1) * 64);
     // "LDS" of one tile: face arrays [r2][SZH_FROWS] per slot, poisoned so that a value used before it is written shows
