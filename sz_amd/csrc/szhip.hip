@@ -28,6 +28,8 @@ double now_ms()
 struct szhip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // the fit + selection pass runs here, concurrently with the interval optimiser's sampling and host decisions
+    hipEvent_t ev_in = nullptr, ev_fit = nullptr;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     char err[512] = {0};
     unsigned epoch = 0;
@@ -215,6 +217,17 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
 
     const int ncols = G.g0.num * G.g1.num;
 
+    // ---- regression fit + predictor selection on the second stream, overlapped with the interval optimiser below.  The pass
+    //      needs only the bound -- except for the mean shortcut of the selection, which the optimiser may switch on; it is run
+    //      WITHOUT it here and repeated in the (rare) use_mean case.
+    const T noise = (T)((double)eb * 1.22);
+    HIPCHK(hipEventRecord(ctx->ev_in, st));                    // input staged, scratch cleared
+    HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_in, 0));
+    hipLaunchKernelGGL((k_fit_select<T>), dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, ctx->stream2,
+                       G, d_in, d_coef, d_lor, noise, 0, (T)0, sm + SM_MINMAX);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev_fit, ctx->stream2));
+
     // ---- interval optimiser
     unsigned intervals = prm->quantization_intervals;
     int use_mean = 0; T mean = 0;
@@ -276,9 +289,8 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     if (intervals > 65536 || intervals < 4) FAIL(SZHIP_ERR_UNSUP, "quantization interval count %u outside [4,65536]", intervals);
     S.intervals = intervals; S.use_mean = use_mean;
 
-    // ---- regression fit + predictor selection, one pass (the interval decision above only needed the bound)
-    {
-        const T noise = (T)((double)eb * 1.22);
+    HIPCHK(hipStreamWaitEvent(st, ctx->ev_fit, 0));           // join the fit + selection pass
+    if (use_mean) {                                            // the selection depends on the mean after all: repeat the pass
         hipLaunchKernelGGL((k_fit_select<T>), dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st,
                            G, d_in, d_coef, d_lor, noise, use_mean, mean, sm + SM_MINMAX);
         HIPCHK(hipGetLastError());
@@ -808,6 +820,8 @@ int szhip_create(szhip_ctx **out, int device)
         delete ctx; return SZHIP_ERR_NODEVICE;
     }
     for (int i = 0; i < 6; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return SZHIP_ERR_NODEVICE; }
+    if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fit, hipEventDisableTiming) != hipSuccess) { delete ctx; return SZHIP_ERR_NODEVICE; }
     *out = ctx;
     return SZHIP_OK;
 }
@@ -824,6 +838,9 @@ void szhip_destroy(szhip_ctx *ctx)
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
     if (ctx->pinned) hipHostFree(ctx->pinned);
     for (int i = 0; i < 6; ++i) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
+    if (ctx->ev_in) hipEventDestroy(ctx->ev_in);
+    if (ctx->ev_fit) hipEventDestroy(ctx->ev_fit);
+    if (ctx->stream2) hipStreamDestroy(ctx->stream2);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -857,9 +874,11 @@ int szhip_compress(szhip_ctx *ctx, int dtype, const void *data, int data_on_devi
     if (r0 < 2 || r1 < 2 || r2 < 2 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff) return SZHIP_ERR_ARG;
     if (!(eb > 0)) return SZHIP_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
-    return dtype == SZHIP_F32
+    const int rc = dtype == SZHIP_F32
                ? compress_impl<float>(ctx, data, data_on_device, r0, r1, r2, eb, params, meta, meta_len, out_on_device, out, out_size, stats)
                : compress_impl<double>(ctx, data, data_on_device, r0, r1, r2, eb, params, meta, meta_len, out_on_device, out, out_size, stats);
+    if (rc != SZHIP_OK) { hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream); } // an early exit must not leave work in flight
+    return rc;
 }
 
 int szhip_decompress(szhip_ctx *ctx, int dtype, const unsigned char *stream, int stream_on_device, size_t stream_len, size_t body_off,
