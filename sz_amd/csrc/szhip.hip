@@ -388,17 +388,25 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     }
 
     // ---- histogram, block ordering, unpredictable counts
+    // The histogram (and its copy to the host) runs on the second stream next to the block-ordering pass, so the host builds
+    // the code book while k_permute is still running.
     TRY(ensure(ctx, ctx->hist, (size_t)(65536 + 8192) * 4 + 64));
     unsigned *d_hist = (unsigned *)ctx->hist.p;
-    HIPCHK(hipMemsetAsync(d_hist, 0, (size_t)intervals * 4, st));
+    TRY(ensure_pinned(ctx, (size_t)intervals * 4 + 64));
+    unsigned *h_hist = (unsigned *)ctx->pinned;
+    HIPCHK(hipEventRecord(ctx->ev_in, st));                    // codes complete
+    HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_in, 0));
+    HIPCHK(hipMemsetAsync(d_hist, 0, (size_t)intervals * 4, ctx->stream2));
     {
         int rshift = 0; int use_lds = intervals <= 16384;
         if (use_lds) { while ((intervals << (rshift + 1)) <= 16384u && rshift < 6) ++rshift; }
         const size_t lds = use_lds ? ((size_t)intervals << rshift) * 4 : 16;
         int grid = (int)std::min<int64_t>((n / 8 + 255) / 256 + 1, 2048);
-        hipLaunchKernelGGL(k_hist_u16, dim3(grid), dim3(256), lds, st, (const uint16_t *)d_nat, n, intervals, rshift, use_lds, d_hist);
+        hipLaunchKernelGGL(k_hist_u16, dim3(grid), dim3(256), lds, ctx->stream2, (const uint16_t *)d_nat, n, intervals, rshift, use_lds, d_hist);
         HIPCHK(hipGetLastError());
     }
+    HIPCHK(hipMemcpyAsync(h_hist, d_hist, (size_t)intervals * 4, hipMemcpyDeviceToHost, ctx->stream2));
+    HIPCHK(hipEventRecord(ctx->ev_fit, ctx->stream2));
     TRY(ensure(ctx, ctx->col_zeros, (size_t)ncols * 4));
     TRY(ensure(ctx, ctx->col_zeros64, (size_t)ncols * 8));
     TRY(ensure(ctx, ctx->col_off, (size_t)ncols * 8));
@@ -414,20 +422,22 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
                        (u64 *)ctx->col_zeros64.p);
     TRY(scan_u64(ctx, (const u64 *)ctx->col_zeros64.p, ncols, (u64 *)ctx->col_off.p, sm + SM_TOTAL_UNPRED));
 
-    TRY(ensure_pinned(ctx, (size_t)intervals * 4 + 64));
-    unsigned *h_hist = (unsigned *)ctx->pinned;
     u64 h_small[SM_COUNT];
-    HIPCHK(hipMemcpyAsync(h_hist, d_hist, (size_t)intervals * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(h_small, sm, SM_COUNT * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if ((unsigned)h_small[SM_ERR] != 0) FAIL(SZHIP_ERR_INTERNAL, "wavefront kernel: halo wait timed out");
-    const u64 total_unpred = h_small[SM_TOTAL_UNPRED];
-    S.n_unpred = total_unpred;
 
-    // ---- Huffman code book (host: heap order decides the codes) and stream header
+    // ---- Huffman code book (host: heap order decides the codes), built as soon as the histogram has arrived
+    HIPCHK(hipEventSynchronize(ctx->ev_fit));
     double h0 = now_ms();
     szhost_huff *hf = szhost_huff_build(2 * (int)intervals, h_hist, nullptr, intervals);
+    host_ms += now_ms() - h0;
+    HIPCHK(hipStreamSynchronize(st));
+    if ((unsigned)h_small[SM_ERR] != 0) { if (hf) szhost_huff_free(hf); FAIL(SZHIP_ERR_INTERNAL, "wavefront kernel: halo wait timed out"); }
+    const u64 total_unpred = h_small[SM_TOTAL_UNPRED];
+    S.n_unpred = total_unpred;
     if (!hf) FAIL(SZHIP_ERR_INTERNAL, "Huffman build failed");
+
+    // ---- stream header
+    h0 = now_ms();
     const size_t tree_bytes = szhost_huff_tree_size(hf);
     const size_t hdr_len = meta_len + 8 + 4 + sizeof(T) + 4 + 4 + 4 + tree_bytes + 1 + sizeof(T) + ind_bytes + coef_sections.size() + 8;
     const size_t unpred_bytes = (size_t)total_unpred * sizeof(T);

@@ -117,6 +117,7 @@ inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (void *)1; return hipSucc
 #define hipEventDisableTiming 2
 inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, int) { *e = (void *)1; return hipSuccess; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, int) { return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0; return hipSuccess; }
