@@ -10,12 +10,8 @@
 // that recurrence is the i+j+k hyperplane wavefront.  One 64-lane wavefront owns a "pencil": an
 // 8x8 cross-section in (dim0,dim1), swept along dim2 (the fastest, contiguous dimension).  Lane
 // (il,jl) handles k = t - il - jl at step t, so its three face neighbours were produced by lanes
-// l-1 / l-8 / l-9 one or two steps earlier and travel by cross-lane shuffles -- no LDS, no barrier.
-// Pencil (I,J) needs the faces of pencils (I-1,J), (I,J-1) and one corner column of (I-1,J-1);
-// these travel through HBM-side "granules": 8-byte {epoch tag, value bits} words written with one
-// agent-scope store and polled with agent-scope loads (data is its own flag; MI355X_MICROARCH
-// "handoff-1to1"/R2).  Pencils are started in anti-diagonal order through an atomic ticket so
-// every dependency is already resident: no deadlock, no grid barrier.
+// l-1 / l-8 / l-9 one or two steps earlier and travel by cross-lane moves.  Pencil (I,J) needs the dim1-face of (I,J-1)
+// and the dim0-face of (I-1,J), delayed by 7 steps: its step t reads what its producers finished in their step t+7.
 //
 // Tiles.  A workgroup owns a TILE of TPI x TPJ neighbouring pencils, one COMPUTE wavefront per pencil, plus two helper
 // wavefronts.  Every hand-off a compute wavefront takes part in is LDS only: it reads its producers' face rows from LDS
@@ -30,7 +26,7 @@
 // halo of (I-1,J), which forwards it as a ninth row of its I-face.
 //
 // The body is written once and instantiated by two back ends:
-//   * the HIP kernel (szh_kernels.hip): NL = 1 value per thread, collectives = DPP/bpermute;
+//   * the HIP kernel (szhip_kernels.h): NL = 1 value per thread, collectives = bpermute / readlane;
 //   * a CPU lane simulator used ONLY by tests/ (tests/sim): NL = 64, collectives = array moves.
 #pragma once
 #include "szh_geom.h"
@@ -56,7 +52,7 @@ template <class T> struct szh_qargs {
                               // wavefront polls these words and then fetches only granules that exist
     int backoff;              // FILL wavefront: sleep units between two rounds that delivered nothing
     int dbg;                  // development: 1 = no hand-off at all (timing only, results become WRONG), 4 = no issue priorities
-    szh_u64 *trace;           // optional (development): per pencil {t_start, t_gate, t_first, t_end, spins, naps, cu, 0}
+    szh_u64 *trace;           // optional (development): per pencil {t_start, t_start, t_first_trip, t_end, wait spins, -, xcc, 0} + per-trip detail
 };
 
 template <class T> struct szh_gran;
