@@ -214,6 +214,40 @@ def test_config4_full_size_slab_properties(sz):
     ctx.close()
 
 
+def test_corrupt_streams_fail_cleanly(sz, oracle):
+    """Malformed input must end in an error (or, for payload damage the format cannot detect, in finite garbage) -- never in
+    a hang or a crash: truncated streams, damaged header fields, damaged Huffman tree, damaged payload."""
+    from sz_amd.fields import m_field
+    d = m_field(40)
+    good = sz.SZ_compress_args(d, sz.ABS, 1e-4)
+    assert np.array_equal(sz.SZ_decompress(good, d.shape, d.dtype).view(np.uint32), oracle.decompress(good, d.shape, d.dtype).view(np.uint32))
+    rng = np.random.default_rng(3)
+    outcomes = {"error": 0, "decoded": 0}
+
+    def attempt(blob):
+        try:
+            out = sz.SZ_decompress(bytes(blob), d.shape, d.dtype)
+            assert out.shape == d.shape
+            outcomes["decoded"] += 1
+        except sz.SZError:
+            outcomes["error"] += 1
+
+    for cut in (0, 3, 17, 40, 44, 60, 200, len(good) // 2, len(good) - 1):            # truncation
+        attempt(good[:cut])
+    body = 4 + 28 + 8
+    for off in list(range(body, body + 24)) + [body + 30, body + 64, body + 200]:     # block size, bound, intervals, tree size, node count, tree
+        for val in (0x00, 0xff, 0x7f):
+            blob = bytearray(good); blob[off] = val
+            attempt(blob)
+    for _ in range(40):                                                                # random damage anywhere
+        blob = bytearray(good)
+        for _ in range(int(rng.integers(1, 6))):
+            blob[int(rng.integers(4, len(blob)))] = int(rng.integers(0, 256))
+        attempt(blob)
+    assert outcomes["error"] > 20                       # the header checks fire ...
+    assert sz.SZ_compress_args(d, sz.ABS, 1e-4) == good  # ... and the library is still healthy afterwards
+
+
 def test_differential_fuzz_against_the_oracle(built):
     """400 random small cases (shape, dtype, field kind, bound mode and size all random): stream byte-identical and decode
     bit-identical to the oracle.  (7 500 cases were run once in development; tools/gpu_fuzz.py prints the failing seeds.)"""
