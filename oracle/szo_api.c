@@ -235,6 +235,13 @@ unsigned char *szo_compress_args(const szo_params *p, int data_type, const void 
             out = szo_sz21_compress_3d_f32(p, meta, 4 + meta_len, (const float *)data, s, r2, r1, (float)eb, &osz, stages);
         else
             out = szo_sz21_compress_3d_f64(p, meta, 4 + meta_len, (const double *)data, s, r2, r1, eb, &osz, stages);
+    } else if (dim == 2 && p->with_regression) {
+        /* SZ 2.1 (2D), sz_float.c:2940-2944 -- parity unpinned, see szo_sz21_impl.h */
+        meta[3] = 0x80 | 0x40 | (p->protect_value_range ? 0x04 : 0);
+        if (data_type == SZO_FLOAT)
+            out = szo_sz21_compress_2d_f32(p, meta, 4 + meta_len, (const float *)data, r2, r1, (float)eb, &osz, stages);
+        else
+            out = szo_sz21_compress_2d_f64(p, meta, 4 + meta_len, (const double *)data, r2, r1, eb, &osz, stages);
     } else {
         fprintf(stderr, "szo: this dimensionality/regression setting is not restated yet (dim=%d)\n", dim);
         return NULL;
@@ -286,6 +293,9 @@ void *szo_decompress(int data_type, const unsigned char *bytes, size_t byte_len,
         size_t s = (dim == 4) ? r4 * r3 : r3;
         if (data_type == SZO_FLOAT) szo_sz21_decompress_3d_f32((float *)out, s, r2, r1, body);
         else szo_sz21_decompress_3d_f64((double *)out, s, r2, r1, body);
+    } else if ((same & 0x80) && dim == 2) {
+        if (data_type == SZO_FLOAT) szo_sz21_decompress_2d_f32((float *)out, r2, r1, body);
+        else szo_sz21_decompress_2d_f64((double *)out, r2, r1, body);
     } else { free(out); return NULL; }
     /* protectValueRange clamp (szd_float.c:161-176) */
     if (same & 0x04) {

@@ -90,7 +90,7 @@ def compress(data, mode=ABS, abs_err=1e-4, rel=0.0, params=None, want_stages=Fal
     if want_stages and st.num_elements:
         T = data.dtype
         ne, nb, rc, tu = st.num_elements, st.num_blocks, st.reg_count, st.total_unpred
-        ncoef = 4
+        ncoef = 3 if sum(1 for d in data.shape if d > 1) == 2 else 4   # 2-D streams carry a|b|c
 
         def arr(ptr, count, dtype):
             if count == 0:
@@ -101,10 +101,10 @@ def compress(data, mode=ABS, abs_err=1e-4, rel=0.0, params=None, want_stages=Fal
                   use_mean=st.use_mean, mean=st.mean, eb=st.eb, dense_pos=st.dense_pos, mean_freq=st.mean_freq,
                   sample_freq=st.sample_freq,
                   codes=arr(st.codes, ne, np.int32), indicator=arr(st.indicator, nb, np.uint8),
-                  unpred=arr(st.unpred, tu, T), reg_params=arr(st.reg_params, 4 * nb, T).reshape(4, nb),
+                  unpred=arr(st.unpred, tu, T), reg_params=arr(st.reg_params, ncoef * nb, T).reshape(ncoef, nb),
                   coeff_codes=arr(st.coeff_codes, ncoef * rc, np.int32).reshape(ncoef, rc),
                   coeff_dec=arr(st.coeff_dec, ncoef * rc, T).reshape(ncoef, rc),
-                  coeff_unpred=[arr(st.coeff_unpred[e], st.coeff_unpred_count[e], T) for e in range(4)],
+                  coeff_unpred=[arr(st.coeff_unpred[e], st.coeff_unpred_count[e], T) for e in range(ncoef)],
                   code_len=arr(st.code_len, 2 * st.intervals, np.uint8),
                   tree_bytes=st.tree_bytes, node_count=st.node_count, huff_bytes=st.huff_bytes)
         L.szo_free_stages(ctypes.byref(st))
