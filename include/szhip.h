@@ -72,6 +72,8 @@ int szhip_minmax(szhip_ctx *ctx, int dtype, const void *data, int data_on_device
 /*
  * Compress a 3-D array (r0 slowest ... r2 fastest, the callee convention of sz_float.c:6527) with
  * absolute bound `eb` (already derived from the user's mode by the caller, sz_float.c:2852-2868).
+ * r0 == 0: a 2-D array r1 x r2 (SZ_compress_float_2D_MDQ_nonblocked_with_blocked_regression, sz_float.c:5516 /
+ * sz_double.c:4900): 16-wide blocks, three plane coefficients per block.
  * `meta`/`meta_len`: the 3 version bytes + flag byte + parameter bytes the stream starts with.
  * Output: out_on_device = 0: *out is malloc'd host memory owned by the caller (free());
  *         out_on_device = 1: *out is a device pointer owned by ctx (valid until the next call);
@@ -85,7 +87,8 @@ int szhip_compress(szhip_ctx *ctx, int dtype, const void *data, int data_on_devi
 /*
  * Decompress a SZ 2.1 regression-type stream.  `stream` points at the first byte of the whole stream
  * (version bytes); `body_off` is the offset of the block-size field (4 + 28|36 + 8).
- * `out`: device pointer (out_on_device) or host pointer to r0*r1*r2 values.
+ * `out`: device pointer (out_on_device) or host pointer to r0*r1*r2 values.  r0 == 0: a 2-D array r1 x r2
+ * (decompressDataSeries_float_2D_nonblocked_with_blocked_regression, szd_float.c:3141 / szd_double.c:2974).
  */
 int szhip_decompress(szhip_ctx *ctx, int dtype, const unsigned char *stream, int stream_on_device, size_t stream_len,
                      size_t body_off, size_t r0, size_t r1, size_t r2,

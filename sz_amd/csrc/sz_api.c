@@ -276,8 +276,8 @@ static int compress_fp(int dataType, int withRegression, unsigned char **newByte
 
     int dim = computeDimension(r5, r4, r3, r2, r1);
     if (dim == 5) { printf("Error: doesn't support 5 dimensions for now.\n"); return SZ_DERR; }
-    if (!(dim == 3 || dim == 4) || withRegression == SZ_NO_REGRESSION || confparams_cpr->randomAccess) {
-        printf("Error: the MI355X build covers 3-D/4-D float/double arrays with withLinearRegression=YES; "
+    if (!(dim == 2 || dim == 3 || dim == 4) || withRegression == SZ_NO_REGRESSION || confparams_cpr->randomAccess) {
+        printf("Error: the MI355X build covers 2-D/3-D/4-D float/double arrays with withLinearRegression=YES; "
                "this call (dim=%d, withRegression=%d, randomAccess=%d) is not covered yet.\n", dim, withRegression, confparams_cpr->randomAccess);
         return SZ_NSCS;
     }
@@ -288,7 +288,7 @@ static int compress_fp(int dataType, int withRegression, unsigned char **newByte
     hp.sample_distance = confparams_cpr->sampleDistance; hp.pred_threshold = confparams_cpr->predThreshold;
     hp.max_quant_intervals = confparams_cpr->maxRangeRadius * 2;
     hp.quantization_intervals = exe_params->optQuantMode == 1 ? 0 : (unsigned)exe_params->intvCapacity;
-    size_t s0 = dim == 4 ? r4 * r3 : r3;
+    size_t s0 = dim == 4 ? r4 * r3 : r3;   /* 2-D: r3 == 0 tells the HIP layer so (sz_float.c:2942 passes (r2, r1)) */
     unsigned char *tmp = NULL; size_t tmpSize = 0;
     int rc = szhip_compress(ctx, dataType == SZ_FLOAT ? SZHIP_F32 : SZHIP_F64, d_in, 1, s0, r2, r1, realPrecision, &hp,
                             meta, 4 + meta_len, 0, &tmp, &tmpSize, &g_last_stats);
@@ -439,8 +439,8 @@ static void *decompress_fp(int dataType, unsigned char *cmpBytes, size_t cmpSize
         }
     } else {
         int dim = computeDimension(r5, r4, r3, r2, r1);
-        if (!(same & 0x80) || !(dim == 3 || dim == 4) || st != 8 || confparams_dec->sol_ID != SZ) {
-            printf("Error: the MI355X build decodes SZ 2.1 regression-type streams of 3-D/4-D float/double arrays; this stream "
+        if (!(same & 0x80) || !(dim == 2 || dim == 3 || dim == 4) || st != 8 || confparams_dec->sol_ID != SZ) {
+            printf("Error: the MI355X build decodes SZ 2.1 regression-type streams of 2-D/3-D/4-D float/double arrays; this stream "
                    "(flags 0x%02x, dim %d) is not covered yet.\n", same, dim);
             ok = 0;
         } else {

@@ -6,6 +6,7 @@
 //   regression fit        sz/src/sz_float.c:6598-6633      (double: sz_double.c:5961-6012)
 //   predictor selection   sz/src/sz_float.c:7083-7123, with mean :6747-6786
 //   interval sampling     sz/src/sz_float.c:6396-6523      (double: sz_double.c:5773)
+//   2-D: fit sz/src/sz_float.c:5569-5605, selection :6003-6028, sampling :5405-5515 (double: sz_double.c:4953-4989, :5384-5409, :4790)
 #pragma once
 #include "szh_geom.h"
 
@@ -79,6 +80,68 @@ SZH_HD int szh_select_block(const Acc &A, int s0, int s1, int s2, const T *coef4
     return err_reg < err_sz ? 1 : 0;
 }
 
+// ---- 2-D: regression fit of one block.  A(i,j) returns the original value at block-local (i,j); coef3 = {a, b, c}.
+template <class T, class Acc, class Visit = szh_no_visit>
+SZH_HD void szh_fit_block_2d(const Acc &A, int s1, int s2, T *coef3, const Visit &visit = Visit())
+{
+    T fx = 0, fy = 0, f = 0;
+    for (int i = 0; i < s1; ++i) {
+        T sum_x = 0;
+        for (int j0 = 0; j0 < s2; j0 += 8) {
+            T row[8];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+            for (int e = 0; e < 8; ++e) row[e] = j0 + e < s2 ? A(i, j0 + e) : (T)0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+            for (int e = 0; e < 8; ++e) {
+                if (j0 + e < s2) {
+                    const T c = row[e];
+                    visit(c);
+                    sum_x += c;
+                    fy += c * (T)(j0 + e);
+                }
+            }
+        }
+        fx += sum_x * (T)i;
+        f += sum_x;
+    }
+    const T coeff = (T)(1.0 / (double)((int64_t)s1 * s2));
+    const T a = ((T)2 * fx / (T)(s1 - 1) - f) * (T)6 * coeff / (T)(s1 + 1);
+    const T b = ((T)2 * fy / (T)(s2 - 1) - f) * (T)6 * coeff / (T)(s2 + 1);
+    const T c = f * coeff - ((T)(s1 - 1) * a / (T)2 + (T)(s2 - 1) * b / (T)2);
+    coef3[0] = a; coef3[1] = b; coef3[2] = c;
+}
+
+// ---- 2-D: predictor selection of one block (1 = the regression plane wins).  The second sample of each pair evaluates the
+// plane at row i - 1 while the point itself lies in row i: that is what the reference computes (sz_float.c:6022).
+template <class T, class Acc>
+SZH_HD int szh_select_block_2d(const Acc &A, int s1, int s2, const T *coef3, T noise)
+{
+    T err_sz = 0, err_reg = 0;
+    const int bs = s1 < s2 ? s1 : s2;
+    for (int i = 1; i < bs; ++i) {
+        {
+            const T x = A(i, i);
+            const T psz = A(i, i - 1) + A(i - 1, i) - A(i - 1, i - 1);
+            const T preg = coef3[0] * (T)i + coef3[1] * (T)i + coef3[2];
+            err_sz += szh_abs(psz - x) + noise;
+            err_reg += szh_abs(preg - x);
+        }
+        {
+            const int bmi = bs - i;
+            const T x = A(i, bmi);
+            const T psz = A(i, bmi - 1) + A(i - 1, bmi) - A(i - 1, bmi - 1);
+            const T preg = coef3[0] * (T)(i - 1) + coef3[1] * (T)bmi + coef3[2];
+            err_sz += szh_abs(psz - x) + noise;
+            err_reg += szh_abs(preg - x);
+        }
+    }
+    return err_reg < err_sz ? 1 : 0;
+}
+
 // ---- strided "mean" samples of the interval optimiser (sz_float.c:6405-6419) in closed form:
 // the walk adds `md` per step and steps back by one whenever a running offset passes r2 / r1*r2.
 struct szh_meanwalk { int64_t md, c1, c2, len; };
@@ -95,12 +158,15 @@ SZH_HD int64_t szh_meanwalk_pos(const szh_meanwalk &w, int64_t m) { return m * w
 // Logical row (n1,n2), n1>=1, 1<=n2<=r1-1, starts at origin n1*r1r2 + n2*r2 and is sampled at columns
 // c0 + m*sd with c0 = sd - ((n1+n2) % sd); at least one sample per row (column c0 even if c0 >= r2),
 // further ones while the column is < r2; the walk as a whole stops at the first position >= len.
+// 2-D (sz_float.c:5441-5475): logical row n >= 1 is array row n, first column sd - 1 for n = 1 and sd - (n % sd) after it; the
+// same "at least one sample per row" and "stop at the first position >= len" rules.  `r12` = 0 selects the 3-point stencil.
 template <class T>
 SZH_HD void szh_sample_point(const T *data, int64_t pos, int64_t r2, int64_t r12, double ebD, T mean,
                              unsigned max_radius, unsigned *radius_index, int *freq_index, int *within_eb)
 {
     const T *d = data + pos;
-    const T pred = d[-1] + d[-r2] + d[-r12] - d[-1 - r12] - d[-r2 - 1] - d[-r2 - r12] + d[-r2 - r12 - 1];
+    const T pred = r12 == 0 ? d[-1] + d[-r2] - d[-r2 - 1]
+                            : d[-1] + d[-r2] + d[-r12] - d[-1 - r12] - d[-r2 - 1] - d[-r2 - r12] + d[-r2 - r12 - 1];
     const T pred_err = szh_abs((T)(pred - *d));
     *within_eb = ((double)pred_err < ebD) ? 1 : 0;
     double rq = ((double)pred_err / ebD + 1) / 2;
@@ -122,9 +188,15 @@ SZH_HD void szh_sample_point(const T *data, int64_t pos, int64_t r2, int64_t r12
 
 // number of logical sample rows the sequential walk of the reference visits before its first
 // position >= len (rows are linearised as (n1-1)*(r1-1) + (n2-1)); host-side helper.
+SZH_HD int64_t szh_sample_col0_2d(int64_t n, int sd) { return n == 1 ? sd - 1 : sd - (n % sd); }
 inline int64_t szh_sample_row_limit(const szh_geom3 &G, int sd)
 {
     const int64_t r1 = G.g1.count, r2 = G.g2.count, r0 = G.g0.count;
+    if (G.ndim == 2) {   // logical rows 1 .. r1-1 are linearised as n - 1; positions n*r2 + col0(n) increase with n
+        int64_t lim = r1 - 1;
+        while (lim > 0 && lim * r2 + szh_sample_col0_2d(lim, sd) >= G.n) --lim;
+        return lim;
+    }
     const int64_t rows_per_plane = r1 - 1;
     const int64_t total = (r0 - 1) * rows_per_plane;
     if (total <= 0) return 0;

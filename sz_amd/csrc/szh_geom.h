@@ -15,7 +15,8 @@
 #define SZH_HD inline
 #endif
 
-#define SZH_BLOCK_SIZE 6
+#define SZH_BLOCK_SIZE 6      /* 3-D: sz/src/sz_float.c:6531 */
+#define SZH_BLOCK_SIZE_2D 16  /* 2-D: sz/src/sz_float.c:5518 */
 
 // one dimension of the block grid
 struct szh_grid1 {
@@ -26,11 +27,11 @@ struct szh_grid1 {
     int split;
 };
 
-SZH_HD szh_grid1 szh_make_grid1(int count)
+SZH_HD szh_grid1 szh_make_grid1(int count, int block_size = SZH_BLOCK_SIZE)
 {
     szh_grid1 g;
     g.count = count;
-    g.num = (count <= SZH_BLOCK_SIZE) ? 1 : count / SZH_BLOCK_SIZE;
+    g.num = (count <= block_size) ? 1 : count / block_size;
     g.early = g.late = count / g.num;
     g.split = count % g.num;
     if (g.split) g.early += 1;
@@ -45,12 +46,17 @@ SZH_HD int szh_blk_of(const szh_grid1 &g, int x)
     return x < edge ? x / g.early : g.split + (x - edge) / g.late;
 }
 
-// 3-D geometry; dim 0 is the slowest, dim 2 the fastest (the callee convention of sz_float.c:6527)
+// 3-D geometry; dim 0 is the slowest, dim 2 the fastest (the callee convention of sz_float.c:6527).
+// A 2-D array (r1 x r2, sz_float.c:5516) is carried as 1 x r1 x r2 with `ndim` = 2: one block layer in dim 0, 16-wide blocks in
+// the other two.  The 7-point Lorenzo stencil then degenerates to the reference's 3-point one exactly (the dim-0 neighbours are
+// the zero halo, and x + 0 is exact); the regression plane keeps a zero dim-0 coefficient.
 struct szh_geom3 {
     szh_grid1 g0, g1, g2;
     int64_t d0, d1;      // element strides of dim 0 and dim 1
     int64_t n;           // number of elements
     int64_t nblocks;
+    int ndim;            // 3, or 2 for the carried 2-D case
+    int block_size;      // what the stream header records
 };
 
 SZH_HD szh_geom3 szh_make_geom3(int r0, int r1, int r2)
@@ -59,6 +65,16 @@ SZH_HD szh_geom3 szh_make_geom3(int r0, int r1, int r2)
     G.g0 = szh_make_grid1(r0); G.g1 = szh_make_grid1(r1); G.g2 = szh_make_grid1(r2);
     G.d1 = r2; G.d0 = (int64_t)r1 * r2; G.n = G.d0 * r0;
     G.nblocks = (int64_t)G.g0.num * G.g1.num * G.g2.num;
+    G.ndim = 3; G.block_size = SZH_BLOCK_SIZE;
+    return G;
+}
+SZH_HD szh_geom3 szh_make_geom2(int r1, int r2)
+{
+    szh_geom3 G;
+    G.g0 = szh_make_grid1(1, SZH_BLOCK_SIZE_2D); G.g1 = szh_make_grid1(r1, SZH_BLOCK_SIZE_2D); G.g2 = szh_make_grid1(r2, SZH_BLOCK_SIZE_2D);
+    G.d1 = r2; G.d0 = (int64_t)r1 * r2; G.n = G.d0;
+    G.nblocks = (int64_t)G.g1.num * G.g2.num;
+    G.ndim = 2; G.block_size = SZH_BLOCK_SIZE_2D;
     return G;
 }
 

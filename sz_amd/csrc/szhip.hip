@@ -191,7 +191,9 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
                   unsigned char **out, size_t *out_size, szhip_stats *stats)
 {
     const int is_double = sizeof(T) == 8;
-    const szh_geom3 G = szh_make_geom3((int)r0, (int)r1, (int)r2);
+    const bool two_d = r0 == 0;                                // r0 == 0: a 2-D array r1 x r2 (sz_float.c:5516)
+    const szh_geom3 G = two_d ? szh_make_geom2((int)r1, (int)r2) : szh_make_geom3((int)r0, (int)r1, (int)r2);
+    const int ncoef = two_d ? 3 : 4;
     const int64_t n = G.n, nb = G.nblocks;
     const T eb = (T)eb_in;
     const double t_begin = now_ms();
@@ -220,7 +222,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     // ---- regression fit + predictor selection on the second stream, overlapped with the interval optimiser below.  The pass
     //      needs only the bound -- except for the mean shortcut of the selection, which the optimiser may switch on; it is run
     //      WITHOUT it here and repeated in the (rare) use_mean case.
-    const T noise = (T)((double)eb * 1.22);
+    const T noise = (T)((double)eb * (two_d ? 0.81 : 1.22));   // sz_float.c:7056 / :5672
     HIPCHK(hipEventRecord(ctx->ev_in, st));                    // input staged, scratch cleared
     HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_in, 0));
     hipLaunchKernelGGL((k_fit_select<T>), dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, ctx->stream2,
@@ -234,7 +236,8 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     if (intervals == 0) {
         const unsigned max_radius = prm->max_quant_intervals / 2;
         const int64_t md = (int64_t)(int)std::sqrt((double)n);
-        const szh_meanwalk w = szh_make_meanwalk(n, G.d0, G.g2.count, md);
+        // 2-D: a plain stride (sz_float.c:5412-5417): no step-backs
+        const szh_meanwalk w = two_d ? szh_make_meanwalk(n, INT64_MAX / 2, INT64_MAX / 2, md) : szh_make_meanwalk(n, G.d0, G.g2.count, md);
         int64_t M = 0; // number of strided samples: first m with pos >= n (positions are increasing)
         {
             int64_t lo = 0, hi = n / std::max<int64_t>(md - 2, 1) + 2;
@@ -274,7 +277,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         szhost_decide(is_double, h_hist, max_radius, h_hist + max_radius, sample_count, within, prm->pred_threshold,
                       (double)eb, smean, &dec);
         host_ms += now_ms() - h0;
-        intervals = dec.intervals; use_mean = dec.use_mean;
+        intervals = dec.intervals; use_mean = two_d ? 0 : dec.use_mean;   // 2-D: `use_mean = 0`, sz_float.c:5615
         if (use_mean) {
             T *d_sum = (T *)(sm + SM_MEANSUM);
             hipLaunchKernelGGL((k_mean_seq<T>), dim3(1), dim3(64), 0, st, d_in, n, (T)dec.dense_pos, eb, d_sum, sm + SM_MEANCNT);
@@ -327,9 +330,10 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         HIPCHK(hipStreamSynchronize(st));
         double h0 = now_ms();
         const std::vector<unsigned char> all_reg(reg_count, 0);
-        szhost_coeff_chain(is_double, hcoef.data(), all_reg.data(), reg_count, (double)eb, G.g0.late, G.g1.late, G.g2.late,
-                           use_mean, &cf);
-        for (int e = 0; e < 4; ++e) {
+        // 2-D planes are carried as {0, a, b, c}: the chain sees components 1..3
+        szhost_coeff_chain(is_double, hcoef.data() + (two_d ? reg_count : 0), all_reg.data(), reg_count, (double)eb, G.g0.late, G.g1.late,
+                           G.g2.late, use_mean, ncoef, &cf);
+        for (int e = 0; e < ncoef; ++e) {
             std::vector<uint32_t> h32(65536, 0);
             for (size_t i = 0; i < reg_count; ++i) h32[(size_t)cf.codes[e][i]]++;
             szhost_huff *ch = szhost_huff_build(131072, h32.data(), nullptr, 65536);
@@ -448,7 +452,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         unsigned char *q = hdr.data();
         memcpy(q, meta, meta_len); q += meta_len;
         szhost_put_u64be(q, (uint64_t)n); q += 8;
-        szhost_put_u32be(q, SZH_BLOCK_SIZE); q += 4;
+        szhost_put_u32be(q, (uint32_t)G.block_size); q += 4;
         if (is_double) szhost_put_f64be(q, (double)eb); else szhost_put_f32be(q, (float)eb);
         q += sizeof(T);
         szhost_put_u32be(q, intervals); q += 4;
@@ -536,9 +540,10 @@ template <class T> struct dec_header {
 
 // returns 0 = parsed, 1 = needs at least *need bytes of the stream on the host, < 0 = malformed (message in err)
 template <class T>
-int parse_header(const unsigned char *hs, size_t avail, size_t stream_len, size_t body_off, size_t nb, dec_header<T> &H,
-                 size_t *need, char *err, size_t errlen)
+int parse_header(const unsigned char *hs, size_t avail, size_t stream_len, size_t body_off, size_t nb, int want_block_size,
+                 dec_header<T> &H, size_t *need, char *err, size_t errlen)
 {
+    const int ncoef = want_block_size == SZH_BLOCK_SIZE_2D ? 3 : 4;
     const int is_double = sizeof(T) == 8;
 #define PFAIL(code, ...) do { snprintf(err, errlen, __VA_ARGS__); if (hf) szhost_huff_free(hf); return (code); } while (0)
 #define NEED(k) do { const size_t end_ = (size_t)(q - hs) + (size_t)(k); if (end_ > stream_len) PFAIL(SZHIP_ERR_STREAM, "truncated stream"); \
@@ -547,7 +552,7 @@ int parse_header(const unsigned char *hs, size_t avail, size_t stream_len, size_
     const unsigned char *q = hs + body_off;
     NEED(4 + sizeof(T) + 12);
     const unsigned block_size = szhost_get_u32be(q); q += 4;
-    if (block_size != SZH_BLOCK_SIZE) PFAIL(SZHIP_ERR_UNSUP, "block size %u", block_size);
+    if ((int)block_size != want_block_size) PFAIL(SZHIP_ERR_UNSUP, "block size %u", block_size);
     H.eb = is_double ? (T)szhost_get_f64be(q) : (T)szhost_get_f32be(q); q += sizeof(T);
     H.intervals = szhost_get_u32be(q); q += 4;
     const unsigned tree_size = szhost_get_u32be(q); q += 4;
@@ -574,7 +579,7 @@ int parse_header(const unsigned char *hs, size_t avail, size_t stream_len, size_
     H.coef.clear();
     if (H.reg_count > 0) {
         std::vector<int> ccodes[4]; int *cptr[4]; int crad[4]; double cprec[4]; const unsigned char *cun[4];
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < ncoef; ++e) {
             NEED(sizeof(T) + 12);
             cprec[e] = is_double ? szhost_get_f64be(q) : (double)szhost_get_f32be(q); q += sizeof(T);
             crad[e] = (int)szhost_get_u32be(q); q += 4;
@@ -606,7 +611,8 @@ int parse_header(const unsigned char *hs, size_t avail, size_t stream_len, size_
         // compact [4][reg_count] in scan order; the device scatters them to the blocks (k_move_coef)
         H.coef.assign(H.reg_count * 4, (T)0);
         const std::vector<unsigned char> all_reg(H.reg_count, 0);
-        szhost_coeff_unchain(is_double, H.coef.data(), all_reg.data(), H.reg_count, cptr, crad, cprec, cun);
+        // 2-D planes {a, b, c} are carried as {0, a, b, c}
+        szhost_coeff_unchain(is_double, H.coef.data() + (ncoef == 3 ? H.reg_count : 0), all_reg.data(), H.reg_count, cptr, crad, cprec, cun, ncoef);
     }
     NEED(8);
     memcpy(&H.total_unpred, q, 8); q += 8;
@@ -628,7 +634,7 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
                     size_t r0, size_t r1, size_t r2, void *out, int out_on_device, szhip_stats *stats)
 {
     const int is_double = sizeof(T) == 8;
-    const szh_geom3 G = szh_make_geom3((int)r0, (int)r1, (int)r2);
+    const szh_geom3 G = r0 == 0 ? szh_make_geom2((int)r1, (int)r2) : szh_make_geom3((int)r0, (int)r1, (int)r2);
     const int64_t n = G.n, nb = G.nblocks;
     const double t_begin = now_ms();
     double host_ms = 0;
@@ -663,7 +669,7 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
             hs = (const unsigned char *)ctx->pinned; avail = want;
         }
         size_t need = 0;
-        const int rc = parse_header<T>(hs, avail, stream_len, body_off, (size_t)nb, H, &need, ctx->err, sizeof(ctx->err));
+        const int rc = parse_header<T>(hs, avail, stream_len, body_off, (size_t)nb, G.block_size, H, &need, ctx->err, sizeof(ctx->err));
         if (rc == 0) break;
         if (rc < 0) { fprintf(stderr, "szhip: %s\n", ctx->err); return rc; }
         want = std::min<size_t>(stream_len, std::max<size_t>(need, avail * 2)); // rc == 1: more bytes needed
@@ -881,7 +887,7 @@ int szhip_compress(szhip_ctx *ctx, int dtype, const void *data, int data_on_devi
                    unsigned char **out, size_t *out_size, szhip_stats *stats)
 {
     if (!ctx || !data || !params || !meta || !out || !out_size) return SZHIP_ERR_ARG;
-    if (r0 < 2 || r1 < 2 || r2 < 2 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff) return SZHIP_ERR_ARG;
+    if ((r0 != 0 && r0 < 2) || r1 < 2 || r2 < 2 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff) return SZHIP_ERR_ARG;
     if (!(eb > 0)) return SZHIP_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
     const int rc = dtype == SZHIP_F32
@@ -895,7 +901,7 @@ int szhip_decompress(szhip_ctx *ctx, int dtype, const unsigned char *stream, int
                      size_t r0, size_t r1, size_t r2, void *out, int out_on_device, szhip_stats *stats)
 {
     if (!ctx || !stream || !out || body_off >= stream_len) return SZHIP_ERR_ARG;
-    if (r0 < 2 || r1 < 2 || r2 < 2 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff) return SZHIP_ERR_ARG;
+    if ((r0 != 0 && r0 < 2) || r1 < 2 || r2 < 2 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff) return SZHIP_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
     return dtype == SZHIP_F32
                ? decompress_impl<float>(ctx, stream, stream_on_device, stream_len, body_off, r0, r1, r2, out, out_on_device, stats)

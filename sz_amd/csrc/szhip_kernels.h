@@ -210,6 +210,7 @@ __global__ __launch_bounds__((szh_tile_shape<T>::TPI * szh_tile_shape<T>::TPJ + 
 template <class T> struct GlobAcc {
     const T *p; int64_t d0, d1;
     __device__ T operator()(int i, int j, int k) const { return p[i * d0 + j * d1 + k]; }
+    __device__ T operator()(int j, int k) const { return p[j * d1 + k]; }     // 2-D blocks
 };
 
 template <class T>
@@ -229,9 +230,18 @@ __global__ __launch_bounds__(256) void k_fit_select(szh_geom3 G, const T *__rest
         const GlobAcc<T> A{data + (int64_t)szh_blk_start(G.g0, b0) * G.d0 + (int64_t)szh_blk_start(G.g1, b1) * G.d1 + szh_blk_start(G.g2, b2),
                            G.d0, G.d1};
         T c4[4];
-        szh_fit_block<T>(A, s0, s1, s2, c4, [&](T v) { const u64 oe = ord_enc(v); lmin = oe < lmin ? oe : lmin; lmax = oe > lmax ? oe : lmax; });
+        auto range = [&](T v) { const u64 oe = ord_enc(v); lmin = oe < lmin ? oe : lmin; lmax = oe > lmax ? oe : lmax; };
+        int reg;
+        if (G.ndim == 2) {   // plane a*j + b*k + c, carried as {0, a, b, c}
+            c4[0] = 0;
+            szh_fit_block_2d<T>(A, s1, s2, c4 + 1, range);
+            reg = szh_select_block_2d<T>(A, s1, s2, c4 + 1, noise);
+        } else {
+            szh_fit_block<T>(A, s0, s1, s2, c4, range);
+            reg = szh_select_block<T>(A, s0, s1, s2, c4, noise, use_mean, mean);
+        }
         for (int e = 0; e < 4; ++e) coef[(int64_t)e * G.nblocks + b] = c4[e];
-        blk_lor[b] = szh_select_block<T>(A, s0, s1, s2, c4, noise, use_mean, mean) ? 0 : 1;
+        blk_lor[b] = reg ? 0 : 1;
     }
     lmin = wave_min_u64(lmin); lmax = wave_max_u64(lmax);
     if (lane == 0) { red[wid] = lmin; red[4 + wid] = lmax; }
@@ -281,10 +291,11 @@ __global__ __launch_bounds__(256) void k_sample(szh_geom3 G, const T *__restrict
     for (int i = threadIdx.x; i < 8192; i += 256) sh_f[i] = 0;
     __syncthreads();
     const int64_t rpp = G.g1.count - 1, r2 = G.g2.count;
+    const bool two_d = G.ndim == 2;
     unsigned w = 0;
     for (int64_t ridx = (int64_t)blockIdx.x * 256 + threadIdx.x; ridx < nrows; ridx += (int64_t)gridDim.x * 256) {
-        const int64_t n1 = ridx / rpp + 1, n2 = ridx - (n1 - 1) * rpp + 1;
-        const int64_t c0 = sd - ((n1 + n2) % sd);
+        const int64_t n1 = two_d ? 0 : ridx / rpp + 1, n2 = two_d ? ridx + 1 : ridx - (n1 - 1) * rpp + 1;
+        const int64_t c0 = two_d ? szh_sample_col0_2d(n2, sd) : sd - ((n1 + n2) % sd);
         const int64_t origin = n1 * G.d0 + n2 * r2;
         for (int64_t m = 0;; ++m) {
             const int64_t col = c0 + m * sd;
@@ -292,7 +303,7 @@ __global__ __launch_bounds__(256) void k_sample(szh_geom3 G, const T *__restrict
             const int64_t pos = origin + col;
             if (pos >= G.n) break;
             unsigned ri; int fi, we;
-            szh_sample_point<T>(data, pos, r2, G.d0, ebD, mean, max_radius, &ri, &fi, &we);
+            szh_sample_point<T>(data, pos, r2, two_d ? 0 : G.d0, ebD, mean, max_radius, &ri, &fi, &we);
             if (ri < SZH_LDS_RADIUS_BINS) atomicAdd(&sh_r[ri], 1u); else atomicAdd(&radius_hist[ri], 1u);
             atomicAdd(&sh_f[fi], 1u);
             w += (unsigned)we;

@@ -327,16 +327,17 @@ void szhost_coeffs_free(szhost_coeffs *c)
 #define CHAIN_BODY(T, FABS, DIVIDE_IN_NOMEAN)                                                              \
     T *cf = (T *)coef;                                                                                     \
     T ebT = (T)eb;                                                                                         \
-    T rel = (T)0.025;                                                                                      \
-    T prec[4], rprec[4], last[4] = {0, 0, 0, 0};                                                           \
-    prec[0] = rel * ebT / late0; prec[1] = rel * ebT / late1; prec[2] = rel * ebT / late2; prec[3] = rel * ebT; \
-    for (int e = 0; e < 4; e++) { rprec[e] = 1 / prec[e]; out->prec[e] = (double)prec[e]; }                \
-    T *un[4];                                                                                              \
-    for (int e = 0; e < 4; e++) { un[e] = (T *)malloc((reg_count ? reg_count : 1) * sizeof(T)); out->unpred[e] = un[e]; } \
+    T rel = ncoef == 3 ? (T)(0.15 / 3) : (T)0.025;   /* sz_float.c:5608 (2-D), :6640 (3-D) */              \
+    T prec[4] = {0, 0, 0, 0}, rprec[4], last[4] = {0, 0, 0, 0};                                            \
+    if (ncoef == 3) { prec[0] = rel * ebT / late1; prec[1] = rel * ebT / late2; prec[2] = rel * ebT; }     \
+    else { prec[0] = rel * ebT / late0; prec[1] = rel * ebT / late1; prec[2] = rel * ebT / late2; prec[3] = rel * ebT; } \
+    for (int e = 0; e < ncoef; e++) { rprec[e] = 1 / prec[e]; out->prec[e] = (double)prec[e]; }            \
+    T *un[4] = {0, 0, 0, 0};                                                                               \
+    for (int e = 0; e < ncoef; e++) { un[e] = (T *)malloc((reg_count ? reg_count : 1) * sizeof(T)); out->unpred[e] = un[e]; } \
     size_t ci = 0;                                                                                         \
     for (size_t b = 0; b < nblocks; b++) {                                                                 \
         if (indicator[b]) continue;                                                                        \
-        for (int e = 0; e < 4; e++) {                                                                      \
+        for (int e = 0; e < ncoef; e++) {                                                                  \
             T cur = cf[(size_t)e * nblocks + b];                                                           \
             T diff = cur - last[e];                                                                        \
             T itv;                                                                                         \
@@ -355,28 +356,30 @@ void szhost_coeffs_free(szhost_coeffs *c)
         ci++;                                                                                              \
     }
 
+/* ncoef = 4: 3-D planes {a,b,c,d}, precisions from late0..late2; ncoef = 3: 2-D planes {a,b,c} (sz_float.c:6031-6055), precisions
+ * from late1, late2 (late0 unused).  `coef` is SoA [ncoef][nblocks]. */
 void szhost_coeff_chain(int is_double, void *coef, const unsigned char *indicator, size_t nblocks, double eb,
-                        int late0, int late1, int late2, int use_mean, szhost_coeffs *out)
+                        int late0, int late1, int late2, int use_mean, int ncoef, szhost_coeffs *out)
 {
     memset(out, 0, sizeof(*out));
     size_t reg_count = 0;
     for (size_t b = 0; b < nblocks; b++) if (!indicator[b]) reg_count++;
     out->reg_count = reg_count;
-    for (int e = 0; e < 4; e++) out->codes[e] = (int *)malloc((reg_count ? reg_count : 1) * sizeof(int));
+    for (int e = 0; e < ncoef; e++) out->codes[e] = (int *)malloc((reg_count ? reg_count : 1) * sizeof(int));
     if (is_double) { CHAIN_BODY(double, fabs, 0) }
     else { CHAIN_BODY(float, fabsf, 1) }
 }
 
 void szhost_coeff_unchain(int is_double, void *coef, const unsigned char *indicator, size_t nblocks,
                           int *const codes[4], const int radius[4], const double prec[4],
-                          const unsigned char *const unpred[4])
+                          const unsigned char *const unpred[4], int ncoef)
 {
     size_t ci = 0, un[4] = {0, 0, 0, 0};
     if (is_double) {
         double *cf = (double *)coef, last[4] = {0, 0, 0, 0};
         for (size_t b = 0; b < nblocks; b++) {
             if (indicator[b]) continue;
-            for (int e = 0; e < 4; e++) {
+            for (int e = 0; e < ncoef; e++) {
                 int t = codes[e][ci];
                 if (t != 0) last[e] = last[e] + 2 * (t - radius[e]) * prec[e];
                 else { memcpy(&last[e], unpred[e] + 8 * (un[e]++), 8); }
@@ -388,7 +391,7 @@ void szhost_coeff_unchain(int is_double, void *coef, const unsigned char *indica
         float *cf = (float *)coef, last[4] = {0, 0, 0, 0};
         for (size_t b = 0; b < nblocks; b++) {
             if (indicator[b]) continue;
-            for (int e = 0; e < 4; e++) {
+            for (int e = 0; e < ncoef; e++) {
                 int t = codes[e][ci];
                 if (t != 0) last[e] = last[e] + 2 * (t - radius[e]) * (float)prec[e];
                 else { memcpy(&last[e], unpred[e] + 4 * (un[e]++), 4); }

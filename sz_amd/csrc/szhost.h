@@ -58,15 +58,15 @@ typedef struct szhost_coeffs {
     size_t   unpred_count[4];
     double   prec[4];        /* T-rounded precisions */
 } szhost_coeffs;
-/* coef: SoA [4][nblocks] fitted coefficients (T); indicator: 1 = Lorenzo.  Overwrites coef for regression blocks
- * with the DECODED coefficients (what the decompressor will use). */
+/* coef: SoA [ncoef][nblocks] fitted coefficients (T); indicator: 1 = Lorenzo.  Overwrites coef for regression blocks
+ * with the DECODED coefficients (what the decompressor will use).  ncoef = 4: 3-D; ncoef = 3: 2-D (late0 unused). */
 void szhost_coeff_chain(int is_double, void *coef, const unsigned char *indicator, size_t nblocks, double eb,
-                        int late0, int late1, int late2, int use_mean, szhost_coeffs *out);
+                        int late0, int late1, int late2, int use_mean, int ncoef, szhost_coeffs *out);
 void szhost_coeffs_free(szhost_coeffs *c);
-/* inverse: codes+unpred -> decoded coefficients written into coef SoA [4][nblocks] for regression blocks */
+/* inverse: codes+unpred -> decoded coefficients written into coef SoA [ncoef][nblocks] for regression blocks */
 void szhost_coeff_unchain(int is_double, void *coef, const unsigned char *indicator, size_t nblocks,
                           int *const codes[4], const int radius[4], const double prec[4],
-                          const unsigned char *const unpred[4]);
+                          const unsigned char *const unpred[4], int ncoef);
 
 /* ---- stream framing ---- */
 typedef struct szhost_meta {
