@@ -64,3 +64,12 @@ def reg_beside_lorenzo(nz, ny, nx, dtype=np.float32):
     h = ny // 2 - 1
     d[:, :h, :] = near_zero_planes(nz, h, nx, dtype)
     return np.ascontiguousarray(d)
+
+
+def plane_field(ny, nx, dtype=np.float32):
+    """2-D: slow ramp + hash noise for x < nx/2 (the 2-D selection picks regression there), smooth sinusoid beyond (Lorenzo)."""
+    h = nx // 2
+    f = np.empty((ny, nx), dtype=dtype)
+    f[:, :h] = l_field(1, ny, h, dtype, n_for_hash=max(nx, 8))[0]
+    f[:, h:] = s_field(1, ny, nx - h, dtype)[0] * dtype(0.5)
+    return np.ascontiguousarray(f)

@@ -24,7 +24,7 @@ def sz(built):
 
 
 def _fields():
-    from sz_amd.fields import l_field, m_field, reg_beside_lorenzo, s_field
+    from sz_amd.fields import l_field, m_field, near_zero_planes, plane_field, reg_beside_lorenzo, s_field
     rng = np.random.default_rng(0)
     z = s_field(40, 40, 40)
     z[np.abs(z) < 0.7] = 0.0
@@ -47,6 +47,15 @@ def _fields():
         "4d": (s_field(12, 20, 24).reshape(3, 4, 20, 24), 0, 1e-4, 0.0),
         "reg-beside-lorenzo": (reg_beside_lorenzo(24, 40, 32), 0, 1e-4, 0.0),
         "reg-beside-lorenzo-f64": (reg_beside_lorenzo(48, 56, 64, np.float64), 0, 1e-4, 0.0),
+        # 2-D (16-wide blocks, three-coefficient planes; the oracle's 2-D restatement is unpinned, see tests/test_two_d.py)
+        "2d-plane": (plane_field(200, 300), 0, 1e-4, 0.0),
+        "2d-ragged": (plane_field(37, 45), 0, 1e-3, 0.0),
+        "2d-wide": (plane_field(2, 500), 0, 1e-3, 0.0),
+        "2d-tall": (plane_field(300, 3), 0, 1e-3, 0.0),
+        "2d-all-regression": (near_zero_planes(1, 100, 150)[0], 0, 1e-4, 0.0),
+        "2d-f64-rel": (plane_field(130, 257, np.float64), 1, 0.0, 1e-4),
+        "2d-from-3d-shape": (plane_field(64, 80).reshape(64, 1, 80), 0, 1e-4, 0.0),
+        "2d-1024": (plane_field(1024, 1024), 0, 1e-4, 0.0),
         "S128": (s_field(128, 128, 128), 0, 1e-4, 0.0),
         "M128": (m_field(128), 0, 1e-4, 0.0),
     }
@@ -212,6 +221,25 @@ def test_config4_full_size_slab_properties(sz):
     ctx.decompress(ptr2, True, n2, 4 + 36 + 8, d.shape, np.float64, dec2.data_ptr(), True)
     assert float((dec2 - dec).abs().max().item()) <= eb          # a second generation stays within the bound of the first
     ctx.close()
+
+
+def test_2d_full_size_properties(sz):
+    """4096 x 4096 float32 (64 MiB), ABS 1e-4: too large for the oracle in seconds, so size-independent properties: the decoded
+    array is within the bound, decoding is deterministic, and re-compressing the decoded array decodes to within the bound of it."""
+    from sz_amd.fields import plane_field
+    d = plane_field(4096, 4096)
+    eb = 1e-4
+    stream = sz.SZ_compress_args(d, sz.ABS, eb)
+    st = sz.SZ_hip_last_stats()
+    assert st.n_blocks == 256 * 256 and st.use_mean == 0 and 0 < st.n_reg_blocks < st.n_blocks
+    dec = sz.SZ_decompress(stream, d.shape, d.dtype)
+    assert float(np.abs(dec.astype(np.float64) - d.astype(np.float64)).max()) <= eb
+    assert np.array_equal(sz.SZ_decompress(stream, d.shape, d.dtype), dec)
+    assert sz.SZ_compress_args(d, sz.ABS, eb) == stream
+    stream2 = sz.SZ_compress_args(dec, sz.ABS, eb)
+    dec2 = sz.SZ_decompress(stream2, d.shape, d.dtype)
+    assert float(np.abs(dec2.astype(np.float64) - dec.astype(np.float64)).max()) <= eb
+    assert len(stream) < d.nbytes / 3
 
 
 def test_corrupt_streams_fail_cleanly(sz, oracle):

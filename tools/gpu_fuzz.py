@@ -18,13 +18,17 @@ for c in range(ncases):
     dt = np.float32 if rng.random() < 0.6 else np.float64
     shape = tuple(int(x) for x in rng.integers(2, 72, size=3))
     if rng.random() < 0.2: shape = (shape[0], shape[1], int(rng.integers(60, 200)))
+    two_d = rng.random() < 0.3     # a 2-D array: generated as one plane of the 3-D field
+    if two_d: shape = (1, int(rng.integers(2, 150)), int(rng.integers(2, 300)))
     if shape[0] * shape[1] * shape[2] <= 20: continue
     kind = int(rng.integers(0, 8))
     nz, ny, nx = shape
     if kind == 0: d = s_field(nz, ny, nx, dt)
     elif kind == 1: d = l_field(nz, ny, nx, dt, n_for_hash=max(nx, 8))
     elif kind == 2:
-        d = s_field(nz, ny, nx, dt); h = nz // 2; d[h:] = l_field(nz - h, ny, nx, dt, n_for_hash=max(nx, 8))
+        d = s_field(nz, ny, nx, dt)
+        if two_d: h = ny // 2; d[:, h:] = l_field(nz, ny - h, nx, dt, n_for_hash=max(nx, 8))
+        else: h = nz // 2; d[h:] = l_field(nz - h, ny, nx, dt, n_for_hash=max(nx, 8))
     elif kind == 3: d = rng.random(shape).astype(dt)
     elif kind == 4:
         d = s_field(nz, ny, nx, dt) * dt(0.02); h = max(1, ny // 2 - 1); d[:, :h, :] = near_zero_planes(nz, h, nx, dt, seed=c)
@@ -36,6 +40,7 @@ for c in range(ncases):
         d = near_zero_planes(nz, ny, nx, dt, seed=c) * dt(10.0 ** rng.integers(-1, 3))
         if rng.random() < 0.5: d[rng.integers(0, nz), rng.integers(0, ny), rng.integers(0, nx)] = 1e5
     d = np.ascontiguousarray(d)
+    if two_d: d = d.reshape(shape[1], shape[2])
     mode = int(rng.choice([0, 0, 0, 1, 2, 3]))
     rng_v = float(d.max()) - float(d.min())
     abs_b = float(10.0 ** rng.uniform(-5, -1)) * max(rng_v, 1e-6)
