@@ -56,6 +56,20 @@ def test_s512_size_and_psnr(oracle, anchors):
     assert f"{psnr:.6f}" == f"{a['psnr']:.6f}" and mx <= 1e-4
 
 
+@pytest.mark.slow
+def test_s512_sz14_no_regression_size_exact_count_psnr(oracle, anchors):
+    """SZ 1.4 path (withLinearRegression = NO): exact stream size, number of "exact" (unpredictable) values, PSNR and maximum error
+    of the unmodified reference on the 512^3 S-field."""
+    a = anchors["S512_f32_abs1e-4_best_speed_no_regression_sz14"]
+    d = s_field(512, 512, 512)
+    stream, st = oracle.compress(d, oracle.ABS, 1e-4, params=oracle.default_params(with_regression=0), want_stages=True)
+    assert len(stream) == a["stream_bytes"] and st["exact_count"] == a["exact_values"]
+    assert f"{d.nbytes / len(stream):.6f}" == f"{a['ratio']:.6f}"
+    dec = oracle.decompress(stream, d.shape, np.float32)
+    mx, psnr, _ = oracle.metrics(d, dec)
+    assert f"{psnr:.6f}" == f"{a['psnr']:.6f}" and f"{mx:.6g}" == f"{a['max_abs_err']:.6g}"
+
+
 def test_oracle_edge_cases(oracle):
     # constant array, tiny array (<= 20 values), 4-D folded to 3-D, expansion fallback on noise
     c = np.full((10, 12, 14), 3.25, dtype=np.float32)
