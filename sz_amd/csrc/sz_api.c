@@ -276,12 +276,13 @@ static int compress_fp(int dataType, int withRegression, unsigned char **newByte
 
     int dim = computeDimension(r5, r4, r3, r2, r1);
     if (dim == 5) { printf("Error: doesn't support 5 dimensions for now.\n"); return SZ_DERR; }
-    if (!(dim == 2 || dim == 3 || dim == 4) || withRegression == SZ_NO_REGRESSION || confparams_cpr->randomAccess) {
-        printf("Error: the MI355X build covers 2-D/3-D/4-D float/double arrays with withLinearRegression=YES; "
-               "this call (dim=%d, withRegression=%d, randomAccess=%d) is not covered yet.\n", dim, withRegression, confparams_cpr->randomAccess);
+    const int sz14 = withRegression == SZ_NO_REGRESSION;      /* the SZ 1.4 path (sz_float.c:2978): 3-D only in this build */
+    if (!(dim == 2 || dim == 3 || dim == 4) || (sz14 && dim != 3) || confparams_cpr->randomAccess) {
+        printf("Error: the MI355X build covers 2-D/3-D/4-D float/double arrays with withLinearRegression=YES and 3-D arrays with "
+               "withLinearRegression=NO; this call (dim=%d, withRegression=%d, randomAccess=%d) is not covered yet.\n", dim, withRegression, confparams_cpr->randomAccess);
         return SZ_NSCS;
     }
-    unsigned char flags = 0x80 | 0x40;
+    unsigned char flags = sz14 ? 0x40 : (0x80 | 0x40);        /* TightDataPointStorageF.c:600-611 / sz_float.c:7396 */
     if (confparams_cpr->protectValueRange) flags |= 0x04;
     szhost_write_meta(&m, flags, meta);
     szhip_params hp;
@@ -290,12 +291,19 @@ static int compress_fp(int dataType, int withRegression, unsigned char **newByte
     hp.quantization_intervals = exe_params->optQuantMode == 1 ? 0 : (unsigned)exe_params->intvCapacity;
     size_t s0 = dim == 4 ? r4 * r3 : r3;   /* 2-D: r3 == 0 tells the HIP layer so (sz_float.c:2942 passes (r2, r1)) */
     unsigned char *tmp = NULL; size_t tmpSize = 0;
-    int rc = szhip_compress(ctx, dataType == SZ_FLOAT ? SZHIP_F32 : SZHIP_F64, d_in, 1, s0, r2, r1, realPrecision, &hp,
+    int rc;
+    if (sz14) {   /* medianValue = min + valueRangeSize/2 in the data's type (dataCompression.c:117) */
+        double median = dataType == SZ_FLOAT ? (double)(float)((float)vmin + (float)valueRangeSize / 2) : vmin + valueRangeSize / 2;
+        rc = szhip_compress_sz14(ctx, dataType == SZ_FLOAT ? SZHIP_F32 : SZHIP_F64, d_in, 1, r3, r2, r1, realPrecision, valueRangeSize, median,
+                                 &hp, meta, 4 + meta_len, 0, &tmp, &tmpSize, &g_last_stats);
+    } else
+        rc = szhip_compress(ctx, dataType == SZ_FLOAT ? SZHIP_F32 : SZHIP_F64, d_in, 1, s0, r2, r1, realPrecision, &hp,
                             meta, 4 + meta_len, 0, &tmp, &tmpSize, &g_last_stats);
     if (rc != SZHIP_OK) { printf("Error: szhip_compress failed (%d): %s\n", rc, szhip_last_error(ctx)); return SZ_NSCS; }
     if (exe_params->optQuantMode == 1) { exe_params->intvCapacity = (int)g_last_stats.intervals; exe_params->intvRadius = exe_params->intvCapacity / 2; } /* updateQuantizationInfo */
 
-    if (tmpSize >= dataLength * esz + 3 + meta_len + exe_params->SZ_SIZE_TYPE + 1) { /* SZ_compress_args_float_StoreOriData, sz_float.c:526 */
+    /* SZ_compress_args_float_StoreOriData, sz_float.c:526; '>=' on the SZ 2.1 path (:2975), '>' on the SZ 1.4 path (:1469) */
+    if (tmpSize + (sz14 ? 0 : 1) > dataLength * esz + 3 + meta_len + exe_params->SZ_SIZE_TYPE + 1) {
         size_t tot = 3 + meta_len + 8 + 1 + esz * dataLength;
         unsigned char *o = (unsigned char *)malloc(tot);
         memcpy(o, meta, 4 + meta_len);
@@ -439,10 +447,15 @@ static void *decompress_fp(int dataType, unsigned char *cmpBytes, size_t cmpSize
         }
     } else {
         int dim = computeDimension(r5, r4, r3, r2, r1);
-        if (!(same & 0x80) || !(dim == 2 || dim == 3 || dim == 4) || st != 8 || confparams_dec->sol_ID != SZ) {
-            printf("Error: the MI355X build decodes SZ 2.1 regression-type streams of 2-D/3-D/4-D float/double arrays; this stream "
-                   "(flags 0x%02x, dim %d) is not covered yet.\n", same, dim);
+        if ((same & (0x20 | 0x08 | 0x02)) || !(dim == 2 || dim == 3 || dim == 4) || (!(same & 0x80) && dim != 3) || st != 8 || confparams_dec->sol_ID != SZ) {
+            printf("Error: the MI355X build decodes SZ 2.1 regression-type streams of 2-D/3-D/4-D arrays and SZ 1.4 streams of 3-D arrays "
+                   "(float/double, no point-wise-relative or random-access form); this stream (flags 0x%02x, dim %d) is not covered yet.\n", same, dim);
             ok = 0;
+        } else if (!(same & 0x80)) {   /* SZ 1.4 container: getSnapshotData_float_3D -> decompressDataSeries_float_3D (szd_float.c:146,600) */
+            szhip_ctx *ctx = get_ctx();
+            int rc = ctx ? szhip_decompress_sz14(ctx, dataType == SZ_FLOAT ? SZHIP_F32 : SZHIP_F64, sz, 0, szlen, 4 + meta_len + st,
+                                                 r3, r2, r1, out, 0, &g_last_stats) : SZHIP_ERR_NODEVICE;
+            if (rc != SZHIP_OK) { printf("Error: szhip_decompress_sz14 failed (%d): %s\n", rc, ctx ? szhip_last_error(ctx) : "no device"); ok = 0; }
         } else {
             szhip_ctx *ctx = get_ctx();
             size_t s0 = dim == 4 ? r4 * r3 : r3;

@@ -50,6 +50,10 @@ template <class T> struct szh_qargs {
     unsigned *err;            // set to 1 if a halo wait timed out
     szh_u64 *progress;        // [pencil][2] (J-face, I-face): {epoch, steps whose face values have been published}: the consumers' FILL
                               // wavefront polls these words and then fetches only granules that exist
+    int fmt;                  // 0: SZ 2.1 block path; 1: SZ 1.4 whole-array Lorenzo (sz_float.c:946): no blocks, capacity = intervals,
+                              //    interval number through double, lossy "exact" values, second-order predictor on the first row
+    T median;                 // fmt 1: exact values are kept as reqLength leading bits of (x - median)
+    int ign_bits;             // fmt 1: 8*sizeof(T) - reqLength, >= 0
     int backoff;              // FILL wavefront: sleep units between two rounds that delivered nothing
     int dbg;                  // development: 1 = no hand-off at all (timing only, results become WRONG), 4 = no issue priorities
     szh_u64 *trace;           // optional (development): per pencil {t_start, t_start, t_first_trip, t_end, wait spins, -, xcc, 0} + per-trip detail
@@ -123,6 +127,39 @@ SZH_HD int szh_quant_sel(T x, T pred, T eb, T recip, int capacity, int radius, T
     return ok ? q + radius : 0;
 }
 
+// SZ 1.4 flavour (sz_float.c:1040-1069): the interval number goes through double (`fabs`), the capacity is the full interval
+// count, and an unpredictable value is reconstructed as its reqLength leading bits against the median (dataCompression.c:454-477)
+SZH_HD float szh_keep_bits(float x, float median, int ign)
+{
+    const float norm = x - median;
+    int32_t s; __builtin_memcpy(&s, &norm, 4);
+    s = (int32_t)((uint32_t)(s >> ign) << ign);
+    float kept; __builtin_memcpy(&kept, &s, 4);
+    return kept + median;
+}
+SZH_HD double szh_keep_bits(double x, double median, int ign)
+{
+    const double norm = x - median;
+    int64_t s; __builtin_memcpy(&s, &norm, 8);
+    s = (int64_t)((uint64_t)(s >> ign) << ign);
+    double kept; __builtin_memcpy(&kept, &s, 8);
+    return kept + median;
+}
+template <class T>
+SZH_HD int szh_quant_sel14(T x, T pred, T eb, T recip, int capacity, int radius, T median, int ign, bool force_exact, T *recon)
+{
+    const T diff = x - pred;
+    T itv = (T)((double)szh_abs(diff) * (double)recip + 1.0);
+    const bool inr = itv < (T)capacity;
+    itv = inr ? itv : (T)0;
+    const T sitv = diff < 0 ? -itv : itv;
+    const int q = (int)(sitv / 2);
+    const T rc = pred + (T)(2 * q) * eb;
+    const bool ok = inr && !(szh_abs(x - rc) > eb) && !force_exact;
+    *recon = ok ? rc : szh_keep_bits(x, median, ign);
+    return ok ? q + radius : 0;
+}
+
 // B: back end. Requires: NL, lane(l), shfl_up(dst,src,d), readlane(src,lane), all(pred),
 //    ld_gran(p), st_gran(p,v), ld_flag(p), st_flag(p,v), backoff(n), nap(), clock(), where(),
 //    ld16(p, T(&)[16/sizeof T]), st16(p, const T(&)[...]) -- one 16-byte vector access (4-byte aligned for 4/8-byte T),
@@ -138,9 +175,10 @@ template <class B> SZH_HD int szh_vslot_top(int J) { return B::TPI * B::TPJ + B:
 // every hand-off is LDS.
 // HASREG: the pencil touches at least one regression block (otherwise the block bookkeeping and the
 //         regression quantiser are compiled out); USEMEAN: the stream's use_mean flag.
-template <class T, bool DEC, bool HASREG, bool USEMEAN, class B>
+template <class T, bool DEC, bool HASREG, bool USEMEAN, class B, int FMT = 0>
 SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_lds<T> &L)
 {
+    static_assert(FMT == 0 || (!HASREG && !USEMEAN), "the SZ 1.4 path has neither blocks nor the mean shortcut");
     constexpr int NL = B::NL;
     const szh_geom3 &G = a.G;
     const int r0 = G.g0.count, r1 = G.g1.count, r2 = G.g2.count;
@@ -317,8 +355,9 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
     };
 
     // rolling neighbour state (values at the previous step)
-    T cur[NL], A1[NL], B1[NL], C1[NL];
-    SZH_FORL { cur[l] = 0; A1[l] = 0; B1[l] = 0; C1[l] = 0; }
+    T cur[NL], A1[NL], B1[NL], C1[NL], cur2[NL];
+    SZH_FORL { cur[l] = 0; A1[l] = 0; B1[l] = 0; C1[l] = 0; cur2[l] = 0; }
+    const bool first_pencil = FMT == 1 && I == 0 && J == 0;   // holds the array's first row (its lane 0)
 
     const int tsteps = r2 + 14;
     int flushed = 0, filled = 0;   // code-ring columns already written back (compress) / already brought in (decompress)
@@ -370,7 +409,9 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
                 const T nB = il[l] > 0 ? shB[l] : (lane == 0 ? h63 : hval[l]);
                 const T nC = il[l] > 0 ? shCi[l] : (jl[l] > 0 ? shCj[l] : h62);
                 // [-1] + [-s1] + [-s0] - [-s1-1] - [-s0-1] - [-s0-s1] + [-s0-s1-1], left to right
-                const T pred = cur[l] + nA + nB - A1[l] - B1[l] - nC + C1[l];
+                // (SZ 1.4 subtracts [-s0-s1] before [-s0-1], sz_float.c:1311; its first row predicts 2P[k-1] - P[k-2] from k = 2 on)
+                T pred = FMT == 1 ? cur[l] + nA + nB - A1[l] - nC - B1[l] + C1[l] : cur[l] + nA + nB - A1[l] - B1[l] - nC + C1[l];
+                if (FMT == 1 && first_pencil && lane == 0 && k >= 2) pred = (T)2 * cur[l] - cur2[l];
                 T predr = 0;
                 if (HASREG) predr = pbase[l] + cc[l] * (T)kk[l] + cd[l];
                 const bool is_lor = HASREG ? lor[l] : true;
@@ -378,7 +419,9 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
                 if (!DEC) {
                     const T x = xr[s][l];
                     T rcl;
-                    int code = szh_quant_sel<T>(x, pred, eb, recip, cap_lor, radius, &rcl);
+                    int code = FMT == 1 ? szh_quant_sel14<T>(x, pred, eb, recip, cap_reg, radius, a.median, a.ign_bits,
+                                                             first_pencil && lane == 0 && k == 0, &rcl)
+                                        : szh_quant_sel<T>(x, pred, eb, recip, cap_lor, radius, &rcl);
                     if (USEMEAN) {
                         if (code != 0 && code <= radius) code -= 1;                 // sz_float.c:6944
                         if (szh_abs(x - mean) <= eb) { code = radius; rcl = mean; } // sz_float.c:6929
@@ -417,7 +460,8 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
                 // roll the neighbour state.  Lanes outside the k range must hand on ZEROS (the reference's zero halo).  With
                 // Lorenzo-only data they produce zeros by themselves (zero input, zero neighbours); the mean shortcut, stale
                 // pre-scattered values and a regression plane (non-zero prediction at k < 0) need the mask.
-                cur[l] = (USEMEAN || DEC || HASREG) ? (act ? nv : (T)0) : nv;
+                if (FMT == 1) cur2[l] = cur[l];
+                cur[l] = (USEMEAN || DEC || HASREG || FMT == 1) ? (act ? nv : (T)0) : nv;
                 A1[l] = nA; B1[l] = nB; C1[l] = nC;
                 // advance along dim2
                 if (HASREG && act) {
@@ -494,6 +538,7 @@ SZH_HD bool szh_pencil_has_reg(const szh_qargs<T> &a, int I, int J)
 template <class T, bool DEC, class B>
 SZH_HD void szh_pencil_run(const szh_qargs<T> &a, int I, int J, const szh_tile_lds<T> &L)
 {
+    if (a.fmt == 1) { szh_pencil_body<T, DEC, false, false, B, 1>(a, I, J, L); return; }
 #ifdef SZH_EXP_NOREG
     const bool hasreg = false;
 #else

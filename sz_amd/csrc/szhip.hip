@@ -530,6 +530,55 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     return SZHIP_OK;
 }
 
+// Huffman decode of `n` symbols on the device (self-synchronising sub-sequence decode, k_hdec_*): `d_bits` points at the payload,
+// `dtab` is the host-built decode table of the tree, `single_symbol` >= 0 for the one-leaf tree (zero payload bits).
+int huff_decode_device(szhip_ctx *ctx, u64 *sm, const unsigned char *d_bits, u64 total_bits, const std::vector<uint32_t> &dtab, int n_nodes,
+                       int single_symbol, int64_t n, uint16_t *d_out_codes)
+{
+    hipStream_t st = ctx->stream;
+    if (single_symbol >= 0) {
+        hipLaunchKernelGGL(k_fill_u16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_out_codes, n, (uint16_t)single_symbol);
+        HIPCHK(hipGetLastError());
+    } else {
+        const int64_t nsub = (int64_t)((total_bits + SZH_SUBSEQ_BITS - 1) / SZH_SUBSEQ_BITS);
+        if (nsub == 0) FAIL(SZHIP_ERR_STREAM, "empty Huffman payload");
+        TRY(ensure(ctx, ctx->dec_tab, dtab.size() * 4));
+        HIPCHK(hipMemcpyAsync(ctx->dec_tab.p, dtab.data(), dtab.size() * 4, hipMemcpyHostToDevice, st));
+        TRY(ensure(ctx, ctx->starts, (size_t)nsub * 8)); TRY(ensure(ctx, ctx->ends, (size_t)nsub * 8));
+        TRY(ensure(ctx, ctx->counts, (size_t)nsub * 8)); TRY(ensure(ctx, ctx->offs, (size_t)nsub * 8));
+        TRY(ensure(ctx, ctx->dirty, (size_t)nsub));
+        szh_hdec_args a;
+        a.bits = d_bits; a.total_bits = total_bits; a.table = (const unsigned *)ctx->dec_tab.p; a.n_nodes = n_nodes;
+        a.table_in_lds = (size_t)n_nodes * 8 <= 48 * 1024; a.nsub = nsub;
+        a.starts = (u64 *)ctx->starts.p; a.ends = (u64 *)ctx->ends.p; a.counts = (u64 *)ctx->counts.p;
+        a.dirty = (unsigned char *)ctx->dirty.p; a.changed = (unsigned *)(sm + SM_CHANGED);
+        const size_t lds = a.table_in_lds ? (size_t)n_nodes * 8 : 16;
+        const unsigned gsub = (unsigned)((nsub + 255) / 256);
+        hipLaunchKernelGGL(k_hdec_init, dim3(gsub), dim3(256), 0, st, a);
+        int64_t iter = 0;
+        for (;;) {
+            hipLaunchKernelGGL(k_hdec_pass, dim3(gsub), dim3(256), lds, st, a);
+            HIPCHK(hipMemsetAsync(sm + SM_CHANGED, 0, 8, st));
+            hipLaunchKernelGGL(k_hdec_update, dim3(gsub), dim3(256), 0, st, a);
+            HIPCHK(hipGetLastError());
+            unsigned changed = 0;
+            HIPCHK(hipMemcpyAsync(&changed, sm + SM_CHANGED, 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            if (!changed) break;
+            if (++iter > nsub + 2) FAIL(SZHIP_ERR_INTERNAL, "Huffman decode did not converge");
+        }
+        TRY(scan_u64(ctx, (const u64 *)ctx->counts.p, nsub, (u64 *)ctx->offs.p, sm + SM_TOTAL_SYM));
+        u64 total_sym = 0;
+        HIPCHK(hipMemcpyAsync(&total_sym, sm + SM_TOTAL_SYM, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if ((int64_t)total_sym < n) FAIL(SZHIP_ERR_STREAM, "Huffman payload holds %llu symbols, need %lld", (unsigned long long)total_sym, (long long)n);
+        hipLaunchKernelGGL(k_hdec_write, dim3(gsub), dim3(256), lds, st, a, (const u64 *)ctx->offs.p, d_out_codes, n);
+        HIPCHK(hipGetLastError());
+    }
+
+    return SZHIP_OK;
+}
+
 // everything the host reads from an SZ 2.1 regression-type stream before the unpredictable values
 template <class T> struct dec_header {
     T eb = 0, mean = 0;
@@ -693,45 +742,7 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
     uint16_t *d_nat = (uint16_t *)ctx->codes_nat.p, *d_blk = (uint16_t *)ctx->codes_blk.p;
 
     // ---- Huffman decode of the type array
-    if (single_symbol >= 0) {
-        hipLaunchKernelGGL(k_fill_u16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_blk, n, (uint16_t)single_symbol);
-        HIPCHK(hipGetLastError());
-    } else {
-        const int64_t nsub = (int64_t)((total_bits + SZH_SUBSEQ_BITS - 1) / SZH_SUBSEQ_BITS);
-        if (nsub == 0) FAIL(SZHIP_ERR_STREAM, "empty Huffman payload");
-        TRY(ensure(ctx, ctx->dec_tab, dtab.size() * 4));
-        HIPCHK(hipMemcpyAsync(ctx->dec_tab.p, dtab.data(), dtab.size() * 4, hipMemcpyHostToDevice, st));
-        TRY(ensure(ctx, ctx->starts, (size_t)nsub * 8)); TRY(ensure(ctx, ctx->ends, (size_t)nsub * 8));
-        TRY(ensure(ctx, ctx->counts, (size_t)nsub * 8)); TRY(ensure(ctx, ctx->offs, (size_t)nsub * 8));
-        TRY(ensure(ctx, ctx->dirty, (size_t)nsub));
-        szh_hdec_args a;
-        a.bits = d_stream + pay_off; a.total_bits = total_bits; a.table = (const unsigned *)ctx->dec_tab.p; a.n_nodes = n_nodes;
-        a.table_in_lds = (size_t)n_nodes * 8 <= 48 * 1024; a.nsub = nsub;
-        a.starts = (u64 *)ctx->starts.p; a.ends = (u64 *)ctx->ends.p; a.counts = (u64 *)ctx->counts.p;
-        a.dirty = (unsigned char *)ctx->dirty.p; a.changed = (unsigned *)(sm + SM_CHANGED);
-        const size_t lds = a.table_in_lds ? (size_t)n_nodes * 8 : 16;
-        const unsigned gsub = (unsigned)((nsub + 255) / 256);
-        hipLaunchKernelGGL(k_hdec_init, dim3(gsub), dim3(256), 0, st, a);
-        int64_t iter = 0;
-        for (;;) {
-            hipLaunchKernelGGL(k_hdec_pass, dim3(gsub), dim3(256), lds, st, a);
-            HIPCHK(hipMemsetAsync(sm + SM_CHANGED, 0, 8, st));
-            hipLaunchKernelGGL(k_hdec_update, dim3(gsub), dim3(256), 0, st, a);
-            HIPCHK(hipGetLastError());
-            unsigned changed = 0;
-            HIPCHK(hipMemcpyAsync(&changed, sm + SM_CHANGED, 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            if (!changed) break;
-            if (++iter > nsub + 2) FAIL(SZHIP_ERR_INTERNAL, "Huffman decode did not converge");
-        }
-        TRY(scan_u64(ctx, (const u64 *)ctx->counts.p, nsub, (u64 *)ctx->offs.p, sm + SM_TOTAL_SYM));
-        u64 total_sym = 0;
-        HIPCHK(hipMemcpyAsync(&total_sym, sm + SM_TOTAL_SYM, 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        if ((int64_t)total_sym < n) FAIL(SZHIP_ERR_STREAM, "Huffman payload holds %llu symbols, need %lld", (unsigned long long)total_sym, (long long)n);
-        hipLaunchKernelGGL(k_hdec_write, dim3(gsub), dim3(256), lds, st, a, (const u64 *)ctx->offs.p, d_blk, n);
-        HIPCHK(hipGetLastError());
-    }
+    TRY(huff_decode_device(ctx, sm, d_stream + pay_off, total_bits, dtab, n_nodes, single_symbol, n, d_blk));
 
     // ---- natural order, unpredictable values into the output array
     const int ncols = G.g0.num * G.g1.num;
@@ -802,6 +813,399 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
         HIPCHK(hipEventRecord(ctx->ev[3], st));
         S.quant_kernel_launches = 1;
     }
+    unsigned kerr = 0;
+    HIPCHK(hipMemcpyAsync(&kerr, sm + SM_ERR, 4, hipMemcpyDeviceToHost, st));
+    if (!out_on_device) HIPCHK(hipMemcpyAsync(out, d_out, (size_t)n * sizeof(T), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(ctx->ev[4], st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (kerr) FAIL(SZHIP_ERR_INTERNAL, "wavefront kernel: halo wait timed out");
+    float ms = 0;
+    hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); S.ms_entropy = ms;
+    hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); S.ms_quant = ms;
+    S.ms_host = host_ms; S.ms_total = now_ms() - t_begin; S.out_bytes = (uint64_t)n * sizeof(T);
+    if (stats) *stats = S;
+    return SZHIP_OK;
+}
+
+// =====================================================================================================================
+// SZ 1.4 ("no regression") 3-D path: SZ_compress_float_3D_MDQ (sz/src/sz_float.c:946-1415) + convertTDPStoFlatBytes_float
+// (TightDataPointStorageF.c:379-479,590-663), and the inverse decompressDataSeries_float_3D (szd_float.c:600-1138).
+// Whole-array Lorenzo on the same wavefront kernel (fmt = 1); the code array is already in stream order; the "exact" values are
+// compacted in scan order and packed by k_exact_*.
+// =====================================================================================================================
+
+// required length (bits) of an exact value and the median it is taken against (sz_float.c:45-56 / sz_double.c:44-55)
+template <class T> int req_length(double eb, T range, T *median);
+template <> int req_length<float>(double eb, float range, float *median)
+{
+    const float half = range / 2; uint32_t u; memcpy(&u, &half, 4);
+    uint64_t e; memcpy(&e, &eb, 8);
+    const int reqExpo = (int)((e >> 52) & 0x7ff) - 1023, radExpo = (int)((u >> 23) & 0xff) - 127;
+    int req = 9 + radExpo - reqExpo + 1;
+    if (req < 9) req = 9;
+    if (req > 32) { req = 32; *median = 0; }
+    return req;
+}
+template <> int req_length<double>(double eb, double range, double *median)
+{
+    const double half = range / 2; uint64_t u; memcpy(&u, &half, 8);
+    uint64_t e; memcpy(&e, &eb, 8);
+    const int reqExpo = (int)((e >> 52) & 0x7ff) - 1023, radExpo = (int)((u >> 52) & 0x7ff) - 1023;
+    int req = 12 + radExpo - reqExpo;
+    if (req < 12) req = 12;
+    if (req > 64) { req = 64; *median = 0; }
+    return req;
+}
+
+template <class T>
+int launch_pencil14(szhip_ctx *ctx, const szh_geom3 &G, u64 *sm, bool dec, const T *d_in, T *d_out, uint16_t *d_codes, T eb, unsigned intervals,
+                    T median, int ign_bits)
+{
+    hipStream_t st = ctx->stream;
+    int nI, nJ, ntiles;
+    using TS = szh_tile_shape<T>;
+    TRY(prepare_pencil(ctx, G, szh_gran<T>::NW, TS::TPI, TS::TPJ, &nI, &nJ, &ntiles));
+    szh_qargs<T> a; memset(&a, 0, sizeof(a));
+    a.G = G; a.data = d_in; a.out = d_out; a.codes = d_codes; a.blk_lor = nullptr; a.coef = nullptr;
+    a.eb = eb; a.recip = 1 / eb; a.mean = 0; a.cap = (int)intervals; a.radius = (int)intervals / 2; a.use_mean = 0;
+    a.fmt = 1; a.median = median; a.ign_bits = ign_bits;
+    a.faceI = (szh_u64 *)ctx->faceI.p; a.faceJ = (szh_u64 *)ctx->faceJ.p; a.epoch = ++ctx->epoch;
+    a.nI = nI; a.nJ = nJ; a.order = (const unsigned *)ctx->order.p;
+    a.ticket = (unsigned *)(sm + SM_TICKET); a.err = (unsigned *)(sm + SM_ERR);
+    a.progress = (szh_u64 *)ctx->progress.p; a.backoff = tune_int("SZ_HIP_BACKOFF", 4);
+    a.trace = nullptr; a.dbg = 0;
+    HIPCHK(hipEventRecord(ctx->ev[2], st));
+    if (dec) hipLaunchKernelGGL((k_pencil<T, true>), dim3((unsigned)ntiles), dim3((TS::TPI * TS::TPJ + 2) * 64), 0, st, a);
+    else hipLaunchKernelGGL((k_pencil<T, false>), dim3((unsigned)ntiles), dim3((TS::TPI * TS::TPJ + 2) * 64), 0, st, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev[3], st));
+    return SZHIP_OK;
+}
+
+template <class T>
+int compress14_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r0, size_t r1, size_t r2, double eb_in, double range_in,
+                    double median_in, const szhip_params *prm, const unsigned char *meta, size_t meta_len, int out_on_device,
+                    unsigned char **out, size_t *out_size, szhip_stats *stats)
+{
+    const int is_double = sizeof(T) == 8;
+    const szh_geom3 G = szh_make_geom3((int)r0, (int)r1, (int)r2);
+    const int64_t n = G.n;
+    const T eb = (T)eb_in;                                     // `float realPrecision` parameter of sz_float.c:946
+    const double t_begin = now_ms();
+    double host_ms = 0;
+    hipStream_t st = ctx->stream;
+    szhip_stats S; memset(&S, 0, sizeof(S));
+    S.n_elements = (uint64_t)n;
+
+    const T *d_in = (const T *)data;
+    if (!data_on_device) {
+        TRY(ensure(ctx, ctx->in, (size_t)n * sizeof(T)));
+        HIPCHK(hipMemcpyAsync(ctx->in.p, data, (size_t)n * sizeof(T), hipMemcpyHostToDevice, st));
+        d_in = (const T *)ctx->in.p;
+    }
+    TRY(ensure(ctx, ctx->small, SM_COUNT * 8));
+    u64 *sm = (u64 *)ctx->small.p;
+    HIPCHK(hipMemsetAsync(sm, 0, SM_COUNT * 8, st));
+    HIPCHK(hipEventRecord(ctx->ev[0], st));
+
+    // ---- interval optimiser (optimize_intervals_float_3D_opt, sz_float.c:4644): the SZ 2.1 sample lattice, radius histogram only
+    unsigned intervals = prm->quantization_intervals;
+    if (intervals == 0) {
+        const unsigned max_radius = prm->max_quant_intervals / 2;
+        TRY(ensure(ctx, ctx->hist, (size_t)(max_radius + 8192) * 4 + 64));
+        TRY(ensure_pinned(ctx, (size_t)(max_radius + 8192) * 4 + 64));
+        unsigned *d_rh = (unsigned *)ctx->hist.p, *d_fh = d_rh + max_radius;
+        HIPCHK(hipMemsetAsync(d_rh, 0, (size_t)(max_radius + 8192) * 4, st));
+        const int64_t nrows = szh_sample_row_limit(G, prm->sample_distance);
+        if (nrows > 0) {
+            int grid = (int)std::min<int64_t>((nrows + 255) / 256, 1024);
+            hipLaunchKernelGGL((k_sample<T>), dim3(grid), dim3(256), 0, st, G, d_in, nrows, prm->sample_distance, (double)eb, (T)0,
+                               max_radius, d_rh, d_fh, sm + SM_WITHIN);
+            HIPCHK(hipGetLastError());
+        }
+        unsigned *h_hist = (unsigned *)ctx->pinned;
+        HIPCHK(hipMemcpyAsync(h_hist, d_rh, (size_t)max_radius * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        double h0 = now_ms();
+        u64 total = 0;
+        for (unsigned i = 0; i < max_radius; ++i) total += h_hist[i];
+        const size_t target = (size_t)((float)total * prm->pred_threshold);       // `size_t targetCount = totalSampleSize*predThreshold`
+        size_t sum = 0; unsigned i = 0;
+        for (; i < max_radius; ++i) { sum += h_hist[i]; if (sum > target) break; }
+        if (i >= max_radius) i = max_radius - 1;
+        unsigned p2 = 2 * (i + 1); p2 -= 1; p2 |= p2 >> 1; p2 |= p2 >> 2; p2 |= p2 >> 4; p2 |= p2 >> 8; p2 |= p2 >> 16; p2 += 1;
+        intervals = p2 < 32 ? 32 : p2;
+        host_ms += now_ms() - h0;
+    }
+    if (intervals > 65536 || intervals < 4) FAIL(SZHIP_ERR_UNSUP, "quantization interval count %u outside [4,65536]", intervals);
+    S.intervals = intervals;
+    T median = (T)median_in;
+    const int req_len = req_length<T>((double)eb, (T)range_in, &median);
+    const int req_bytes = req_len / 8, resi_bits = req_len % 8, ign_bits = (int)sizeof(T) * 8 - req_len;
+    HIPCHK(hipEventRecord(ctx->ev[1], st));
+
+    // ---- predict + quantise
+    TRY(ensure(ctx, ctx->codes_nat, (size_t)n * 2 + 64));
+    uint16_t *d_codes = (uint16_t *)ctx->codes_nat.p;
+    TRY(launch_pencil14<T>(ctx, G, sm, false, d_in, nullptr, d_codes, eb, intervals, median, ign_bits));
+    S.quant_kernel_launches = 1;
+
+    // ---- histogram -> code book (host), exact-value counts
+    TRY(ensure(ctx, ctx->hist, (size_t)(65536 + 8192) * 4 + 64));
+    unsigned *d_hist = (unsigned *)ctx->hist.p;
+    TRY(ensure_pinned(ctx, (size_t)intervals * 4 + 64));
+    unsigned *h_hist = (unsigned *)ctx->pinned;
+    HIPCHK(hipMemsetAsync(d_hist, 0, (size_t)intervals * 4, st));
+    {
+        int rshift = 0; int use_lds = intervals <= 16384;
+        if (use_lds) { while ((intervals << (rshift + 1)) <= 16384u && rshift < 6) ++rshift; }
+        const size_t lds = use_lds ? ((size_t)intervals << rshift) * 4 : 16;
+        int grid = (int)std::min<int64_t>((n / 8 + 255) / 256 + 1, 2048);
+        hipLaunchKernelGGL(k_hist_u16, dim3(grid), dim3(256), lds, st, (const uint16_t *)d_codes, n, intervals, rshift, use_lds, d_hist);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipMemcpyAsync(h_hist, d_hist, (size_t)intervals * 4, hipMemcpyDeviceToHost, st));
+    const int64_t nlin = (n + SZH_LIN_CHUNK - 1) / SZH_LIN_CHUNK;
+    TRY(ensure(ctx, ctx->col_zeros64, (size_t)nlin * 8));
+    TRY(ensure(ctx, ctx->col_off, (size_t)nlin * 8));
+    hipLaunchKernelGGL(k_lin_zero_count, dim3((unsigned)nlin), dim3(256), 0, st, (const uint16_t *)d_codes, n, (u64 *)ctx->col_zeros64.p);
+    TRY(scan_u64(ctx, (const u64 *)ctx->col_zeros64.p, nlin, (u64 *)ctx->col_off.p, sm + SM_TOTAL_UNPRED));
+    u64 h_small[SM_COUNT];
+    HIPCHK(hipMemcpyAsync(h_small, sm, SM_COUNT * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if ((unsigned)h_small[SM_ERR] != 0) FAIL(SZHIP_ERR_INTERNAL, "wavefront kernel: halo wait timed out");
+    const u64 E = h_small[SM_TOTAL_UNPRED];
+    S.n_unpred = E;
+    double h0 = now_ms();
+    szhost_huff *hf = szhost_huff_build(2 * (int)intervals, h_hist, nullptr, intervals);
+    if (!hf) FAIL(SZHIP_ERR_INTERNAL, "Huffman build failed");
+    const size_t tree_bytes = szhost_huff_tree_size(hf);
+    const u64 total_bits = hf->total_bits;
+    const size_t pay_bytes = (size_t)((total_bits + 7) / 8);
+    std::vector<u64> tab_code(intervals); std::vector<uint8_t> tab_len(intervals);
+    for (unsigned s2 = 0; s2 < intervals; ++s2) { tab_code[s2] = hf->code[s2]; tab_len[s2] = hf->len[s2]; }
+    host_ms += now_ms() - h0;
+
+    // ---- exact values: compact in scan order, lead numbers, mid-byte offsets
+    u64 nmid = 0;
+    if (E > 0) {
+        TRY(ensure(ctx, ctx->unpred, (size_t)E * sizeof(T)));
+        TRY(ensure(ctx, ctx->lor_bits, (size_t)E + 8));              // lead numbers, one byte each
+        TRY(ensure(ctx, ctx->reg_flags, (size_t)E * 8));             // mid-byte counts
+        TRY(ensure(ctx, ctx->reg_rank, (size_t)E * 8));              // mid-byte offsets
+        hipLaunchKernelGGL((k_lin_zero_move<T, 0>), dim3((unsigned)nlin), dim3(256), 0, st, (const uint16_t *)d_codes, n, (const u64 *)ctx->col_off.p,
+                           d_in, (T *)ctx->unpred.p, (T *)nullptr);
+        hipLaunchKernelGGL((k_exact_lead<T>), dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, (const T *)ctx->unpred.p, (int64_t)E, median,
+                           req_bytes, (uint8_t *)ctx->lor_bits.p, (u64 *)ctx->reg_flags.p);
+        HIPCHK(hipGetLastError());
+        TRY(scan_u64(ctx, (const u64 *)ctx->reg_flags.p, (int64_t)E, (u64 *)ctx->reg_rank.p, sm + SM_SCRATCH));
+        HIPCHK(hipMemcpyAsync(&nmid, sm + SM_SCRATCH, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    const size_t lead_size = (size_t)((E * 2 + 7) / 8), resi_size = resi_bits ? (size_t)((E * (u64)resi_bits + 7) / 8) : 0;
+
+    // ---- container
+    h0 = now_ms();
+    const size_t type_size = 8 + tree_bytes + pay_bytes;
+    const size_t hdr_len = meta_len + 8 + 4 + 4 + sizeof(T) + 1 + 8 + 8 + 8 + 8 + 8 + tree_bytes;     // ... up to the Huffman payload
+    const size_t total_len = hdr_len + pay_bytes + lead_size + (size_t)nmid + resi_size;
+    std::vector<unsigned char> hdr(hdr_len, 0);
+    {
+        unsigned char *q = hdr.data();
+        memcpy(q, meta, meta_len); q += meta_len;
+        szhost_put_u64be(q, (uint64_t)n); q += 8;
+        szhost_put_u32be(q, prm->max_quant_intervals); q += 4;
+        szhost_put_u32be(q, intervals); q += 4;
+        if (is_double) szhost_put_f64be(q, (double)median); else szhost_put_f32be(q, (float)median);
+        q += sizeof(T);
+        *q++ = (unsigned char)req_len;
+        szhost_put_f64be(q, (double)eb); q += 8;
+        szhost_put_u64be(q, (uint64_t)type_size); q += 8;
+        szhost_put_u64be(q, (uint64_t)E); q += 8;
+        szhost_put_u64be(q, (uint64_t)nmid); q += 8;
+        szhost_put_u32be(q, (uint32_t)hf->n_nodes); q += 4;      // encode_withTree blob (Huffman.c:790-816)
+        szhost_put_u32be(q, intervals); q += 4;
+        szhost_huff_tree_write(hf, q); q += tree_bytes;
+    }
+    szhost_huff_free(hf);
+    host_ms += now_ms() - h0;
+
+    TRY(ensure(ctx, ctx->code_tab, (size_t)intervals * 8));
+    TRY(ensure(ctx, ctx->len_tab, (size_t)intervals));
+    HIPCHK(hipMemcpyAsync(ctx->code_tab.p, tab_code.data(), (size_t)intervals * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->len_tab.p, tab_len.data(), (size_t)intervals, hipMemcpyHostToDevice, st));
+    TRY(ensure(ctx, ctx->stream_buf, total_len + 64));
+    unsigned char *d_stream = (unsigned char *)ctx->stream_buf.p;
+    HIPCHK(hipMemsetAsync(d_stream, 0, total_len + 64, st));
+    HIPCHK(hipMemcpyAsync(d_stream, hdr.data(), hdr_len, hipMemcpyHostToDevice, st));
+    if (total_bits > 0) {
+        const int64_t nchunks = (n + SZH_ENC_CHUNK - 1) / SZH_ENC_CHUNK;
+        TRY(ensure(ctx, ctx->chunk_bits, (size_t)nchunks * 8));
+        TRY(ensure(ctx, ctx->chunk_off, (size_t)nchunks * 8));
+        hipLaunchKernelGGL(k_chunk_bits, dim3((unsigned)nchunks), dim3(256), 0, st, (const uint16_t *)d_codes, n, (const uint8_t *)ctx->len_tab.p,
+                           intervals, (u64 *)ctx->chunk_bits.p);
+        TRY(scan_u64(ctx, (const u64 *)ctx->chunk_bits.p, nchunks, (u64 *)ctx->chunk_off.p, sm + SM_TOTAL_BITS));
+        hipLaunchKernelGGL(k_encode, dim3((unsigned)nchunks), dim3(256), 0, st, (const uint16_t *)d_codes, n, (const u64 *)ctx->code_tab.p,
+                           (const uint8_t *)ctx->len_tab.p, intervals, (const u64 *)ctx->chunk_off.p, (u64)hdr_len * 8, (unsigned *)d_stream);
+        HIPCHK(hipGetLastError());
+    }
+    if (E > 0) {
+        unsigned char *lead_out = d_stream + hdr_len + pay_bytes, *mid_out = lead_out + lead_size, *resi_out = mid_out + nmid;
+        hipLaunchKernelGGL((k_exact_write<T>), dim3((unsigned)(((E + 7) / 8 + 255) / 256)), dim3(256), 0, st, (const T *)ctx->unpred.p, (int64_t)E,
+                           median, req_bytes, resi_bits, (const uint8_t *)ctx->lor_bits.p, (const u64 *)ctx->reg_rank.p, lead_out, mid_out, resi_out,
+                           (int64_t)resi_size);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(ctx->ev[4], st));
+    if (out_on_device == 2) {
+        if (!*out || *out_size < total_len) FAIL(SZHIP_ERR_ARG, "caller's device buffer too small (%zu < %zu)", *out_size, total_len);
+        HIPCHK(hipMemcpyAsync(*out, d_stream, total_len, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+    } else if (out_on_device) {
+        HIPCHK(hipStreamSynchronize(st));
+        *out = d_stream;
+    } else {
+        unsigned char *h = (unsigned char *)malloc(total_len ? total_len : 1);
+        if (!h) FAIL(SZHIP_ERR_INTERNAL, "out of host memory");
+        HIPCHK(hipMemcpyAsync(h, d_stream, total_len, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        *out = h;
+    }
+    *out_size = total_len;
+    {
+        u64 tb = 0;
+        if (total_bits > 0) { HIPCHK(hipMemcpy(&tb, sm + SM_TOTAL_BITS, 8, hipMemcpyDeviceToHost)); }
+        if (tb != total_bits) FAIL(SZHIP_ERR_INTERNAL, "encoded bit count mismatch (%llu vs %llu)", (unsigned long long)tb, (unsigned long long)total_bits);
+    }
+    float ms = 0;
+    hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); S.ms_prequant = ms;
+    hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); S.ms_quant = ms;
+    hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]); S.ms_entropy = ms;
+    S.ms_host = host_ms; S.ms_total = now_ms() - t_begin; S.out_bytes = total_len;
+    if (stats) *stats = S;
+    return SZHIP_OK;
+}
+
+// `body_off`: offset of the max_quant_intervals field (4 + 28|36 + 8)
+template <class T>
+int decompress14_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_on_device, size_t stream_len, size_t body_off,
+                      size_t r0, size_t r1, size_t r2, void *out, int out_on_device, szhip_stats *stats)
+{
+    const int is_double = sizeof(T) == 8;
+    const szh_geom3 G = szh_make_geom3((int)r0, (int)r1, (int)r2);
+    const int64_t n = G.n;
+    const double t_begin = now_ms();
+    double host_ms = 0;
+    hipStream_t st = ctx->stream;
+    szhip_stats S; memset(&S, 0, sizeof(S));
+    S.n_elements = (uint64_t)n;
+
+    TRY(ensure(ctx, ctx->stream_buf, stream_len + 64));
+    unsigned char *d_stream = (unsigned char *)ctx->stream_buf.p;
+    if (stream_on_device) { if (stream_in != d_stream) HIPCHK(hipMemcpyAsync(d_stream, stream_in, stream_len, hipMemcpyDeviceToDevice, st)); }
+    else HIPCHK(hipMemcpyAsync(d_stream, stream_in, stream_len, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(d_stream + stream_len, 0, 64, st));
+    HIPCHK(hipEventRecord(ctx->ev[0], st));
+
+    // ---- header + tree on the host (TightDataPointStorageF.c:54-265); a device-resident stream hands over a prefix
+    double h0 = now_ms();
+    const size_t fixed = 4 + 4 + sizeof(T) + 1 + 8 + 8 + 8 + 8 + 8;
+    if (body_off + fixed > stream_len) FAIL(SZHIP_ERR_STREAM, "truncated stream");
+    std::vector<unsigned char> hbuf;
+    const unsigned char *hs = stream_in;
+    auto fetch = [&](size_t want) -> int {
+        if (!stream_on_device) return SZHIP_OK;
+        hbuf.resize(want);
+        HIPCHK(hipMemcpyAsync(hbuf.data(), d_stream, want, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        hs = hbuf.data();
+        return SZHIP_OK;
+    };
+    TRY(fetch(body_off + fixed));
+    const unsigned char *q = hs + body_off;
+    q += 4;                                                        // max_quant_intervals
+    const unsigned intervals = szhost_get_u32be(q); q += 4;
+    const T median = is_double ? (T)szhost_get_f64be(q) : (T)szhost_get_f32be(q); q += sizeof(T);
+    const int req_len = *q++;
+    const T eb = (T)szhost_get_f64be(q); q += 8;                   // `float realPrecision = tdps->realPrecision`, szd_float.c:610
+    const uint64_t type_size = szhost_get_u64be(q); q += 8;
+    const uint64_t E = szhost_get_u64be(q); q += 8;
+    const uint64_t nmid = szhost_get_u64be(q); q += 8;
+    const size_t type_off = body_off + fixed - 8;                  // the blob starts with nodeCount | intervals
+    if (intervals < 4 || intervals > 65536) FAIL(SZHIP_ERR_STREAM, "bad interval count %u", intervals);
+    if (req_len < 9 || req_len > (int)sizeof(T) * 8) FAIL(SZHIP_ERR_STREAM, "bad exact-value length %d", req_len);
+    if (!(eb > 0)) FAIL(SZHIP_ERR_STREAM, "bad error bound");
+    const int req_bytes = req_len / 8, resi_bits = req_len % 8;
+    const size_t lead_size = (size_t)((E * 2 + 7) / 8), resi_size = resi_bits ? (size_t)((E * (uint64_t)resi_bits + 7) / 8) : 0;
+    if (E > (uint64_t)n || type_size < 8 || type_size > stream_len || nmid > stream_len ||
+        type_off + type_size + lead_size + nmid + resi_size > stream_len) FAIL(SZHIP_ERR_STREAM, "truncated stream");
+    const int node_count = (int)szhost_get_u32be(q);
+    if (node_count <= 0 || 8 + szhost_huff_serial_size(node_count) > type_size) FAIL(SZHIP_ERR_STREAM, "bad Huffman tree size");
+    const size_t tree_bytes = szhost_huff_serial_size(node_count);
+    TRY(fetch(type_off + 8 + tree_bytes));
+    szhost_huff *hf = szhost_huff_from_bytes(2 * (int)intervals, hs + type_off + 8, node_count);
+    if (!hf) FAIL(SZHIP_ERR_STREAM, "bad Huffman tree");
+    std::vector<uint32_t> dtab((size_t)hf->n_nodes * 2);
+    szhost_huff_decode_table(hf, dtab.data());
+    const int single_symbol = hf->t[0] ? (int)hf->C[0] : -1;
+    const int n_nodes = hf->n_nodes;
+    szhost_huff_free(hf);
+    const size_t pay_off = type_off + 8 + tree_bytes;
+    const u64 total_bits = (u64)(type_size - 8 - tree_bytes) * 8;
+    S.intervals = intervals; S.n_unpred = E;
+    host_ms += now_ms() - h0;
+
+    TRY(ensure(ctx, ctx->small, SM_COUNT * 8));
+    u64 *sm = (u64 *)ctx->small.p;
+    HIPCHK(hipMemsetAsync(sm, 0, SM_COUNT * 8, st));
+    TRY(ensure(ctx, ctx->codes_nat, (size_t)n * 2 + 64));
+    uint16_t *d_codes = (uint16_t *)ctx->codes_nat.p;
+    TRY(huff_decode_device(ctx, sm, d_stream + pay_off, total_bits, dtab, n_nodes, single_symbol, n, d_codes));
+
+    // ---- exact values back into the output array
+    const int64_t nlin = (n + SZH_LIN_CHUNK - 1) / SZH_LIN_CHUNK;
+    TRY(ensure(ctx, ctx->col_zeros64, (size_t)nlin * 8));
+    TRY(ensure(ctx, ctx->col_off, (size_t)nlin * 8));
+    hipLaunchKernelGGL(k_lin_zero_count, dim3((unsigned)nlin), dim3(256), 0, st, (const uint16_t *)d_codes, n, (u64 *)ctx->col_zeros64.p);
+    TRY(scan_u64(ctx, (const u64 *)ctx->col_zeros64.p, nlin, (u64 *)ctx->col_off.p, sm + SM_TOTAL_UNPRED));
+    u64 zeros_found = 0;
+    HIPCHK(hipMemcpyAsync(&zeros_found, sm + SM_TOTAL_UNPRED, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (zeros_found != E) FAIL(SZHIP_ERR_STREAM, "stream lists %llu exact values, codes need %llu", (unsigned long long)E, (unsigned long long)zeros_found);
+    T *d_out = (T *)out;
+    if (!out_on_device) { TRY(ensure(ctx, ctx->out, (size_t)n * sizeof(T))); d_out = (T *)ctx->out.p; }
+    if (E > 0) {
+        const unsigned char *lead_in = d_stream + type_off + type_size, *mid_in = lead_in + lead_size, *resi_in = mid_in + nmid;
+        const unsigned gE = (unsigned)((E + 255) / 256);
+        TRY(ensure(ctx, ctx->unpred, (size_t)E * sizeof(T)));
+        TRY(ensure(ctx, ctx->reg_flags, (size_t)E * 8 * 3));         // flag words: f01 | f2 | mid counts
+        TRY(ensure(ctx, ctx->reg_rank, (size_t)E * 8 * 3));          // their exclusive prefix sums
+        TRY(ensure(ctx, ctx->lor_bits, (size_t)E * 3 + 8));          // compacted own bytes of positions 0..2
+        u64 *f01 = (u64 *)ctx->reg_flags.p, *f2 = f01 + E, *mc = f2 + E;
+        u64 *s01 = (u64 *)ctx->reg_rank.p, *s2 = s01 + E, *mo = s2 + E;
+        uint8_t *own0 = (uint8_t *)ctx->lor_bits.p, *own1 = own0 + E, *own2 = own1 + E;
+        hipLaunchKernelGGL(k_exact_flags, dim3(gE), dim3(256), 0, st, lead_in, (int64_t)E, req_bytes, resi_bits, f01, f2, mc);
+        TRY(scan_u64(ctx, f01, (int64_t)E, s01, sm + SM_SCRATCH));
+        TRY(scan_u64(ctx, f2, (int64_t)E, s2, sm + SM_SCRATCH));
+        TRY(scan_u64(ctx, mc, (int64_t)E, mo, sm + SM_SCRATCH));
+        u64 mid_need = 0;
+        HIPCHK(hipMemcpyAsync(&mid_need, sm + SM_SCRATCH, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (mid_need != nmid) FAIL(SZHIP_ERR_STREAM, "stream holds %llu mid bytes, lead numbers need %llu", (unsigned long long)nmid, (unsigned long long)mid_need);
+        hipLaunchKernelGGL(k_exact_own, dim3(gE), dim3(256), 0, st, lead_in, (int64_t)E, req_bytes, resi_bits, mid_in, resi_in,
+                           (const u64 *)s01, (const u64 *)s2, (const u64 *)mo, own0, own1, own2);
+        hipLaunchKernelGGL((k_exact_build<T>), dim3(gE), dim3(256), 0, st, lead_in, (int64_t)E, req_bytes, resi_bits, mid_in, resi_in,
+                           (const u64 *)s01, (const u64 *)s2, (const u64 *)mo, (const uint8_t *)own0, (const uint8_t *)own1, (const uint8_t *)own2,
+                           median, (T *)ctx->unpred.p);
+        hipLaunchKernelGGL((k_lin_zero_move<T, 1>), dim3((unsigned)nlin), dim3(256), 0, st, (const uint16_t *)d_codes, n, (const u64 *)ctx->col_off.p,
+                           (const T *)nullptr, (T *)ctx->unpred.p, d_out);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(ctx->ev[1], st));
+
+    // ---- reconstruct
+    TRY(launch_pencil14<T>(ctx, G, sm, true, nullptr, d_out, d_codes, eb, intervals, median, 0));
+    S.quant_kernel_launches = 1;
     unsigned kerr = 0;
     HIPCHK(hipMemcpyAsync(&kerr, sm + SM_ERR, 4, hipMemcpyDeviceToHost, st));
     if (!out_on_device) HIPCHK(hipMemcpyAsync(out, d_out, (size_t)n * sizeof(T), hipMemcpyDeviceToHost, st));
@@ -894,6 +1298,34 @@ int szhip_compress(szhip_ctx *ctx, int dtype, const void *data, int data_on_devi
                ? compress_impl<float>(ctx, data, data_on_device, r0, r1, r2, eb, params, meta, meta_len, out_on_device, out, out_size, stats)
                : compress_impl<double>(ctx, data, data_on_device, r0, r1, r2, eb, params, meta, meta_len, out_on_device, out, out_size, stats);
     if (rc != SZHIP_OK) { hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream); } // an early exit must not leave work in flight
+    return rc;
+}
+
+int szhip_compress_sz14(szhip_ctx *ctx, int dtype, const void *data, int data_on_device, size_t r0, size_t r1, size_t r2, double eb,
+                        double value_range, double median, const szhip_params *params, const unsigned char *meta, size_t meta_len,
+                        int out_on_device, unsigned char **out, size_t *out_size, szhip_stats *stats)
+{
+    if (!ctx || !data || !params || !meta || !out || !out_size) return SZHIP_ERR_ARG;
+    if (r0 < 2 || r1 < 2 || r2 < 2 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff) return SZHIP_ERR_ARG;
+    if (!(eb > 0)) return SZHIP_ERR_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
+    const int rc = dtype == SZHIP_F32
+               ? compress14_impl<float>(ctx, data, data_on_device, r0, r1, r2, eb, value_range, median, params, meta, meta_len, out_on_device, out, out_size, stats)
+               : compress14_impl<double>(ctx, data, data_on_device, r0, r1, r2, eb, value_range, median, params, meta, meta_len, out_on_device, out, out_size, stats);
+    if (rc != SZHIP_OK) { hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream); }
+    return rc;
+}
+
+int szhip_decompress_sz14(szhip_ctx *ctx, int dtype, const unsigned char *stream, int stream_on_device, size_t stream_len, size_t body_off,
+                          size_t r0, size_t r1, size_t r2, void *out, int out_on_device, szhip_stats *stats)
+{
+    if (!ctx || !stream || !out || body_off >= stream_len) return SZHIP_ERR_ARG;
+    if (r0 < 2 || r1 < 2 || r2 < 2 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff) return SZHIP_ERR_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
+    const int rc = dtype == SZHIP_F32
+               ? decompress14_impl<float>(ctx, stream, stream_on_device, stream_len, body_off, r0, r1, r2, out, out_on_device, stats)
+               : decompress14_impl<double>(ctx, stream, stream_on_device, stream_len, body_off, r0, r1, r2, out, out_on_device, stats);
+    if (rc != SZHIP_OK) { hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream); }
     return rc;
 }
 

@@ -821,3 +821,176 @@ __global__ __launch_bounds__(256) void k_fill_u16(uint16_t *p, int64_t n, uint16
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = v;
 }
+
+// ------------------------------------------------------------------ SZ 1.4 container: the "exact" values
+// (TightDataPointStorageF: sz/src/TightDataPointStorageF.c:275-327,379-479; the per-value rules are
+//  compressSingleFloatValue dataCompression.c:454-477, updateLossyCompElement_Float CompressElement.c:230-254,
+//  compIdenticalLeadingBytesCount_float / addExactData dataCompression.c:562-592; inverse szd_float.c:627-676.)
+// An exact value is the image of (x - median) cut to reqLength leading bits.  Stored per value, in scan order: the number of
+// leading BYTES it shares with the previous exact value's full image (0..3, 2 bits), its bytes [lead, reqBytes) ("mid" bytes) and
+// its next reqLength % 8 bits ("residual" bits, packed MSB first).  The only coupling between values is the previous image, so
+// the encoder is one pass over the compacted list; the decoder resolves inherited bytes with prefix counts of "own byte" flags.
+#define SZH_LIN_CHUNK 2048 /* codes per workgroup (256 threads x 8) */
+
+// zero codes per chunk of the (natural = stream order) code array
+__global__ __launch_bounds__(256) void k_lin_zero_count(const uint16_t *__restrict__ codes, int64_t n, u64 *cnt)
+{
+    __shared__ u64 sh[8];
+    const int64_t e0 = (int64_t)blockIdx.x * SZH_LIN_CHUNK + threadIdx.x * 8;
+    unsigned z = 0;
+    for (int q = 0; q < 8; ++q) if (e0 + q < n && codes[e0 + q] == 0) ++z;
+    u64 tot;
+    block_excl_scan_256((u64)z, sh, &tot);
+    if (threadIdx.x == 0) cnt[blockIdx.x] = tot;
+}
+// DIR 0: list[rank] = data[position of the rank-th zero code]; DIR 1: out[position] = list[rank]
+template <class T, int DIR>
+__global__ __launch_bounds__(256) void k_lin_zero_move(const uint16_t *__restrict__ codes, int64_t n, const u64 *__restrict__ chunk_off,
+                                                       const T *data, T *list, T *out)
+{
+    __shared__ u64 sh[8];
+    const int64_t e0 = (int64_t)blockIdx.x * SZH_LIN_CHUNK + threadIdx.x * 8;
+    unsigned zmask = 0;
+    for (int q = 0; q < 8; ++q) if (e0 + q < n && codes[e0 + q] == 0) zmask |= 1u << q;
+    u64 tot;
+    u64 rank = chunk_off[blockIdx.x] + block_excl_scan_256((u64)__builtin_popcount(zmask), sh, &tot);
+    for (int q = 0; q < 8; ++q) {
+        if (!(zmask >> q & 1)) continue;
+        if (DIR == 0) list[rank] = data[e0 + q]; else out[e0 + q] = list[rank];
+        ++rank;
+    }
+}
+
+template <class T> struct szh_image;
+template <> struct szh_image<float> {
+    typedef uint32_t U; static constexpr int NB = 4;
+    __device__ static U of(float v) { U u; __builtin_memcpy(&u, &v, 4); return u; }
+    __device__ static float to(U u) { float v; __builtin_memcpy(&v, &u, 4); return v; }
+};
+template <> struct szh_image<double> {
+    typedef u64 U; static constexpr int NB = 8;
+    __device__ static U of(double v) { U u; __builtin_memcpy(&u, &v, 8); return u; }
+    __device__ static double to(U u) { double v; __builtin_memcpy(&v, &u, 8); return v; }
+};
+// byte b (0 = most significant) of an image
+template <class U> __device__ __forceinline__ unsigned img_byte(U u, int b, int nb) { return (unsigned)(u >> (8 * (nb - 1 - b))) & 0xffu; }
+template <class U> __device__ __forceinline__ int img_lead(U pre, U cur, int nb)
+{
+    int l = 0;
+    for (int b = 0; b < 3; ++b) { if (img_byte(pre, b, nb) == img_byte(cur, b, nb) && l == b) ++l; }
+    return l;   // identical leading bytes, capped at 3
+}
+
+// encoder pass 1: lead numbers and mid-byte counts
+template <class T>
+__global__ __launch_bounds__(256) void k_exact_lead(const T *__restrict__ list, int64_t E, T median, int req_bytes, uint8_t *lead, u64 *midcnt)
+{
+    typedef szh_image<T> IM;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= E) return;
+    const typename IM::U cur = IM::of(list[i] - median), pre = i ? IM::of(list[i - 1] - median) : 0;
+    const int l = img_lead(pre, cur, IM::NB);
+    lead[i] = (uint8_t)l;
+    midcnt[i] = (u64)(req_bytes > l ? req_bytes - l : 0);
+}
+// encoder pass 2: one thread per 8 values writes their 2 lead bytes, their mid bytes and their resi_bits residual bytes
+template <class T>
+__global__ __launch_bounds__(256) void k_exact_write(const T *__restrict__ list, int64_t E, T median, int req_bytes, int resi_bits,
+                                                     const uint8_t *__restrict__ lead, const u64 *__restrict__ midoff,
+                                                     uint8_t *lead_out, uint8_t *mid_out, uint8_t *resi_out, int64_t resi_size)
+{
+    typedef szh_image<T> IM;
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i0 = g * 8;
+    if (i0 >= E) return;
+    unsigned lb[2] = {0, 0};
+    u64 rbuf = 0;   // 8 values x resi_bits (<= 7) bits, MSB first
+    for (int q = 0; q < 8; ++q) {
+        const int64_t i = i0 + q;
+        if (i >= E) { rbuf <<= resi_bits; continue; }
+        const typename IM::U cur = IM::of(list[i] - median);
+        const int l = lead[i];
+        lb[q >> 2] |= (unsigned)l << (6 - 2 * (q & 3));
+        uint8_t *m = mid_out + midoff[i];
+        for (int b = l; b < req_bytes; ++b) *m++ = (uint8_t)img_byte(cur, b, IM::NB);
+        unsigned rb = 0;
+        if (resi_bits && req_bytes < IM::NB) rb = img_byte(cur, req_bytes, IM::NB) >> (8 - resi_bits);
+        rbuf = (rbuf << resi_bits) | rb;
+    }
+    lead_out[2 * g] = (uint8_t)lb[0];
+    if (i0 + 4 < E) lead_out[2 * g + 1] = (uint8_t)lb[1];
+    for (int b = 0; b < resi_bits; ++b) {                 // 8 * resi_bits bits = resi_bits bytes
+        const int64_t o = g * resi_bits + b;
+        if (o < resi_size) resi_out[o] = (uint8_t)(rbuf >> (8 * (resi_bits - 1 - b)));
+    }
+}
+
+__device__ __forceinline__ int exact_lead_at(const uint8_t *__restrict__ lead_packed, int64_t i) { return (lead_packed[i >> 2] >> (6 - 2 * (i & 3))) & 3; }
+__device__ __forceinline__ unsigned exact_resi_at(const uint8_t *__restrict__ resi, int64_t i, int resi_bits)
+{
+    const int64_t bit = i * resi_bits;
+    const unsigned w = ((unsigned)resi[bit >> 3] << 8) | resi[(bit >> 3) + 1];   // the stream buffer is zero-padded past its end
+    return (w >> (16 - resi_bits - (int)(bit & 7))) & ((1u << resi_bits) - 1u);
+}
+// byte position b of a value is its OWN (not inherited from the previous value) from its lead number on -- and, whatever the lead
+// number, at the position of the residual bits, which the decoder always overwrites (szd_float.c:669-672)
+__device__ __forceinline__ bool exact_is_own(int l, int b, int req_bytes, int resi_bits) { return b >= l || (resi_bits && b == req_bytes); }
+// decoder pass 1: per value, "own byte" flags of byte positions 0..2 and the mid-byte count
+__global__ __launch_bounds__(256) void k_exact_flags(const uint8_t *__restrict__ lead_packed, int64_t E, int req_bytes, int resi_bits,
+                                                     u64 *f01, u64 *f2, u64 *midcnt)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= E) return;
+    const int l = exact_lead_at(lead_packed, i);
+    f01[i] = ((u64)exact_is_own(l, 0, req_bytes, resi_bits) << 32) | (u64)exact_is_own(l, 1, req_bytes, resi_bits);
+    f2[i] = (u64)exact_is_own(l, 2, req_bytes, resi_bits);
+    midcnt[i] = (u64)(req_bytes > l ? req_bytes - l : 0);
+}
+// own value of byte position b of value i: a mid byte, the residual byte, or zero
+__device__ __forceinline__ unsigned exact_own_byte(const uint8_t *__restrict__ mid, u64 moff, int l, int b, int req_bytes, unsigned resi_byte)
+{
+    if (b < req_bytes) return mid[moff + (u64)(b - l)];
+    return b == req_bytes ? resi_byte : 0u;
+}
+// decoder pass 2: compact the own bytes of positions 0..2 (s01 / s2: exclusive prefix counts of the flags)
+__global__ __launch_bounds__(256) void k_exact_own(const uint8_t *__restrict__ lead_packed, int64_t E, int req_bytes, int resi_bits,
+                                                   const uint8_t *__restrict__ mid, const uint8_t *__restrict__ resi,
+                                                   const u64 *__restrict__ s01, const u64 *__restrict__ s2, const u64 *__restrict__ midoff,
+                                                   uint8_t *own0, uint8_t *own1, uint8_t *own2)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= E) return;
+    const int l = exact_lead_at(lead_packed, i);
+    const unsigned rbyte = resi_bits ? exact_resi_at(resi, i, resi_bits) << (8 - resi_bits) : 0u;
+    const u64 mo = midoff[i];
+    if (exact_is_own(l, 0, req_bytes, resi_bits)) own0[s01[i] >> 32] = (uint8_t)exact_own_byte(mid, mo, l, 0, req_bytes, rbyte);
+    if (exact_is_own(l, 1, req_bytes, resi_bits)) own1[s01[i] & 0xffffffffull] = (uint8_t)exact_own_byte(mid, mo, l, 1, req_bytes, rbyte);
+    if (exact_is_own(l, 2, req_bytes, resi_bits)) own2[s2[i]] = (uint8_t)exact_own_byte(mid, mo, l, 2, req_bytes, rbyte);
+}
+// decoder pass 3: assemble every value: inherited bytes come from the latest own byte of that position before it (zero if none)
+template <class T>
+__global__ __launch_bounds__(256) void k_exact_build(const uint8_t *__restrict__ lead_packed, int64_t E, int req_bytes, int resi_bits,
+                                                     const uint8_t *__restrict__ mid, const uint8_t *__restrict__ resi,
+                                                     const u64 *__restrict__ s01, const u64 *__restrict__ s2, const u64 *__restrict__ midoff,
+                                                     const uint8_t *__restrict__ own0, const uint8_t *__restrict__ own1,
+                                                     const uint8_t *__restrict__ own2, T median, T *list)
+{
+    typedef szh_image<T> IM;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= E) return;
+    const int l = exact_lead_at(lead_packed, i);
+    const unsigned rbyte = resi_bits ? exact_resi_at(resi, i, resi_bits) << (8 - resi_bits) : 0u;
+    const u64 mo = midoff[i];
+    typename IM::U u = 0;
+    for (int b = 0; b < IM::NB; ++b) {
+        unsigned v;
+        if (exact_is_own(l, b, req_bytes, resi_bits)) v = exact_own_byte(mid, mo, l, b, req_bytes, rbyte);
+        else {   // b < l <= 3: this value has no own byte here, so the exclusive count is the inclusive one
+            const u64 c = b == 0 ? (s01[i] >> 32) : b == 1 ? (s01[i] & 0xffffffffull) : s2[i];
+            const uint8_t *own = b == 0 ? own0 : b == 1 ? own1 : own2;
+            v = c ? own[c - 1] : 0u;
+        }
+        u = (u << 8) | (typename IM::U)v;
+    }
+    list[i] = IM::to(u) + median;
+}
