@@ -223,6 +223,74 @@ def test_config4_full_size_slab_properties(sz):
     ctx.close()
 
 
+def _sz14_fields():
+    from sz_amd.fields import l_field, m_field, near_zero_planes, s_field
+    rng = np.random.default_rng(7)
+    spike = s_field(30, 30, 30); spike[5, 7, 11] = 1e6; spike[:, :3, :] = 0
+    noisy = s_field(40, 48, 56) + (rng.random((40, 48, 56)).astype(np.float32) - np.float32(0.5)) * np.float32(3e-4)
+    return {
+        "S40": (s_field(40, 40, 40), 0, 1e-4, 0.0),
+        "noisy": (noisy, 0, 1e-5, 0.0),
+        "L": (l_field(30, 50, 70), 0, 1e-4, 0.0),
+        "ragged": (s_field(37, 45, 70), 0, 1e-4, 0.0),
+        "thin": (s_field(200, 9, 7), 0, 1e-4, 0.0),
+        "min-dims": (s_field(2, 3, 50), 0, 1e-3, 0.0),
+        "random": (rng.random((33, 20, 17), dtype=np.float32), 0, 1e-2, 0.0),
+        "spike": (spike, 0, 1e-2, 0.0),
+        "tight-bound-32-bit-exact": (s_field(24, 24, 24), 0, 1e-7, 0.0),
+        "M48-f64": (m_field(48, np.float64), 0, 1e-5, 0.0),
+        "planes-f64": (near_zero_planes(20, 30, 40, np.float64), 0, 1e-6, 0.0),
+        "S-f64-rel": (s_field(32, 64, 64, np.float64), 1, 0.0, 1e-3),
+        "abs-and-rel": (s_field(24, 32, 40), 2, 1e-3, 1e-4),
+        "S128": (s_field(128, 128, 128), 0, 1e-4, 0.0),
+    }
+
+
+@pytest.fixture()
+def sz14(sz, oracle):
+    """The same library with `withLinearRegression = NO`: the SZ 1.4 path (sz_float.c:2978)."""
+    sz.conf_params().withRegression = 0
+    yield sz, oracle.default_params(with_regression=0)
+    sz.conf_params().withRegression = 1
+
+
+@pytest.mark.parametrize("name", list(_sz14_fields().keys()))
+def test_sz14_stream_and_decode_identical_to_oracle(sz14, oracle, name):
+    sz, p = sz14
+    d, mode, ab, rel = _sz14_fields()[name]
+    ref, st = oracle.compress(d, mode, ab, rel, params=p, want_stages=True)
+    got = sz.SZ_compress_args(d, mode, ab, rel)
+    assert len(got) == len(ref) and got == ref, f"{name}: stream differs (first diff at {next((i for i, (x, y) in enumerate(zip(got, ref)) if x != y), None)})"
+    if st is not None:
+        stats = sz.SZ_hip_last_stats()
+        assert (stats.intervals, stats.n_unpred) == (st["intervals"], st["exact_count"])
+    dec = sz.SZ_decompress(ref, d.shape, d.dtype)
+    ref_dec = oracle.decompress(ref, d.shape, d.dtype)
+    iv = np.uint32 if d.dtype == np.float32 else np.uint64
+    assert np.array_equal(dec.view(iv), ref_dec.view(iv)), name
+    if st is not None:
+        assert float(np.abs(dec.astype(np.float64) - d.astype(np.float64)).max()) <= st["eb"]
+
+
+def test_sz14_recorded_reference_output_at_512(sz14, anchors):
+    """The unmodified reference's recorded result for the 512^3 S-field with withLinearRegression = NO: exact stream size and
+    exact-value count, compression ratio and PSNR to six decimals, maximum error to six significant digits -- no oracle involved."""
+    sz, _ = sz14
+    from sz_amd.fields import s_field
+    a = anchors["S512_f32_abs1e-4_best_speed_no_regression_sz14"]
+    d = s_field(512, 512, 512)
+    stream = sz.SZ_compress_args(d, sz.ABS, 1e-4)
+    st = sz.SZ_hip_last_stats()
+    assert len(stream) == a["stream_bytes"] and st.n_unpred == a["exact_values"]
+    assert f"{d.nbytes / len(stream):.6f}" == f"{a['ratio']:.6f}"
+    dec = sz.SZ_decompress(stream, d.shape, d.dtype)
+    err = float(np.abs(dec.astype(np.float64) - d.astype(np.float64)).max())
+    mse = float(((dec.astype(np.float64) - d.astype(np.float64)) ** 2).mean())
+    rng = float(d.max()) - float(d.min())
+    psnr = 20 * np.log10(rng) - 10 * np.log10(mse)
+    assert f"{err:.6g}" == f"{a['max_abs_err']:.6g}" and abs(psnr - a["psnr"]) < 2e-6
+
+
 def test_2d_full_size_properties(sz):
     """4096 x 4096 float32 (64 MiB), ABS 1e-4: too large for the oracle in seconds, so size-independent properties: the decoded
     array is within the bound, decoding is deterministic, and re-compressing the decoded array decodes to within the bound of it."""
@@ -283,6 +351,14 @@ def test_differential_fuzz_against_the_oracle(built):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_fuzz.py"), "400", "11"], capture_output=True, text=True, timeout=600)
     tail = [ln for ln in out.stdout.splitlines() if ln.startswith("fuzz:") or ln.startswith("FAIL")]
     assert tail and tail[-1].startswith("fuzz: 400 cases, 0 failures"), "\n".join(tail[-10:]) + out.stderr[-2000:]
+
+
+def test_differential_fuzz_sz14_against_the_oracle(built):
+    """The same with withLinearRegression = NO (SZ 1.4 path), 300 random 3-D cases."""
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_fuzz.py"), "300", "13", "sz14"], capture_output=True, text=True, timeout=600)
+    tail = [ln for ln in out.stdout.splitlines() if ln.startswith("fuzz:") or ln.startswith("FAIL")]
+    assert tail and tail[-1].startswith("fuzz: 300 cases, 0 failures"), "\n".join(tail[-10:]) + out.stderr[-2000:]
 
 
 def test_config1_through_a_plain_c_caller(built, anchors, tmp_path):
