@@ -72,6 +72,42 @@ static unsigned FN(szo_optimize_intervals_3d_opt)(const szo_params *p, const T *
     return pow2;
 }
 
+/* 2-D (sz_float.c:5015-5068): the lattice of the 2-D SZ 2.1 optimiser, radius histogram only */
+static unsigned FN(szo_optimize_intervals_2d_opt)(const szo_params *p, const T *data, size_t r1, size_t r2, double ebD)
+{
+    const size_t len = r1 * r2;
+    unsigned maxRangeRadius = p->max_quant_intervals / 2;
+    size_t *iv = (size_t *)calloc(maxRangeRadius, sizeof(size_t));
+    const size_t sd = (size_t)p->sample_distance;
+    size_t total = 0, oc = sd - 1, n1 = 1;
+    size_t pos = r2 + oc;
+    while (pos < len) {
+        const T *d = data + pos;
+        total++;
+        T pred = d[-1] + d[-(ptrdiff_t)r2] - d[-(ptrdiff_t)r2 - 1];
+        T pred_err = (T)fabs((double)(T)(pred - *d));
+        size_t ri = (size_t)(((double)pred_err / ebD + 1) / 2);
+        if (ri >= maxRangeRadius) ri = maxRangeRadius - 1;
+        iv[ri]++;
+        oc += sd;
+        if (oc >= r2) {
+            n1++;
+            size_t oc2 = n1 % sd;
+            pos += (r2 + sd - oc) + (sd - oc2);
+            oc = sd - oc2;
+            if (oc == 0) oc++;
+        } else pos += sd;
+    }
+    size_t target = (size_t)(total * p->pred_threshold);
+    size_t sum = 0, i;
+    for (i = 0; i < maxRangeRadius; i++) { sum += iv[i]; if (sum > target) break; }
+    if (i >= maxRangeRadius) i = maxRangeRadius - 1;
+    unsigned pow2 = szo_round_up_pow2(2 * (unsigned)(i + 1));
+    if (pow2 < 32) pow2 = 32;
+    free(iv);
+    return pow2;
+}
+
 /* required length of an "exact" value in bits, and the median it is taken against (sz_float.c:45-56 / sz_double.c:44-55) */
 static int FN(szo_req_length)(double eb, T range, T *median)
 {
@@ -148,7 +184,10 @@ static inline int FN(szo_sz14_point)(FN(szo_exact) *E, T x, T pred, T eb, T reci
     return 0;
 }
 
-/* r1 slowest ... r3 fastest (callee convention of sz_float.c:946).  `meta` = version bytes, flag byte and parameter bytes. */
+/* r1 slowest ... r3 fastest (callee convention of sz_float.c:946).  `meta` = version bytes, flag byte and parameter bytes.
+ * r1 == 1 is the 2-D compressor SZ_compress_float_2D_MDQ (sz_float.c:610-894; inverse szd_float.c:284-598): its predictors are
+ * exactly those of layer 0 below (:686, :727, :772, :814); only its optimiser walks another lattice.  2-D is PARITY UNPINNED
+ * (no recorded reference output of a 2-D array). */
 static unsigned char *FN(szo_sz14_compress_3d)(const szo_params *p, const unsigned char *meta, size_t meta_len,
                                                const T *data, size_t r1, size_t r2, size_t r3, T eb, T range, T median_in,
                                                size_t *out_size, szo_stages *st)
@@ -156,7 +195,8 @@ static unsigned char *FN(szo_sz14_compress_3d)(const szo_params *p, const unsign
     const size_t n = r1 * r2 * r3, r23 = r2 * r3;
     const T recip = 1 / eb;
     unsigned intervals = p->quantization_intervals ? p->quantization_intervals
-                                                   : FN(szo_optimize_intervals_3d_opt)(p, data, r1, r2, r3, (double)eb);
+                         : r1 == 1 ? FN(szo_optimize_intervals_2d_opt)(p, data, r2, r3, (double)eb)
+                                   : FN(szo_optimize_intervals_3d_opt)(p, data, r1, r2, r3, (double)eb);
     const int radius = (int)intervals / 2;
     FN(szo_exact) E; memset(&E, 0, sizeof(E));
     E.median = median_in;

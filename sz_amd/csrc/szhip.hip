@@ -888,7 +888,9 @@ int compress14_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t
                     unsigned char **out, size_t *out_size, szhip_stats *stats)
 {
     const int is_double = sizeof(T) == 8;
-    const szh_geom3 G = szh_make_geom3((int)r0, (int)r1, (int)r2);
+    // r0 == 0: the 2-D compressor SZ_compress_float_2D_MDQ (sz_float.c:610): its predictors are those of the 3-D one's first layer,
+    // so it is carried as 1 x r1 x r2 (the block size of the carried geometry plays no role here); its optimiser has the 2-D lattice
+    const szh_geom3 G = r0 == 0 ? szh_make_geom2((int)r1, (int)r2) : szh_make_geom3((int)r0, (int)r1, (int)r2);
     const int64_t n = G.n;
     const T eb = (T)eb_in;                                     // `float realPrecision` parameter of sz_float.c:946
     const double t_begin = now_ms();
@@ -1092,7 +1094,7 @@ int decompress14_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream
                       size_t r0, size_t r1, size_t r2, void *out, int out_on_device, szhip_stats *stats)
 {
     const int is_double = sizeof(T) == 8;
-    const szh_geom3 G = szh_make_geom3((int)r0, (int)r1, (int)r2);
+    const szh_geom3 G = r0 == 0 ? szh_make_geom2((int)r1, (int)r2) : szh_make_geom3((int)r0, (int)r1, (int)r2);
     const int64_t n = G.n;
     const double t_begin = now_ms();
     double host_ms = 0;
@@ -1306,7 +1308,7 @@ int szhip_compress_sz14(szhip_ctx *ctx, int dtype, const void *data, int data_on
                         int out_on_device, unsigned char **out, size_t *out_size, szhip_stats *stats)
 {
     if (!ctx || !data || !params || !meta || !out || !out_size) return SZHIP_ERR_ARG;
-    if (r0 < 2 || r1 < 2 || r2 < 2 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff) return SZHIP_ERR_ARG;
+    if ((r0 != 0 && r0 < 2) || r1 < 2 || r2 < 2 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff) return SZHIP_ERR_ARG;
     if (!(eb > 0)) return SZHIP_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
     const int rc = dtype == SZHIP_F32
@@ -1320,7 +1322,7 @@ int szhip_decompress_sz14(szhip_ctx *ctx, int dtype, const unsigned char *stream
                           size_t r0, size_t r1, size_t r2, void *out, int out_on_device, szhip_stats *stats)
 {
     if (!ctx || !stream || !out || body_off >= stream_len) return SZHIP_ERR_ARG;
-    if (r0 < 2 || r1 < 2 || r2 < 2 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff) return SZHIP_ERR_ARG;
+    if ((r0 != 0 && r0 < 2) || r1 < 2 || r2 < 2 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff) return SZHIP_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
     const int rc = dtype == SZHIP_F32
                ? decompress14_impl<float>(ctx, stream, stream_on_device, stream_len, body_off, r0, r1, r2, out, out_on_device, stats)

@@ -224,7 +224,7 @@ def test_config4_full_size_slab_properties(sz):
 
 
 def _sz14_fields():
-    from sz_amd.fields import l_field, m_field, near_zero_planes, s_field
+    from sz_amd.fields import l_field, m_field, near_zero_planes, plane_field, s_field
     rng = np.random.default_rng(7)
     spike = s_field(30, 30, 30); spike[5, 7, 11] = 1e6; spike[:, :3, :] = 0
     noisy = s_field(40, 48, 56) + (rng.random((40, 48, 56)).astype(np.float32) - np.float32(0.5)) * np.float32(3e-4)
@@ -243,6 +243,12 @@ def _sz14_fields():
         "S-f64-rel": (s_field(32, 64, 64, np.float64), 1, 0.0, 1e-3),
         "abs-and-rel": (s_field(24, 32, 40), 2, 1e-3, 1e-4),
         "S128": (s_field(128, 128, 128), 0, 1e-4, 0.0),
+        # 2-D arrays on the SZ 1.4 path (sz_float.c:610; the oracle's 2-D lattice is unpinned)
+        "2d-plane": (plane_field(200, 300), 0, 1e-4, 0.0),
+        "2d-ragged-f64": (plane_field(37, 45, np.float64), 0, 1e-5, 0.0),
+        "2d-wide": (plane_field(2, 500), 0, 1e-3, 0.0),
+        "2d-tall": (plane_field(300, 3), 0, 1e-3, 0.0),
+        "2d-1024": (plane_field(1024, 1024), 0, 1e-4, 0.0),
     }
 
 

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import sim_lib
-from sz_amd.fields import s_field
+from sz_amd.fields import plane_field, s_field
 
 
 def _noisy(shape, dtype, amp, seed=5):
@@ -46,6 +46,17 @@ def test_oracle_sz14_round_trip_and_container(oracle, shape, dtype, eb):
     assert int(st["lead"].max()) <= 3 and mid_n == int(np.maximum(req // 8 - st["lead"].astype(np.int64), 0).sum())
 
 
+@pytest.mark.parametrize("shape,dtype,eb", [((200, 300), np.float32, 1e-4), ((37, 45), np.float64, 1e-5), ((2, 500), np.float32, 1e-3)])
+def test_oracle_sz14_2d_round_trip(oracle, shape, dtype, eb):
+    """2-D arrays on the SZ 1.4 path (SZ_compress_float_2D_MDQ, sz_float.c:610): PARITY UNPINNED (no recorded reference output);
+    the restatement shares everything but the optimiser's lattice with the pinned 3-D one."""
+    d = plane_field(*shape, dtype)
+    stream, st = oracle.compress(d, oracle.ABS, eb, params=oracle.default_params(with_regression=0), want_stages=True)
+    dec = oracle.decompress(stream, shape, dtype)
+    assert float(np.abs(dec.astype(np.float64) - d.astype(np.float64)).max()) <= eb
+    assert st is None or (st["codes"][0] == 0 and st["exact_count"] == int((st["codes"] == 0).sum()))
+
+
 @pytest.mark.slow
 def test_sz14_hip_layer_on_cpu_shim(oracle):
     """Kernels + orchestration of the product compiled against the HIP-on-CPU shim reproduce the oracle's SZ 1.4 streams byte
@@ -60,7 +71,8 @@ def test_sz14_hip_layer_on_cpu_shim(oracle):
         p = oracle.default_params(with_regression=0)
         spike = s_field(16, 16, 16); spike[3, 4, 5] = 1e4; spike[:, :2, :] = 0
         cases = (("smooth", s_field(10, 12, 40), 1e-4), ("noisy", _noisy((9, 17, 33), np.float32, 3e-4), 1e-5),
-                 ("noisy-f64", _noisy((12, 10, 24), np.float64, 3e-4), 1e-6), ("spike", spike, 1e-3))
+                 ("noisy-f64", _noisy((12, 10, 24), np.float64, 3e-4), 1e-6), ("spike", spike, 1e-3),
+                 ("2d", plane_field(40, 70), 1e-4), ("2d-f64", plane_field(33, 40, np.float64), 1e-5))   # 2-D: sz_float.c:610 (unpinned)
         for name, d, eb in cases:
             ref, _ = oracle.compress(d, oracle.ABS, eb, params=p)
             got = sz_amd.SZ_compress_args(d, sz_amd.ABS, eb)

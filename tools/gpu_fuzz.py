@@ -11,7 +11,7 @@ from sz_amd.fields import l_field, m_field, near_zero_planes, s_field
 assert sz_amd.SZ_Init(os.path.join(ROOT, "tests", "golden", "sz_speed.config")) == 0
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-sz14 = len(sys.argv) > 3 and sys.argv[3] == "sz14"      # withLinearRegression = NO: the SZ 1.4 path (3-D arrays only)
+sz14 = len(sys.argv) > 3 and sys.argv[3] == "sz14"      # withLinearRegression = NO: the SZ 1.4 path
 oparams = O.default_params(with_regression=0) if sz14 else None
 if sz14: sz_amd.conf_params().withRegression = 0
 fails = 0
@@ -21,7 +21,7 @@ for c in range(ncases):
     dt = np.float32 if rng.random() < 0.6 else np.float64
     shape = tuple(int(x) for x in rng.integers(2, 72, size=3))
     if rng.random() < 0.2: shape = (shape[0], shape[1], int(rng.integers(60, 200)))
-    two_d = rng.random() < 0.3 and not sz14     # a 2-D array: generated as one plane of the 3-D field
+    two_d = rng.random() < 0.3     # a 2-D array: generated as one plane of the 3-D field
     if two_d: shape = (1, int(rng.integers(2, 150)), int(rng.integers(2, 300)))
     if shape[0] * shape[1] * shape[2] <= 20: continue
     kind = int(rng.integers(0, 8))
