@@ -199,7 +199,7 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
     const int mybase = myslot * stride;
 
     // ---- per-lane constants ----
-    int il[NL], jl[NL], skew[NL], hskew[NL], hlds[NL], pjb[NL], pib[NL], pcb[NL], trash[NL], ctrash[NL];
+    int il[NL], jl[NL], skew[NL], hskew[NL], hlds[NL], hrd[NL], pjb[NL], pib[NL], pcb[NL], trash[NL], ctrash[NL];
     bool inb[NL];
     int64_t rowoff[NL], blkrow[NL];
     T fii[NL], fjj[NL];
@@ -222,6 +222,7 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
         else if (il[l] == 0 && jl[l] > 0 && hasPI && j < r1) { hskew[l] = jl[l]; hlds[l] = slotPI * stride + (8 + jl[l]) * RS; } // (8I-1, j, k): I-face of (I-1,J), row jl
         else if (lane == 63 && hasPI) hlds[l] = slotPI * stride + 8 * RS;                                                   // for lane 0: (8I-1, 8J, k)
         else if (lane == 62 && hasPI && hasPJ) hlds[l] = slotPI * stride + 16 * RS;                                         // for lane 0: (8I-1, 8J-1, k), forwarded by (I-1,J)
+        hrd[l] = hlds[l] >= 0 ? hlds[l] : 0;   // lanes without a halo row read (and discard) some valid slot
         // rows of the own ring this lane writes (-1: none): J-face row il, I-face row jl, forwarded corner column
         pjb[l] = (pubJ && jl[l] == 7 && inb[l]) ? mybase + il[l] * RS : -1;
         pib[l] = (pubI && il[l] == 7 && inb[l]) ? mybase + (8 + jl[l]) * RS : -1;
@@ -386,10 +387,14 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
                 const int need = t + 8 < tsteps ? t + 8 : tsteps;
                 if (pstepJ < need) pstepJ = wait_ctr(L.cstep + slotPJ, need);
                 if (pstepI < need) pstepI = wait_ctr(L.cstep + slotPI, need);
+                // A face value sits at the ring position of the PRODUCER'S STEP that made it (column + the producing lane's skew), so
+                // every lane of this wavefront reads position t + 7 and every lane of the producer wrote position t: one
+                // wavefront-uniform offset per step instead of per-lane address arithmetic.
+                const int rpos = B::ring(t + 7);
                 SZH_FORL {      // every lane reads (lanes without a halo row read a don't-care slot)
                     const int kh = t - hskew[l];
                     const bool lact = hlds[l] >= 0 && (unsigned)kh < (unsigned)r2;
-                    const T v = B::lds_ld(L.faces + (lact ? hlds[l] + B::ring(kh) : trash[l]));
+                    const T v = B::lds_ld(L.faces + hrd[l] + rpos);
                     hval[l] = lact ? v : (T)0;
                 }
             }
@@ -451,11 +456,12 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
                 }
                 // faces for the pencils to the right / below (in this tile or, through the STORE wavefront, in the next one):
                 // every lane stores; lanes without a face row, or outside the k range, store to their trash slot
-                if (pubJ) B::lds_st(L.faces + ((act && pjb[l] >= 0) ? pjb[l] + B::ring(k) : trash[l]), nv);
+                const int wpos = B::ring(t);
+                if (pubJ) B::lds_st(L.faces + ((act && pjb[l] >= 0) ? pjb[l] + wpos : trash[l]), nv);
                 if (pubI) {
-                    B::lds_st(L.faces + ((act && pib[l] >= 0) ? pib[l] + B::ring(k) : trash[l]), nv);
+                    B::lds_st(L.faces + ((act && pib[l] >= 0) ? pib[l] + wpos : trash[l]), nv);
                     // lane (7,0): its halo value IS the corner column of the pencil below, same k
-                    B::lds_st(L.faces + ((act && pcb[l] >= 0) ? pcb[l] + B::ring(k) : trash[l]), hval[l]);
+                    B::lds_st(L.faces + ((act && pcb[l] >= 0) ? pcb[l] + wpos : trash[l]), hval[l]);
                 }
                 // roll the neighbour state.  Lanes outside the k range must hand on ZEROS (the reference's zero halo).  With
                 // Lorenzo-only data they produce zeros by themselves (zero input, zero neighbours); the mean shortcut, stale
@@ -626,7 +632,7 @@ SZH_HD void szh_tile_store(const szh_qargs<T> &a, int TI, int TJ, const szh_tile
             for (int e = 0; e < KP; ++e) {
                 if (e < n) {
                     const int k = pk[l] + e;
-                    const T v = B::lds_ld(L.faces + rbase[l] + B::ring(k));
+                    const T v = B::lds_ld(L.faces + rbase[l] + B::ring(k + m.sr));   // ring position = the producer's step
                     szh_u64 w2[NW];
                     szh_gran<T>::pack(v, a.epoch, w2);
                     SZH_UNROLL
@@ -727,7 +733,7 @@ SZH_HD void szh_tile_fill(const szh_qargs<T> &a, int TI, int TJ, const szh_tile_
                 SZH_UNROLL
                 for (int w = 0; w < NW; ++w) { w2[w] = g[e][w][l]; v = v && ((unsigned)(w2[w] >> 32) == a.epoch); }
                 run = run && v;                    // a row advances by its run of leading delivered columns
-                if (run) { B::lds_st(L.faces + wbase[l] + B::ring(fk[l] + e), szh_gran<T>::unpack(w2)); ++lead; }
+                if (run) { B::lds_st(L.faces + wbase[l] + B::ring(fk[l] + e + m.sr), szh_gran<T>::unpack(w2)); ++lead; }
             }
             fk[l] += lead;
             none[l] = lead == 0; fin[l] = fk[l] >= r2;

@@ -24,8 +24,8 @@ struct SimBackend {
     // keep every column: RL covers all of dim2.
     static constexpr int TPI = 2, TPJ = 3, RL = 1 << 20;
     static int ring(int k) { return k; }
-    static int face_rowstride(int r2) { return r2; }
-    static int face_stride(int r2) { return r2 * SZH_FROWS; }
+    static int face_rowstride(int r2) { return r2 + 16; }   // ring position = column + the producing lane's skew (<= 14)
+    static int face_stride(int r2) { return (r2 + 16) * SZH_FROWS; }
     template <class E> static E lds_ld(const E *p) { return *p; }
     template <class E> static E lds_ld_u(const E *p) { return *p; }
     template <class E> static void lds_st(E *p, E v) { *p = v; }
@@ -61,7 +61,7 @@ static int run_all(szh_qargs<T> a)
     constexpr int NP = B::TPI * B::TPJ, NV = B::TPI + B::TPJ;
     std::vector<uint16_t> ring((size_t)NP * (SZH_XC + 1) * 64);
     // "LDS" of one tile: face arrays [r2][SZH_FROWS] per slot, poisoned so that a value used before it is written shows
-    const size_t fsz = (size_t)(NP + NV) * r2 * SZH_FROWS;
+    const size_t fsz = (size_t)(NP + NV) * B::face_stride(r2);
     std::vector<T> faces(fsz + 64);
     std::vector<unsigned> cstep(NP + NV), spubJ(NP), spubI(NP);
     std::vector<int> scratch(128);
