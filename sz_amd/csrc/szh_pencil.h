@@ -597,7 +597,7 @@ SZH_HD void szh_tile_store(const szh_qargs<T> &a, int TI, int TJ, const szh_tile
 {
     constexpr int NL = B::NL;
     constexpr int NW = szh_gran<T>::NW;
-    constexpr int KP = 4;                       // columns per row per round
+    constexpr int KP = 8;                       // columns per row per round
     const int r0 = a.G.g0.count, r1 = a.G.g1.count, r2 = a.G.g2.count;
     const int stride = B::face_stride(r2);
     int pk[NL], slot[NL], rbase[NL];
@@ -681,7 +681,7 @@ SZH_HD void szh_tile_fill(const szh_qargs<T> &a, int TI, int TJ, const szh_tile_
 {
     constexpr int NL = B::NL;
     constexpr int NW = szh_gran<T>::NW;
-    constexpr int KF = 8;                       // columns per row per round
+    constexpr int KF = 16;                      // columns per row per round
     const int r0 = a.G.g0.count, r1 = a.G.g1.count, r2 = a.G.g2.count;
     const int stride = B::face_stride(r2);
     int fk[NL], cslot[NL], wbase[NL];
