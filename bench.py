@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--edge", type=int, default=EDGE, help="cube edge (512 = the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--other-paths", action="store_true",
+                    help="also time the SZ 1.4 container and a 2-D array (extra kernels: keep it off when profiling the headline kernel)")
     args = ap.parse_args()
 
     import torch
@@ -143,6 +145,37 @@ def main():
                 "traffic_source": "profiles/r01_pmc_traffic_pencil.json (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes)",
                 "algorithmic_bytes_per_launch": nbytes_in, "avg_kernel_ms": round(quant_avg_ms, 4)}
 
+    # ---- the other paths of the same library, one line each (outside the timed region; single GPU only): the SZ 1.4 container
+    #      (withLinearRegression = NO) on the same array, and a 2-D array through the SZ 2.1 path
+    other = None
+    if args.other_paths and world == 1 and n == EDGE:
+        def timed(fn, reps=3):
+            fn(); torch.cuda.synchronize(); t = time.perf_counter()
+            for _ in range(reps):
+                r = fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / reps, r
+
+        def run(fn_name, ptr, dims, extra, mbytes):
+            out = ctypes.c_void_p(out_buf.data_ptr()); nn = ctypes.c_size_t(out_cap); st = sz_amd.szhip_stats()
+            p = sz_amd.szhip_params(100, 0.99, 65536, 0)
+            rc = getattr(sz_amd.lib(), fn_name)(ctx._h, 0, ptr, 1, *dims, EB, *extra, ctypes.byref(p), mbytes, len(mbytes), 2,
+                                                ctypes.byref(out), ctypes.byref(nn), ctypes.byref(st))
+            if rc:
+                raise RuntimeError(f"{fn_name} failed: {sz_amd.lib().szhip_last_error(ctx._h)}")
+            return nn.value
+        rng = vmax - vmin
+        med = float(np.float32(np.float32(vmin) + np.float32(rng) / np.float32(2)))
+        meta14 = bytes([meta[0], meta[1], meta[2], 0x40]) + bytes(meta[4:])
+        t14, size14 = timed(lambda: run("szhip_compress_sz14", x.data_ptr(), (n, n, n), (float(np.float32(rng)), med), meta14))
+        from sz_amd.fields import plane_field
+        p2 = torch.from_numpy(plane_field(4096, 4096)).to(dev)
+        meta2 = sz_amd.make_meta(np.float32, err_mode=sz_amd.ABS, abs_bound=EB, vmin=float(p2.min().item()), vmax=float(p2.max().item()))
+        t2, size2 = timed(lambda: run("szhip_compress", p2.data_ptr(), (0, 4096, 4096), (), meta2))
+        other = {"sz14_3d_512_f32": {"GB/s": round(nbytes_in / t14 / 1e9, 2), "ms": round(t14 * 1e3, 3), "out_bytes": size14},
+                 "sz21_2d_4096x4096_f32": {"GB/s": round(p2.numel() * 4 / t2 / 1e9, 2), "ms": round(t2 * 1e3, 3), "out_bytes": size2}}
+        del p2
+
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -167,7 +200,7 @@ def main():
             "phase_ms": {"prequant": round(stats.ms_prequant, 3), "quant": round(stats.ms_quant, 3), "entropy": round(stats.ms_entropy, 3),
                          "host_glue": round(stats.ms_host, 3), "total": round(stats.ms_total, 3),
                          "decompress_quant": round(dst.ms_quant, 3), "decompress_total": round(dst.ms_total, 3)},
-            "roofline": roofline, "cpu_baseline": cpu}
+            "roofline": roofline, "cpu_baseline": cpu, "other_paths": other}
     print(json.dumps(line))
     if world > 1:
         dist.barrier(); dist.destroy_process_group()

@@ -113,6 +113,13 @@ def _bind(L):
     L.szhip_decompress.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, sz, sz, sz, sz, sz,
                                    ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(szhip_stats)]
     L.szhip_decompress.restype = ctypes.c_int
+    L.szhip_compress_sz14.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, sz, sz, sz, ctypes.c_double,
+                                      ctypes.c_double, ctypes.c_double, ctypes.POINTER(szhip_params), ctypes.c_char_p, sz, ctypes.c_int,
+                                      ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(sz), ctypes.POINTER(szhip_stats)]
+    L.szhip_compress_sz14.restype = ctypes.c_int
+    L.szhip_decompress_sz14.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, sz, sz, sz, sz, sz,
+                                        ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(szhip_stats)]
+    L.szhip_decompress_sz14.restype = ctypes.c_int
     L.szhip_debug_fetch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, sz]; L.szhip_debug_fetch.restype = ctypes.c_int
     L.szhost_write_meta.argtypes = [ctypes.POINTER(szhost_meta), ctypes.c_ubyte, ctypes.c_char_p]
     L.szhost_write_meta.restype = sz
