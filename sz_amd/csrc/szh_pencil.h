@@ -628,15 +628,30 @@ SZH_HD void szh_tile_store(const szh_qargs<T> &a, int TI, int TJ, const szh_tile
             const int cs = (int)B::lds_ld(L.cstep + slot[l]);
             int avail = cs - m.sr; if (avail > r2) avail = r2;
             int n = avail - pk[l]; if (n > KP) n = KP; if (n < 0 || !en[l]) n = 0;
+            // granules leave as 16-byte stores wherever two of them are neighbours at a 16-byte boundary (half the fabric writes):
+            // double: the two words of a column; float: the columns k, k+1 with an even granule index
+            szh_u64 gw[KP + 1][NW];
             SZH_UNROLL
             for (int e = 0; e < KP; ++e) {
-                if (e < n) {
-                    const int k = pk[l] + e;
-                    const T v = B::lds_ld(L.faces + rbase[l] + B::ring(k + m.sr));   // ring position = the producer's step
-                    szh_u64 w2[NW];
-                    szh_gran<T>::pack(v, a.epoch, w2);
-                    SZH_UNROLL
-                    for (int w = 0; w < NW; ++w) B::st_gran(dst[l] + (int64_t)k * NW + w, w2[w]);
+                const int k = pk[l] + e;
+                const T v = e < n ? B::lds_ld(L.faces + rbase[l] + B::ring(k + m.sr)) : (T)0;   // ring position = the producer's step
+                szh_gran<T>::pack(v, a.epoch, gw[e]);
+            }
+            SZH_UNROLL
+            for (int w = 0; w < NW; ++w) gw[KP][w] = 0;
+            if (NW == 2) {
+                SZH_UNROLL
+                for (int e = 0; e < KP; ++e) { if (e < n) B::st_gran2(dst[l] + (int64_t)(pk[l] + e) * 2, gw[e][0], gw[e][NW - 1]); }
+            } else {
+                szh_u64 *const p0 = dst[l] + pk[l];
+                const int odd = (int)(((uintptr_t)p0 >> 3) & 1);          // the first granule sits in the upper half of a 16-byte slot
+                if (odd && n > 0) B::st_gran(p0, gw[0][0]);
+                SZH_UNROLL
+                for (int j = 0; j < KP / 2; ++j) {
+                    const int e = 2 * j + odd;                             // pair (e, e+1), 16-byte aligned
+                    const szh_u64 wa = odd ? gw[2 * j + 1][0] : gw[2 * j][0], wb = odd ? gw[2 * j + 2][0] : gw[2 * j + 1][0];
+                    if (e + 1 < n) B::st_gran2(p0 + e, wa, wb);
+                    else if (e < n) B::st_gran(p0 + e, wa);
                 }
             }
             pk[l] += n;
@@ -720,10 +735,26 @@ SZH_HD void szh_tile_fill(const szh_qargs<T> &a, int TI, int TJ, const szh_tile_
                 if (avail > room) avail = room;
             }
             int n = avail - fk[l]; if (n > KF) n = KF; if (n < 0) n = 0;
-            SZH_UNROLL
-            for (int e = 0; e < KF; ++e) {
+            // 16-byte loads (two granules) wherever possible, see STORE
+            if (NW == 2) {
                 SZH_UNROLL
-                for (int w = 0; w < NW; ++w) g[e][w][l] = e < n ? B::ld_gran(src[l] + (int64_t)(fk[l] + e) * NW + w) : 0;
+                for (int e = 0; e < KF; ++e) {
+                    szh_u64 wa = 0, wb = 0;
+                    if (e < n) B::ld_gran2(src[l] + (int64_t)(fk[l] + e) * 2, wa, wb);
+                    g[e][0][l] = wa; g[e][NW - 1][l] = wb;
+                }
+            } else {
+                const szh_u64 *const p0 = src[l] + fk[l];
+                const int odd = (int)(((uintptr_t)p0 >> 3) & 1);
+                szh_u64 q[KF + 2];                                           // granules p0 - odd ... (pairs at 16-byte boundaries)
+                SZH_UNROLL
+                for (int j = 0; j <= KF / 2; ++j) {
+                    szh_u64 wa = 0, wb = 0;
+                    if (n > 0 && 2 * j - odd < n && (j < KF / 2 || odd)) B::ld_gran2(p0 - odd + 2 * j, wa, wb);
+                    q[2 * j] = wa; q[2 * j + 1] = wb;
+                }
+                SZH_UNROLL
+                for (int e = 0; e < KF; ++e) g[e][0][l] = e < n ? (odd ? q[e + 1] : q[e]) : 0;
             }
             int lead = 0; bool run = true;
             SZH_UNROLL

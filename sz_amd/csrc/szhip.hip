@@ -132,8 +132,8 @@ int prepare_pencil(szhip_ctx *ctx, const szh_geom3 &G, int nw, int tpi, int tpj,
     const int nI = (G.g0.count + 7) / 8, nJ = (G.g1.count + 7) / 8;
     if (nI > 65535 || nJ > 65535) FAIL(SZHIP_ERR_UNSUP, "dimension too large for the pencil grid");
     const size_t rowg = (size_t)G.g2.count * nw * sizeof(u64);
-    TRY(ensure(ctx, ctx->faceI, (size_t)nI * nJ * 9 * rowg, true));
-    TRY(ensure(ctx, ctx->faceJ, (size_t)nI * nJ * 8 * rowg, true));
+    TRY(ensure(ctx, ctx->faceI, (size_t)nI * nJ * 9 * rowg + 64, true));   // + 64: a 16-byte granule pair may reach one granule past a row's end
+    TRY(ensure(ctx, ctx->faceJ, (size_t)nI * nJ * 8 * rowg + 64, true));
     TRY(ensure(ctx, ctx->progress, (size_t)nI * nJ * 2 * sizeof(u64), true));
     if (tune_int("SZ_HIP_TRACE", 0)) TRY(ensure(ctx, ctx->trace, ((size_t)nI * nJ * 8 + 256) * sizeof(u64), true));
     const int nTI = (nI + tpi - 1) / tpi, nTJ = (nJ + tpj - 1) / tpj;

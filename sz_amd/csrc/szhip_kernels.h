@@ -134,6 +134,24 @@ struct GpuBackend {
         return __hip_atomic_load(const_cast<szh_u64 *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __device__ static void st_gran(szh_u64 *p, szh_u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    // two neighbouring granules at a 16-byte boundary in one access (volatile 16-byte vector = `sc0 sc1`: L1 bypassed on loads, written
+    // through and not kept in L2 on stores, like the agent-scope forms above; each 8-byte half is read and written whole)
+#ifdef SZH_HIPSIM
+    __device__ static void st_gran2(szh_u64 *p, szh_u64 a, szh_u64 b) { st_gran(p, a); st_gran(p + 1, b); }
+    __device__ static void ld_gran2(const szh_u64 *p, szh_u64 &a, szh_u64 &b) { a = ld_gran(p); b = ld_gran(p + 1); }
+#else
+    typedef unsigned int v4u_ __attribute__((ext_vector_type(4)));
+    __device__ static void st_gran2(szh_u64 *p, szh_u64 a, szh_u64 b)
+    {
+        v4u_ v; v.x = (unsigned)a; v.y = (unsigned)(a >> 32); v.z = (unsigned)b; v.w = (unsigned)(b >> 32);
+        *(volatile __attribute__((address_space(1))) v4u_ *)p = v;
+    }
+    __device__ static void ld_gran2(const szh_u64 *p, szh_u64 &a, szh_u64 &b)
+    {
+        const v4u_ v = *(const volatile __attribute__((address_space(1))) v4u_ *)p;
+        a = ((szh_u64)v.y << 32) | v.x; b = ((szh_u64)v.w << 32) | v.z;
+    }
+#endif
     __device__ static unsigned ld_flag(const unsigned *p) { return __hip_atomic_load(const_cast<unsigned *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     __device__ static void st_flag(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     __device__ static void backoff(int n) { for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(2); }

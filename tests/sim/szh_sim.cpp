@@ -33,6 +33,8 @@ struct SimBackend {
     static bool all(const bool (&p)[64]) { for (int l = 0; l < 64; ++l) if (!p[l]) return false; return true; }
     static szh_u64 ld_gran(const szh_u64 *p) { return *p; }
     static void st_gran(szh_u64 *p, szh_u64 v) { *p = v; }
+    static void st_gran2(szh_u64 *p, szh_u64 a, szh_u64 b) { st_gran(p, a); st_gran(p + 1, b); }
+    static void ld_gran2(const szh_u64 *p, szh_u64 &a, szh_u64 &b) { a = ld_gran(p); b = ld_gran(p + 1); }
     static unsigned ld_flag(const unsigned *p) { return *p; }
     static void st_flag(unsigned *p, unsigned v) { *p = v; }
     static void backoff(int) {}
