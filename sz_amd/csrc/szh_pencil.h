@@ -261,10 +261,19 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
     T xr[SZH_U][NL];                              // compress: originals; decompress: pre-scattered values in, reconstruction out
     const bool vec_codes = (r2 % 8) == 0;         // rows of the u16 code array are 16-byte aligned
 
+    // decompress: which columns of this lane's OWN row (row = lane, as in move_codes) hold a zero code, one bit per ring column.
+    // Only those positions need the pre-scattered value, so a lane fetches its 16 values of a trip only when one of them does.
+    unsigned zcols[NL];
+    SZH_FORL zcols[l] = 0;
     auto load_x = [&](int t0) {
         const T *src = DEC ? a.out : a.data;
         SZH_FORL {
             const int k0 = t0 - skew[l];
+            if (DEC && SZH_XC == 32) {
+                const unsigned sh = (unsigned)k0 & 31u;
+                const unsigned win = (zcols[l] >> sh) | (sh ? zcols[l] << (32u - sh) : 0u);      // bit s = column k0 + s
+                if ((win & 0xffffu) == 0) continue;                                              // no unpredictable value in this lane's trip
+            }
             if (inb[l] && k0 >= 0 && k0 + SZH_U <= r2) {
                 SZH_UNROLL
                 for (int v = 0; v < NVEC; ++v) {
@@ -317,8 +326,11 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
                     uint16_t tmp[8];
                     if (DEC) {
                         B::ld16(a.codes + off + c0, tmp);
+                        unsigned z = 0;
                         SZH_UNROLL
-                        for (int e = 0; e < 8; ++e) cring[((c0 + e) % SZH_XC) * 64 + row] = tmp[e];
+                        for (int e = 0; e < 8; ++e) { cring[((c0 + e) % SZH_XC) * 64 + row] = tmp[e]; z |= (tmp[e] == 0 ? 1u : 0u) << e; }
+                        const unsigned sh = (unsigned)c0 & 31u;                                   // c0 is a multiple of 8: the byte of the mask
+                        zcols[l] = (zcols[l] & ~(0xffu << sh)) | (z << sh);
                     } else {
                         SZH_UNROLL
                         for (int e = 0; e < 8; ++e) tmp[e] = cring[((c0 + e) % SZH_XC) * 64 + row];
@@ -338,6 +350,7 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
                     }
                 }
             }
+            if (DEC) { SZH_FORL zcols[l] |= 0xffu << ((unsigned)c0 & 31u); }   // ragged rows: treat the group as "may hold zeros"
         }
     };
     // bounded wait until an LDS counter reaches `need`; returns the value seen.  A lost hand-off ends the launch, it must not hang the GPU
