@@ -217,7 +217,7 @@ static int compress_fp(int dataType, int withRegression, unsigned char **newByte
     size_t dataLength = computeDataLength(r5, r4, r3, r2, r1);
     if (dataLength <= MIN_NUM_OF_ELEMENTS) { /* SZ_skip_compress_float, sz_float.c:37 */
         *outSize = dataLength * esz;
-        *newByteData = (unsigned char *)malloc(dataLength * esz ? dataLength * esz : 1);
+        *newByteData = (unsigned char *)malloc(dataLength * esz != 0 ? dataLength * esz : 1);
         memcpy(*newByteData, oriData, dataLength * esz);
         return SZ_SCES;
     }
@@ -413,7 +413,7 @@ static void *decompress_fp(int dataType, unsigned char *cmpBytes, size_t cmpSize
         }
     }
     if (dataLength <= MIN_NUM_OF_ELEMENTS) { /* raw copy written by SZ_skip_compress */
-        void *o = malloc(dataLength * esz ? dataLength * esz : 1);
+        void *o = malloc(dataLength * esz != 0 ? dataLength * esz : 1);
         memcpy(o, sz, dataLength * esz);
         if (owned) free(sz);
         return o;

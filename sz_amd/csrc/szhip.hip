@@ -682,7 +682,6 @@ template <class T>
 int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_on_device, size_t stream_len, size_t body_off,
                     size_t r0, size_t r1, size_t r2, void *out, int out_on_device, szhip_stats *stats)
 {
-    const int is_double = sizeof(T) == 8;
     const szh_geom3 G = r0 == 0 ? szh_make_geom2((int)r1, (int)r2) : szh_make_geom3((int)r0, (int)r1, (int)r2);
     const int64_t n = G.n, nb = G.nblocks;
     const double t_begin = now_ms();
