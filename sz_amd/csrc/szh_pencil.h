@@ -709,7 +709,7 @@ SZH_HD void szh_tile_fill(const szh_qargs<T> &a, int TI, int TJ, const szh_tile_
 {
     constexpr int NL = B::NL;
     constexpr int NW = szh_gran<T>::NW;
-    constexpr int KF = 16;                      // columns per row per round
+    constexpr int KF = sizeof(T) == 8 ? 16 : 8;   // (measured: 8 for float, 16 for double)                     // columns per row per round
     const int r0 = a.G.g0.count, r1 = a.G.g1.count, r2 = a.G.g2.count;
     const int stride = B::face_stride(r2);
     int fk[NL], cslot[NL], wbase[NL];
