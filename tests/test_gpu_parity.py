@@ -101,6 +101,25 @@ def test_edge_cases_constant_tiny_raw(sz, oracle):
     assert s == oracle.compress(noise, oracle.ABS, 1e-7)[0] and np.array_equal(sz.SZ_decompress(s, noise.shape, np.float32), noise)
 
 
+def test_psnr_and_norm_modes_identical_to_oracle(sz, oracle):
+    """errorBoundMode PSNR and NORM are turned into an absolute bound on the host (conf.c:54-65); the streams record the effective
+    ABS mode.  Same bytes and same decoded values as the oracle."""
+    from sz_amd.fields import m_field, s_field
+    cp = sz.conf_params()
+    saved = (cp.psnr, cp.normErr)
+    try:
+        for name, d, mode, psnr, norm in (("psnr-80", s_field(24, 32, 40), sz.PSNR, 80.0, 0.0), ("psnr-60-f64", m_field(32, np.float64), sz.PSNR, 60.0, 0.0),
+                                          ("norm", s_field(30, 30, 30), sz.NORM, 0.0, 0.05)):
+            cp.psnr, cp.normErr = psnr, norm
+            ref, _ = oracle.compress(d, mode, 0.0, 0.0, params=oracle.default_params(psnr=psnr, norm_err=norm))
+            got = sz.SZ_compress_args(d, mode, 0.0, 0.0)
+            assert got == ref, name
+            dec = sz.SZ_decompress(ref, d.shape, d.dtype)
+            assert np.array_equal(dec.view(np.uint8), oracle.decompress(ref, d.shape, d.dtype).view(np.uint8)), name
+    finally:
+        cp.psnr, cp.normErr = saved
+
+
 def test_unsupported_calls_fail_loudly(sz):
     import sz_amd
     with pytest.raises(sz_amd.SZError):
