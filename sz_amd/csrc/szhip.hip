@@ -38,6 +38,7 @@ struct szhip_ctx {
         col_off, partial, samples, unpred, stream_buf, chunk_bits, chunk_off, code_tab, len_tab, dec_tab,
         starts, ends, counts, offs, dirty;
     void *pinned = nullptr; size_t pinned_cap = 0;
+    void *pinned2 = nullptr; size_t pinned2_cap = 0;   // target of the second stream's copies (indicator bits, regression-block count)
     int order_nI = -1, order_nJ = -1;
 };
 
@@ -79,6 +80,16 @@ int ensure_pinned(szhip_ctx *ctx, size_t bytes)
     size_t cap = bytes + bytes / 4 + 4096;
     HIPCHK(hipHostMalloc(&ctx->pinned, cap, hipHostMallocDefault));
     ctx->pinned_cap = cap;
+    return SZHIP_OK;
+}
+
+int ensure_pinned2(szhip_ctx *ctx, size_t bytes)
+{
+    if (ctx->pinned2_cap >= bytes) return SZHIP_OK;
+    if (ctx->pinned2) { HIPCHK(hipStreamSynchronize(ctx->stream2)); HIPCHK(hipHostFree(ctx->pinned2)); ctx->pinned2 = nullptr; ctx->pinned2_cap = 0; }
+    size_t cap = bytes + bytes / 4 + 4096;
+    HIPCHK(hipHostMalloc(&ctx->pinned2, cap, hipHostMallocDefault));
+    ctx->pinned2_cap = cap;
     return SZHIP_OK;
 }
 
@@ -228,6 +239,18 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     hipLaunchKernelGGL((k_fit_select<T>), dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, ctx->stream2,
                        G, d_in, d_coef, d_lor, noise, 0, (T)0, sm + SM_MINMAX);
     HIPCHK(hipGetLastError());
+    // the stream's indicator bit array and the regression-block count come from the device (no per-block host loop); they follow the
+    // speculative pass on the second stream, so that they are on the host by the time the interval decision is made
+    const size_t ind_bytes = ((size_t)nb + 7) / 8;
+    TRY(ensure(ctx, ctx->lor_bits, ind_bytes + 8));
+    TRY(ensure_pinned2(ctx, ind_bytes + 16));                   // pinned: the copies below must not block this thread
+    unsigned char *const ind_bits = (unsigned char *)ctx->pinned2 + 16;
+    u64 *const nreg_h = (u64 *)ctx->pinned2;
+    hipLaunchKernelGGL(k_pack_lor, dim3((unsigned)((ind_bytes + 255) / 256)), dim3(256), 0, ctx->stream2, (const uint8_t *)d_lor, nb,
+                       (uint8_t *)ctx->lor_bits.p, sm + SM_NREG);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(ind_bits, ctx->lor_bits.p, ind_bytes, hipMemcpyDeviceToHost, ctx->stream2));
+    HIPCHK(hipMemcpyAsync(nreg_h, sm + SM_NREG, 8, hipMemcpyDeviceToHost, ctx->stream2));
     HIPCHK(hipEventRecord(ctx->ev_fit, ctx->stream2));
 
     // ---- interval optimiser
@@ -298,18 +321,16 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
                            G, d_in, d_coef, d_lor, noise, use_mean, mean, sm + SM_MINMAX);
         HIPCHK(hipGetLastError());
     }
-    // the stream's indicator bit array and the regression-block count come from the device (no per-block host loop)
-    const size_t ind_bytes = ((size_t)nb + 7) / 8;
-    TRY(ensure(ctx, ctx->lor_bits, ind_bytes + 8));
-    hipLaunchKernelGGL(k_pack_lor, dim3((unsigned)((ind_bytes + 255) / 256)), dim3(256), 0, st, (const uint8_t *)d_lor, nb,
-                       (uint8_t *)ctx->lor_bits.p, sm + SM_NREG);
-    HIPCHK(hipGetLastError());
-    std::vector<unsigned char> ind_bits(ind_bytes);
-    u64 nreg64 = 0;
-    HIPCHK(hipMemcpyAsync(ind_bits.data(), ctx->lor_bits.p, ind_bytes, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&nreg64, sm + SM_NREG, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    const size_t reg_count = (size_t)nreg64;
+    if (use_mean) {                                            // (the repeated pass: its indicator bits replace the speculative ones)
+        HIPCHK(hipMemsetAsync(sm + SM_NREG, 0, 8, st));
+        hipLaunchKernelGGL(k_pack_lor, dim3((unsigned)((ind_bytes + 255) / 256)), dim3(256), 0, st, (const uint8_t *)d_lor, nb,
+                           (uint8_t *)ctx->lor_bits.p, sm + SM_NREG);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(ind_bits, ctx->lor_bits.p, ind_bytes, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(nreg_h, sm + SM_NREG, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    } else HIPCHK(hipEventSynchronize(ctx->ev_fit));           // usually long done
+    const size_t reg_count = (size_t)*nreg_h;
     S.n_reg_blocks = reg_count;
     // ---- regression coefficient chain (serial, host) and its Huffman streams
     szhost_coeffs cf; memset(&cf, 0, sizeof(cf));
@@ -461,7 +482,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         szhost_huff_tree_write(hf, q); q += tree_bytes;
         *q++ = (unsigned char)use_mean;
         memcpy(q, &mean, sizeof(T)); q += sizeof(T);
-        memcpy(q, ind_bits.data(), ind_bytes); q += ind_bytes;
+        memcpy(q, ind_bits, ind_bytes); q += ind_bytes;
         if (!coef_sections.empty()) { memcpy(q, coef_sections.data(), coef_sections.size()); q += coef_sections.size(); }
         const uint64_t tu = total_unpred; memcpy(q, &tu, 8); q += 8;
     }
@@ -1258,6 +1279,7 @@ void szhip_destroy(szhip_ctx *ctx)
                       &ctx->len_tab, &ctx->dec_tab, &ctx->starts, &ctx->ends, &ctx->counts, &ctx->offs, &ctx->dirty};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
     if (ctx->pinned) hipHostFree(ctx->pinned);
+    if (ctx->pinned2) hipHostFree(ctx->pinned2);
     for (int i = 0; i < 6; ++i) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
     if (ctx->ev_in) hipEventDestroy(ctx->ev_in);
     if (ctx->ev_fit) hipEventDestroy(ctx->ev_fit);
