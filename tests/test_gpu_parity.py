@@ -369,6 +369,41 @@ def test_corrupt_streams_fail_cleanly(sz, oracle):
     assert sz.SZ_compress_args(d, sz.ABS, 1e-4) == good  # ... and the library is still healthy afterwards
 
 
+def test_corrupt_sz14_streams_fail_cleanly(sz14, oracle):
+    """The same for the SZ 1.4 container: truncation, damaged size fields (type array, exact-value count, mid-byte count), damaged
+    tree, damaged lead / mid / residual sections -- an error or finite garbage, never a hang or a crash."""
+    sz, p = sz14
+    from sz_amd.fields import s_field
+    rng = np.random.default_rng(4)
+    d = s_field(24, 32, 40) + (rng.random((24, 32, 40)).astype(np.float32) - np.float32(0.5)) * np.float32(3e-4)
+    good = sz.SZ_compress_args(d, sz.ABS, 1e-5)
+    assert good == oracle.compress(d, oracle.ABS, 1e-5, params=p)[0]
+    outcomes = {"error": 0, "decoded": 0}
+
+    def attempt(blob):
+        try:
+            out = sz.SZ_decompress(bytes(blob), d.shape, d.dtype)
+            assert out.shape == d.shape
+            outcomes["decoded"] += 1
+        except sz.SZError:
+            outcomes["error"] += 1
+
+    for cut in (0, 3, 17, 40, 44, 60, 77, 200, len(good) // 2, len(good) - 1):
+        attempt(good[:cut])
+    body = 4 + 28 + 8
+    for off in list(range(body, body + 4 + 4 + 4 + 1 + 8 + 24 + 8)) + [body + 60, body + 100, body + 300]:
+        for val in (0x00, 0xff, 0x7f):
+            blob = bytearray(good); blob[off] = val
+            attempt(blob)
+    for _ in range(60):
+        blob = bytearray(good)
+        for _ in range(int(rng.integers(1, 6))):
+            blob[int(rng.integers(4, len(blob)))] = int(rng.integers(0, 256))
+        attempt(blob)
+    assert outcomes["error"] > 20
+    assert sz.SZ_compress_args(d, sz.ABS, 1e-5) == good
+
+
 def test_differential_fuzz_against_the_oracle(built):
     """400 random small cases (shape, dtype, field kind, bound mode and size all random): stream byte-identical and decode
     bit-identical to the oracle.  (7 500 cases were run once in development; tools/gpu_fuzz.py prints the failing seeds.)"""
