@@ -176,10 +176,12 @@ struct GpuBackend {
     __device__ static void nap() { __builtin_amdgcn_s_sleep(40); } // ~1 us
 };
 
-// tile shape by element type: TPI x TPJ COMPUTE wavefronts + STORE + FILL per workgroup.  float: 14 wavefronts (<= 128 VGPRs
-// each) fill most of a CU; double needs twice the registers, so half the wavefronts
+// tile shape by element type: TPI x TPJ COMPUTE wavefronts + STORE + FILL per workgroup.  Measured for float on one box, k_pencil at
+// 512^3: 3x3 and 2x4 1.57-1.61 ms, 4x3 1.68-1.69, 2x2 1.69-1.77, 3x2 1.74-1.85, 2x3 1.73-1.81 (more pencils per tile = fewer tile
+// boundaries on the longest path, but more wavefronts per CU step more slowly; 11 wavefronts also leave 170 VGPRs each).
+// double keeps its rings at 32 columns to fit the LDS
 template <class T> struct szh_tile_shape;
-template <> struct szh_tile_shape<float> { static constexpr int TPI = 4, TPJ = 3, RL = 64; };
+template <> struct szh_tile_shape<float> { static constexpr int TPI = 3, TPJ = 3, RL = 64; };
 template <> struct szh_tile_shape<double> { static constexpr int TPI = 3, TPJ = 3, RL = 32; };
 
 template <class T, bool DEC>
