@@ -40,15 +40,15 @@ for i in range(min(40, (n + 14 + 15) // 16)):
     if r[0] == 0: break
     print("  trip %2d: top->step0 %.2f  steps %.2f  flush %.2f   (top at %.1f)" % (i, (r[1]-r[0])/100, (r[2]-r[1])/100, (r[3]-r[2])/100, us(r[0])))
 
-# tile view (float tiles are 4 x 3 pencils): first-trip-end and end times of the pencils of the tile holding pencil (32,33)
+# tile view (float tiles are 3 x 3 pencils): first-trip-end and end times of the pencils of the tile holding pencil (32,33)
 if n == 512:
-    I0, J0 = 32, 33
+    I0, J0 = 33, 33
     print("tile at pencil (%d,%d): first_trip end (us) per pencil [pi][pj]  |  pencil end" % (I0, J0))
-    for pi in range(4): print("   ", " ".join("%7.1f" % us(tr[I0 + pi, J0 + pj, 2]) for pj in range(3)), "  |  ", " ".join("%7.1f" % us(tr[I0 + pi, J0 + pj, 3]) for pj in range(3)))
-    print("first_trip of the first pencils of the next tiles: right (%d,%d) %.1f ; below (%d,%d) %.1f" % (I0, J0 + 3, us(tr[I0, J0 + 3, 2]), I0 + 4, J0, us(tr[I0 + 4, J0, 2])))
+    for pi in range(3): print("   ", " ".join("%7.1f" % us(tr[I0 + pi, J0 + pj, 2]) for pj in range(3)), "  |  ", " ".join("%7.1f" % us(tr[I0 + pi, J0 + pj, 3]) for pj in range(3)))
+    print("first_trip of the first pencils of the next tiles: right (%d,%d) %.1f ; below (%d,%d) %.1f" % (I0, J0 + 3, us(tr[I0, J0 + 3, 2]), I0 + 3, J0, us(tr[I0 + 3, J0, 2])))
 
 if n == 512:
     print("waits (us) per pencil of that tile: J-producer | I-producer | ring space")
-    for pi in range(4): print("   ", "  ".join("%6.0f %6.0f %5.0f" % (tr[I0 + pi, J0 + pj, 4] / 100, tr[I0 + pi, J0 + pj, 5] / 100, tr[I0 + pi, J0 + pj, 7] / 100) for pj in range(3)))
+    for pi in range(3): print("   ", "  ".join("%6.0f %6.0f %5.0f" % (tr[I0 + pi, J0 + pj, 4] / 100, tr[I0 + pi, J0 + pj, 5] / 100, tr[I0 + pi, J0 + pj, 7] / 100) for pj in range(3)))
     w = tr[..., 4] + tr[..., 5]; 
     print("all pencils: median wait on producers %.0f us, on ring space %.0f us; pencil (0,0) %.0f" % (np.median(w) / 100, np.median(tr[..., 7]) / 100, w[0, 0] / 100))
