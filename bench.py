@@ -72,6 +72,10 @@ def main():
     ctx = sz_amd.HipContext(local_rank)
     out_cap = nbytes_in // 2 + (1 << 20)
     out_buf = torch.empty(out_cap, dtype=torch.uint8, device=dev)
+    # N > 1: the all-gather of step k's sub-streams runs while step k+1 compresses (RCCL on its own stream; the payload travels
+    # from a private copy).  All gathers are completed inside the timed region.
+    gather = slab.StreamGather() if world > 1 else None
+    pending = []
 
     import ctypes
 
@@ -85,8 +89,17 @@ def main():
         if rc:
             raise RuntimeError(f"szhip_compress failed: {sz_amd.lib().szhip_last_error(ctx._h)}")
         if world > 1:
-            slab.allgather_streams(out_buf, nn.value)
+            if os.environ.get("SZ_BENCH_SYNC_GATHER"):          # fallback: the plain, non-overlapped all-gather
+                slab.allgather_streams(out_buf, nn.value)
+            else:
+                pending.append(gather.begin(out_buf, nn.value))
+                if len(pending) > 1:
+                    slab.StreamGather.end(pending.pop(0))
         return nn.value, st
+
+    def drain():
+        while pending:
+            slab.StreamGather.end(pending.pop(0))
 
     def sync_all():
         torch.cuda.synchronize()
@@ -96,12 +109,14 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
+    drain()
     sync_all()
     t0 = time.perf_counter()
     quant_ms, stats = [], None
     for _ in range(args.steps):
         size, stats = one_step()
         quant_ms.append(stats.ms_quant)
+    drain()
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:

@@ -84,3 +84,45 @@ def allgather_streams(local_stream, nbytes=None):
     recv = torch.empty(world * cap, dtype=torch.uint8, device=dev)
     dist.all_gather_into_tensor(recv, send)
     return [recv[r * cap:r * cap + sizes[r]] for r in range(world)], sizes
+
+
+class StreamGather:
+    """The same all-gather, overlapped with the next compression step: begin() launches the gather of this step's sub-stream
+    and returns; end() completes one.  The payload travels from a private copy, so the caller's buffer may be overwritten as
+    soon as begin() returns; two gathers may be in flight (two sets of buffers)."""
+
+    def __init__(self, depth=2):
+        self.depth = depth
+        self.send = [None] * depth
+        self.recv = [None] * depth
+        self.slot = 0
+
+    def begin(self, local_stream, nbytes):
+        import torch
+        import torch.distributed as dist
+        n = int(nbytes)
+        world = dist.get_world_size()
+        dev = local_stream.device
+        sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(sizes, torch.tensor([n], dtype=torch.int64, device=dev))
+        sizes = [int(x) for x in sizes.tolist()]
+        cap = (max(sizes) + 255) // 256 * 256
+        k = self.slot
+        self.slot = (self.slot + 1) % self.depth
+        if self.send[k] is None or self.send[k].numel() < cap:
+            self.send[k] = torch.empty(cap + cap // 4, dtype=torch.uint8, device=dev)
+            self.recv[k] = torch.empty(world * (cap + cap // 4), dtype=torch.uint8, device=dev)
+        send = self.send[k][:cap]
+        send[:n] = local_stream[:n]
+        if send.is_cuda:
+            torch.cuda.current_stream(dev).synchronize()   # the copy is done before the caller reuses local_stream (its producer
+                                                           # runs on a stream of its own)
+        recv = self.recv[k][:world * cap]
+        work = dist.all_gather_into_tensor(recv, send, async_op=True)
+        return (work, recv, sizes, cap)
+
+    @staticmethod
+    def end(handle):
+        work, recv, sizes, cap = handle
+        work.wait()
+        return [recv[r * cap:r * cap + sizes[r]] for r in range(len(sizes))], sizes

@@ -29,6 +29,13 @@ def _worker(rank, world, port, ret):
     stream, _ = O.compress(mine, O.ABS, eb)
     t = torch.frombuffer(bytearray(stream), dtype=torch.uint8)
     parts, sizes = slab.allgather_streams(t)
+    # the overlapped form used by bench.py for N > 1: two gathers in flight, completed in order, same result
+    sg = slab.StreamGather()
+    t2 = torch.frombuffer(bytearray(stream[::-1]), dtype=torch.uint8)
+    h1 = sg.begin(t, len(stream)); h2 = sg.begin(t2, len(stream))
+    p1, s1 = slab.StreamGather.end(h1); p2, s2 = slab.StreamGather.end(h2)
+    assert s1 == sizes and s2 == sizes and all(bytes(a.numpy().tobytes()) == bytes(b.numpy().tobytes()) for a, b in zip(p1, parts))
+    assert bytes(p2[rank].numpy().tobytes()) == stream[::-1]
     blob = slab.pack_container(np.float64, dims, bounds, [bytes(p.numpy().tobytes()) for p in parts])
     if rank == 0:
         ret["blob"] = blob; ret["range"] = (lo, hi); ret["sizes"] = sizes
