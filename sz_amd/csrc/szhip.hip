@@ -1159,6 +1159,7 @@ int decompress14_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream
     if (!(eb > 0)) FAIL(SZHIP_ERR_STREAM, "bad error bound");
     const int req_bytes = req_len / 8, resi_bits = req_len % 8;
     const size_t lead_size = (size_t)((E * 2 + 7) / 8), resi_size = resi_bits ? (size_t)((E * (uint64_t)resi_bits + 7) / 8) : 0;
+    if (E >= ((uint64_t)1 << 32)) FAIL(SZHIP_ERR_UNSUP, "more than 2^32 exact values");   // the prefix counts of k_exact_* are packed in 32-bit halves
     if (E > (uint64_t)n || type_size < 8 || type_size > stream_len || nmid > stream_len ||
         type_off + type_size + lead_size + nmid + resi_size > stream_len) FAIL(SZHIP_ERR_STREAM, "truncated stream");
     const int node_count = (int)szhost_get_u32be(q);
