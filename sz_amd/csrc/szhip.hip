@@ -582,6 +582,7 @@ int huff_decode_device(szhip_ctx *ctx, u64 *sm, const unsigned char *d_bits, u64
             HIPCHK(hipMemsetAsync(sm + SM_CHANGED, 0, 8, st));
             hipLaunchKernelGGL(k_hdec_update, dim3(gsub), dim3(256), 0, st, a);
             HIPCHK(hipGetLastError());
+            if (iter == 0 && nsub > 1) { ++iter; continue; }     // the first propagation always moves guesses: no need to ask
             unsigned changed = 0;
             HIPCHK(hipMemcpyAsync(&changed, sm + SM_CHANGED, 4, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
