@@ -554,8 +554,11 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
 // Huffman decode of `n` symbols on the device (self-synchronising sub-sequence decode, k_hdec_*): `d_bits` points at the payload,
 // `dtab` is the host-built decode table of the tree, `single_symbol` >= 0 for the one-leaf tree (zero payload bits).
 int huff_decode_device(szhip_ctx *ctx, u64 *sm, const unsigned char *d_bits, u64 total_bits, const std::vector<uint32_t> &dtab, int n_nodes,
-                       int single_symbol, int64_t n, uint16_t *d_out_codes)
+                       int single_symbol, int64_t n, uint16_t *d_out_codes, u64 *total_sym_host)
 {
+    // *total_sym_host receives the number of symbols the payload holds ASYNCHRONOUSLY: the caller compares it with n after its next
+    // synchronisation of the stream (the write pass below never stores beyond n, so a short payload is harmless until then)
+    *total_sym_host = (u64)n;
     hipStream_t st = ctx->stream;
     if (single_symbol >= 0) {
         hipLaunchKernelGGL(k_fill_u16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_out_codes, n, (uint16_t)single_symbol);
@@ -590,10 +593,7 @@ int huff_decode_device(szhip_ctx *ctx, u64 *sm, const unsigned char *d_bits, u64
             if (++iter > nsub + 2) FAIL(SZHIP_ERR_INTERNAL, "Huffman decode did not converge");
         }
         TRY(scan_u64(ctx, (const u64 *)ctx->counts.p, nsub, (u64 *)ctx->offs.p, sm + SM_TOTAL_SYM));
-        u64 total_sym = 0;
-        HIPCHK(hipMemcpyAsync(&total_sym, sm + SM_TOTAL_SYM, 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        if ((int64_t)total_sym < n) FAIL(SZHIP_ERR_STREAM, "Huffman payload holds %llu symbols, need %lld", (unsigned long long)total_sym, (long long)n);
+        HIPCHK(hipMemcpyAsync(total_sym_host, sm + SM_TOTAL_SYM, 8, hipMemcpyDeviceToHost, st));
         hipLaunchKernelGGL(k_hdec_write, dim3(gsub), dim3(256), lds, st, a, (const u64 *)ctx->offs.p, d_out_codes, n);
         HIPCHK(hipGetLastError());
     }
@@ -763,7 +763,8 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
     uint16_t *d_nat = (uint16_t *)ctx->codes_nat.p, *d_blk = (uint16_t *)ctx->codes_blk.p;
 
     // ---- Huffman decode of the type array
-    TRY(huff_decode_device(ctx, sm, d_stream + pay_off, total_bits, dtab, n_nodes, single_symbol, n, d_blk));
+    u64 total_sym = 0;
+    TRY(huff_decode_device(ctx, sm, d_stream + pay_off, total_bits, dtab, n_nodes, single_symbol, n, d_blk, &total_sym));
 
     // ---- natural order, unpredictable values into the output array
     const int ncols = G.g0.num * G.g1.num;
@@ -784,6 +785,7 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
     u64 zeros_found = 0;
     HIPCHK(hipMemcpyAsync(&zeros_found, sm + SM_TOTAL_UNPRED, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    if ((int64_t)total_sym < n) FAIL(SZHIP_ERR_STREAM, "Huffman payload holds %llu symbols, need %lld", (unsigned long long)total_sym, (long long)n);
     if (zeros_found != total_unpred) FAIL(SZHIP_ERR_STREAM, "stream lists %llu unpredictable values, codes need %llu",
                                           (unsigned long long)total_unpred, (unsigned long long)zeros_found);
     T *d_out = (T *)out;
@@ -1184,7 +1186,8 @@ int decompress14_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream
     HIPCHK(hipMemsetAsync(sm, 0, SM_COUNT * 8, st));
     TRY(ensure(ctx, ctx->codes_nat, (size_t)n * 2 + 64));
     uint16_t *d_codes = (uint16_t *)ctx->codes_nat.p;
-    TRY(huff_decode_device(ctx, sm, d_stream + pay_off, total_bits, dtab, n_nodes, single_symbol, n, d_codes));
+    u64 total_sym = 0;
+    TRY(huff_decode_device(ctx, sm, d_stream + pay_off, total_bits, dtab, n_nodes, single_symbol, n, d_codes, &total_sym));
 
     // ---- exact values back into the output array
     const int64_t nlin = (n + SZH_LIN_CHUNK - 1) / SZH_LIN_CHUNK;
@@ -1195,6 +1198,7 @@ int decompress14_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream
     u64 zeros_found = 0;
     HIPCHK(hipMemcpyAsync(&zeros_found, sm + SM_TOTAL_UNPRED, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    if ((int64_t)total_sym < n) FAIL(SZHIP_ERR_STREAM, "Huffman payload holds %llu symbols, need %lld", (unsigned long long)total_sym, (long long)n);
     if (zeros_found != E) FAIL(SZHIP_ERR_STREAM, "stream lists %llu exact values, codes need %llu", (unsigned long long)E, (unsigned long long)zeros_found);
     T *d_out = (T *)out;
     if (!out_on_device) { TRY(ensure(ctx, ctx->out, (size_t)n * sizeof(T))); d_out = (T *)ctx->out.p; }
