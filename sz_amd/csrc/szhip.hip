@@ -521,6 +521,8 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(ctx->ev[4], st));
+    u64 tb = 0;                                                // the shuffled bit count, checked after the synchronisation below
+    if (total_bits > 0) HIPCHK(hipMemcpyAsync(&tb, sm + SM_TOTAL_BITS, 8, hipMemcpyDeviceToHost, st));
     if (out_on_device == 2) { // caller-provided device buffer of capacity *out_size
         if (!*out || *out_size < total_len) FAIL(SZHIP_ERR_ARG, "caller's device buffer too small (%zu < %zu)", *out_size, total_len);
         HIPCHK(hipMemcpyAsync(*out, d_stream, total_len, hipMemcpyDeviceToDevice, st));
@@ -538,8 +540,6 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     *out_size = total_len;
     // the shuffled bit count must match what the code book predicted
     {
-        u64 tb = 0;
-        if (total_bits > 0) { HIPCHK(hipMemcpy(&tb, sm + SM_TOTAL_BITS, 8, hipMemcpyDeviceToHost)); }
         if (tb != total_bits) FAIL(SZHIP_ERR_INTERNAL, "encoded bit count mismatch (%llu vs %llu)", (unsigned long long)tb, (unsigned long long)total_bits);
     }
     float ms = 0;
