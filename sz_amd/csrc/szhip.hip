@@ -36,7 +36,7 @@ struct szhip_ctx {
     // workspaces (grow-only)
     DevBuf lor_bits, reg_flags, reg_rank, coef_compact, in, out, codes_nat, codes_blk, coef, blk_lor, faceI, faceJ, progress, trace, order, small, hist, col_zeros, col_zeros64,
         col_off, partial, samples, unpred, stream_buf, chunk_bits, chunk_off, code_tab, len_tab, dec_tab,
-        starts, ends, counts, offs, dirty;
+        starts, ends, counts, offs, dirty, zcnt, zpos;
     void *pinned = nullptr; size_t pinned_cap = 0;
     void *pinned2 = nullptr; size_t pinned2_cap = 0;   // target of the second stream's copies (indicator bits, regression-block count)
     int order_nI = -1, order_nJ = -1;
@@ -436,11 +436,15 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     TRY(ensure(ctx, ctx->col_zeros64, (size_t)ncols * 8));
     TRY(ensure(ctx, ctx->col_off, (size_t)ncols * 8));
     HIPCHK(hipMemsetAsync(ctx->col_zeros.p, 0, (size_t)ncols * 4, st));
+    int perm_segb = 1, perm_nseg = 1;
     {
         const int segb = choose_segb(G, 2, 32 * 1024);
         const int nseg = (G.g2.num + segb - 1) / segb;
+        TRY(ensure(ctx, ctx->zcnt, (size_t)ncols * nseg * 4));
+        TRY(ensure(ctx, ctx->zpos, (size_t)ncols * nseg * SZH_ZCAP * 4));
         hipLaunchKernelGGL((k_permute<0>), dim3(ncols, nseg), dim3(256), tile_bytes(G, segb, 2), st, G, (const uint16_t *)d_nat,
-                           d_blk, (unsigned *)ctx->col_zeros.p, segb);
+                           d_blk, (unsigned *)ctx->col_zeros.p, segb, (unsigned *)ctx->zcnt.p, (unsigned *)ctx->zpos.p);
+        perm_segb = segb; perm_nseg = nseg;
         HIPCHK(hipGetLastError());
     }
     hipLaunchKernelGGL(k_u32_to_u64, dim3((ncols + 255) / 256), dim3(256), 0, st, (const unsigned *)ctx->col_zeros.p, (int64_t)ncols,
@@ -504,7 +508,8 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     if (total_unpred > 0) {
         TRY(ensure(ctx, ctx->unpred, unpred_bytes));
         hipLaunchKernelGGL((k_unpred<T, 0>), dim3(ncols), dim3(256), 0, st, G, (const uint16_t *)d_blk, (const unsigned *)ctx->col_zeros.p,
-                           (const u64 *)ctx->col_off.p, d_in, (T *)ctx->unpred.p, (T *)nullptr);
+                           (const u64 *)ctx->col_off.p, d_in, (T *)ctx->unpred.p, (T *)nullptr, (const unsigned *)ctx->zcnt.p,
+                           (const unsigned *)ctx->zpos.p, perm_segb, perm_nseg);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(d_stream + hdr_len, ctx->unpred.p, unpred_bytes, hipMemcpyDeviceToDevice, st));
     }
@@ -772,11 +777,15 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
     TRY(ensure(ctx, ctx->col_zeros64, (size_t)ncols * 8));
     TRY(ensure(ctx, ctx->col_off, (size_t)ncols * 8));
     HIPCHK(hipMemsetAsync(ctx->col_zeros.p, 0, (size_t)ncols * 4, st));
+    int perm_segb = 1, perm_nseg = 1;
     {
         const int segb = choose_segb(G, 2, 32 * 1024);
         const int nseg = (G.g2.num + segb - 1) / segb;
+        TRY(ensure(ctx, ctx->zcnt, (size_t)ncols * nseg * 4));
+        TRY(ensure(ctx, ctx->zpos, (size_t)ncols * nseg * SZH_ZCAP * 4));
         hipLaunchKernelGGL((k_permute<1>), dim3(ncols, nseg), dim3(256), tile_bytes(G, segb, 2), st, G, (const uint16_t *)d_blk, d_nat,
-                           (unsigned *)ctx->col_zeros.p, segb);
+                           (unsigned *)ctx->col_zeros.p, segb, (unsigned *)ctx->zcnt.p, (unsigned *)ctx->zpos.p);
+        perm_segb = segb; perm_nseg = nseg;
         HIPCHK(hipGetLastError());
     }
     hipLaunchKernelGGL(k_u32_to_u64, dim3((ncols + 255) / 256), dim3(256), 0, st, (const unsigned *)ctx->col_zeros.p, (int64_t)ncols,
@@ -794,7 +803,8 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
         TRY(ensure(ctx, ctx->unpred, (size_t)total_unpred * sizeof(T)));
         HIPCHK(hipMemcpyAsync(ctx->unpred.p, d_stream + unpred_off, (size_t)total_unpred * sizeof(T), hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL((k_unpred<T, 1>), dim3(ncols), dim3(256), 0, st, G, (const uint16_t *)d_blk, (const unsigned *)ctx->col_zeros.p,
-                           (const u64 *)ctx->col_off.p, (const T *)nullptr, (T *)ctx->unpred.p, d_out);
+                           (const u64 *)ctx->col_off.p, (const T *)nullptr, (T *)ctx->unpred.p, d_out, (const unsigned *)ctx->zcnt.p,
+                           (const unsigned *)ctx->zpos.p, perm_segb, perm_nseg);
         HIPCHK(hipGetLastError());
     }
     TRY(ensure(ctx, ctx->coef, (size_t)nb * 4 * sizeof(T)));

@@ -412,10 +412,16 @@ __global__ __launch_bounds__(256) void k_hist_u16(const uint16_t *__restrict__ c
 // contiguous range in block order and s0*s1 contiguous row pieces in natural order, so both sides stream.
 // DIR 0: natural -> block order (compress); DIR 1: block order -> natural (decompress).
 // col_zeros[col] += number of zero codes (unpredictable points) seen.
+// It also notes WHERE the zero codes are (segment-local block-order index, up to SZH_ZCAP per workgroup, unordered), so that
+// k_unpred does not have to read the code array again to find them.
+#define SZH_ZCAP 128
 template <int DIR>
 __global__ __launch_bounds__(256) void k_permute(szh_geom3 G, const uint16_t *__restrict__ src, uint16_t *__restrict__ dst,
-                                                 unsigned *col_zeros, int segb)
+                                                 unsigned *col_zeros, int segb, unsigned *zcnt, unsigned *zpos)
 {
+    __shared__ unsigned zc_s, zp_s[SZH_ZCAP];
+    if (threadIdx.x == 0) zc_s = 0;
+    __syncthreads();
     SZH_DYN_SMEM(smem);
     uint16_t *tile = reinterpret_cast<uint16_t *>(smem);
     const int col = blockIdx.x, b0 = col / G.g1.num, b1 = col - b0 * G.g1.num;
@@ -466,8 +472,8 @@ __global__ __launch_bounds__(256) void k_permute(szh_geom3 G, const uint16_t *__
             }
             for (int e = elo; e < ehi; ++e) {
                 const int ti = row * kp + kshift + koff + kk;
-                if (DIR == 0) { v[e - e0] = tile[ti]; zeros += (v[e - e0] == 0); }
-                else { tile[ti] = v[e - e0]; zeros += (v[e - e0] == 0); }
+                if (DIR == 0) v[e - e0] = tile[ti]; else tile[ti] = v[e - e0];
+                if (v[e - e0] == 0) { ++zeros; const unsigned q = atomicAdd(&zc_s, 1u); if (q < SZH_ZCAP) zp_s[q] = (unsigned)e; }
                 if (++kk == s2) { kk = 0; if (++row == rows && e + 1 < ehi) locate(e + 1, row, kk, s2, koff); }
             }
             if (DIR == 0) {
@@ -492,18 +498,28 @@ __global__ __launch_bounds__(256) void k_permute(szh_geom3 G, const uint16_t *__
     }
     zeros = wave_sum_u32(zeros);
     if ((threadIdx.x & 63) == 0 && zeros) atomicAdd(&col_zeros[col], zeros);
+    __syncthreads();
+    const unsigned zc = zc_s;
+    const size_t slot = (size_t)col * gridDim.y + blockIdx.y;
+    if (threadIdx.x == 0) zcnt[slot] = zc;
+    if (threadIdx.x < zc && threadIdx.x < SZH_ZCAP) zpos[slot * SZH_ZCAP + threadIdx.x] = zp_s[threadIdx.x];
 }
 
 // ------------------------------------------------------------------ unpredictable values, in block order
 // One workgroup per block column that contains zeros.  DIR 0: gather originals into the list
 // (compress); DIR 1: scatter the list into the output array (decompress).
+#define SZH_ZMAX 1024 /* zero codes of one block column that k_unpred orders in LDS; beyond that it scans the codes */
 template <class T, int DIR>
 __global__ __launch_bounds__(256) void k_unpred(szh_geom3 G, const uint16_t *__restrict__ codes_blk, const unsigned *__restrict__ col_zeros,
-                                                const u64 *__restrict__ col_off, const T *data, T *unpred, T *out)
+                                                const u64 *__restrict__ col_off, const T *data, T *unpred, T *out,
+                                                const unsigned *__restrict__ zcnt, const unsigned *__restrict__ zpos, int segb, int nseg)
 {
     __shared__ u64 sh[8];
+    __shared__ u64 keys[SZH_ZMAX];
+    __shared__ int use_list;
     const int col = blockIdx.x;
-    if (col_zeros[col] == 0) return;
+    const unsigned K = col_zeros[col];
+    if (K == 0) return;
     const int b0 = col / G.g1.num, b1 = col - b0 * G.g1.num;
     const int s0 = szh_blk_size(G.g0, b0), s1 = szh_blk_size(G.g1, b1);
     const int o0 = szh_blk_start(G.g0, b0), o1 = szh_blk_start(G.g1, b1);
@@ -512,6 +528,40 @@ __global__ __launch_bounds__(256) void k_unpred(szh_geom3 G, const uint16_t *__r
     const int64_t base = szh_code_base01(G, b0, b1);
     const int64_t esz = (int64_t)rows * G.g2.early, lsz = (int64_t)rows * G.g2.late, eregion = (int64_t)G.g2.split * esz;
     u64 run = col_off[col];
+    // column-relative block-order index -> natural index
+    auto natural = [&](int64_t e) -> int64_t {
+        int64_t rem; int s2, o2;
+        if (e < eregion) { const int64_t bl = e / esz; rem = e - bl * esz; s2 = G.g2.early; o2 = (int)bl * G.g2.early; }
+        else { const int64_t e2 = e - eregion; const int64_t bl = e2 / lsz; rem = e2 - bl * lsz; s2 = G.g2.late; o2 = G.g2.split * G.g2.early + (int)bl * G.g2.late; }
+        const int row = (int)(rem / s2), kk = (int)(rem - (int64_t)row * s2);
+        const int ii = row / s1, jj = row - ii * s1;
+        return (int64_t)(o0 + ii) * G.d0 + (int64_t)(o1 + jj) * G.d1 + o2 + kk;
+    };
+    // the positions k_permute noted, if every segment's note is complete: order them (they are few) and move the values
+    if (threadIdx.x == 0) {
+        int ok = K <= SZH_ZMAX;
+        for (int sg = 0; sg < nseg && ok; ++sg) if (zcnt[(size_t)col * nseg + sg] > SZH_ZCAP) ok = 0;
+        use_list = ok;
+    }
+    __syncthreads();
+    if (use_list) {
+        unsigned at = 0;
+        for (int sg = 0; sg < nseg; ++sg) {
+            const unsigned c = zcnt[(size_t)col * nseg + sg];
+            const int64_t segoff = (int64_t)rows * szh_blk_start(G.g2, sg * segb);     // of the segment's first block within the column
+            for (unsigned q = threadIdx.x; q < c; q += 256) keys[at + q] = (u64)(segoff + zpos[((size_t)col * nseg + sg) * SZH_ZCAP + q]);
+            at += c;
+        }
+        __syncthreads();
+        for (unsigned q = threadIdx.x; q < K; q += 256) {
+            const u64 key = keys[q];
+            unsigned rank = 0;
+            for (unsigned o = 0; o < K; ++o) rank += keys[o] < key ? 1u : 0u;
+            const int64_t nat = natural((int64_t)key);
+            if (DIR == 0) unpred[run + rank] = data[nat]; else out[nat] = unpred[run + rank];
+        }
+        return;
+    }
     // the column is one contiguous block-order range; 8 codes per thread per round (16-byte groups by absolute address)
     const int head = (int)(base & 7);
     const int64_t ngroups = (head + len + 7) / 8;
@@ -530,13 +580,7 @@ __global__ __launch_bounds__(256) void k_unpred(szh_geom3 G, const uint16_t *__r
         for (int q = 0; q < 8 && zmask; ++q) {
             if (!(zmask >> q & 1)) continue;
             zmask &= ~(1u << q);
-            const int64_t e = e0 + q;
-            int64_t rem; int s2, o2;
-            if (e < eregion) { const int64_t bl = e / esz; rem = e - bl * esz; s2 = G.g2.early; o2 = (int)bl * G.g2.early; }
-            else { const int64_t e2 = e - eregion; const int64_t bl = e2 / lsz; rem = e2 - bl * lsz; s2 = G.g2.late; o2 = G.g2.split * G.g2.early + (int)bl * G.g2.late; }
-            const int row = (int)(rem / s2), kk = (int)(rem - (int64_t)row * s2);
-            const int ii = row / s1, jj = row - ii * s1;
-            const int64_t nat = (int64_t)(o0 + ii) * G.d0 + (int64_t)(o1 + jj) * G.d1 + o2 + kk;
+            const int64_t nat = natural(e0 + q);
             if (DIR == 0) unpred[run + rank] = data[nat];
             else out[nat] = unpred[run + rank];
             ++rank;
