@@ -89,7 +89,8 @@ def allgather_streams(local_stream, nbytes=None):
 class StreamGather:
     """The same all-gather, overlapped with the next compression step: begin() launches the gather of this step's sub-stream
     and returns; end() completes one.  The payload travels from a private copy, so the caller's buffer may be overwritten as
-    soon as begin() returns; two gathers may be in flight (two sets of buffers)."""
+    soon as begin() returns; two gathers may be in flight (two sets of buffers).  What end() returns are views of those
+    buffers: valid until the second begin() after the one that started this gather."""
 
     def __init__(self, depth=2):
         self.depth = depth

@@ -36,6 +36,23 @@ def _worker(rank, world, port, ret):
     p1, s1 = slab.StreamGather.end(h1); p2, s2 = slab.StreamGather.end(h2)
     assert s1 == sizes and s2 == sizes and all(bytes(a.numpy().tobytes()) == bytes(b.numpy().tobytes()) for a, b in zip(p1, parts))
     assert bytes(p2[rank].numpy().tobytes()) == stream[::-1]
+    # the benchmark's pipeline: one gather in flight while the next step runs, buffers reused every second step
+    # (a result is a view of its buffers: it is checked when the gather is completed, before those buffers are used again)
+    def payload_of(step, r):
+        return bytes([(step * 7 + r) & 0xff]) * (1000 + 100 * step + 10 * r)
+
+    def check(step, res):
+        parts_k, sizes_k = res
+        for r in range(world):
+            assert sizes_k[r] == len(payload_of(step, r)) and bytes(parts_k[r].numpy().tobytes()) == payload_of(step, r)
+    pending = []
+    for step in range(5):
+        mine_k = payload_of(step, rank)
+        pending.append((step, sg.begin(torch.frombuffer(bytearray(mine_k), dtype=torch.uint8), len(mine_k))))
+        if len(pending) > 1:
+            k, h = pending.pop(0); check(k, slab.StreamGather.end(h))
+    while pending:
+        k, h = pending.pop(0); check(k, slab.StreamGather.end(h))
     blob = slab.pack_container(np.float64, dims, bounds, [bytes(p.numpy().tobytes()) for p in parts])
     if rank == 0:
         ret["blob"] = blob; ret["range"] = (lo, hi); ret["sizes"] = sizes
