@@ -8,7 +8,8 @@ A "step" is one pass of the hot path (fit + interval optimiser + predictor selec
 encode, into the reference's SZ 2.1 stream) over one 512x512x512 float32 array (BASELINE.json configs[1]: smooth
 sinusoid "S-field", ABS 1e-4) that is already resident in HBM; the stream is left in HBM.  With N ranks every rank
 owns one such slab of an (N*512)x512x512 array (weak scaling, no data-path collective) and the step ends with one
-all-gather of the variable-length sub-streams (RCCL).  Rank 0 prints ONE JSON line.
+all-gather of the variable-length sub-streams (RCCL), launched asynchronously so that it overlaps the next step's
+compression; every gather is completed inside the timed region.  Rank 0 prints ONE JSON line.
 
 Extra objects on that line:
   roofline     -- the predict+quantise wavefront kernel: algorithmic bytes (N*4, the array read once) / its average
