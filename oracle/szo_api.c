@@ -238,9 +238,11 @@ unsigned char *szo_compress_args(const szo_params *p, int data_type, const void 
             out = szo_sz21_compress_3d_f32(p, meta, 4 + meta_len, (const float *)data, s, r2, r1, (float)eb, &osz, stages);
         else
             out = szo_sz21_compress_3d_f64(p, meta, 4 + meta_len, (const double *)data, s, r2, r1, eb, &osz, stages);
-    } else if ((dim == 3 || dim == 2) && !p->with_regression) {
+    } else if (dim == 1 || ((dim == 3 || dim == 2) && !p->with_regression)) {
+        /* 1-D, whatever the regression switch says: SZ_compress_args_float_NoCkRngeNoGzip_1D (sz_float.c:561, :2885-2900) */
         /* SZ 1.4 path: SZ_compress_args_float_NoCkRngeNoGzip_3D / _2D (sz_float.c:1422, :896), flag byte TightDataPointStorageF.c:600-611 */
         size_t s0 = dim == 3 ? r3 : 1;
+        if (dim == 1) r2 = 1;
         meta[3] = 0x40 | (p->protect_value_range ? 0x04 : 0);
         if (data_type == SZO_FLOAT)
             out = szo_sz14_compress_3d_f32(p, meta, 4 + meta_len, (const float *)data, s0, r2, r1, (float)eb, (float)range, (float)median, &osz, stages);
@@ -305,8 +307,9 @@ void *szo_decompress(int data_type, const unsigned char *bytes, size_t byte_len,
         size_t s = (dim == 4) ? r4 * r3 : r3;
         if (data_type == SZO_FLOAT) szo_sz21_decompress_3d_f32((float *)out, s, r2, r1, body);
         else szo_sz21_decompress_3d_f64((double *)out, s, r2, r1, body);
-    } else if (!(same & 0x80) && (dim == 3 || dim == 2)) {
+    } else if (dim == 1 || (!(same & 0x80) && (dim == 3 || dim == 2))) {
         size_t s0 = dim == 3 ? r3 : 1;
+        if (dim == 1) r2 = 1;
         int rc = data_type == SZO_FLOAT ? szo_sz14_decompress_3d_f32((float *)out, s0, r2, r1, body, byte_len - (size_t)(body - bytes))
                                         : szo_sz14_decompress_3d_f64((double *)out, s0, r2, r1, body, byte_len - (size_t)(body - bytes));
         if (rc) { free(out); return NULL; }

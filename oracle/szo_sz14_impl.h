@@ -108,6 +108,31 @@ static unsigned FN(szo_optimize_intervals_2d_opt)(const szo_params *p, const T *
     return pow2;
 }
 
+/* 1-D optimiser (optimize_intervals_float_1D_opt, sz_float.c:5070-5111 / sz_double.c:4747): previous-value predictor at
+ * positions 2, 2+sampleDistance, ...  1-D is PARITY UNPINNED (no recorded reference output of a 1-D array). */
+static unsigned FN(szo_optimize_intervals_1d_opt)(const szo_params *p, const T *data, size_t len, double ebD)
+{
+    unsigned maxRangeRadius = p->max_quant_intervals / 2;
+    size_t *iv = (size_t *)calloc(maxRangeRadius, sizeof(size_t));
+    size_t total = 0;
+    for (size_t pos = 2; pos < len; pos += (size_t)p->sample_distance) {
+        total++;
+        T pe = data[pos - 1] - data[pos];
+        double pred_err = fabs((double)pe);
+        size_t ri = (size_t)(uint64_t)((pred_err / ebD + 1) / 2);
+        if (ri >= maxRangeRadius) ri = maxRangeRadius - 1;
+        iv[ri]++;
+    }
+    size_t target = (size_t)(total * p->pred_threshold);
+    size_t sum = 0, i;
+    for (i = 0; i < maxRangeRadius; i++) { sum += iv[i]; if (sum > target) break; }
+    if (i >= maxRangeRadius) i = maxRangeRadius - 1;
+    unsigned pow2 = szo_round_up_pow2(2 * (unsigned)(i + 1));
+    if (pow2 < 32) pow2 = 32;
+    free(iv);
+    return pow2;
+}
+
 /* required length of an "exact" value in bits, and the median it is taken against (sz_float.c:45-56 / sz_double.c:44-55) */
 static int FN(szo_req_length)(double eb, T range, T *median)
 {
@@ -195,6 +220,7 @@ static unsigned char *FN(szo_sz14_compress_3d)(const szo_params *p, const unsign
     const size_t n = r1 * r2 * r3, r23 = r2 * r3;
     const T recip = 1 / eb;
     unsigned intervals = p->quantization_intervals ? p->quantization_intervals
+                         : r1 == 1 && r2 == 1 ? FN(szo_optimize_intervals_1d_opt)(p, data, r3, (double)eb)
                          : r1 == 1 ? FN(szo_optimize_intervals_2d_opt)(p, data, r2, r3, (double)eb)
                                    : FN(szo_optimize_intervals_3d_opt)(p, data, r1, r2, r3, (double)eb);
     const int radius = (int)intervals / 2;
@@ -205,6 +231,41 @@ static unsigned char *FN(szo_sz14_compress_3d)(const szo_params *p, const unsign
 
     int *type = (int *)malloc(n * sizeof(int));
     T *P0 = (T *)malloc(r23 * sizeof(T)), *P1 = (T *)malloc(r23 * sizeof(T));   /* P1: previous layer, P0: current (roles swap) */
+
+    if (r1 == 1 && r2 == 1) {
+        /* the 1-D compressor SZ_compress_float_1D_MDQ (sz_float.c:353-540) / SZ_compress_double_1D_MDQ (sz_double.c:260-400): the
+         * first two values exact, then the previous reconstruction as predictor; its own quantiser (a radius test, the state
+         * from a truncation and a shift); only the float version re-checks the bound.  PARITY UNPINNED. */
+        const T check_radius = (T)((intervals - 1) * eb), interval = 2 * eb;
+        type[0] = 0; (void)FN(szo_exact_add)(&E, data[0]);
+        type[1] = 0;
+        T pred = FN(szo_exact_add)(&E, data[1]);
+        for (size_t i = 2; i < n; i++) {
+            const T x = data[i];
+#if IS_F64
+            const T err = fabs(x - pred);
+#else
+            const T err = fabsf(x - pred);
+#endif
+            if (err < check_radius) {
+#if IS_F64
+                const int state = (int)((err * recip + 1) * 0.5);
+#else
+                const int state = ((int)(T)(err * recip + 1)) >> 1;
+#endif
+                const T step = (T)(state * interval);
+                if (x >= pred) { type[i] = radius + state; pred = pred + step; }
+                else { type[i] = radius - state; pred = pred - step; }
+#if !IS_F64
+                if (fabs((double)(T)(x - pred)) > (double)eb) { type[i] = 0; pred = FN(szo_exact_add)(&E, x); }
+#endif
+                continue;
+            }
+            type[i] = 0;
+            pred = FN(szo_exact_add)(&E, x);
+        }
+        goto pack;
+    }
 
     /* layer 0 */
     type[0] = 0;
@@ -246,6 +307,7 @@ static unsigned char *FN(szo_sz14_compress_3d)(const szo_params *p, const unsign
         }
         T *t = P1; P1 = P0; P0 = t;
     }
+pack:
     free(P0); free(P1);
 
     /* type array blob (Huffman.c:790-816): nodeCount | stateNum/2 | tree | payload */
@@ -369,6 +431,10 @@ static int FN(szo_sz14_decompress_3d)(T *out, size_t r1, size_t r2, size_t r3, c
     const int radius = (int)intervals / 2;
 
 #define SZO_DEC(IDX, PRED) do { int t_ = type[IDX]; out[IDX] = t_ ? (T)((PRED) + 2 * (t_ - radius) * eb) : FN(szo_exact_next)(&R); } while (0)
+    if (r1 == 1 && r2 == 1) {   /* decompressDataSeries_float_1D (szd_float.c:185-282): codes 0 at positions 0 and 1 by construction */
+        for (size_t i = 0; i < n; i++) { T pred = i ? out[i - 1] : 0; SZO_DEC(i, pred); }
+        goto done;
+    }
     out[0] = FN(szo_exact_next)(&R);
     if (r3 > 1) SZO_DEC(1, out[0]);
     for (size_t j = 2; j < r3; j++) { T pred = 2 * out[j - 1] - out[j - 2]; SZO_DEC(j, pred); }
@@ -392,6 +458,7 @@ static int FN(szo_sz14_decompress_3d)(T *out, size_t r1, size_t r2, size_t r3, c
             }
         }
     }
+done:
 #undef SZO_DEC
     free(type); free(resi_pad);
     return 0;

@@ -97,7 +97,7 @@ def compress(data, mode=ABS, abs_err=1e-4, rel=0.0, params=None, want_stages=Fal
                 return np.zeros(0, dtype=dtype)
             a = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(np.ctypeslib.as_ctypes_type(dtype))), shape=(count,))
             return a.copy()
-        if not p.with_regression:   # SZ 1.4 path: the struct's fields carry other things (szo_sz14_impl.h)
+        if not p.with_regression or data.ndim == 1:   # SZ 1.4 path (1-D always takes it): the struct's fields carry other things (szo_sz14_impl.h)
             sd = dict(num_elements=ne, exact_count=tu, intervals=st.intervals, req_length=st.use_mean, median=st.mean, eb=st.eb,
                       codes=arr(st.codes, ne, np.int32), lead=arr(st.indicator, tu, np.uint8), mid=arr(st.unpred, nb, np.uint8),
                       code_len=arr(st.code_len, 2 * st.intervals, np.uint8),
