@@ -231,6 +231,7 @@ unsigned char *szo_compress_args(const szo_params *p, int data_type, const void 
 
     int dim = (r2 == 0) ? 1 : (r3 == 0) ? 2 : (r4 == 0) ? 3 : (r5 == 0) ? 4 : 5;
     unsigned char *out = NULL; size_t osz = 0;
+    int strict_raw_rule = 0;
     if ((dim == 3 || dim == 4) && p->with_regression) {
         size_t s = (dim == 4) ? r4 * r3 : r3; /* 4-D is treated as 3-D (r4*r3, r2, r1), sz_float.c:3010 */
         meta[3] = 0x80 | 0x40 | (p->protect_value_range ? 0x04 : 0);
@@ -248,7 +249,9 @@ unsigned char *szo_compress_args(const szo_params *p, int data_type, const void 
             out = szo_sz14_compress_3d_f32(p, meta, 4 + meta_len, (const float *)data, s0, r2, r1, (float)eb, (float)range, (float)median, &osz, stages);
         else
             out = szo_sz14_compress_3d_f64(p, meta, 4 + meta_len, (const double *)data, s0, r2, r1, eb, range, median, &osz, stages);
-        if (osz > n * esz + 3 + meta_len + 8 + 1) osz = (size_t)-1;   /* strict '>' here (sz_float.c:1469); forces the raw form below */
+        /* strict '>' inside the 2-D/3-D callee (sz_float.c:1469, :940) and nothing after it; the 1-D call site adds a '>=' of
+         * its own (sz_float.c:2908, sz_double.c:2624) */
+        strict_raw_rule = dim != 1;
     } else if (dim == 2 && p->with_regression) {
         /* SZ 2.1 (2D), sz_float.c:2940-2944 -- parity unpinned, see szo_sz21_impl.h */
         meta[3] = 0x80 | 0x40 | (p->protect_value_range ? 0x04 : 0);
@@ -261,7 +264,7 @@ unsigned char *szo_compress_args(const szo_params *p, int data_type, const void 
         return NULL;
     }
     /* expansion fallback: SZ_compress_args_float_StoreOriData (sz_float.c:526) */
-    if (osz >= n * esz + 3 + meta_len + 8 + 1) {
+    if (osz + (strict_raw_rule ? 0 : 1) > n * esz + 3 + meta_len + 8 + 1) {
         size_t tot = 3 + meta_len + 8 + 1 + esz * n;
         unsigned char *o = (unsigned char *)malloc(tot);
         memcpy(o, meta, 4 + meta_len);

@@ -276,9 +276,10 @@ static int compress_fp(int dataType, int withRegression, unsigned char **newByte
 
     int dim = computeDimension(r5, r4, r3, r2, r1);
     if (dim == 5) { printf("Error: doesn't support 5 dimensions for now.\n"); return SZ_DERR; }
-    const int sz14 = withRegression == SZ_NO_REGRESSION;      /* the SZ 1.4 path (sz_float.c:2938,2978): 2-D and 3-D in this build */
-    if (!(dim == 2 || dim == 3 || dim == 4) || (sz14 && dim == 4) || confparams_cpr->randomAccess) {
-        printf("Error: the MI355X build covers 2-D/3-D/4-D float/double arrays with withLinearRegression=YES and 2-D/3-D arrays with "
+    /* the SZ 1.4 path (sz_float.c:2938,2978): 2-D and 3-D in this build; a 1-D array takes its container whatever the switch says (:2885-2900) */
+    const int sz14 = withRegression == SZ_NO_REGRESSION || dim == 1;
+    if (!(dim >= 1 && dim <= 4) || (sz14 && dim == 4) || confparams_cpr->randomAccess) {
+        printf("Error: the MI355X build covers 2-D/3-D/4-D float/double arrays with withLinearRegression=YES and 1-D/2-D/3-D arrays with "
                "withLinearRegression=NO; this call (dim=%d, withRegression=%d, randomAccess=%d) is not covered yet.\n", dim, withRegression, confparams_cpr->randomAccess);
         return SZ_NSCS;
     }
@@ -294,7 +295,7 @@ static int compress_fp(int dataType, int withRegression, unsigned char **newByte
     int rc;
     if (sz14) {   /* medianValue = min + valueRangeSize/2 in the data's type (dataCompression.c:117) */
         double median = dataType == SZ_FLOAT ? (double)(float)((float)vmin + (float)valueRangeSize / 2) : vmin + valueRangeSize / 2;
-        rc = szhip_compress_sz14(ctx, dataType == SZ_FLOAT ? SZHIP_F32 : SZHIP_F64, d_in, 1, r3, r2, r1, realPrecision, valueRangeSize, median,   /* r3 == 0: 2-D */
+        rc = szhip_compress_sz14(ctx, dataType == SZ_FLOAT ? SZHIP_F32 : SZHIP_F64, d_in, 1, r3, r2, r1, realPrecision, valueRangeSize, median,   /* r3 == 0: 2-D; r3 == r2 == 0: 1-D */
                                  &hp, meta, 4 + meta_len, 0, &tmp, &tmpSize, &g_last_stats);
     } else
         rc = szhip_compress(ctx, dataType == SZ_FLOAT ? SZHIP_F32 : SZHIP_F64, d_in, 1, s0, r2, r1, realPrecision, &hp,
@@ -302,8 +303,9 @@ static int compress_fp(int dataType, int withRegression, unsigned char **newByte
     if (rc != SZHIP_OK) { printf("Error: szhip_compress failed (%d): %s\n", rc, szhip_last_error(ctx)); return SZ_NSCS; }
     if (exe_params->optQuantMode == 1) { exe_params->intvCapacity = (int)g_last_stats.intervals; exe_params->intvRadius = exe_params->intvCapacity / 2; } /* updateQuantizationInfo */
 
-    /* SZ_compress_args_float_StoreOriData, sz_float.c:526; '>=' on the SZ 2.1 path (:2975), '>' on the SZ 1.4 path (:1469) */
-    if (tmpSize + (sz14 ? 0 : 1) > dataLength * esz + 3 + meta_len + exe_params->SZ_SIZE_TYPE + 1) {
+    /* SZ_compress_args_float_StoreOriData, sz_float.c:526; '>=' on the SZ 2.1 path (:2975) and at the 1-D call site (:2908),
+     * '>' on the 2-D/3-D SZ 1.4 path (:1469) */
+    if (tmpSize + (sz14 && dim != 1 ? 0 : 1) > dataLength * esz + 3 + meta_len + exe_params->SZ_SIZE_TYPE + 1) {
         size_t tot = 3 + meta_len + 8 + 1 + esz * dataLength;
         unsigned char *o = (unsigned char *)malloc(tot);
         memcpy(o, meta, 4 + meta_len);
@@ -447,8 +449,8 @@ static void *decompress_fp(int dataType, unsigned char *cmpBytes, size_t cmpSize
         }
     } else {
         int dim = computeDimension(r5, r4, r3, r2, r1);
-        if ((same & (0x20 | 0x08 | 0x02)) || !(dim == 2 || dim == 3 || dim == 4) || (!(same & 0x80) && dim == 4) || st != 8 || confparams_dec->sol_ID != SZ) {
-            printf("Error: the MI355X build decodes SZ 2.1 regression-type streams of 2-D/3-D/4-D arrays and SZ 1.4 streams of 2-D/3-D arrays "
+        if ((same & (0x20 | 0x08 | 0x02)) || !(dim >= 1 && dim <= 4) || (!(same & 0x80) && dim == 4) || ((same & 0x80) && dim == 1) || st != 8 || confparams_dec->sol_ID != SZ) {
+            printf("Error: the MI355X build decodes SZ 2.1 regression-type streams of 2-D/3-D/4-D arrays and SZ 1.4 streams of 1-D/2-D/3-D arrays "
                    "(float/double, no point-wise-relative or random-access form); this stream (flags 0x%02x, dim %d) is not covered yet.\n", same, dim);
             ok = 0;
         } else if (!(same & 0x80)) {   /* SZ 1.4 container: getSnapshotData_float_3D -> decompressDataSeries_float_3D (szd_float.c:146,600) */

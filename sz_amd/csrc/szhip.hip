@@ -923,9 +923,12 @@ int compress14_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t
     const int is_double = sizeof(T) == 8;
     // r0 == 0: the 2-D compressor SZ_compress_float_2D_MDQ (sz_float.c:610): its predictors are those of the 3-D one's first layer,
     // so it is carried as 1 x r1 x r2 (the block size of the carried geometry plays no role here); its optimiser has the 2-D lattice
-    const szh_geom3 G = r0 == 0 ? szh_make_geom2((int)r1, (int)r2) : szh_make_geom3((int)r0, (int)r1, (int)r2);
+    // r0 == 0 and r1 == 0: the 1-D compressor SZ_compress_float_1D_MDQ (sz_float.c:353): a chain through the previous reconstructed
+    // value, walked by k_chain_1d; the container and everything after the code array are the same
+    const bool one_d = r0 == 0 && r1 == 0;
+    const szh_geom3 G = one_d ? szh_make_geom2(1, (int)r2) : r0 == 0 ? szh_make_geom2((int)r1, (int)r2) : szh_make_geom3((int)r0, (int)r1, (int)r2);
     const int64_t n = G.n;
-    const T eb = (T)eb_in;                                     // `float realPrecision` parameter of sz_float.c:946
+    const T eb = (T)eb_in;                                     // `float realPrecision` parameter of sz_float.c:946 (:353 for 1-D)
     const double t_begin = now_ms();
     double host_ms = 0;
     hipStream_t st = ctx->stream;
@@ -951,8 +954,13 @@ int compress14_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t
         TRY(ensure_pinned(ctx, (size_t)(max_radius + 8192) * 4 + 64));
         unsigned *d_rh = (unsigned *)ctx->hist.p, *d_fh = d_rh + max_radius;
         HIPCHK(hipMemsetAsync(d_rh, 0, (size_t)(max_radius + 8192) * 4, st));
-        const int64_t nrows = szh_sample_row_limit(G, prm->sample_distance);
-        if (nrows > 0) {
+        const int64_t nrows = one_d ? 0 : szh_sample_row_limit(G, prm->sample_distance);
+        if (one_d) {
+            const int64_t count = (n - 2 + prm->sample_distance - 1) / prm->sample_distance;
+            int grid = (int)std::min<int64_t>((count + 255) / 256 + 1, 1024);
+            hipLaunchKernelGGL((k_sample_1d<T>), dim3(grid), dim3(256), 0, st, d_in, n, prm->sample_distance, (double)eb, max_radius, d_rh);
+            HIPCHK(hipGetLastError());
+        } else if (nrows > 0) {
             int grid = (int)std::min<int64_t>((nrows + 255) / 256, 1024);
             hipLaunchKernelGGL((k_sample<T>), dim3(grid), dim3(256), 0, st, G, d_in, nrows, prm->sample_distance, (double)eb, (T)0,
                                max_radius, d_rh, d_fh, sm + SM_WITHIN);
@@ -982,8 +990,28 @@ int compress14_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t
     // ---- predict + quantise
     TRY(ensure(ctx, ctx->codes_nat, (size_t)n * 2 + 64));
     uint16_t *d_codes = (uint16_t *)ctx->codes_nat.p;
-    TRY(launch_pencil14<T>(ctx, G, sm, false, d_in, nullptr, d_codes, eb, intervals, median, ign_bits));
     S.quant_kernel_launches = 1;
+    if (one_d) {
+        // the chain cut at its certain restarts, one thread per segment; a segment whose successor turns out not to restart raises
+        // the flag, and the array is then walked by the one-wavefront kernel (same result, by construction; SZ_HIP_1D_SERIAL=1 forces it)
+        HIPCHK(hipEventRecord(ctx->ev[2], st));
+        unsigned violation = 1;
+        if (!tune_int("SZ_HIP_1D_SERIAL", 0)) {
+            const int grid = (int)std::min<int64_t>((n + 255) / 256, 1 << 20);
+            hipLaunchKernelGGL((k_chain_seg_1d<T, false>), dim3(grid), dim3(256), 0, st, d_in, (T *)nullptr, d_codes, n, eb, (T)(1 / eb), (int)intervals,
+                               median, ign_bits, tune_int("SZ_HIP_1D_REACH_PCT", 100) / 100.0, (unsigned *)(sm + SM_CHANGED));
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(&violation, sm + SM_CHANGED, 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+        }
+        if (violation) {
+            hipLaunchKernelGGL((k_chain_1d<T, false>), dim3(1), dim3(64), 0, st, d_in, (T *)nullptr, d_codes, n, eb, (T)(1 / eb), (int)intervals, median, ign_bits);
+            HIPCHK(hipGetLastError());
+            S.quant_kernel_launches = 2;
+        }
+        HIPCHK(hipEventRecord(ctx->ev[3], st));
+    } else
+        TRY(launch_pencil14<T>(ctx, G, sm, false, d_in, nullptr, d_codes, eb, intervals, median, ign_bits));
 
     // ---- histogram -> code book (host), exact-value counts
     TRY(ensure(ctx, ctx->hist, (size_t)(65536 + 8192) * 4 + 64));
@@ -1127,7 +1155,8 @@ int decompress14_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream
                       size_t r0, size_t r1, size_t r2, void *out, int out_on_device, szhip_stats *stats)
 {
     const int is_double = sizeof(T) == 8;
-    const szh_geom3 G = r0 == 0 ? szh_make_geom2((int)r1, (int)r2) : szh_make_geom3((int)r0, (int)r1, (int)r2);
+    const bool one_d = r0 == 0 && r1 == 0;                     // decompressDataSeries_float_1D (szd_float.c:185)
+    const szh_geom3 G = one_d ? szh_make_geom2(1, (int)r2) : r0 == 0 ? szh_make_geom2((int)r1, (int)r2) : szh_make_geom3((int)r0, (int)r1, (int)r2);
     const int64_t n = G.n;
     const double t_begin = now_ms();
     double host_ms = 0;
@@ -1242,7 +1271,19 @@ int decompress14_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream
     HIPCHK(hipEventRecord(ctx->ev[1], st));
 
     // ---- reconstruct
-    TRY(launch_pencil14<T>(ctx, G, sm, true, nullptr, d_out, d_codes, eb, intervals, median, 0));
+    if (one_d) {
+        HIPCHK(hipEventRecord(ctx->ev[2], st));
+        if (tune_int("SZ_HIP_1D_SERIAL", 0))
+            hipLaunchKernelGGL((k_chain_1d<T, true>), dim3(1), dim3(64), 0, st, (const T *)nullptr, d_out, d_codes, n, eb, (T)(1 / eb), (int)intervals, median, 0);
+        else {   // decoding sees where the chain restarts (code 0): one thread per segment, nothing to verify
+            const int grid = (int)std::min<int64_t>((n + 255) / 256, 1 << 20);
+            hipLaunchKernelGGL((k_chain_seg_1d<T, true>), dim3(grid), dim3(256), 0, st, (const T *)nullptr, d_out, d_codes, n, eb, (T)(1 / eb), (int)intervals,
+                               median, 0, 1.0, (unsigned *)nullptr);
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(ctx->ev[3], st));
+    } else
+        TRY(launch_pencil14<T>(ctx, G, sm, true, nullptr, d_out, d_codes, eb, intervals, median, 0));
     S.quant_kernel_launches = 1;
     unsigned kerr = 0;
     HIPCHK(hipMemcpyAsync(&kerr, sm + SM_ERR, 4, hipMemcpyDeviceToHost, st));
@@ -1345,7 +1386,7 @@ int szhip_compress_sz14(szhip_ctx *ctx, int dtype, const void *data, int data_on
                         int out_on_device, unsigned char **out, size_t *out_size, szhip_stats *stats)
 {
     if (!ctx || !data || !params || !meta || !out || !out_size) return SZHIP_ERR_ARG;
-    if ((r0 != 0 && r0 < 2) || r1 < 2 || r2 < 2 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff) return SZHIP_ERR_ARG;
+    if ((r0 != 0 && r0 < 2) || (r1 < 2 && !(r0 == 0 && r1 == 0)) || r2 < 2 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff) return SZHIP_ERR_ARG;
     if (!(eb > 0)) return SZHIP_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
     const int rc = dtype == SZHIP_F32
@@ -1359,7 +1400,7 @@ int szhip_decompress_sz14(szhip_ctx *ctx, int dtype, const unsigned char *stream
                           size_t r0, size_t r1, size_t r2, void *out, int out_on_device, szhip_stats *stats)
 {
     if (!ctx || !stream || !out || body_off >= stream_len) return SZHIP_ERR_ARG;
-    if ((r0 != 0 && r0 < 2) || r1 < 2 || r2 < 2 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff) return SZHIP_ERR_ARG;
+    if ((r0 != 0 && r0 < 2) || (r1 < 2 && !(r0 == 0 && r1 == 0)) || r2 < 2 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff) return SZHIP_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
     const int rc = dtype == SZHIP_F32
                ? decompress14_impl<float>(ctx, stream, stream_on_device, stream_len, body_off, r0, r1, r2, out, out_on_device, stats)

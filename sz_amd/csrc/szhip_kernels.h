@@ -366,6 +366,147 @@ __global__ __launch_bounds__(64) void k_mean_seq(const T *__restrict__ data, int
     if (lane == 0) { *out_sum = sum; *out_cnt = cnt; }
 }
 
+// ------------------------------------------------------------------ 1-D arrays
+// interval optimiser of a 1-D array (optimize_intervals_float_1D_opt, sz/src/sz_float.c:5070-5111): positions 2, 2+sd, ...,
+// previous-value predictor, radius histogram only
+template <class T>
+__global__ __launch_bounds__(256) void k_sample_1d(const T *__restrict__ data, int64_t n, int sd, double ebD, unsigned max_radius,
+                                                   unsigned *radius_hist)
+{
+    __shared__ unsigned sh_r[SZH_LDS_RADIUS_BINS];
+    for (int i = threadIdx.x; i < SZH_LDS_RADIUS_BINS; i += 256) sh_r[i] = 0;
+    __syncthreads();
+    const int64_t count = n > 2 ? (n - 2 + sd - 1) / sd : 0;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < count; k += (int64_t)gridDim.x * 256) {
+        const int64_t pos = 2 + k * sd;
+        const T pred_err = szh_abs((T)(data[pos - 1] - data[pos]));
+        const double rq = ((double)pred_err / ebD + 1) / 2;
+        unsigned ri = rq >= (double)max_radius ? max_radius - 1 : (unsigned)rq;
+        if (ri >= max_radius) ri = max_radius - 1;
+        if (ri < SZH_LDS_RADIUS_BINS) atomicAdd(&sh_r[ri], 1u); else atomicAdd(&radius_hist[ri], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SZH_LDS_RADIUS_BINS; i += 256) if (sh_r[i]) atomicAdd(&radius_hist[i], sh_r[i]);
+}
+
+// The 1-D predictor is the previous RECONSTRUCTED value (SZ_compress_float_1D_MDQ, sz/src/sz_float.c:353-540;
+// SZ_compress_double_1D_MDQ, sz/src/sz_double.c:260-400; inverse szd_float.c:185-282): one dependency chain through the whole
+// array in float arithmetic, so ONE wavefront walks it, every lane carrying the same `pred`.  What does not depend on the chain
+// (loads, the exact-value reconstruction, stores) is done 64 wide.  The float version re-checks the bound after quantising, the
+// double version does not; positions 0 and 1 are always exact.
+//   DEC = false: data -> codes.          DEC = true: codes + out (exact values already at the code-0 positions) -> out
+template <class T, bool DEC>
+__global__ __launch_bounds__(64) void k_chain_1d(const T *__restrict__ data, T *out, uint16_t *codes, int64_t n, T eb, T recip,
+                                                 int intervals, T median, int ign_bits)
+{
+    const int lane = threadIdx.x;
+    const int radius = intervals / 2;
+    const T check_radius = (T)((unsigned)(intervals - 1)) * eb, interval = 2 * eb;
+    T pred = 0;
+    for (int64_t base = 0; base < n; base += 64) {
+        const int64_t i = base + lane;
+        T x = 0, mine = 0; int c = 0, mycode = 0;
+        if (i < n) {
+            if (DEC) { c = codes[i]; x = out[i]; }
+            else { x = data[i]; }
+        }
+        const T ex = DEC ? x : szh_keep_bits(x, median, ign_bits);      // what an exact value reconstructs to
+#pragma unroll 16
+        for (int j = 0; j < 64; ++j) {
+            const T exj = __shfl(ex, j, 64);
+            if (DEC) {
+                const int cj = __shfl(c, j, 64);
+                const T step = (T)(cj - radius) * interval;
+                const T p2 = pred + step;
+                pred = cj ? p2 : exj;
+            } else {
+                const T xj = __shfl(x, j, 64);
+                const T err = szh_abs(xj - pred);
+                int state;
+                if (sizeof(T) == 8) state = (int)((err * recip + 1) * (T)0.5);
+                else state = ((int)(err * recip + 1)) >> 1;
+                const T step = (T)state * interval;
+                const bool up = xj >= pred;
+                const T p2 = up ? pred + step : pred - step;
+                bool ok = err < check_radius && base + j >= 2;
+                if (sizeof(T) == 4) ok = ok && !(szh_abs(xj - p2) > eb);
+                pred = ok ? p2 : exj;
+                const int code = ok ? (up ? radius + state : radius - state) : 0;
+                if (lane == j) mycode = code;
+            }
+            if (lane == j) mine = pred;
+        }
+        if (i < n) {
+            if (DEC) out[i] = mine;
+            else codes[i] = (uint16_t)mycode;
+        }
+    }
+}
+
+// The same chain, cut where it is known to restart.  An exact value does not depend on what came before it, so the chain
+// restarts there.  Decoding sees those places (code 0).  Encoding cannot see them before walking the chain -- except where
+// two neighbouring values differ by more than the quantiser's reach plus what a reconstruction can be off by: there the walk
+// takes the exact branch whatever it carries.  One THREAD per such segment walks it; the thread checks, with the value it really
+// carries, that the next segment's first value does take the exact branch, and raises `violation` otherwise (the caller then
+// walks the array with k_chain_1d).  With every check passed the segments are the serial walk, by induction from position 0.
+template <class T>
+__device__ __forceinline__ bool szh_certain_restart(T prev, T cur, double reach, double rel)
+{
+    const double a = (double)prev, b = (double)cur;
+    const double m = fmax(fabs(a), fabs(b));
+    return fabs(a - b) > reach + m * rel;      // false for NaN: such places stay inside a segment
+}
+template <class T, bool DEC>
+__global__ __launch_bounds__(256) void k_chain_seg_1d(const T *__restrict__ data, T *out, uint16_t *codes, int64_t n, T eb, T recip,
+                                                      int intervals, T median, int ign_bits, double reach_scale, unsigned *violation)
+{
+    const int radius = intervals / 2;
+    const T check_radius = (T)((unsigned)(intervals - 1)) * eb, interval = 2 * eb;
+    // reach_scale = 1; a test shrinks it to cut where the chain does NOT restart, which the check below must catch
+    const double reach = (double)check_radius * reach_scale + 4.0 * (double)eb, rel = sizeof(T) == 8 ? 0x1p-48 : 0x1p-19;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        if (DEC) {
+            if (i != 0 && codes[i] != 0) continue;
+            T pred = 0;
+            int c = codes[i];
+            for (int64_t j = i;;) {
+                const T step = (T)(c - radius) * interval;
+                const T p2 = pred + step;
+                pred = c ? p2 : out[j];
+                out[j] = pred;
+                if (++j >= n) break;
+                c = codes[j];
+                if (c == 0) break;
+            }
+        } else {
+            if (i == 1) continue;
+            T x = data[i];
+            if (i != 0 && !szh_certain_restart<T>(data[i - 1], x, reach, rel)) continue;
+            T pred = 0;
+            for (int64_t j = i;;) {
+                const T xn = j + 1 < n ? data[j + 1] : (T)0;
+                const T err = szh_abs(x - pred);
+                int state;
+                if (sizeof(T) == 8) state = (int)((err * recip + 1) * (T)0.5);
+                else state = ((int)(err * recip + 1)) >> 1;
+                const T step = (T)state * interval;
+                const bool up = x >= pred;
+                const T p2 = up ? pred + step : pred - step;
+                bool ok = err < check_radius && j >= 2 && j != i;
+                if (sizeof(T) == 4) ok = ok && !(szh_abs(x - p2) > eb);
+                pred = ok ? p2 : szh_keep_bits(x, median, ign_bits);
+                codes[j] = (uint16_t)(ok ? (up ? radius + state : radius - state) : 0);
+                if (++j >= n) break;
+                if (j >= 2 && szh_certain_restart<T>(x, xn, reach, rel)) {
+                    if (szh_abs(xn - pred) < check_radius) atomicOr(violation, 1u);
+                    break;
+                }
+                x = xn;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ code histogram (order independent)
 // LDS-privatised with R replicas per bin to spread same-symbol atomics over banks.
 __global__ __launch_bounds__(256) void k_hist_u16(const uint16_t *__restrict__ codes, int64_t n, unsigned nbins, int rshift,

@@ -123,11 +123,79 @@ def test_psnr_and_norm_modes_identical_to_oracle(sz, oracle):
 def test_unsupported_calls_fail_loudly(sz):
     import sz_amd
     with pytest.raises(sz_amd.SZError):
-        sz.SZ_compress_args(np.zeros(4096, dtype=np.float32) + np.arange(4096, dtype=np.float32), sz.ABS, 1e-3)  # 1-D: not covered yet
+        sz.SZ_compress_args(np.random.default_rng(0).random((3, 4, 5, 6, 7), dtype=np.float32), sz.ABS, 1e-3)    # 5-D: the reference refuses too
     with pytest.raises(sz_amd.SZError):
         sz.SZ_compress_args(np.random.default_rng(0).random((8, 9, 10), dtype=np.float32), sz.PW_REL, 0, 0, 1e-3)
     with pytest.raises(sz_amd.SZError):
         sz.SZ_decompress(b"\x02\x01\x0c\xc0" + b"\x00" * 60, (8, 9, 10), np.float32)
+
+
+def _series(n, dtype, seed):
+    """1-D test series: a smooth walk, a noisy stretch, a jump and a run of exact zeros."""
+    rng = np.random.default_rng(seed)
+    x = np.cumsum(rng.standard_normal(n)) * 0.01 + np.sin(np.arange(n) * 0.003)
+    a, b = n // 5, n // 5 + max(1, n // 50)
+    x[a:b] += 30.0 * rng.standard_normal(b - a)
+    x[n // 2:] += 4.0
+    x[3 * n // 4:3 * n // 4 + n // 40] = 0.0
+    return np.ascontiguousarray(x.astype(dtype))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n,eb,mode", [(21, 1e-3, 0), (64, 1e-2, 0), (65, 1e-4, 0), (1000, 1e-3, 0), (4097, 1e-5, 0), (200000, 1e-3, 0),
+                                        (200000, 1e-6, 0), (50000, 1e-4, 1)])
+def test_1d_stream_and_decode_identical_to_oracle(sz, oracle, dtype, n, eb, mode):
+    """1-D arrays (SZ_compress_float_1D_MDQ, sz_float.c:353; decompressDataSeries_float_1D, szd_float.c:185): the chain through
+    the previous reconstructed value, walked by one wavefront.  The stream must match byte for byte, with and without the
+    regression switch (a 1-D array ignores it), and decode bit for bit.  (1-D is parity-unpinned: the oracle restates the
+    reference's code; no recorded reference output of a 1-D array exists.)"""
+    d = _series(n, dtype, seed=n)
+    ref, _ = oracle.compress(d, mode, eb, eb)
+    got = sz.SZ_compress_args(d, mode, eb, eb)
+    assert got == ref
+    dec = sz.SZ_decompress(ref, d.shape, d.dtype)
+    want = oracle.decompress(ref, d.shape, d.dtype)
+    assert np.array_equal(dec.view(np.uint8), want.view(np.uint8))
+    if dtype == np.float32 and mode == 0:   # the float chain re-checks the bound; the double chain of the reference does not
+        assert float(np.abs(dec.astype(np.float64) - d).max()) <= eb * (1 + 1e-6)
+    cp = sz.conf_params()
+    saved = cp.withRegression
+    try:
+        cp.withRegression = 0
+        assert sz.SZ_compress_args(d, mode, eb, eb) == ref
+    finally:
+        cp.withRegression = saved
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_1d_segment_check_and_one_wavefront_walk(sz, oracle, dtype, monkeypatch):
+    """The 1-D chain is cut where it must restart and walked one thread per segment; each thread checks that its successor's
+    first value really takes the exact branch.  Cutting too eagerly (SZ_HIP_1D_REACH_PCT shrinks the reach) must raise the flag
+    and fall back to the one-wavefront walk of the whole array, with the same stream; SZ_HIP_1D_SERIAL=1 takes that walk directly."""
+    d = _series(60000, dtype, seed=9)
+    ref, _ = oracle.compress(d, 0, 1e-3, 0.0)
+    want = oracle.decompress(ref, d.shape, d.dtype)
+    assert sz.SZ_compress_args(d, 0, 1e-3, 0.0) == ref
+    assert sz.SZ_hip_last_stats().quant_kernel_launches == 1
+    monkeypatch.setenv("SZ_HIP_1D_REACH_PCT", "3")
+    assert sz.SZ_compress_args(d, 0, 1e-3, 0.0) == ref
+    assert sz.SZ_hip_last_stats().quant_kernel_launches == 2          # flag raised -> walked again by one wavefront
+    monkeypatch.delenv("SZ_HIP_1D_REACH_PCT")
+    monkeypatch.setenv("SZ_HIP_1D_SERIAL", "1")
+    assert sz.SZ_compress_args(d, 0, 1e-3, 0.0) == ref
+    dec = sz.SZ_decompress(ref, d.shape, d.dtype)
+    assert np.array_equal(dec.view(np.uint8), want.view(np.uint8))
+
+
+def test_1d_constant_tiny_and_incompressible_arrays(sz, oracle):
+    for d in (np.full(5000, 3.25, dtype=np.float32),                                  # constant: header + one value
+              np.arange(20, dtype=np.float64),                                        # <= 20 values: stored as they are
+              np.random.default_rng(5).standard_normal(30000).astype(np.float32)):    # white noise at a tiny bound: raw fallback
+        eb = 1e-9 if d.size == 30000 else 1e-3
+        ref, _ = oracle.compress(d, 0, eb, 0.0)
+        assert sz.SZ_compress_args(d, 0, eb, 0.0) == ref
+        dec = sz.SZ_decompress(ref, d.shape, d.dtype)
+        assert np.array_equal(dec.view(np.uint8), oracle.decompress(ref, d.shape, d.dtype).view(np.uint8))
 
 
 def test_context_reuse_and_device_resident_entry_points(sz, oracle):

@@ -23,6 +23,8 @@ for c in range(ncases):
     if rng.random() < 0.2: shape = (shape[0], shape[1], int(rng.integers(60, 200)))
     two_d = rng.random() < 0.3     # a 2-D array: generated as one plane of the 3-D field
     if two_d: shape = (1, int(rng.integers(2, 150)), int(rng.integers(2, 300)))
+    one_d = rng.random() < 0.15    # a 1-D array: one row of the field
+    if one_d: two_d = False; shape = (1, 1, int(rng.integers(2, 20000)))
     if shape[0] * shape[1] * shape[2] <= 20: continue
     kind = int(rng.integers(0, 8))
     nz, ny, nx = shape
@@ -44,6 +46,7 @@ for c in range(ncases):
         if rng.random() < 0.5: d[rng.integers(0, nz), rng.integers(0, ny), rng.integers(0, nx)] = 1e5
     d = np.ascontiguousarray(d)
     if two_d: d = d.reshape(shape[1], shape[2])
+    if one_d: d = d.reshape(shape[2])
     mode = int(rng.choice([0, 0, 0, 1, 2, 3]))
     rng_v = float(d.max()) - float(d.min())
     abs_b = float(10.0 ** rng.uniform(-5, -1)) * max(rng_v, 1e-6)
