@@ -101,6 +101,8 @@ int szhip_decompress(szhip_ctx *ctx, int dtype, const unsigned char *stream, int
  * SZ_compress_args_float_NoCkRngeNoGzip_3D (sz_float.c:1422).  `value_range` and `median` are the range scan's results
  * (max - min and min + range/2 in the data's type, dataCompression.c:102-119); `meta` as for szhip_compress, with the flag byte of
  * TightDataPointStorageF.c:600-611.  r0 == 0: a 2-D array r1 x r2 (SZ_compress_float_2D_MDQ, sz_float.c:610-894, called from :896).
+ * r0 == 0 and r1 == 0: a 1-D array of r2 values (SZ_compress_float_1D_MDQ, sz_float.c:353-540, called from :561; doubles:
+ * sz_double.c:260); the caller applies the call site's own raw-store rule (sz_float.c:2908).
  */
 int szhip_compress_sz14(szhip_ctx *ctx, int dtype, const void *data, int data_on_device,
                         size_t r0, size_t r1, size_t r2, double eb, double value_range, double median,
@@ -108,7 +110,8 @@ int szhip_compress_sz14(szhip_ctx *ctx, int dtype, const void *data, int data_on
                         int out_on_device, unsigned char **out, size_t *out_size, szhip_stats *stats);
 /* Inverse: decompressDataSeries_float_3D (sz/src/szd_float.c:600-1138; doubles: szd_double.c) on a TightDataPointStorage stream
  * (parse: TightDataPointStorageF.c:54-265).  `body_off` is the offset of the max_quant_intervals field (4 + 28|36 + 8).
- * r0 == 0: a 2-D array (decompressDataSeries_float_2D, szd_float.c:284-598). */
+ * r0 == 0: a 2-D array (decompressDataSeries_float_2D, szd_float.c:284-598); r0 == 0 and r1 == 0: a 1-D array
+ * (decompressDataSeries_float_1D, szd_float.c:185-282). */
 int szhip_decompress_sz14(szhip_ctx *ctx, int dtype, const unsigned char *stream, int stream_on_device, size_t stream_len,
                           size_t body_off, size_t r0, size_t r1, size_t r2, void *out, int out_on_device, szhip_stats *stats);
 

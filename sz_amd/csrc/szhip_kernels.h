@@ -9,6 +9,7 @@
 //   k_sample             interval-optimiser lattice sampling    sz/src/sz_float.c:6442-6485
 //   k_mean_seq           mean of values near dense_pos          sz/src/sz_float.c:6657-6669
 //   k_pencil             predict + quantise / reconstruct       sz/src/sz_float.c:6719-7374, szd_float.c:3590-5866
+//   k_sample_1d / k_chain_seg_1d / k_chain_1d   1-D arrays      sz/src/sz_float.c:353-540,5070-5111, szd_float.c:185-282
 //   k_hist_u16           Huffman histogram                      sz/src/Huffman.c:165-174
 //   k_permute            type array block ordering              sz/src/sz_float.c:7064,7359
 //   k_unpred             unpredictable-value list               sz/src/sz_float.c:7280,7286 / szd_float.c
