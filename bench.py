@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--edge", type=int, default=EDGE, help="cube edge (512 = the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--other-paths", action="store_true",
-                    help="also time the SZ 1.4 container and a 2-D array (extra kernels: keep it off when profiling the headline kernel)")
+                    help="also time the SZ 1.4 container, a 2-D array and a 1-D series (extra kernels: keep it off when profiling the headline kernel)")
     args = ap.parse_args()
 
     import torch
@@ -172,10 +172,10 @@ def main():
             torch.cuda.synchronize()
             return (time.perf_counter() - t) / reps, r
 
-        def run(fn_name, ptr, dims, extra, mbytes):
+        def run(fn_name, ptr, dims, extra, mbytes, eb=EB):
             out = ctypes.c_void_p(out_buf.data_ptr()); nn = ctypes.c_size_t(out_cap); st = sz_amd.szhip_stats()
             p = sz_amd.szhip_params(100, 0.99, 65536, 0)
-            rc = getattr(sz_amd.lib(), fn_name)(ctx._h, 0, ptr, 1, *dims, EB, *extra, ctypes.byref(p), mbytes, len(mbytes), 2,
+            rc = getattr(sz_amd.lib(), fn_name)(ctx._h, 0, ptr, 1, *dims, eb, *extra, ctypes.byref(p), mbytes, len(mbytes), 2,
                                                 ctypes.byref(out), ctypes.byref(nn), ctypes.byref(st))
             if rc:
                 raise RuntimeError(f"{fn_name} failed: {sz_amd.lib().szhip_last_error(ctx._h)}")
@@ -188,9 +188,20 @@ def main():
         p2 = torch.from_numpy(plane_field(4096, 4096)).to(dev)
         meta2 = sz_amd.make_meta(np.float32, err_mode=sz_amd.ABS, abs_bound=EB, vmin=float(p2.min().item()), vmax=float(p2.max().item()))
         t2, size2 = timed(lambda: run("szhip_compress", p2.data_ptr(), (0, 4096, 4096), (), meta2))
+        # a 1-D series (16 Mi values): a random walk with a sine, resident in HBM; the chain is cut at its certain restarts
+        g = torch.Generator(device="cpu"); g.manual_seed(1)
+        s1 = (torch.cumsum(torch.randn(1 << 24, generator=g, dtype=torch.float64), 0) * 0.01
+              + torch.sin(torch.arange(1 << 24, dtype=torch.float64) * 0.003)).to(torch.float32).to(dev)
+        lo1, hi1 = float(s1.min().item()), float(s1.max().item())
+        rng1 = float(np.float32(np.float32(hi1) - np.float32(lo1)))
+        med1 = float(np.float32(np.float32(lo1) + np.float32(rng1) / np.float32(2)))
+        m1 = sz_amd.make_meta(np.float32, err_mode=sz_amd.ABS, abs_bound=1e-3, vmin=lo1, vmax=hi1)
+        m1 = bytes([m1[0], m1[1], m1[2], 0x40]) + bytes(m1[4:])
+        t1d, size1d = timed(lambda: run("szhip_compress_sz14", s1.data_ptr(), (0, 0, 1 << 24), (rng1, med1), m1, eb=1e-3))
         other = {"sz14_3d_512_f32": {"GB/s": round(nbytes_in / t14 / 1e9, 2), "ms": round(t14 * 1e3, 3), "out_bytes": size14},
-                 "sz21_2d_4096x4096_f32": {"GB/s": round(p2.numel() * 4 / t2 / 1e9, 2), "ms": round(t2 * 1e3, 3), "out_bytes": size2}}
-        del p2
+                 "sz21_2d_4096x4096_f32": {"GB/s": round(p2.numel() * 4 / t2 / 1e9, 2), "ms": round(t2 * 1e3, 3), "out_bytes": size2},
+                 "sz_1d_16Mi_f32_abs1e-3": {"GB/s": round(s1.numel() * 4 / t1d / 1e9, 2), "ms": round(t1d * 1e3, 3), "out_bytes": size1d}}
+        del p2, s1
 
     cpu = None
     if not args.no_cpu_baseline and world == 1:

@@ -187,6 +187,25 @@ def test_1d_segment_check_and_one_wavefront_walk(sz, oracle, dtype, monkeypatch)
     assert np.array_equal(dec.view(np.uint8), want.view(np.uint8))
 
 
+def test_1d_full_size_identical_to_oracle_and_idempotent(sz, oracle):
+    """32 Mi values (the oracle still finishes in a second): stream and decoded values identical; compressing the decoded
+    series again reproduces it exactly where the codes were non-zero (a reconstruction sits on its own quantisation lattice)."""
+    n = 1 << 25
+    rng = np.random.default_rng(11)
+    d = np.cumsum(rng.standard_normal(n)) * 0.01 + np.sin(np.arange(n) * 0.003)
+    d[rng.integers(0, n, 2000)] += 50.0
+    d = np.ascontiguousarray(d.astype(np.float32))
+    ref, _ = oracle.compress(d, 0, 1e-3, 0.0)
+    got = sz.SZ_compress_args(d, 0, 1e-3, 0.0)
+    assert got == ref
+    assert sz.SZ_hip_last_stats().quant_kernel_launches == 1
+    dec = sz.SZ_decompress(got, d.shape, d.dtype)
+    assert np.array_equal(dec.view(np.uint32), oracle.decompress(ref, d.shape, d.dtype).view(np.uint32))
+    assert float(np.abs(dec.astype(np.float64) - d).max()) <= 1e-3 * (1 + 1e-6)
+    again = sz.SZ_decompress(sz.SZ_compress_args(dec, 0, 1e-3, 0.0), d.shape, d.dtype)
+    assert float(np.abs(again.astype(np.float64) - dec).max()) <= 1e-3 * (1 + 1e-6)
+
+
 def test_1d_constant_tiny_and_incompressible_arrays(sz, oracle):
     for d in (np.full(5000, 3.25, dtype=np.float32),                                  # constant: header + one value
               np.arange(20, dtype=np.float64),                                        # <= 20 values: stored as they are

@@ -7,8 +7,9 @@ import oracle_lib as O
 import sz_amd
 assert sz_amd.SZ_Init(os.path.join(ROOT, "tests", "golden", "sz_speed.config")) == 0
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
-for dt, serial in ((np.float32, "0"), (np.float64, "0"), (np.float32, "1")):
-    os.environ["SZ_HIP_1D_SERIAL"] = serial
+for dt, serial in ((np.float32, "0"), (np.float64, "0"), (np.float32, "1"), (np.float32, "one-thread")):
+    os.environ["SZ_HIP_1D_SERIAL"] = "1" if serial == "1" else "0"
+    if serial == "one-thread": os.environ["SZ_HIP_1D_REACH_PCT"] = "100000000"     # no cut ever: one thread walks the array
     rng = np.random.default_rng(1)
     d = np.ascontiguousarray((np.cumsum(rng.standard_normal(n)) * 0.01 + np.sin(np.arange(n) * 0.003)).astype(dt))
     for rep in range(2):
