@@ -396,6 +396,19 @@ __global__ __launch_bounds__(256) void k_sample_1d(const T *__restrict__ data, i
 // (loads, the exact-value reconstruction, stores) is done 64 wide.  The float version re-checks the bound after quantising, the
 // double version does not; positions 0 and 1 are always exact.
 //   DEC = false: data -> codes.          DEC = true: codes + out (exact values already at the code-0 positions) -> out
+// the value lane j holds, handed to every lane: v_readlane_b32 (no LDS round trip in the chain)
+#ifdef SZH_HIPSIM
+template <class T> __device__ __forceinline__ T szh_lane_value(T v, int j) { return __shfl(v, j, 64); }
+#else
+__device__ __forceinline__ int szh_lane_value(int v, int j) { return __builtin_amdgcn_readlane(v, j); }
+__device__ __forceinline__ float szh_lane_value(float v, int j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j)); }
+__device__ __forceinline__ double szh_lane_value(double v, int j)
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, j), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), j);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+#endif
 template <class T, bool DEC>
 __global__ __launch_bounds__(64) void k_chain_1d(const T *__restrict__ data, T *out, uint16_t *codes, int64_t n, T eb, T recip,
                                                  int intervals, T median, int ign_bits)
@@ -414,14 +427,14 @@ __global__ __launch_bounds__(64) void k_chain_1d(const T *__restrict__ data, T *
         const T ex = DEC ? x : szh_keep_bits(x, median, ign_bits);      // what an exact value reconstructs to
 #pragma unroll 16
         for (int j = 0; j < 64; ++j) {
-            const T exj = __shfl(ex, j, 64);
+            const T exj = szh_lane_value(ex, j);
             if (DEC) {
-                const int cj = __shfl(c, j, 64);
+                const int cj = szh_lane_value(c, j);
                 const T step = (T)(cj - radius) * interval;
                 const T p2 = pred + step;
                 pred = cj ? p2 : exj;
             } else {
-                const T xj = __shfl(x, j, 64);
+                const T xj = szh_lane_value(x, j);
                 const T err = szh_abs(xj - pred);
                 int state;
                 if (sizeof(T) == 8) state = (int)((err * recip + 1) * (T)0.5);

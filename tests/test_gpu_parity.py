@@ -456,13 +456,17 @@ def test_corrupt_streams_fail_cleanly(sz, oracle):
     assert sz.SZ_compress_args(d, sz.ABS, 1e-4) == good  # ... and the library is still healthy afterwards
 
 
-def test_corrupt_sz14_streams_fail_cleanly(sz14, oracle):
+@pytest.mark.parametrize("which", ["3-D", "1-D"])
+def test_corrupt_sz14_streams_fail_cleanly(sz14, oracle, which):
     """The same for the SZ 1.4 container: truncation, damaged size fields (type array, exact-value count, mid-byte count), damaged
-    tree, damaged lead / mid / residual sections -- an error or finite garbage, never a hang or a crash."""
+    tree, damaged lead / mid / residual sections -- an error or finite garbage, never a hang or a crash.  Also for a 1-D series
+    (same container; the decoder's segments then start at whatever the damaged code array says)."""
     sz, p = sz14
     from sz_amd.fields import s_field
     rng = np.random.default_rng(4)
     d = s_field(24, 32, 40) + (rng.random((24, 32, 40)).astype(np.float32) - np.float32(0.5)) * np.float32(3e-4)
+    if which == "1-D":
+        d = _series(30720, np.float32, seed=4) * np.float32(1e-2)
     good = sz.SZ_compress_args(d, sz.ABS, 1e-5)
     assert good == oracle.compress(d, oracle.ABS, 1e-5, params=p)[0]
     outcomes = {"error": 0, "decoded": 0}
