@@ -13,6 +13,15 @@ import sim_lib
 from sz_amd.fields import plane_field, s_field
 
 
+def _walk(n, dtype, seed=6):
+    """a 1-D series: random walk with a few jumps (segments of the chain) and a run of zeros"""
+    rng = np.random.default_rng(seed)
+    x = np.cumsum(rng.standard_normal(n)) * 0.01
+    x[rng.integers(0, n, 12)] += 20.0
+    x[n // 2:n // 2 + 40] = 0.0
+    return np.ascontiguousarray(x.astype(dtype))
+
+
 def _noisy(shape, dtype, amp, seed=5):
     rng = np.random.default_rng(seed)
     return s_field(*shape, dtype) + (rng.random(shape).astype(dtype) - dtype(0.5)) * dtype(amp)
@@ -72,13 +81,25 @@ def test_sz14_hip_layer_on_cpu_shim(oracle):
         spike = s_field(16, 16, 16); spike[3, 4, 5] = 1e4; spike[:, :2, :] = 0
         cases = (("smooth", s_field(10, 12, 40), 1e-4), ("noisy", _noisy((9, 17, 33), np.float32, 3e-4), 1e-5),
                  ("noisy-f64", _noisy((12, 10, 24), np.float64, 3e-4), 1e-6), ("spike", spike, 1e-3),
-                 ("2d", plane_field(40, 70), 1e-4), ("2d-f64", plane_field(33, 40, np.float64), 1e-5))   # 2-D: sz_float.c:610 (unpinned)
+                 ("2d", plane_field(40, 70), 1e-4), ("2d-f64", plane_field(33, 40, np.float64), 1e-5),   # 2-D: sz_float.c:610 (unpinned)
+                 ("1d", _walk(3000, np.float32), 1e-3), ("1d-f64", _walk(2500, np.float64), 1e-4))        # 1-D: sz_float.c:353 (unpinned)
         for name, d, eb in cases:
             ref, _ = oracle.compress(d, oracle.ABS, eb, params=p)
             got = sz_amd.SZ_compress_args(d, sz_amd.ABS, eb)
             assert got == ref, name
             dec = sz_amd.SZ_decompress(ref, d.shape, d.dtype)
             assert np.array_equal(dec.view(np.uint8), oracle.decompress(ref, d.shape, d.dtype).view(np.uint8)), name
+        # the 1-D chain's other walks: the whole array by one wavefront, and the segmented walk cut too eagerly (flag -> fallback)
+        d = _walk(1500, np.float32); ref, _ = oracle.compress(d, oracle.ABS, 1e-3, params=p)
+        for knob, val in (("SZ_HIP_1D_SERIAL", "1"), ("SZ_HIP_1D_REACH_PCT", "3")):
+            os.environ[knob] = val
+            try:
+                assert sz_amd.SZ_compress_args(d, sz_amd.ABS, 1e-3) == ref, knob
+                assert sz_amd.SZ_hip_last_stats().quant_kernel_launches == 2, knob
+                dec = sz_amd.SZ_decompress(ref, d.shape, d.dtype)
+                assert np.array_equal(dec.view(np.uint8), oracle.decompress(ref, d.shape, d.dtype).view(np.uint8)), knob
+            finally:
+                del os.environ[knob]
         sz_amd.SZ_Finalize()
     finally:
         api._lib = saved
