@@ -463,12 +463,13 @@ __global__ __launch_bounds__(64) void k_chain_1d(const T *__restrict__ data, T *
 // takes the exact branch whatever it carries.  One THREAD per such segment walks it; the thread checks, with the value it really
 // carries, that the next segment's first value does take the exact branch, and raises `violation` otherwise (the caller then
 // walks the array with k_chain_1d).  With every check passed the segments are the serial walk, by induction from position 0.
+// (evaluated in T: how sharp this test is decides only how often the fallback runs, and both users hand it the same two values)
 template <class T>
-__device__ __forceinline__ bool szh_certain_restart(T prev, T cur, double reach, double rel)
+__device__ __forceinline__ bool szh_certain_restart(T prev, T cur, T reach, T rel)
 {
-    const double a = (double)prev, b = (double)cur;
-    const double m = fmax(fabs(a), fabs(b));
-    return fabs(a - b) > reach + m * rel;      // false for NaN: such places stay inside a segment
+    const T pa = szh_abs(prev), ca = szh_abs(cur);
+    const T m = pa > ca ? pa : ca;
+    return szh_abs(prev - cur) > reach + m * rel;      // false for NaN: such places stay inside a segment
 }
 template <class T, bool DEC>
 __global__ __launch_bounds__(256) void k_chain_seg_1d(const T *__restrict__ data, T *out, uint16_t *codes, int64_t n, T eb, T recip,
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(256) void k_chain_seg_1d(const T *__restrict__ data
     const int radius = intervals / 2;
     const T check_radius = (T)((unsigned)(intervals - 1)) * eb, interval = 2 * eb;
     // reach_scale = 1; a test shrinks it to cut where the chain does NOT restart, which the check below must catch
-    const double reach = (double)check_radius * reach_scale + 4.0 * (double)eb, rel = sizeof(T) == 8 ? 0x1p-48 : 0x1p-19;
+    const T reach = (T)((double)check_radius * reach_scale + 4.0 * (double)eb), rel = sizeof(T) == 8 ? (T)0x1p-48 : (T)0x1p-19;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         if (DEC) {
             if (i != 0 && codes[i] != 0) continue;
@@ -497,8 +498,12 @@ __global__ __launch_bounds__(256) void k_chain_seg_1d(const T *__restrict__ data
             T x = data[i];
             if (i != 0 && !szh_certain_restart<T>(data[i - 1], x, reach, rel)) continue;
             T pred = 0;
+            // loads run four values ahead of the walk (the chain's arithmetic hides one L1 round trip, not an HBM one)
+            T x1 = i + 1 < n ? data[i + 1] : (T)0, x2 = i + 2 < n ? data[i + 2] : (T)0, x3 = i + 3 < n ? data[i + 3] : (T)0;
+#pragma unroll 4
             for (int64_t j = i;;) {
-                const T xn = j + 1 < n ? data[j + 1] : (T)0;
+                const T x4 = j + 4 < n ? data[j + 4] : (T)0;
+                const T xn = x1;
                 const T err = szh_abs(x - pred);
                 int state;
                 if (sizeof(T) == 8) state = (int)((err * recip + 1) * (T)0.5);
@@ -515,7 +520,7 @@ __global__ __launch_bounds__(256) void k_chain_seg_1d(const T *__restrict__ data
                     if (szh_abs(xn - pred) < check_radius) atomicOr(violation, 1u);
                     break;
                 }
-                x = xn;
+                x = xn; x1 = x2; x2 = x3; x3 = x4;
             }
         }
     }
