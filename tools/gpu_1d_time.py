@@ -7,7 +7,9 @@ import oracle_lib as O
 import sz_amd
 assert sz_amd.SZ_Init(os.path.join(ROOT, "tests", "golden", "sz_speed.config")) == 0
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
-for dt, serial in ((np.float32, "0"), (np.float64, "0"), (np.float32, "1"), (np.float32, "one-thread")):
+configs = ((np.float32, "0"), (np.float64, "0"), (np.float32, "1"), (np.float32, "one-thread"))
+if os.environ.get("ONLY_SEG"): configs = configs[:2]          # under the profiler: the segmented walk only
+for dt, serial in configs:
     os.environ["SZ_HIP_1D_SERIAL"] = "1" if serial == "1" else "0"
     if serial == "one-thread": os.environ["SZ_HIP_1D_REACH_PCT"] = "100000000"     # no cut ever: one thread walks the array
     rng = np.random.default_rng(1)
