@@ -495,33 +495,38 @@ __global__ __launch_bounds__(256) void k_chain_seg_1d(const T *__restrict__ data
             }
         } else {
             if (i == 1) continue;
-            T x = data[i];
-            if (i != 0 && !szh_certain_restart<T>(data[i - 1], x, reach, rel)) continue;
-            T pred = 0;
-            // loads run four values ahead of the walk (the chain's arithmetic hides one L1 round trip, not an HBM one)
-            T x1 = i + 1 < n ? data[i + 1] : (T)0, x2 = i + 2 < n ? data[i + 2] : (T)0, x3 = i + 3 < n ? data[i + 3] : (T)0;
-#pragma unroll 4
-            for (int64_t j = i;;) {
-                const T x4 = j + 4 < n ? data[j + 4] : (T)0;
-                const T xn = x1;
+            T prev = data[i];
+            if (i != 0 && !szh_certain_restart<T>(data[i - 1], prev, reach, rel)) continue;
+            // the segment's first value is exact by construction (and so is position 1, which belongs to the segment of position 0)
+            T pred = szh_keep_bits(prev, median, ign_bits);
+            codes[i] = 0;
+            int64_t j = i + 1;
+            if (i == 0 && n > 1) { prev = data[1]; pred = szh_keep_bits(prev, median, ign_bits); codes[1] = 0; j = 2; }
+            // one block per value, one exit test per trip: a lone wavefront issues an instruction about every four cycles, so what the
+            // walk costs is its instruction count -- selects instead of branches, a clamped index instead of a guarded load
+            const int64_t last = n - 1;
+            T x = data[j < last ? j : last];
+            bool go = j < n && !szh_certain_restart<T>(prev, x, reach, rel);
+            while (go) {
+                const T xn = data[j + 1 < last ? j + 1 : last];     // in flight during this value's arithmetic
                 const T err = szh_abs(x - pred);
                 int state;
                 if (sizeof(T) == 8) state = (int)((err * recip + 1) * (T)0.5);
                 else state = ((int)(err * recip + 1)) >> 1;
                 const T step = (T)state * interval;
                 const bool up = x >= pred;
-                const T p2 = up ? pred + step : pred - step;
-                bool ok = err < check_radius && j >= 2 && j != i;
+                const T p2 = pred + (up ? step : -step);            // pred - step and pred + (-step) are the same IEEE operation
+                bool ok = err < check_radius;
                 if (sizeof(T) == 4) ok = ok && !(szh_abs(x - p2) > eb);
-                pred = ok ? p2 : szh_keep_bits(x, median, ign_bits);
-                codes[j] = (uint16_t)(ok ? (up ? radius + state : radius - state) : 0);
-                if (++j >= n) break;
-                if (j >= 2 && szh_certain_restart<T>(x, xn, reach, rel)) {
-                    if (szh_abs(xn - pred) < check_radius) atomicOr(violation, 1u);
-                    break;
-                }
-                x = xn; x1 = x2; x2 = x3; x3 = x4;
+                const T ex = szh_keep_bits(x, median, ign_bits);
+                pred = ok ? p2 : ex;
+                const int q = radius + (up ? state : -state);
+                codes[j] = (uint16_t)(q & -(int)ok);
+                prev = x; x = xn; ++j;
+                go = j < n && !szh_certain_restart<T>(prev, x, reach, rel);
             }
+            // stopped before the end: the next segment starts here -- check, with the state really carried, that it does
+            if (j < n && szh_abs(x - pred) < check_radius) atomicOr(violation, 1u);
         }
     }
 }
