@@ -481,17 +481,19 @@ __global__ __launch_bounds__(256) void k_chain_seg_1d(const T *__restrict__ data
     const T reach = (T)((double)check_radius * reach_scale + 4.0 * (double)eb), rel = sizeof(T) == 8 ? (T)0x1p-48 : (T)0x1p-19;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         if (DEC) {
-            if (i != 0 && codes[i] != 0) continue;
-            T pred = 0;
-            int c = codes[i];
-            for (int64_t j = i;;) {
-                const T step = (T)(c - radius) * interval;
-                const T p2 = pred + step;
-                pred = c ? p2 : out[j];
+            const int c0 = codes[i];
+            if (i != 0 && c0 != 0) continue;
+            // the segment's first value is there already (a damaged stream may put a non-zero code at position 0: predicted from 0)
+            T pred = c0 ? (T)(c0 - radius) * interval : out[i];
+            if (c0) out[i] = pred;
+            const int64_t last = n - 1;
+            int64_t j = i + 1;
+            int c = codes[j < last ? j : last];
+            while (j < n && c != 0) {                                // one block per value, as in the encoder's walk
+                const int cn = codes[j + 1 < last ? j + 1 : last];
+                pred = pred + (T)(c - radius) * interval;
                 out[j] = pred;
-                if (++j >= n) break;
-                c = codes[j];
-                if (c == 0) break;
+                c = cn; ++j;
             }
         } else {
             if (i == 1) continue;
