@@ -18,6 +18,11 @@
  * terms as zeros is exact) EXCEPT on the very first row, where it is P[0] for j = 1 and 2P[j-1] - P[j-2] beyond (:1034, :1072).
  * The first value is always stored "exactly".  "Exact" values are lossy: the value minus the median keeps its reqLength leading
  * bits, and THAT is what the neighbours see.
+ *
+ * Pinning: the 3-D path is pinned to a recorded output of the unmodified reference (tests/test_oracle_pins.py).  The 2-D path
+ * (r1 == 1) and the 1-D path (r1 == r2 == 1: SZ_compress_float_1D_MDQ, sz_float.c:353-540, its optimiser :5070-5111, inverse
+ * szd_float.c:185-282; doubles sz_double.c:260-400, :4747) share the pinned container and exact-value code but have no recorded
+ * reference output of their own: PARITY UNPINNED for 2-D and 1-D.
  */
 
 #ifndef SZO_CAT
