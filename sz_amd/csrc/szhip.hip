@@ -666,15 +666,16 @@ int parse_header(const unsigned char *hs, size_t avail, size_t stream_len, size_
             const unsigned char *tree_at = q;
             q += ts;
             NEED(8);
-            const size_t enc = (size_t)szhost_get_u64be(q); q += 8;
+            const uint64_t enc64 = szhost_get_u64be(q); q += 8;
+            if (enc64 > (uint64_t)(stream_len - (size_t)(q - hs))) PFAIL(SZHIP_ERR_STREAM, "truncated stream");   // before any size arithmetic on it
+            const size_t enc = (size_t)enc64;
             NEED(enc);
             szhost_huff *ch = szhost_huff_from_bytes(4 * crad[e], tree_at, cnc);
             if (!ch) PFAIL(SZHIP_ERR_STREAM, "bad coefficient tree");
             ccodes[e].resize(H.reg_count);
-            {   // decode from a zero-padded copy so that a corrupt stream cannot run off the end
-                std::vector<unsigned char> tmp(enc + 16, 0);
-                memcpy(tmp.data(), q, enc);
-                szhost_huff_decode_i32(ch, tmp.data(), H.reg_count, ccodes[e].data());
+            if (!szhost_huff_decode_i32(ch, q, enc, H.reg_count, ccodes[e].data())) {   // bounded by the section's own length
+                szhost_huff_free(ch);
+                PFAIL(SZHIP_ERR_STREAM, "coefficient payload too short");
             }
             szhost_huff_free(ch);
             cptr[e] = ccodes[e].data();
@@ -682,6 +683,11 @@ int parse_header(const unsigned char *hs, size_t avail, size_t stream_len, size_
             NEED(4);
             const unsigned cu = szhost_get_u32be(q); q += 4;
             NEED((size_t)cu * sizeof(T));
+            {   // every zero code takes one verbatim coefficient (szd_float.c:5809-5820): the list must hold them all
+                size_t zeros = 0;
+                for (size_t i = 0; i < H.reg_count; ++i) zeros += ccodes[e][i] == 0;
+                if (zeros > cu) PFAIL(SZHIP_ERR_STREAM, "coefficient section lists %u verbatim values, codes need %zu", cu, zeros);
+            }
             cun[e] = q; q += (size_t)cu * sizeof(T);
         }
         // compact [4][reg_count] in scan order; the device scatters them to the blocks (k_move_coef)

@@ -83,29 +83,37 @@ void szhost_huff_free(szhost_huff *h)
     free(h->code); free(h->len); free(h->L); free(h->R); free(h->C); free(h->t); free(h);
 }
 
-/* assign codes by walking the serialised (pre-order) tree: left edge 0, right edge 1 */
+/* assign codes by walking the serialised (pre-order) tree: left edge 0, right edge 1.
+ * The arrays may come from an untrusted stream: every node must be reached exactly once, an internal node has two children with
+ * larger (pre-order) indices, so the walk can neither cycle nor outgrow its stacks. */
 static int huff_codes_from_arrays(szhost_huff *h)
 {
     int n = h->n_nodes;
-    uint32_t *stk = (uint32_t *)malloc((size_t)(n + 1) * sizeof(uint32_t));
-    uint64_t *sbits = (uint64_t *)malloc((size_t)(n + 1) * sizeof(uint64_t));
-    uint8_t *slen = (uint8_t *)malloc((size_t)(n + 1));
-    int sp = 0, ok = 1;
-    stk[0] = 0; sbits[0] = 0; slen[0] = 0; sp = 1;
-    while (sp) {
+    uint32_t *stk = (uint32_t *)malloc((size_t)(n + 2) * sizeof(uint32_t));
+    uint64_t *sbits = (uint64_t *)malloc((size_t)(n + 2) * sizeof(uint64_t));
+    uint8_t *slen = (uint8_t *)malloc((size_t)(n + 2));
+    uint8_t *seen = (uint8_t *)calloc((size_t)n + 1, 1);
+    int sp = 0, ok = stk && sbits && slen && seen;
+    int visited = 0;
+    if (ok) { stk[0] = 0; sbits[0] = 0; slen[0] = 0; sp = 1; seen[0] = 1; }
+    while (ok && sp) {
         sp--;
         uint32_t nd = stk[sp]; uint64_t bits = sbits[sp]; int len = slen[sp];
+        visited++;
         if (h->t[nd]) {
             if (len > 64 || h->C[nd] >= (uint32_t)h->state_num) { ok = 0; break; }
             h->code[h->C[nd]] = bits;
             h->len[h->C[nd]] = (uint8_t)len;
             continue;
         }
-        if (len >= 64) { ok = 0; break; }
-        if (h->R[nd]) { stk[sp] = h->R[nd]; sbits[sp] = (bits << 1) | 1; slen[sp] = (uint8_t)(len + 1); sp++; }
-        if (h->L[nd]) { stk[sp] = h->L[nd]; sbits[sp] = bits << 1; slen[sp] = (uint8_t)(len + 1); sp++; }
+        const uint32_t l = h->L[nd], r = h->R[nd];
+        if (len >= 64 || l <= nd || r <= nd || l >= (uint32_t)n || r >= (uint32_t)n || l == r || seen[l] || seen[r]) { ok = 0; break; }
+        seen[l] = seen[r] = 1;
+        stk[sp] = r; sbits[sp] = (bits << 1) | 1; slen[sp] = (uint8_t)(len + 1); sp++;
+        stk[sp] = l; sbits[sp] = bits << 1; slen[sp] = (uint8_t)(len + 1); sp++;
     }
-    free(stk); free(sbits); free(slen);
+    if (ok && visited != n) ok = 0;   /* unreachable nodes: not a tree of n nodes */
+    free(stk); free(sbits); free(slen); free(seen);
     return ok;
 }
 
@@ -261,15 +269,18 @@ size_t szhost_huff_encode_i32(const szhost_huff *h, const int *s, size_t n, unsi
     return o;
 }
 
-void szhost_huff_decode_i32(const szhost_huff *h, const unsigned char *in, size_t n, int *out)
+int szhost_huff_decode_i32(const szhost_huff *h, const unsigned char *in, size_t in_bytes, size_t n, int *out)
 {
-    if (h->t[0]) { for (size_t i = 0; i < n; i++) out[i] = (int)h->C[0]; return; }
+    if (h->t[0]) { for (size_t i = 0; i < n; i++) out[i] = (int)h->C[0]; return 1; }
+    const size_t max_bits = in_bytes * 8;
     size_t bit = 0, cnt = 0; uint32_t nd = 0;
     while (cnt < n) {
+        if (bit >= max_bits) return 0;               /* the payload ends before n symbols: corrupt stream */
         int b = (in[bit >> 3] >> (7 - (bit & 7))) & 1; bit++;
         nd = b ? h->R[nd] : h->L[nd];
         if (h->t[nd]) { out[cnt++] = (int)h->C[nd]; nd = 0; }
     }
+    return 1;
 }
 
 /* ------------------------------------------------------------------ interval decision */

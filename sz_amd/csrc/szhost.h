@@ -32,7 +32,8 @@ size_t szhost_huff_tree_size(const szhost_huff *h);                 /* serialise
 size_t szhost_huff_serial_size(int node_count);                     /* serialised size of a tree with that many nodes */
 void   szhost_huff_tree_write(const szhost_huff *h, unsigned char *out);
 size_t szhost_huff_encode_i32(const szhost_huff *h, const int *s, size_t n, unsigned char *out);
-void   szhost_huff_decode_i32(const szhost_huff *h, const unsigned char *in, size_t n, int *out);
+/* decodes n symbols from at most in_bytes bytes; returns 0 if the payload runs out first (corrupt stream) */
+int    szhost_huff_decode_i32(const szhost_huff *h, const unsigned char *in, size_t in_bytes, size_t n, int *out);
 /* device decode table: entry[2*node+bit] = child index, or 0x80000000|symbol when the child is a leaf */
 void   szhost_huff_decode_table(const szhost_huff *h, uint32_t *table);
 void   szhost_huff_free(szhost_huff *h);
