@@ -15,7 +15,8 @@ _CSRC = os.path.join(_HERE, "csrc")
 
 
 def lib_path():
-    return os.path.join(_CSRC, "libszhip.so")
+    """The product library; SZ_AMD_LIB names another build of it (development: libszhip_dev.so, variants)."""
+    return os.environ.get("SZ_AMD_LIB") or os.path.join(_CSRC, "libszhip.so")
 
 
 class SZError(RuntimeError):

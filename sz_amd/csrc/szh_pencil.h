@@ -55,6 +55,8 @@ template <class T> struct szh_qargs {
     T median;                 // fmt 1: exact values are kept as reqLength leading bits of (x - median)
     int ign_bits;             // fmt 1: 8*sizeof(T) - reqLength, >= 0
     int backoff;              // FILL wavefront: sleep units between two rounds that delivered nothing
+    int wide;                 // 1: the granule rows of a tile lie within 4 GB of the tile's first row: 16-byte buffer accesses with 32-bit offsets
+    int trace_tile;           // development: (TI << 16) | TJ of the tile whose left-hand hand-off is logged round by round (SZH_TRACE_LOG)
     int dbg;                  // development: 1 = no hand-off at all (timing only, results become WRONG), 4 = no issue priorities
     szh_u64 *trace;           // optional (development): per pencil {t_start, t_start, t_first_trip, t_end, wait spins, -, xcc, 0} + per-trip detail
 };
@@ -94,13 +96,20 @@ template <class T> struct szh_tile_lds {
     T *faces;                 // [NP + NV][SZH_FROWS][row stride] face rings: rows 0-7 = J-face (il), 8-15 = I-face (jl), 16 = corner column;
                               // the row stride (RL + 2) spreads the skewed columns of neighbouring rows over different LDS banks
                               // forwarded to the pencil below
-    int ftrash;               // element offset in faces[] of 64 write-only / don't-care slots (one per lane): masked-off lanes go there,
-                              // so that the ring accesses need no exec-mask juggling
+    int ftrash;               // element offset in faces[] of 64 x (SZH_U + 1) write-only slots (SZH_U + 1 per lane): lanes without a face row
+                              // store there, so that the ring accesses need no exec-mask juggling (SZH_FTRASH elements)
     unsigned *cstep;          // [NP + NV] steps completed (all face values of those steps are in the ring); virtual: same scale, by FILL
     unsigned *spubJ, *spubI;  // [NP] columns of the J- / I-face already forwarded by STORE (ring space for the producer)
     int *scratch;             // [2][64] helper wavefronts (STORE, FILL): per-row values for a per-slot minimum
 };
 #define SZH_FROWS 17
+
+// development plumbing (timing-only "free run", per-pencil trace stamps) is compiled out of the production library; `make dev`
+// builds libszhip_dev.so with it (SZ_HIP_DBG / SZ_HIP_TRACE, tools/gpu_trace.py)
+#ifndef SZH_DEV
+#define SZH_DEV 0
+#endif
+#define SZH_TRACE_LOG 2048   /* entries {clock, value} per hand-off log (development): producer steps, STORE rounds, FILL rounds, consumer steps */
 
 #define SZH_U 16 /* steps per loop trip: a trip first requests all of its inputs (values and halo granules), then steps */
 #if defined(__HIPCC__)
@@ -109,6 +118,7 @@ template <class T> struct szh_tile_lds {
 #define SZH_UNROLL
 #endif
 #define SZH_FORL for (int l = 0; l < NL; ++l)
+#define SZH_FTRASH (64 * (SZH_U + 1))
 #define SZH_XC 32 /* columns of the per-pencil LDS code ring ([column % SZH_XC][lane]); column SZH_XC is a write-only trash column */
 
 // branch-free form of szh_quant_point (same arithmetic, same results)
@@ -160,8 +170,10 @@ SZH_HD int szh_quant_sel14(T x, T pred, T eb, T recip, int capacity, int radius,
     return ok ? q + radius : 0;
 }
 
-// B: back end. Requires: NL, lane(l), shfl_up(dst,src,d), readlane(src,lane), all(pred),
+// B: back end. Requires: NL, lane(l), shfl_up(dst,src,d), shfl_up1(dst,src) (d = 1; lanes with lane % 8 == 0 may receive anything),
+//    readlane(src,lane), all(pred), lds_order(), touch(v) (the value must be in its register here),
 //    ld_gran(p), st_gran(p,v), ld_flag(p), st_flag(p,v), backoff(n), nap(), clock(), where(),
+//    gbuf_t, make_gbuf(base), ld_gran2_b(buf, byte offset, a, b), st_gran2_b(...): two granules in one 16-byte access relative to a wavefront-uniform base,
 //    ld16(p, T(&)[16/sizeof T]), st16(p, const T(&)[...]) -- one 16-byte vector access (4-byte aligned for 4/8-byte T),
 //    lds_ld(p), lds_st(p,v), lds_ld_u(p) (wavefront-uniform address), lds_fence() (orders this wavefront's LDS accesses),
 //    RL / ring(k) (face-ring length), face_stride(r2) (elements per ring), TPI / TPJ (tile shape).
@@ -180,18 +192,21 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
 {
     static_assert(FMT == 0 || (!HASREG && !USEMEAN), "the SZ 1.4 path has neither blocks nor the mean shortcut");
     constexpr int NL = B::NL;
+    static_assert(B::RL % SZH_U == 0, "a trip must not wrap the face rings: ring(t0 + s) = ring(t0) + s");
     const szh_geom3 &G = a.G;
     const int r0 = G.g0.count, r1 = G.g1.count, r2 = G.g2.count;
     const int nbz = G.g2.num;
     const int cap_lor = a.cap - 2, cap_reg = a.cap, radius = a.radius;
     const T eb = a.eb, recip = a.recip, mean = a.mean;
-    const bool free_run = a.dbg == 1;   // development: no hand-off at all (timing only, results are wrong)
-    const bool pubJ = (J + 1 < a.nJ) && !free_run, pubI = (I + 1 < a.nI) && !free_run;
+    const bool free_run = SZH_DEV && a.dbg == 1;   // development: no hand-off at all (timing only, results are wrong)
+    szh_u64 *const trace = SZH_DEV ? a.trace : nullptr;
     const int pi = I % B::TPI, pj = J % B::TPJ;
+    const bool cut = SZH_DEV && a.dbg == 2;     // development: tiles cut apart (no hand-off across tile boundaries; timing only, results are wrong)
+    const bool pubJ = (J + 1 < a.nJ) && !free_run && !(cut && pj == B::TPJ - 1), pubI = (I + 1 < a.nI) && !free_run && !(cut && pi == B::TPI - 1);
     const int myslot = szh_slot<B>(I, J);
     uint16_t *const cring = L.cring + (size_t)myslot * (SZH_XC + 1) * 64;
     // producers: a pencil of this tile, or the virtual producer the FILL wavefront keeps filled
-    const bool hasPJ = J > 0 && !free_run, hasPI = I > 0 && !free_run;
+    const bool hasPJ = J > 0 && !free_run && !(cut && pj == 0), hasPI = I > 0 && !free_run && !(cut && pi == 0);
     const int slotPJ = pj > 0 ? myslot - 1 : szh_vslot_left<B>(I), slotPI = pi > 0 ? myslot - B::TPJ : szh_vslot_top<B>(J);
     // consumers: a pencil of this tile (its step counter tells which ring slots it has read), or the STORE wavefront
     const bool consJ_in = pubJ && pj + 1 < B::TPJ, consI_in = pubI && pi + 1 < B::TPI;
@@ -199,10 +214,11 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
     const int mybase = myslot * stride;
 
     // ---- per-lane constants ----
-    int il[NL], jl[NL], skew[NL], hskew[NL], hlds[NL], hrd[NL], pjb[NL], pib[NL], pcb[NL], trash[NL], ctrash[NL];
-    bool inb[NL];
+    int il[NL], jl[NL], skew[NL], askew[NL], hsk[NL], hrd[NL], st1[NL], st2[NL], cidx[NL], ctrash[NL];
+    bool inb[NL], corner[NL];
     int64_t rowoff[NL], blkrow[NL];
     T fii[NL], fjj[NL];
+    constexpr int NEVER = -(1 << 30);          // as a skew: (unsigned)(t - NEVER) < r2 never holds
     SZH_FORL {
         const int lane = B::lane(l);
         il[l] = lane >> 3; jl[l] = lane & 7;
@@ -215,19 +231,32 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
         rowoff[l] = (int64_t)ic * G.d0 + (int64_t)jc * G.d1;
         blkrow[l] = ((int64_t)b0 * G.g1.num + b1) * nbz;
         skew[l] = il[l] + jl[l];
-        trash[l] = L.ftrash + lane; ctrash[l] = SZH_XC * 64 + lane;
-        // halo role: which face row this lane reads (for k = t - hskew); hlds = element offset of that row in faces[], -1: none
-        hskew[l] = 0; hlds[l] = -1;
-        if (jl[l] == 0 && hasPJ && i < r0) { hskew[l] = il[l]; hlds[l] = slotPJ * stride + il[l] * RS; }                   // (i, 8J-1, k): J-face of (I,J-1), row il
-        else if (il[l] == 0 && jl[l] > 0 && hasPI && j < r1) { hskew[l] = jl[l]; hlds[l] = slotPI * stride + (8 + jl[l]) * RS; } // (8I-1, j, k): I-face of (I-1,J), row jl
-        else if (lane == 63 && hasPI) hlds[l] = slotPI * stride + 8 * RS;                                                   // for lane 0: (8I-1, 8J, k)
-        else if (lane == 62 && hasPI && hasPJ) hlds[l] = slotPI * stride + 16 * RS;                                         // for lane 0: (8I-1, 8J-1, k), forwarded by (I-1,J)
-        hrd[l] = hlds[l] >= 0 ? hlds[l] : 0;   // lanes without a halo row read (and discard) some valid slot
-        // rows of the own ring this lane writes (-1: none): J-face row il, I-face row jl, forwarded corner column
-        pjb[l] = (pubJ && jl[l] == 7 && inb[l]) ? mybase + il[l] * RS : -1;
-        pib[l] = (pubI && il[l] == 7 && inb[l]) ? mybase + (8 + jl[l]) * RS : -1;
-        pcb[l] = (pubI && hasPJ && il[l] == 7 && jl[l] == 0 && inb[l]) ? mybase + 16 * RS : -1;
+        askew[l] = inb[l] ? skew[l] : NEVER;                  // "this lane has a point at step t": (unsigned)(t - askew) < r2
+        const int trash = L.ftrash + lane * (SZH_U + 1);      // SZH_U + 1 write-only face slots per lane (odd stride: no bank conflicts)
+        ctrash[l] = SZH_XC * 64 + lane;
+        cidx[l] = lane - (skew[l] << 6);                      // code-ring slot of column k = t - skew: ((t << 6) + cidx) mod (SZH_XC * 64)
+        // halo role: which face row this lane reads (for k = t - hsk); hlds = element offset of that row in faces[], -1: none
+        int hskew = 0, hlds = -1;
+        if (jl[l] == 0 && hasPJ && i < r0) { hskew = il[l]; hlds = slotPJ * stride + il[l] * RS; }                   // (i, 8J-1, k): J-face of (I,J-1), row il
+        else if (il[l] == 0 && jl[l] > 0 && hasPI && j < r1) { hskew = jl[l]; hlds = slotPI * stride + (8 + jl[l]) * RS; } // (8I-1, j, k): I-face of (I-1,J), row jl
+        else if (lane == 63 && hasPI) hlds = slotPI * stride + 8 * RS;                                              // for lane 0: (8I-1, 8J, k)
+        else if (lane == 62 && hasPI && hasPJ) hlds = slotPI * stride + 16 * RS;                                    // for lane 0: (8I-1, 8J-1, k), forwarded by (I-1,J)
+        hsk[l] = hlds >= 0 ? hskew : NEVER;
+        hrd[l] = hlds >= 0 ? hlds : 0;         // lanes without a halo row read (and discard) some valid slot
+        // face stores.  A lane's value goes into the ring row of its role at the position of the step (whether or not the step
+        // is inside the lane's k range: positions outside it are never read -- consumers and the STORE wavefront check the range
+        // themselves), so the address is `row base + ring(t)`: one add per TRIP and an immediate offset per step.
+        //   first store : J-face row il (lanes jl = 7), else I-face row jl (lanes il = 7)
+        //   second store: I-face row 7 for lane (7,7) when it also owns a J-face row; the corner column (the lane's HALO value) for lane (7,0)
+        const int pjb = (pubJ && jl[l] == 7 && inb[l]) ? mybase + il[l] * RS : -1;
+        const int pib = (pubI && il[l] == 7 && inb[l]) ? mybase + (8 + jl[l]) * RS : -1;
+        const int pcb = (pubI && hasPJ && il[l] == 7 && jl[l] == 0 && inb[l]) ? mybase + 16 * RS : -1;
+        corner[l] = pcb >= 0;
+        st1[l] = pjb >= 0 ? pjb : (pib >= 0 ? pib : trash);
+        st2[l] = (pjb >= 0 && pib >= 0) ? pib : (pcb >= 0 ? pcb : trash);
+        (void)hskew;
     }
+    const int ftrash0 = L.ftrash;
 
     // ---- per-lane block tracking along dim2 (only when the pencil touches regression blocks) ----
     int kk[NL], bz[NL], bk[NL];
@@ -258,23 +287,34 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
     //      and are moved between ring and HBM as aligned 16-byte row segments.
     constexpr int VPT = 16 / (int)sizeof(T);      // values per 16-byte vector
     constexpr int NVEC = SZH_U / VPT;             // vectors per lane per trip
-    T xr[SZH_U][NL];                              // compress: originals; decompress: pre-scattered values in, reconstruction out
+    // compress: originals; decompress: pre-scattered values in, reconstruction out.  Two buffers: while a trip steps through one, the
+    // NEXT trip's values are on their way into the other (compress), so the sweep never waits for HBM at the top of a trip -- and,
+    // since a wavefront's loads and stores return in issue order, never for the acknowledgement of the code stores issued before them
+    typedef T xbuf_t[SZH_U][NL];
+    xbuf_t xr0, xr1;
     const bool vec_codes = (r2 % 8) == 0;         // rows of the u16 code array are 16-byte aligned
 
     // decompress: which columns of this lane's OWN row (row = lane, as in move_codes) hold a zero code, one bit per ring column.
     // Only those positions need the pre-scattered value, so a lane fetches its 16 values of a trip only when one of them does.
     unsigned zcols[NL];
     SZH_FORL zcols[l] = 0;
-    auto load_x = [&](int t0) {
+    const bool no_ld = SZH_DEV && (a.dbg == 3 || a.dbg == 5), no_st = SZH_DEV && (a.dbg == 3 || a.dbg == 4);   // development: the sweep loads / stores nothing (timing only, results are wrong)
+    auto load_x = [&](int t0, xbuf_t &xr) {
         const T *src = DEC ? a.out : a.data;
-        SZH_FORL {
-            const int k0 = t0 - skew[l];
-            if (DEC && SZH_XC == 32) {
-                const unsigned sh = (unsigned)k0 & 31u;
-                const unsigned win = (zcols[l] >> sh) | (sh ? zcols[l] << (32u - sh) : 0u);      // bit s = column k0 + s
-                if ((win & 0xffffu) == 0) continue;                                              // no unpredictable value in this lane's trip
-            }
-            if (inb[l] && k0 >= 0 && k0 + SZH_U <= r2) {
+        if (no_ld) { SZH_FORL { SZH_UNROLL for (int s = 0; s < SZH_U; ++s) xr[s][l] = (T)0; } return; }
+        // interior trips: the SZH_U columns of every lane (skews 0..14) lie inside its row, so the whole wavefront takes the vector
+        // path -- a wavefront-uniform branch (a per-lane choice between the two paths makes hipcc wait for the vector loads before
+        // it issues the other path's loads into the same registers, which would undo the prefetch).  Lanes outside the array load
+        // their clamped row: their values reach nothing (no code, no face, no valid neighbour).
+        const bool interior = t0 >= SZH_U && t0 + SZH_U <= r2;
+        if (interior) {
+            SZH_FORL {
+                const int k0 = t0 - skew[l];
+                if (DEC && SZH_XC == 32) {
+                    const unsigned sh = (unsigned)k0 & 31u;
+                    const unsigned win = (zcols[l] >> sh) | (sh ? zcols[l] << (32u - sh) : 0u);      // bit s = column k0 + s
+                    if ((win & 0xffffu) == 0) continue;                                              // no unpredictable value in this lane's trip
+                }
                 SZH_UNROLL
                 for (int v = 0; v < NVEC; ++v) {
                     T tmp[VPT];
@@ -282,7 +322,10 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
                     SZH_UNROLL
                     for (int e = 0; e < VPT; ++e) xr[v * VPT + e][l] = tmp[e];
                 }
-            } else {
+            }
+        } else {
+            SZH_FORL {
+                const int k0 = t0 - skew[l];
                 SZH_UNROLL
                 for (int s = 0; s < SZH_U; ++s) {
                     const int k = k0 + s;
@@ -291,18 +334,25 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
             }
         }
     };
-    auto store_out = [&](int t0) {
-        SZH_FORL {
-            const int k0 = t0 - skew[l];
-            if (inb[l] && k0 >= 0 && k0 + SZH_U <= r2) {
-                SZH_UNROLL
-                for (int v = 0; v < NVEC; ++v) {
-                    T tmp[VPT];
+    auto store_out = [&](int t0, xbuf_t &xr) {
+        if (no_st) return;
+        const bool interior = t0 >= SZH_U && t0 + SZH_U <= r2;   // wavefront-uniform, as in load_x
+        if (interior) {
+            SZH_FORL {
+                const int k0 = t0 - skew[l];
+                if (inb[l]) {
                     SZH_UNROLL
-                    for (int e = 0; e < VPT; ++e) tmp[e] = xr[v * VPT + e][l];
-                    B::st16(a.out + rowoff[l] + k0 + v * VPT, tmp);
+                    for (int v = 0; v < NVEC; ++v) {
+                        T tmp[VPT];
+                        SZH_UNROLL
+                        for (int e = 0; e < VPT; ++e) tmp[e] = xr[v * VPT + e][l];
+                        B::st16(a.out + rowoff[l] + k0 + v * VPT, tmp);
+                    }
                 }
-            } else {
+            }
+        } else {
+            SZH_FORL {
+                const int k0 = t0 - skew[l];
                 SZH_UNROLL
                 for (int s = 0; s < SZH_U; ++s) {
                     const int k = k0 + s;
@@ -318,6 +368,7 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
         return i < r0 && j < r1;
     };
     auto move_codes = [&](int c0) {
+        if (no_st) return;
         if (vec_codes && c0 + 8 <= r2) {
             SZH_FORL {
                 const int row = B::lane(l);
@@ -364,7 +415,7 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
             B::backoff(1);
             v = (int)B::lds_ld_u(ctr);
         }
-        tr_spins += spins;
+        if (SZH_DEV) tr_spins += spins;
         return v;
     };
 
@@ -376,10 +427,20 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
     const int tsteps = r2 + 14;
     int flushed = 0, filled = 0;   // code-ring columns already written back (compress) / already brought in (decompress)
     szh_u64 tr_start = 0, tr_first = 0;
-    if (a.trace) tr_start = B::clock();
-    const bool detail = a.trace && I == a.nI / 2 && J == a.nJ / 2;
-    szh_u64 *dt = a.trace ? a.trace + (int64_t)a.nI * a.nJ * 8 : nullptr;
-    for (int t0 = 0; t0 < tsteps; t0 += SZH_U) {
+    if (trace) tr_start = B::clock();
+    const bool detail = trace && I == a.nI / 2 && J == a.nJ / 2;
+    szh_u64 *steplog = nullptr;   // development: clock at the end of every step of the observed producer / consumer pencil
+    if (trace) {
+        const int oTI = a.trace_tile >> 16, oTJ = a.trace_tile & 0xffff;
+        szh_u64 *logs = trace + (int64_t)a.nI * a.nJ * 8 + 256;
+        if (I == oTI * B::TPI && J == oTJ * B::TPJ - 1) steplog = logs;                              // producer: last pencil column of the tile to the left
+        if (I == oTI * B::TPI && J == oTJ * B::TPJ) steplog = logs + 3 * 2 * SZH_TRACE_LOG;         // consumer: first pencil of the observed tile
+    }
+    szh_u64 *dt = trace ? trace + (int64_t)a.nI * a.nJ * 8 : nullptr;
+    // (decompress learns which values it needs from the trip's own codes: it asks at the top of the trip; double has no registers to spare for
+    //  a second buffer next to 2 x 4 pencils per workgroup)
+    constexpr bool PREFETCH = !DEC && sizeof(T) == 4;
+    auto trip = [&](const int t0, xbuf_t &xr, xbuf_t &xnext) {
         if (detail && t0 / SZH_U < 64) { SZH_FORL { if (B::lane(l) == 0) dt[(t0 / SZH_U) * 4 + 0] = B::clock(); } }
         // ring space: the consumers must have read the slots this trip overwrites.  A pencil of the tile reads column k no later
         // than its step k+7; the STORE wavefront counts the columns it has forwarded.  (This trip writes columns <= t0 + SZH_U - 8.)
@@ -389,7 +450,24 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
         int pstepJ = hasPJ ? (int)B::lds_ld_u(L.cstep + slotPJ) : (1 << 30);
         int pstepI = hasPI ? (int)B::lds_ld_u(L.cstep + slotPI) : (1 << 30);
         if (DEC) { while (filled < t0 + SZH_U && filled < r2) { move_codes(filled); filled += 8; } } // ring holds columns < filled
-        load_x(t0);
+        if (PREFETCH) {
+            // ALL of this trip's global memory traffic is issued here, in one batch: first the wait for this trip's own values (asked for
+            // a whole trip ago -- hipcc waits for the wavefront's entire memory queue, so the wait must come BEFORE anything new is
+            // issued: B::touch makes it), then the next trip's values, then the code columns that every lane has passed.  Whatever
+            // the next trip's wait finds in the queue is then a whole trip (SZH_U steps) old.  The code ring just holds it: columns
+            // [t0 - SZH_U, t0 + SZH_U) are in flight during the trip (SZH_XC = 2 * SZH_U).
+            static_assert(DEC || SZH_XC >= 2 * SZH_U, "code ring too small for one flush per trip");
+            SZH_FORL { SZH_UNROLL for (int s = 0; s < SZH_U; ++s) B::touch(xr[s][l]); }
+            if (t0 + SZH_U < tsteps) load_x(t0 + SZH_U, xnext);
+        } else load_x(t0, xr);
+        if (!DEC) { while (flushed + 8 <= t0 - 14 && flushed < r2) { move_codes(flushed); flushed += 8; } }
+        // face-store addresses of this trip: row base + ring(t0) (write-only slots keep their place); ring(t0 + s) = ring(t0) + s
+        int stb1[NL], stb2[NL];
+        SZH_FORL {
+            const int w0 = B::ring(t0);
+            stb1[l] = st1[l] >= ftrash0 ? st1[l] : st1[l] + w0;
+            stb2[l] = st2[l] >= ftrash0 ? st2[l] : st2[l] + w0;
+        }
         if (detail && t0 / SZH_U < 64) { SZH_FORL { if (B::lane(l) == 0) dt[(t0 / SZH_U) * 4 + 1] = B::clock(); } }
         SZH_UNROLL
         for (int s = 0; s < SZH_U; ++s) {
@@ -405,24 +483,24 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
                 // wavefront-uniform offset per step instead of per-lane address arithmetic.
                 const int rpos = B::ring(t + 7);
                 SZH_FORL {      // every lane reads (lanes without a halo row read a don't-care slot)
-                    const int kh = t - hskew[l];
-                    const bool lact = hlds[l] >= 0 && (unsigned)kh < (unsigned)r2;
+                    const bool lact = (unsigned)(t - hsk[l]) < (unsigned)r2;
                     const T v = B::lds_ld(L.faces + hrd[l] + rpos);
                     hval[l] = lact ? v : (T)0;
                 }
             }
             // -- neighbours through cross-lane moves (values of the previous step) --
             T shA[NL], shB[NL], shCi[NL], shCj[NL];
-            B::shfl_up(shA, cur, 1);
+            B::shfl_up1(shA, cur);
             B::shfl_up(shB, cur, 8);
             B::shfl_up(shCi, A1, 8);
-            B::shfl_up(shCj, B1, 1);
+            B::shfl_up1(shCj, B1);
             const T h63 = B::readlane(hval, 63), h62 = B::readlane(hval, 62);
 
             SZH_FORL {
                 const int k = t - skew[l];
-                const bool act = inb[l] && (unsigned)k < (unsigned)r2;
+                const bool act = (unsigned)(t - askew[l]) < (unsigned)r2;
                 const int lane = B::lane(l);
+                const int cslot = act ? (((t << 6) + cidx[l]) & (SZH_XC * 64 - 1)) : ctrash[l];
                 const T nA = jl[l] > 0 ? shA[l] : hval[l];
                 const T nB = il[l] > 0 ? shB[l] : (lane == 0 ? h63 : hval[l]);
                 const T nC = il[l] > 0 ? shCi[l] : (jl[l] > 0 ? shCj[l] : h62);
@@ -451,9 +529,9 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
                         code = is_lor ? code : cr;
                         nv = is_lor ? rcl : rcr;
                     }
-                    B::lds_st(cring + (act ? ((unsigned)k % SZH_XC) * 64 + lane : ctrash[l]), (uint16_t)code);
+                    B::lds_st(cring + cslot, (uint16_t)code);
                 } else {
-                    const int cread = (int)B::lds_ld(cring + (act ? ((unsigned)k % SZH_XC) * 64 + lane : ctrash[l]));
+                    const int cread = (int)B::lds_ld(cring + cslot);
                     const int c0 = act ? cread : radius;
                     int c = c0;
                     const T p = is_lor ? pred : predr;
@@ -467,15 +545,9 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
                     if (act && c0 == 0) nv = xr[s][l];                              // pre-scattered unpredictable value (read at the top of the trip)
                     xr[s][l] = nv;
                 }
-                // faces for the pencils to the right / below (in this tile or, through the STORE wavefront, in the next one):
-                // every lane stores; lanes without a face row, or outside the k range, store to their trash slot
-                const int wpos = B::ring(t);
-                if (pubJ) B::lds_st(L.faces + ((act && pjb[l] >= 0) ? pjb[l] + wpos : trash[l]), nv);
-                if (pubI) {
-                    B::lds_st(L.faces + ((act && pib[l] >= 0) ? pib[l] + wpos : trash[l]), nv);
-                    // lane (7,0): its halo value IS the corner column of the pencil below, same k
-                    B::lds_st(L.faces + ((act && pcb[l] >= 0) ? pcb[l] + wpos : trash[l]), hval[l]);
-                }
+                // faces for the pencils to the right / below (in this tile or, through the STORE wavefront, in the next one)
+                if (pubJ || pubI) B::lds_st(L.faces + stb1[l] + s, nv);
+                if (pubI) B::lds_st(L.faces + stb2[l] + s, corner[l] ? hval[l] : nv);   // lane (7,0): its halo value IS the corner column of the pencil below, same k
                 // roll the neighbour state.  Lanes outside the k range must hand on ZEROS (the reference's zero halo).  With
                 // Lorenzo-only data they produce zeros by themselves (zero input, zero neighbours); the mean shortcut, stale
                 // pre-scattered values and a regression plane (non-zero prediction at k < 0) need the mask.
@@ -502,27 +574,33 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
                     }
                 }
             }
-            // step t is complete: its face values are in the ring (LDS executes a wavefront's accesses in order)
-            B::lds_fence();
+            // step t is complete: its face values are in the ring.  The LDS executes one wavefront's accesses in order, so the counter
+            // store needs no wait behind the face stores -- only the compiler must keep the order (lds_order)
+            B::lds_order();
             SZH_FORL { B::lds_st(L.cstep + myslot, (unsigned)(t + 1)); }
+            if (SZH_DEV && steplog && t < SZH_TRACE_LOG) { SZH_FORL { if (B::lane(l) == 0) { steplog[2 * t] = B::clock(); steplog[2 * t + 1] = (szh_u64)(pstepJ < pstepI ? pstepJ : pstepI); } } }
             // half-way through the trip: write back the code columns that are complete (keeps the 32-column ring from wrapping)
-            if (!DEC && s == SZH_U / 2 - 1) { while (flushed + 8 <= t + 1 - 14 && flushed < r2) { move_codes(flushed); flushed += 8; } }
         }
         if (detail && t0 / SZH_U < 64) { SZH_FORL { if (B::lane(l) == 0) dt[(t0 / SZH_U) * 4 + 2] = B::clock(); } }
-        if (DEC) store_out(t0);
-        else {
-            // after this trip every lane is past column t0 + SZH_U - 15: flush the 8-column groups that are complete
-            while (flushed + 8 <= t0 + SZH_U - 14 && flushed < r2) { move_codes(flushed); flushed += 8; }
-        }
+        if (DEC) store_out(t0, xr);
         if (detail && t0 / SZH_U < 64) { SZH_FORL { if (B::lane(l) == 0) dt[(t0 / SZH_U) * 4 + 3] = B::clock(); } }
-        if (a.trace && t0 == 0) tr_first = B::clock();
+        if (trace && t0 == 0) tr_first = B::clock();
+    };
+    if (PREFETCH) {
+        load_x(0, xr0);
+        for (int t0 = 0; t0 < tsteps; t0 += 2 * SZH_U) {
+            trip(t0, xr0, xr1);
+            if (t0 + SZH_U < tsteps) trip(t0 + SZH_U, xr1, xr0);
+        }
+    } else {
+        for (int t0 = 0; t0 < tsteps; t0 += SZH_U) trip(t0, xr0, xr0);
     }
     if (!DEC) { for (; flushed < r2; flushed += 8) move_codes(flushed); }
-    if (a.trace) {
+    if (trace) {
         const szh_u64 tr_end = B::clock();
         SZH_FORL {
             if (B::lane(l) == 0) {
-                szh_u64 *tp = a.trace + ((int64_t)I * a.nJ + J) * 8;
+                szh_u64 *tp = trace + ((int64_t)I * a.nJ + J) * 8;
                 tp[0] = tr_start; tp[1] = tr_start; tp[2] = tr_first; tp[3] = tr_end; tp[4] = tr_spins; tp[6] = B::where(); tp[7] = 0;
             }
         }
@@ -617,11 +695,19 @@ SZH_HD void szh_tile_store(const szh_qargs<T> &a, int TI, int TJ, const szh_tile
     bool en[NL];
     szh_u64 *dst[NL];
     int64_t penc[NL];
+    // granules travel as 16-byte `sc0 sc1` buffer accesses (two neighbouring granules), addressed by a 32-bit offset from the first
+    // row of the tile's J- / I-face group (a.wide; otherwise as single 8-byte agent-scope atomics).  hipcc waits for the completion of
+    // a VOLATILE 16-byte access before it issues the next one -- one fabric round trip per access; these are ordinary accesses with
+    // the cache policy in the instruction, so a round's stores (and the FILL wavefront's loads) are all in flight together.
+    szh_u64 *const gbaseJ = a.faceJ + ((int64_t)(TI * B::TPI) * a.nJ + (TJ * B::TPJ + B::TPJ - 1)) * 8 * (int64_t)r2 * NW;
+    szh_u64 *const gbaseI = a.faceI + ((int64_t)(TI * B::TPI + B::TPI - 1) * a.nJ + TJ * B::TPJ) * 9 * (int64_t)r2 * NW;
+    const typename B::gbuf_t bufJ = B::make_gbuf(gbaseJ), bufI = B::make_gbuf(gbaseI);
+    const bool wide = a.wide != 0;
     SZH_FORL {
         const szh_rowmap<B> m(B::lane(l));
         // J-face rows come from the pencils of the tile's LAST column, I-face rows from its LAST row
         const int I = m.isJ ? TI * B::TPI + m.pp : TI * B::TPI + B::TPI - 1, J = m.isJ ? TJ * B::TPJ + B::TPJ - 1 : TJ * B::TPJ + m.pp;
-        en[l] = m.valid && I < a.nI && J < a.nJ && a.dbg != 1;
+        en[l] = m.valid && I < a.nI && J < a.nJ && !(SZH_DEV && (a.dbg == 1 || a.dbg == 2));
         if (m.isJ) en[l] = en[l] && J + 1 < a.nJ && 8 * I + m.r < r0;
         else en[l] = en[l] && I + 1 < a.nI && (m.r < 8 ? 8 * J + m.r < r1 : J > 0);
         penc[l] = (int64_t)I * a.nJ + J;
@@ -633,6 +719,7 @@ SZH_HD void szh_tile_store(const szh_qargs<T> &a, int TI, int TJ, const szh_tile
     int reported[NL];
     SZH_FORL reported[l] = -1;
     unsigned idle = 0;
+    int slog = 0;
     for (;;) {
         bool none[NL], fin[NL];
         int steps[NL];
@@ -652,9 +739,14 @@ SZH_HD void szh_tile_store(const szh_qargs<T> &a, int TI, int TJ, const szh_tile
             }
             SZH_UNROLL
             for (int w = 0; w < NW; ++w) gw[KP][w] = 0;
+            auto put2 = [&](szh_u64 *p, szh_u64 wa, szh_u64 wb) {   // two granules at a 16-byte boundary
+                if (wide) {
+                    if (m.isJ) B::st_gran2_b(bufJ, (unsigned)((p - gbaseJ) * 8), wa, wb); else B::st_gran2_b(bufI, (unsigned)((p - gbaseI) * 8), wa, wb);
+                } else { B::st_gran(p, wa); B::st_gran(p + 1, wb); }
+            };
             if (NW == 2) {
                 SZH_UNROLL
-                for (int e = 0; e < KP; ++e) { if (e < n) B::st_gran2(dst[l] + (int64_t)(pk[l] + e) * 2, gw[e][0], gw[e][NW - 1]); }
+                for (int e = 0; e < KP; ++e) { if (e < n) put2(dst[l] + (int64_t)(pk[l] + e) * 2, gw[e][0], gw[e][NW - 1]); }
             } else {
                 szh_u64 *const p0 = dst[l] + pk[l];
                 const int odd = (int)(((uintptr_t)p0 >> 3) & 1);          // the first granule sits in the upper half of a 16-byte slot
@@ -663,13 +755,17 @@ SZH_HD void szh_tile_store(const szh_qargs<T> &a, int TI, int TJ, const szh_tile
                 for (int j = 0; j < KP / 2; ++j) {
                     const int e = 2 * j + odd;                             // pair (e, e+1), 16-byte aligned
                     const szh_u64 wa = odd ? gw[2 * j + 1][0] : gw[2 * j][0], wb = odd ? gw[2 * j + 2][0] : gw[2 * j + 1][0];
-                    if (e + 1 < n) B::st_gran2(p0 + e, wa, wb);
+                    if (e + 1 < n) put2(p0 + e, wa, wb);
                     else if (e < n) B::st_gran(p0 + e, wa);
                 }
             }
             pk[l] += n;
             none[l] = n == 0; fin[l] = pk[l] >= r2;
             steps[l] = en[l] ? (pk[l] >= r2 ? (1 << 29) : pk[l] + m.sr) : (1 << 30);
+        }
+        if (SZH_DEV && a.trace && TI == (a.trace_tile >> 16) && TJ + 1 == (a.trace_tile & 0xffff) && slog < SZH_TRACE_LOG) {
+            SZH_FORL { if (B::lane(l) == 0) { szh_u64 *lg = a.trace + (int64_t)a.nI * a.nJ * 8 + 256 + 1 * 2 * SZH_TRACE_LOG; lg[2 * slog] = B::clock(); lg[2 * slog + 1] = (szh_u64)pk[l]; } }
+            ++slog;
         }
         // per pencil: ring space for the producer (columns forwarded on every row) and the progress word for the consumers' FILL
         int cols[NL], gcols[NL], gsteps[NL];
@@ -715,12 +811,18 @@ SZH_HD void szh_tile_fill(const szh_qargs<T> &a, int TI, int TJ, const szh_tile_
     int fk[NL], cslot[NL], wbase[NL];
     bool en[NL];
     const szh_u64 *src[NL];
+    // (see the STORE wavefront: 16-byte buffer loads with 32-bit offsets from the first producing row of each face group)
+    // (two granules below the group's first row: a 16-byte pair may start one granule before a row)
+    const szh_u64 *const gbaseJ = a.faceJ + ((int64_t)(TI * B::TPI) * a.nJ + (TJ > 0 ? TJ * B::TPJ - 1 : 0)) * 8 * (int64_t)r2 * NW - 2;
+    const szh_u64 *const gbaseI = a.faceI + ((int64_t)(TI > 0 ? TI * B::TPI - 1 : 0) * a.nJ + TJ * B::TPJ) * 9 * (int64_t)r2 * NW - 2;
+    const typename B::gbuf_t bufJ = B::make_gbuf(gbaseJ), bufI = B::make_gbuf(gbaseI);
+    const bool wide = a.wide != 0;
     const szh_u64 *prog[NL];
     SZH_FORL {
         const szh_rowmap<B> m(B::lane(l));
         // J-face rows feed the pencils of the tile's FIRST column (from the tile to the left), I-face rows its FIRST row (from above)
         const int I = m.isJ ? TI * B::TPI + m.pp : TI * B::TPI, J = m.isJ ? TJ * B::TPJ : TJ * B::TPJ + m.pp;
-        en[l] = m.valid && I < a.nI && J < a.nJ && a.dbg != 1;
+        en[l] = m.valid && I < a.nI && J < a.nJ && !(SZH_DEV && (a.dbg == 1 || a.dbg == 2));
         if (m.isJ) en[l] = en[l] && J > 0 && 8 * I + m.r < r0;
         else en[l] = en[l] && I > 0 && (m.r < 8 ? 8 * J + m.r < r1 : J > 0);
         const int64_t pp = m.isJ ? (int64_t)I * a.nJ + (J - 1) : (int64_t)(I - 1) * a.nJ + J;   // the producing pencil
@@ -731,7 +833,13 @@ SZH_HD void szh_tile_fill(const szh_qargs<T> &a, int TI, int TJ, const szh_tile_
         wbase[l] = vslot * stride + m.ringrow * B::face_rowstride(r2);
         fk[l] = en[l] ? 0 : r2;
     }
+    auto get2 = [&](bool isJ, const szh_u64 *p, szh_u64 &wa, szh_u64 &wb) {   // two granules at a 16-byte boundary
+        if (wide) {
+            if (isJ) B::ld_gran2_b(bufJ, (unsigned)((p - gbaseJ) * 8), wa, wb); else B::ld_gran2_b(bufI, (unsigned)((p - gbaseI) * 8), wa, wb);
+        } else { wa = B::ld_gran(p); wb = B::ld_gran(p + 1); }
+    };
     unsigned idle = 0;
+    int flog = 0;
     for (;;) {
         // how far have the producers got?  (every lane asks for its own row's producer: a handful of distinct words per round)
         szh_u64 g[KF][NW][NL];
@@ -753,7 +861,7 @@ SZH_HD void szh_tile_fill(const szh_qargs<T> &a, int TI, int TJ, const szh_tile_
                 SZH_UNROLL
                 for (int e = 0; e < KF; ++e) {
                     szh_u64 wa = 0, wb = 0;
-                    if (e < n) B::ld_gran2(src[l] + (int64_t)(fk[l] + e) * 2, wa, wb);
+                    if (e < n) get2(m.isJ, src[l] + (int64_t)(fk[l] + e) * 2, wa, wb);
                     g[e][0][l] = wa; g[e][NW - 1][l] = wb;
                 }
             } else {
@@ -763,7 +871,7 @@ SZH_HD void szh_tile_fill(const szh_qargs<T> &a, int TI, int TJ, const szh_tile_
                 SZH_UNROLL
                 for (int j = 0; j <= KF / 2; ++j) {
                     szh_u64 wa = 0, wb = 0;
-                    if (n > 0 && 2 * j - odd < n && (j < KF / 2 || odd)) B::ld_gran2(p0 - odd + 2 * j, wa, wb);
+                    if (n > 0 && 2 * j - odd < n && (j < KF / 2 || odd)) get2(m.isJ, p0 - odd + 2 * j, wa, wb);
                     q[2 * j] = wa; q[2 * j + 1] = wb;
                 }
                 SZH_UNROLL
@@ -783,6 +891,10 @@ SZH_HD void szh_tile_fill(const szh_qargs<T> &a, int TI, int TJ, const szh_tile_
             none[l] = lead == 0; fin[l] = fk[l] >= r2;
             // the consumer reads column k of this row at its step k + hs: "steps covered" on the scale of the step counters (+7)
             vsteps[l] = en[l] ? (fk[l] >= r2 ? (1 << 29) : fk[l] + m.hs + 7) : (1 << 30);
+        }
+        if (SZH_DEV && a.trace && TI == (a.trace_tile >> 16) && TJ == (a.trace_tile & 0xffff) && flog < SZH_TRACE_LOG) {
+            SZH_FORL { if (B::lane(l) == 0) { szh_u64 *lg = a.trace + (int64_t)a.nI * a.nJ * 8 + 256 + 2 * 2 * SZH_TRACE_LOG; lg[2 * flog] = B::clock(); lg[2 * flog + 1] = (szh_u64)fk[l]; } }
+            ++flog;
         }
         B::lds_fence();          // the values are in the ring before the counter says so
         int gv[NL];

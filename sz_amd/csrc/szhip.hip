@@ -146,7 +146,7 @@ int prepare_pencil(szhip_ctx *ctx, const szh_geom3 &G, int nw, int tpi, int tpj,
     TRY(ensure(ctx, ctx->faceI, (size_t)nI * nJ * 9 * rowg + 64, true));   // + 64: a 16-byte granule pair may reach one granule past a row's end
     TRY(ensure(ctx, ctx->faceJ, (size_t)nI * nJ * 8 * rowg + 64, true));
     TRY(ensure(ctx, ctx->progress, (size_t)nI * nJ * 2 * sizeof(u64), true));
-    if (tune_int("SZ_HIP_TRACE", 0)) TRY(ensure(ctx, ctx->trace, ((size_t)nI * nJ * 8 + 256) * sizeof(u64), true));
+    if (tune_int("SZ_HIP_TRACE", 0)) TRY(ensure(ctx, ctx->trace, ((size_t)nI * nJ * 8 + 256 + 4 * 2 * SZH_TRACE_LOG) * sizeof(u64), true));
     const int nTI = (nI + tpi - 1) / tpi, nTJ = (nJ + tpj - 1) / tpj;
     if (ctx->order_nI != nTI || ctx->order_nJ != nTJ) {
         std::vector<unsigned> ord((size_t)nTI * nTJ);
@@ -402,9 +402,9 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         a.faceI = (szh_u64 *)ctx->faceI.p; a.faceJ = (szh_u64 *)ctx->faceJ.p; a.epoch = ++ctx->epoch;
         a.nI = nI; a.nJ = nJ; a.order = (const unsigned *)ctx->order.p;
         a.ticket = (unsigned *)(sm + SM_TICKET); a.err = (unsigned *)(sm + SM_ERR);
-        a.progress = (szh_u64 *)ctx->progress.p; a.backoff = tune_int("SZ_HIP_BACKOFF", 4);
+        a.progress = (szh_u64 *)ctx->progress.p; a.backoff = tune_int("SZ_HIP_BACKOFF", 4); a.wide = tune_int("SZ_HIP_WIDE", 1) && (double)TS::TPI * nJ * 9.0 * (double)G.g2.count * szh_gran<T>::NW * 8.0 < 4.0e9 && (double)TS::TPJ * 9.0 * (double)G.g2.count * szh_gran<T>::NW * 8.0 < 4.0e9;
         a.trace = tune_int("SZ_HIP_TRACE", 0) ? (szh_u64 *)ctx->trace.p : nullptr;
-        a.dbg = tune_int("SZ_HIP_DBG", 0);
+        a.dbg = tune_int("SZ_HIP_DBG", 0); a.trace_tile = tune_int("SZ_HIP_TRACE_TILE", 1);
         HIPCHK(hipEventRecord(ctx->ev[2], st));
         hipLaunchKernelGGL((k_pencil<T, false>), dim3((unsigned)ntiles), dim3((TS::TPI * TS::TPJ + 2) * 64), 0, st, a);
         HIPCHK(hipGetLastError());
@@ -843,9 +843,9 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
         a.faceI = (szh_u64 *)ctx->faceI.p; a.faceJ = (szh_u64 *)ctx->faceJ.p; a.epoch = ++ctx->epoch;
         a.nI = nI; a.nJ = nJ; a.order = (const unsigned *)ctx->order.p;
         a.ticket = (unsigned *)(sm + SM_TICKET); a.err = (unsigned *)(sm + SM_ERR);
-        a.progress = (szh_u64 *)ctx->progress.p; a.backoff = tune_int("SZ_HIP_BACKOFF", 4);
+        a.progress = (szh_u64 *)ctx->progress.p; a.backoff = tune_int("SZ_HIP_BACKOFF", 4); a.wide = tune_int("SZ_HIP_WIDE", 1) && (double)TS::TPI * nJ * 9.0 * (double)G.g2.count * szh_gran<T>::NW * 8.0 < 4.0e9 && (double)TS::TPJ * 9.0 * (double)G.g2.count * szh_gran<T>::NW * 8.0 < 4.0e9;
         a.trace = tune_int("SZ_HIP_TRACE", 0) ? (szh_u64 *)ctx->trace.p : nullptr;
-        a.dbg = tune_int("SZ_HIP_DBG", 0);
+        a.dbg = tune_int("SZ_HIP_DBG", 0); a.trace_tile = tune_int("SZ_HIP_TRACE_TILE", 1);
         HIPCHK(hipEventRecord(ctx->ev[2], st));
         hipLaunchKernelGGL((k_pencil<T, true>), dim3((unsigned)ntiles), dim3((TS::TPI * TS::TPJ + 2) * 64), 0, st, a);
         HIPCHK(hipGetLastError());
@@ -911,7 +911,7 @@ int launch_pencil14(szhip_ctx *ctx, const szh_geom3 &G, u64 *sm, bool dec, const
     a.faceI = (szh_u64 *)ctx->faceI.p; a.faceJ = (szh_u64 *)ctx->faceJ.p; a.epoch = ++ctx->epoch;
     a.nI = nI; a.nJ = nJ; a.order = (const unsigned *)ctx->order.p;
     a.ticket = (unsigned *)(sm + SM_TICKET); a.err = (unsigned *)(sm + SM_ERR);
-    a.progress = (szh_u64 *)ctx->progress.p; a.backoff = tune_int("SZ_HIP_BACKOFF", 4);
+    a.progress = (szh_u64 *)ctx->progress.p; a.backoff = tune_int("SZ_HIP_BACKOFF", 4); a.wide = tune_int("SZ_HIP_WIDE", 1) && (double)TS::TPI * nJ * 9.0 * (double)G.g2.count * szh_gran<T>::NW * 8.0 < 4.0e9 && (double)TS::TPJ * 9.0 * (double)G.g2.count * szh_gran<T>::NW * 8.0 < 4.0e9;
     a.trace = nullptr; a.dbg = 0;
     HIPCHK(hipEventRecord(ctx->ev[2], st));
     if (dec) hipLaunchKernelGGL((k_pencil<T, true>), dim3((unsigned)ntiles), dim3((TS::TPI * TS::TPJ + 2) * 64), 0, st, a);

@@ -92,6 +92,19 @@ struct GpuBackend {
     __device__ static int lane(int) { return (int)(threadIdx.x & 63); }
     template <class T> __device__ static void shfl_up(T (&dst)[1], const T (&src)[1], int d) { dst[0] = __shfl_up(src[0], d, 64); }
 #ifdef SZH_HIPSIM
+    template <class T> __device__ static void shfl_up1(T (&dst)[1], const T (&src)[1]) { dst[0] = __shfl_up(src[0], 1, 64); }
+#else
+    // the value of lane l - 1: a DPP row shift (no trip through the LDS crossbar, and hipcc folds it into the consuming add).  Lanes at
+    // the start of a 16-lane row receive 0; the sweep uses the result only in lanes with jl = lane % 8 > 0
+    template <class T> __device__ static void shfl_up1(T (&dst)[1], const T (&src)[1])
+    {
+        int w[sizeof(T) / 4];
+        __builtin_memcpy(w, &src[0], sizeof(T));
+        for (unsigned i = 0; i < sizeof(T) / 4; ++i) w[i] = __builtin_amdgcn_update_dpp(0, w[i], 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+        __builtin_memcpy(&dst[0], w, sizeof(T));
+    }
+#endif
+#ifdef SZH_HIPSIM
     template <class T> __device__ static T readlane(const T (&src)[1], int lane) { return __shfl(src[0], lane, 64); }
 #else
     // lane is wavefront-uniform: v_readlane_b32 instead of a trip through the LDS crossbar
@@ -124,33 +137,46 @@ struct GpuBackend {
     template <class E> __device__ static E lds_ld_u(const E *p) { return __shfl(lds_ld(p), 0, 64); } // one read, so every lane branches alike
     // lanes are free-running OS threads in the shim: re-converge the wavefront, as lock-step execution would
     __device__ static void lds_fence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); (void)__all(1); __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+    __device__ static void lds_order() { lds_fence(); }
 #else
     template <class E> __device__ static E lds_ld(const E *p) { return *(const volatile __attribute__((address_space(3))) E *)p; }
     template <class E> __device__ static void lds_st(E *p, E v) { *(volatile __attribute__((address_space(3))) E *)p = v; }
     template <class E> __device__ static E lds_ld_u(const E *p) { return (E)__builtin_amdgcn_readfirstlane((int)lds_ld(p)); } // scalar: waits on it are s_cmp/s_cbranch
     __device__ static void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+    __device__ static void lds_order() { asm volatile("" ::: "memory"); }   // one wavefront's LDS accesses execute in program order
+#endif
+#ifdef SZH_HIPSIM
+    template <class E> __device__ static void touch(E &) {}
+#else
+    __device__ static void touch(float &v) { asm volatile("" : "+v"(v)); }
+    __device__ static void touch(double &v) { asm volatile("" : "+v"(v)); }
 #endif
     __device__ static szh_u64 ld_gran(const szh_u64 *p)
     {
         return __hip_atomic_load(const_cast<szh_u64 *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __device__ static void st_gran(szh_u64 *p, szh_u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    // two neighbouring granules at a 16-byte boundary in one access (volatile 16-byte vector = `sc0 sc1`: L1 bypassed on loads, written
-    // through and not kept in L2 on stores, like the agent-scope forms above; each 8-byte half is read and written whole)
+    // two neighbouring granules at a 16-byte boundary in one access: raw buffer load / store with the cache policy `sc0 sc1` (aux 17: L1
+    // bypassed on loads, written through and not kept in L2 on stores, like the agent-scope forms above; each 8-byte half is read
+    // and written whole).  NOT volatile: hipcc drains the memory queue after every volatile 16-byte access.
 #ifdef SZH_HIPSIM
-    __device__ static void st_gran2(szh_u64 *p, szh_u64 a, szh_u64 b) { st_gran(p, a); st_gran(p + 1, b); }
-    __device__ static void ld_gran2(const szh_u64 *p, szh_u64 &a, szh_u64 &b) { a = ld_gran(p); b = ld_gran(p + 1); }
+    typedef const szh_u64 *gbuf_t;
+    __device__ static gbuf_t make_gbuf(const szh_u64 *base) { return base; }
+    __device__ static void st_gran2_b(gbuf_t b, unsigned off, szh_u64 x, szh_u64 y) { szh_u64 *p = const_cast<szh_u64 *>(b) + off / 8; st_gran(p, x); st_gran(p + 1, y); }
+    __device__ static void ld_gran2_b(gbuf_t b, unsigned off, szh_u64 &x, szh_u64 &y) { x = ld_gran(b + off / 8); y = ld_gran(b + off / 8 + 1); }
 #else
     typedef unsigned int v4u_ __attribute__((ext_vector_type(4)));
-    __device__ static void st_gran2(szh_u64 *p, szh_u64 a, szh_u64 b)
+    typedef __amdgpu_buffer_rsrc_t gbuf_t;
+    __device__ static gbuf_t make_gbuf(const szh_u64 *base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<szh_u64 *>(base), 0, 0xffffffffu, 0x00020000); }
+    __device__ static void st_gran2_b(gbuf_t b, unsigned off, szh_u64 x, szh_u64 y)
     {
-        v4u_ v; v.x = (unsigned)a; v.y = (unsigned)(a >> 32); v.z = (unsigned)b; v.w = (unsigned)(b >> 32);
-        *(volatile __attribute__((address_space(1))) v4u_ *)p = v;
+        v4u_ v; v.x = (unsigned)x; v.y = (unsigned)(x >> 32); v.z = (unsigned)y; v.w = (unsigned)(y >> 32);
+        __builtin_amdgcn_raw_buffer_store_b128(v, b, (int)off, 0, 17);
     }
-    __device__ static void ld_gran2(const szh_u64 *p, szh_u64 &a, szh_u64 &b)
+    __device__ static void ld_gran2_b(gbuf_t b, unsigned off, szh_u64 &x, szh_u64 &y)
     {
-        const v4u_ v = *(const volatile __attribute__((address_space(1))) v4u_ *)p;
-        a = ((szh_u64)v.y << 32) | v.x; b = ((szh_u64)v.w << 32) | v.z;
+        const v4u_ v = __builtin_amdgcn_raw_buffer_load_b128(b, (int)off, 0, 17);
+        x = ((szh_u64)v.y << 32) | v.x; y = ((szh_u64)v.w << 32) | v.z;
     }
 #endif
     __device__ static unsigned ld_flag(const unsigned *p) { return __hip_atomic_load(const_cast<unsigned *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -192,7 +218,7 @@ __global__ __launch_bounds__((szh_tile_shape<T>::TPI * szh_tile_shape<T>::TPJ + 
     using B = GpuBackend<S::TPI, S::TPJ, S::RL>;
     constexpr int NP = S::TPI * S::TPJ, NV = S::TPI + S::TPJ, NT = (NP + 2) * 64;
     __shared__ uint16_t cring[NP * (SZH_XC + 1) * 64];
-    __shared__ T faces[(NP + NV) * (S::RL + 2) * SZH_FROWS + 64];
+    __shared__ T faces[(NP + NV) * (S::RL + 2) * SZH_FROWS + SZH_FTRASH];
     __shared__ unsigned cstep[NP + NV];
     __shared__ unsigned spubJ[NP], spubI[NP];
     __shared__ int scratch[128];
@@ -202,16 +228,24 @@ __global__ __launch_bounds__((szh_tile_shape<T>::TPI * szh_tile_shape<T>::TPJ + 
     if (threadIdx.x == 0) tk_s = atomicAdd(a.ticket, 1u);
     __syncthreads();
     (void)NT;
+    // wavefront-uniform by construction: say so (readfirstlane), so that slots, ring bases, publish flags and the wait loops of the
+    // sweep live in scalar registers and branch on the scalar unit instead of through exec masks
+#ifdef SZH_HIPSIM
     const unsigned ij = a.order[tk_s];
     const int w = (int)(threadIdx.x >> 6);
+#else
+    const unsigned ij = (unsigned)__builtin_amdgcn_readfirstlane((int)a.order[tk_s]);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#endif
     const int TI = (int)(ij >> 16), TJ = (int)(ij & 0xffffu);
     const szh_tile_lds<T> L{cring, faces, (NP + NV) * (S::RL + 2) * SZH_FROWS, cstep, spubJ, spubI, scratch};
 #ifndef SZH_HIPSIM
     // issue priority: the helpers (light, latency-critical) first, then the pencils in dependency order, so that the chain
     // of hand-offs advances at single-wavefront speed while the downstream pencils fill the issue gaps
-    if (a.dbg != 4) {
-        const int d = w < NP ? (w / S::TPJ + w % S::TPJ) : 0;
-        if (d == 0) __builtin_amdgcn_s_setprio(3); else if (d == 1) __builtin_amdgcn_s_setprio(2);
+    {
+        const int d = w < NP ? (w / S::TPJ + w % S::TPJ) : -1;
+        if (d < 0) __builtin_amdgcn_s_setprio(3);
+        else if (d == 0) __builtin_amdgcn_s_setprio(3); else if (d == 1) __builtin_amdgcn_s_setprio(2);
         else if (d <= 3) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
     }
 #endif

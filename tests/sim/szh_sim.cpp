@@ -19,22 +19,27 @@ struct SimBackend {
         for (int l = 0; l < 64; ++l) tmp[l] = (l >= d) ? src[l - d] : src[l];
         for (int l = 0; l < 64; ++l) dst[l] = tmp[l];
     }
+    template <class T> static void shfl_up1(T (&dst)[64], const T (&src)[64]) { shfl_up(dst, src, 1); }
     template <class T> static T readlane(const T (&src)[64], int lane) { return src[lane]; }
     // tiles of 2 x 3 pencils.  The simulator runs a tile's FILL, its pencils and its STORE one after the other, so a ring must
     // keep every column: RL covers all of dim2.
     static constexpr int TPI = 2, TPJ = 3, RL = 1 << 20;
     static int ring(int k) { return k; }
-    static int face_rowstride(int r2) { return r2 + 16; }   // ring position = column + the producing lane's skew (<= 14)
-    static int face_stride(int r2) { return (r2 + 16) * SZH_FROWS; }
+    static int face_rowstride(int r2) { return r2 + 32; }   // ring position = the producing step: < r2 + 14 rounded up to whole trips
+    static int face_stride(int r2) { return (r2 + 32) * SZH_FROWS; }
     template <class E> static E lds_ld(const E *p) { return *p; }
     template <class E> static E lds_ld_u(const E *p) { return *p; }
     template <class E> static void lds_st(E *p, E v) { *p = v; }
     static void lds_fence() {}
+    static void lds_order() {}
+    template <class E> static void touch(E &) {}
     static bool all(const bool (&p)[64]) { for (int l = 0; l < 64; ++l) if (!p[l]) return false; return true; }
     static szh_u64 ld_gran(const szh_u64 *p) { return *p; }
     static void st_gran(szh_u64 *p, szh_u64 v) { *p = v; }
-    static void st_gran2(szh_u64 *p, szh_u64 a, szh_u64 b) { st_gran(p, a); st_gran(p + 1, b); }
-    static void ld_gran2(const szh_u64 *p, szh_u64 &a, szh_u64 &b) { a = ld_gran(p); b = ld_gran(p + 1); }
+    typedef const szh_u64 *gbuf_t;
+    static gbuf_t make_gbuf(const szh_u64 *base) { return base; }
+    static void st_gran2_b(gbuf_t b, unsigned off, szh_u64 x, szh_u64 y) { szh_u64 *p = const_cast<szh_u64 *>(b) + off / 8; p[0] = x; p[1] = y; }
+    static void ld_gran2_b(gbuf_t b, unsigned off, szh_u64 &x, szh_u64 &y) { x = b[off / 8]; y = b[off / 8 + 1]; }
     static unsigned ld_flag(const unsigned *p) { return *p; }
     static void st_flag(unsigned *p, unsigned v) { *p = v; }
     static void backoff(int) {}
@@ -59,12 +64,12 @@ static int run_all(szh_qargs<T> a)
     szh_fill_pencil_order(nTI, nTJ, order.data());
     unsigned err = 0; a.err = &err;
     std::vector<szh_u64> prog((size_t)a.nI * a.nJ * 2, 0);
-    a.progress = prog.data(); a.backoff = 1;
+    a.progress = prog.data(); a.backoff = 1; a.wide = getenv("SZH_SIM_NARROW") ? 0 : 1;
     constexpr int NP = B::TPI * B::TPJ, NV = B::TPI + B::TPJ;
     std::vector<uint16_t> ring((size_t)NP * (SZH_XC + 1) * 64);
     // "LDS" of one tile: face arrays [r2][SZH_FROWS] per slot, poisoned so that a value used before it is written shows
     const size_t fsz = (size_t)(NP + NV) * B::face_stride(r2);
-    std::vector<T> faces(fsz + 64);
+    std::vector<T> faces(fsz + SZH_FTRASH);
     std::vector<unsigned> cstep(NP + NV), spubJ(NP), spubI(NP);
     std::vector<int> scratch(128);
     for (size_t tk = 0; tk < order.size(); ++tk) {

@@ -71,7 +71,7 @@ def test_whole_hip_layer_on_cpu_shim(oracle, c1_data):
         api._lib = api._bind(ctypes.CDLL(sim_lib.shim_path()))
         import os
         assert sz_amd.SZ_Init(os.path.join(sim_lib.ROOT, "tests", "golden", "sz_speed.config")) == 0
-        for name, d, eb in (("C1", c1_data, 1e-4), ("M20", m_field(20), 1e-4)):
+        for name, d, eb in (("C1", c1_data, 1e-4), ("M20", m_field(20), 1e-4), ("S-odd-rows", s_field(26, 30, 57), 1e-4)):   # odd r2: granule rows start at odd 8-byte slots
             ref, _ = oracle.compress(d, oracle.ABS, eb)
             got = sz_amd.SZ_compress_args(d, sz_amd.ABS, eb)
             assert got == ref, name

@@ -51,6 +51,7 @@ for c in range(ncases):
     rng_v = float(d.max()) - float(d.min())
     abs_b = float(10.0 ** rng.uniform(-5, -1)) * max(rng_v, 1e-6)
     rel_b = float(10.0 ** rng.uniform(-5, -2))
+    if os.environ.get("FUZZ_VERBOSE"): print(f"case={c} dtype={np.dtype(dt).name} shape={d.shape} kind={kind} mode={mode} abs={abs_b:.3e} rel={rel_b:.3e}", flush=True)
     try:
         ref, _ = O.compress(d, mode, abs_b, rel_b, params=oparams)
         got = sz_amd.SZ_compress_args(d, mode, abs_b, rel_b)
