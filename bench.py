@@ -1,24 +1,33 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the MI355X SZ 2.1 hot path.
+"""bench.py -- benchmarks of the MI355X SZ 2.1 hot path.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config headline|c4]
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
 
-A "step" is one pass of the hot path (fit + interval optimiser + predictor selection + predict/quantise + Huffman
-encode, into the reference's SZ 2.1 stream) over one 512x512x512 float32 array (BASELINE.json configs[1]: smooth
-sinusoid "S-field", ABS 1e-4) that is already resident in HBM; the stream is left in HBM.  With N ranks every rank
-owns one such slab of an (N*512)x512x512 array (weak scaling, no data-path collective) and the step ends with one
-all-gather of the variable-length sub-streams (RCCL), launched asynchronously so that it overlaps the next step's
-compression; every gather is completed inside the timed region.  Rank 0 prints ONE JSON line.
+--config headline (default; BASELINE.json configs[1]/[2], the configuration the metric is quoted on).  A "step" is one pass of
+the hot path as SZ_compress_args runs it -- value-range scan, regression fit + predictor selection, interval optimiser,
+predict/quantise, Huffman encode into the reference's SZ 2.1 stream -- over one 512x512x512 float32 array (smooth sinusoid
+"S-field", ABS 1e-4) that is already resident in HBM; the stream is left in HBM.  With N ranks every rank owns one such slab of
+an (N*512)x512x512 array (weak scaling, no data-path collective) and the step ends with one all-gather of the variable-length
+sub-streams (RCCL), launched asynchronously so that it overlaps the next step's compression; every gather is completed inside
+the timed region.  Rank 0 prints ONE JSON line.  Extra objects on that line:
+  roofline     -- the predict+quantise wavefront kernel: algorithmic bytes (N*4, the array read once) / its average duration
+                  measured with HIP events on the library's stream, against the 8 TB/s HBM3E peak.
+  m_field      -- BASELINE configs[2]: the same step on the 512^3 "M-field" (half of the blocks choose the regression predictor;
+                  this times the regression instantiation of the kernel and the serial host coefficient chain).
+  e2e          -- SZ_compress_args / SZ_decompress from and to HOST memory (pageable), PCIe included: never the `value`.
+  cpu_baseline -- the oracle (a C restatement of the reference CPU loops, oracle/), pinned to one core, median of 3; and
+                  cpu_baseline_mt: the same code on P slabs in P processes.
 
-Extra objects on that line:
-  roofline     -- the predict+quantise wavefront kernel: algorithmic bytes (N*4, the array read once) / its average
-                  duration measured with HIP events on the library's stream, against the 8 TB/s HBM3E peak.
-  cpu_baseline -- the oracle (a C restatement of the reference CPU loops, oracle/), single core, on the same array.
+--config c4 (BASELINE.json configs[3]): 1024^3 float64 S-field, REL 1e-3, slab-sharded: rank r owns planes of the outer
+dimension (at N = 8: 128x1024x1024 = 1 GiB; at N = 1 the bench runs ONE such slab, it does not pretend to hold the 8 GiB
+array), the value range is all-reduced, eb = 1e-3 * range, every rank compresses its slab, the sub-streams are all-gathered,
+every rank decompresses its own sub-stream and checks max|x - x'| <= eb.
 """
 import argparse
 import json
 import os
+import platform
 import sys
 import time
 
@@ -32,75 +41,123 @@ EB = 1e-4
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--edge", type=int, default=EDGE, help="cube edge (512 = the BASELINE config)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--other-paths", action="store_true",
-                    help="also time the SZ 1.4 container, a 2-D array and a 1-D series (extra kernels: keep it off when profiling the headline kernel)")
-    args = ap.parse_args()
+def cpu_info():
+    model = platform.processor() or ""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return model, os.cpu_count()
 
-    import torch
-    import torch.distributed as dist
+
+def _mt_worker(args):
+    idx, planes, n = args
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from sz_amd.fields import s_field
+    d = s_field(planes, n, n, np.float32, z0=idx * planes)
+    t = time.perf_counter()
+    s, _ = O.compress(d, O.ABS, EB)
+    return time.perf_counter() - t, len(s)
+
+
+def cpu_baselines(host, n, gpu_size):
+    """The oracle timed on the host cores of this box: pinned to one core (median of 3 passes over the whole array), and P
+    independent slabs in P processes (what the slab decomposition gives a multi-core CPU)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O  # the checker, timed here as the CPU baseline ("port" of the reference loops)
+    model, ncpu = cpu_info()
+    sample = host if n <= 512 else host[:512]
+    old = None
+    try:
+        old = os.sched_getaffinity(0)
+        os.sched_setaffinity(0, {sorted(old)[len(old) // 2]})
+    except (AttributeError, OSError):
+        pass
+    times, ref = [], None
+    for _ in range(3):
+        t1 = time.perf_counter()
+        ref, _ = O.compress(sample, O.ABS, EB)
+        times.append(time.perf_counter() - t1)
+    if old is not None:
+        os.sched_setaffinity(0, old)
+    tc = float(np.median(times))
+    one = {"value": round(sample.nbytes / tc / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+           "sample": f"median of 3 compress passes over the full {sample.shape[0]}x{n}x{n} float32 S-field by oracle/liboracle.so, pinned to one "
+                     f"core ({tc:.2f} s per pass)",
+           "cpu_model": model, "nproc": ncpu, "stream_bytes": len(ref), "gpu_stream_identical": bool(len(ref) == gpu_size),
+           "note": "the port is the same loops restated type-generically with one strip buffer; the survey timed the unmodified reference "
+                   "binary at 0.10 GB/s on this array (SURVEY.md section 6, shared 8-core container), i.e. the port is about 2x faster "
+                   "than the reference itself"}
+    mt = None
+    try:
+        import multiprocessing as mp
+        P = 1
+        while P * 2 <= min(ncpu or 1, 8):
+            P *= 2
+        if P > 1:
+            planes = sample.shape[0] // P
+            with mp.get_context("fork").Pool(P) as pool:
+                t1 = time.perf_counter()
+                res = pool.map(_mt_worker, [(i, planes, n) for i in range(P)])
+                wall = time.perf_counter() - t1
+            mt = {"value": round(P * planes * n * n * 4 / wall / 1e9, 4), "unit": "GB/s", "cores": P, "kind": "port",
+                  "sample": f"{P} slabs of {planes}x{n}x{n} compressed at the same time by {P} processes ({wall:.2f} s wall, data generation "
+                            "included in no process's timed part but in the wall time)",
+                  "slowest_slab_s": round(max(r[0] for r in res), 3)}
+    except Exception as e:  # noqa: BLE001 -- a baseline, not the product
+        mt = {"error": repr(e)}
+    return one, mt
+
+
+def run_headline(args, torch, dist, world, rank, local_rank, dev):
+    import ctypes
     import sz_amd
     from sz_amd import slab
-    from sz_amd.fields import s_field
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the product has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+    from sz_amd.fields import m_field, s_field
 
     n = args.edge
     # this rank's slab of the (world*n) x n x n S-field (z offset = rank*n); host generation is exact numpy float64 math
     host = s_field(n, n, n, np.float32, z0=rank * n)
     x = torch.from_numpy(host).to(dev)
     nbytes_in = host.nbytes
-    vmin, vmax = float(host.min()), float(host.max())
-    meta = sz_amd.make_meta(np.float32, err_mode=sz_amd.ABS, abs_bound=EB, vmin=vmin, vmax=vmax)
     ctx = sz_amd.HipContext(local_rank)
     out_cap = nbytes_in // 2 + (1 << 20)
-    out_buf = torch.empty(out_cap, dtype=torch.uint8, device=dev)
-    # N > 1: the all-gather of step k's sub-streams runs while step k+1 compresses (RCCL on its own stream; the payload travels
-    # from a private copy).  All gathers are completed inside the timed region.
+    out_bufs = [torch.empty(out_cap, dtype=torch.uint8, device=dev) for _ in range(2)]   # alternate: a gather may still read the other
     gather = slab.StreamGather() if world > 1 else None
     pending = []
+    step_no = [0]
 
-    import ctypes
-
-    def one_step():
-        out = ctypes.c_void_p(out_buf.data_ptr())
+    def one_step(src=x):
+        # (1) value range (computeRangeSize_float: what SZ_compress_args does first; the stream header records it)
+        vmin, vmax = ctx.minmax(src.data_ptr(), True, src.numel(), np.float32)
+        meta = sz_amd.make_meta(np.float32, err_mode=sz_amd.ABS, abs_bound=EB, vmin=vmin, vmax=vmax)
+        # (2) everything else of the hot path, into the stream
+        ob = out_bufs[step_no[0] & 1]
+        step_no[0] += 1
+        out = ctypes.c_void_p(ob.data_ptr())
         nn = ctypes.c_size_t(out_cap)
         st = sz_amd.szhip_stats()
         p = sz_amd.szhip_params(100, 0.99, 65536, 0)
-        rc = sz_amd.lib().szhip_compress(ctx._h, 0, x.data_ptr(), 1, n, n, n, EB, ctypes.byref(p), meta, len(meta), 2,
+        rc = sz_amd.lib().szhip_compress(ctx._h, 0, src.data_ptr(), 1, n, n, n, EB, ctypes.byref(p), meta, len(meta), 2,
                                          ctypes.byref(out), ctypes.byref(nn), ctypes.byref(st))
         if rc:
             raise RuntimeError(f"szhip_compress failed: {sz_amd.lib().szhip_last_error(ctx._h)}")
         if world > 1:
             if os.environ.get("SZ_BENCH_SYNC_GATHER"):          # fallback: the plain, non-overlapped all-gather
-                slab.allgather_streams(out_buf, nn.value)
+                slab.allgather_streams(ob, nn.value)
             else:
-                pending.append(gather.begin(out_buf, nn.value))
+                pending.append(gather.begin(ob, nn.value))
                 if len(pending) > 1:
-                    slab.StreamGather.end(pending.pop(0))
-        return nn.value, st
+                    gather.end(pending.pop(0))
+        return nn.value, st, ob
 
     def drain():
         while pending:
-            slab.StreamGather.end(pending.pop(0))
+            gather.end(pending.pop(0))
 
     def sync_all():
         torch.cuda.synchronize()
@@ -113,9 +170,9 @@ def main():
     drain()
     sync_all()
     t0 = time.perf_counter()
-    quant_ms, stats = [], None
+    quant_ms, stats, size, ob = [], None, 0, None
     for _ in range(args.steps):
-        size, stats = one_step()
+        size, stats, ob = one_step()
         quant_ms.append(stats.ms_quant)
     drain()
     sync_all()
@@ -129,15 +186,15 @@ def main():
 
     # ---- quality of the result (outside the timed region): decompress on the GPU, compare with the input
     dec = torch.empty_like(x)
-    dst = ctx.decompress(out_buf.data_ptr(), True, size, 4 + 28 + 8, (n, n, n), np.float32, dec.data_ptr(), True)
+    dst = ctx.decompress(ob.data_ptr(), True, size, 4 + 28 + 8, (n, n, n), np.float32, dec.data_ptr(), True)
     err = (dec - x).abs()
     max_abs_err = float(err.max().item())
     mse = float((err * err).double().sum().item()) / x.numel()
     psnr = 20 * np.log10(float((x.max() - x.min()).item())) - 10 * np.log10(mse)
-    # decompression throughput (same array, 3 passes)
+    del err
     torch.cuda.synchronize(); td = time.perf_counter()
     for _ in range(3):
-        ctx.decompress(out_buf.data_ptr(), True, size, 4 + 28 + 8, (n, n, n), np.float32, dec.data_ptr(), True)
+        ctx.decompress(ob.data_ptr(), True, size, 4 + 28 + 8, (n, n, n), np.float32, dec.data_ptr(), True)
     torch.cuda.synchronize(); td = (time.perf_counter() - td) / 3
 
     if rank != 0:
@@ -149,88 +206,195 @@ def main():
     achieved = nbytes_in / (quant_avg_ms * 1e-3) / 1e9
     # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside the timed process);
     # only valid for the workload it was measured on
-    traffic = None
-    try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_pencil.json")))
-        if n == EDGE:
-            traffic = pm["traffic_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
+    traffic, traffic_src = None, None
+    for name in ("r02_pmc_traffic_pencil.json", "r01_pmc_traffic_pencil.json"):
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if n == EDGE:
+                traffic = pm["traffic_bytes_per_launch"]
+                traffic_src = f"profiles/{name} (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes)"
+                break
+        except (OSError, KeyError, ValueError):
+            pass
     roofline = {"bound": "hbm", "kernel": "k_pencil<float,false>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "traffic_source": "profiles/r01_pmc_traffic_pencil.json (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes)",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": nbytes_in, "avg_kernel_ms": round(quant_avg_ms, 4)}
 
-    # ---- the other paths of the same library, one line each (outside the timed region; single GPU only): the SZ 1.4 container
-    #      (withLinearRegression = NO) on the same array, and a 2-D array through the SZ 2.1 path
-    other = None
-    if args.other_paths and world == 1 and n == EDGE:
-        def timed(fn, reps=3):
-            fn(); torch.cuda.synchronize(); t = time.perf_counter()
-            for _ in range(reps):
-                r = fn()
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t) / reps, r
+    # ---- BASELINE configs[2]: the adaptive case proper -- 512^3 M-field, half of the blocks regression (single GPU, outside the timed region)
+    mfield = None
+    if world == 1 and n == EDGE and not args.no_m_field:
+        xm = torch.from_numpy(m_field(n)).to(dev)
+        for _ in range(2):
+            one_step(xm)
+        torch.cuda.synchronize(); tm = time.perf_counter()
+        msteps = max(3, min(args.steps, 5))
+        for _ in range(msteps):
+            msize, mst, mob = one_step(xm)
+        torch.cuda.synchronize(); tm = (time.perf_counter() - tm) / msteps
+        mdec = torch.empty_like(xm)
+        ctx.decompress(mob.data_ptr(), True, msize, 4 + 28 + 8, (n, n, n), np.float32, mdec.data_ptr(), True)
+        mfield = {"GB/s": round(nbytes_in / tm / 1e9, 2), "ms": round(tm * 1e3, 3), "reg_blocks": int(mst.n_reg_blocks), "blocks": int(mst.n_blocks),
+                  "out_bytes": int(msize), "ratio": round(nbytes_in / msize, 4), "max_abs_err": float((mdec - xm).abs().max().item()),
+                  "phase_ms": {"prequant_incl_host_coefficient_chain": round(mst.ms_prequant, 3), "quant": round(mst.ms_quant, 3),
+                               "entropy": round(mst.ms_entropy, 3), "host_glue": round(mst.ms_host, 3)}}
+        del xm, mdec
 
-        def run(fn_name, ptr, dims, extra, mbytes, eb=EB):
-            out = ctypes.c_void_p(out_buf.data_ptr()); nn = ctypes.c_size_t(out_cap); st = sz_amd.szhip_stats()
-            p = sz_amd.szhip_params(100, 0.99, 65536, 0)
-            rc = getattr(sz_amd.lib(), fn_name)(ctx._h, 0, ptr, 1, *dims, eb, *extra, ctypes.byref(p), mbytes, len(mbytes), 2,
-                                                ctypes.byref(out), ctypes.byref(nn), ctypes.byref(st))
-            if rc:
-                raise RuntimeError(f"{fn_name} failed: {sz_amd.lib().szhip_last_error(ctx._h)}")
-            return nn.value
-        rng = vmax - vmin
-        med = float(np.float32(np.float32(vmin) + np.float32(rng) / np.float32(2)))
-        meta14 = bytes([meta[0], meta[1], meta[2], 0x40]) + bytes(meta[4:])
-        t14, size14 = timed(lambda: run("szhip_compress_sz14", x.data_ptr(), (n, n, n), (float(np.float32(rng)), med), meta14))
-        from sz_amd.fields import plane_field
-        p2 = torch.from_numpy(plane_field(4096, 4096)).to(dev)
-        meta2 = sz_amd.make_meta(np.float32, err_mode=sz_amd.ABS, abs_bound=EB, vmin=float(p2.min().item()), vmax=float(p2.max().item()))
-        t2, size2 = timed(lambda: run("szhip_compress", p2.data_ptr(), (0, 4096, 4096), (), meta2))
-        # a 1-D series (16 Mi values): a random walk with a sine, resident in HBM; the chain is cut at its certain restarts
-        g = torch.Generator(device="cpu"); g.manual_seed(1)
-        s1 = (torch.cumsum(torch.randn(1 << 24, generator=g, dtype=torch.float64), 0) * 0.01
-              + torch.sin(torch.arange(1 << 24, dtype=torch.float64) * 0.003)).to(torch.float32).to(dev)
-        lo1, hi1 = float(s1.min().item()), float(s1.max().item())
-        rng1 = float(np.float32(np.float32(hi1) - np.float32(lo1)))
-        med1 = float(np.float32(np.float32(lo1) + np.float32(rng1) / np.float32(2)))
-        m1 = sz_amd.make_meta(np.float32, err_mode=sz_amd.ABS, abs_bound=1e-3, vmin=lo1, vmax=hi1)
-        m1 = bytes([m1[0], m1[1], m1[2], 0x40]) + bytes(m1[4:])
-        t1d, size1d = timed(lambda: run("szhip_compress_sz14", s1.data_ptr(), (0, 0, 1 << 24), (rng1, med1), m1, eb=1e-3))
-        other = {"sz14_3d_512_f32": {"GB/s": round(nbytes_in / t14 / 1e9, 2), "ms": round(t14 * 1e3, 3), "out_bytes": size14},
-                 "sz21_2d_4096x4096_f32": {"GB/s": round(p2.numel() * 4 / t2 / 1e9, 2), "ms": round(t2 * 1e3, 3), "out_bytes": size2},
-                 "sz_1d_16Mi_f32_abs1e-3": {"GB/s": round(s1.numel() * 4 / t1d / 1e9, 2), "ms": round(t1d * 1e3, 3), "out_bytes": size1d}}
-        del p2, s1
+    # ---- host-pointer API, PCIe included (never the headline value)
+    e2e = None
+    if world == 1 and n == EDGE:
+        assert sz_amd.SZ_Init(os.path.join(ROOT, "tests", "golden", "sz_speed.config")) == 0
+        tcs, tds, s2 = [], [], None
+        for _ in range(3):
+            t1 = time.perf_counter(); s2 = sz_amd.SZ_compress_args(host, sz_amd.ABS, EB); tcs.append(time.perf_counter() - t1)
+        for _ in range(3):
+            t1 = time.perf_counter(); sz_amd.SZ_decompress(s2, host.shape, host.dtype); tds.append(time.perf_counter() - t1)
+        sz_amd.SZ_Finalize()
+        e2e = {"compress_GBps": round(nbytes_in / float(np.median(tcs)) / 1e9, 2), "decompress_GBps": round(nbytes_in / float(np.median(tds)) / 1e9, 2),
+               "what": "SZ_compress_args / SZ_decompress on a pageable host array (H2D of 512 MiB + D2H of the stream, and the reverse), median of 3",
+               "stream_identical_to_device_path": bool(len(s2) == size)}
 
-    cpu = None
+    cpu, cpu_mt = (None, None)
     if not args.no_cpu_baseline and world == 1:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle_lib as O  # checker, timed here as the CPU baseline ("port" of the reference loops)
-        sample = host if n <= 512 else host[:512]
-        t1 = time.perf_counter()
-        ref, _ = O.compress(sample, O.ABS, EB)
-        tc = time.perf_counter() - t1
-        cpu = {"value": round(sample.nbytes / tc / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
-               "sample": f"one compress pass of the full {sample.shape[0]}x{n}x{n} float32 S-field by oracle/liboracle.so ({tc:.1f} s)",
-               "stream_bytes": len(ref), "gpu_stream_identical": bool(len(ref) == size)}
+        cpu, cpu_mt = cpu_baselines(host, n, size)
 
     line = {"metric": "compression GB/s (input), 512^3 float32 ABS 1e-4", "value": round(value, 3), "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{n}x{n}x{n} float32 S-field (smooth sinusoid) per GPU, ABS 1e-4, adaptive Lorenzo+regression "
-                                   "(SZ 2.1 stream, bit-identical to the reference); input and output resident in HBM",
+            "config": {"workload": f"{n}x{n}x{n} float32 S-field (smooth sinusoid) per GPU, ABS 1e-4, SZ 2.1 path with adaptive Lorenzo+regression "
+                                   "selection per block (on this field every block chooses Lorenzo; m_field is the mixed case), stream "
+                                   "bit-identical to the reference; range scan included in the step; input and output resident in HBM",
                        "error_bound_mode": "ABS", "abs_err_bound": EB, "slabs": world},
             "ratio": round(nbytes_in / size, 6), "out_bytes": size, "max_abs_err": max_abs_err, "psnr": round(psnr, 6),
             "intervals": stats.intervals, "reg_blocks": stats.n_reg_blocks, "unpredictable": stats.n_unpred,
             "decompress_GBps": round(nbytes_in / td / 1e9, 3),
-            "phase_ms": {"prequant": round(stats.ms_prequant, 3), "quant": round(stats.ms_quant, 3), "entropy": round(stats.ms_entropy, 3),
-                         "host_glue": round(stats.ms_host, 3), "total": round(stats.ms_total, 3),
+            "phase_ms": {"range_scan_and_glue": round(ms_per_step - stats.ms_total, 3), "prequant": round(stats.ms_prequant, 3), "quant": round(stats.ms_quant, 3),
+                         "entropy": round(stats.ms_entropy, 3), "host_glue": round(stats.ms_host, 3), "compress_call_total": round(stats.ms_total, 3),
                          "decompress_quant": round(dst.ms_quant, 3), "decompress_total": round(dst.ms_total, 3)},
-            "roofline": roofline, "cpu_baseline": cpu, "other_paths": other}
+            "roofline": roofline, "m_field": mfield, "e2e": e2e, "cpu_baseline": cpu, "cpu_baseline_mt": cpu_mt}
     print(json.dumps(line))
     if world > 1:
         dist.barrier(); dist.destroy_process_group()
+
+
+def run_c4(args, torch, dist, world, rank, local_rank, dev):
+    """BASELINE configs[3]: 1024^3 float64, REL 1e-3, slabs of the outer dimension, RCCL all-reduce of the range + all-gather of the streams."""
+    import ctypes
+    import sz_amd
+    from sz_amd import slab
+    from sz_amd.fields import s_field
+    N = args.c4_edge
+    nslabs = max(world, 8) if world < 8 else world          # the array is cut for 8 GPUs; with fewer ranks each rank still runs ONE slab of that cut
+    bounds = slab.slab_bounds(N, nslabs)
+    z0, z1 = bounds[rank]
+    planes = z1 - z0
+    host = s_field(planes, N, N, np.float64, z0=z0)
+    x = torch.from_numpy(host).to(dev)
+    nbytes_in = host.nbytes
+    ctx = sz_amd.HipContext(local_rank)
+    out_cap = nbytes_in // 2 + (1 << 20)
+    out_bufs = [torch.empty(out_cap, dtype=torch.uint8, device=dev) for _ in range(2)]
+    gather = slab.StreamGather() if world > 1 else None
+    pending, step_no = [], [0]
+    eb_box = [0.0]
+
+    def one_step():
+        lo, hi = ctx.minmax(x.data_ptr(), True, x.numel(), np.float64)                 # local range scan on the GPU
+        lo, hi = slab.global_minmax(lo, hi, device=dev)                                # 2 scalars over RCCL (sz_float.c:2845-2866 needs the GLOBAL range)
+        eb = 1e-3 * (hi - lo)
+        eb_box[0] = eb
+        meta = sz_amd.make_meta(np.float64, err_mode=sz_amd.REL, rel_ratio=1e-3, vmin=lo, vmax=hi)
+        ob = out_bufs[step_no[0] & 1]; step_no[0] += 1
+        out = ctypes.c_void_p(ob.data_ptr()); nn = ctypes.c_size_t(out_cap); st = sz_amd.szhip_stats()
+        p = sz_amd.szhip_params(100, 0.99, 65536, 0)
+        rc = sz_amd.lib().szhip_compress(ctx._h, 1, x.data_ptr(), 1, planes, N, N, eb, ctypes.byref(p), meta, len(meta), 2,
+                                         ctypes.byref(out), ctypes.byref(nn), ctypes.byref(st))
+        if rc:
+            raise RuntimeError(f"szhip_compress failed: {sz_amd.lib().szhip_last_error(ctx._h)}")
+        if world > 1:
+            pending.append(gather.begin(ob, nn.value))
+            if len(pending) > 1:
+                gather.end(pending.pop(0))
+        return nn.value, st, ob
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    while pending:
+        gather.end(pending.pop(0))
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        size, st, ob = one_step()
+    parts = None
+    while pending:
+        parts = gather.end(pending.pop(0))
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    # every rank decompresses its OWN sub-stream (from the gathered set when there is one) and checks the bound
+    eb = eb_box[0]
+    dec = torch.empty_like(x)
+    src = ob if parts is None else parts[0][rank].contiguous()
+    torch.cuda.synchronize(); td = time.perf_counter()
+    ctx.decompress(src.data_ptr(), True, size, 4 + 36 + 8, (planes, N, N), np.float64, dec.data_ptr(), True)
+    torch.cuda.synchronize(); td = time.perf_counter() - td
+    max_err = float((dec - x).abs().max().item())
+    stats_t = torch.tensor([elapsed, max_err, float(size), td], dtype=torch.float64, device=dev)
+    if world > 1:
+        allst = [torch.zeros_like(stats_t) for _ in range(world)]
+        dist.all_gather(allst, stats_t)
+    else:
+        allst = [stats_t]
+    if rank == 0:
+        el = max(float(s[0]) for s in allst)
+        worst = max(float(s[1]) for s in allst)
+        total_out = sum(float(s[2]) for s in allst)
+        line = {"metric": "compression GB/s (input), 1024^3 float64 REL 1e-3, slab-sharded", "value": round(world * nbytes_in / (el / args.steps) / 1e9, 3),
+                "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 4),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": f"{N}^3 float64 S-field cut into {nslabs} slabs of the outer dimension (block-aligned cuts); {world} rank(s), each "
+                                       f"running ONE slab ({planes}x{N}x{N}); REL 1e-3 on the all-reduced range; range scan, all-reduce and the "
+                                       "all-gather of the sub-streams inside the step", "slabs_run": world, "slabs_of_array": nslabs},
+                "eb": eb, "max_abs_err": worst, "bound_held": bool(worst <= eb), "out_bytes_all_ranks": int(total_out),
+                "ratio": round(world * nbytes_in / total_out, 4), "decompress_GBps_per_gpu": round(nbytes_in / max(float(s[3]) for s in allst) / 1e9, 2),
+                "phase_ms_rank0": {"prequant": round(st.ms_prequant, 3), "quant": round(st.ms_quant, 3), "entropy": round(st.ms_entropy, 3)}}
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="headline", choices=["headline", "c4"])
+    ap.add_argument("--edge", type=int, default=EDGE, help="cube edge of the headline config (512 = the BASELINE config)")
+    ap.add_argument("--c4-edge", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-m-field", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    (run_c4 if args.config == "c4" else run_headline)(args, torch, dist, world, rank, local_rank, dev)
 
 
 if __name__ == "__main__":

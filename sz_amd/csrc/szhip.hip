@@ -7,7 +7,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <ctime>
+#include <future>
+#include <thread>
 #include <vector>
 #include "../../include/szhip.h"
 #include "szhost.h"
@@ -332,12 +335,46 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     } else HIPCHK(hipEventSynchronize(ctx->ev_fit));           // usually long done
     const size_t reg_count = (size_t)*nreg_h;
     S.n_reg_blocks = reg_count;
-    // ---- regression coefficient chain (serial, host) and its Huffman streams
+    // ---- regression coefficient chain (a serial recurrence with reconstruction feedback: host) and its Huffman streams.
+    //      The chains of the four (three) coefficients are independent of each other and each is bound by the latency of its own
+    //      ~45-cycle dependence per block, so they run on one host thread each; a thread goes on to build its coefficient's section
+    //      of the stream header (histogram, tree, payload) while the wavefront kernel is already running on the decoded values.
     szhost_coeffs cf; memset(&cf, 0, sizeof(cf));
     std::vector<unsigned char> coef_sections;
+    std::vector<unsigned char> section[4];
+    std::vector<std::thread> section_threads;
+    std::atomic<int> section_failed(0);
+    std::vector<T> hcoef;
+    auto make_section = [&](int e) {   // (lives as long as the threads that call it: declared in the function's scope)
+        std::vector<uint32_t> h32(65536, 0);
+        for (size_t i = 0; i < reg_count; ++i) h32[(size_t)cf.codes[e][i]]++;
+        szhost_huff *ch = szhost_huff_build(131072, h32.data(), nullptr, 65536);
+        if (!ch) { section_failed = 1; return; }
+        const size_t tb = szhost_huff_tree_size(ch);
+        const size_t enc_cap = (size_t)((ch->total_bits + 7) / 8) + 16;
+        std::vector<unsigned char> &sec = section[e];
+        sec.assign(sizeof(T) + 12 + tb + 8 + enc_cap + 4 + cf.unpred_count[e] * sizeof(T), 0);
+        unsigned char *q = sec.data();
+        if (is_double) szhost_put_f64be(q, cf.prec[e]); else szhost_put_f32be(q, (float)cf.prec[e]);
+        q += sizeof(T);
+        szhost_put_u32be(q, 32768); q += 4;
+        szhost_put_u32be(q, (uint32_t)tb); q += 4;
+        szhost_put_u32be(q, (uint32_t)ch->n_nodes); q += 4;
+        szhost_huff_tree_write(ch, q); q += tb;
+        const size_t enc = szhost_huff_encode_i32(ch, cf.codes[e], reg_count, q + 8);
+        szhost_put_u64be(q, enc); q += 8 + enc;
+        szhost_put_u32be(q, (uint32_t)cf.unpred_count[e]); q += 4;
+        memcpy(q, cf.unpred[e], cf.unpred_count[e] * sizeof(T)); q += cf.unpred_count[e] * sizeof(T);
+        sec.resize((size_t)(q - sec.data()));
+        szhost_huff_free(ch);
+    };
+    struct JoinSections {   // no early return may leave the section threads running on this frame's data
+        std::vector<std::thread> &t; szhost_coeffs &c;
+        ~JoinSections() { for (auto &x : t) if (x.joinable()) x.join(); szhost_coeffs_free(&c); }
+    } join_sections{section_threads, cf};
     if (reg_count > 0) {
         // only the regression blocks' coefficients travel: rank them in scan order, gather [4][reg_count], chain on the host
-        // (the compact arrays are "all regression blocks" to szhost_coeff_chain), scatter the decoded values back
+        // (the compact arrays are "all regression blocks" to the chain), scatter the decoded values back
         TRY(ensure(ctx, ctx->reg_flags, (size_t)nb * 8));
         TRY(ensure(ctx, ctx->reg_rank, (size_t)nb * 8));
         TRY(ensure(ctx, ctx->coef_compact, reg_count * 4 * sizeof(T)));
@@ -346,45 +383,34 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         hipLaunchKernelGGL((k_move_coef<T, 0>), dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, (const uint8_t *)d_lor,
                            (const u64 *)ctx->reg_rank.p, nb, (int64_t)reg_count, d_coef, (T *)ctx->coef_compact.p);
         HIPCHK(hipGetLastError());
-        std::vector<T> hcoef(reg_count * 4);
+        hcoef.resize(reg_count * 4);
         HIPCHK(hipMemcpyAsync(hcoef.data(), ctx->coef_compact.p, hcoef.size() * sizeof(T), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         double h0 = now_ms();
         const std::vector<unsigned char> all_reg(reg_count, 0);
         // 2-D planes are carried as {0, a, b, c}: the chain sees components 1..3
-        szhost_coeff_chain(is_double, hcoef.data() + (two_d ? reg_count : 0), all_reg.data(), reg_count, (double)eb, G.g0.late, G.g1.late,
-                           G.g2.late, use_mean, ncoef, &cf);
-        for (int e = 0; e < ncoef; ++e) {
-            std::vector<uint32_t> h32(65536, 0);
-            for (size_t i = 0; i < reg_count; ++i) h32[(size_t)cf.codes[e][i]]++;
-            szhost_huff *ch = szhost_huff_build(131072, h32.data(), nullptr, 65536);
-            if (!ch) { szhost_coeffs_free(&cf); FAIL(SZHIP_ERR_INTERNAL, "coefficient Huffman build failed"); }
-            const size_t tb = szhost_huff_tree_size(ch);
-            const size_t enc_cap = (size_t)((ch->total_bits + 7) / 8) + 16;
-            size_t pos = coef_sections.size();
-            coef_sections.resize(pos + sizeof(T) + 12 + tb + 8 + enc_cap + 4 + cf.unpred_count[e] * sizeof(T));
-            unsigned char *q = coef_sections.data() + pos;
-            if (is_double) szhost_put_f64be(q, cf.prec[e]); else szhost_put_f32be(q, (float)cf.prec[e]);
-            q += sizeof(T);
-            szhost_put_u32be(q, 32768); q += 4;
-            szhost_put_u32be(q, (uint32_t)tb); q += 4;
-            szhost_put_u32be(q, (uint32_t)ch->n_nodes); q += 4;
-            szhost_huff_tree_write(ch, q); q += tb;
-            memset(q + 8, 0, enc_cap);
-            const size_t enc = szhost_huff_encode_i32(ch, cf.codes[e], reg_count, q + 8);
-            szhost_put_u64be(q, enc); q += 8 + enc;
-            szhost_put_u32be(q, (uint32_t)cf.unpred_count[e]); q += 4;
-            memcpy(q, cf.unpred[e], cf.unpred_count[e] * sizeof(T)); q += cf.unpred_count[e] * sizeof(T);
-            coef_sections.resize((size_t)(q - coef_sections.data()));
-            szhost_huff_free(ch);
+        T *const chain_in = hcoef.data() + (two_d ? reg_count : 0);
+        szhost_coeff_chain_begin(is_double, all_reg.data(), reg_count, (double)eb, G.g0.late, G.g1.late, G.g2.late, ncoef, &cf);
+        if (reg_count >= 20000) {
+            std::vector<std::promise<void>> chained(ncoef);
+            std::vector<std::future<void>> chained_f;
+            for (int e = 0; e < ncoef; ++e) chained_f.push_back(chained[e].get_future());
+            for (int e = 0; e < ncoef; ++e)
+                section_threads.emplace_back([&, e, chain_in, ind = all_reg.data()](std::promise<void> done) {
+                    szhost_coeff_chain_one(is_double, chain_in, ind, reg_count, use_mean, e, &cf);
+                    done.set_value();                     // the decoded coefficients of e are final: the main thread may ship them
+                    make_section(e);
+                }, std::move(chained[e]));
+            for (auto &f : chained_f) f.wait();
+        } else {
+            for (int e = 0; e < ncoef; ++e) { szhost_coeff_chain_one(is_double, chain_in, all_reg.data(), reg_count, use_mean, e, &cf); make_section(e); }
         }
         host_ms += now_ms() - h0;
-        szhost_coeffs_free(&cf);
         HIPCHK(hipMemcpyAsync(ctx->coef_compact.p, hcoef.data(), hcoef.size() * sizeof(T), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL((k_move_coef<T, 1>), dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, (const uint8_t *)d_lor,
                            (const u64 *)ctx->reg_rank.p, nb, (int64_t)reg_count, d_coef, (T *)ctx->coef_compact.p);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(st)); // hcoef goes out of scope
+        // (hcoef stays alive until the end of the call: the copy above is asynchronous)
     }
     HIPCHK(hipEventRecord(ctx->ev[1], st));
 
@@ -451,21 +477,22 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
                        (u64 *)ctx->col_zeros64.p);
     TRY(scan_u64(ctx, (const u64 *)ctx->col_zeros64.p, ncols, (u64 *)ctx->col_off.p, sm + SM_TOTAL_UNPRED));
 
-    u64 h_small[SM_COUNT];
-    HIPCHK(hipMemcpyAsync(h_small, sm, SM_COUNT * 8, hipMemcpyDeviceToHost, st));
-
-    // ---- Huffman code book (host: heap order decides the codes), built as soon as the histogram has arrived
+    // ---- Huffman code book (host: heap order decides the codes), built as soon as the histogram has arrived.  This is the only host
+    //      round trip of the entropy stage: the number of unpredictable values is the histogram's bin 0, so the header can be written
+    //      and the remaining kernels enqueued while the block-ordering pass is still running; the kernel error flag and the device's
+    //      own count of zero codes are checked after the final synchronisation.
     HIPCHK(hipEventSynchronize(ctx->ev_fit));
     double h0 = now_ms();
     szhost_huff *hf = szhost_huff_build(2 * (int)intervals, h_hist, nullptr, intervals);
     host_ms += now_ms() - h0;
-    HIPCHK(hipStreamSynchronize(st));
-    if ((unsigned)h_small[SM_ERR] != 0) { if (hf) szhost_huff_free(hf); FAIL(SZHIP_ERR_INTERNAL, "wavefront kernel: halo wait timed out"); }
-    const u64 total_unpred = h_small[SM_TOTAL_UNPRED];
+    const u64 total_unpred = h_hist[0];
     S.n_unpred = total_unpred;
     if (!hf) FAIL(SZHIP_ERR_INTERNAL, "Huffman build failed");
 
     // ---- stream header
+    for (auto &x : section_threads) if (x.joinable()) x.join();
+    if (section_failed) { szhost_huff_free(hf); FAIL(SZHIP_ERR_INTERNAL, "coefficient Huffman build failed"); }
+    for (int e = 0; e < ncoef; ++e) coef_sections.insert(coef_sections.end(), section[e].begin(), section[e].end());
     h0 = now_ms();
     const size_t tree_bytes = szhost_huff_tree_size(hf);
     const size_t hdr_len = meta_len + 8 + 4 + sizeof(T) + 4 + 4 + 4 + tree_bytes + 1 + sizeof(T) + ind_bytes + coef_sections.size() + 8;
@@ -526,8 +553,8 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(ctx->ev[4], st));
-    u64 tb = 0;                                                // the shuffled bit count, checked after the synchronisation below
-    if (total_bits > 0) HIPCHK(hipMemcpyAsync(&tb, sm + SM_TOTAL_BITS, 8, hipMemcpyDeviceToHost, st));
+    u64 h_small[SM_COUNT];                                     // checked after the synchronisation below
+    HIPCHK(hipMemcpyAsync(h_small, sm, SM_COUNT * 8, hipMemcpyDeviceToHost, st));
     if (out_on_device == 2) { // caller-provided device buffer of capacity *out_size
         if (!*out || *out_size < total_len) FAIL(SZHIP_ERR_ARG, "caller's device buffer too small (%zu < %zu)", *out_size, total_len);
         HIPCHK(hipMemcpyAsync(*out, d_stream, total_len, hipMemcpyDeviceToDevice, st));
@@ -543,10 +570,12 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         *out = h;
     }
     *out_size = total_len;
-    // the shuffled bit count must match what the code book predicted
-    {
-        if (tb != total_bits) FAIL(SZHIP_ERR_INTERNAL, "encoded bit count mismatch (%llu vs %llu)", (unsigned long long)tb, (unsigned long long)total_bits);
-    }
+    // after the final synchronisation: the wavefront kernel's error flag; the shuffled bit count and the device's count of zero codes
+    // must match what the histogram predicted
+    if ((unsigned)h_small[SM_ERR] != 0) FAIL(SZHIP_ERR_INTERNAL, "wavefront kernel: halo wait timed out");
+    if ((total_bits > 0 && h_small[SM_TOTAL_BITS] != total_bits) || h_small[SM_TOTAL_UNPRED] != total_unpred)
+        FAIL(SZHIP_ERR_INTERNAL, "entropy stage mismatch (bits %llu vs %llu, unpredictable %llu vs %llu)", (unsigned long long)h_small[SM_TOTAL_BITS],
+             (unsigned long long)total_bits, (unsigned long long)h_small[SM_TOTAL_UNPRED], (unsigned long long)total_unpred);
     float ms = 0;
     hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); S.ms_prequant = ms;
     hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); S.ms_quant = ms;

@@ -335,50 +335,73 @@ void szhost_coeffs_free(szhost_coeffs *c)
     for (int e = 0; e < 4; e++) { free(c->codes[e]); free(c->unpred[e]); c->codes[e] = NULL; c->unpred[e] = NULL; }
 }
 
-#define CHAIN_BODY(T, FABS, DIVIDE_IN_NOMEAN)                                                              \
-    T *cf = (T *)coef;                                                                                     \
-    T ebT = (T)eb;                                                                                         \
-    T rel = ncoef == 3 ? (T)(0.15 / 3) : (T)0.025;   /* sz_float.c:5608 (2-D), :6640 (3-D) */              \
-    T prec[4] = {0, 0, 0, 0}, rprec[4], last[4] = {0, 0, 0, 0};                                            \
-    if (ncoef == 3) { prec[0] = rel * ebT / late1; prec[1] = rel * ebT / late2; prec[2] = rel * ebT; }     \
-    else { prec[0] = rel * ebT / late0; prec[1] = rel * ebT / late1; prec[2] = rel * ebT / late2; prec[3] = rel * ebT; } \
-    for (int e = 0; e < ncoef; e++) { rprec[e] = 1 / prec[e]; out->prec[e] = (double)prec[e]; }            \
-    T *un[4] = {0, 0, 0, 0};                                                                               \
-    for (int e = 0; e < ncoef; e++) { un[e] = (T *)malloc((reg_count ? reg_count : 1) * sizeof(T)); out->unpred[e] = un[e]; } \
-    size_t ci = 0;                                                                                         \
+/* one coefficient's chain: the four (three) chains of a block sequence are independent of each other, so callers may run them on
+ * different threads (szhost_coeff_chain_begin once, then szhost_coeff_chain_one per e) */
+#define CHAIN_ONE(T, FABS, DIVIDE_IN_NOMEAN)                                                              \
+    T *cf = (T *)coef + (size_t)e * nblocks;                                                               \
+    const T prec = (T)out->prec[e], rprec = 1 / prec;                                                      \
+    T last = 0;                                                                                            \
+    T *un = (T *)out->unpred[e];                                                                           \
+    int *codes = out->codes[e];                                                                            \
+    size_t ci = 0, nun = 0;                                                                                \
     for (size_t b = 0; b < nblocks; b++) {                                                                 \
         if (indicator[b]) continue;                                                                        \
-        for (int e = 0; e < ncoef; e++) {                                                                  \
-            T cur = cf[(size_t)e * nblocks + b];                                                           \
-            T diff = cur - last[e];                                                                        \
-            T itv;                                                                                         \
-            if (DIVIDE_IN_NOMEAN && !use_mean) itv = FABS(diff) / prec[e] + 1;                             \
-            else itv = FABS(diff) * rprec[e] + 1;                                                          \
-            int cc = 0;                                                                                    \
-            if (itv < 65536) {                                                                             \
-                if (diff < 0) itv = -itv;                                                                  \
-                cc = (int)(itv / 2) + 32768;                                                               \
-                last[e] = last[e] + 2 * (cc - 32768) * prec[e];                                            \
-                if (FABS(cur - last[e]) > prec[e]) { cc = 0; last[e] = cur; un[e][out->unpred_count[e]++] = cur; } \
-            } else { cc = 0; last[e] = cur; un[e][out->unpred_count[e]++] = cur; }                         \
-            out->codes[e][ci] = cc;                                                                        \
-            cf[(size_t)e * nblocks + b] = last[e];                                                         \
-        }                                                                                                  \
-        ci++;                                                                                              \
-    }
+        T cur = cf[b];                                                                                     \
+        T diff = cur - last;                                                                               \
+        T itv;                                                                                             \
+        if (DIVIDE_IN_NOMEAN && !use_mean) itv = FABS(diff) / prec + 1;                                    \
+        else itv = FABS(diff) * rprec + 1;                                                                 \
+        int cc = 0;                                                                                        \
+        if (itv < 65536) {                                                                                 \
+            if (diff < 0) itv = -itv;                                                                      \
+            cc = (int)(itv / 2) + 32768;                                                                   \
+            last = last + 2 * (cc - 32768) * prec;                                                         \
+            if (FABS(cur - last) > prec) { cc = 0; last = cur; un[nun++] = cur; }                          \
+        } else { cc = 0; last = cur; un[nun++] = cur; }                                                    \
+        codes[ci++] = cc;                                                                                  \
+        cf[b] = last;                                                                                      \
+    }                                                                                                      \
+    out->unpred_count[e] = nun;
 
 /* ncoef = 4: 3-D planes {a,b,c,d}, precisions from late0..late2; ncoef = 3: 2-D planes {a,b,c} (sz_float.c:6031-6055), precisions
  * from late1, late2 (late0 unused).  `coef` is SoA [ncoef][nblocks]. */
-void szhost_coeff_chain(int is_double, void *coef, const unsigned char *indicator, size_t nblocks, double eb,
-                        int late0, int late1, int late2, int use_mean, int ncoef, szhost_coeffs *out)
+void szhost_coeff_chain_begin(int is_double, const unsigned char *indicator, size_t nblocks, double eb,
+                              int late0, int late1, int late2, int ncoef, szhost_coeffs *out)
 {
     memset(out, 0, sizeof(*out));
     size_t reg_count = 0;
     for (size_t b = 0; b < nblocks; b++) if (!indicator[b]) reg_count++;
     out->reg_count = reg_count;
-    for (int e = 0; e < ncoef; e++) out->codes[e] = (int *)malloc((reg_count ? reg_count : 1) * sizeof(int));
-    if (is_double) { CHAIN_BODY(double, fabs, 0) }
-    else { CHAIN_BODY(float, fabsf, 1) }
+    const size_t esz = is_double ? 8 : 4;
+    for (int e = 0; e < ncoef; e++) {
+        out->codes[e] = (int *)malloc((reg_count ? reg_count : 1) * sizeof(int));
+        out->unpred[e] = malloc((reg_count ? reg_count : 1) * esz);
+    }
+    /* the precisions, in the data's type (sz_float.c:5608 (2-D), :6640 (3-D)) */
+    if (is_double) {
+        double ebT = eb, rel = ncoef == 3 ? (double)(0.15 / 3) : (double)0.025, p[4] = {0, 0, 0, 0};
+        if (ncoef == 3) { p[0] = rel * ebT / late1; p[1] = rel * ebT / late2; p[2] = rel * ebT; }
+        else { p[0] = rel * ebT / late0; p[1] = rel * ebT / late1; p[2] = rel * ebT / late2; p[3] = rel * ebT; }
+        for (int e = 0; e < ncoef; e++) out->prec[e] = p[e];
+    } else {
+        float ebT = (float)eb, rel = ncoef == 3 ? (float)(0.15 / 3) : (float)0.025, p[4] = {0, 0, 0, 0};
+        if (ncoef == 3) { p[0] = rel * ebT / late1; p[1] = rel * ebT / late2; p[2] = rel * ebT; }
+        else { p[0] = rel * ebT / late0; p[1] = rel * ebT / late1; p[2] = rel * ebT / late2; p[3] = rel * ebT; }
+        for (int e = 0; e < ncoef; e++) out->prec[e] = (double)p[e];
+    }
+}
+
+void szhost_coeff_chain_one(int is_double, void *coef, const unsigned char *indicator, size_t nblocks, int use_mean, int e, szhost_coeffs *out)
+{
+    if (is_double) { CHAIN_ONE(double, fabs, 0) }
+    else { CHAIN_ONE(float, fabsf, 1) }
+}
+
+void szhost_coeff_chain(int is_double, void *coef, const unsigned char *indicator, size_t nblocks, double eb,
+                        int late0, int late1, int late2, int use_mean, int ncoef, szhost_coeffs *out)
+{
+    szhost_coeff_chain_begin(is_double, indicator, nblocks, eb, late0, late1, late2, ncoef, out);
+    for (int e = 0; e < ncoef; e++) szhost_coeff_chain_one(is_double, coef, indicator, nblocks, use_mean, e, out);
 }
 
 void szhost_coeff_unchain(int is_double, void *coef, const unsigned char *indicator, size_t nblocks,

@@ -63,6 +63,10 @@ typedef struct szhost_coeffs {
  * with the DECODED coefficients (what the decompressor will use).  ncoef = 4: 3-D; ncoef = 3: 2-D (late0 unused). */
 void szhost_coeff_chain(int is_double, void *coef, const unsigned char *indicator, size_t nblocks, double eb,
                         int late0, int late1, int late2, int use_mean, int ncoef, szhost_coeffs *out);
+/* the same in pieces: the chains of the ncoef coefficients are independent (one thread each) */
+void szhost_coeff_chain_begin(int is_double, const unsigned char *indicator, size_t nblocks, double eb,
+                              int late0, int late1, int late2, int ncoef, szhost_coeffs *out);
+void szhost_coeff_chain_one(int is_double, void *coef, const unsigned char *indicator, size_t nblocks, int use_mean, int e, szhost_coeffs *out);
 void szhost_coeffs_free(szhost_coeffs *c);
 /* inverse: codes+unpred -> decoded coefficients written into coef SoA [ncoef][nblocks] for regression blocks */
 void szhost_coeff_unchain(int is_double, void *coef, const unsigned char *indicator, size_t nblocks,

@@ -16,12 +16,25 @@ import numpy as np
 MAGIC = b"SZSL"
 
 
-def slab_bounds(n0, world):
-    """Contiguous split of the slowest dimension; the first n0 % world slabs get one extra plane."""
-    base, rem = divmod(n0, world)
+def slab_bounds(n0, world, block=6):
+    """Contiguous split of the slowest dimension into `world` slabs whose cuts fall on multiples of the block edge, so
+    that every slab's block grid is the whole array's; the planes that do not fill a block go to the last slab.  Arrays with fewer
+    blocks than ranks are cut plane-wise."""
+    units = n0 // block
+    if units < world:
+        base, rem = divmod(n0, world)
+        out, z = [], 0
+        for r in range(world):
+            h = base + (1 if r < rem else 0)
+            out.append((z, z + h))
+            z += h
+        return out
+    base, rem = divmod(units, world)
     out, z = [], 0
     for r in range(world):
-        h = base + (1 if r < rem else 0)
+        h = (base + (1 if r < rem else 0)) * block
+        if r == world - 1:
+            h = n0 - z
         out.append((z, z + h))
         z += h
     return out
@@ -87,16 +100,18 @@ def allgather_streams(local_stream, nbytes=None):
 
 
 class StreamGather:
-    """The same all-gather, overlapped with the next compression step: begin() launches the gather of this step's sub-stream
-    and returns; end() completes one.  The payload travels from a private copy, so the caller's buffer may be overwritten as
-    soon as begin() returns; two gathers may be in flight (two sets of buffers).  What end() returns are views of those
-    buffers: valid until the second begin() after the one that started this gather."""
+    """The same all-gather, overlapped with the next compression step: begin() launches the gather of this step's sub-stream and
+    returns without touching the host; end() completes one.  No size exchange per step: every payload carries its length in its
+    first 8 bytes and travels in a buffer sized from what the streams needed before (+25 %); the first gather (and one whose
+    stream outgrew the buffer -- every rank sees that in the lengths) is done with the plain, blocking form.  The caller keeps
+    `local_stream` untouched until end() (bench.py alternates two output buffers)."""
 
     def __init__(self, depth=2):
         self.depth = depth
         self.send = [None] * depth
         self.recv = [None] * depth
         self.slot = 0
+        self.cap = 0
 
     def begin(self, local_stream, nbytes):
         import torch
@@ -104,26 +119,37 @@ class StreamGather:
         n = int(nbytes)
         world = dist.get_world_size()
         dev = local_stream.device
-        sizes = torch.zeros(world, dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(sizes, torch.tensor([n], dtype=torch.int64, device=dev))
-        sizes = [int(x) for x in sizes.tolist()]
-        cap = (max(sizes) + 255) // 256 * 256
+        if self.cap == 0:                                  # first use: learn the sizes the blocking way
+            parts, sizes = allgather_streams(local_stream, n)
+            self.cap = ((max(sizes) * 5 // 4 + 8) + 255) // 256 * 256
+            return ("done", parts, sizes)
+        cap = self.cap
         k = self.slot
         self.slot = (self.slot + 1) % self.depth
-        if self.send[k] is None or self.send[k].numel() < cap:
-            self.send[k] = torch.empty(cap + cap // 4, dtype=torch.uint8, device=dev)
-            self.recv[k] = torch.empty(world * (cap + cap // 4), dtype=torch.uint8, device=dev)
-        send = self.send[k][:cap]
-        send[:n] = local_stream[:n]
-        if send.is_cuda:
-            torch.cuda.current_stream(dev).synchronize()   # the copy is done before the caller reuses local_stream (its producer
-                                                           # runs on a stream of its own)
-        recv = self.recv[k][:world * cap]
-        work = dist.all_gather_into_tensor(recv, send, async_op=True)
-        return (work, recv, sizes, cap)
+        if self.send[k] is None or self.send[k].numel() != cap:
+            self.send[k] = torch.empty(cap, dtype=torch.uint8, device=dev)
+            self.recv[k] = torch.empty(world * cap, dtype=torch.uint8, device=dev)
+        send = self.send[k]
+        send[:8] = torch.tensor([n], dtype=torch.int64).view(torch.uint8).to(dev, non_blocking=True)
+        m = min(n, cap - 8)
+        send[8:8 + m] = local_stream[:m]
+        work = dist.all_gather_into_tensor(self.recv[k], send, async_op=True)
+        return ("async", work, self.recv[k], cap, local_stream, n)
 
-    @staticmethod
-    def end(handle):
-        work, recv, sizes, cap = handle
+    def end(self, handle):
+        if handle[0] == "done":
+            return handle[1], handle[2]
+        _, work, recv, cap, local_stream, n = handle
         work.wait()
-        return [recv[r * cap:r * cap + sizes[r]] for r in range(len(sizes))], sizes
+        world = recv.numel() // cap
+        sizes = [int(x) for x in recv.view(world, cap)[:, :8].contiguous().view(torch_int64()).flatten().tolist()]
+        if max(sizes) > cap - 8:                           # a stream outgrew the buffers: every rank sees it, all redo this one
+            parts, sizes = allgather_streams(local_stream, n)
+            self.cap = ((max(sizes) * 5 // 4 + 8) + 255) // 256 * 256
+            return parts, sizes
+        return [recv[r * cap + 8:r * cap + 8 + sizes[r]] for r in range(world)], sizes
+
+
+def torch_int64():
+    import torch
+    return torch.int64

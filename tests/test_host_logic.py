@@ -183,7 +183,9 @@ def test_host_huffman_matches_reference_stream(L, oracle, c1_data, case):
 def test_slab_container_roundtrip():
     from sz_amd import slab
     b = slab.slab_bounds(1030, 8)
-    assert b[0] == (0, 129) and b[-1][1] == 1030 and all(x[1] == y[0] for x, y in zip(b, b[1:]))
+    # cuts on multiples of the block edge (6): every slab's block grid is the whole array's; the remainder goes to the last slab
+    assert b[0] == (0, 132) and b[-1][1] == 1030 and all(x[1] == y[0] for x, y in zip(b, b[1:])) and all(x[0] % 6 == 0 for x in b)
+    assert slab.slab_bounds(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]          # fewer blocks than ranks: plane-wise
     streams = [os.urandom(10 + 7 * r) for r in range(8)]
     blob = slab.pack_container(np.float64, (1030, 64, 32), b, streams)
     dt, dims, bounds, got = slab.unpack_container(blob)
