@@ -81,6 +81,26 @@ static int zstd_load(void)
     return 1;
 }
 
+/* ---- zlib (GZIP_COMPRESSOR; callZlib.c:205-253 deflates with deflateInit(level), :496-527 inflates) through the system library ---- */
+typedef int (*z_compress2_fn)(unsigned char *, unsigned long *, const unsigned char *, unsigned long, int);
+typedef int (*z_uncompress_fn)(unsigned char *, unsigned long *, const unsigned char *, unsigned long);
+typedef unsigned long (*z_bound_fn)(unsigned long);
+static struct { int tried; void *h; z_compress2_fn compress2; z_uncompress_fn uncompress; z_bound_fn bound; } g_zlib;
+
+static int zlib_load(void)
+{
+    if (g_zlib.tried) return g_zlib.h != NULL;
+    g_zlib.tried = 1;
+    const char *names[] = {"libz.so.1", "libz.so", NULL};
+    for (int i = 0; names[i] && !g_zlib.h; i++) g_zlib.h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+    if (!g_zlib.h) return 0;
+    g_zlib.compress2 = (z_compress2_fn)dlsym(g_zlib.h, "compress2");
+    g_zlib.uncompress = (z_uncompress_fn)dlsym(g_zlib.h, "uncompress");
+    g_zlib.bound = (z_bound_fn)dlsym(g_zlib.h, "compressBound");
+    if (!g_zlib.compress2 || !g_zlib.uncompress || !g_zlib.bound) { dlclose(g_zlib.h); g_zlib.h = NULL; return 0; }
+    return 1;
+}
+
 /* ---- init / finalize ---- */
 int SZ_Init(const char *configFilePath)
 {
@@ -320,18 +340,25 @@ static int compress_fp(int dataType, int withRegression, unsigned char **newByte
 
     if (confparams_cpr->szMode == SZ_BEST_SPEED) { *newByteData = tmp; *outSize = tmpSize; }
     else if (confparams_cpr->szMode == SZ_BEST_COMPRESSION || confparams_cpr->szMode == SZ_DEFAULT_COMPRESSION) {
-        if (confparams_cpr->losslessCompressor == ZSTD_COMPRESSOR && zstd_load()) { /* sz_lossless_compress, utility.c:174-195 */
+        /* sz_lossless_compress, utility.c:174-195.  A missing back end is an error: returning the bare SZ stream would silently
+         * change what szMode promises (and the reference's default is SZ_BEST_COMPRESSION, conf.c:114) */
+        if (confparams_cpr->losslessCompressor == ZSTD_COMPRESSOR) {
+            if (!zstd_load()) { printf("Error: szMode asks for the zstd back end but libzstd.so.1 cannot be loaded (use SZ_BEST_SPEED or GZIP_COMPRESSOR).\n"); free(tmp); return SZ_NSCS; }
             size_t est = tmpSize < 100 ? 200 : (size_t)(tmpSize * 1.2);
             unsigned char *z = (unsigned char *)malloc(est);
+            if (!z) { free(tmp); return SZ_NSCS; }
             size_t zs = g_zstd.compress(z, est, tmp, tmpSize, confparams_cpr->gzipMode);
             if (g_zstd.iserr(zs)) { printf("Error: ZSTD_compress failed.\n"); free(z); free(tmp); return SZ_NSCS; }
             free(tmp); *newByteData = z; *outSize = zs;
-        } else {
-            static int warned = 0;
-            if (!warned) { fprintf(stderr, "[SZ] note: lossless back-end (%s) not available in this build; returning the SZ stream without it\n",
-                                   confparams_cpr->losslessCompressor == ZSTD_COMPRESSOR ? "libzstd.so.1" : "gzip"); warned = 1; }
-            *newByteData = tmp; *outSize = tmpSize;
-        }
+        } else if (confparams_cpr->losslessCompressor == GZIP_COMPRESSOR) {
+            if (!zlib_load()) { printf("Error: szMode asks for the gzip back end but libz.so.1 cannot be loaded (use SZ_BEST_SPEED).\n"); free(tmp); return SZ_NSCS; }
+            unsigned long zl = g_zlib.bound((unsigned long)tmpSize);
+            unsigned char *z = (unsigned char *)malloc(zl);
+            if (!z) { free(tmp); return SZ_NSCS; }
+            int zr = g_zlib.compress2(z, &zl, tmp, (unsigned long)tmpSize, confparams_cpr->gzipMode);   /* zlib_compress5: deflateInit(level), one stream */
+            if (zr != 0) { printf("Error: zlib compress2 failed (%d).\n", zr); free(z); free(tmp); return SZ_NSCS; }
+            free(tmp); *newByteData = z; *outSize = (size_t)zl;
+        } else { printf("Error: Unrecognized lossless compressor in sz_lossless_compress()\n"); free(tmp); return SZ_NSCS; }
     } else { printf("Error: Wrong setting of confparams_cpr->szMode in the compression.\n"); free(tmp); return SZ_MERR; }
     return status;
 }
@@ -392,26 +419,40 @@ static void *decompress_fp(int dataType, unsigned char *cmpBytes, size_t cmpSize
     size_t dataLength = computeDataLength(r5, r4, r3, r2, r1);
     unsigned char *sz = cmpBytes; size_t szlen = cmpSize; int owned = 0;
 
-    if (cmpSize != 8 + 4 + meta_len && cmpSize != 8 + 8 + meta_len) { /* szd_float.c:62-95 */
+    /* the two sizes a constant-data stream can have (SZ_SIZE_TYPE 4 or 8) are never sniffed: szd_float.c:62, szd_double.c:32 */
+    const size_t cbase = (dataType == SZ_FLOAT ? 8 : 12) + meta_len;
+    if (cmpSize != cbase + 4 && cmpSize != cbase + 8) { /* szd_float.c:62-95 */
         int lossless = -1;
-        if (zstd_load()) { if (g_zstd.fcs(cmpBytes, cmpSize) != (unsigned long long)-2) lossless = ZSTD_COMPRESSOR; } /* ZSTD_CONTENTSIZE_ERROR */
-        else if (cmpSize >= 4 && cmpBytes[0] == 0x28 && cmpBytes[1] == 0xB5 && cmpBytes[2] == 0x2F && cmpBytes[3] == 0xFD) {
+        if (cmpSize >= 4 && zstd_load() && g_zstd.fcs(cmpBytes, cmpSize) != (unsigned long long)-2) lossless = ZSTD_COMPRESSOR; /* != ZSTD_CONTENTSIZE_ERROR */
+        else if (cmpSize >= 4 && cmpBytes[0] == 0x28 && cmpBytes[1] == 0xB5 && cmpBytes[2] == 0x2F && cmpBytes[3] == 0xFD && !zstd_load()) {
             printf("Error: zstd-wrapped stream but libzstd.so.1 is not available.\n"); return NULL;
         }
-        if (lossless == -1 && cmpSize >= 2 && is_zlib_format(cmpBytes[0], cmpBytes[1])) {
-            printf("Error: gzip-wrapped streams are outside the scope of the MI355X build (use zstd or SZ_BEST_SPEED).\n"); return NULL;
-        }
+        if (lossless == -1 && cmpSize >= 2 && is_zlib_format(cmpBytes[0], cmpBytes[1])) lossless = GZIP_COMPRESSOR;
         confparams_dec->losslessCompressor = lossless;
         confparams_dec->szMode = lossless != -1 ? SZ_BEST_COMPRESSION : SZ_BEST_SPEED;
-        if (lossless == ZSTD_COMPRESSOR) { /* sz_lossless_decompress, utility.c:197-214 */
-            size_t target = dataLength * esz; if (target < 1000000) target = 1000000;
+        if (lossless != -1) { /* sz_lossless_decompress, utility.c:197-214 */
+            size_t target = dataLength * esz; if (target < 1000000) target = 1000000;   /* MIN_ZLIB_DEC_ALLOMEM_BYTES */
             target += 4 + meta_len + exe_params->SZ_SIZE_TYPE;
-            unsigned long long fcs = g_zstd.fcs(cmpBytes, cmpSize);
-            if (fcs != (unsigned long long)-1 && fcs > target) target = (size_t)fcs;
-            unsigned char *buf = (unsigned char *)malloc(target);
-            size_t got = g_zstd.decompress(buf, target, cmpBytes, cmpSize);
-            if (g_zstd.iserr(got)) { printf("Error: ZSTD_decompress failed.\n"); free(buf); return NULL; }
-            sz = buf; szlen = got; owned = 1;
+            if (lossless == ZSTD_COMPRESSOR) {
+                unsigned long long fcs = g_zstd.fcs(cmpBytes, cmpSize);
+                if (fcs != (unsigned long long)-1 && fcs > target) {
+                    if (fcs > (unsigned long long)dataLength * esz * 2 + (64u << 20)) { printf("Error: implausible zstd frame size.\n"); return NULL; }
+                    target = (size_t)fcs;
+                }
+                unsigned char *buf = (unsigned char *)malloc(target);
+                if (!buf) { printf("Error: out of memory.\n"); return NULL; }
+                size_t got = g_zstd.decompress(buf, target, cmpBytes, cmpSize);
+                if (g_zstd.iserr(got)) { printf("Error: ZSTD_decompress failed.\n"); free(buf); return NULL; }
+                sz = buf; szlen = got; owned = 1;
+            } else {
+                if (!zlib_load()) { printf("Error: gzip-wrapped stream but libz.so.1 is not available.\n"); return NULL; }
+                unsigned char *buf = (unsigned char *)malloc(target);
+                if (!buf) { printf("Error: out of memory.\n"); return NULL; }
+                unsigned long got = (unsigned long)target;
+                int zr = g_zlib.uncompress(buf, &got, cmpBytes, (unsigned long)cmpSize);
+                if (zr != 0) { printf("Error: zlib uncompress failed (%d).\n", zr); free(buf); return NULL; }
+                sz = buf; szlen = (size_t)got; owned = 1;
+            }
         }
     }
     if (dataLength <= MIN_NUM_OF_ELEMENTS) { /* raw copy written by SZ_skip_compress */
@@ -437,6 +478,7 @@ static void *decompress_fp(int dataType, unsigned char *cmpBytes, size_t cmpSize
     const size_t st = exe_params->SZ_SIZE_TYPE;
     const unsigned char *body = sz + 4 + meta_len + st;
     void *out = malloc(dataLength * esz);
+    if (!out) { printf("Error: out of memory.\n"); if (owned) free(sz); return NULL; }
     int ok = 1;
     if (same & 0x10) { /* lossless raw copy, big-endian values (szd_float.c:106-118) */
         if (szlen < 4 + meta_len + st + dataLength * esz) ok = 0;
@@ -444,7 +486,8 @@ static void *decompress_fp(int dataType, unsigned char *cmpBytes, size_t cmpSize
             if (dataType == SZ_FLOAT) ((float *)out)[i] = szhost_get_f32be(body + 4 * i); else ((double *)out)[i] = szhost_get_f64be(body + 8 * i);
         }
     } else if (same & 0x01) { /* constant */
-        for (size_t i = 0; i < dataLength; i++) {
+        if (szlen < 4 + meta_len + st + esz) ok = 0;
+        else for (size_t i = 0; i < dataLength; i++) {
             if (dataType == SZ_FLOAT) ((float *)out)[i] = szhost_get_f32be(body); else ((double *)out)[i] = szhost_get_f64be(body);
         }
     } else {
@@ -477,6 +520,9 @@ static void *decompress_fp(int dataType, unsigned char *cmpBytes, size_t cmpSize
     }
     if (owned) free(sz);
     if (!ok) { free(out); return NULL; }
+    /* updateQuantizationInfo(tdps->intervals) (TightDataPointStorageF.c / szd_float.c): a later compression with fixed
+     * quantization_intervals finds what this stream used, as after the reference's decompression */
+    if (!(same & (0x10 | 0x01)) && g_last_stats.intervals) { exe_params->intvCapacity = (int)g_last_stats.intervals; exe_params->intvRadius = exe_params->intvCapacity / 2; }
     return out;
 }
 
