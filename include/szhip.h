@@ -115,6 +115,21 @@ int szhip_compress_sz14(szhip_ctx *ctx, int dtype, const void *data, int data_on
 int szhip_decompress_sz14(szhip_ctx *ctx, int dtype, const unsigned char *stream, int stream_on_device, size_t stream_len,
                           size_t body_off, size_t r0, size_t r1, size_t r2, void *out, int out_on_device, szhip_stats *stats);
 
+/*
+ * FAST mode (opt-in; SZ_HIP_MODE=fast through the SZ_* API): pre-quantised integer Lorenzo inside tiles of 16 x 16 x 64 points,
+ * no reconstruction feedback -- the block-local precedent is the reference's own OpenMP variant (SZ_compress_float_3D_MDQ_RA_block,
+ * sz/src/sz_float.c:4704-5012; sz/src/sz_omp.c:63-358) -- so that predict + quantise runs at HBM speed.  The absolute bound `eb`
+ * always holds; codes and ratio differ slightly from the exact path, and the stream is this library's own container (magic "SZHF"),
+ * which a stock SZ reader rejects at its version check.  1-D / 2-D arrays: leading extents 1.  `intervals`: code alphabet
+ * (even, 4 .. 65536; 0 = 1024).  Output conventions as for szhip_compress.
+ */
+int szhip_compress_fast(szhip_ctx *ctx, int dtype, const void *data, int data_on_device, size_t r0, size_t r1, size_t r2, double eb,
+                        unsigned intervals, int out_on_device, unsigned char **out, size_t *out_size, szhip_stats *stats);
+int szhip_decompress_fast(szhip_ctx *ctx, int dtype, const unsigned char *stream, int stream_on_device, size_t stream_len,
+                          size_t r0, size_t r1, size_t r2, void *out, int out_on_device, szhip_stats *stats);
+/* 1 if the bytes start a fast-mode container */
+int szhip_is_fast_stream(const unsigned char *stream, size_t stream_len);
+
 /* test/diagnostic hook: copy the first `bytes` bytes of an internal device workspace of the LAST call to host.
  * which: 0 coef (T SoA[4][nblocks]) 1 blk_lor (u8) 2 codes in natural order (u16) 3 codes in block order (u16)
  *        4 code histogram (u32) 5 per-column zero counts (u32) 6 per-column unpredictable offsets (u64)

@@ -303,6 +303,20 @@ static int compress_fp(int dataType, int withRegression, unsigned char **newByte
                "withLinearRegression=NO; this call (dim=%d, withRegression=%d, randomAccess=%d) is not covered yet.\n", dim, withRegression, confparams_cpr->randomAccess);
         return SZ_NSCS;
     }
+    /* opt-in FAST mode (SZ_HIP_MODE=fast): the feedback-free quantiser and this library's own container (include/szhip.h).  Off by
+     * default; the bound still holds, the stream is NOT a reference stream (a stock reader rejects it at its version check). */
+    {
+        const char *mode = getenv("SZ_HIP_MODE");
+        if (mode && strcmp(mode, "fast") == 0) {
+            unsigned char *ftmp = NULL; size_t fsize = 0;
+            const size_t f0 = dim >= 3 ? (dim == 4 ? r4 * r3 : r3) : 1, f1 = dim >= 2 ? r2 : 1;
+            int frc = szhip_compress_fast(ctx, dataType == SZ_FLOAT ? SZHIP_F32 : SZHIP_F64, d_in, 1, f0, f1, r1, realPrecision,
+                                          exe_params->optQuantMode == 1 ? 0u : (unsigned)exe_params->intvCapacity, 0, &ftmp, &fsize, &g_last_stats);
+            if (frc != SZHIP_OK) { printf("Error: szhip_compress_fast failed (%d): %s\n", frc, szhip_last_error(ctx)); return SZ_NSCS; }
+            *newByteData = ftmp; *outSize = fsize;
+            return status;
+        }
+    }
     unsigned char flags = sz14 ? 0x40 : (0x80 | 0x40);        /* TightDataPointStorageF.c:600-611 / sz_float.c:7396 */
     if (confparams_cpr->protectValueRange) flags |= 0x04;
     szhost_write_meta(&m, flags, meta);
@@ -454,6 +468,15 @@ static void *decompress_fp(int dataType, unsigned char *cmpBytes, size_t cmpSize
                 sz = buf; szlen = (size_t)got; owned = 1;
             }
         }
+    }
+    if (szhip_is_fast_stream(cmpBytes, cmpSize)) {            /* this library's own FAST-mode container */
+        szhip_ctx *fctx = get_ctx();
+        const int fdim = computeDimension(r5, r4, r3, r2, r1);
+        const size_t f0 = fdim >= 3 ? (fdim == 4 ? r4 * r3 : r3) : 1, f1 = fdim >= 2 ? r2 : 1;
+        void *fo = malloc(dataLength * esz + 1);
+        int frc = fctx && fo ? szhip_decompress_fast(fctx, dataType == SZ_FLOAT ? SZHIP_F32 : SZHIP_F64, cmpBytes, 0, cmpSize, f0, f1, r1, fo, 0, &g_last_stats) : SZHIP_ERR_NODEVICE;
+        if (frc != SZHIP_OK) { printf("Error: szhip_decompress_fast failed (%d): %s\n", frc, fctx ? szhip_last_error(fctx) : "no device"); free(fo); return NULL; }
+        return fo;
     }
     if (dataLength <= MIN_NUM_OF_ELEMENTS) { /* raw copy written by SZ_skip_compress */
         void *o = malloc(dataLength * esz != 0 ? dataLength * esz : 1);

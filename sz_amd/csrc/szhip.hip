@@ -1334,9 +1334,274 @@ int decompress14_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream
     return SZHIP_OK;
 }
 
+// =====================================================================================================================
+// FAST mode (szh_fast.h).  Container (little endian, 8-byte aligned sections):
+//   "SZHF" | u8 version 1 | u8 dtype | u16 0 | u64 r0 r1 r2 | f64 eb | u32 intervals | u32 0,0,0 | u64 nA | u64 nB
+//   | u32 tree_bytes | u32 n_nodes | u64 payload_bytes | tree (padded to 8) | i32 listA[nA] (padded) | i32 listBd[nB] (padded)
+//   | T listB[nB] (padded) | Huffman payload
+// =====================================================================================================================
+#define SZF_HDR_FIXED 88
+static inline size_t pad8(size_t x) { return (x + 7) & ~(size_t)7; }
+
+template <class T>
+int compress_fast_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r0, size_t r1, size_t r2, double eb_in, unsigned intervals,
+                       int out_on_device, unsigned char **out, size_t *out_size, szhip_stats *stats)
+{
+    const szf_geom g = szf_make_geom(r0, r1, r2);
+    const int64_t n = g.n;
+    const T eb = (T)eb_in;
+    const double t_begin = now_ms();
+    double host_ms = 0;
+    hipStream_t st = ctx->stream;
+    szhip_stats S; memset(&S, 0, sizeof(S));
+    S.n_elements = (uint64_t)n; S.intervals = intervals;
+    const T *d_in = (const T *)data;
+    if (!data_on_device) {
+        TRY(ensure(ctx, ctx->in, (size_t)n * sizeof(T)));
+        HIPCHK(hipMemcpyAsync(ctx->in.p, data, (size_t)n * sizeof(T), hipMemcpyHostToDevice, st));
+        d_in = (const T *)ctx->in.p;
+    }
+    TRY(ensure(ctx, ctx->small, SM_COUNT * 8));
+    u64 *sm = (u64 *)ctx->small.p;
+    HIPCHK(hipMemsetAsync(sm, 0, SM_COUNT * 8, st));
+    TRY(ensure(ctx, ctx->codes_nat, (size_t)n * 2 + 64));
+    uint16_t *d_codes = (uint16_t *)ctx->codes_nat.p;
+    const unsigned ntiles = (unsigned)((int64_t)g.n0 * g.n1 * g.n2);
+    HIPCHK(hipEventRecord(ctx->ev[0], st));
+    HIPCHK(hipEventRecord(ctx->ev[1], st));
+    HIPCHK(hipEventRecord(ctx->ev[2], st));
+    hipLaunchKernelGGL((k_fast_quant<T>), dim3(ntiles), dim3(256), 0, st, g, d_in, d_codes, eb, (int)intervals / 2);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev[3], st));
+    S.quant_kernel_launches = 1;
+    // histogram -> host code book; side-list counts meanwhile
+    TRY(ensure(ctx, ctx->hist, (size_t)(65536 + 8192) * 4 + 64));
+    unsigned *d_hist = (unsigned *)ctx->hist.p;
+    TRY(ensure_pinned(ctx, (size_t)intervals * 4 + 64));
+    unsigned *h_hist = (unsigned *)ctx->pinned;
+    HIPCHK(hipMemsetAsync(d_hist, 0, (size_t)intervals * 4, st));
+    {
+        int rshift = 0; int use_lds = intervals <= 16384;
+        if (use_lds) { while ((intervals << (rshift + 1)) <= 16384u && rshift < 6) ++rshift; }
+        const size_t lds = use_lds ? ((size_t)intervals << rshift) * 4 : 16;
+        int grid = (int)std::min<int64_t>((n / 8 + 255) / 256 + 1, 2048);
+        hipLaunchKernelGGL(k_hist_u16, dim3(grid), dim3(256), lds, st, (const uint16_t *)d_codes, n, intervals, rshift, use_lds, d_hist);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipMemcpyAsync(h_hist, d_hist, (size_t)intervals * 4, hipMemcpyDeviceToHost, st));
+    const int64_t nchunks = (n + 2047) / 2048;
+    TRY(ensure(ctx, ctx->col_zeros64, (size_t)nchunks * 8)); TRY(ensure(ctx, ctx->col_off, (size_t)nchunks * 8));
+    TRY(ensure(ctx, ctx->reg_flags, (size_t)nchunks * 8)); TRY(ensure(ctx, ctx->reg_rank, (size_t)nchunks * 8));
+    TRY(ensure(ctx, ctx->chunk_bits, (size_t)nchunks * 8)); TRY(ensure(ctx, ctx->chunk_off, (size_t)nchunks * 8));
+    hipLaunchKernelGGL(k_fast_count, dim3((unsigned)nchunks), dim3(256), 0, st, (const uint16_t *)d_codes, n, (u64 *)ctx->col_zeros64.p, (u64 *)ctx->reg_flags.p);
+    TRY(scan_u64(ctx, (const u64 *)ctx->col_zeros64.p, nchunks, (u64 *)ctx->col_off.p, sm + SM_TOTAL_UNPRED));
+    TRY(scan_u64(ctx, (const u64 *)ctx->reg_flags.p, nchunks, (u64 *)ctx->reg_rank.p, sm + SM_SCRATCH));
+    HIPCHK(hipStreamSynchronize(st));
+    double h0 = now_ms();
+    szhost_huff *hf = szhost_huff_build(2 * (int)intervals, h_hist, nullptr, intervals);
+    if (!hf) FAIL(SZHIP_ERR_INTERNAL, "Huffman build failed");
+    const u64 nA = h_hist[0], nB = h_hist[1];
+    S.n_unpred = nA + nB;
+    const size_t tree_bytes = szhost_huff_tree_size(hf);
+    const u64 total_bits = hf->total_bits;
+    const size_t pay_bytes = (size_t)((total_bits + 7) / 8);
+    const size_t offA = SZF_HDR_FIXED + pad8(tree_bytes), offBd = offA + pad8((size_t)nA * 4), offB = offBd + pad8((size_t)nB * 4);
+    const size_t pay_off = offB + pad8((size_t)nB * sizeof(T));
+    const size_t total_len = pay_off + pay_bytes;
+    std::vector<unsigned char> hdr(offA, 0);
+    {
+        unsigned char *q = hdr.data();
+        memcpy(q, "SZHF", 4); q[4] = 1; q[5] = (unsigned char)(sizeof(T) == 8); q += 8;
+        const uint64_t dims[3] = {r0, r1, r2}; memcpy(q, dims, 24); q += 24;
+        const double ebd = (double)eb; memcpy(q, &ebd, 8); q += 8;
+        const uint32_t w[4] = {intervals, 0, 0, 0}; memcpy(q, w, 16); q += 16;
+        memcpy(q, &nA, 8); q += 8; memcpy(q, &nB, 8); q += 8;
+        const uint32_t tw[2] = {(uint32_t)tree_bytes, (uint32_t)hf->n_nodes}; memcpy(q, tw, 8); q += 8;
+        const uint64_t pb = pay_bytes; memcpy(q, &pb, 8); q += 8;
+        szhost_huff_tree_write(hf, q);
+    }
+    std::vector<u64> tab_code(intervals); std::vector<uint8_t> tab_len(intervals);
+    for (unsigned s2 = 0; s2 < intervals; ++s2) { tab_code[s2] = hf->code[s2]; tab_len[s2] = hf->len[s2]; }
+    szhost_huff_free(hf);
+    host_ms += now_ms() - h0;
+    TRY(ensure(ctx, ctx->code_tab, (size_t)intervals * 8));
+    TRY(ensure(ctx, ctx->len_tab, (size_t)intervals));
+    HIPCHK(hipMemcpyAsync(ctx->code_tab.p, tab_code.data(), (size_t)intervals * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->len_tab.p, tab_len.data(), (size_t)intervals, hipMemcpyHostToDevice, st));
+    TRY(ensure(ctx, ctx->stream_buf, total_len + 64));
+    unsigned char *d_stream = (unsigned char *)ctx->stream_buf.p;
+    HIPCHK(hipMemsetAsync(d_stream, 0, total_len + 64, st));
+    HIPCHK(hipMemcpyAsync(d_stream, hdr.data(), hdr.size(), hipMemcpyHostToDevice, st));
+    if (nA + nB > 0) {
+        hipLaunchKernelGGL((k_fast_lists<T>), dim3((unsigned)nchunks), dim3(256), 0, st, g, (const uint16_t *)d_codes, (const u64 *)ctx->col_off.p,
+                           (const u64 *)ctx->reg_rank.p, d_in, eb, (int32_t *)(d_stream + offA), (int32_t *)(d_stream + offBd), (T *)(d_stream + offB));
+        HIPCHK(hipGetLastError());
+    }
+    if (total_bits > 0) {
+        hipLaunchKernelGGL(k_chunk_bits, dim3((unsigned)nchunks), dim3(256), 0, st, (const uint16_t *)d_codes, n, (const uint8_t *)ctx->len_tab.p,
+                           intervals, (u64 *)ctx->chunk_bits.p);
+        TRY(scan_u64(ctx, (const u64 *)ctx->chunk_bits.p, nchunks, (u64 *)ctx->chunk_off.p, sm + SM_TOTAL_BITS));
+        hipLaunchKernelGGL(k_encode, dim3((unsigned)nchunks), dim3(256), 0, st, (const uint16_t *)d_codes, n, (const u64 *)ctx->code_tab.p,
+                           (const uint8_t *)ctx->len_tab.p, intervals, (const u64 *)ctx->chunk_off.p, (u64)pay_off * 8, (unsigned *)d_stream);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(ctx->ev[4], st));
+    u64 h_small[SM_COUNT];
+    HIPCHK(hipMemcpyAsync(h_small, sm, SM_COUNT * 8, hipMemcpyDeviceToHost, st));
+    if (out_on_device == 2) {
+        if (!*out || *out_size < total_len) FAIL(SZHIP_ERR_ARG, "caller's device buffer too small (%zu < %zu)", *out_size, total_len);
+        HIPCHK(hipMemcpyAsync(*out, d_stream, total_len, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+    } else if (out_on_device) {
+        HIPCHK(hipStreamSynchronize(st));
+        *out = d_stream;
+    } else {
+        unsigned char *h = (unsigned char *)malloc(total_len ? total_len : 1);
+        if (!h) FAIL(SZHIP_ERR_INTERNAL, "out of host memory");
+        HIPCHK(hipMemcpyAsync(h, d_stream, total_len, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        *out = h;
+    }
+    *out_size = total_len;
+    if ((total_bits > 0 && h_small[SM_TOTAL_BITS] != total_bits) || h_small[SM_TOTAL_UNPRED] != nA || h_small[SM_SCRATCH] != nB)
+        FAIL(SZHIP_ERR_INTERNAL, "fast mode: entropy stage mismatch");
+    float ms = 0;
+    hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); S.ms_quant = ms;
+    hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]); S.ms_entropy = ms;
+    S.ms_host = host_ms; S.ms_total = now_ms() - t_begin; S.out_bytes = total_len;
+    if (stats) *stats = S;
+    return SZHIP_OK;
+}
+
+template <class T>
+int decompress_fast_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_on_device, size_t stream_len, size_t r0, size_t r1, size_t r2,
+                         void *out, int out_on_device, szhip_stats *stats)
+{
+    const szf_geom g = szf_make_geom(r0, r1, r2);
+    const int64_t n = g.n;
+    const double t_begin = now_ms();
+    hipStream_t st = ctx->stream;
+    szhip_stats S; memset(&S, 0, sizeof(S));
+    S.n_elements = (uint64_t)n;
+    TRY(ensure(ctx, ctx->stream_buf, stream_len + 64));
+    unsigned char *d_stream = (unsigned char *)ctx->stream_buf.p;
+    if (stream_on_device) { if (stream_in != d_stream) HIPCHK(hipMemcpyAsync(d_stream, stream_in, stream_len, hipMemcpyDeviceToDevice, st)); }
+    else HIPCHK(hipMemcpyAsync(d_stream, stream_in, stream_len, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(d_stream + stream_len, 0, 64, st));
+    HIPCHK(hipEventRecord(ctx->ev[0], st));
+    if (stream_len < SZF_HDR_FIXED) FAIL(SZHIP_ERR_STREAM, "truncated stream");
+    std::vector<unsigned char> hbuf;
+    const unsigned char *hs = stream_in;
+    auto fetch = [&](size_t want) -> int {
+        if (!stream_on_device) return SZHIP_OK;
+        hbuf.resize(want);
+        HIPCHK(hipMemcpyAsync(hbuf.data(), d_stream, want, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        hs = hbuf.data();
+        return SZHIP_OK;
+    };
+    TRY(fetch(SZF_HDR_FIXED));
+    if (memcmp(hs, "SZHF", 4) != 0 || hs[4] != 1 || hs[5] != (unsigned char)(sizeof(T) == 8)) FAIL(SZHIP_ERR_STREAM, "not a fast-mode stream of this type");
+    uint64_t dims[3]; memcpy(dims, hs + 8, 24);
+    if (dims[0] != r0 || dims[1] != r1 || dims[2] != r2) FAIL(SZHIP_ERR_STREAM, "dimensions differ from the stream's");
+    double ebd; memcpy(&ebd, hs + 32, 8);
+    uint32_t w[4]; memcpy(w, hs + 40, 16);
+    u64 nA, nB; memcpy(&nA, hs + 56, 8); memcpy(&nB, hs + 64, 8);
+    uint32_t tw[2]; memcpy(tw, hs + 72, 8);
+    uint64_t pay_bytes; memcpy(&pay_bytes, hs + 80, 8);
+    const unsigned intervals = w[0];
+    if (!(ebd > 0) || intervals < 4 || intervals > 65536 || (intervals & 1)) FAIL(SZHIP_ERR_STREAM, "bad fast-mode header");
+    const size_t tree_bytes = tw[0]; const int node_count = (int)tw[1];
+    if (nA > (u64)n || nB > (u64)n || tree_bytes > stream_len || pay_bytes > stream_len) FAIL(SZHIP_ERR_STREAM, "truncated stream");
+    const size_t offA = SZF_HDR_FIXED + pad8(tree_bytes), offBd = offA + pad8((size_t)nA * 4), offB = offBd + pad8((size_t)nB * 4);
+    const size_t pay_off = offB + pad8((size_t)nB * sizeof(T));
+    if (pay_off + pay_bytes > stream_len || node_count <= 0 || szhost_huff_serial_size(node_count) > tree_bytes) FAIL(SZHIP_ERR_STREAM, "truncated stream");
+    TRY(fetch(SZF_HDR_FIXED + tree_bytes));
+    szhost_huff *hf = szhost_huff_from_bytes(2 * (int)intervals, hs + SZF_HDR_FIXED, node_count);
+    if (!hf) FAIL(SZHIP_ERR_STREAM, "bad Huffman tree");
+    std::vector<uint32_t> dtab((size_t)hf->n_nodes * 2);
+    szhost_huff_decode_table(hf, dtab.data());
+    const int single_symbol = hf->t[0] ? (int)hf->C[0] : -1;
+    const int n_nodes = hf->n_nodes;
+    szhost_huff_free(hf);
+    S.intervals = intervals; S.n_unpred = nA + nB;
+    TRY(ensure(ctx, ctx->small, SM_COUNT * 8));
+    u64 *sm = (u64 *)ctx->small.p;
+    HIPCHK(hipMemsetAsync(sm, 0, SM_COUNT * 8, st));
+    TRY(ensure(ctx, ctx->codes_nat, (size_t)n * 2 + 64));
+    uint16_t *d_codes = (uint16_t *)ctx->codes_nat.p;
+    u64 total_sym = 0;
+    TRY(huff_decode_device(ctx, sm, d_stream + pay_off, (u64)pay_bytes * 8, dtab, n_nodes, single_symbol, n, d_codes, &total_sym));
+    const int64_t nchunks = (n + 2047) / 2048;
+    TRY(ensure(ctx, ctx->col_zeros64, (size_t)nchunks * 8)); TRY(ensure(ctx, ctx->col_off, (size_t)nchunks * 8));
+    TRY(ensure(ctx, ctx->reg_flags, (size_t)nchunks * 8)); TRY(ensure(ctx, ctx->reg_rank, (size_t)nchunks * 8));
+    hipLaunchKernelGGL(k_fast_count, dim3((unsigned)nchunks), dim3(256), 0, st, (const uint16_t *)d_codes, n, (u64 *)ctx->col_zeros64.p, (u64 *)ctx->reg_flags.p);
+    TRY(scan_u64(ctx, (const u64 *)ctx->col_zeros64.p, nchunks, (u64 *)ctx->col_off.p, sm + SM_TOTAL_UNPRED));
+    TRY(scan_u64(ctx, (const u64 *)ctx->reg_flags.p, nchunks, (u64 *)ctx->reg_rank.p, sm + SM_SCRATCH));
+    u64 h_small[SM_COUNT];
+    HIPCHK(hipMemcpyAsync(h_small, sm, SM_COUNT * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if ((int64_t)total_sym < n) FAIL(SZHIP_ERR_STREAM, "Huffman payload holds %llu symbols, need %lld", (unsigned long long)total_sym, (long long)n);
+    if (h_small[SM_TOTAL_UNPRED] != nA || h_small[SM_SCRATCH] != nB) FAIL(SZHIP_ERR_STREAM, "side lists do not match the codes");
+    T *d_out = (T *)out;
+    if (!out_on_device) { TRY(ensure(ctx, ctx->out, (size_t)n * sizeof(T))); d_out = (T *)ctx->out.p; }
+    HIPCHK(hipEventRecord(ctx->ev[1], st));
+    // deltas + scan along dim2, scan along dim1, scan along dim0 + scaling (three passes over a uint32 workspace), raw values last
+    TRY(ensure(ctx, ctx->faceI, (size_t)n * 4 + 64));
+    uint32_t *d_acc = (uint32_t *)ctx->faceI.p;
+    HIPCHK(hipEventRecord(ctx->ev[2], st));
+    {
+        const int64_t rows = (int64_t)g.r0 * g.r1;
+        if (nA + nB > 0)
+            hipLaunchKernelGGL(k_fast_scatter, dim3((unsigned)nchunks), dim3(256), 0, st, (const uint16_t *)d_codes, n, (const u64 *)ctx->col_off.p,
+                               (const u64 *)ctx->reg_rank.p, (const int32_t *)(d_stream + offA), (const int32_t *)(d_stream + offBd), d_acc);
+        hipLaunchKernelGGL(k_fast_expand_scan2, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, g, (const uint16_t *)d_codes, (int)intervals / 2, d_acc);
+        hipLaunchKernelGGL(k_fast_scan1, dim3((unsigned)(((int64_t)g.r0 * g.r2 + 255) / 256)), dim3(256), 0, st, g, d_acc);
+        hipLaunchKernelGGL((k_fast_scan0_out<T>), dim3((unsigned)(((int64_t)g.r1 * g.r2 + 255) / 256)), dim3(256), 0, st, g, (const uint32_t *)d_acc, d_out, (T)ebd);
+    }
+    HIPCHK(hipEventRecord(ctx->ev[3], st));
+    if (nB > 0) hipLaunchKernelGGL((k_fast_raw<T>), dim3((unsigned)nchunks), dim3(256), 0, st, (const uint16_t *)d_codes, n, (const u64 *)ctx->reg_rank.p,
+                                   (const T *)(d_stream + offB), d_out);
+    HIPCHK(hipGetLastError());
+    if (!out_on_device) HIPCHK(hipMemcpyAsync(out, d_out, (size_t)n * sizeof(T), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    float ms = 0;
+    hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); S.ms_entropy = ms;
+    hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); S.ms_quant = ms;
+    S.ms_total = now_ms() - t_begin; S.out_bytes = (uint64_t)n * sizeof(T);
+    if (stats) *stats = S;
+    return SZHIP_OK;
+}
+
 } // namespace
 
 extern "C" {
+
+int szhip_is_fast_stream(const unsigned char *stream, size_t stream_len) { return stream && stream_len >= SZF_HDR_FIXED && memcmp(stream, "SZHF", 4) == 0; }
+
+int szhip_compress_fast(szhip_ctx *ctx, int dtype, const void *data, int data_on_device, size_t r0, size_t r1, size_t r2, double eb,
+                        unsigned intervals, int out_on_device, unsigned char **out, size_t *out_size, szhip_stats *stats)
+{
+    if (!ctx || !data || !out || !out_size || !(eb > 0)) return SZHIP_ERR_ARG;
+    if (intervals == 0) intervals = 1024;
+    if (r0 < 1 || r1 < 1 || r2 < 1 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff || intervals < 4 || intervals > 65536 || (intervals & 1)) return SZHIP_ERR_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
+    const int rc = dtype == SZHIP_F32 ? compress_fast_impl<float>(ctx, data, data_on_device, r0, r1, r2, eb, intervals, out_on_device, out, out_size, stats)
+                                      : compress_fast_impl<double>(ctx, data, data_on_device, r0, r1, r2, eb, intervals, out_on_device, out, out_size, stats);
+    if (rc != SZHIP_OK) hipStreamSynchronize(ctx->stream);
+    return rc;
+}
+
+int szhip_decompress_fast(szhip_ctx *ctx, int dtype, const unsigned char *stream, int stream_on_device, size_t stream_len,
+                          size_t r0, size_t r1, size_t r2, void *out, int out_on_device, szhip_stats *stats)
+{
+    if (!ctx || !stream || !out || r0 < 1 || r1 < 1 || r2 < 1) return SZHIP_ERR_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
+    const int rc = dtype == SZHIP_F32 ? decompress_fast_impl<float>(ctx, stream, stream_on_device, stream_len, r0, r1, r2, out, out_on_device, stats)
+                                      : decompress_fast_impl<double>(ctx, stream, stream_on_device, stream_len, r0, r1, r2, out, out_on_device, stats);
+    if (rc != SZHIP_OK) hipStreamSynchronize(ctx->stream);
+    return rc;
+}
 
 int szhip_create(szhip_ctx **out, int device)
 {

@@ -1259,3 +1259,6 @@ __global__ __launch_bounds__(256) void k_exact_build(const uint8_t *__restrict__
     }
     list[i] = IM::to(u) + median;
 }
+
+// ------------------------------------------------------------------ the opt-in fast mode (feedback-free; own container)
+#include "szh_fast.h"

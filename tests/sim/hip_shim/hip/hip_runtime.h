@@ -25,6 +25,7 @@
 
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
 struct uint4 { unsigned x, y, z, w; };
+struct uint2 { unsigned x, y; };
 
 namespace hipsim {
 struct TIdx { unsigned x, y, z; };
