@@ -25,7 +25,7 @@
 #define SZF_TI 16
 #define SZF_TJ 16
 #define SZF_TK 64
-#define SZF_KP (SZF_TK + 2)                 /* LDS row pitch in words: 1 halo column + 64 + 1 pad */
+#define SZF_KP (SZF_TK + 4)                 /* LDS row pitch in words: the halo column at word 3, the 64 tile columns 16-byte aligned from word 4 */
 #define SZF_TILE_WORDS ((SZF_TI + 1) * (SZF_TJ + 1) * SZF_KP)
 #define SZF_RAW INT32_MIN                   /* LDS marker of a raw point (a legal q is < 2^30 in magnitude) */
 
@@ -53,74 +53,119 @@ template <class T> __device__ __forceinline__ bool szf_prequant(T x, T recip, T 
     return true;
 }
 
-// 7-point integer Lorenzo prediction from the LDS image of the tile + its one-point halo (tile point (i,j,k) sits at (i+1, j+1, k+1));
-// raw neighbours and points outside the array count as 0
-__device__ __forceinline__ uint32_t szf_nb(const int32_t *qs, int i, int j, int k)
+// ---- predict + quantise: one workgroup per tile.  Phase 1 pre-quantises the tile and its one-point halo (rows i0-1, j0-1, column
+// k0-1) into LDS, 16-byte loads along dim2.  Phase 2: a thread owns 8 consecutive columns of one (j) row and walks 8 planes of dim0,
+// keeping the previous plane's two rows in registers, so every LDS word is read about twice instead of eight times (the first
+// version, one point at a time, was bound by LDS reads).  8 codes = one 16-byte store.  Raw neighbours and points outside the array
+// count as 0.  Tiles are handed out so that consecutive tiles (neighbours along dim2 / dim1, who share halo rows) run on the same
+// XCD and find each other's rows in its L2.  Algorithmic bytes: N * sizeof(T) read + 2 N written.
+__device__ __forceinline__ void szf_row9(const int32_t *row, int kg, int32_t *v)
 {
-    const int32_t v = qs[((i + 1) * (SZF_TJ + 1) + (j + 1)) * SZF_KP + (k + 1)];
-    return v == SZF_RAW ? 0u : (uint32_t)v;
+    v[0] = row[3 + kg * 8];
+    const int4 a = *reinterpret_cast<const int4 *>(row + 4 + kg * 8), b = *reinterpret_cast<const int4 *>(row + 8 + kg * 8);
+    v[1] = a.x; v[2] = a.y; v[3] = a.z; v[4] = a.w; v[5] = b.x; v[6] = b.y; v[7] = b.z; v[8] = b.w;
 }
-__device__ __forceinline__ uint32_t szf_pred(const int32_t *qs, int i, int j, int k)
-{
-    return szf_nb(qs, i, j, k - 1) + szf_nb(qs, i, j - 1, k) + szf_nb(qs, i - 1, j, k) - szf_nb(qs, i, j - 1, k - 1) - szf_nb(qs, i - 1, j, k - 1)
-         - szf_nb(qs, i - 1, j - 1, k) + szf_nb(qs, i - 1, j - 1, k - 1);
-}
-
-// ---- predict + quantise: one workgroup per tile.  Reads the tile once (16-byte vectors along dim2), writes the u16 codes.
-// Algorithmic bytes: N * sizeof(T) read + 2 N written.
 template <class T>
 __global__ __launch_bounds__(256) void k_fast_quant(szf_geom g, const T *__restrict__ data, uint16_t *__restrict__ codes, T eb, int radius)
 {
-    __shared__ int32_t qs[SZF_TILE_WORDS];
-    const int tk = blockIdx.x % g.n2, tj = (blockIdx.x / g.n2) % g.n1, ti = blockIdx.x / (g.n2 * g.n1);
+    __shared__ __attribute__((aligned(16))) int32_t qs[SZF_TILE_WORDS];
+    const int64_t ntiles = (int64_t)g.n0 * g.n1 * g.n2, per = (ntiles + 7) / 8;
+    const int64_t tile = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (tile >= ntiles) return;
+    const int tk = (int)(tile % g.n2), tj = (int)((tile / g.n2) % g.n1), ti = (int)(tile / ((int64_t)g.n2 * g.n1));
     const int i0 = ti * SZF_TI, j0 = tj * SZF_TJ, k0 = tk * SZF_TK;
     const T twoeb = eb + eb, recip = (T)1 / twoeb;
     constexpr int V = 16 / (int)sizeof(T);                          // values per 16-byte vector
     constexpr int VPR = SZF_TK / V;                                 // vectors per tile row
     const bool vec = (g.r2 % V) == 0 && k0 + SZF_TK <= g.r2;        // rows 16-byte aligned and whole
-    // rows i0-1 .. i0+15, j0-1 .. j0+15 (the -1 rows are the halo), columns k0 .. k0+63 as vectors
-    for (int v = threadIdx.x; v < (SZF_TI + 1) * (SZF_TJ + 1) * VPR; v += 256) {
-        const int row = v / VPR, c = (v - row * VPR) * V;
-        const int ih = row / (SZF_TJ + 1), jh = row - ih * (SZF_TJ + 1);        // halo-shifted row indices
-        const int gi = i0 + ih - 1, gj = j0 + jh - 1;
-        int32_t *dst = qs + row * SZF_KP + 1 + c;
-        if (gi >= 0 && gj >= 0 && gi < g.r0 && gj < g.r1) {
-            const T *src = data + ((int64_t)gi * g.r1 + gj) * g.r2 + k0 + c;
-            T x[V];
-            if (vec) { const uint4 w = *reinterpret_cast<const uint4 *>(src); __builtin_memcpy(x, &w, 16); }
-            else { for (int e = 0; e < V; ++e) x[e] = k0 + c + e < g.r2 ? src[e] : (T)0; }
-            for (int e = 0; e < V; ++e) { int32_t q; dst[e] = szf_prequant<T>(x[e], recip, twoeb, eb, &q) ? q : SZF_RAW; }
-        } else { for (int e = 0; e < V; ++e) dst[e] = 0; }
-    }
-    // the halo column k0-1 of every row
-    for (int row = threadIdx.x; row < (SZF_TI + 1) * (SZF_TJ + 1); row += 256) {
+    constexpr int NVEC = (SZF_TI + 1) * (SZF_TJ + 1) * VPR;
+    // the halo column k0-1 of every row: loads issued first, used last
+    T hx[2] = {(T)0, (T)0}; bool hok[2];
+    for (int b = 0; b < 2; ++b) {
+        const int row = threadIdx.x + 256 * b;
         const int ih = row / (SZF_TJ + 1), jh = row - ih * (SZF_TJ + 1);
         const int gi = i0 + ih - 1, gj = j0 + jh - 1;
-        int32_t q = 0;
-        if (k0 > 0 && gi >= 0 && gj >= 0 && gi < g.r0 && gj < g.r1) {
-            int32_t t;
-            q = szf_prequant<T>(data[((int64_t)gi * g.r1 + gj) * g.r2 + k0 - 1], recip, twoeb, eb, &t) ? t : SZF_RAW;
+        hok[b] = row < (SZF_TI + 1) * (SZF_TJ + 1) && k0 > 0 && gi >= 0 && gj >= 0 && gi < g.r0 && gj < g.r1;
+        if (hok[b]) hx[b] = data[((int64_t)gi * g.r1 + gj) * g.r2 + k0 - 1];
+    }
+    if (vec) {
+        // whole, aligned rows: eight 16-byte loads in flight per thread before the first is used (one load per round trip made this
+        // kernel latency-bound)
+        constexpr int B = 8;
+        for (int v0 = threadIdx.x; v0 < NVEC; v0 += 256 * B) {
+            uint4 w[B]; bool ok[B];
+            for (int b = 0; b < B; ++b) {
+                const int v = v0 + 256 * b;
+                const int row = v / VPR, c = (v - row * VPR) * V;
+                const int ih = row / (SZF_TJ + 1), jh = row - ih * (SZF_TJ + 1);        // halo-shifted row indices
+                const int gi = i0 + ih - 1, gj = j0 + jh - 1;
+                ok[b] = v < NVEC && gi >= 0 && gj >= 0 && gi < g.r0 && gj < g.r1;
+                w[b] = make_uint4(0, 0, 0, 0);
+                if (ok[b]) w[b] = *reinterpret_cast<const uint4 *>(data + ((int64_t)gi * g.r1 + gj) * g.r2 + k0 + c);
+            }
+            for (int b = 0; b < B; ++b) {
+                const int v = v0 + 256 * b;
+                if (v >= NVEC) break;
+                const int row = v / VPR, c = (v - row * VPR) * V;
+                T x[V]; int32_t q[V];
+                __builtin_memcpy(x, &w[b], 16);
+                for (int e = 0; e < V; ++e) { int32_t t; q[e] = !ok[b] ? 0 : (szf_prequant<T>(x[e], recip, twoeb, eb, &t) ? t : SZF_RAW); }
+                int32_t *dst = qs + row * SZF_KP + 4 + c;
+                if (V == 4) { int4 o; __builtin_memcpy(&o, q, 16); *reinterpret_cast<int4 *>(dst) = o; }
+                else { for (int e = 0; e < V; ++e) dst[e] = q[e]; }
+            }
         }
-        qs[row * SZF_KP] = q;
+    } else {
+        for (int v = threadIdx.x; v < NVEC; v += 256) {
+            const int row = v / VPR, c = (v - row * VPR) * V;
+            const int ih = row / (SZF_TJ + 1), jh = row - ih * (SZF_TJ + 1);
+            const int gi = i0 + ih - 1, gj = j0 + jh - 1;
+            int32_t *dst = qs + row * SZF_KP + 4 + c;
+            for (int e = 0; e < V; ++e) {
+                int32_t q = 0, t;
+                if (gi >= 0 && gj >= 0 && gi < g.r0 && gj < g.r1 && k0 + c + e < g.r2)
+                    q = szf_prequant<T>(data[((int64_t)gi * g.r1 + gj) * g.r2 + k0 + c + e], recip, twoeb, eb, &t) ? t : SZF_RAW;
+                dst[e] = q;
+            }
+        }
+    }
+    for (int b = 0; b < 2; ++b) {
+        const int row = threadIdx.x + 256 * b;
+        if (row < (SZF_TI + 1) * (SZF_TJ + 1)) {
+            int32_t q = 0, t;
+            if (hok[b]) q = szf_prequant<T>(hx[b], recip, twoeb, eb, &t) ? t : SZF_RAW;
+            qs[row * SZF_KP + 3] = q;
+        }
     }
     __syncthreads();
-    for (int v = threadIdx.x; v < SZF_TI * SZF_TJ * (SZF_TK / 4); v += 256) {     // four codes (8 bytes) per store
-        const int row = v / (SZF_TK / 4), c = (v - row * (SZF_TK / 4)) * 4;
-        const int i = row / SZF_TJ, j = row - i * SZF_TJ;
-        if (i0 + i >= g.r0 || j0 + j >= g.r1 || k0 + c >= g.r2) continue;
-        uint16_t out[4];
-        for (int e = 0; e < 4; ++e) {
-            const int32_t q = qs[((i + 1) * (SZF_TJ + 1) + (j + 1)) * SZF_KP + 1 + c + e];
-            unsigned code = 1;                                                      // raw
-            if (q != SZF_RAW) {
-                const int32_t delta = (int32_t)((uint32_t)q - szf_pred(qs, i, j, c + e));
-                code = (delta >= 2 - radius && delta < radius) ? (unsigned)(delta + radius) : 0u;
-            }
+    const int kg = threadIdx.x & 7, j = (threadIdx.x >> 3) & 15, ih0 = (threadIdx.x >> 7) * 8;
+    const int gj = j0 + j, gk = k0 + kg * 8;
+    // rows of the LDS image: point (i, j) of the tile is row (i + 1) * 17 + (j + 1); `a` = row j-1, `b` = row j, masked for the neighbour role
+    int32_t pa[9], pb[9], ca[9], cb[9];
+    szf_row9(qs + ((ih0 + 0) * (SZF_TJ + 1) + j) * SZF_KP, kg, pa);
+    szf_row9(qs + ((ih0 + 0) * (SZF_TJ + 1) + j + 1) * SZF_KP, kg, pb);
+    for (int e = 0; e < 9; ++e) { pa[e] = pa[e] == SZF_RAW ? 0 : pa[e]; pb[e] = pb[e] == SZF_RAW ? 0 : pb[e]; }
+    const bool inside_jk = gj < g.r1 && gk < g.r2;
+    for (int s = 0; s < 8; ++s) {
+        const int i = ih0 + s;
+        szf_row9(qs + ((i + 1) * (SZF_TJ + 1) + j) * SZF_KP, kg, ca);
+        szf_row9(qs + ((i + 1) * (SZF_TJ + 1) + j + 1) * SZF_KP, kg, cb);
+        unsigned rawmask = 0;
+        for (int e = 0; e < 9; ++e) { ca[e] = ca[e] == SZF_RAW ? 0 : ca[e]; if (cb[e] == SZF_RAW) { cb[e] = 0; rawmask |= 1u << e; } }
+        uint16_t out[8];
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t pred = (uint32_t)cb[e] + (uint32_t)ca[e + 1] + (uint32_t)pb[e + 1] - (uint32_t)ca[e] - (uint32_t)pb[e] - (uint32_t)pa[e + 1] + (uint32_t)pa[e];
+            const int32_t delta = (int32_t)((uint32_t)cb[e + 1] - pred);
+            unsigned code = (delta >= 2 - radius && delta < radius) ? (unsigned)(delta + radius) : 0u;
+            if (rawmask >> (e + 1) & 1) code = 1;
             out[e] = (uint16_t)code;
         }
-        uint16_t *dst = codes + ((int64_t)(i0 + i) * g.r1 + (j0 + j)) * g.r2 + k0 + c;
-        if ((g.r2 % 4) == 0 && k0 + c + 4 <= g.r2) { uint2 w; __builtin_memcpy(&w, out, 8); *reinterpret_cast<uint2 *>(dst) = w; }
-        else { for (int e = 0; e < 4 && k0 + c + e < g.r2; ++e) dst[e] = out[e]; }
+        if (inside_jk && i0 + i < g.r0) {
+            uint16_t *dst = codes + ((int64_t)(i0 + i) * g.r1 + gj) * g.r2 + gk;
+            if ((g.r2 & 7) == 0) { uint4 w; __builtin_memcpy(&w, out, 16); *reinterpret_cast<uint4 *>(dst) = w; }
+            else { for (int e = 0; e < 8 && gk + e < g.r2; ++e) dst[e] = out[e]; }
+        }
+        for (int e = 0; e < 9; ++e) { pa[e] = ca[e]; pb[e] = cb[e]; }
     }
 }
 
@@ -143,13 +188,25 @@ template <class T> __device__ int32_t szf_delta_at(const szf_geom &g, const T *d
     return (int32_t)(q - pred);
 }
 
+// bit masks of the codes equal to 0 (m0) and to 1 (m1) among the eight codes at e0 (a multiple of 8): one 16-byte load
+__device__ __forceinline__ void szf_masks(const uint16_t *__restrict__ codes, int64_t e0, int64_t n, unsigned *m0, unsigned *m1)
+{
+    uint16_t c[8];
+    if (e0 + 8 <= n) { const uint4 w = *reinterpret_cast<const uint4 *>(codes + e0); __builtin_memcpy(c, &w, 16); }
+    else { for (int q = 0; q < 8; ++q) c[q] = e0 + q < n ? codes[e0 + q] : (uint16_t)2; }
+    unsigned a = 0, b = 0;
+    for (int q = 0; q < 8; ++q) { a |= (unsigned)(c[q] == 0) << q; b |= (unsigned)(c[q] == 1) << q; }
+    *m0 = a; *m1 = b;
+}
+
 // ---- side lists, in stream (= natural) order.  counts: codes equal to 0 and to 1 per chunk of 2048 (one launch, both at once)
 __global__ __launch_bounds__(256) void k_fast_count(const uint16_t *__restrict__ codes, int64_t n, u64 *cnt0, u64 *cnt1)
 {
     __shared__ u64 sh[8];
     const int64_t e0 = (int64_t)blockIdx.x * 2048 + threadIdx.x * 8;
-    u64 z = 0;
-    for (int q = 0; q < 8; ++q) if (e0 + q < n) { const unsigned c = codes[e0 + q]; z += c == 0 ? 1ull : (c == 1 ? (1ull << 32) : 0ull); }
+    unsigned m0, m1;
+    szf_masks(codes, e0, n, &m0, &m1);
+    const u64 z = (u64)__builtin_popcount(m0) | ((u64)__builtin_popcount(m1) << 32);
     u64 tot;
     block_excl_scan_256(z, sh, &tot);
     if (threadIdx.x == 0) { cnt0[blockIdx.x] = tot & 0xffffffffull; cnt1[blockIdx.x] = tot >> 32; }
@@ -161,8 +218,8 @@ __global__ __launch_bounds__(256) void k_fast_lists(szf_geom g, const uint16_t *
 {
     __shared__ u64 sh[8];
     const int64_t e0 = (int64_t)blockIdx.x * 2048 + threadIdx.x * 8;
-    unsigned m0 = 0, m1 = 0;
-    for (int q = 0; q < 8; ++q) if (e0 + q < g.n) { const unsigned c = codes[e0 + q]; if (c == 0) m0 |= 1u << q; else if (c == 1) m1 |= 1u << q; }
+    unsigned m0, m1;
+    szf_masks(codes, e0, g.n, &m0, &m1);
     u64 tot;
     const u64 ex = block_excl_scan_256((u64)__builtin_popcount(m0) | ((u64)__builtin_popcount(m1) << 32), sh, &tot);
     u64 r0 = off0[blockIdx.x] + (ex & 0xffffffffull), r1 = off1[blockIdx.x] + (ex >> 32);
@@ -177,8 +234,8 @@ __global__ __launch_bounds__(256) void k_fast_scatter(const uint16_t *__restrict
 {
     __shared__ u64 sh[8];
     const int64_t e0 = (int64_t)blockIdx.x * 2048 + threadIdx.x * 8;
-    unsigned m0 = 0, m1 = 0;
-    for (int q = 0; q < 8; ++q) if (e0 + q < n) { const unsigned c = codes[e0 + q]; m0 |= (unsigned)(c == 0) << q; m1 |= (unsigned)(c == 1) << q; }
+    unsigned m0, m1;
+    szf_masks(codes, e0, n, &m0, &m1);
     u64 tot;
     u64 r0 = off0[blockIdx.x] + block_excl_scan_256((u64)__builtin_popcount(m0), sh, &tot);
     u64 r1 = off1[blockIdx.x] + block_excl_scan_256((u64)__builtin_popcount(m1), sh, &tot);
@@ -263,8 +320,8 @@ __global__ __launch_bounds__(256) void k_fast_raw(const uint16_t *__restrict__ c
 {
     __shared__ u64 sh[8];
     const int64_t e0 = (int64_t)blockIdx.x * 2048 + threadIdx.x * 8;
-    unsigned m1 = 0;
-    for (int q = 0; q < 8; ++q) if (e0 + q < n && codes[e0 + q] == 1) m1 |= 1u << q;
+    unsigned m0, m1;
+    szf_masks(codes, e0, n, &m0, &m1);
     u64 tot;
     u64 r1 = off1[blockIdx.x] + block_excl_scan_256((u64)__builtin_popcount(m1), sh, &tot);
     for (int q = 0; q < 8; ++q) if (m1 >> q & 1) out[e0 + q] = listB[r1++];

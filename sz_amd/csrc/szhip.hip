@@ -1370,7 +1370,7 @@ int compress_fast_impl(szhip_ctx *ctx, const void *data, int data_on_device, siz
     HIPCHK(hipEventRecord(ctx->ev[0], st));
     HIPCHK(hipEventRecord(ctx->ev[1], st));
     HIPCHK(hipEventRecord(ctx->ev[2], st));
-    hipLaunchKernelGGL((k_fast_quant<T>), dim3(ntiles), dim3(256), 0, st, g, d_in, d_codes, eb, (int)intervals / 2);
+    hipLaunchKernelGGL((k_fast_quant<T>), dim3((ntiles + 7) / 8 * 8), dim3(256), 0, st, g, d_in, d_codes, eb, (int)intervals / 2);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[3], st));
     S.quant_kernel_launches = 1;

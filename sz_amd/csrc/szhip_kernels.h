@@ -582,14 +582,21 @@ __global__ __launch_bounds__(256) void k_hist_u16(const uint16_t *__restrict__ c
     const unsigned rep = threadIdx.x & (R - 1);
     const int64_t nvec = n / 8;
     const uint4 *v4 = reinterpret_cast<const uint4 *>(codes);
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
-        const uint4 v = v4[i];
-        const unsigned wv[4] = {v.x, v.y, v.z, v.w};
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += 4 * stride) {     // four loads in flight per thread
+        uint4 v[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const unsigned c0 = wv[q] & 0xffffu, c1 = wv[q] >> 16;
-            if (use_lds) { atomicAdd(&sh[(c0 << rshift) + rep], 1u); atomicAdd(&sh[(c1 << rshift) + rep], 1u); }
-            else { atomicAdd(&hist[c0], 1u); atomicAdd(&hist[c1], 1u); }
+        for (int u = 0; u < 4; ++u) if (i + u * stride < nvec) v[u] = v4[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i + u * stride >= nvec) break;
+            const unsigned wv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned c0 = wv[q] & 0xffffu, c1 = wv[q] >> 16;
+                if (use_lds) { atomicAdd(&sh[(c0 << rshift) + rep], 1u); atomicAdd(&sh[(c1 << rshift) + rep], 1u); }
+                else { atomicAdd(&hist[c0], 1u); atomicAdd(&hist[c1], 1u); }
+            }
         }
     }
     if (blockIdx.x == 0) {
@@ -928,7 +935,6 @@ __global__ __launch_bounds__(256) void k_encode(const uint16_t *__restrict__ cod
     __shared__ u64 lcode[SZH_ENC_TAB];
     __shared__ uint8_t llen[SZH_ENC_TAB];
     const bool tab_lds = nsym <= SZH_ENC_TAB;
-    for (int i = threadIdx.x; i < SZH_ENC_CHUNK * 2 + 2; i += 256) buf[i] = 0;
     if (tab_lds) { for (unsigned i = threadIdx.x; i < nsym; i += 256) { lcode[i] = code[i]; llen[i] = len[i]; } __syncthreads(); }
     const u64 gbit = bit0 + chunk_off[blockIdx.x];
     const unsigned lead = (unsigned)(gbit & 31);
@@ -940,11 +946,22 @@ __global__ __launch_bounds__(256) void k_encode(const uint16_t *__restrict__ cod
         s += l[q];
     }
     u64 tot;
-    const u64 ex = block_excl_scan_256((u64)s, sh, &tot); // also orders the LDS clear above
+    const u64 ex = block_excl_scan_256((u64)s, sh, &tot);
+    // only the words this chunk fills are cleared (a chunk of the S-field fills ~160 of the 4098)
+    for (unsigned w = threadIdx.x; w < (unsigned)((lead + tot + 31) >> 5) + 1; w += 256) buf[w] = 0;
+    __syncthreads();
+    // a thread's eight codes are consecutive in the stream: they are concatenated in a register and reach LDS as one or two ORs
+    // (one atomic per code meant a dozen lanes hitting the same word)
     unsigned pos = lead + (unsigned)ex;
+    u64 acc = 0; int accn = 0;
     for (int q = 0; q < 8; ++q) {
-        if (l[q]) { lds_put_bits(buf, pos, tab_lds ? lcode[c[q]] : code[c[q]], (int)l[q]); pos += l[q]; }
+        if (!l[q]) continue;
+        const u64 cw = tab_lds ? lcode[c[q]] : code[c[q]];
+        if (accn + (int)l[q] > 64) { lds_put_bits(buf, pos, acc, accn); pos += accn; acc = 0; accn = 0; }
+        acc = l[q] == 64 ? cw : ((acc << l[q]) | (cw & ((1ull << l[q]) - 1)));
+        accn += (int)l[q];
     }
+    if (accn) lds_put_bits(buf, pos, acc, accn);
     __syncthreads();
     const unsigned nwords = (unsigned)((lead + tot + 31) >> 5);
     const u64 w0 = gbit >> 5;

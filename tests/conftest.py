@@ -40,3 +40,17 @@ def anchors():
 def c1_data():
     import numpy as np
     return np.fromfile(os.path.join(ROOT, "tests", "golden", "testfloat_8_8_128.dat"), dtype=np.float32).reshape(128, 8, 8)
+
+
+_torch_gpu_ready = []
+
+
+def pytest_runtest_setup(item):
+    """The first GPU test brings up torch's HIP context before the product library has touched the device: some GPU tests hand torch
+    tensors to the C ABI, and torch initialising AFTER hundreds of library calls in the same process was seen to fail once
+    ("No HIP GPUs are available") when the files ran in another order."""
+    if item.get_closest_marker("gpu") is not None and not _torch_gpu_ready:
+        _torch_gpu_ready.append(True)
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()

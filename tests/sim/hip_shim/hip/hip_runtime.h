@@ -25,6 +25,8 @@
 
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
 struct uint4 { unsigned x, y, z, w; };
+struct int4 { int x, y, z, w; };
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { uint4 r = {x, y, z, w}; return r; }
 struct uint2 { unsigned x, y; };
 
 namespace hipsim {

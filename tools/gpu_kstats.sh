@@ -9,6 +9,6 @@ rm -rf $R/gpurun_out/prof
 python3 - $R/gpurun_out/kstats.csv <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-for r in rows[:22]:
+for r in rows[:40]:
     print("%-70s calls %4s avg %9.1f us  total %8.2f ms  %5s%%" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
 PY
