@@ -12,7 +12,7 @@ rm -rf $R/gpurun_out/prof
 head -40 $R/gpurun_out/prof_kernel_stats.csv | cut -c1-130
 for c in FETCH_SIZE WRITE_SIZE; do
   n=pmc_$(echo $c | tr A-Z a-z | cut -d_ -f1)
-  rocprofv3 --pmc $c --kernel-trace -d $R/gpurun_out/$n -o $n --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/$n.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace -d $R/gpurun_out/$n -o $n --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-m-field > $R/gpurun_out/$n.log 2>&1
   f=$(find $R/gpurun_out/$n -name "*counter_collection.csv" | head -1)
   python3 - "$f" "$R/gpurun_out/$n.csv" <<'PY'
 import csv, sys, collections
