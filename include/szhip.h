@@ -116,6 +116,43 @@ int szhip_decompress_sz14(szhip_ctx *ctx, int dtype, const unsigned char *stream
                           size_t body_off, size_t r0, size_t r1, size_t r2, void *out, int out_on_device, szhip_stats *stats);
 
 /*
+ * Point-wise relative bounds (PW_REL and its AND/OR combinations) in their log-domain form: the `_pwr_pre_log` functions of
+ * sz/src/sz_float_pwr.c:1791-1975 / sz_double_pwr.c:1781-1965 (dispatch sz_float.c:2888-2996) and their inverses
+ * szd_float_pwr.c:1353-1422.  Three steps, the sign bytes being compressed on the host (zstd) in between:
+ *   szhip_pwr_prepare       log2|x| into a device array owned by the context (*d_log), sign bytes to `signs_host` (n bytes) when any
+ *                           value is negative (*positive == 0), and what the quantiser needs: the absolute bound in the log domain
+ *                           (*real_precision), the log array's range and median, and the header's minLogValue.
+ *                           vmin / vmax: the array's range (szhip_minmax).
+ *   szhip_compress_sz14_pwr szhip_compress_sz14 on that array, writing the extra PW_REL container fields (TightDataPointStorageF.c:
+ *                           408-419, 454-467): radExpo, segment_size, the compressed sign bytes and minLogValue.
+ *   szhip_sz14_pwr_locate   (host only) where a PW_REL stream keeps its sign bytes, and its minLogValue;
+ *   szhip_decompress_sz14_pwr  the SZ 1.4 inverse on a stream with those fields, then x = exp2(l) (0 below minLogValue), signs applied
+ *                           (`signs_host`: n bytes or NULL).
+ * The default form of the reference (accelerate_pw_rel_compression = 1: the table-driven "MSST19" quantiser, sz_float.c:1824-2725) is
+ * not implemented: this build writes the log-domain form whatever that switch says (a valid stream for every stock reader, flagged as
+ * such in its header) and refuses to decode MSST19 streams.
+ */
+typedef struct szhip_pwr {
+    uint64_t segment_size;             /* confparams_cpr->segment_size, recorded in the header */
+    const unsigned char *signs_blob;   /* compressed sign bytes (host memory) or NULL */
+    uint32_t signs_blob_size;
+    double min_log_value;
+    unsigned char rad_expo;            /* 0 on this path */
+} szhip_pwr;
+int szhip_pwr_prepare(szhip_ctx *ctx, int dtype, const void *data, int data_on_device, size_t n, double vmin, double vmax, double pwr_ratio,
+                      void **d_log, unsigned char *signs_host, int *positive, double *real_precision, double *value_range, double *median,
+                      double *min_log_value);
+int szhip_compress_sz14_pwr(szhip_ctx *ctx, int dtype, const void *data, int data_on_device,
+                            size_t r0, size_t r1, size_t r2, double eb, double value_range, double median,
+                            const szhip_params *params, const unsigned char *meta, size_t meta_len, const szhip_pwr *pwr,
+                            int out_on_device, unsigned char **out, size_t *out_size, szhip_stats *stats);
+int szhip_sz14_pwr_locate(int dtype, const unsigned char *stream, size_t stream_len, size_t body_off, size_t *blob_off, size_t *blob_size,
+                          double *min_log_value);
+int szhip_decompress_sz14_pwr(szhip_ctx *ctx, int dtype, const unsigned char *stream, int stream_on_device, size_t stream_len,
+                              size_t body_off, size_t r0, size_t r1, size_t r2, const unsigned char *signs_host, void *out,
+                              int out_on_device, szhip_stats *stats);
+
+/*
  * FAST mode (opt-in; SZ_HIP_MODE=fast through the SZ_* API): pre-quantised integer Lorenzo inside tiles of 16 x 16 x 64 points,
  * no reconstruction feedback -- the block-local precedent is the reference's own OpenMP variant (SZ_compress_float_3D_MDQ_RA_block,
  * sz/src/sz_float.c:4704-5012; sz/src/sz_omp.c:63-358) -- so that predict + quantise runs at HBM speed.  The absolute bound `eb`

@@ -42,6 +42,9 @@ typedef struct szo_params {
     double   conf_rel_bound_ratio;   /* confparams_cpr->relBoundRatio: what the parameter bytes record in the REL-type modes.
                                         SZ_compress_args never copies its relBoundRatio ARGUMENT into the config struct
                                         (sz_float.c:2815-2820), so the header carries the configured value. */
+    double   pw_rel_bound_ratio;     /* pwRelBoundRatio argument of the PW_REL-type modes (10..14); the log-domain form
+                                        (accelerate_pw_rel_compression = 0) is the one restated, szo_pwr_impl.h */
+    int      segment_size;           /* confparams_cpr->segment_size, recorded in a PW_REL header (default 36, conf.c:128) */
 } szo_params;
 
 void szo_default_params(szo_params *p);

@@ -23,6 +23,11 @@
 #define SZO_ABS_OR_REL 3
 #define SZO_PSNR 4
 #define SZO_NORM 5
+#define SZO_PW_REL 10
+#define SZO_ABS_AND_PW_REL 11
+#define SZO_ABS_OR_PW_REL 12
+#define SZO_REL_AND_PW_REL 13
+#define SZO_REL_OR_PW_REL 14
 #define SZO_FLOAT 0
 #define SZO_DOUBLE 1
 #define SZO_META_F32 28
@@ -42,6 +47,8 @@ void szo_default_params(szo_params *p)
     p->psnr = 90;
     p->norm_err = 0.05;
     p->conf_rel_bound_ratio = 1E-4; /* conf.c:123 */
+    p->pw_rel_bound_ratio = 1E-3;   /* conf.c:127 */
+    p->segment_size = 36;           /* conf.c:128 */
 }
 
 void szo_free_stages(szo_stages *s)
@@ -85,12 +92,52 @@ static void szo_put_be_f64(unsigned char *b, double v) { uint64_t u; memcpy(&u, 
 static float szo_get_be_f32(const unsigned char *b) { uint32_t u = szo_get_u32be(b); float v; memcpy(&v, &u, 4); return v; }
 static double szo_get_be_f64(const unsigned char *b) { uint64_t u = szo_get_u64be(b); double v; memcpy(&v, &u, 8); return v; }
 
+/* the extra container fields of a point-wise-relative stream */
+typedef struct szo_pwr_extra { size_t segment_size; const unsigned char *blob; size_t blob_size; double min_log_value; } szo_pwr_extra;
+
+/* zstd for the sign bytes of the PW_REL path, loaded at run time (the image has libzstd.so.1 but no headers) */
+#include <dlfcn.h>
+static struct { int tried; void *h; size_t (*compress)(void *, size_t, const void *, size_t, int); size_t (*decompress)(void *, size_t, const void *, size_t);
+                unsigned (*iserr)(size_t); } szo_zstd;
+static int szo_zstd_load(void)
+{
+    if (!szo_zstd.tried) {
+        szo_zstd.tried = 1;
+        szo_zstd.h = dlopen("libzstd.so.1", RTLD_NOW);
+        if (szo_zstd.h) {
+            szo_zstd.compress = (size_t (*)(void *, size_t, const void *, size_t, int))dlsym(szo_zstd.h, "ZSTD_compress");
+            szo_zstd.decompress = (size_t (*)(void *, size_t, const void *, size_t))dlsym(szo_zstd.h, "ZSTD_decompress");
+            szo_zstd.iserr = (unsigned (*)(size_t))dlsym(szo_zstd.h, "ZSTD_isError");
+        }
+    }
+    return szo_zstd.h && szo_zstd.compress && szo_zstd.decompress && szo_zstd.iserr;
+}
+static unsigned char *szo_zstd_compress(const unsigned char *src, size_t n, int level, size_t *out_size)
+{
+    if (!szo_zstd_load()) { fprintf(stderr, "szo: libzstd.so.1 not available\n"); return NULL; }
+    size_t est = n < 100 ? 200 : (size_t)(n * 1.2);          /* utility.c:181-184 */
+    unsigned char *o = (unsigned char *)malloc(est);
+    size_t z = szo_zstd.compress(o, est, src, n, level);
+    if (szo_zstd.iserr(z)) { free(o); return NULL; }
+    *out_size = z;
+    return o;
+}
+static unsigned char *szo_zstd_decompress(const unsigned char *src, size_t len, size_t n)
+{
+    if (!szo_zstd_load()) { fprintf(stderr, "szo: libzstd.so.1 not available\n"); return NULL; }
+    unsigned char *o = (unsigned char *)malloc(n ? n : 1);
+    size_t z = szo_zstd.decompress(o, n, src, len);
+    if (szo_zstd.iserr(z) || z != n) { free(o); return NULL; }
+    return o;
+}
+
 #define T float
 #define SUF f32
 #define FABS_T fabsf
 #define IS_F64 0
 #include "szo_sz21_impl.h"
 #include "szo_sz14_impl.h"
+#include "szo_pwr_impl.h"
 #undef T
 #undef SUF
 #undef FABS_T
@@ -102,6 +149,7 @@ static double szo_get_be_f64(const unsigned char *b) { uint64_t u = szo_get_u64b
 #define IS_F64 1
 #include "szo_sz21_impl.h"
 #include "szo_sz14_impl.h"
+#include "szo_pwr_impl.h"
 #undef T
 #undef SUF
 #undef FABS_T
@@ -110,7 +158,7 @@ static double szo_get_be_f64(const unsigned char *b) { uint64_t u = szo_get_u64b
 /* convertSZParamsToBytes (ByteToolkit.c:874-972).  abs_bound is confparams_cpr->absErrBound at the time
  * of the call, i.e. the DERIVED bound (sz_float.c:2867). */
 static void szo_params_to_bytes(const szo_params *p, int data_type, int err_mode, double abs_bound, double rel_ratio,
-                                double fmin_, double fmax_, unsigned char *r)
+                                double fmin_, double fmax_, unsigned char *r, double pwr_ratio)
 {
     unsigned char buf = (p->quantization_intervals == 0) ? 1 : 0; /* optQuantMode */
     buf = (unsigned char)((buf << 1) | (p->data_endian & 1));
@@ -131,6 +179,9 @@ static void szo_params_to_bytes(const szo_params *p, int data_type, int err_mode
     case SZO_ABS_AND_REL: case SZO_ABS_OR_REL:
         szo_put_be_f32(r + 6, (float)abs_bound); szo_put_be_f32(r + 10, (float)rel_ratio); break;
     case SZO_PSNR: szo_put_be_f32(r + 6, (float)p->psnr); memset(r + 9, 0, 4); break;
+    case SZO_ABS_AND_PW_REL: case SZO_ABS_OR_PW_REL: szo_put_be_f32(r + 6, (float)abs_bound); szo_put_be_f32(r + 10, (float)pwr_ratio); break;
+    case SZO_REL_AND_PW_REL: case SZO_REL_OR_PW_REL: szo_put_be_f32(r + 6, (float)rel_ratio); szo_put_be_f32(r + 10, (float)pwr_ratio); break;
+    case SZO_PW_REL: memset(r + 6, 0, 4); szo_put_be_f32(r + 10, (float)pwr_ratio); break;
     default: break;
     }
     r[14] = (unsigned char)p->sol_id;
@@ -208,12 +259,16 @@ unsigned char *szo_compress_args(const szo_params *p, int data_type, const void 
     } else if (err_mode == SZO_ABS_OR_REL) {
         if (data_type == SZO_FLOAT) { float a = (float)abs_err, b = (float)(rel_ratio * range); eb = a > b ? a : b; }
         else { double b = rel_ratio * range; eb = abs_err > b ? abs_err : b; }
-    } else { fprintf(stderr, "szo: unsupported error bound mode %d\n", err_mode); return NULL; }
+    } else if (err_mode == SZO_ABS_AND_PW_REL || err_mode == SZO_ABS_OR_PW_REL) eb = abs_err;        /* getRealPrecision_float, dataCompression.c:314-325 */
+    else if (err_mode == SZO_REL_AND_PW_REL || err_mode == SZO_REL_OR_PW_REL) eb = rel_ratio * range;
+    else if (err_mode == SZO_PW_REL) eb = 0;
+    else { fprintf(stderr, "szo: unsupported error bound mode %d\n", err_mode); return NULL; }
 
     unsigned char meta[4 + SZO_META_F64];
     memset(meta, 0, sizeof(meta));
     meta[0] = 2; meta[1] = 1; meta[2] = 12;
-    szo_params_to_bytes(p, data_type, eff_mode, eb, p->conf_rel_bound_ratio, vmin, vmax, meta + 4);
+    /* confparams_cpr->pw_relBoundRatio takes the argument only in mode PW_REL (sz_float.c:2817-2820); the combinations record the configured one */
+    szo_params_to_bytes(p, data_type, eff_mode, eb, p->conf_rel_bound_ratio, vmin, vmax, meta + 4, p->pw_rel_bound_ratio);
 
     if (range <= eb) {
         /* constant data: SZ_compress_args_float_withinRange (sz_float.c:2728) -> header + first value */
@@ -232,7 +287,17 @@ unsigned char *szo_compress_args(const szo_params *p, int data_type, const void 
     int dim = (r2 == 0) ? 1 : (r3 == 0) ? 2 : (r4 == 0) ? 3 : (r5 == 0) ? 4 : 5;
     unsigned char *out = NULL; size_t osz = 0;
     int strict_raw_rule = 0;
-    if ((dim == 3 || dim == 4) && p->with_regression) {
+    if (err_mode >= SZO_PW_REL && dim <= 4) {
+        /* every mode >= PW_REL goes to the _pwr_pre_log functions with pwRelBoundRatio alone (sz_float.c:2888-2996); 4-D as (r4*r3, r2, r1) */
+        size_t s0 = dim >= 3 ? (dim == 4 ? r4 * r3 : r3) : 1, s1 = dim >= 2 ? r2 : 1;
+        meta[3] = 0x40 | 0x20 | (p->protect_value_range ? 0x04 : 0);
+        if (data_type == SZO_FLOAT)
+            out = szo_pwr_compress_f32(p, meta, 4 + meta_len, (const float *)data, s0, s1, r1, p->pw_rel_bound_ratio, (float)vmin, (float)vmax, (size_t)p->segment_size, &osz);
+        else
+            out = szo_pwr_compress_f64(p, meta, 4 + meta_len, (const double *)data, s0, s1, r1, p->pw_rel_bound_ratio, vmin, vmax, (size_t)p->segment_size, &osz);
+        if (!out) return NULL;
+        strict_raw_rule = 1;                                     /* '>' at sz_float_pwr.c:1971 */
+    } else if ((dim == 3 || dim == 4) && p->with_regression) {
         size_t s = (dim == 4) ? r4 * r3 : r3; /* 4-D is treated as 3-D (r4*r3, r2, r1), sz_float.c:3010 */
         meta[3] = 0x80 | 0x40 | (p->protect_value_range ? 0x04 : 0);
         if (data_type == SZO_FLOAT)
@@ -246,9 +311,9 @@ unsigned char *szo_compress_args(const szo_params *p, int data_type, const void 
         if (dim == 1) r2 = 1;
         meta[3] = 0x40 | (p->protect_value_range ? 0x04 : 0);
         if (data_type == SZO_FLOAT)
-            out = szo_sz14_compress_3d_f32(p, meta, 4 + meta_len, (const float *)data, s0, r2, r1, (float)eb, (float)range, (float)median, &osz, stages);
+            out = szo_sz14_compress_3d_f32(p, meta, 4 + meta_len, (const float *)data, s0, r2, r1, (float)eb, (float)range, (float)median, &osz, stages, NULL);
         else
-            out = szo_sz14_compress_3d_f64(p, meta, 4 + meta_len, (const double *)data, s0, r2, r1, eb, range, median, &osz, stages);
+            out = szo_sz14_compress_3d_f64(p, meta, 4 + meta_len, (const double *)data, s0, r2, r1, eb, range, median, &osz, stages, NULL);
         /* strict '>' inside the 2-D/3-D callee (sz_float.c:1469, :940) and nothing after it; the 1-D call site adds a '>=' of
          * its own (sz_float.c:2908, sz_double.c:2624) */
         strict_raw_rule = dim != 1;
@@ -306,6 +371,11 @@ void *szo_decompress(int data_type, const unsigned char *bytes, size_t byte_len,
             if (data_type == SZO_FLOAT) ((float *)out)[i] = szo_get_be_f32(body);
             else ((double *)out)[i] = szo_get_be_f64(body);
         }
+    } else if ((same & 0x20) && !(same & 0x08) && dim <= 4) {    /* point-wise relative, log-domain form (szd_float.c:2716, :2757, :2798, :2838) */
+        size_t s0 = dim >= 3 ? (dim == 4 ? r4 * r3 : r3) : 1, s1 = dim >= 2 ? r2 : 1;
+        int rc = data_type == SZO_FLOAT ? szo_pwr_decompress_f32((float *)out, s0, s1, r1, body, byte_len - (size_t)(body - bytes))
+                                        : szo_pwr_decompress_f64((double *)out, s0, s1, r1, body, byte_len - (size_t)(body - bytes));
+        if (rc) { free(out); return NULL; }
     } else if ((same & 0x80) && (dim == 3 || dim == 4)) {
         size_t s = (dim == 4) ? r4 * r3 : r3;
         if (data_type == SZO_FLOAT) szo_sz21_decompress_3d_f32((float *)out, s, r2, r1, body);
@@ -313,8 +383,8 @@ void *szo_decompress(int data_type, const unsigned char *bytes, size_t byte_len,
     } else if (dim == 1 || (!(same & 0x80) && (dim == 3 || dim == 2))) {
         size_t s0 = dim == 3 ? r3 : 1;
         if (dim == 1) r2 = 1;
-        int rc = data_type == SZO_FLOAT ? szo_sz14_decompress_3d_f32((float *)out, s0, r2, r1, body, byte_len - (size_t)(body - bytes))
-                                        : szo_sz14_decompress_3d_f64((double *)out, s0, r2, r1, body, byte_len - (size_t)(body - bytes));
+        int rc = data_type == SZO_FLOAT ? szo_sz14_decompress_3d_f32((float *)out, s0, r2, r1, body, byte_len - (size_t)(body - bytes), NULL)
+                                        : szo_sz14_decompress_3d_f64((double *)out, s0, r2, r1, body, byte_len - (size_t)(body - bytes), NULL);
         if (rc) { free(out); return NULL; }
     } else if ((same & 0x80) && dim == 2) {
         if (data_type == SZO_FLOAT) szo_sz21_decompress_2d_f32((float *)out, r2, r1, body);

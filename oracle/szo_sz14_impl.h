@@ -220,8 +220,8 @@ static inline int FN(szo_sz14_point)(FN(szo_exact) *E, T x, T pred, T eb, T reci
  * (no recorded reference output of a 2-D array). */
 static unsigned char *FN(szo_sz14_compress_3d)(const szo_params *p, const unsigned char *meta, size_t meta_len,
                                                const T *data, size_t r1, size_t r2, size_t r3, T eb, T range, T median_in,
-                                               size_t *out_size, szo_stages *st)
-{
+                                               size_t *out_size, szo_stages *st, const szo_pwr_extra *pw)
+{   /* pw != NULL: the extra container fields of a point-wise-relative stream (TightDataPointStorageF.c:408-419, 454-467) */
     const size_t n = r1 * r2 * r3, r23 = r2 * r3;
     const T recip = 1 / eb;
     unsigned intervals = p->quantization_intervals ? p->quantization_intervals
@@ -329,12 +329,14 @@ pack:
     const size_t resi_size = E.resi_bits ? (E.n * (size_t)E.resi_bits + 7) / 8 : 0;
 
     /* container (TightDataPointStorageF.c:379-479): sizes are 8 bytes (SZ_SIZE_TYPE) */
-    const size_t total = meta_len + 8 + 4 + 4 + NBYTES + 1 + 8 + 8 + 8 + 8 + type_size + lead_size + E.nmid + resi_size;
+    const size_t total = meta_len + 8 + 4 + 4 + NBYTES + 1 + 8 + 8 + 8 + 8 + type_size + lead_size + E.nmid + resi_size
+                       + (pw ? 1 + 8 + 4 + NBYTES + pw->blob_size : 0);
     unsigned char *out = (unsigned char *)calloc(total + 8, 1);
     unsigned char *q = out;
     memcpy(q, meta, meta_len); q += meta_len;
     szo_put_u64be(q, n); q += 8;
     szo_put_u32be(q, p->max_quant_intervals); q += 4;
+    if (pw) { *q++ = 0; /* radExpo */ szo_put_u64be(q, (uint64_t)pw->segment_size); q += 8; szo_put_u32be(q, (uint32_t)pw->blob_size); q += 4; }
     szo_put_u32be(q, intervals); q += 4;
     FN(szo_put_be)(q, E.median); q += NBYTES;
     *q++ = (unsigned char)E.req_len;
@@ -342,8 +344,10 @@ pack:
     szo_put_u64be(q, type_size); q += 8;
     szo_put_u64be(q, E.n); q += 8;
     szo_put_u64be(q, E.nmid); q += 8;
+    if (pw) { FN(szo_put_be)(q, (T)pw->min_log_value); q += NBYTES; }
     szo_put_u32be(q, (uint32_t)node_count); szo_put_u32be(q + 4, intervals);
     memcpy(q + 8, tree, tree_bytes); memcpy(q + 8 + tree_bytes, payload, huff_bytes); q += type_size;
+    if (pw && pw->blob_size) { memcpy(q, pw->blob, pw->blob_size); q += pw->blob_size; }
     for (size_t i = 0; i < E.n; i++) q[i >> 2] |= (unsigned char)(E.lead[i] << (6 - 2 * (i & 3)));
     q += lead_size;
     memcpy(q, E.mid, E.nmid); q += E.nmid;
@@ -404,11 +408,12 @@ static T FN(szo_exact_next)(FN(szo_exact_rd) *R)
     return v + R->median;
 }
 
-static int FN(szo_sz14_decompress_3d)(T *out, size_t r1, size_t r2, size_t r3, const unsigned char *b, size_t avail)
-{
+static int FN(szo_sz14_decompress_3d)(T *out, size_t r1, size_t r2, size_t r3, const unsigned char *b, size_t avail, szo_pwr_extra *pw)
+{   /* pw != NULL: a point-wise-relative stream; its extra fields are skipped here and handed back */
     const size_t n = r1 * r2 * r3, r23 = r2 * r3;
     const unsigned char *q = b;
     q += 4;                                              /* max_quant_intervals */
+    if (pw) { q += 1; pw->segment_size = (size_t)szo_get_u64be(q); q += 8; pw->blob_size = szo_get_u32be(q); q += 4; }
     unsigned intervals = szo_get_u32be(q); q += 4;
     FN(szo_exact_rd) R; memset(&R, 0, sizeof(R));
     R.median = FN(szo_get_be)(q); q += NBYTES;
@@ -417,7 +422,8 @@ static int FN(szo_sz14_decompress_3d)(T *out, size_t r1, size_t r2, size_t r3, c
     size_t type_size = (size_t)szo_get_u64be(q); q += 8;
     size_t exact_n = (size_t)szo_get_u64be(q); q += 8;
     size_t mid_n = (size_t)szo_get_u64be(q); q += 8;
-    if ((size_t)(q - b) + type_size + (exact_n * 2 + 7) / 8 + mid_n > avail) return -1;
+    if (pw) { pw->min_log_value = (double)FN(szo_get_be)(q); q += NBYTES; }
+    if ((size_t)(q - b) + type_size + (pw ? pw->blob_size : 0) + (exact_n * 2 + 7) / 8 + mid_n > avail) return -1;
     int node_count = (int)szo_get_u32be(q);
     int *type = (int *)malloc(n * sizeof(int));
     {
@@ -427,6 +433,7 @@ static int FN(szo_sz14_decompress_3d)(T *out, size_t r1, size_t r2, size_t r3, c
         szo_huff_free(h);
     }
     q += type_size;
+    if (pw) { pw->blob = q; q += pw->blob_size; }
     R.lead = q; q += (exact_n * 2 + 7) / 8;
     R.mid = q; q += mid_n;
     unsigned char *resi_pad = (unsigned char *)calloc((size_t)(b + avail - q) + 8, 1);   /* the bit reader looks one byte ahead */

@@ -182,7 +182,7 @@ static void fill_meta(szhost_meta *m, const sz_params *p, int data_type)
 {
     memset(m, 0, sizeof(*m));
     m->data_type = data_type; m->err_mode = p->errorBoundMode;
-    m->abs_bound = p->absErrBound; m->rel_ratio = p->relBoundRatio; m->psnr = p->psnr;
+    m->abs_bound = p->absErrBound; m->rel_ratio = p->relBoundRatio; m->psnr = p->psnr; m->pwr_ratio = p->pw_relBoundRatio;
     m->vmin = data_type == SZ_FLOAT ? p->fmin : p->dmin; m->vmax = data_type == SZ_FLOAT ? p->fmax : p->dmax;
     m->opt_quant_mode = exe_params->optQuantMode; m->data_endian = dataEndianType; m->sz_mode = p->szMode; m->gzip_mode = p->gzipMode;
     m->sample_distance = p->sampleDistance; m->pred_threshold = p->predThreshold; m->sol_id = p->sol_ID;
@@ -214,6 +214,9 @@ void convertBytesToSZParams(unsigned char *bytes, sz_params *params)
     case REL: params->relBoundRatio = szhost_get_f32be(bytes + 10); break;
     case ABS_AND_REL: case ABS_OR_REL: params->absErrBound = szhost_get_f32be(bytes + 6); params->relBoundRatio = szhost_get_f32be(bytes + 10); break;
     case PSNR: params->psnr = szhost_get_f32be(bytes + 6); break;
+    case ABS_AND_PW_REL: case ABS_OR_PW_REL: params->absErrBound = szhost_get_f32be(bytes + 6); params->pw_relBoundRatio = szhost_get_f32be(bytes + 10); break;
+    case REL_AND_PW_REL: case REL_OR_PW_REL: params->relBoundRatio = szhost_get_f32be(bytes + 6); params->pw_relBoundRatio = szhost_get_f32be(bytes + 10); break;
+    case PW_REL: params->pw_relBoundRatio = szhost_get_f32be(bytes + 10); break;
     default: break;
     }
     params->sol_ID = (int)bytes[14];
@@ -221,6 +224,34 @@ void convertBytesToSZParams(unsigned char *bytes, sz_params *params)
     else { params->max_quant_intervals = 0; params->quantization_intervals = szhost_get_u32be(bytes + 16); }
     if (params->dataType == SZ_FLOAT) { params->fmin = szhost_get_f32be(bytes + 20); params->fmax = szhost_get_f32be(bytes + 24); }
     else if (params->dataType == SZ_DOUBLE) { params->dmin = szhost_get_f64be(bytes + 20); params->dmax = szhost_get_f64be(bytes + 28); }
+}
+
+/* the lossless stage after the SZ stream (sz_float.c:3027-3040); takes ownership of `tmp` */
+static int finish_lossless(unsigned char *tmp, size_t tmpSize, unsigned char **newByteData, size_t *outSize, int status)
+{
+    if (confparams_cpr->szMode == SZ_BEST_SPEED) { *newByteData = tmp; *outSize = tmpSize; }
+    else if (confparams_cpr->szMode == SZ_BEST_COMPRESSION || confparams_cpr->szMode == SZ_DEFAULT_COMPRESSION) {
+        /* sz_lossless_compress, utility.c:174-195.  A missing back end is an error: returning the bare SZ stream would silently
+         * change what szMode promises (and the reference's default is SZ_BEST_COMPRESSION, conf.c:114) */
+        if (confparams_cpr->losslessCompressor == ZSTD_COMPRESSOR) {
+            if (!zstd_load()) { printf("Error: szMode asks for the zstd back end but libzstd.so.1 cannot be loaded (use SZ_BEST_SPEED or GZIP_COMPRESSOR).\n"); free(tmp); return SZ_NSCS; }
+            size_t est = tmpSize < 100 ? 200 : (size_t)(tmpSize * 1.2);
+            unsigned char *z = (unsigned char *)malloc(est);
+            if (!z) { free(tmp); return SZ_NSCS; }
+            size_t zs = g_zstd.compress(z, est, tmp, tmpSize, confparams_cpr->gzipMode);
+            if (g_zstd.iserr(zs)) { printf("Error: ZSTD_compress failed.\n"); free(z); free(tmp); return SZ_NSCS; }
+            free(tmp); *newByteData = z; *outSize = zs;
+        } else if (confparams_cpr->losslessCompressor == GZIP_COMPRESSOR) {
+            if (!zlib_load()) { printf("Error: szMode asks for the gzip back end but libz.so.1 cannot be loaded (use SZ_BEST_SPEED).\n"); free(tmp); return SZ_NSCS; }
+            unsigned long zl = g_zlib.bound((unsigned long)tmpSize);
+            unsigned char *z = (unsigned char *)malloc(zl);
+            if (!z) { free(tmp); return SZ_NSCS; }
+            int zr = g_zlib.compress2(z, &zl, tmp, (unsigned long)tmpSize, confparams_cpr->gzipMode);   /* zlib_compress5: deflateInit(level), one stream */
+            if (zr != 0) { printf("Error: zlib compress2 failed (%d).\n", zr); free(z); free(tmp); return SZ_NSCS; }
+            free(tmp); *newByteData = z; *outSize = (size_t)zl;
+        } else { printf("Error: Unrecognized lossless compressor in sz_lossless_compress()\n"); free(tmp); return SZ_NSCS; }
+    } else { printf("Error: Wrong setting of confparams_cpr->szMode in the compression.\n"); free(tmp); return SZ_MERR; }
+    return status;
 }
 
 /* ---- compression ---- */
@@ -241,8 +272,6 @@ static int compress_fp(int dataType, int withRegression, unsigned char **newByte
         memcpy(*newByteData, oriData, dataLength * esz);
         return SZ_SCES;
     }
-    if (errBoundMode >= PW_REL) { printf("Error: point-wise relative error bounds are outside the scope of the MI355X build.\n"); return SZ_BERR; }
-
     szhip_ctx *ctx = get_ctx();
     if (!ctx) return SZ_NSCS;
     void *d_in = NULL;
@@ -273,7 +302,10 @@ static int compress_fp(int dataType, int withRegression, unsigned char **newByte
                 float fa = (float)absErr_Bound, fb = (float)b;
                 realPrecision = errBoundMode == ABS_AND_REL ? (fa < fb ? fa : fb) : (fa > fb ? fa : fb);
             } else realPrecision = errBoundMode == ABS_AND_REL ? (absErr_Bound < b ? absErr_Bound : b) : (absErr_Bound > b ? absErr_Bound : b);
-        } else { printf("Error: error-bound-mode is incorrect!\n"); status = SZ_BERR; }
+        } else if (errBoundMode == ABS_AND_PW_REL || errBoundMode == ABS_OR_PW_REL) realPrecision = absErr_Bound;
+        else if (errBoundMode == REL_AND_PW_REL || errBoundMode == REL_OR_PW_REL) realPrecision = relBoundRatio * valueRangeSize;
+        else if (errBoundMode == PW_REL) realPrecision = 0;
+        else { printf("Error: error-bound-mode is incorrect!\n"); status = SZ_BERR; }
         confparams_cpr->absErrBound = realPrecision;
     }
 
@@ -296,6 +328,59 @@ static int compress_fp(int dataType, int withRegression, unsigned char **newByte
 
     int dim = computeDimension(r5, r4, r3, r2, r1);
     if (dim == 5) { printf("Error: doesn't support 5 dimensions for now.\n"); return SZ_DERR; }
+    if (errBoundMode >= PW_REL) {
+        /* Point-wise relative bounds: log2|x| through the SZ 1.4 quantiser with an absolute bound in the log domain -- the `_pwr_pre_log`
+         * form (sz_float_pwr.c:1791-1975; dispatch sz_float.c:2888-2996: every mode >= PW_REL takes it, and only pwRelBoundRatio counts).
+         * The reference prefers its table-driven MSST19 form when accelerate_pw_rel_compression is set (its default) and the ratio is
+         * >= 1e-5; this build always writes the log-domain form, which every stock reader decodes (flag 0x20 without 0x08). */
+        if (!(pwRelBoundRatio > 0)) { printf("Error: pw_relBoundRatio must be positive.\n"); return SZ_BERR; }
+        const int dt = dataType == SZ_FLOAT ? SZHIP_F32 : SZHIP_F64;
+        unsigned char *signs = (unsigned char *)malloc(dataLength);
+        if (!signs) return SZ_NSCS;
+        void *d_log = NULL; int positive = 1; double rp = 0, lrange = 0, lmedian = 0, minlog = 0;
+        int prc = szhip_pwr_prepare(ctx, dt, d_in, 1, dataLength, vmin, vmax, pwRelBoundRatio, &d_log, signs, &positive, &rp, &lrange, &lmedian, &minlog);
+        if (prc != SZHIP_OK) { printf("Error: szhip_pwr_prepare failed (%d): %s\n", prc, szhip_last_error(ctx)); free(signs); return SZ_NSCS; }
+        if (!(rp > 0)) { printf("Error: pw_relBoundRatio %g leaves no room below the rounding margin of this data.\n", pwRelBoundRatio); free(signs); return SZ_BERR; }
+        szhip_pwr pw; memset(&pw, 0, sizeof(pw));
+        pw.segment_size = (uint64_t)confparams_cpr->segment_size; pw.min_log_value = minlog;
+        unsigned char *blob = NULL;
+        if (!positive) {                                           /* sz_lossless_compress(ZSTD_COMPRESSOR, 3, signs, ...) (utility.c:174-195) */
+            if (!zstd_load()) { printf("Error: PW_REL on data with negative values needs libzstd.so.1 for the sign bytes.\n"); free(signs); return SZ_NSCS; }
+            size_t est = dataLength < 100 ? 200 : (size_t)(dataLength * 1.2);
+            blob = (unsigned char *)malloc(est);
+            if (!blob) { free(signs); return SZ_NSCS; }
+            size_t zs = g_zstd.compress(blob, est, signs, dataLength, 3);
+            if (g_zstd.iserr(zs) || zs > 0xffffffffu) { printf("Error: ZSTD_compress failed on the sign bytes.\n"); free(blob); free(signs); return SZ_NSCS; }
+            pw.signs_blob = blob; pw.signs_blob_size = (uint32_t)zs;
+        }
+        free(signs);
+        unsigned char pflags = 0x40 | 0x20;                        /* TightDataPointStorageF.c:600-611: isPW_REL, no MSST19 bit */
+        if (confparams_cpr->protectValueRange) pflags |= 0x04;
+        szhost_write_meta(&m, pflags, meta);
+        szhip_params php;
+        php.sample_distance = confparams_cpr->sampleDistance; php.pred_threshold = confparams_cpr->predThreshold;
+        php.max_quant_intervals = confparams_cpr->maxRangeRadius * 2;
+        php.quantization_intervals = exe_params->optQuantMode == 1 ? 0 : (unsigned)exe_params->intvCapacity;
+        unsigned char *ptmp = NULL; size_t ptmpSize = 0;
+        int crc = szhip_compress_sz14_pwr(ctx, dt, d_log, 1, dim == 4 ? r4 * r3 : r3, r2, r1, rp, lrange, lmedian, &php, meta, 4 + meta_len, &pw, 0,
+                                          &ptmp, &ptmpSize, &g_last_stats);
+        free(blob);
+        if (crc != SZHIP_OK) { printf("Error: szhip_compress_sz14_pwr failed (%d): %s\n", crc, szhip_last_error(ctx)); return SZ_NSCS; }
+        if (exe_params->optQuantMode == 1) { exe_params->intvCapacity = (int)g_last_stats.intervals; exe_params->intvRadius = exe_params->intvCapacity / 2; }
+        if (ptmpSize > 3 + meta_len + exe_params->SZ_SIZE_TYPE + 1 + esz * dataLength) {     /* sz_float_pwr.c:1971 */
+            size_t tot = 3 + meta_len + 8 + 1 + esz * dataLength;
+            unsigned char *o = (unsigned char *)malloc(tot);
+            memcpy(o, meta, 4 + meta_len);
+            o[3] = 80;
+            szhost_put_u64be(o + 4 + meta_len, dataLength);
+            unsigned char *q = o + 4 + meta_len + 8;
+            for (size_t i = 0; i < dataLength; i++, q += esz) {
+                if (dataType == SZ_FLOAT) szhost_put_f32be(q, ((float *)oriData)[i]); else szhost_put_f64be(q, ((double *)oriData)[i]);
+            }
+            free(ptmp); ptmp = o; ptmpSize = tot;
+        }
+        return finish_lossless(ptmp, ptmpSize, newByteData, outSize, status);
+    }
     /* the SZ 1.4 path (sz_float.c:2938,2978): 2-D and 3-D in this build; a 1-D array takes its container whatever the switch says (:2885-2900) */
     const int sz14 = withRegression == SZ_NO_REGRESSION || dim == 1;
     if (!(dim >= 1 && dim <= 4) || (sz14 && dim == 4) || confparams_cpr->randomAccess) {
@@ -352,29 +437,7 @@ static int compress_fp(int dataType, int withRegression, unsigned char **newByte
         free(tmp); tmp = o; tmpSize = tot;
     }
 
-    if (confparams_cpr->szMode == SZ_BEST_SPEED) { *newByteData = tmp; *outSize = tmpSize; }
-    else if (confparams_cpr->szMode == SZ_BEST_COMPRESSION || confparams_cpr->szMode == SZ_DEFAULT_COMPRESSION) {
-        /* sz_lossless_compress, utility.c:174-195.  A missing back end is an error: returning the bare SZ stream would silently
-         * change what szMode promises (and the reference's default is SZ_BEST_COMPRESSION, conf.c:114) */
-        if (confparams_cpr->losslessCompressor == ZSTD_COMPRESSOR) {
-            if (!zstd_load()) { printf("Error: szMode asks for the zstd back end but libzstd.so.1 cannot be loaded (use SZ_BEST_SPEED or GZIP_COMPRESSOR).\n"); free(tmp); return SZ_NSCS; }
-            size_t est = tmpSize < 100 ? 200 : (size_t)(tmpSize * 1.2);
-            unsigned char *z = (unsigned char *)malloc(est);
-            if (!z) { free(tmp); return SZ_NSCS; }
-            size_t zs = g_zstd.compress(z, est, tmp, tmpSize, confparams_cpr->gzipMode);
-            if (g_zstd.iserr(zs)) { printf("Error: ZSTD_compress failed.\n"); free(z); free(tmp); return SZ_NSCS; }
-            free(tmp); *newByteData = z; *outSize = zs;
-        } else if (confparams_cpr->losslessCompressor == GZIP_COMPRESSOR) {
-            if (!zlib_load()) { printf("Error: szMode asks for the gzip back end but libz.so.1 cannot be loaded (use SZ_BEST_SPEED).\n"); free(tmp); return SZ_NSCS; }
-            unsigned long zl = g_zlib.bound((unsigned long)tmpSize);
-            unsigned char *z = (unsigned char *)malloc(zl);
-            if (!z) { free(tmp); return SZ_NSCS; }
-            int zr = g_zlib.compress2(z, &zl, tmp, (unsigned long)tmpSize, confparams_cpr->gzipMode);   /* zlib_compress5: deflateInit(level), one stream */
-            if (zr != 0) { printf("Error: zlib compress2 failed (%d).\n", zr); free(z); free(tmp); return SZ_NSCS; }
-            free(tmp); *newByteData = z; *outSize = (size_t)zl;
-        } else { printf("Error: Unrecognized lossless compressor in sz_lossless_compress()\n"); free(tmp); return SZ_NSCS; }
-    } else { printf("Error: Wrong setting of confparams_cpr->szMode in the compression.\n"); free(tmp); return SZ_MERR; }
-    return status;
+    return finish_lossless(tmp, tmpSize, newByteData, outSize, status);
 }
 
 unsigned char *SZ_compress_args(int dataType, void *data, size_t *outSize, int errBoundMode, double absErrBound,
@@ -515,9 +578,31 @@ static void *decompress_fp(int dataType, unsigned char *cmpBytes, size_t cmpSize
         }
     } else {
         int dim = computeDimension(r5, r4, r3, r2, r1);
-        if ((same & (0x20 | 0x08 | 0x02)) || !(dim >= 1 && dim <= 4) || (!(same & 0x80) && dim == 4) || ((same & 0x80) && dim == 1) || st != 8 || confparams_dec->sol_ID != SZ) {
+        if ((same & 0x20) && !(same & (0x08 | 0x02 | 0x80)) && dim >= 1 && dim <= 4 && st == 8 && confparams_dec->sol_ID == SZ) {
+            /* point-wise relative, log-domain form: decompressDataSeries_float_{1D,2D,3D}_pwr_pre_log (szd_float_pwr.c:1353-1422; 4-D as
+             * (r4*r3, r2, r1), szd_float.c:2838) */
+            szhip_ctx *ctx = get_ctx();
+            const int dt = dataType == SZ_FLOAT ? SZHIP_F32 : SZHIP_F64;
+            size_t bo = 0, bs = 0; double thr = 0;
+            unsigned char *signs = NULL;
+            if (!ctx || szhip_sz14_pwr_locate(dt, sz, szlen, 4 + meta_len + st, &bo, &bs, &thr) != SZHIP_OK) { printf("Error: truncated PW_REL stream.\n"); ok = 0; }
+            else if (bs > 0) {                                     /* sz_lossless_decompress(ZSTD_COMPRESSOR, ...) of the sign bytes */
+                signs = (unsigned char *)malloc(dataLength ? dataLength : 1);
+                if (!zstd_load()) { printf("Error: the sign bytes of this PW_REL stream need libzstd.so.1.\n"); ok = 0; }
+                else if (!signs) ok = 0;
+                else {
+                    size_t got = g_zstd.decompress(signs, dataLength, sz + bo, bs);
+                    if (g_zstd.iserr(got) || got != dataLength) { printf("Error: the sign bytes of this PW_REL stream do not decode to %zu bytes.\n", dataLength); ok = 0; }
+                }
+            }
+            if (ok) {
+                int rc = szhip_decompress_sz14_pwr(ctx, dt, sz, 0, szlen, 4 + meta_len + st, dim == 4 ? r4 * r3 : r3, r2, r1, signs, out, 0, &g_last_stats);
+                if (rc != SZHIP_OK) { printf("Error: szhip_decompress_sz14_pwr failed (%d): %s\n", rc, szhip_last_error(ctx)); ok = 0; }
+            }
+            free(signs);
+        } else if ((same & (0x20 | 0x08 | 0x02)) || !(dim >= 1 && dim <= 4) || (!(same & 0x80) && dim == 4) || ((same & 0x80) && dim == 1) || st != 8 || confparams_dec->sol_ID != SZ) {
             printf("Error: the MI355X build decodes SZ 2.1 regression-type streams of 2-D/3-D/4-D arrays and SZ 1.4 streams of 1-D/2-D/3-D arrays "
-                   "(float/double, no point-wise-relative or random-access form); this stream (flags 0x%02x, dim %d) is not covered yet.\n", same, dim);
+                   "(float/double; point-wise-relative streams in their log-domain form only, no MSST19 and no random-access form); this stream (flags 0x%02x, dim %d) is not covered yet.\n", same, dim);
             ok = 0;
         } else if (!(same & 0x80)) {   /* SZ 1.4 container: getSnapshotData_float_3D -> decompressDataSeries_float_3D (szd_float.c:146,600) */
             szhip_ctx *ctx = get_ctx();

@@ -39,7 +39,7 @@ struct szhip_ctx {
     // workspaces (grow-only)
     DevBuf lor_bits, reg_flags, reg_rank, coef_compact, in, out, codes_nat, codes_blk, coef, blk_lor, faceI, faceJ, progress, trace, order, small, hist, col_zeros, col_zeros64,
         col_off, partial, samples, unpred, stream_buf, chunk_bits, chunk_off, code_tab, len_tab, dec_tab,
-        starts, ends, counts, offs, dirty, zcnt, zpos;
+        starts, ends, counts, offs, dirty, zcnt, zpos, pwr_log, pwr_signs, pwr_small;
     void *pinned = nullptr; size_t pinned_cap = 0;
     void *pinned2 = nullptr; size_t pinned2_cap = 0;   // target of the second stream's copies (indicator bits, regression-block count)
     int order_nI = -1, order_nJ = -1;
@@ -952,10 +952,11 @@ int launch_pencil14(szhip_ctx *ctx, const szh_geom3 &G, u64 *sm, bool dec, const
 
 template <class T>
 int compress14_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r0, size_t r1, size_t r2, double eb_in, double range_in,
-                    double median_in, const szhip_params *prm, const unsigned char *meta, size_t meta_len, int out_on_device,
+                    double median_in, const szhip_params *prm, const unsigned char *meta, size_t meta_len, const szhip_pwr *pw, int out_on_device,
                     unsigned char **out, size_t *out_size, szhip_stats *stats)
 {
     const int is_double = sizeof(T) == 8;
+    // pw != NULL: the data are log2|x| of a point-wise-relative call and the container carries the PW_REL fields
     // r0 == 0: the 2-D compressor SZ_compress_float_2D_MDQ (sz_float.c:610): its predictors are those of the 3-D one's first layer,
     // so it is carried as 1 x r1 x r2 (the block size of the carried geometry plays no role here); its optimiser has the 2-D lattice
     // r0 == 0 and r1 == 0: the 1-D compressor SZ_compress_float_1D_MDQ (sz_float.c:353): a chain through the previous reconstructed
@@ -1105,14 +1106,20 @@ int compress14_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t
     // ---- container
     h0 = now_ms();
     const size_t type_size = 8 + tree_bytes + pay_bytes;
-    const size_t hdr_len = meta_len + 8 + 4 + 4 + sizeof(T) + 1 + 8 + 8 + 8 + 8 + 8 + tree_bytes;     // ... up to the Huffman payload
-    const size_t total_len = hdr_len + pay_bytes + lead_size + (size_t)nmid + resi_size;
+    const size_t blob = pw ? (size_t)pw->signs_blob_size : 0;
+    const size_t hdr_len = meta_len + 8 + 4 + (pw ? 1 + 8 + 4 : 0) + 4 + sizeof(T) + 1 + 8 + 8 + 8 + 8 + (pw ? sizeof(T) : 0) + 8 + tree_bytes; // ... up to the Huffman payload
+    const size_t total_len = hdr_len + pay_bytes + blob + lead_size + (size_t)nmid + resi_size;
     std::vector<unsigned char> hdr(hdr_len, 0);
     {
         unsigned char *q = hdr.data();
         memcpy(q, meta, meta_len); q += meta_len;
         szhost_put_u64be(q, (uint64_t)n); q += 8;
         szhost_put_u32be(q, prm->max_quant_intervals); q += 4;
+        if (pw) {                                                // TightDataPointStorageF.c:408-419
+            *q++ = pw->rad_expo;
+            szhost_put_u64be(q, pw->segment_size); q += 8;
+            szhost_put_u32be(q, pw->signs_blob_size); q += 4;
+        }
         szhost_put_u32be(q, intervals); q += 4;
         if (is_double) szhost_put_f64be(q, (double)median); else szhost_put_f32be(q, (float)median);
         q += sizeof(T);
@@ -1121,6 +1128,10 @@ int compress14_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t
         szhost_put_u64be(q, (uint64_t)type_size); q += 8;
         szhost_put_u64be(q, (uint64_t)E); q += 8;
         szhost_put_u64be(q, (uint64_t)nmid); q += 8;
+        if (pw) {                                                // minLogValue in the data's type (:454-459; TightDataPointStorageD.c:456-461)
+            if (is_double) szhost_put_f64be(q, pw->min_log_value); else szhost_put_f32be(q, (float)pw->min_log_value);
+            q += sizeof(T);
+        }
         szhost_put_u32be(q, (uint32_t)hf->n_nodes); q += 4;      // encode_withTree blob (Huffman.c:790-816)
         szhost_put_u32be(q, intervals); q += 4;
         szhost_huff_tree_write(hf, q); q += tree_bytes;
@@ -1136,6 +1147,7 @@ int compress14_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t
     unsigned char *d_stream = (unsigned char *)ctx->stream_buf.p;
     HIPCHK(hipMemsetAsync(d_stream, 0, total_len + 64, st));
     HIPCHK(hipMemcpyAsync(d_stream, hdr.data(), hdr_len, hipMemcpyHostToDevice, st));
+    if (blob) HIPCHK(hipMemcpyAsync(d_stream + hdr_len + pay_bytes, pw->signs_blob, blob, hipMemcpyHostToDevice, st));   // after the type array (:463-467)
     if (total_bits > 0) {
         const int64_t nchunks = (n + SZH_ENC_CHUNK - 1) / SZH_ENC_CHUNK;
         TRY(ensure(ctx, ctx->chunk_bits, (size_t)nchunks * 8));
@@ -1148,7 +1160,7 @@ int compress14_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t
         HIPCHK(hipGetLastError());
     }
     if (E > 0) {
-        unsigned char *lead_out = d_stream + hdr_len + pay_bytes, *mid_out = lead_out + lead_size, *resi_out = mid_out + nmid;
+        unsigned char *lead_out = d_stream + hdr_len + pay_bytes + blob, *mid_out = lead_out + lead_size, *resi_out = mid_out + nmid;
         hipLaunchKernelGGL((k_exact_write<T>), dim3((unsigned)(((E + 7) / 8 + 255) / 256)), dim3(256), 0, st, (const T *)ctx->unpred.p, (int64_t)E,
                            median, req_bytes, resi_bits, (const uint8_t *)ctx->lor_bits.p, (const u64 *)ctx->reg_rank.p, lead_out, mid_out, resi_out,
                            (int64_t)resi_size);
@@ -1186,7 +1198,7 @@ int compress14_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t
 
 // `body_off`: offset of the max_quant_intervals field (4 + 28|36 + 8)
 template <class T>
-int decompress14_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_on_device, size_t stream_len, size_t body_off,
+int decompress14_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_on_device, size_t stream_len, size_t body_off, bool pwr,
                       size_t r0, size_t r1, size_t r2, void *out, int out_on_device, szhip_stats *stats)
 {
     const int is_double = sizeof(T) == 8;
@@ -1208,7 +1220,7 @@ int decompress14_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream
 
     // ---- header + tree on the host (TightDataPointStorageF.c:54-265); a device-resident stream hands over a prefix
     double h0 = now_ms();
-    const size_t fixed = 4 + 4 + sizeof(T) + 1 + 8 + 8 + 8 + 8 + 8;
+    const size_t fixed = 4 + (pwr ? 1 + 8 + 4 : 0) + 4 + sizeof(T) + 1 + 8 + 8 + 8 + 8 + (pwr ? sizeof(T) : 0) + 8;
     if (body_off + fixed > stream_len) FAIL(SZHIP_ERR_STREAM, "truncated stream");
     std::vector<unsigned char> hbuf;
     const unsigned char *hs = stream_in;
@@ -1223,6 +1235,8 @@ int decompress14_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream
     TRY(fetch(body_off + fixed));
     const unsigned char *q = hs + body_off;
     q += 4;                                                        // max_quant_intervals
+    size_t blob = 0;
+    if (pwr) { q += 1 + 8; blob = szhost_get_u32be(q); q += 4; }   // radExpo, segment_size, size of the sign bytes (TightDataPointStorageF.c:137-148)
     const unsigned intervals = szhost_get_u32be(q); q += 4;
     const T median = is_double ? (T)szhost_get_f64be(q) : (T)szhost_get_f32be(q); q += sizeof(T);
     const int req_len = *q++;
@@ -1230,6 +1244,7 @@ int decompress14_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream
     const uint64_t type_size = szhost_get_u64be(q); q += 8;
     const uint64_t E = szhost_get_u64be(q); q += 8;
     const uint64_t nmid = szhost_get_u64be(q); q += 8;
+    if (pwr) q += sizeof(T);                                       // minLogValue (the caller read it: szhip_sz14_pwr_locate)
     const size_t type_off = body_off + fixed - 8;                  // the blob starts with nodeCount | intervals
     if (intervals < 4 || intervals > 65536) FAIL(SZHIP_ERR_STREAM, "bad interval count %u", intervals);
     if (req_len < 9 || req_len > (int)sizeof(T) * 8) FAIL(SZHIP_ERR_STREAM, "bad exact-value length %d", req_len);
@@ -1238,7 +1253,7 @@ int decompress14_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream
     const size_t lead_size = (size_t)((E * 2 + 7) / 8), resi_size = resi_bits ? (size_t)((E * (uint64_t)resi_bits + 7) / 8) : 0;
     if (E >= ((uint64_t)1 << 32)) FAIL(SZHIP_ERR_UNSUP, "more than 2^32 exact values");   // the prefix counts of k_exact_* are packed in 32-bit halves
     if (E > (uint64_t)n || type_size < 8 || type_size > stream_len || nmid > stream_len ||
-        type_off + type_size + lead_size + nmid + resi_size > stream_len) FAIL(SZHIP_ERR_STREAM, "truncated stream");
+        blob > stream_len || type_off + type_size + blob + lead_size + nmid + resi_size > stream_len) FAIL(SZHIP_ERR_STREAM, "truncated stream");
     const int node_count = (int)szhost_get_u32be(q);
     if (node_count <= 0 || 8 + szhost_huff_serial_size(node_count) > type_size) FAIL(SZHIP_ERR_STREAM, "bad Huffman tree size");
     const size_t tree_bytes = szhost_huff_serial_size(node_count);
@@ -1277,7 +1292,7 @@ int decompress14_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream
     T *d_out = (T *)out;
     if (!out_on_device) { TRY(ensure(ctx, ctx->out, (size_t)n * sizeof(T))); d_out = (T *)ctx->out.p; }
     if (E > 0) {
-        const unsigned char *lead_in = d_stream + type_off + type_size, *mid_in = lead_in + lead_size, *resi_in = mid_in + nmid;
+        const unsigned char *lead_in = d_stream + type_off + type_size + blob, *mid_in = lead_in + lead_size, *resi_in = mid_in + nmid;
         const unsigned gE = (unsigned)((E + 255) / 256);
         TRY(ensure(ctx, ctx->unpred, (size_t)E * sizeof(T)));
         TRY(ensure(ctx, ctx->reg_flags, (size_t)E * 8 * 3));         // flag words: f01 | f2 | mid counts
@@ -1331,6 +1346,88 @@ int decompress14_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream
     hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); S.ms_quant = ms;
     S.ms_host = host_ms; S.ms_total = now_ms() - t_begin; S.out_bytes = (uint64_t)n * sizeof(T);
     if (stats) *stats = S;
+    return SZHIP_OK;
+}
+
+// =====================================================================================================================
+// Point-wise relative bounds, log-domain form (szh_pwr.h)
+// =====================================================================================================================
+template <class T>
+int pwr_prepare_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t n, double vmin, double vmax, double ratio, void **d_log_out,
+                     unsigned char *signs_host, int *positive, double *real_precision, double *value_range, double *median, double *min_log_value)
+{
+    hipStream_t st = ctx->stream;
+    const T *d_in = (const T *)data;
+    if (!data_on_device) {
+        TRY(ensure(ctx, ctx->in, n * sizeof(T)));
+        HIPCHK(hipMemcpyAsync(ctx->in.p, data, n * sizeof(T), hipMemcpyHostToDevice, st));
+        d_in = (const T *)ctx->in.p;
+    }
+    TRY(ensure(ctx, ctx->pwr_log, n * sizeof(T)));
+    TRY(ensure(ctx, ctx->pwr_signs, n));
+    TRY(ensure(ctx, ctx->pwr_small, PWR_RED * 8));
+    T *d_log = (T *)ctx->pwr_log.p;
+    u64 *red = (u64 *)ctx->pwr_small.p;
+    const u64 init[PWR_RED] = {~0ull, 0ull, ~0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    HIPCHK(hipMemcpyAsync(red, init, sizeof(init), hipMemcpyHostToDevice, st));
+    const int grid = (int)std::min<int64_t>(((int64_t)n + 255) / 256, 4096);
+    hipLaunchKernelGGL((k_pwr_log<T>), dim3(grid), dim3(256), 0, st, d_in, (int64_t)n, d_log, (unsigned char *)ctx->pwr_signs.p, red);
+    HIPCHK(hipGetLastError());
+    u64 res[PWR_RED];
+    HIPCHK(hipMemcpyAsync(res, red, sizeof(res), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    // sz_float_pwr.c:1923-1947, in the data's type where the reference's variables have it
+    const T tmin = (T)vmin, tmax = (T)vmax;
+    T max_abs_log;
+    if (tmin == 0) max_abs_log = (T)fabs(log2(fabs((double)tmax)));
+    else if (tmax == 0) max_abs_log = (T)fabs(log2(fabs((double)tmin)));
+    else max_abs_log = (T)(fabs(log2(fabs((double)tmin))) > fabs(log2(fabs((double)tmax))) ? fabs(log2(fabs((double)tmin))) : fabs(log2(fabs((double)tmax))));
+    T min_log = max_abs_log;
+    if (res[PWR_NONZERO]) {
+        const T lo = (T)ord_dec<T>(res[PWR_MINLOG]), hi = (T)ord_dec<T>(res[PWR_MAXLOG]);
+        if (hi > max_abs_log) max_abs_log = hi;
+        if (lo < min_log) min_log = lo;
+    }
+    const T amin = (T)ord_dec<T>(res[PWR_MINALL]), amax = (T)ord_dec<T>(res[PWR_MAXALL]);     // computeRangeSize_float on the log array, zeros still 0
+    const T range = amax - amin;
+    *value_range = (double)range;
+    *median = (double)(T)(amin + range / 2);
+    if (fabs((double)min_log) > (double)max_abs_log) max_abs_log = (T)fabs((double)min_log);
+    const double rp = log2(1.0 + ratio) - (double)max_abs_log * (sizeof(T) == 4 ? 1.2e-7 : 2.23e-16);
+    *real_precision = rp;
+    const T zval = (T)((double)min_log - 2.0001 * rp);
+    *min_log_value = (double)(T)((double)min_log - 1.0001 * rp);
+    hipLaunchKernelGGL((k_pwr_zero<T>), dim3(grid), dim3(256), 0, st, d_in, (int64_t)n, d_log, zval);
+    HIPCHK(hipGetLastError());
+    *positive = res[PWR_NEG] ? 0 : 1;
+    if (res[PWR_NEG] && signs_host) HIPCHK(hipMemcpyAsync(signs_host, ctx->pwr_signs.p, n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    *d_log_out = d_log;
+    return SZHIP_OK;
+}
+
+template <class T>
+int decompress14_pwr_impl(szhip_ctx *ctx, const unsigned char *stream, int stream_on_device, size_t stream_len, size_t body_off,
+                          size_t r0, size_t r1, size_t r2, const unsigned char *signs_host, double threshold, void *out, int out_on_device, szhip_stats *stats)
+{
+    const size_t n = (r0 ? r0 : 1) * (r1 ? r1 : 1) * r2;
+    hipStream_t st = ctx->stream;
+    TRY(ensure(ctx, ctx->pwr_log, n * sizeof(T)));
+    T *d_log = (T *)ctx->pwr_log.p;
+    TRY(decompress14_impl<T>(ctx, stream, stream_on_device, stream_len, body_off, true, r0, r1, r2, d_log, 1, stats));
+    const unsigned char *d_signs = nullptr;
+    if (signs_host) {
+        TRY(ensure(ctx, ctx->pwr_signs, n));
+        HIPCHK(hipMemcpyAsync(ctx->pwr_signs.p, signs_host, n, hipMemcpyHostToDevice, st));
+        d_signs = (const unsigned char *)ctx->pwr_signs.p;
+    }
+    T *d_out = (T *)out;
+    if (!out_on_device) { TRY(ensure(ctx, ctx->out, n * sizeof(T))); d_out = (T *)ctx->out.p; }
+    const int grid = (int)std::min<int64_t>(((int64_t)n + 255) / 256, 4096);
+    hipLaunchKernelGGL((k_pwr_exp<T>), dim3(grid), dim3(256), 0, st, (const T *)d_log, (int64_t)n, (T)threshold, d_signs, d_out);
+    HIPCHK(hipGetLastError());
+    if (!out_on_device) HIPCHK(hipMemcpyAsync(out, d_out, n * sizeof(T), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
     return SZHIP_OK;
 }
 
@@ -1633,7 +1730,8 @@ void szhip_destroy(szhip_ctx *ctx)
     DevBuf *bufs[] = {&ctx->lor_bits, &ctx->reg_flags, &ctx->reg_rank, &ctx->coef_compact, &ctx->in, &ctx->out, &ctx->codes_nat, &ctx->codes_blk, &ctx->coef, &ctx->blk_lor, &ctx->faceI, &ctx->faceJ, &ctx->progress, &ctx->trace,
                       &ctx->order, &ctx->small, &ctx->hist, &ctx->col_zeros, &ctx->col_zeros64, &ctx->col_off, &ctx->partial,
                       &ctx->samples, &ctx->unpred, &ctx->stream_buf, &ctx->chunk_bits, &ctx->chunk_off, &ctx->code_tab,
-                      &ctx->len_tab, &ctx->dec_tab, &ctx->starts, &ctx->ends, &ctx->counts, &ctx->offs, &ctx->dirty};
+                      &ctx->len_tab, &ctx->dec_tab, &ctx->starts, &ctx->ends, &ctx->counts, &ctx->offs, &ctx->dirty, &ctx->zcnt, &ctx->zpos,
+                      &ctx->pwr_log, &ctx->pwr_signs, &ctx->pwr_small};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
     if (ctx->pinned) hipHostFree(ctx->pinned);
     if (ctx->pinned2) hipHostFree(ctx->pinned2);
@@ -1690,8 +1788,8 @@ int szhip_compress_sz14(szhip_ctx *ctx, int dtype, const void *data, int data_on
     if (!(eb > 0)) return SZHIP_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
     const int rc = dtype == SZHIP_F32
-               ? compress14_impl<float>(ctx, data, data_on_device, r0, r1, r2, eb, value_range, median, params, meta, meta_len, out_on_device, out, out_size, stats)
-               : compress14_impl<double>(ctx, data, data_on_device, r0, r1, r2, eb, value_range, median, params, meta, meta_len, out_on_device, out, out_size, stats);
+               ? compress14_impl<float>(ctx, data, data_on_device, r0, r1, r2, eb, value_range, median, params, meta, meta_len, nullptr, out_on_device, out, out_size, stats)
+               : compress14_impl<double>(ctx, data, data_on_device, r0, r1, r2, eb, value_range, median, params, meta, meta_len, nullptr, out_on_device, out, out_size, stats);
     if (rc != SZHIP_OK) { hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream); }
     return rc;
 }
@@ -1703,8 +1801,66 @@ int szhip_decompress_sz14(szhip_ctx *ctx, int dtype, const unsigned char *stream
     if ((r0 != 0 && r0 < 2) || (r1 < 2 && !(r0 == 0 && r1 == 0)) || r2 < 2 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff) return SZHIP_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
     const int rc = dtype == SZHIP_F32
-               ? decompress14_impl<float>(ctx, stream, stream_on_device, stream_len, body_off, r0, r1, r2, out, out_on_device, stats)
-               : decompress14_impl<double>(ctx, stream, stream_on_device, stream_len, body_off, r0, r1, r2, out, out_on_device, stats);
+               ? decompress14_impl<float>(ctx, stream, stream_on_device, stream_len, body_off, false, r0, r1, r2, out, out_on_device, stats)
+               : decompress14_impl<double>(ctx, stream, stream_on_device, stream_len, body_off, false, r0, r1, r2, out, out_on_device, stats);
+    if (rc != SZHIP_OK) { hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream); }
+    return rc;
+}
+
+int szhip_pwr_prepare(szhip_ctx *ctx, int dtype, const void *data, int data_on_device, size_t n, double vmin, double vmax, double pwr_ratio,
+                      void **d_log, unsigned char *signs_host, int *positive, double *real_precision, double *value_range, double *median,
+                      double *min_log_value)
+{
+    if (!ctx || !data || !n || !d_log || !positive || !real_precision || !value_range || !median || !min_log_value || !(pwr_ratio > 0)) return SZHIP_ERR_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
+    const int rc = dtype == SZHIP_F32
+        ? pwr_prepare_impl<float>(ctx, data, data_on_device, n, vmin, vmax, pwr_ratio, d_log, signs_host, positive, real_precision, value_range, median, min_log_value)
+        : pwr_prepare_impl<double>(ctx, data, data_on_device, n, vmin, vmax, pwr_ratio, d_log, signs_host, positive, real_precision, value_range, median, min_log_value);
+    if (rc != SZHIP_OK) hipStreamSynchronize(ctx->stream);
+    return rc;
+}
+
+int szhip_compress_sz14_pwr(szhip_ctx *ctx, int dtype, const void *data, int data_on_device, size_t r0, size_t r1, size_t r2, double eb,
+                            double value_range, double median, const szhip_params *params, const unsigned char *meta, size_t meta_len,
+                            const szhip_pwr *pwr, int out_on_device, unsigned char **out, size_t *out_size, szhip_stats *stats)
+{
+    if (!ctx || !data || !params || !meta || !out || !out_size || !pwr || (pwr->signs_blob_size && !pwr->signs_blob)) return SZHIP_ERR_ARG;
+    if ((r0 != 0 && r0 < 2) || (r1 < 2 && !(r0 == 0 && r1 == 0)) || r2 < 2 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff) return SZHIP_ERR_ARG;
+    if (!(eb > 0)) return SZHIP_ERR_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
+    const int rc = dtype == SZHIP_F32
+               ? compress14_impl<float>(ctx, data, data_on_device, r0, r1, r2, eb, value_range, median, params, meta, meta_len, pwr, out_on_device, out, out_size, stats)
+               : compress14_impl<double>(ctx, data, data_on_device, r0, r1, r2, eb, value_range, median, params, meta, meta_len, pwr, out_on_device, out, out_size, stats);
+    if (rc != SZHIP_OK) { hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream); }
+    return rc;
+}
+
+int szhip_sz14_pwr_locate(int dtype, const unsigned char *stream, size_t stream_len, size_t body_off, size_t *blob_off, size_t *blob_size, double *min_log_value)
+{
+    if (!stream || !blob_off || !blob_size || !min_log_value) return SZHIP_ERR_ARG;
+    const size_t es = dtype == SZHIP_F32 ? 4 : 8;
+    const size_t fixed = 4 + 1 + 8 + 4 + 4 + es + 1 + 8 + 8 + 8 + 8 + es;          // ... up to the type array (TightDataPointStorageF.c:133-240)
+    if (body_off + fixed > stream_len) return SZHIP_ERR_STREAM;
+    const unsigned char *q = stream + body_off + 4 + 1 + 8;
+    *blob_size = szhost_get_u32be(q); q += 4 + 4 + es + 1 + 8;
+    const uint64_t type_size = szhost_get_u64be(q); q += 8 + 8 + 8;
+    *min_log_value = dtype == SZHIP_F32 ? (double)szhost_get_f32be(q) : szhost_get_f64be(q);
+    if (type_size > stream_len || *blob_size > stream_len || body_off + fixed + type_size + *blob_size > stream_len) return SZHIP_ERR_STREAM;
+    *blob_off = body_off + fixed + (size_t)type_size;
+    return SZHIP_OK;
+}
+
+int szhip_decompress_sz14_pwr(szhip_ctx *ctx, int dtype, const unsigned char *stream, int stream_on_device, size_t stream_len, size_t body_off,
+                              size_t r0, size_t r1, size_t r2, const unsigned char *signs_host, void *out, int out_on_device, szhip_stats *stats)
+{
+    if (!ctx || !stream || !out || body_off >= stream_len || stream_on_device) return SZHIP_ERR_ARG;        // the header is read on the host
+    if ((r0 != 0 && r0 < 2) || (r1 < 2 && !(r0 == 0 && r1 == 0)) || r2 < 2 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff) return SZHIP_ERR_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
+    size_t bo, bs; double thr;
+    if (szhip_sz14_pwr_locate(dtype, stream, stream_len, body_off, &bo, &bs, &thr) != SZHIP_OK) return SZHIP_ERR_STREAM;
+    const int rc = dtype == SZHIP_F32
+               ? decompress14_pwr_impl<float>(ctx, stream, 0, stream_len, body_off, r0, r1, r2, signs_host, thr, out, out_on_device, stats)
+               : decompress14_pwr_impl<double>(ctx, stream, 0, stream_len, body_off, r0, r1, r2, signs_host, thr, out, out_on_device, stats);
     if (rc != SZHIP_OK) { hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream); }
     return rc;
 }

@@ -1279,3 +1279,4 @@ __global__ __launch_bounds__(256) void k_exact_build(const uint8_t *__restrict__
 
 // ------------------------------------------------------------------ the opt-in fast mode (feedback-free; own container)
 #include "szh_fast.h"
+#include "szh_pwr.h"

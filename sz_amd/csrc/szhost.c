@@ -463,6 +463,9 @@ size_t szhost_write_meta(const szhost_meta *m, unsigned char flags, unsigned cha
     case 1: szhost_put_f32be(r + 10, (float)m->rel_ratio); break;
     case 2: case 3: szhost_put_f32be(r + 6, (float)m->abs_bound); szhost_put_f32be(r + 10, (float)m->rel_ratio); break;
     case 4: szhost_put_f32be(r + 6, (float)m->psnr); memset(r + 9, 0, 4); break;
+    case 11: case 12: szhost_put_f32be(r + 6, (float)m->abs_bound); szhost_put_f32be(r + 10, (float)m->pwr_ratio); break;   /* ABS_AND/OR_PW_REL (ByteToolkit.c:935-939) */
+    case 13: case 14: szhost_put_f32be(r + 6, (float)m->rel_ratio); szhost_put_f32be(r + 10, (float)m->pwr_ratio); break;   /* REL_AND/OR_PW_REL */
+    case 10: szhost_put_f32be(r + 10, (float)m->pwr_ratio); break;                                                          /* PW_REL */
     default: break;
     }
     r[14] = (unsigned char)m->sol_id;

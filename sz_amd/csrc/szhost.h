@@ -77,7 +77,7 @@ void szhost_coeff_unchain(int is_double, void *coef, const unsigned char *indica
 typedef struct szhost_meta {
     int data_type;          /* 0 float, 1 double */
     int err_mode;           /* effective mode written in the params bytes */
-    double abs_bound, rel_ratio, psnr;
+    double abs_bound, rel_ratio, psnr, pwr_ratio;
     double vmin, vmax;
     int opt_quant_mode;     /* exe_params->optQuantMode */
     int data_endian, sz_mode, gzip_mode;

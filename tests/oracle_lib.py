@@ -8,6 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _SO = os.path.join(ROOT, "oracle", "liboracle.so")
 
 ABS, REL, ABS_AND_REL, ABS_OR_REL, PSNR, NORM = 0, 1, 2, 3, 4, 5
+PW_REL, ABS_AND_PW_REL, ABS_OR_PW_REL, REL_AND_PW_REL, REL_OR_PW_REL = 10, 11, 12, 13, 14
 SZ_FLOAT, SZ_DOUBLE = 0, 1
 
 
@@ -16,7 +17,8 @@ class Params(ctypes.Structure):
                 ("max_quant_intervals", ctypes.c_uint), ("quantization_intervals", ctypes.c_uint),
                 ("with_regression", ctypes.c_int), ("sz_mode", ctypes.c_int), ("gzip_mode", ctypes.c_int),
                 ("protect_value_range", ctypes.c_int), ("data_endian", ctypes.c_int), ("sol_id", ctypes.c_int),
-                ("psnr", ctypes.c_double), ("norm_err", ctypes.c_double), ("conf_rel_bound_ratio", ctypes.c_double)]
+                ("psnr", ctypes.c_double), ("norm_err", ctypes.c_double), ("conf_rel_bound_ratio", ctypes.c_double),
+                ("pw_rel_bound_ratio", ctypes.c_double), ("segment_size", ctypes.c_int)]
 
 
 class Stages(ctypes.Structure):

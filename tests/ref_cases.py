@@ -13,6 +13,7 @@ from sz_amd.fields import l_field, m_field, plane_field, reg_beside_lorenzo, s_f
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ABS, REL, ABS_AND_REL, ABS_OR_REL, PSNR, NORM, PW_REL = 0, 1, 2, 3, 4, 5, 10
+ABS_AND_PW_REL, ABS_OR_PW_REL, REL_AND_PW_REL, REL_OR_PW_REL = 11, 12, 13, 14
 
 BASE_CONF = {   # tests/golden/sz_speed.config
     "withLinearRegression": "YES", "protectValueRange": "NO", "sampleDistance": 100, "quantization_intervals": 0,
@@ -152,6 +153,19 @@ CASES = [
     case("pwr-pos-1D-f64", lambda: _pos((20000,), f64), mode=PW_REL, pwr=1e-3),
     case("pwr-negative-3D-f32", lambda: -_pos((16, 20, 24), f32, 17), mode=PW_REL, pwr=1e-2),
     case("pwr-noaccel-3D-f32", lambda: _pos((20, 24, 28), f32), mode=PW_REL, pwr=1e-2, accelerate_pw_rel_compression=0),
+    # the log-domain form (accelerate_pw_rel_compression = 0, or a ratio below 1e-5: sz_float.c:2837-2838) -- the one the MI355X build writes
+    case("pwrlog-pos-3D-f64", lambda: _pos((20, 24, 28), f64), mode=PW_REL, pwr=1e-3, accelerate_pw_rel_compression=0),
+    case("pwrlog-signed-zeros-3D-f32", lambda: _signed_with_zeros((20, 24, 28), f32), mode=PW_REL, pwr=1e-2, accelerate_pw_rel_compression=0),
+    case("pwrlog-signed-zeros-3D-f64", lambda: _signed_with_zeros((18, 20, 22), f64), mode=PW_REL, pwr=1e-2, accelerate_pw_rel_compression=0),
+    case("pwrlog-pos-2D-f32", lambda: _pos((60, 72), f32), mode=PW_REL, pwr=1e-2, accelerate_pw_rel_compression=0),
+    case("pwrlog-signed-2D-f64", lambda: _signed_with_zeros((50, 64), f64), mode=PW_REL, pwr=1e-3, accelerate_pw_rel_compression=0),
+    case("pwrlog-pos-1D-f32", lambda: _pos((20000,), f32), mode=PW_REL, pwr=1e-2, accelerate_pw_rel_compression=0),
+    case("pwrlog-pos-1D-f64", lambda: _pos((20000,), f64), mode=PW_REL, pwr=1e-3, accelerate_pw_rel_compression=0),
+    case("pwrlog-negative-3D-f32", lambda: -_pos((16, 20, 24), f32, 17), mode=PW_REL, pwr=1e-2, accelerate_pw_rel_compression=0),
+    case("pwrlog-tight-3D-f32", lambda: _pos((20, 24, 28), f32), mode=PW_REL, pwr=5e-6),
+    case("pwrlog-abs-and-pwr-3D-f32", lambda: _pos((20, 24, 28), f32), mode=ABS_AND_PW_REL, abs=1e-3, pwr=1e-2, accelerate_pw_rel_compression=0,
+         pw_relBoundRatio=1e-2),
+    case("pwrlog-4D-f32", lambda: _pos((3, 20, 24), f32).reshape(3, 4, 5, 24), mode=PW_REL, pwr=1e-2, accelerate_pw_rel_compression=0),
     # ---- lossless back end (utility.c:156-214): the wrapped bytes depend on the zstd/zlib build, the decoded values do not
     case("C1-zstd", lambda: _c1(f32), szMode="SZ_BEST_COMPRESSION"),
     case("C1-gzip", lambda: _c1(f32), szMode="SZ_BEST_COMPRESSION", losslessCompressor="GZIP_COMPRESSOR"),
