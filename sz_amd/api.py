@@ -55,7 +55,7 @@ class szhip_stats(ctypes.Structure):  # include/szhip.h
 
 class szhost_meta(ctypes.Structure):  # sz_amd/csrc/szhost.h
     _fields_ = [("data_type", ctypes.c_int), ("err_mode", ctypes.c_int), ("abs_bound", ctypes.c_double),
-                ("rel_ratio", ctypes.c_double), ("psnr", ctypes.c_double), ("vmin", ctypes.c_double),
+                ("rel_ratio", ctypes.c_double), ("psnr", ctypes.c_double), ("pwr_ratio", ctypes.c_double), ("vmin", ctypes.c_double),
                 ("vmax", ctypes.c_double), ("opt_quant_mode", ctypes.c_int), ("data_endian", ctypes.c_int),
                 ("sz_mode", ctypes.c_int), ("gzip_mode", ctypes.c_int), ("sample_distance", ctypes.c_int),
                 ("pred_threshold", ctypes.c_float), ("sol_id", ctypes.c_int), ("max_quant_intervals", ctypes.c_uint),

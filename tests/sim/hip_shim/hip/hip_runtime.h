@@ -31,8 +31,10 @@ struct uint2 { unsigned x, y; };
 
 namespace hipsim {
 struct TIdx { unsigned x, y, z; };
-extern thread_local TIdx t_threadIdx;
-extern dim3 g_blockIdx, g_blockDim, g_gridDim;
+extern TIdx t_threadIdx;
+extern dim3 t_blockIdx;
+void fiber_yield();
+extern dim3 g_blockDim, g_gridDim;
 extern char *g_dyn_smem;
 void sync_block();
 void wave_exchange(const void *src, void *dst_all, size_t elem); // every lane of the calling thread's wave contributes one element
@@ -40,7 +42,7 @@ int lanes_in_wave();
 void launch(const std::function<void()> &body, dim3 grid, dim3 block, size_t shmem);
 }
 #define threadIdx hipsim::t_threadIdx
-#define blockIdx hipsim::g_blockIdx
+#define blockIdx hipsim::t_blockIdx
 #define blockDim hipsim::g_blockDim
 #define gridDim hipsim::g_gridDim
 inline char *hipsim_dyn_smem() { return hipsim::g_dyn_smem; }
@@ -81,7 +83,7 @@ inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 inline long long __double_as_longlong(double d) { long long u; memcpy(&u, &d, 8); return u; }
-inline void __builtin_amdgcn_s_sleep(int) { sched_yield(); } // waiting "wavefronts" are OS threads here
+inline void __builtin_amdgcn_s_sleep(int) { hipsim::fiber_yield(); } // a waiting lane hands the processor to the next fibre
 inline unsigned long long wall_clock64() { return 0; }
 inline int min(int a, int b) { return a < b ? a : b; }
 

@@ -1,54 +1,68 @@
 // hipsim.cpp -- TEST INFRASTRUCTURE ONLY: thread-pool execution engine of the HIP-on-CPU shim
 // (tests/sim/hip_shim/hip/hip_runtime.h), plus the product's szhip.hip compiled against it.
 #include <hip/hip_runtime.h>
-#include <condition_variable>
-#include <mutex>
-#include <thread>
+#include <sys/mman.h>
+#include <ucontext.h>
 #include <vector>
 
+// Execution model: the lanes of ONE workgroup are fibres (ucontext) of the calling thread, switched round-robin at every barrier,
+// wavefront exchange and s_sleep (the kernels' spin-waits all nap through s_sleep, so a waiting "wavefront" hands the processor on).
+// Workgroups run one after the other in launch order.  (The first engine gave every lane an OS thread: a 704-lane workgroup of
+// k_pencil spinning on 8 cores spent its time in the kernel's scheduler -- 35 s for an 8 x 8 x 128 array.)
 namespace hipsim {
-thread_local TIdx t_threadIdx;
-dim3 g_blockIdx, g_blockDim, g_gridDim;
+TIdx t_threadIdx;
+dim3 t_blockIdx;
+dim3 g_blockDim, g_gridDim;
 char *g_dyn_smem = nullptr;
 
 namespace {
+constexpr int MAXT = 1024;
+constexpr size_t STACK = 256 << 10;
+struct Fiber { ucontext_t ctx; char *stack = nullptr; bool done = true; };
+Fiber g_f[MAXT];
+ucontext_t g_main;
+int g_cur = 0, g_nthreads = 0, g_live = 0;
+const std::function<void()> *g_body = nullptr;
+alignas(16) unsigned char g_xbuf[MAXT / 64][64][16];
+
+inline void enter(int f) { g_cur = f; t_threadIdx = TIdx{(unsigned)f, 0, 0}; }
+int next_runnable(int me)
+{
+    for (int k = 1; k <= g_nthreads; ++k) { const int f = (me + k) % g_nthreads; if (!g_f[f].done) return f; }
+    return -1;
+}
+void yield()
+{
+    const int me = g_cur, nx = next_runnable(me);
+    if (nx < 0 || nx == me) return;
+    enter(nx);
+    swapcontext(&g_f[me].ctx, &g_f[nx].ctx);
+}
+void fiber_main()
+{
+    (*g_body)();
+    const int me = g_cur;
+    g_f[me].done = true;
+    --g_live;
+    const int nx = next_runnable(me);
+    if (nx < 0) { swapcontext(&g_f[me].ctx, &g_main); return; }
+    enter(nx);
+    swapcontext(&g_f[me].ctx, &g_f[nx].ctx);
+}
 struct Barrier {
-    std::mutex m; std::condition_variable cv; int count = 0, waiting = 0; unsigned gen = 0;
+    int count = 0, waiting = 0; unsigned gen = 0;
     void reset(int n) { count = n; waiting = 0; }
     void wait()
     {
-        std::unique_lock<std::mutex> lk(m);
-        unsigned g = gen;
-        if (++waiting == count) { waiting = 0; ++gen; cv.notify_all(); }
-        else cv.wait(lk, [&] { return gen != g; });
+        const unsigned g = gen;
+        if (++waiting == count) { waiting = 0; ++gen; }
+        else while (gen == g) yield();
     }
 };
-constexpr int MAXT = 1024;
-Barrier g_block_bar, g_wave_bar[MAXT / 64], g_start, g_done;
-alignas(16) unsigned char g_xbuf[MAXT / 64][64][16];
-int g_nthreads = 0;
-const std::function<void()> *g_body = nullptr;
-std::vector<std::thread> g_pool;
-bool g_quit = false;
-
-void worker(int tid)
-{
-    for (;;) {
-        g_start.wait();
-        if (g_quit) return;
-        if (tid < g_nthreads) { t_threadIdx = TIdx{(unsigned)tid, 0, 0}; (*g_body)(); }
-        g_done.wait();
-    }
-}
-void ensure_pool()
-{
-    if (!g_pool.empty()) return;
-    g_start.reset(MAXT + 1); g_done.reset(MAXT + 1);
-    for (int t = 0; t < MAXT; ++t) g_pool.emplace_back(worker, t);
-    atexit([] { g_quit = true; g_start.wait(); for (auto &t : g_pool) t.join(); });
-}
+Barrier g_block_bar, g_wave_bar[MAXT / 64];
 } // namespace
 
+void fiber_yield() { yield(); }
 int lanes_in_wave()
 {
     const int w = t_threadIdx.x >> 6;
@@ -66,20 +80,35 @@ void wave_exchange(const void *src, void *dst_all, size_t elem)
 }
 void launch(const std::function<void()> &body, dim3 grid, dim3 block, size_t shmem)
 {
-    ensure_pool();
     if ((int)block.x > MAXT || block.y != 1 || block.z != 1) { fprintf(stderr, "hipsim: unsupported block shape\n"); abort(); }
+    if (grid.x == 0 || grid.y == 0 || block.x == 0) return;
+    if (g_nthreads != 0) { fprintf(stderr, "hipsim: nested or concurrent launch\n"); abort(); }
     std::vector<char> smem(shmem + 64);
     g_dyn_smem = (char *)(((uintptr_t)smem.data() + 15) & ~(uintptr_t)15);
     g_nthreads = (int)block.x; g_blockDim = block; g_gridDim = grid; g_body = &body;
-    g_block_bar.reset(g_nthreads);
-    for (int w = 0; w < MAXT / 64; ++w) { int rem = g_nthreads - w * 64; g_wave_bar[w].reset(rem < 0 ? 0 : (rem < 64 ? rem : 64)); }
+    for (int f = 0; f < g_nthreads; ++f)
+        if (!g_f[f].stack) {
+            g_f[f].stack = (char *)mmap(nullptr, STACK, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+            if (g_f[f].stack == MAP_FAILED) { fprintf(stderr, "hipsim: cannot map a fibre stack\n"); abort(); }
+        }
     for (unsigned by = 0; by < grid.y; ++by)
         for (unsigned bx = 0; bx < grid.x; ++bx) {
-            g_blockIdx = dim3(bx, by, 0);
-            memset(g_dyn_smem, 0xCD, shmem); // poison dynamic LDS per workgroup
-            g_start.wait();
-            g_done.wait();
+            t_blockIdx = dim3(bx, by, 0);
+            memset(g_dyn_smem, 0xCD, shmem);                     // poison dynamic LDS per workgroup
+            g_block_bar.reset(g_nthreads);
+            for (int w = 0; w < MAXT / 64; ++w) { int rem = g_nthreads - w * 64; g_wave_bar[w].reset(rem < 0 ? 0 : (rem < 64 ? rem : 64)); }
+            for (int f = 0; f < g_nthreads; ++f) {
+                getcontext(&g_f[f].ctx);
+                g_f[f].ctx.uc_stack.ss_sp = g_f[f].stack; g_f[f].ctx.uc_stack.ss_size = STACK; g_f[f].ctx.uc_link = nullptr;
+                makecontext(&g_f[f].ctx, fiber_main, 0);
+                g_f[f].done = false;
+            }
+            g_live = g_nthreads;
+            enter(0);
+            swapcontext(&g_main, &g_f[0].ctx);
+            if (g_live != 0) { fprintf(stderr, "hipsim: workgroup left %d lanes behind\n", g_live); abort(); }
         }
+    g_nthreads = 0;
 }
 } // namespace hipsim
 
