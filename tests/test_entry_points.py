@@ -1,0 +1,114 @@
+"""The other entry points of the reference's C API (sz/include/sz.h:276-334, sz/src/sz.c:399-481, :579-681, :1083-1201) on the product
+library, called the way a C caller does -- raw ctypes on the shared object, no Python convenience layer in between:
+SZ_compress (bounds from sz.config), SZ_compress_args2 and SZ_decompress_args (caller-owned buffers), SZ_getMetadata,
+SZ_compress_customize / SZ_decompress_customize and their _threadsafe forms.  Expected streams come from the oracle.
+GPU: libszhip.so; without a GPU the same calls run on the product code compiled against the CPU shim."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from sz_amd.fields import s_field
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SZ_FLOAT, SZ_DOUBLE, ABS, REL = 0, 1, 0, 1
+SZ_SCES, SZ_NSCS = 0, -1
+
+
+class sz_metadata(ctypes.Structure):
+    _fields_ = [("versionNumber", ctypes.c_int * 3), ("isConstant", ctypes.c_int), ("isLossless", ctypes.c_int), ("sizeType", ctypes.c_int),
+                ("dataSeriesLength", ctypes.c_size_t), ("defactoNBBins", ctypes.c_int), ("conf_params", ctypes.c_void_p)]
+
+
+def _exercise(L, oracle):
+    from sz_amd.api import sz_params
+    sz = ctypes.c_size_t
+    vp = ctypes.c_void_p
+    L.SZ_Init.argtypes = [ctypes.c_char_p]
+    L.SZ_compress.restype = vp
+    L.SZ_compress.argtypes = [ctypes.c_int, vp, ctypes.POINTER(sz)] + [sz] * 5
+    L.SZ_compress_args2.restype = ctypes.c_int
+    L.SZ_compress_args2.argtypes = [ctypes.c_int, vp, vp, ctypes.POINTER(sz), ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double] + [sz] * 5
+    L.SZ_decompress_args.restype = sz
+    L.SZ_decompress_args.argtypes = [ctypes.c_int, vp, sz, vp] + [sz] * 5
+    L.SZ_getMetadata.restype = ctypes.POINTER(sz_metadata)
+    L.SZ_getMetadata.argtypes = [vp]
+    for name in ("SZ_compress_customize", "SZ_compress_customize_threadsafe"):
+        f = getattr(L, name); f.restype = vp
+        f.argtypes = [ctypes.c_char_p, vp, ctypes.c_int, vp] + [sz] * 5 + [ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_int)]
+    for name in ("SZ_decompress_customize", "SZ_decompress_customize_threadsafe"):
+        f = getattr(L, name); f.restype = vp
+        f.argtypes = [ctypes.c_char_p, vp, ctypes.c_int, vp, sz] + [sz] * 5 + [ctypes.POINTER(ctypes.c_int)]
+    L.free.argtypes = [vp]
+
+    def take(p, n):
+        b = ctypes.string_at(p, n); L.free(p); return b
+
+    assert L.SZ_Init(os.path.join(ROOT, "tests", "golden", "sz_speed.config").encode()) == 0
+    d = s_field(12, 16, 20)                                       # r3 = 12, r2 = 16, r1 = 20
+    dims = (0, 0, 12, 16, 20)
+    ref_cfg, _ = oracle.compress(d, oracle.ABS, 1e-4)            # what sz_speed.config asks for
+    ref_3, _ = oracle.compress(d, oracle.ABS, 1e-3)
+    dec_3 = oracle.decompress(ref_3, d.shape, d.dtype)
+
+    # SZ_compress: everything from the configuration (sz.c:399-405)
+    n = sz(0)
+    assert take(L.SZ_compress(SZ_FLOAT, d.ctypes.data, ctypes.byref(n), *dims), n.value) == ref_cfg
+    # SZ_compress_args2 into the caller's buffer (sz.c:407-417)
+    buf = ctypes.create_string_buffer(d.nbytes + 1024)
+    n = sz(0)
+    assert L.SZ_compress_args2(SZ_FLOAT, d.ctypes.data, buf, ctypes.byref(n), ABS, 1e-3, 0.0, 0.0, *dims) == SZ_SCES
+    assert buf.raw[:n.value] == ref_3
+    # SZ_decompress_args into the caller's array (sz.c:579-591)
+    out = np.empty_like(d)
+    sbuf = ctypes.create_string_buffer(ref_3, len(ref_3))
+    assert L.SZ_decompress_args(SZ_FLOAT, sbuf, len(ref_3), out.ctypes.data, *dims) == d.size
+    assert np.array_equal(out.view(np.uint32), dec_3.view(np.uint32))
+    # SZ_getMetadata (sz.c:683-760)
+    md = L.SZ_getMetadata(sbuf).contents
+    assert list(md.versionNumber) == [2, 1, 12] and md.isConstant == 0 and md.isLossless == 0 and md.sizeType == 8
+    assert md.dataSeriesLength == d.size and md.defactoNBBins > 0
+    # SZ_compress_customize: "SZ2.1" with no parameters = SZ_compress; an unknown name is refused (sz.c:1083-1148).
+    # The configuration is global state: the SZ_compress_args2 call above left its derived bound in confparams_cpr->absErrBound
+    # (sz_float.c:2867), so SZ_compress now compresses with 1e-3 -- in the reference and here.
+    n = sz(0); st = ctypes.c_int(7)
+    p = L.SZ_compress_customize(b"SZ2.1", None, SZ_FLOAT, d.ctypes.data, *dims, ctypes.byref(n), ctypes.byref(st))
+    assert st.value == SZ_SCES and take(p, n.value) == ref_3
+    st = ctypes.c_int(7)
+    assert not L.SZ_compress_customize(b"no-such-compressor", None, SZ_FLOAT, d.ctypes.data, *dims, ctypes.byref(n), ctypes.byref(st)) and st.value == SZ_NSCS
+    # ... _threadsafe: bounds from the parameter block, the global configuration stays as it is (sz.c:1150-1178)
+    par = sz_params()
+    par.errorBoundMode = ABS; par.absErrBound = 1e-3; par.relBoundRatio = 0; par.pw_relBoundRatio = 0
+    n = sz(0); st = ctypes.c_int(7)
+    p = L.SZ_compress_customize_threadsafe(b"SZ2.1", ctypes.byref(par), SZ_FLOAT, d.ctypes.data, *dims, ctypes.byref(n), ctypes.byref(st))
+    assert st.value == SZ_SCES and take(p, n.value) == ref_3
+    # SZ_decompress_customize and _threadsafe (sz.c:1180-1201)
+    for name in ("SZ_decompress_customize", "SZ_decompress_customize_threadsafe"):
+        st = ctypes.c_int(7)
+        q = getattr(L, name)(b"SZ2.1", None, SZ_FLOAT, sbuf, len(ref_3), *dims, ctypes.byref(st))
+        assert st.value == SZ_SCES and q
+        got = np.frombuffer(ctypes.string_at(q, d.nbytes), dtype=np.float32).reshape(d.shape); L.free(q)
+        assert np.array_equal(got.view(np.uint32), dec_3.view(np.uint32))
+    # a double array through the caller-buffer pair, REL bound
+    d64 = s_field(10, 12, 14, np.float64)
+    r64, _ = oracle.compress(d64, oracle.REL, 0.0, 1e-3)
+    buf = ctypes.create_string_buffer(d64.nbytes + 1024); n = sz(0)
+    assert L.SZ_compress_args2(SZ_DOUBLE, d64.ctypes.data, buf, ctypes.byref(n), REL, 0.0, 1e-3, 0.0, 0, 0, 10, 12, 14) == SZ_SCES
+    assert buf.raw[:n.value] == r64
+    out64 = np.empty_like(d64)
+    assert L.SZ_decompress_args(SZ_DOUBLE, buf, n.value, out64.ctypes.data, 0, 0, 10, 12, 14) == d64.size
+    assert np.array_equal(out64.view(np.uint64), oracle.decompress(r64, d64.shape, d64.dtype).view(np.uint64))
+    L.SZ_Finalize()
+
+
+@pytest.mark.gpu
+def test_c_api_entry_points_on_the_gpu(built, oracle):
+    import sz_amd
+    _exercise(ctypes.CDLL(sz_amd.api.lib_path()), oracle)
+
+
+@pytest.mark.slow
+def test_c_api_entry_points_on_the_cpu_shim(built, oracle):
+    import sim_lib
+    _exercise(ctypes.CDLL(sim_lib.shim_path()), oracle)

@@ -529,3 +529,16 @@ def test_config1_through_a_plain_c_caller(built, anchors, tmp_path):
     assert len(stream) == a["stream_bytes"] and hashlib.md5(stream).hexdigest() == a["md5"]
     out = subprocess.check_output([cli, "-x", "-f", "-s", str(dat) + ".sz", "-i", str(dat), "-3", "8", "8", "128", "-a"]).decode()
     assert f"PSNR = {a['psnr']:.6f}" in out and "Max absolute error = 0.0000999272" in out
+    # the rest of the option surface (example/sz.c:30-88): -p, output names after -z / -x, -t text output, -M PW_REL -P, -v
+    meta = subprocess.check_output([cli, "-p", "-s", str(dat) + ".sz"]).decode()
+    assert "2.1.12" in meta and "Num of elements:" in meta and "8192" in meta and "ABS" in meta and "FLOAT" in meta
+    named = tmp_path / "named.sz"
+    subprocess.check_call([cli, "-z", str(named), "-f", "-c", cfg, "-M", "PW_REL", "-P", "1e-2", "-i", str(dat), "-3", "8", "8", "128"])
+    assert named.exists() and open(named, "rb").read()[3] & 0x20
+    txt = tmp_path / "dec.txt"
+    subprocess.check_call([cli, "-x", str(txt), "-f", "-s", str(named), "-3", "8", "8", "128", "-t"])
+    vals = np.array([float(v) for v in open(txt).read().split()], dtype=np.float64)
+    ori = np.fromfile(dat, dtype=np.float32).astype(np.float64)
+    nz = ori != 0
+    assert vals.size == ori.size and float((np.abs(vals[nz] - ori[nz]) / np.abs(ori[nz])).max()) <= 1e-2
+    assert "2.1.12" in subprocess.check_output([cli, "-v"]).decode()
