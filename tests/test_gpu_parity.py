@@ -125,9 +125,11 @@ def test_unsupported_calls_fail_loudly(sz):
     with pytest.raises(sz_amd.SZError):
         sz.SZ_compress_args(np.random.default_rng(0).random((3, 4, 5, 6, 7), dtype=np.float32), sz.ABS, 1e-3)    # 5-D: the reference refuses too
     with pytest.raises(sz_amd.SZError):
-        sz.SZ_compress_args(np.random.default_rng(0).random((8, 9, 10), dtype=np.float32), sz.PW_REL, 0, 0, 1e-3)
+        sz.SZ_compress_args(np.random.default_rng(0).random((8, 9, 10), dtype=np.float32), sz.PW_REL, 0, 0, 0.0)       # a point-wise ratio of 0
     with pytest.raises(sz_amd.SZError):
         sz.SZ_decompress(b"\x02\x01\x0c\xc0" + b"\x00" * 60, (8, 9, 10), np.float32)
+    with pytest.raises(sz_amd.SZError):                                                                             # an MSST19 point-wise-relative stream
+        sz.SZ_decompress(b"\x02\x01\x0c\x68" + b"\x00" * 200, (8, 9, 10), np.float32)
 
 
 def _series(n, dtype, seed):

@@ -279,7 +279,11 @@ def test_hip_pw_rel_bound_at_size(built):
             x, y = d.astype(np.float64), back.astype(np.float64)
             nz = x != 0
             assert float((np.abs(y[nz] - x[nz]) / np.abs(x[nz])).max()) <= ratio
-            assert np.all(y[~nz] == 0) and np.array_equal(np.signbit(back[nz]), np.signbit(d[nz]))
+            # a zero comes back as 0 -- or, when its placeholder lands within a float ulp of the threshold, as a value below every
+            # nonzero magnitude of the array: the reference's own behaviour (the oracle gives 12 such values of 62 965 zeros on this
+            # array at ratio 1e-2; the 0.0001 * realPrecision margin of sz_float_pwr.c:1950-1955 is smaller than a float ulp of the logs)
+            assert np.all(np.abs(y[~nz]) < np.abs(x[nz]).min()) and int((y[~nz] != 0).sum()) <= 64
+            assert np.array_equal(np.signbit(back[nz]), np.signbit(d[nz]))
             assert len(s) < d.nbytes
     finally:
         sz_amd.SZ_Finalize()
