@@ -318,7 +318,7 @@ unsigned char *szo_compress_args(const szo_params *p, int data_type, const void 
          * its own (sz_float.c:2908, sz_double.c:2624) */
         strict_raw_rule = dim != 1;
     } else if (dim == 2 && p->with_regression) {
-        /* SZ 2.1 (2D), sz_float.c:2940-2944 -- parity unpinned, see szo_sz21_impl.h */
+        /* SZ 2.1 (2D), sz_float.c:2940-2944; pinned by the recorded 2D-* cases, see szo_sz21_impl.h */
         meta[3] = 0x80 | 0x40 | (p->protect_value_range ? 0x04 : 0);
         if (data_type == SZO_FLOAT)
             out = szo_sz21_compress_2d_f32(p, meta, 4 + meta_len, (const float *)data, r2, r1, (float)eb, &osz, stages);

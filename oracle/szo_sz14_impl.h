@@ -21,8 +21,8 @@
  *
  * Pinning: the 3-D path is pinned to a recorded output of the unmodified reference (tests/test_oracle_pins.py).  The 2-D path
  * (r1 == 1) and the 1-D path (r1 == r2 == 1: SZ_compress_float_1D_MDQ, sz_float.c:353-540, its optimiser :5070-5111, inverse
- * szd_float.c:185-282; doubles sz_double.c:260-400, :4747) share the pinned container and exact-value code but have no recorded
- * reference output of their own: PARITY UNPINNED for 2-D and 1-D.
+ * szd_float.c:185-282; doubles sz_double.c:260-400, :4747) share the pinned container and exact-value code; since round 2 they are pinned
+ * by recorded outputs of the unmodified reference of their own (2-D and 1-D cases of tests/golden/ref_recorded.json).
  */
 
 #ifndef SZO_CAT
@@ -114,7 +114,7 @@ static unsigned FN(szo_optimize_intervals_2d_opt)(const szo_params *p, const T *
 }
 
 /* 1-D optimiser (optimize_intervals_float_1D_opt, sz_float.c:5070-5111 / sz_double.c:4747): previous-value predictor at
- * positions 2, 2+sampleDistance, ...  1-D is PARITY UNPINNED (no recorded reference output of a 1-D array). */
+ * positions 2, 2+sampleDistance, ...  Pinned by the recorded 1-D cases of tests/golden/ref_recorded.json. */
 static unsigned FN(szo_optimize_intervals_1d_opt)(const szo_params *p, const T *data, size_t len, double ebD)
 {
     unsigned maxRangeRadius = p->max_quant_intervals / 2;
@@ -216,8 +216,8 @@ static inline int FN(szo_sz14_point)(FN(szo_exact) *E, T x, T pred, T eb, T reci
 
 /* r1 slowest ... r3 fastest (callee convention of sz_float.c:946).  `meta` = version bytes, flag byte and parameter bytes.
  * r1 == 1 is the 2-D compressor SZ_compress_float_2D_MDQ (sz_float.c:610-894; inverse szd_float.c:284-598): its predictors are
- * exactly those of layer 0 below (:686, :727, :772, :814); only its optimiser walks another lattice.  2-D is PARITY UNPINNED
- * (no recorded reference output of a 2-D array). */
+ * exactly those of layer 0 below (:686, :727, :772, :814); only its optimiser walks another lattice.  Pinned by the recorded
+ * `sz14-2D-*` cases of tests/golden/ref_recorded.json. */
 static unsigned char *FN(szo_sz14_compress_3d)(const szo_params *p, const unsigned char *meta, size_t meta_len,
                                                const T *data, size_t r1, size_t r2, size_t r3, T eb, T range, T median_in,
                                                size_t *out_size, szo_stages *st, const szo_pwr_extra *pw)
@@ -240,7 +240,7 @@ static unsigned char *FN(szo_sz14_compress_3d)(const szo_params *p, const unsign
     if (r1 == 1 && r2 == 1) {
         /* the 1-D compressor SZ_compress_float_1D_MDQ (sz_float.c:353-540) / SZ_compress_double_1D_MDQ (sz_double.c:260-400): the
          * first two values exact, then the previous reconstruction as predictor; its own quantiser (a radius test, the state
-         * from a truncation and a shift); only the float version re-checks the bound.  PARITY UNPINNED. */
+         * from a truncation and a shift); only the float version re-checks the bound.  Pinned by the recorded `1D-*` cases. */
         const T check_radius = (T)((intervals - 1) * eb), interval = 2 * eb;
         type[0] = 0; (void)FN(szo_exact_add)(&E, data[0]);
         type[1] = 0;

@@ -11,8 +11,8 @@
  *
  * 2-D (block size 16, three coefficients): sz_float.c:5405-5515 (optimiser), :5516-6395 (compressor; the reference forces
  * use_mean = 0 at :5615, so only its "else" branch :5984-6282 is live), szd_float.c:3141-3482; sz_double.c:4790-4899, :4900-5757,
- * szd_double.c:2974.  PARITY UNPINNED: no output of the reference for a 2-D array is recorded in SURVEY.md / BASELINE.md and the
- * reference cannot be built here, so the 2-D restatement is checked only against itself (round trips) -- see DESIGN.md.
+ * szd_double.c:2974.  Pinned since round 2 by the recorded `2D-*` outputs of the unmodified reference (tests/golden/ref_recorded.json,
+ * tests/test_ref_recorded.py); see DESIGN.md section 2.
  */
 
 #ifndef SZO_CAT

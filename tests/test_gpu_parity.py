@@ -47,7 +47,7 @@ def _fields():
         "4d": (s_field(12, 20, 24).reshape(3, 4, 20, 24), 0, 1e-4, 0.0),
         "reg-beside-lorenzo": (reg_beside_lorenzo(24, 40, 32), 0, 1e-4, 0.0),
         "reg-beside-lorenzo-f64": (reg_beside_lorenzo(48, 56, 64, np.float64), 0, 1e-4, 0.0),
-        # 2-D (16-wide blocks, three-coefficient planes; the oracle's 2-D restatement is unpinned, see tests/test_two_d.py)
+        # 2-D (16-wide blocks, three-coefficient planes; the oracle's 2-D restatement is pinned by tests/test_ref_recorded.py)
         "2d-plane": (plane_field(200, 300), 0, 1e-4, 0.0),
         "2d-ragged": (plane_field(37, 45), 0, 1e-3, 0.0),
         "2d-wide": (plane_field(2, 500), 0, 1e-3, 0.0),
@@ -149,8 +149,8 @@ def _series(n, dtype, seed):
 def test_1d_stream_and_decode_identical_to_oracle(sz, oracle, dtype, n, eb, mode):
     """1-D arrays (SZ_compress_float_1D_MDQ, sz_float.c:353; decompressDataSeries_float_1D, szd_float.c:185): the chain through
     the previous reconstructed value, walked by one wavefront.  The stream must match byte for byte, with and without the
-    regression switch (a 1-D array ignores it), and decode bit for bit.  (1-D is parity-unpinned: the oracle restates the
-    reference's code; no recorded reference output of a 1-D array exists.)"""
+    regression switch (a 1-D array ignores it), and decode bit for bit.  (The 1-D restatement itself is pinned by the recorded
+    1D-* reference outputs, tests/test_ref_recorded.py.)"""
     d = _series(n, dtype, seed=n)
     ref, _ = oracle.compress(d, mode, eb, eb)
     got = sz.SZ_compress_args(d, mode, eb, eb)
@@ -351,7 +351,7 @@ def _sz14_fields():
         "S-f64-rel": (s_field(32, 64, 64, np.float64), 1, 0.0, 1e-3),
         "abs-and-rel": (s_field(24, 32, 40), 2, 1e-3, 1e-4),
         "S128": (s_field(128, 128, 128), 0, 1e-4, 0.0),
-        # 2-D arrays on the SZ 1.4 path (sz_float.c:610; the oracle's 2-D lattice is unpinned)
+        # 2-D arrays on the SZ 1.4 path (sz_float.c:610; pinned by the recorded sz14-2D cases)
         "2d-plane": (plane_field(200, 300), 0, 1e-4, 0.0),
         "2d-ragged-f64": (plane_field(37, 45, np.float64), 0, 1e-5, 0.0),
         "2d-wide": (plane_field(2, 500), 0, 1e-3, 0.0),

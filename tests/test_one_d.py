@@ -1,7 +1,7 @@
 """1-D arrays (SZ_compress_float_1D_MDQ, sz/src/sz_float.c:353-540; SZ_compress_double_1D_MDQ, sz/src/sz_double.c:260-400;
-decompressDataSeries_float_1D, sz/src/szd_float.c:185-282): CPU-side checks of the oracle's restatement.  PARITY UNPINNED: no
-recorded output of the reference for a 1-D array exists, so these tests hold the restatement against a second, independent
-statement of the same chain written with numpy scalars, and against its own decoder.  The GPU runs are in test_gpu_parity.py."""
+decompressDataSeries_float_1D, sz/src/szd_float.c:185-282): CPU-side checks of the oracle's restatement.  Its pin is tests/test_ref_recorded.py (recorded
+1-D outputs of the unmodified reference, round 2); these tests add a second, independent statement of the same chain written with
+numpy scalars, and the restatement's own decoder.  The GPU runs are in test_gpu_parity.py."""
 import numpy as np
 import pytest
 

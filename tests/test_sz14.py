@@ -57,8 +57,8 @@ def test_oracle_sz14_round_trip_and_container(oracle, shape, dtype, eb):
 
 @pytest.mark.parametrize("shape,dtype,eb", [((200, 300), np.float32, 1e-4), ((37, 45), np.float64, 1e-5), ((2, 500), np.float32, 1e-3)])
 def test_oracle_sz14_2d_round_trip(oracle, shape, dtype, eb):
-    """2-D arrays on the SZ 1.4 path (SZ_compress_float_2D_MDQ, sz_float.c:610): PARITY UNPINNED (no recorded reference output);
-    the restatement shares everything but the optimiser's lattice with the pinned 3-D one."""
+    """2-D arrays on the SZ 1.4 path (SZ_compress_float_2D_MDQ, sz_float.c:610): pinned by the recorded sz14-2D-* cases (tests/test_ref_recorded.py);
+    the restatement shares everything but the optimiser's lattice with the 3-D one."""
     d = plane_field(*shape, dtype)
     stream, st = oracle.compress(d, oracle.ABS, eb, params=oracle.default_params(with_regression=0), want_stages=True)
     dec = oracle.decompress(stream, shape, dtype)
@@ -81,8 +81,8 @@ def test_sz14_hip_layer_on_cpu_shim(oracle):
         spike = s_field(16, 16, 16); spike[3, 4, 5] = 1e4; spike[:, :2, :] = 0
         cases = (("smooth", s_field(10, 12, 40), 1e-4), ("noisy", _noisy((9, 17, 33), np.float32, 3e-4), 1e-5),
                  ("noisy-f64", _noisy((12, 10, 24), np.float64, 3e-4), 1e-6), ("spike", spike, 1e-3),
-                 ("2d", plane_field(40, 70), 1e-4), ("2d-f64", plane_field(33, 40, np.float64), 1e-5),   # 2-D: sz_float.c:610 (unpinned)
-                 ("1d", _walk(3000, np.float32), 1e-3), ("1d-f64", _walk(2500, np.float64), 1e-4))        # 1-D: sz_float.c:353 (unpinned)
+                 ("2d", plane_field(40, 70), 1e-4), ("2d-f64", plane_field(33, 40, np.float64), 1e-5),   # 2-D: sz_float.c:610
+                 ("1d", _walk(3000, np.float32), 1e-3), ("1d-f64", _walk(2500, np.float64), 1e-4))        # 1-D: sz_float.c:353
         for name, d, eb in cases:
             ref, _ = oracle.compress(d, oracle.ABS, eb, params=p)
             got = sz_amd.SZ_compress_args(d, sz_amd.ABS, eb)

@@ -1,7 +1,7 @@
 """2-D SZ 2.1 path (sz_float.c:5516, szd_float.c:3141): CPU-side checks.
 
-PARITY UNPINNED for 2-D: neither SURVEY.md nor BASELINE.md records an output of the reference for a 2-D array, and the
-reference cannot be built in this image.  What can be checked without it: the oracle's 2-D restatement against itself
+The 2-D restatement is pinned by recorded outputs of the unmodified reference (tests/test_ref_recorded.py, round 2).  Kept from
+round 1, when no such output existed: the oracle's 2-D restatement against itself
 (round trips within the bound, stream structure), and the product's kernels + orchestration against the oracle (here on
 the HIP-on-CPU shim; on the GPU in test_gpu_parity.py)."""
 import ctypes
