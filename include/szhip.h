@@ -43,7 +43,13 @@ typedef struct szhip_params {
     float    pred_threshold;         /* predThreshold */
     unsigned max_quant_intervals;    /* max_quant_intervals (maxRangeRadius = half of it) */
     unsigned quantization_intervals; /* 0: optimise (optQuantMode 1); else fixed capacity */
+    unsigned flags;                  /* SZHIP_RANGE_FROM_DATA: szhip_compress takes the array's value range from its own fit pass
+                                        (one read of the input less than szhip_minmax + szhip_compress) and writes it into the
+                                        range field of the parameter bytes in `meta` (min at +20, max = min + range, sz_float.c:2849);
+                                        szhip_stats.vmin / vmax report it.  For callers whose bound does not depend on the range
+                                        (ABS).  0: `meta` is used as given. */
 } szhip_params;
+#define SZHIP_RANGE_FROM_DATA 1u
 
 /* per-call measurements (all times in milliseconds, device events on the ctx stream) */
 typedef struct szhip_stats {
@@ -56,6 +62,7 @@ typedef struct szhip_stats {
     unsigned intervals; int use_mean;
     uint64_t out_bytes;
     uint64_t quant_kernel_launches; /* launches of the wavefront kernel (1 per call) */
+    double vmin, vmax;      /* the array's range when SZHIP_RANGE_FROM_DATA was set (else 0) */
 } szhip_stats;
 
 int  szhip_create(szhip_ctx **ctx, int device);

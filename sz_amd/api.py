@@ -39,7 +39,7 @@ class sz_params(ctypes.Structure):  # include/sz.h (reference sz/include/sz.h:16
 
 class szhip_params(ctypes.Structure):  # include/szhip.h
     _fields_ = [("sample_distance", ctypes.c_int), ("pred_threshold", ctypes.c_float),
-                ("max_quant_intervals", ctypes.c_uint), ("quantization_intervals", ctypes.c_uint)]
+                ("max_quant_intervals", ctypes.c_uint), ("quantization_intervals", ctypes.c_uint), ("flags", ctypes.c_uint)]
 
 
 class szhip_stats(ctypes.Structure):  # include/szhip.h
@@ -47,7 +47,7 @@ class szhip_stats(ctypes.Structure):  # include/szhip.h
                 ("ms_entropy", ctypes.c_double), ("ms_host", ctypes.c_double),
                 ("n_elements", ctypes.c_uint64), ("n_blocks", ctypes.c_uint64), ("n_reg_blocks", ctypes.c_uint64),
                 ("n_unpred", ctypes.c_uint64), ("intervals", ctypes.c_uint), ("use_mean", ctypes.c_int),
-                ("out_bytes", ctypes.c_uint64), ("quant_kernel_launches", ctypes.c_uint64)]
+                ("out_bytes", ctypes.c_uint64), ("quant_kernel_launches", ctypes.c_uint64), ("vmin", ctypes.c_double), ("vmax", ctypes.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

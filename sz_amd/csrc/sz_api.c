@@ -226,6 +226,34 @@ void convertBytesToSZParams(unsigned char *bytes, sz_params *params)
     else if (params->dataType == SZ_DOUBLE) { params->dmin = szhost_get_f64be(bytes + 20); params->dmax = szhost_get_f64be(bytes + 28); }
 }
 
+/* valueRangeSize and confparams_cpr->{f,d}{min,max} from the scanned range: float arithmetic for float data, max = min + range (sz_float.c:2849) */
+static void set_range(int dataType, double vmin, double vmax, double *valueRangeSize)
+{
+    if (dataType == SZ_FLOAT) {
+        float fr = (float)vmax - (float)vmin; *valueRangeSize = fr;
+        confparams_cpr->fmin = (float)vmin; confparams_cpr->fmax = (float)vmin + fr;
+    } else { *valueRangeSize = vmax - vmin; confparams_cpr->dmin = vmin; confparams_cpr->dmax = vmin + *valueRangeSize; }
+}
+
+/* SZ_compress_args_float_withinRange, sz_float.c:2728: header + the first value */
+static int constant_stream(int dataType, const szhost_meta *m, const void *oriData, size_t dataLength, unsigned char **newByteData, size_t *outSize)
+{
+    const size_t esz = dataType == SZ_FLOAT ? 4 : 8, meta_len = dataType == SZ_FLOAT ? MetaDataByteLength : MetaDataByteLength_double;
+    unsigned char meta[4 + MetaDataByteLength_double];
+    unsigned char same = 0x01 | 0x40;
+    if (confparams_cpr->protectValueRange) same |= 0x04;
+    szhost_write_meta(m, same, meta);
+    size_t tot = 4 + meta_len + 8 + esz;
+    unsigned char *o = (unsigned char *)malloc(tot);
+    if (!o) return SZ_NSCS;
+    memcpy(o, meta, 4 + meta_len);
+    szhost_put_u64be(o + 4 + meta_len, dataLength);
+    if (dataType == SZ_FLOAT) szhost_put_f32be(o + 4 + meta_len + 8, ((const float *)oriData)[0]);
+    else szhost_put_f64be(o + 4 + meta_len + 8, ((const double *)oriData)[0]);
+    *newByteData = o; *outSize = tot;
+    return SZ_SCES;
+}
+
 /* the lossless stage after the SZ stream (sz_float.c:3027-3040); takes ownership of `tmp` */
 static int finish_lossless(unsigned char *tmp, size_t tmpSize, unsigned char **newByteData, size_t *outSize, int status)
 {
@@ -276,13 +304,19 @@ static int compress_fp(int dataType, int withRegression, unsigned char **newByte
     if (!ctx) return SZ_NSCS;
     void *d_in = NULL;
     if (szhip_stage_input(ctx, oriData, dataLength * esz, &d_in) != SZHIP_OK) return SZ_NSCS;
-    double vmin, vmax;
-    if (szhip_minmax(ctx, dataType == SZ_FLOAT ? SZHIP_F32 : SZHIP_F64, d_in, 1, dataLength, &vmin, &vmax) != SZHIP_OK) return SZ_NSCS;
-    double valueRangeSize;
-    if (dataType == SZ_FLOAT) { /* float arithmetic: max - min, then max = min + range (sz_float.c:2849) */
-        float fr = (float)vmax - (float)vmin; valueRangeSize = fr;
-        confparams_cpr->fmin = (float)vmin; confparams_cpr->fmax = (float)vmin + fr;
-    } else { valueRangeSize = vmax - vmin; confparams_cpr->dmin = vmin; confparams_cpr->dmax = vmin + valueRangeSize; }
+    /* The value range (computeRangeSize_float, sz_float.c:2845).  With an absolute bound on the SZ 2.1 path nothing before the
+     * quantiser depends on it -- it only goes into the header and decides the constant-data case -- so it is taken from the library's
+     * own fit pass, which reads the array anyway (SZHIP_RANGE_FROM_DATA), instead of a separate pass over the input. */
+    const int dim_in = computeDimension(r5, r4, r3, r2, r1);
+    const char *hip_mode = getenv("SZ_HIP_MODE");
+    const int fuse_range = errBoundMode == ABS && withRegression != SZ_NO_REGRESSION && dim_in >= 2 && dim_in <= 4 && !confparams_cpr->randomAccess
+                           && !(hip_mode && strcmp(hip_mode, "fast") == 0) && absErr_Bound > 0;
+    double vmin = 0, vmax = 0;
+    double valueRangeSize = 0;
+    if (!fuse_range) {
+        if (szhip_minmax(ctx, dataType == SZ_FLOAT ? SZHIP_F32 : SZHIP_F64, d_in, 1, dataLength, &vmin, &vmax) != SZHIP_OK) return SZ_NSCS;
+        set_range(dataType, vmin, vmax, &valueRangeSize);
+    }
 
     int status = SZ_SCES;
     double realPrecision = 0;
@@ -312,18 +346,9 @@ static int compress_fp(int dataType, int withRegression, unsigned char **newByte
     szhost_meta m; fill_meta(&m, confparams_cpr, dataType);
     unsigned char meta[4 + MetaDataByteLength_double];
 
-    if (valueRangeSize <= realPrecision) { /* SZ_compress_args_float_withinRange, sz_float.c:2728 */
-        unsigned char same = 0x01 | 0x40;
-        if (confparams_cpr->protectValueRange) same |= 0x04;
-        szhost_write_meta(&m, same, meta);
-        size_t tot = 4 + meta_len + 8 + esz;
-        unsigned char *o = (unsigned char *)malloc(tot);
-        memcpy(o, meta, 4 + meta_len);
-        szhost_put_u64be(o + 4 + meta_len, dataLength);
-        if (dataType == SZ_FLOAT) szhost_put_f32be(o + 4 + meta_len + 8, ((float *)oriData)[0]);
-        else szhost_put_f64be(o + 4 + meta_len + 8, ((double *)oriData)[0]);
-        *newByteData = o; *outSize = tot;
-        return status;
+    if (!fuse_range && valueRangeSize <= realPrecision) {
+        int crc = constant_stream(dataType, &m, oriData, dataLength, newByteData, outSize);
+        return crc == SZ_SCES ? status : crc;
     }
 
     int dim = computeDimension(r5, r4, r3, r2, r1);
@@ -357,7 +382,7 @@ static int compress_fp(int dataType, int withRegression, unsigned char **newByte
         unsigned char pflags = 0x40 | 0x20;                        /* TightDataPointStorageF.c:600-611: isPW_REL, no MSST19 bit */
         if (confparams_cpr->protectValueRange) pflags |= 0x04;
         szhost_write_meta(&m, pflags, meta);
-        szhip_params php;
+        szhip_params php; memset(&php, 0, sizeof(php));
         php.sample_distance = confparams_cpr->sampleDistance; php.pred_threshold = confparams_cpr->predThreshold;
         php.max_quant_intervals = confparams_cpr->maxRangeRadius * 2;
         php.quantization_intervals = exe_params->optQuantMode == 1 ? 0 : (unsigned)exe_params->intvCapacity;
@@ -405,7 +430,8 @@ static int compress_fp(int dataType, int withRegression, unsigned char **newByte
     unsigned char flags = sz14 ? 0x40 : (0x80 | 0x40);        /* TightDataPointStorageF.c:600-611 / sz_float.c:7396 */
     if (confparams_cpr->protectValueRange) flags |= 0x04;
     szhost_write_meta(&m, flags, meta);
-    szhip_params hp;
+    szhip_params hp; memset(&hp, 0, sizeof(hp));
+    hp.flags = fuse_range ? SZHIP_RANGE_FROM_DATA : 0;
     hp.sample_distance = confparams_cpr->sampleDistance; hp.pred_threshold = confparams_cpr->predThreshold;
     hp.max_quant_intervals = confparams_cpr->maxRangeRadius * 2;
     hp.quantization_intervals = exe_params->optQuantMode == 1 ? 0 : (unsigned)exe_params->intvCapacity;
@@ -420,6 +446,16 @@ static int compress_fp(int dataType, int withRegression, unsigned char **newByte
         rc = szhip_compress(ctx, dataType == SZ_FLOAT ? SZHIP_F32 : SZHIP_F64, d_in, 1, s0, r2, r1, realPrecision, &hp,
                             meta, 4 + meta_len, 0, &tmp, &tmpSize, &g_last_stats);
     if (rc != SZHIP_OK) { printf("Error: szhip_compress failed (%d): %s\n", rc, szhip_last_error(ctx)); return SZ_NSCS; }
+    if (fuse_range) {   /* the range arrived with the stream: record it where the reference's callers look for it, and settle the constant case */
+        set_range(dataType, g_last_stats.vmin, g_last_stats.vmax, &valueRangeSize);
+        fill_meta(&m, confparams_cpr, dataType);
+        szhost_write_meta(&m, flags, meta);
+        if (valueRangeSize <= realPrecision) {
+            free(tmp);
+            int crc = constant_stream(dataType, &m, oriData, dataLength, newByteData, outSize);
+            return crc == SZ_SCES ? status : crc;
+        }
+    }
     if (exe_params->optQuantMode == 1) { exe_params->intvCapacity = (int)g_last_stats.intervals; exe_params->intvRadius = exe_params->intvCapacity / 2; } /* updateQuantizationInfo */
 
     /* SZ_compress_args_float_StoreOriData, sz_float.c:526; '>=' on the SZ 2.1 path (:2975) and at the 1-D call site (:2908),

@@ -42,6 +42,7 @@ struct szhip_ctx {
         starts, ends, counts, offs, dirty, zcnt, zpos, pwr_log, pwr_signs, pwr_small;
     void *pinned = nullptr; size_t pinned_cap = 0;
     void *pinned2 = nullptr; size_t pinned2_cap = 0;   // target of the second stream's copies (indicator bits, regression-block count)
+    void *pinned3 = nullptr; size_t pinned3_cap = 0;   // the regression coefficients on their way to the host chain and back
     int order_nI = -1, order_nJ = -1;
 };
 
@@ -93,6 +94,16 @@ int ensure_pinned2(szhip_ctx *ctx, size_t bytes)
     size_t cap = bytes + bytes / 4 + 4096;
     HIPCHK(hipHostMalloc(&ctx->pinned2, cap, hipHostMallocDefault));
     ctx->pinned2_cap = cap;
+    return SZHIP_OK;
+}
+
+int ensure_pinned3(szhip_ctx *ctx, size_t bytes)
+{
+    if (ctx->pinned3_cap >= bytes) return SZHIP_OK;
+    if (ctx->pinned3) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipHostFree(ctx->pinned3)); ctx->pinned3 = nullptr; ctx->pinned3_cap = 0; }
+    size_t cap = bytes + bytes / 4 + 4096;
+    HIPCHK(hipHostMalloc(&ctx->pinned3, cap, hipHostMallocDefault));
+    ctx->pinned3_cap = cap;
     return SZHIP_OK;
 }
 
@@ -212,6 +223,8 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     const T eb = (T)eb_in;
     const double t_begin = now_ms();
     double host_ms = 0;
+    const int tp_on = tune_int("SZ_HIP_TIMING", 0); double tp_t[24]; const char *tp_n[24]; int tp_k = 0;
+    auto TP = [&](const char *nm) { if (tp_on && tp_k < 24) { tp_t[tp_k] = now_ms() - t_begin; tp_n[tp_k++] = nm; } };
     hipStream_t st = ctx->stream;
     szhip_stats S; memset(&S, 0, sizeof(S));
     S.n_elements = (uint64_t)n; S.n_blocks = (uint64_t)nb;
@@ -225,11 +238,15 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     TRY(ensure(ctx, ctx->small, SM_COUNT * 8));
     u64 *sm = (u64 *)ctx->small.p;
     HIPCHK(hipMemsetAsync(sm, 0, SM_COUNT * 8, st));
+    static const u64 minmax_init[2] = {~0ull, 0ull};          // ordered encodings: the fit pass reduces the array's range into these
+    HIPCHK(hipMemcpyAsync(sm + SM_MINMAX, minmax_init, 16, hipMemcpyHostToDevice, st));
+    const bool range_from_data = (prm->flags & SZHIP_RANGE_FROM_DATA) != 0;
     TRY(ensure(ctx, ctx->coef, (size_t)nb * 4 * sizeof(T)));
     TRY(ensure(ctx, ctx->blk_lor, (size_t)nb));
     T *d_coef = (T *)ctx->coef.p;
     uint8_t *d_lor = (uint8_t *)ctx->blk_lor.p;
     HIPCHK(hipEventRecord(ctx->ev[0], st));
+    TP("ev0");
 
     const int ncols = G.g0.num * G.g1.num;
 
@@ -246,14 +263,16 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     // speculative pass on the second stream, so that they are on the host by the time the interval decision is made
     const size_t ind_bytes = ((size_t)nb + 7) / 8;
     TRY(ensure(ctx, ctx->lor_bits, ind_bytes + 8));
-    TRY(ensure_pinned2(ctx, ind_bytes + 16));                   // pinned: the copies below must not block this thread
-    unsigned char *const ind_bits = (unsigned char *)ctx->pinned2 + 16;
+    TRY(ensure_pinned2(ctx, ind_bytes + 32));                   // pinned: the copies below must not block this thread
+    unsigned char *const ind_bits = (unsigned char *)ctx->pinned2 + 32;
     u64 *const nreg_h = (u64 *)ctx->pinned2;
+    u64 *const minmax_h = (u64 *)ctx->pinned2 + 2;
     hipLaunchKernelGGL(k_pack_lor, dim3((unsigned)((ind_bytes + 255) / 256)), dim3(256), 0, ctx->stream2, (const uint8_t *)d_lor, nb,
                        (uint8_t *)ctx->lor_bits.p, sm + SM_NREG);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(ind_bits, ctx->lor_bits.p, ind_bytes, hipMemcpyDeviceToHost, ctx->stream2));
     HIPCHK(hipMemcpyAsync(nreg_h, sm + SM_NREG, 8, hipMemcpyDeviceToHost, ctx->stream2));
+    HIPCHK(hipMemcpyAsync(minmax_h, sm + SM_MINMAX, 16, hipMemcpyDeviceToHost, ctx->stream2));
     HIPCHK(hipEventRecord(ctx->ev_fit, ctx->stream2));
 
     // ---- interval optimiser
@@ -333,8 +352,22 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         HIPCHK(hipMemcpyAsync(nreg_h, sm + SM_NREG, 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
     } else HIPCHK(hipEventSynchronize(ctx->ev_fit));           // usually long done
+    TP("fit joined");
     const size_t reg_count = (size_t)*nreg_h;
     S.n_reg_blocks = reg_count;
+    // the parameter bytes as they go into the stream: with SZHIP_RANGE_FROM_DATA the range field comes from the fit pass
+    // (computeRangeSize_float + `max = min + valueRangeSize`, sz_float.c:2845-2849, in the data's type)
+    std::vector<unsigned char> meta_own(meta, meta + meta_len);
+    if (range_from_data) {
+        if (meta_len < 4 + 20 + 2 * sizeof(T)) FAIL(SZHIP_ERR_ARG, "parameter bytes too short for a range field");
+        const T lo = (T)ord_dec<T>(minmax_h[0]), hi = (T)ord_dec<T>(minmax_h[1]);
+        const T range = hi - lo, top = lo + range;
+        unsigned char *q = meta_own.data() + 4 + 20;
+        if (is_double) { szhost_put_f64be(q, (double)lo); szhost_put_f64be(q + 8, (double)top); }
+        else { szhost_put_f32be(q, (float)lo); szhost_put_f32be(q + 4, (float)top); }
+        S.vmin = (double)lo; S.vmax = (double)hi;
+    }
+    meta = meta_own.data();
     // ---- regression coefficient chain (a serial recurrence with reconstruction feedback: host) and its Huffman streams.
     //      The chains of the four (three) coefficients are independent of each other and each is bound by the latency of its own
     //      ~45-cycle dependence per block, so they run on one host thread each; a thread goes on to build its coefficient's section
@@ -344,7 +377,8 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     std::vector<unsigned char> section[4];
     std::vector<std::thread> section_threads;
     std::atomic<int> section_failed(0);
-    std::vector<T> hcoef;
+    T *hcoef = nullptr;   // pinned: an asynchronous copy to or from pageable memory makes the runtime pin and unpin the pages around it,
+                          // which was seen to stall later calls for ~20 ms
     auto make_section = [&](int e) {   // (lives as long as the threads that call it: declared in the function's scope)
         std::vector<uint32_t> h32(65536, 0);
         for (size_t i = 0; i < reg_count; ++i) h32[(size_t)cf.codes[e][i]]++;
@@ -383,15 +417,17 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         hipLaunchKernelGGL((k_move_coef<T, 0>), dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, (const uint8_t *)d_lor,
                            (const u64 *)ctx->reg_rank.p, nb, (int64_t)reg_count, d_coef, (T *)ctx->coef_compact.p);
         HIPCHK(hipGetLastError());
-        hcoef.resize(reg_count * 4);
-        HIPCHK(hipMemcpyAsync(hcoef.data(), ctx->coef_compact.p, hcoef.size() * sizeof(T), hipMemcpyDeviceToHost, st));
+        TRY(ensure_pinned3(ctx, reg_count * 4 * sizeof(T)));
+        hcoef = (T *)ctx->pinned3;
+        HIPCHK(hipMemcpyAsync(hcoef, ctx->coef_compact.p, reg_count * 4 * sizeof(T), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        TP("coef on host");
         double h0 = now_ms();
         const std::vector<unsigned char> all_reg(reg_count, 0);
         // 2-D planes are carried as {0, a, b, c}: the chain sees components 1..3
-        T *const chain_in = hcoef.data() + (two_d ? reg_count : 0);
+        T *const chain_in = hcoef + (two_d ? reg_count : 0);
         szhost_coeff_chain_begin(is_double, all_reg.data(), reg_count, (double)eb, G.g0.late, G.g1.late, G.g2.late, ncoef, &cf);
-        if (reg_count >= 20000) {
+        if (reg_count >= 20000 && tune_int("SZ_HIP_CHAIN_THREADS", 1)) {
             std::vector<std::promise<void>> chained(ncoef);
             std::vector<std::future<void>> chained_f;
             for (int e = 0; e < ncoef; ++e) chained_f.push_back(chained[e].get_future());
@@ -406,13 +442,14 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
             for (int e = 0; e < ncoef; ++e) { szhost_coeff_chain_one(is_double, chain_in, all_reg.data(), reg_count, use_mean, e, &cf); make_section(e); }
         }
         host_ms += now_ms() - h0;
-        HIPCHK(hipMemcpyAsync(ctx->coef_compact.p, hcoef.data(), hcoef.size() * sizeof(T), hipMemcpyHostToDevice, st));
+        TP("chain done");
+        HIPCHK(hipMemcpyAsync(ctx->coef_compact.p, hcoef, reg_count * 4 * sizeof(T), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL((k_move_coef<T, 1>), dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, (const uint8_t *)d_lor,
                            (const u64 *)ctx->reg_rank.p, nb, (int64_t)reg_count, d_coef, (T *)ctx->coef_compact.p);
         HIPCHK(hipGetLastError());
-        // (hcoef stays alive until the end of the call: the copy above is asynchronous)
     }
     HIPCHK(hipEventRecord(ctx->ev[1], st));
+    TP("ev1");
 
     // ---- predict + quantise: the wavefront kernel
     TRY(ensure(ctx, ctx->codes_nat, (size_t)n * 2 + 64));
@@ -435,6 +472,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         hipLaunchKernelGGL((k_pencil<T, false>), dim3((unsigned)ntiles), dim3((TS::TPI * TS::TPJ + 2) * 64), 0, st, a);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(ctx->ev[3], st));
+        TP("pencil launched");
         S.quant_kernel_launches = 1;
     }
 
@@ -481,7 +519,9 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     //      round trip of the entropy stage: the number of unpredictable values is the histogram's bin 0, so the header can be written
     //      and the remaining kernels enqueued while the block-ordering pass is still running; the kernel error flag and the device's
     //      own count of zero codes are checked after the final synchronisation.
+    TP("permute launched");
     HIPCHK(hipEventSynchronize(ctx->ev_fit));
+    TP("hist on host");
     double h0 = now_ms();
     szhost_huff *hf = szhost_huff_build(2 * (int)intervals, h_hist, nullptr, intervals);
     host_ms += now_ms() - h0;
@@ -490,7 +530,9 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     if (!hf) FAIL(SZHIP_ERR_INTERNAL, "Huffman build failed");
 
     // ---- stream header
+    TP("tree built");
     for (auto &x : section_threads) if (x.joinable()) x.join();
+    TP("sections joined");
     if (section_failed) { szhost_huff_free(hf); FAIL(SZHIP_ERR_INTERNAL, "coefficient Huffman build failed"); }
     for (int e = 0; e < ncoef; ++e) coef_sections.insert(coef_sections.end(), section[e].begin(), section[e].end());
     h0 = now_ms();
@@ -499,9 +541,13 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     const size_t unpred_bytes = (size_t)total_unpred * sizeof(T);
     const size_t pay_bytes = (size_t)((hf->total_bits + 7) / 8);
     const size_t total_len = hdr_len + unpred_bytes + pay_bytes;
-    std::vector<unsigned char> hdr(hdr_len, 0);
+    // assembled in pinned memory (the histogram that lived there has been consumed): with coefficient sections the header is megabytes,
+    // and an asynchronous copy from pageable memory of that size makes the runtime pin and unpin the pages
+    TRY(ensure_pinned(ctx, hdr_len + 64));
+    unsigned char *const hdr = (unsigned char *)ctx->pinned;
+    memset(hdr, 0, hdr_len);
     {
-        unsigned char *q = hdr.data();
+        unsigned char *q = hdr;
         memcpy(q, meta, meta_len); q += meta_len;
         szhost_put_u64be(q, (uint64_t)n); q += 8;
         szhost_put_u32be(q, (uint32_t)G.block_size); q += 4;
@@ -531,14 +577,18 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     TRY(ensure(ctx, ctx->stream_buf, total_len + 64));
     unsigned char *d_stream = (unsigned char *)ctx->stream_buf.p;
     HIPCHK(hipMemsetAsync(d_stream, 0, total_len + 64, st));
-    HIPCHK(hipMemcpyAsync(d_stream, hdr.data(), hdr_len, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_stream, hdr, hdr_len, hipMemcpyHostToDevice, st));
     if (total_unpred > 0) {
+        // the unpredictable values are gathered on the second stream while the payload is being encoded on the first (both only read
+        // the block-ordered codes); their copy into the stream follows the join below
         TRY(ensure(ctx, ctx->unpred, unpred_bytes));
-        hipLaunchKernelGGL((k_unpred<T, 0>), dim3(ncols), dim3(256), 0, st, G, (const uint16_t *)d_blk, (const unsigned *)ctx->col_zeros.p,
+        HIPCHK(hipEventRecord(ctx->ev_in, st));                // block order, per-column offsets ready
+        HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_in, 0));
+        hipLaunchKernelGGL((k_unpred<T, 0>), dim3(ncols), dim3(256), 0, ctx->stream2, G, (const uint16_t *)d_blk, (const unsigned *)ctx->col_zeros.p,
                            (const u64 *)ctx->col_off.p, d_in, (T *)ctx->unpred.p, (T *)nullptr, (const unsigned *)ctx->zcnt.p,
                            (const unsigned *)ctx->zpos.p, perm_segb, perm_nseg);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(d_stream + hdr_len, ctx->unpred.p, unpred_bytes, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipEventRecord(ctx->ev_fit, ctx->stream2));
     }
     if (total_bits > 0) {
         const int64_t nchunks = (n + SZH_ENC_CHUNK - 1) / SZH_ENC_CHUNK;
@@ -552,7 +602,12 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
                            (unsigned *)d_stream);
         HIPCHK(hipGetLastError());
     }
+    if (total_unpred > 0) {
+        HIPCHK(hipStreamWaitEvent(st, ctx->ev_fit, 0));
+        HIPCHK(hipMemcpyAsync(d_stream + hdr_len, ctx->unpred.p, unpred_bytes, hipMemcpyDeviceToDevice, st));
+    }
     HIPCHK(hipEventRecord(ctx->ev[4], st));
+    TP("encode launched");
     u64 h_small[SM_COUNT];                                     // checked after the synchronisation below
     HIPCHK(hipMemcpyAsync(h_small, sm, SM_COUNT * 8, hipMemcpyDeviceToHost, st));
     if (out_on_device == 2) { // caller-provided device buffer of capacity *out_size
@@ -570,6 +625,8 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         *out = h;
     }
     *out_size = total_len;
+    TP("final sync");
+    if (tp_on) { for (int i = 0; i < tp_k; ++i) fprintf(stderr, "%s %.2f | ", tp_n[i], tp_t[i]); fprintf(stderr, "\n"); }
     // after the final synchronisation: the wavefront kernel's error flag; the shuffled bit count and the device's count of zero codes
     // must match what the histogram predicted
     if ((unsigned)h_small[SM_ERR] != 0) FAIL(SZHIP_ERR_INTERNAL, "wavefront kernel: halo wait timed out");
@@ -852,7 +909,9 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
         TRY(ensure(ctx, ctx->reg_flags, (size_t)nb * 8));
         TRY(ensure(ctx, ctx->reg_rank, (size_t)nb * 8));
         TRY(ensure(ctx, ctx->coef_compact, reg_count * 4 * sizeof(T)));
-        HIPCHK(hipMemcpyAsync(ctx->coef_compact.p, hcoef.data(), hcoef.size() * sizeof(T), hipMemcpyHostToDevice, st));
+        TRY(ensure_pinned3(ctx, hcoef.size() * sizeof(T)));    // (asynchronous copies from pageable memory stall later calls, see compress_impl)
+        memcpy(ctx->pinned3, hcoef.data(), hcoef.size() * sizeof(T));
+        HIPCHK(hipMemcpyAsync(ctx->coef_compact.p, ctx->pinned3, hcoef.size() * sizeof(T), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_reg_flags, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, (const uint8_t *)ctx->blk_lor.p, nb, (u64 *)ctx->reg_flags.p);
         TRY(scan_u64(ctx, (const u64 *)ctx->reg_flags.p, nb, (u64 *)ctx->reg_rank.p, sm + SM_SCRATCH));
         hipLaunchKernelGGL((k_move_coef<T, 1>), dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, (const uint8_t *)ctx->blk_lor.p,
@@ -1735,6 +1794,7 @@ void szhip_destroy(szhip_ctx *ctx)
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
     if (ctx->pinned) hipHostFree(ctx->pinned);
     if (ctx->pinned2) hipHostFree(ctx->pinned2);
+    if (ctx->pinned3) hipHostFree(ctx->pinned3);
     for (int i = 0; i < 6; ++i) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
     if (ctx->ev_in) hipEventDestroy(ctx->ev_in);
     if (ctx->ev_fit) hipEventDestroy(ctx->ev_fit);

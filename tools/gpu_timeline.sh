@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/tl
-rocprofv3 --kernel-trace --memory-copy-trace -d $R/gpurun_out/tl -o tl --output-format csv -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > $R/gpurun_out/tl_bench.log 2>&1
+rocprofv3 --kernel-trace --memory-copy-trace -d $R/gpurun_out/tl -o tl --output-format csv -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-m-field --no-fast > $R/gpurun_out/tl_bench.log 2>&1
 tail -1 $R/gpurun_out/tl_bench.log | cut -c1-300
 python3 - <<PY
 import csv, glob, os
@@ -18,10 +18,11 @@ for f in glob.glob(R+"/gpurun_out/tl/**/*memory_copy_trace.csv", recursive=True)
 ev.sort()
 # last compress step = the last k_pencil<float,false> ... find index of last gather_mean before it
 idx=[i for i,e in enumerate(ev) if "k_gather_mean" in e[2]]
-st=idx[-1]
+st=idx[3]                          # warmup 2 + steps 3: the fourth headline step
+while st > 0 and "k_minmax" not in ev[st][2]: st -= 1
 t0=ev[st][0]; prev=t0
 out=open(R+"/gpurun_out/timeline.txt","w")
-for s,e,n in ev[st:st+120]:
+for s,e,n in ev[st:st+48]:
     line="%9.1f us  +gap %7.1f  dur %8.1f  %s"%((s-t0)/1e3,(s-prev)/1e3,(e-s)/1e3,n)
     print(line); out.write(line+"\n"); prev=e
 PY
