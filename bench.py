@@ -278,15 +278,33 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
     e2e = None
     if world == 1 and n == EDGE:
         assert sz_amd.SZ_Init(os.path.join(ROOT, "tests", "golden", "sz_speed.config")) == 0
-        tcs, tds, s2 = [], [], None
+        L = sz_amd.lib()
+        dims = (0, 0, n, n, n)
+        tcs, tds, s2len, s2 = [], [], 0, None
+        for _ in range(3):                                       # the C calls themselves: no Python-side copy inside the timed part
+            nn2 = ctypes.c_size_t(0)
+            t1 = time.perf_counter()
+            p2 = L.SZ_compress_args(0, host.ctypes.data, ctypes.byref(nn2), sz_amd.ABS, EB, 0.0, 0.0, *dims)
+            tcs.append(time.perf_counter() - t1)
+            if not p2:
+                raise RuntimeError("SZ_compress_args failed")
+            s2len = nn2.value
+            if s2 is None:
+                s2 = ctypes.string_at(p2, s2len)
+            L.free(p2)
+        sbuf = ctypes.create_string_buffer(s2, len(s2))
         for _ in range(3):
-            t1 = time.perf_counter(); s2 = sz_amd.SZ_compress_args(host, sz_amd.ABS, EB); tcs.append(time.perf_counter() - t1)
-        for _ in range(3):
-            t1 = time.perf_counter(); sz_amd.SZ_decompress(s2, host.shape, host.dtype); tds.append(time.perf_counter() - t1)
+            t1 = time.perf_counter()
+            q2 = L.SZ_decompress(0, sbuf, len(s2), *dims)
+            tds.append(time.perf_counter() - t1)
+            if not q2:
+                raise RuntimeError("SZ_decompress failed")
+            L.free(q2)
         sz_amd.SZ_Finalize()
         e2e = {"compress_GBps": round(nbytes_in / float(np.median(tcs)) / 1e9, 2), "decompress_GBps": round(nbytes_in / float(np.median(tds)) / 1e9, 2),
-               "what": "SZ_compress_args / SZ_decompress on a pageable host array (H2D of 512 MiB + D2H of the stream, and the reverse), median of 3",
-               "stream_identical_to_device_path": bool(len(s2) == size)}
+               "what": "SZ_compress_args / SZ_decompress (the C entry points) on a pageable host array: 512 MiB staged to the device in 8 MiB chunks through "
+                       "pinned buffers by four host threads + the stream back, and the reverse into a freshly malloc'd array; median of 3",
+               "stream_identical_to_device_path": bool(s2len == size)}
 
     cpu, cpu_mt = (None, None)
     if not args.no_cpu_baseline and world == 1:

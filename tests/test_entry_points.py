@@ -112,3 +112,12 @@ def test_c_api_entry_points_on_the_gpu(built, oracle):
 def test_c_api_entry_points_on_the_cpu_shim(built, oracle):
     import sim_lib
     _exercise(ctypes.CDLL(sim_lib.shim_path()), oracle)
+
+
+@pytest.mark.slow
+def test_staged_host_copies_on_the_cpu_shim(built, oracle, monkeypatch):
+    """the bulk host <-> device copies of the host-pointer API (8 MiB chunks through pinned buffers, four host threads) with 1 KiB chunks,
+    so that a small array takes that path: same stream, same decoded values"""
+    import sim_lib
+    monkeypatch.setenv("SZ_HIP_STAGE_CHUNK_KB", "1")
+    _exercise(ctypes.CDLL(sim_lib.shim_path()), oracle)
