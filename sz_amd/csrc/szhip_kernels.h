@@ -204,11 +204,17 @@ struct GpuBackend {
 };
 
 // tile shape by element type: TPI x TPJ COMPUTE wavefronts + STORE + FILL per workgroup.  Measured for float on one box, k_pencil at
-// 512^3: 3x3 and 2x4 1.57-1.61 ms, 4x3 1.68-1.69, 2x2 1.69-1.77, 3x2 1.74-1.85, 2x3 1.73-1.81 (more pencils per tile = fewer tile
+// Round 2, after the helpers' accesses stopped being serialised (a cross-tile hand-off fell from 15-25 to ~5 us): 2x2 1.36-1.38 ms, 3x3
+// 1.41-1.52, 2x3 / 3x2 1.41-1.42, 2x4 1.44, 4x2 1.47, 1x4 1.70, 1x3 1.72, 3x1 1.75, 1x2 1.89, 2x1 2.00, 1x1 2.18 -- float tiles are 2x2 now.
+// Round 1, 512^3: 3x3 and 2x4 1.57-1.61 ms, 4x3 1.68-1.69, 2x2 1.69-1.77, 3x2 1.74-1.85, 2x3 1.73-1.81 (more pencils per tile = fewer tile
 // boundaries on the longest path, but more wavefronts per CU step more slowly; 11 wavefronts also leave 170 VGPRs each).
 // double keeps its rings at 32 columns to fit the LDS
 template <class T> struct szh_tile_shape;
-template <> struct szh_tile_shape<float> { static constexpr int TPI = 3, TPJ = 3, RL = 64; };
+#ifndef SZH_TPI_F32
+#define SZH_TPI_F32 2
+#define SZH_TPJ_F32 2
+#endif
+template <> struct szh_tile_shape<float> { static constexpr int TPI = SZH_TPI_F32, TPJ = SZH_TPJ_F32, RL = 64; };
 template <> struct szh_tile_shape<double> { static constexpr int TPI = 2, TPJ = 4, RL = 32; };   // measured on the 128x1024x1024 slab: 2x4 ~4 % ahead of 3x3
 
 template <class T, bool DEC>
@@ -222,6 +228,10 @@ __global__ __launch_bounds__((szh_tile_shape<T>::TPI * szh_tile_shape<T>::TPJ + 
     __shared__ unsigned cstep[NP + NV];
     __shared__ unsigned spubJ[NP], spubI[NP];
     __shared__ int scratch[128];
+#ifdef SZH_LDS_PAD
+    __shared__ int lds_pad[SZH_LDS_PAD / 4];            // development: occupy LDS to bound the workgroups per CU
+    if (a.backoff == -12345) lds_pad[threadIdx.x] = 1;
+#endif
     __shared__ unsigned tk_s;
     if (threadIdx.x < NP + NV) cstep[threadIdx.x] = 0;
     if (threadIdx.x < NP) { spubJ[threadIdx.x] = 0; spubI[threadIdx.x] = 0; }
