@@ -208,14 +208,20 @@ struct GpuBackend {
 // 1.41-1.52, 2x3 / 3x2 1.41-1.42, 2x4 1.44, 4x2 1.47, 1x4 1.70, 1x3 1.72, 3x1 1.75, 1x2 1.89, 2x1 2.00, 1x1 2.18 -- float tiles are 2x2 now.
 // Round 1, 512^3: 3x3 and 2x4 1.57-1.61 ms, 4x3 1.68-1.69, 2x2 1.69-1.77, 3x2 1.74-1.85, 2x3 1.73-1.81 (more pencils per tile = fewer tile
 // boundaries on the longest path, but more wavefronts per CU step more slowly; 11 wavefronts also leave 170 VGPRs each).
-// double keeps its rings at 32 columns to fit the LDS
+// double keeps its rings at 32 columns to fit the LDS; on the 132x1024x1024 slab of BASELINE configs[3] (round 2, after the hand-off fix):
+// 3x3 154 GB/s, 3x4 152, 2x2 148, 2x4 142-147, 4x3 147, 2x3 140 -- double tiles are 3x3
 template <class T> struct szh_tile_shape;
 #ifndef SZH_TPI_F32
 #define SZH_TPI_F32 2
 #define SZH_TPJ_F32 2
 #endif
 template <> struct szh_tile_shape<float> { static constexpr int TPI = SZH_TPI_F32, TPJ = SZH_TPJ_F32, RL = 64; };
-template <> struct szh_tile_shape<double> { static constexpr int TPI = 2, TPJ = 4, RL = 32; };   // measured on the 128x1024x1024 slab: 2x4 ~4 % ahead of 3x3
+#ifndef SZH_TPI_F64
+#define SZH_TPI_F64 3
+#define SZH_TPJ_F64 3
+#define SZH_RL_F64 32
+#endif
+template <> struct szh_tile_shape<double> { static constexpr int TPI = SZH_TPI_F64, TPJ = SZH_TPJ_F64, RL = SZH_RL_F64; };
 
 template <class T, bool DEC>
 __global__ __launch_bounds__((szh_tile_shape<T>::TPI * szh_tile_shape<T>::TPJ + 2) * 64) void k_pencil(szh_qargs<T> a)
