@@ -496,7 +496,9 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         // 2-D planes are carried as {0, a, b, c}: the chain sees components 1..3
         T *const chain_in = hcoef + (two_d ? reg_count : 0);
         szhost_coeff_chain_begin(is_double, all_reg.data(), reg_count, (double)eb, G.g0.late, G.g1.late, G.g2.late, ncoef, &cf);
-        if (reg_count >= 20000 && tune_int("SZ_HIP_CHAIN_THREADS", 1)) {
+        // (threads also for a handful of regression blocks: a section's fixed cost -- a 131 072-state code book -- is ~0.5 ms, and
+        //  four of them in line delayed the wavefront kernel of BASELINE configs[3] by 2 ms)
+        if (tune_int("SZ_HIP_CHAIN_THREADS", 1)) {
             std::vector<std::promise<void>> chained(ncoef);
             std::vector<std::future<void>> chained_f;
             for (int e = 0; e < ncoef; ++e) chained_f.push_back(chained[e].get_future());
@@ -571,7 +573,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     HIPCHK(hipMemsetAsync(ctx->col_zeros.p, 0, (size_t)ncols * 4, st));
     int perm_segb = 1, perm_nseg = 1;
     {
-        const int segb = choose_segb(G, 2, 32 * 1024);
+        const int segb = choose_segb(G, 2, tune_int("SZ_HIP_PERM_TILE_KB", 32) * 1024);
         const int nseg = (G.g2.num + segb - 1) / segb;
         TRY(ensure(ctx, ctx->zcnt, (size_t)ncols * nseg * 4));
         TRY(ensure(ctx, ctx->zpos, (size_t)ncols * nseg * SZH_ZCAP * 4));
@@ -939,7 +941,7 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
     HIPCHK(hipMemsetAsync(ctx->col_zeros.p, 0, (size_t)ncols * 4, st));
     int perm_segb = 1, perm_nseg = 1;
     {
-        const int segb = choose_segb(G, 2, 32 * 1024);
+        const int segb = choose_segb(G, 2, tune_int("SZ_HIP_PERM_TILE_KB", 32) * 1024);
         const int nseg = (G.g2.num + segb - 1) / segb;
         TRY(ensure(ctx, ctx->zcnt, (size_t)ncols * nseg * 4));
         TRY(ensure(ctx, ctx->zpos, (size_t)ncols * nseg * SZH_ZCAP * 4));
