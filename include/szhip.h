@@ -160,12 +160,14 @@ int szhip_decompress_sz14_pwr(szhip_ctx *ctx, int dtype, const unsigned char *st
                               int out_on_device, szhip_stats *stats);
 
 /*
- * FAST mode (opt-in; SZ_HIP_MODE=fast through the SZ_* API): pre-quantised integer Lorenzo inside tiles of 16 x 16 x 64 points,
- * no reconstruction feedback -- the block-local precedent is the reference's own OpenMP variant (SZ_compress_float_3D_MDQ_RA_block,
- * sz/src/sz_float.c:4704-5012; sz/src/sz_omp.c:63-358) -- so that predict + quantise runs at HBM speed.  The absolute bound `eb`
- * always holds; codes and ratio differ slightly from the exact path, and the stream is this library's own container (magic "SZHF"),
- * which a stock SZ reader rejects at its version check.  1-D / 2-D arrays: leading extents 1.  `intervals`: code alphabet
- * (even, 4 .. 65536; 0 = 1024).  Output conventions as for szhip_compress.
+ * FAST mode (opt-in; SZ_HIP_MODE=fast through the SZ_* API): values pre-quantised to integers (q = rint(x / 2eb), verified per point), then
+ * a 7-point Lorenzo difference on q over the whole array in integer arithmetic -- no reconstruction feedback, every point independent,
+ * so predict + quantise is a streaming kernel.  The precedent for trading the reference's codes for parallelism is its own OpenMP
+ * variant (block-local Lorenzo: SZ_compress_float_3D_MDQ_RA_block, sz/src/sz_float.c:4704-5012; sz/src/sz_omp.c:63-358).  The absolute
+ * bound `eb` always holds; codes and ratio differ slightly from the exact path (no regression predictor), and the stream is this
+ * library's own container (magic "SZHF"), which a stock SZ reader rejects at its version check.  Inverse: three prefix sums.
+ * 1-D / 2-D arrays: leading extents 1.  `intervals`: code alphabet (even, 4 .. 65536; 0 = 1024).  Output conventions as for
+ * szhip_compress.  DESIGN.md section 4e.
  */
 int szhip_compress_fast(szhip_ctx *ctx, int dtype, const void *data, int data_on_device, size_t r0, size_t r1, size_t r2, double eb,
                         unsigned intervals, int out_on_device, unsigned char **out, size_t *out_size, szhip_stats *stats);

@@ -32,6 +32,27 @@ def test_library_exports_every_declared_symbol(L):
         assert hasattr(L, n), f"{n} is declared but not exported"
     for g in ("confparams_cpr", "confparams_dec", "exe_params", "dataEndianType", "sysEndianType", "versionNumber"):
         ctypes.c_int.in_dll(L, g)
+    # include/rw.h: the file helpers of the reference's examples
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "rw.h")).read(), flags=re.S)
+    rw = set(re.findall(r"\b((?:read|write)[A-Za-z0-9_]+)\s*\(", text))
+    assert len(rw) >= 4
+    for n in sorted(rw):
+        assert hasattr(L, n), f"{n} is declared in rw.h but not exported"
+
+
+def test_hdf5_plugin_exports_every_declared_symbol(built):
+    """include/H5Z_SZ.h against sz_amd/h5z/libhdf5sz.so (built when the HDF5 C library is present)"""
+    so = os.path.join(ROOT, "sz_amd", "h5z", "libhdf5sz.so")
+    if not os.path.exists(so):
+        pytest.skip("no HDF5 C library in this environment: the plugin was not built")
+    P = ctypes.CDLL(so)
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "H5Z_SZ.h")).read(), flags=re.S)
+    names = set(re.findall(r"\b((?:H5Z_SZ_|SZ_)[A-Za-z0-9_]+|checkCDValuesWithErrors)\s*\(", text))
+    assert len(names) >= 9
+    for n in sorted(names | {"H5PLget_plugin_type", "H5PLget_plugin_info"}):
+        assert hasattr(P, n), f"{n} is declared but not exported by the plugin"
+    for g in ("load_conffile_flag", "init_sz_flag", "cfgFile"):
+        ctypes.c_int.in_dll(P, g)
 
 
 def test_no_cpu_fallback_without_gpu(L):

@@ -25,5 +25,13 @@ out=open(R+"/gpurun_out/timeline.txt","w")
 for s,e,n in ev[st:st+48]:
     line="%9.1f us  +gap %7.1f  dur %8.1f  %s"%((s-t0)/1e3,(s-prev)/1e3,(e-s)/1e3,n)
     print(line); out.write(line+"\n"); prev=e
+# one decompress step: from the last k_hdec_init back to the copy before it, through the k_pencil<float, true> that follows
+di=[i for i,e in enumerate(ev) if "k_hdec_init" in e[2]]
+if di:
+    st=di[-1]-3; t0=ev[st][0]; prev=t0
+    out.write("---- decompress\n"); print("---- decompress")
+    for s,e,n in ev[st:st+40]:
+        line="%9.1f us  +gap %7.1f  dur %8.1f  %s"%((s-t0)/1e3,(s-prev)/1e3,(e-s)/1e3,n)
+        print(line); out.write(line+"\n"); prev=e
 PY
 rm -rf $R/gpurun_out/tl
