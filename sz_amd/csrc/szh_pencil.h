@@ -48,6 +48,8 @@ template <class T> struct szh_qargs {
     const unsigned *order;    // ticket -> (tile row << 16) | tile column, anti-diagonal order over the tiles
     unsigned *ticket;
     unsigned *err;            // set to 1 if a halo wait timed out
+    const szh_u64 *coef_progress; // compress, optional: number of blocks (scan order) whose decoded coefficients have arrived in `coef`;
+                              // the host's coefficient chain runs NEXT TO this kernel and ships them as it goes (nullptr: all there)
     szh_u64 *progress;        // [pencil][2] (J-face, I-face): {epoch, steps whose face values have been published}: the consumers' FILL
                               // wavefront polls these words and then fetches only granules that exist
     int fmt;                  // 0: SZ 2.1 block path; 1: SZ 1.4 whole-array Lorenzo (sz_float.c:946): no blocks, capacity = intervals,
@@ -272,11 +274,11 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
             if (nbz > 1) nlor[l] = a.blk_lor[b + 1] != 0;
             if (nbz > 2) nnlor[l] = a.blk_lor[b + 2] != 0;
             if (!lor[l]) {
-                ca[l] = a.coef[b]; cb[l] = a.coef[G.nblocks + b]; cc[l] = a.coef[2 * G.nblocks + b]; cd[l] = a.coef[3 * G.nblocks + b];
+                ca[l] = B::ld_coef(a.coef + b); cb[l] = B::ld_coef(a.coef + G.nblocks + b); cc[l] = B::ld_coef(a.coef + 2 * G.nblocks + b); cd[l] = B::ld_coef(a.coef + 3 * G.nblocks + b);
                 pbase[l] = ca[l] * fii[l] + cb[l] * fjj[l];
             }
             if (!nlor[l]) {
-                na[l] = a.coef[b + 1]; nb_[l] = a.coef[G.nblocks + b + 1]; nc[l] = a.coef[2 * G.nblocks + b + 1]; nd[l] = a.coef[3 * G.nblocks + b + 1];
+                na[l] = B::ld_coef(a.coef + b + 1); nb_[l] = B::ld_coef(a.coef + G.nblocks + b + 1); nc[l] = B::ld_coef(a.coef + 2 * G.nblocks + b + 1); nd[l] = B::ld_coef(a.coef + 3 * G.nblocks + b + 1);
             }
         }
     }
@@ -566,8 +568,8 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
                             nlor[l] = nnlor[l];
                             const int64_t b = blkrow[l] + bk[l];
                             if (bk[l] + 1 < nbz && !nlor[l]) {
-                                na[l] = a.coef[b + 1]; nb_[l] = a.coef[G.nblocks + b + 1];
-                                nc[l] = a.coef[2 * G.nblocks + b + 1]; nd[l] = a.coef[3 * G.nblocks + b + 1];
+                                na[l] = B::ld_coef(a.coef + b + 1); nb_[l] = B::ld_coef(a.coef + G.nblocks + b + 1);
+                                nc[l] = B::ld_coef(a.coef + 2 * G.nblocks + b + 1); nd[l] = B::ld_coef(a.coef + 3 * G.nblocks + b + 1);
                             }
                             nnlor[l] = (bk[l] + 2 < nbz) ? (a.blk_lor[b + 2] != 0) : true;
                         }
@@ -641,6 +643,19 @@ SZH_HD void szh_pencil_run(const szh_qargs<T> &a, int I, int J, const szh_tile_l
 #else
     const bool hasreg = szh_pencil_has_reg<T, B>(a, I, J);
 #endif
+    if (!DEC && hasreg && a.coef_progress) {
+        // the decoded coefficients are still arriving (the host's chain runs next to this launch): wait until the last block this pencil
+        // reads -- scan order: its largest (b0, b1), whole row of dim2 -- is final.  Bounded like every other wait of the kernel.
+        const szh_geom3 &G = a.G;
+        const int i1 = 8 * I + 7 < G.g0.count ? 8 * I + 7 : G.g0.count - 1, j1 = 8 * J + 7 < G.g1.count ? 8 * J + 7 : G.g1.count - 1;
+        const szh_u64 need = ((szh_u64)szh_blk_of(G.g0, i1) * G.g1.num + szh_blk_of(G.g1, j1) + 1) * (szh_u64)G.g2.num;
+        unsigned spins = 0;
+        while (B::ld_sys_u64(a.coef_progress) < need) {
+            if (++spins > (1u << 23)) { B::st_flag(a.err, 1u); break; }
+            if ((spins & 1023u) == 0 && B::ld_flag(a.err) != 0) break;
+            B::nap();
+        }
+    }
     if (a.use_mean) {
         if (hasreg) szh_pencil_body<T, DEC, true, true, B>(a, I, J, L);
         else szh_pencil_body<T, DEC, false, true, B>(a, I, J, L);

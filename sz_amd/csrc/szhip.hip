@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <ctime>
 #include <future>
 #include <thread>
@@ -39,7 +40,7 @@ struct szhip_ctx {
     // workspaces (grow-only)
     DevBuf lor_bits, reg_flags, reg_rank, coef_compact, in, out, codes_nat, codes_blk, coef, blk_lor, faceI, faceJ, progress, trace, order, small, hist, col_zeros, col_zeros64,
         col_off, partial, samples, unpred, stream_buf, chunk_bits, chunk_off, code_tab, len_tab, dec_tab,
-        starts, ends, counts, offs, dirty, zcnt, zpos, pwr_log, pwr_signs, pwr_small;
+        starts, ends, counts, offs, dirty, zcnt, zpos, pwr_log, pwr_signs, pwr_small, coef_prog;
     void *pinned = nullptr; size_t pinned_cap = 0;
     void *pinned2 = nullptr; size_t pinned2_cap = 0;   // target of the second stream's copies (indicator bits, regression-block count)
     // bulk copies between the caller's pageable arrays and the device: SZH_STAGE_T host threads, two pinned buffers + events each
@@ -446,6 +447,10 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     std::vector<unsigned char> section[4];
     std::vector<std::thread> section_threads;
     std::atomic<int> section_failed(0);
+    std::vector<unsigned char> all_reg_keep;   // "every block is a regression block" for the chain over the compacted coefficients
+    std::vector<uint32_t> blk_of_rank;
+    size_t chain_done[4] = {0, 0, 0, 0};       // regression blocks finished per coefficient (written by the chain threads)
+    bool overlap = false;
     T *hcoef = nullptr;   // pinned: an asynchronous copy to or from pageable memory makes the runtime pin and unpin the pages around it,
                           // which was seen to stall later calls for ~20 ms
     auto make_section = [&](int e) {   // (lives as long as the threads that call it: declared in the function's scope)
@@ -486,19 +491,36 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         hipLaunchKernelGGL((k_move_coef<T, 0>), dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, (const uint8_t *)d_lor,
                            (const u64 *)ctx->reg_rank.p, nb, (int64_t)reg_count, d_coef, (T *)ctx->coef_compact.p);
         HIPCHK(hipGetLastError());
-        TRY(ensure_pinned3(ctx, reg_count * 4 * sizeof(T)));
+#ifndef SZH_SYNC_LAUNCH
+        overlap = !two_d && tune_int("SZ_HIP_CHAIN_THREADS", 1) && tune_int("SZ_HIP_CHAIN_OVERLAP", 1);
+#endif
+        // pinned: [4][reg_count] compacted coefficients | (overlap) [4][nb] block-indexed staging | 64 progress words
+        TRY(ensure_pinned3(ctx, reg_count * 4 * sizeof(T) + (overlap ? (size_t)nb * 4 * sizeof(T) + 64 * 8 + 64 : 0)));
         hcoef = (T *)ctx->pinned3;
         HIPCHK(hipMemcpyAsync(hcoef, ctx->coef_compact.p, reg_count * 4 * sizeof(T), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         TP("coef on host");
         double h0 = now_ms();
-        const std::vector<unsigned char> all_reg(reg_count, 0);
+        all_reg_keep.assign(reg_count, 0);
+        const std::vector<unsigned char> &all_reg = all_reg_keep;
         // 2-D planes are carried as {0, a, b, c}: the chain sees components 1..3
         T *const chain_in = hcoef + (two_d ? reg_count : 0);
         szhost_coeff_chain_begin(is_double, all_reg.data(), reg_count, (double)eb, G.g0.late, G.g1.late, G.g2.late, ncoef, &cf);
         // (threads also for a handful of regression blocks: a section's fixed cost -- a 131 072-state code book -- is ~0.5 ms, and
         //  four of them in line delayed the wavefront kernel of BASELINE configs[3] by 2 ms)
-        if (tune_int("SZ_HIP_CHAIN_THREADS", 1)) {
+        if (overlap) {
+            // The chain runs NEXT TO the wavefront kernel: the threads publish how far they are, the kernel is launched right away and
+            // makes a pencil that touches a regression block wait until the blocks it reads are final, and this thread ships the decoded
+            // coefficients as they appear (after the launch, below).  blk_of_rank: scan-order block index of the r-th regression block.
+            blk_of_rank.resize(reg_count);
+            { size_t r = 0; for (int64_t bb = 0; bb < nb && r < reg_count; ++bb) if (!((ind_bits[bb >> 3] >> (7 - (bb & 7))) & 1)) blk_of_rank[r++] = (uint32_t)bb; if (r != reg_count) FAIL(SZHIP_ERR_INTERNAL, "indicator bits and regression-block count disagree"); }
+            for (int e = 0; e < 4; ++e) chain_done[e] = 0;
+            for (int e = 0; e < ncoef; ++e)
+                section_threads.emplace_back([&, e, chain_in, ind = all_reg_keep.data()] {
+                    szhost_coeff_chain_one_p(is_double, chain_in, ind, reg_count, use_mean, e, &cf, &chain_done[e]);
+                    make_section(e);
+                });
+        } else if (tune_int("SZ_HIP_CHAIN_THREADS", 1)) {
             std::vector<std::promise<void>> chained(ncoef);
             std::vector<std::future<void>> chained_f;
             for (int e = 0; e < ncoef; ++e) chained_f.push_back(chained[e].get_future());
@@ -514,10 +536,12 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         }
         host_ms += now_ms() - h0;
         TP("chain done");
-        HIPCHK(hipMemcpyAsync(ctx->coef_compact.p, hcoef, reg_count * 4 * sizeof(T), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL((k_move_coef<T, 1>), dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, (const uint8_t *)d_lor,
-                           (const u64 *)ctx->reg_rank.p, nb, (int64_t)reg_count, d_coef, (T *)ctx->coef_compact.p);
-        HIPCHK(hipGetLastError());
+        if (!overlap) {
+            HIPCHK(hipMemcpyAsync(ctx->coef_compact.p, hcoef, reg_count * 4 * sizeof(T), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL((k_move_coef<T, 1>), dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, (const uint8_t *)d_lor,
+                               (const u64 *)ctx->reg_rank.p, nb, (int64_t)reg_count, d_coef, (T *)ctx->coef_compact.p);
+            HIPCHK(hipGetLastError());
+        }
     }
     HIPCHK(hipEventRecord(ctx->ev[1], st));
     TP("ev1");
@@ -539,12 +563,46 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         a.progress = (szh_u64 *)ctx->progress.p; a.backoff = tune_int("SZ_HIP_BACKOFF", 4); a.wide = tune_int("SZ_HIP_WIDE", 1) && (double)TS::TPI * nJ * 9.0 * (double)G.g2.count * szh_gran<T>::NW * 8.0 < 4.0e9 && (double)TS::TPJ * 9.0 * (double)G.g2.count * szh_gran<T>::NW * 8.0 < 4.0e9;
         a.trace = tune_int("SZ_HIP_TRACE", 0) ? (szh_u64 *)ctx->trace.p : nullptr;
         a.dbg = tune_int("SZ_HIP_DBG", 0); a.trace_tile = tune_int("SZ_HIP_TRACE_TILE", 1);
+        a.coef_progress = nullptr;
+        if (overlap) {
+            TRY(ensure(ctx, ctx->coef_prog, 64));
+            HIPCHK(hipMemsetAsync(ctx->coef_prog.p, 0, 8, st));
+            a.coef_progress = (const szh_u64 *)ctx->coef_prog.p;
+        }
         HIPCHK(hipEventRecord(ctx->ev[2], st));
         hipLaunchKernelGGL((k_pencil<T, false>), dim3((unsigned)ntiles), dim3((TS::TPI * TS::TPJ + 2) * 64), 0, st, a);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(ctx->ev[3], st));
         TP("pencil launched");
         S.quant_kernel_launches = 1;
+        if (overlap) {
+            // ship the decoded coefficients while the kernel runs: DMA only (no kernel that could queue behind the waiting tiles), on the
+            // second stream, in scan order: the values of the newly finished regression blocks go into a block-indexed pinned staging
+            // array, the contiguous block range [first, last] of each coefficient into d_coef, then the progress word (same stream: it
+            // lands after the data).  Blocks between regression blocks are Lorenzo blocks: whatever they receive is never read.
+            const double h1 = now_ms();
+            T *const full = hcoef + reg_count * 4;
+            szh_u64 *const prog_h = (szh_u64 *)(((uintptr_t)(full + (size_t)nb * 4) + 63) & ~(uintptr_t)63);
+            const size_t chunk = std::max<size_t>(4096, reg_count / 24);
+            size_t shipped = 0; int slot = 0, idle = 0;
+            while (shipped < reg_count) {
+                size_t p = reg_count;
+                for (int e = 0; e < ncoef; ++e) { const size_t d = __atomic_load_n(&chain_done[e], __ATOMIC_ACQUIRE); if (d < p) p = d; }
+                if (p > shipped && (p - shipped >= chunk || p == reg_count)) {
+                    const size_t b_lo = blk_of_rank[shipped], b_hi = blk_of_rank[p - 1];
+                    for (int e = 0; e < ncoef; ++e) {
+                        for (size_t r = shipped; r < p; ++r) full[(size_t)e * nb + blk_of_rank[r]] = hcoef[(size_t)e * reg_count + r];
+                        HIPCHK(hipMemcpyAsync(d_coef + (size_t)e * nb + b_lo, full + (size_t)e * nb + b_lo, (b_hi - b_lo + 1) * sizeof(T), hipMemcpyHostToDevice, ctx->stream2));
+                    }
+                    prog_h[slot] = p == reg_count ? (szh_u64)nb : (szh_u64)blk_of_rank[p];     // every block below this index is final
+                    HIPCHK(hipMemcpyAsync(ctx->coef_prog.p, &prog_h[slot], 8, hipMemcpyHostToDevice, ctx->stream2));
+                    slot = (slot + 1) & 63; shipped = p; idle = 0;
+                } else if (++idle > 200000) FAIL(SZHIP_ERR_INTERNAL, "coefficient chain made no progress");
+                else std::this_thread::sleep_for(std::chrono::microseconds(20));
+            }
+            host_ms += now_ms() - h1;
+            TP("coefficients shipped");
+        }
     }
 
     // ---- histogram, block ordering, unpredictable counts
@@ -1858,7 +1916,7 @@ void szhip_destroy(szhip_ctx *ctx)
                       &ctx->order, &ctx->small, &ctx->hist, &ctx->col_zeros, &ctx->col_zeros64, &ctx->col_off, &ctx->partial,
                       &ctx->samples, &ctx->unpred, &ctx->stream_buf, &ctx->chunk_bits, &ctx->chunk_off, &ctx->code_tab,
                       &ctx->len_tab, &ctx->dec_tab, &ctx->starts, &ctx->ends, &ctx->counts, &ctx->offs, &ctx->dirty, &ctx->zcnt, &ctx->zpos,
-                      &ctx->pwr_log, &ctx->pwr_signs, &ctx->pwr_small};
+                      &ctx->pwr_log, &ctx->pwr_signs, &ctx->pwr_small, &ctx->coef_prog};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
     if (ctx->pinned) hipHostFree(ctx->pinned);
     if (ctx->pinned2) hipHostFree(ctx->pinned2);

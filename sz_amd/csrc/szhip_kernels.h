@@ -181,6 +181,10 @@ struct GpuBackend {
 #endif
     __device__ static unsigned ld_flag(const unsigned *p) { return __hip_atomic_load(const_cast<unsigned *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     __device__ static void st_flag(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    // system scope (sc0 sc1): data the host's DMA writes while the kernel runs -- the progress word and the regression coefficients
+    __device__ static szh_u64 ld_sys_u64(const szh_u64 *p) { return __hip_atomic_load(const_cast<szh_u64 *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+    __device__ static float ld_coef(const float *p) { return __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned *>(const_cast<float *>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)); }
+    __device__ static double ld_coef(const double *p) { return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<szh_u64 *>(const_cast<double *>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)); }
     __device__ static void backoff(int n) { for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(2); }
     template <class E, int N> __device__ static void ld16(const E *p, E (&v)[N])
     {

@@ -360,8 +360,10 @@ void szhost_coeffs_free(szhost_coeffs *c)
         } else { cc = 0; last = cur; un[nun++] = cur; }                                                    \
         codes[ci++] = cc;                                                                                  \
         cf[b] = last;                                                                                      \
+        if (progress && (ci & 1023) == 0) __atomic_store_n(progress, ci, __ATOMIC_RELEASE);               \
     }                                                                                                      \
-    out->unpred_count[e] = nun;
+    out->unpred_count[e] = nun;                                                                            \
+    if (progress) __atomic_store_n(progress, ci, __ATOMIC_RELEASE);
 
 /* ncoef = 4: 3-D planes {a,b,c,d}, precisions from late0..late2; ncoef = 3: 2-D planes {a,b,c} (sz_float.c:6031-6055), precisions
  * from late1, late2 (late0 unused).  `coef` is SoA [ncoef][nblocks]. */
@@ -391,10 +393,15 @@ void szhost_coeff_chain_begin(int is_double, const unsigned char *indicator, siz
     }
 }
 
-void szhost_coeff_chain_one(int is_double, void *coef, const unsigned char *indicator, size_t nblocks, int use_mean, int e, szhost_coeffs *out)
+void szhost_coeff_chain_one_p(int is_double, void *coef, const unsigned char *indicator, size_t nblocks, int use_mean, int e, szhost_coeffs *out,
+                              size_t *progress)
 {
     if (is_double) { CHAIN_ONE(double, fabs, 0) }
     else { CHAIN_ONE(float, fabsf, 1) }
+}
+void szhost_coeff_chain_one(int is_double, void *coef, const unsigned char *indicator, size_t nblocks, int use_mean, int e, szhost_coeffs *out)
+{
+    szhost_coeff_chain_one_p(is_double, coef, indicator, nblocks, use_mean, e, out, NULL);
 }
 
 void szhost_coeff_chain(int is_double, void *coef, const unsigned char *indicator, size_t nblocks, double eb,

@@ -67,6 +67,9 @@ void szhost_coeff_chain(int is_double, void *coef, const unsigned char *indicato
 void szhost_coeff_chain_begin(int is_double, const unsigned char *indicator, size_t nblocks, double eb,
                               int late0, int late1, int late2, int ncoef, szhost_coeffs *out);
 void szhost_coeff_chain_one(int is_double, void *coef, const unsigned char *indicator, size_t nblocks, int use_mean, int e, szhost_coeffs *out);
+/* the same, publishing the number of regression blocks finished so far in *progress (release stores, every 1024 blocks and at the end) */
+void szhost_coeff_chain_one_p(int is_double, void *coef, const unsigned char *indicator, size_t nblocks, int use_mean, int e, szhost_coeffs *out,
+                              size_t *progress);
 void szhost_coeffs_free(szhost_coeffs *c);
 /* inverse: codes+unpred -> decoded coefficients written into coef SoA [ncoef][nblocks] for regression blocks */
 void szhost_coeff_unchain(int is_double, void *coef, const unsigned char *indicator, size_t nblocks,

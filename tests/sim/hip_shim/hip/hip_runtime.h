@@ -21,7 +21,9 @@
 #define __forceinline__ inline
 #define __launch_bounds__(...)
 #define __shared__ static
+#define SZH_SYNC_LAUNCH 1   /* a launch returns when the kernel has finished: nothing on the host can overlap with it */
 #define __HIP_MEMORY_SCOPE_AGENT 4
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
 
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
 struct uint4 { unsigned x, y, z, w; };
@@ -103,6 +105,9 @@ template <class T> inline T atomicMax(T *p, T v)
 }
 template <class T> inline T __hip_atomic_load(T *p, int, int) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
 template <class T> inline void __hip_atomic_store(T *p, T v, int, int) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
+
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static inline double __longlong_as_double(long long u) { double f; memcpy(&f, &u, 8); return f; }
 
 // ---- host runtime API subset ----
 typedef int hipError_t;

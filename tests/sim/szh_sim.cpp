@@ -42,6 +42,8 @@ struct SimBackend {
     static void ld_gran2_b(gbuf_t b, unsigned off, szh_u64 &x, szh_u64 &y) { x = b[off / 8]; y = b[off / 8 + 1]; }
     static unsigned ld_flag(const unsigned *p) { return *p; }
     static void st_flag(unsigned *p, unsigned v) { *p = v; }
+    static szh_u64 ld_sys_u64(const szh_u64 *p) { return *p; }
+    template <class U> static U ld_coef(const U *p) { return *p; }
     static void backoff(int) {}
     static void nap() {}
     template <class E, int N> static void ld16(const E *p, E (&v)[N]) { memcpy(v, p, 16); }
