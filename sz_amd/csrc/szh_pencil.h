@@ -39,7 +39,8 @@ template <class T> struct szh_qargs {
     T *out;                   // decompress: output (unpredictable values pre-scattered)
     uint16_t *codes;          // NATURAL-order codes: written by compress, read by decompress
     const uint8_t *blk_lor;   // per block: 1 = Lorenzo, 0 = regression (the stream's indicator)
-    const T *coef;            // decoded regression coefficients, SoA [4][nblocks]
+    const T *coef;            // decoded regression coefficients, SoA [4][coef_stride]
+    int64_t coef_stride;      // nblocks, or nblocks rounded up to whole 128-byte lines when the coefficients arrive during the launch
     T eb, recip, mean;
     int cap, radius, use_mean;
     szh_u64 *faceI, *faceJ;   // granule buffers: faceJ [pencil][8 rows][r2][NW], faceI [pencil][9 rows][r2][NW] (row 8 = forwarded corner column)
@@ -274,11 +275,11 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
             if (nbz > 1) nlor[l] = a.blk_lor[b + 1] != 0;
             if (nbz > 2) nnlor[l] = a.blk_lor[b + 2] != 0;
             if (!lor[l]) {
-                ca[l] = B::ld_coef(a.coef + b); cb[l] = B::ld_coef(a.coef + G.nblocks + b); cc[l] = B::ld_coef(a.coef + 2 * G.nblocks + b); cd[l] = B::ld_coef(a.coef + 3 * G.nblocks + b);
+                ca[l] = B::ld_coef(a.coef + b); cb[l] = B::ld_coef(a.coef + a.coef_stride + b); cc[l] = B::ld_coef(a.coef + 2 * a.coef_stride + b); cd[l] = B::ld_coef(a.coef + 3 * a.coef_stride + b);
                 pbase[l] = ca[l] * fii[l] + cb[l] * fjj[l];
             }
             if (!nlor[l]) {
-                na[l] = B::ld_coef(a.coef + b + 1); nb_[l] = B::ld_coef(a.coef + G.nblocks + b + 1); nc[l] = B::ld_coef(a.coef + 2 * G.nblocks + b + 1); nd[l] = B::ld_coef(a.coef + 3 * G.nblocks + b + 1);
+                na[l] = B::ld_coef(a.coef + b + 1); nb_[l] = B::ld_coef(a.coef + a.coef_stride + b + 1); nc[l] = B::ld_coef(a.coef + 2 * a.coef_stride + b + 1); nd[l] = B::ld_coef(a.coef + 3 * a.coef_stride + b + 1);
             }
         }
     }
@@ -568,8 +569,8 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
                             nlor[l] = nnlor[l];
                             const int64_t b = blkrow[l] + bk[l];
                             if (bk[l] + 1 < nbz && !nlor[l]) {
-                                na[l] = B::ld_coef(a.coef + b + 1); nb_[l] = B::ld_coef(a.coef + G.nblocks + b + 1);
-                                nc[l] = B::ld_coef(a.coef + 2 * G.nblocks + b + 1); nd[l] = B::ld_coef(a.coef + 3 * G.nblocks + b + 1);
+                                na[l] = B::ld_coef(a.coef + b + 1); nb_[l] = B::ld_coef(a.coef + a.coef_stride + b + 1);
+                                nc[l] = B::ld_coef(a.coef + 2 * a.coef_stride + b + 1); nd[l] = B::ld_coef(a.coef + 3 * a.coef_stride + b + 1);
                             }
                             nnlor[l] = (bk[l] + 2 < nbz) ? (a.blk_lor[b + 2] != 0) : true;
                         }
@@ -649,9 +650,13 @@ SZH_HD void szh_pencil_run(const szh_qargs<T> &a, int I, int J, const szh_tile_l
         const szh_geom3 &G = a.G;
         const int i1 = 8 * I + 7 < G.g0.count ? 8 * I + 7 : G.g0.count - 1, j1 = 8 * J + 7 < G.g1.count ? 8 * J + 7 : G.g1.count - 1;
         const szh_u64 need = ((szh_u64)szh_blk_of(G.g0, i1) * G.g1.num + szh_blk_of(G.g1, j1) + 1) * (szh_u64)G.g2.num;
+        // the word is {launch epoch << 40 | blocks}: it is written by the host's DMA only and never cleared -- a word that a kernel (a
+        // memset) has stored stays in that XCD's L2, where this wavefront's loads would keep finding the old value
+        const szh_u64 tag = (szh_u64)(a.epoch & 0xffffffu);
+        auto arrived = [&]() { const szh_u64 v = B::ld_sys_u64(a.coef_progress); return (v >> 40) == tag && (v & ((1ull << 40) - 1)) >= need; };
         unsigned spins = 0;
-        while (B::ld_sys_u64(a.coef_progress) < need) {
-            if (++spins > (1u << 23)) { B::st_flag(a.err, 1u); break; }
+        while (!arrived()) {
+            if (++spins > (1u << 22)) { B::st_flag(a.err, 2u); break; }        // 2: the coefficients did not arrive
             if ((spins & 1023u) == 0 && B::ld_flag(a.err) != 0) break;
             B::nap();
         }

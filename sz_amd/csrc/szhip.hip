@@ -40,13 +40,15 @@ struct szhip_ctx {
     // workspaces (grow-only)
     DevBuf lor_bits, reg_flags, reg_rank, coef_compact, in, out, codes_nat, codes_blk, coef, blk_lor, faceI, faceJ, progress, trace, order, small, hist, col_zeros, col_zeros64,
         col_off, partial, samples, unpred, stream_buf, chunk_bits, chunk_off, code_tab, len_tab, dec_tab,
-        starts, ends, counts, offs, dirty, zcnt, zpos, pwr_log, pwr_signs, pwr_small, coef_prog;
+        starts, ends, counts, offs, dirty, zcnt, zpos, pwr_log, pwr_signs, pwr_small, coef_dec;
     void *pinned = nullptr; size_t pinned_cap = 0;
     void *pinned2 = nullptr; size_t pinned2_cap = 0;   // target of the second stream's copies (indicator bits, regression-block count)
     // bulk copies between the caller's pageable arrays and the device: SZH_STAGE_T host threads, two pinned buffers + events each
     void *stage_buf[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
     hipEvent_t stage_ev[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
-    void *pinned3 = nullptr; size_t pinned3_cap = 0;   // the regression coefficients on their way to the host chain and back
+    void *pinned3 = nullptr; size_t pinned3_cap = 0;
+    int streams_independent = -1;                      // -1 not probed yet; 1: work on stream2 proceeds while a kernel on stream is running
+    void *coh = nullptr; size_t coh_cap = 0;           // host-coherent (uncached on the GPU) pinned memory the wavefront kernel reads while the host writes   // the regression coefficients on their way to the host chain and back
     int order_nI = -1, order_nJ = -1;
 };
 
@@ -111,7 +113,46 @@ int ensure_pinned3(szhip_ctx *ctx, size_t bytes)
     return SZHIP_OK;
 }
 
+int ensure_coherent(szhip_ctx *ctx, size_t bytes)
+{
+    if (ctx->coh_cap >= bytes) return SZHIP_OK;
+    if (ctx->coh) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipHostFree(ctx->coh)); ctx->coh = nullptr; ctx->coh_cap = 0; }
+    size_t cap = bytes + bytes / 4 + 4096;
+    HIPCHK(hipHostMalloc(&ctx->coh, cap, hipHostMallocCoherent | hipHostMallocMapped));
+    ctx->coh_cap = cap;
+    return SZHIP_OK;
+}
+
 #define TRY(x) do { int rc_ = (x); if (rc_ != SZHIP_OK) return rc_; } while (0)
+
+enum { SM_MINMAX = 0, SM_WITHIN = 2, SM_MEANCNT = 3, SM_TOTAL_UNPRED = 4, SM_TOTAL_BITS = 5, SM_TICKET = 6, SM_ERR = 7,
+       SM_CHANGED = 8, SM_MEANSUM = 9, SM_TOTAL_SYM = 10, SM_NREG = 11, SM_SCRATCH = 12, SM_COUNT = 16 };
+
+// Does a copy on the second stream complete while a kernel on the first one is still running?  HIP maps streams onto a few hardware
+// queues; two streams of one context can land on the same queue (seen with several contexts + torch in one process), and then anything
+// queued behind a kernel that WAITS for it is a deadlock.  Probed once per context: a kernel on `stream` spins (bounded, ~4 ms) on a
+// host-coherent word; a small copy goes onto `stream2`; if it completes while the kernel is still spinning the queues are independent.
+int probe_streams(szhip_ctx *ctx)
+{
+    if (ctx->streams_independent >= 0) return SZHIP_OK;
+    TRY(ensure_coherent(ctx, 256));
+    TRY(ensure(ctx, ctx->small, SM_COUNT * 8));
+    volatile unsigned long long *flag = (volatile unsigned long long *)((char *)ctx->coh + 128);
+    unsigned long long *src = (unsigned long long *)((char *)ctx->coh + 192);
+    *flag = 0; *src = 1;
+    HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream2));
+    u64 *sm = (u64 *)ctx->small.p;
+    hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(1), 0, ctx->stream, (const unsigned long long *)flag, (unsigned long long *)(sm + SM_SCRATCH));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(sm + SM_SCRATCH + 1, src, 8, hipMemcpyHostToDevice, ctx->stream2));
+    const double t0 = now_ms();
+    HIPCHK(hipStreamSynchronize(ctx->stream2));
+    const double waited = now_ms() - t0;
+    *flag = 1;                                                      // release the kernel
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->streams_independent = waited < 2.0 ? 1 : 0;
+    return SZHIP_OK;
+}
 
 // ---- bulk copies between pageable host memory and the device.
 // hipMemcpyAsync on pageable memory makes the runtime pin and unpin the caller's pages around the transfer: measured on this pool,
@@ -200,8 +241,6 @@ int scan_u64(szhip_ctx *ctx, const u64 *in, int64_t n, u64 *out, u64 *total_dev)
 }
 
 // layout of the "small" device scratch (u64 slots)
-enum { SM_MINMAX = 0, SM_WITHIN = 2, SM_MEANCNT = 3, SM_TOTAL_UNPRED = 4, SM_TOTAL_BITS = 5, SM_TICKET = 6, SM_ERR = 7,
-       SM_CHANGED = 8, SM_MEANSUM = 9, SM_TOTAL_SYM = 10, SM_NREG = 11, SM_SCRATCH = 12, SM_COUNT = 16 };
 
 int choose_segb(const szh_geom3 &G, size_t elem, size_t budget)
 {
@@ -493,9 +532,9 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         HIPCHK(hipGetLastError());
 #ifndef SZH_SYNC_LAUNCH
         overlap = !two_d && tune_int("SZ_HIP_CHAIN_THREADS", 1) && tune_int("SZ_HIP_CHAIN_OVERLAP", 1);
+        if (overlap) { TRY(probe_streams(ctx)); overlap = ctx->streams_independent == 1; }
 #endif
-        // pinned: [4][reg_count] compacted coefficients | (overlap) [4][nb] block-indexed staging | 64 progress words
-        TRY(ensure_pinned3(ctx, reg_count * 4 * sizeof(T) + (overlap ? (size_t)nb * 4 * sizeof(T) + 64 * 8 + 64 : 0)));
+        TRY(ensure_pinned3(ctx, reg_count * 4 * sizeof(T) + (overlap ? ((size_t)nb + 64) * 4 * sizeof(T) + 256 : 0)));
         hcoef = (T *)ctx->pinned3;
         HIPCHK(hipMemcpyAsync(hcoef, ctx->coef_compact.p, reg_count * 4 * sizeof(T), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
@@ -555,7 +594,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     TRY(prepare_pencil(ctx, G, szh_gran<T>::NW, TS::TPI, TS::TPJ, &nI, &nJ, &ntiles));
     {
         szh_qargs<T> a; memset(&a, 0, sizeof(a));
-        a.G = G; a.data = d_in; a.out = nullptr; a.codes = d_nat; a.blk_lor = d_lor; a.coef = d_coef;
+        a.G = G; a.data = d_in; a.out = nullptr; a.codes = d_nat; a.blk_lor = d_lor; a.coef = d_coef; a.coef_stride = nb;
         a.eb = eb; a.recip = 1 / eb; a.mean = mean; a.cap = (int)intervals; a.radius = (int)intervals / 2; a.use_mean = use_mean;
         a.faceI = (szh_u64 *)ctx->faceI.p; a.faceJ = (szh_u64 *)ctx->faceJ.p; a.epoch = ++ctx->epoch;
         a.nI = nI; a.nJ = nJ; a.order = (const unsigned *)ctx->order.p;
@@ -564,10 +603,25 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         a.trace = tune_int("SZ_HIP_TRACE", 0) ? (szh_u64 *)ctx->trace.p : nullptr;
         a.dbg = tune_int("SZ_HIP_DBG", 0); a.trace_tile = tune_int("SZ_HIP_TRACE_TILE", 1);
         a.coef_progress = nullptr;
+        szh_u64 *coh_prog = nullptr;
+        T *dec = nullptr;                                          // the decoded coefficients as the kernel reads them
+        constexpr int64_t LINE = 128 / (int64_t)sizeof(T);         // values per 128-byte cache line
+        const int64_t nbp = (nb + LINE - 1) / LINE * LINE;         // a coefficient's array starts on a line boundary
         if (overlap) {
-            TRY(ensure(ctx, ctx->coef_prog, 64));
-            HIPCHK(hipMemsetAsync(ctx->coef_prog.p, 0, 8, st));
-            a.coef_progress = (const szh_u64 *)ctx->coef_prog.p;
+            // Hand-off between the host's chain and the running kernel (per-XCD L2s are not coherent, and DMA writes do not touch them):
+            //  * the progress word lives in HOST-COHERENT pinned memory (uncached on the GPU; the kernel polls it over PCIe).  In device
+            //    memory a poll leaves the line in that XCD's L2 and every later poll finds the old value -- seen as a pencil that never saw
+            //    the word the memory held.  It carries the launch epoch, so it is never cleared;
+            //  * the coefficients go by DMA into a device buffer that no kernel ever stores to (reading them over PCIe was 45 ms: every lane
+            //    of a block's rows reads them).  A line of it must never be loaded while only part of it is final -- the rest would stay
+            //    stale in that L2 -- so progress is published in whole 128-byte lines of blocks, every coefficient array is line-aligned,
+            //    and a pencil only loads below the published mark.  Lines of an earlier launch are gone at kernel start.
+            TRY(ensure_coherent(ctx, 256));
+            TRY(ensure(ctx, ctx->coef_dec, (size_t)nbp * 4 * sizeof(T)));
+            coh_prog = (szh_u64 *)ctx->coh;
+            dec = (T *)ctx->coef_dec.p;
+            a.coef_progress = coh_prog;
+            a.coef = dec; a.coef_stride = nbp;
         }
         HIPCHK(hipEventRecord(ctx->ev[2], st));
         hipLaunchKernelGGL((k_pencil<T, false>), dim3((unsigned)ntiles), dim3((TS::TPI * TS::TPJ + 2) * 64), 0, st, a);
@@ -581,24 +635,31 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
             // array, the contiguous block range [first, last] of each coefficient into d_coef, then the progress word (same stream: it
             // lands after the data).  Blocks between regression blocks are Lorenzo blocks: whatever they receive is never read.
             const double h1 = now_ms();
-            T *const full = hcoef + reg_count * 4;
-            szh_u64 *const prog_h = (szh_u64 *)(((uintptr_t)(full + (size_t)nb * 4) + 63) & ~(uintptr_t)63);
-            const size_t chunk = std::max<size_t>(4096, reg_count / 24);
-            size_t shipped = 0; int slot = 0, idle = 0;
-            while (shipped < reg_count) {
+            const szh_u64 tag = (szh_u64)(a.epoch & 0xffffffu) << 40;
+            T *const full = (T *)(((uintptr_t)(hcoef + reg_count * 4) + 127) & ~(uintptr_t)127);     // pinned staging, [4][nbp] block-indexed
+            const size_t chunk = std::max<size_t>(2048, reg_count / 32);
+            size_t shipped = 0; int64_t sent = 0;                 // ranks scattered into the staging array; blocks [0, sent) are on the device
+            int idle = 0;
+            while (sent < nb) {
                 size_t p = reg_count;
                 for (int e = 0; e < ncoef; ++e) { const size_t d = __atomic_load_n(&chain_done[e], __ATOMIC_ACQUIRE); if (d < p) p = d; }
                 if (p > shipped && (p - shipped >= chunk || p == reg_count)) {
-                    const size_t b_lo = blk_of_rank[shipped], b_hi = blk_of_rank[p - 1];
-                    for (int e = 0; e < ncoef; ++e) {
-                        for (size_t r = shipped; r < p; ++r) full[(size_t)e * nb + blk_of_rank[r]] = hcoef[(size_t)e * reg_count + r];
-                        HIPCHK(hipMemcpyAsync(d_coef + (size_t)e * nb + b_lo, full + (size_t)e * nb + b_lo, (b_hi - b_lo + 1) * sizeof(T), hipMemcpyHostToDevice, ctx->stream2));
+                    for (int e = 0; e < ncoef; ++e)
+                        for (size_t r = shipped; r < p; ++r) full[(size_t)e * nbp + blk_of_rank[r]] = hcoef[(size_t)e * reg_count + r];
+                    shipped = p;
+                    // every block below `fin` is final; whole lines of them travel
+                    const int64_t fin = p == reg_count ? nb : (int64_t)blk_of_rank[p];
+                    const int64_t upto = fin == nb ? nb : fin / LINE * LINE;
+                    if (upto > sent) {
+                        for (int e = 0; e < ncoef; ++e)
+                            HIPCHK(hipMemcpyAsync(dec + (size_t)e * nbp + sent, full + (size_t)e * nbp + sent, (size_t)(upto - sent) * sizeof(T), hipMemcpyHostToDevice, ctx->stream2));
+                        HIPCHK(hipStreamSynchronize(ctx->stream2));            // the values are in device memory ...
+                        __atomic_store_n(coh_prog, tag | (szh_u64)upto, __ATOMIC_RELEASE);   // ... before the kernel may look for them
+                        sent = upto;
                     }
-                    prog_h[slot] = p == reg_count ? (szh_u64)nb : (szh_u64)blk_of_rank[p];     // every block below this index is final
-                    HIPCHK(hipMemcpyAsync(ctx->coef_prog.p, &prog_h[slot], 8, hipMemcpyHostToDevice, ctx->stream2));
-                    slot = (slot + 1) & 63; shipped = p; idle = 0;
+                    idle = 0;
                 } else if (++idle > 200000) FAIL(SZHIP_ERR_INTERNAL, "coefficient chain made no progress");
-                else std::this_thread::sleep_for(std::chrono::microseconds(20));
+                else std::this_thread::sleep_for(std::chrono::microseconds(10));
             }
             host_ms += now_ms() - h1;
             TP("coefficients shipped");
@@ -757,6 +818,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     if (tp_on) { for (int i = 0; i < tp_k; ++i) fprintf(stderr, "%s %.2f | ", tp_n[i], tp_t[i]); fprintf(stderr, "\n"); }
     // after the final synchronisation: the wavefront kernel's error flag; the shuffled bit count and the device's count of zero codes
     // must match what the histogram predicted
+    if ((unsigned)h_small[SM_ERR] == 2) FAIL(SZHIP_ERR_INTERNAL, "wavefront kernel: the regression coefficients did not arrive");
     if ((unsigned)h_small[SM_ERR] != 0) FAIL(SZHIP_ERR_INTERNAL, "wavefront kernel: halo wait timed out");
     if ((total_bits > 0 && h_small[SM_TOTAL_BITS] != total_bits) || h_small[SM_TOTAL_UNPRED] != total_unpred)
         FAIL(SZHIP_ERR_INTERNAL, "entropy stage mismatch (bits %llu vs %llu, unpredictable %llu vs %llu)", (unsigned long long)h_small[SM_TOTAL_BITS],
@@ -1054,7 +1116,7 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
     TRY(prepare_pencil(ctx, G, szh_gran<T>::NW, TS::TPI, TS::TPJ, &nI, &nJ, &ntiles));
     {
         szh_qargs<T> a; memset(&a, 0, sizeof(a));
-        a.G = G; a.data = nullptr; a.out = d_out; a.codes = d_nat; a.blk_lor = (const uint8_t *)ctx->blk_lor.p; a.coef = (const T *)ctx->coef.p;
+        a.G = G; a.data = nullptr; a.out = d_out; a.codes = d_nat; a.blk_lor = (const uint8_t *)ctx->blk_lor.p; a.coef = (const T *)ctx->coef.p; a.coef_stride = nb;
         a.eb = eb; a.recip = 1 / eb; a.mean = mean; a.cap = (int)intervals; a.radius = (int)intervals / 2; a.use_mean = use_mean;
         a.faceI = (szh_u64 *)ctx->faceI.p; a.faceJ = (szh_u64 *)ctx->faceJ.p; a.epoch = ++ctx->epoch;
         a.nI = nI; a.nJ = nJ; a.order = (const unsigned *)ctx->order.p;
@@ -1121,7 +1183,7 @@ int launch_pencil14(szhip_ctx *ctx, const szh_geom3 &G, u64 *sm, bool dec, const
     using TS = szh_tile_shape<T>;
     TRY(prepare_pencil(ctx, G, szh_gran<T>::NW, TS::TPI, TS::TPJ, &nI, &nJ, &ntiles));
     szh_qargs<T> a; memset(&a, 0, sizeof(a));
-    a.G = G; a.data = d_in; a.out = d_out; a.codes = d_codes; a.blk_lor = nullptr; a.coef = nullptr;
+    a.G = G; a.data = d_in; a.out = d_out; a.codes = d_codes; a.blk_lor = nullptr; a.coef = nullptr; a.coef_stride = 0;
     a.eb = eb; a.recip = 1 / eb; a.mean = 0; a.cap = (int)intervals; a.radius = (int)intervals / 2; a.use_mean = 0;
     a.fmt = 1; a.median = median; a.ign_bits = ign_bits;
     a.faceI = (szh_u64 *)ctx->faceI.p; a.faceJ = (szh_u64 *)ctx->faceJ.p; a.epoch = ++ctx->epoch;
@@ -1916,11 +1978,12 @@ void szhip_destroy(szhip_ctx *ctx)
                       &ctx->order, &ctx->small, &ctx->hist, &ctx->col_zeros, &ctx->col_zeros64, &ctx->col_off, &ctx->partial,
                       &ctx->samples, &ctx->unpred, &ctx->stream_buf, &ctx->chunk_bits, &ctx->chunk_off, &ctx->code_tab,
                       &ctx->len_tab, &ctx->dec_tab, &ctx->starts, &ctx->ends, &ctx->counts, &ctx->offs, &ctx->dirty, &ctx->zcnt, &ctx->zpos,
-                      &ctx->pwr_log, &ctx->pwr_signs, &ctx->pwr_small, &ctx->coef_prog};
+                      &ctx->pwr_log, &ctx->pwr_signs, &ctx->pwr_small, &ctx->coef_dec};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
     if (ctx->pinned) hipHostFree(ctx->pinned);
     if (ctx->pinned2) hipHostFree(ctx->pinned2);
     if (ctx->pinned3) hipHostFree(ctx->pinned3);
+    if (ctx->coh) hipHostFree(ctx->coh);
     for (int w = 0; w < 4; ++w) for (int k = 0; k < 2; ++k) { if (ctx->stage_buf[w][k]) hipHostFree(ctx->stage_buf[w][k]); if (ctx->stage_ev[w][k]) hipEventDestroy(ctx->stage_ev[w][k]); }
     for (int i = 0; i < 6; ++i) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
     if (ctx->ev_in) hipEventDestroy(ctx->ev_in);

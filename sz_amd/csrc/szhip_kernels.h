@@ -1298,5 +1298,14 @@ __global__ __launch_bounds__(256) void k_exact_build(const uint8_t *__restrict__
 }
 
 // ------------------------------------------------------------------ the opt-in fast mode (feedback-free; own container)
+// One-time probe of a context (szhip.hip: streams_independent): spins on a host-coherent word until the host sets it or ~4 ms pass
+__global__ void k_probe_wait(const unsigned long long *flag, unsigned long long *saw)
+{
+    const long long t0 = wall_clock64();                           // 100 MHz
+    unsigned long long v = 0;
+    while ((v = __hip_atomic_load(const_cast<unsigned long long *>(flag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) == 0 && wall_clock64() - t0 < 400000) __builtin_amdgcn_s_sleep(40);
+    *saw = v;
+}
+
 #include "szh_fast.h"
 #include "szh_pwr.h"

@@ -117,6 +117,8 @@ typedef void *hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
 #define hipStreamNonBlocking 1
 #define hipHostMallocDefault 0
+#define hipHostMallocCoherent 0x40000000
+#define hipHostMallocMapped 0x2
 inline const char *hipGetErrorString(hipError_t) { return "hipsim"; }
 inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }

@@ -97,7 +97,7 @@ static int quantize(const T *data, int r0, int r1, int r2, double eb, int cap, i
 {
     szh_qargs<T> a; memset(&a, 0, sizeof(a));
     a.G = szh_make_geom3(r0, r1, r2);
-    a.data = data; a.codes = codes_nat; a.blk_lor = blk_lor; a.coef = coef;
+    a.data = data; a.codes = codes_nat; a.blk_lor = blk_lor; a.coef = coef; a.coef_stride = a.G.nblocks;
     a.eb = (T)eb; a.recip = 1 / a.eb; a.mean = (T)mean; a.cap = cap; a.radius = cap / 2; a.use_mean = use_mean;
     return run_all<T, false>(a);
 }
@@ -107,7 +107,7 @@ static int reconstruct(T *out, int r0, int r1, int r2, double eb, int cap, int u
 {
     szh_qargs<T> a; memset(&a, 0, sizeof(a));
     a.G = szh_make_geom3(r0, r1, r2);
-    a.out = out; a.codes = const_cast<uint16_t *>(codes_nat); a.blk_lor = blk_lor; a.coef = coef;
+    a.out = out; a.codes = const_cast<uint16_t *>(codes_nat); a.blk_lor = blk_lor; a.coef = coef; a.coef_stride = a.G.nblocks;
     a.eb = (T)eb; a.recip = 1 / a.eb; a.mean = (T)mean; a.cap = cap; a.radius = cap / 2; a.use_mean = use_mean;
     return run_all<T, true>(a);
 }
