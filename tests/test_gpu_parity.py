@@ -544,3 +544,28 @@ def test_config1_through_a_plain_c_caller(built, anchors, tmp_path):
     nz = ori != 0
     assert vals.size == ori.size and float((np.abs(vals[nz] - ori[nz]) / np.abs(ori[nz])).max()) <= 1e-2
     assert "2.1.12" in subprocess.check_output([cli, "-v"]).decode()
+
+
+def test_coefficient_hand_off_with_alternating_inputs(sz, oracle):
+    """The coefficient chain runs next to the wavefront kernel and ships decoded coefficients into a buffer the kernel reads meanwhile
+    (DESIGN section 8).  Two different arrays of one shape alternate through ONE context: a coefficient line left in an L2 by the previous
+    launch, or a progress word of the previous launch, would give the other array's codes.  Small arrays on purpose: nothing evicts a
+    stale line there."""
+    import torch
+    from sz_amd.fields import m_field
+    ctx = sz.HipContext(0)
+    for dtype, eb in ((np.float32, 1e-4), (np.float64, 1e-5)):
+        d1 = m_field(48, dtype)
+        d2 = np.ascontiguousarray((m_field(48, dtype)[::-1] * dtype(1.7) + dtype(0.3)).astype(dtype))
+        refs = []
+        for d in (d1, d2):
+            ref, st = oracle.compress(d, oracle.ABS, eb, want_stages=True)
+            assert st["reg_count"] > 100
+            refs.append((d, ref, torch.from_numpy(d).cuda()))
+        assert refs[0][1] != refs[1][1]
+        for k in range(8):
+            d, ref, x = refs[k & 1]
+            meta = ref[:4 + (28 if dtype == np.float32 else 36)]
+            got, n, stats = ctx.compress(x.data_ptr(), True, d.shape, d.dtype, eb, meta)
+            assert got == ref, (str(dtype), k)
+    ctx.close()
