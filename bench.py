@@ -274,6 +274,49 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
                              "algorithmic_bytes_per_launch": falg, "avg_kernel_ms": round(fq_ms, 4),
                              "note": "algorithmic bytes = 4 N read + 2 N codes written"}}
 
+    # ---- the other paths of the same library, one line each (optional; outside the timed region; single GPU only): the SZ 1.4 container
+    #      (withLinearRegression = NO) on the same array, a 2-D array through the SZ 2.1 path, a 1-D series
+    other = None
+    if args.other_paths and world == 1 and n == EDGE:
+        def timed(fn, reps=3):
+            fn(); torch.cuda.synchronize(); t = time.perf_counter()
+            for _ in range(reps):
+                r = fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / reps, r
+
+        def run(fn_name, ptr, dims, extra, mbytes, eb=EB):
+            out = ctypes.c_void_p(out_bufs[0].data_ptr()); nn = ctypes.c_size_t(out_cap); st = sz_amd.szhip_stats()
+            p = sz_amd.szhip_params(100, 0.99, 65536, 0, 0)
+            rc = getattr(sz_amd.lib(), fn_name)(ctx._h, 0, ptr, 1, *dims, eb, *extra, ctypes.byref(p), mbytes, len(mbytes), 2,
+                                                ctypes.byref(out), ctypes.byref(nn), ctypes.byref(st))
+            if rc:
+                raise RuntimeError(f"{fn_name} failed: {sz_amd.lib().szhip_last_error(ctx._h)}")
+            return nn.value
+        vmin, vmax = ctx.minmax(x.data_ptr(), True, x.numel(), np.float32)
+        rng = vmax - vmin
+        med = float(np.float32(np.float32(vmin) + np.float32(rng) / np.float32(2)))
+        meta0 = sz_amd.make_meta(np.float32, err_mode=sz_amd.ABS, abs_bound=EB, vmin=vmin, vmax=vmax)
+        meta14 = bytes([meta0[0], meta0[1], meta0[2], 0x40]) + bytes(meta0[4:])
+        t14, size14 = timed(lambda: run("szhip_compress_sz14", x.data_ptr(), (n, n, n), (float(np.float32(rng)), med), meta14))
+        from sz_amd.fields import plane_field
+        p2 = torch.from_numpy(plane_field(4096, 4096)).to(dev)
+        meta2 = sz_amd.make_meta(np.float32, err_mode=sz_amd.ABS, abs_bound=EB, vmin=float(p2.min().item()), vmax=float(p2.max().item()))
+        t2, size2 = timed(lambda: run("szhip_compress", p2.data_ptr(), (0, 4096, 4096), (), meta2))
+        g = torch.Generator(device="cpu"); g.manual_seed(1)
+        s1 = (torch.cumsum(torch.randn(1 << 24, generator=g, dtype=torch.float64), 0) * 0.01
+              + torch.sin(torch.arange(1 << 24, dtype=torch.float64) * 0.003)).to(torch.float32).to(dev)
+        lo1, hi1 = float(s1.min().item()), float(s1.max().item())
+        rng1 = float(np.float32(np.float32(hi1) - np.float32(lo1)))
+        med1 = float(np.float32(np.float32(lo1) + np.float32(rng1) / np.float32(2)))
+        m1 = sz_amd.make_meta(np.float32, err_mode=sz_amd.ABS, abs_bound=1e-3, vmin=lo1, vmax=hi1)
+        m1 = bytes([m1[0], m1[1], m1[2], 0x40]) + bytes(m1[4:])
+        t1d, size1d = timed(lambda: run("szhip_compress_sz14", s1.data_ptr(), (0, 0, 1 << 24), (rng1, med1), m1, eb=1e-3))
+        other = {"sz14_3d_512_f32": {"GB/s": round(nbytes_in / t14 / 1e9, 2), "ms": round(t14 * 1e3, 3), "out_bytes": size14},
+                 "sz21_2d_4096x4096_f32": {"GB/s": round(p2.numel() * 4 / t2 / 1e9, 2), "ms": round(t2 * 1e3, 3), "out_bytes": size2},
+                 "sz14_1d_16Mi_f32_abs1e-3": {"GB/s": round(s1.numel() * 4 / t1d / 1e9, 2), "ms": round(t1d * 1e3, 3), "out_bytes": size1d}}
+        del p2, s1
+
     # ---- host-pointer API, PCIe included (never the headline value)
     e2e = None
     if world == 1 and n == EDGE:
@@ -323,7 +366,7 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
             "phase_ms": {"caller_glue": round(ms_per_step - stats.ms_total, 3), "prequant": round(stats.ms_prequant, 3), "quant": round(stats.ms_quant, 3),
                          "entropy": round(stats.ms_entropy, 3), "host_glue": round(stats.ms_host, 3), "compress_call_total": round(stats.ms_total, 3),
                          "decompress_quant": round(dst.ms_quant, 3), "decompress_total": round(dst.ms_total, 3)},
-            "roofline": roofline, "m_field": mfield, "fast_mode": fast, "e2e": e2e, "cpu_baseline": cpu, "cpu_baseline_mt": cpu_mt}
+            "roofline": roofline, "m_field": mfield, "fast_mode": fast, "other_paths": other, "e2e": e2e, "cpu_baseline": cpu, "cpu_baseline_mt": cpu_mt}
     print(json.dumps(line))
     if world > 1:
         dist.barrier(); dist.destroy_process_group()
@@ -429,6 +472,7 @@ def main():
     ap.add_argument("--edge", type=int, default=EDGE, help="cube edge of the headline config (512 = the BASELINE config)")
     ap.add_argument("--c4-edge", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--other-paths", action="store_true", help="also time the SZ 1.4 container, a 2-D array and a 1-D series (one line each)")
     ap.add_argument("--no-fast", action="store_true", help="skip the opt-in fast-mode object")
     ap.add_argument("--no-m-field", action="store_true")
     args = ap.parse_args()
