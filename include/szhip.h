@@ -63,6 +63,8 @@ typedef struct szhip_stats {
     uint64_t out_bytes;
     uint64_t quant_kernel_launches; /* launches of the wavefront kernel (1 per call) */
     double vmin, vmax;      /* the array's range when SZHIP_RANGE_FROM_DATA was set (else 0) */
+    int chain_overlapped;   /* 1: the regression-coefficient chain ran next to the wavefront kernel */
+    int reserved_;
 } szhip_stats;
 
 int  szhip_create(szhip_ctx **ctx, int device);

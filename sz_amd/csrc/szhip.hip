@@ -662,6 +662,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
                 else std::this_thread::sleep_for(std::chrono::microseconds(10));
             }
             host_ms += now_ms() - h1;
+            S.chain_overlapped = 1;
             TP("coefficients shipped");
         }
     }

@@ -568,4 +568,12 @@ def test_coefficient_hand_off_with_alternating_inputs(sz, oracle):
             meta = ref[:4 + (28 if dtype == np.float32 else 36)]
             got, n, stats = ctx.compress(x.data_ptr(), True, d.shape, d.dtype, eb, meta)
             assert got == ref, (str(dtype), k)
+        # the same through the process's first context (the SZ_* API's): its two streams are the likeliest to sit on separate hardware
+        # queues, which the overlapped form needs (a context whose streams share a queue falls back to the serial order by itself)
+        overlapped = []
+        for k in range(6):
+            d, ref, x = refs[k & 1]
+            assert sz.SZ_compress_args(d, sz.ABS, eb) == ref, (str(dtype), "api", k)
+            overlapped.append(sz.SZ_hip_last_stats().chain_overlapped)
+        print("chain overlapped:", overlapped)
     ctx.close()
