@@ -514,6 +514,15 @@ def test_differential_fuzz_sz14_against_the_oracle(built):
     assert tail and tail[-1].startswith("fuzz: 300 cases, 0 failures"), "\n".join(tail[-10:]) + out.stderr[-2000:]
 
 
+def test_fuzz_pw_rel_and_fast_mode(built):
+    """random differential cases for the two paths added in round 2: point-wise relative bounds (log-domain form) and the opt-in fast mode"""
+    import subprocess
+    for args in (("300", "41", "pwr"), ("300", "43", "fast")):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_fuzz.py"), *args], capture_output=True, text=True, timeout=600)
+        tail = [ln for ln in out.stdout.splitlines() if ln.startswith("fuzz:") or ln.startswith("FAIL")]
+        assert tail and tail[-1].startswith("fuzz: 300 cases, 0 failures"), "\n".join(tail[-10:]) + out.stderr[-2000:]
+
+
 def test_config1_through_a_plain_c_caller(built, anchors, tmp_path):
     """BASELINE configs[0] plumbing: a C program that only knows include/sz.h + include/rw.h (examples/sz_cli.c, the option
     letters of the reference's `sz` tool) compresses example/testdata's 8x8x128 float file with ABS 1e-4 and reproduces the

@@ -15,6 +15,8 @@ ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 sz14 = len(sys.argv) > 3 and sys.argv[3] == "sz14"      # withLinearRegression = NO: the SZ 1.4 path
 pwr = len(sys.argv) > 3 and sys.argv[3] == "pwr"
+fast = len(sys.argv) > 3 and sys.argv[3] == "fast"        # the opt-in fast mode against oracle/szo_fast.c
+fctx = sz_amd.HipContext(0) if fast else None
 oparams = O.default_params(with_regression=0) if sz14 else None
 if sz14: sz_amd.conf_params().withRegression = 0
 fails = 0
@@ -50,6 +52,29 @@ for c in range(ncases):
     d = np.ascontiguousarray(d)
     if two_d: d = d.reshape(shape[1], shape[2])
     if one_d: d = d.reshape(shape[2])
+    if fast:
+        import ctypes
+        eb = float(10.0 ** rng.uniform(-5, -1)) * max(float(d.max()) - float(d.min()), 1e-6)
+        iv = int(rng.choice([0, 0, 64, 256, 4096]))
+        if rng.random() < 0.2: d.reshape(-1)[rng.integers(0, d.size, size=3)] = dt(1e30)
+        d3 = np.ascontiguousarray(d.reshape((1,) * (3 - d.ndim) + d.shape))
+        try:
+            ref = O.fast_compress(d, eb, iv)
+            got, n, st = fctx.compress_fast(d3.ctypes.data, False, d3.shape, d.dtype, eb, iv)
+            out = np.empty_like(d3)
+            buf = ctypes.create_string_buffer(ref, len(ref))
+            fctx.decompress_fast(ctypes.addressof(buf), False, len(ref), d3.shape, d.dtype, out.ctypes.data, False)
+            ivw = np.uint32 if dt == np.float32 else np.uint64
+            okd = np.array_equal(out.reshape(d.shape).view(ivw), O.fast_decompress(ref, d.shape, d.dtype).view(ivw))
+            fin = np.isfinite(d)
+            okb = float(np.abs(out.reshape(d.shape).astype(np.float64)[fin] - d.astype(np.float64)[fin]).max()) <= float(dt(eb))
+            if not (got == ref and okd and okb):
+                fails += 1
+                print(f"FAIL fast case={c} seed0={seed0} dtype={np.dtype(dt).name} shape={d.shape} eb={eb:.3e} intervals={iv} stream_ok={got == ref} dec_ok={okd} bound_ok={okb}")
+        except Exception as e:  # noqa
+            fails += 1
+            print("case", c, "EXCEPTION", repr(e))
+        continue
     if pwr:
         sgn = rng.random()
         mag = np.exp(rng.uniform(0.5, 4.0) * d.astype(np.float64) / max(float(np.abs(d).max()), 1e-30) + 0.05 * rng.standard_normal(d.shape))
