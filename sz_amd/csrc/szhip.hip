@@ -785,10 +785,10 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         const int64_t nchunks = (n + SZH_ENC_CHUNK - 1) / SZH_ENC_CHUNK;
         TRY(ensure(ctx, ctx->chunk_bits, (size_t)nchunks * 8));
         TRY(ensure(ctx, ctx->chunk_off, (size_t)nchunks * 8));
-        hipLaunchKernelGGL(k_chunk_bits, dim3((unsigned)nchunks), dim3(256), 0, st, (const uint16_t *)d_blk, n, (const uint8_t *)ctx->len_tab.p,
+        hipLaunchKernelGGL(k_chunk_bits, dim3((unsigned)((nchunks + SZH_CB_PER - 1) / SZH_CB_PER)), dim3(256), 0, st, (const uint16_t *)d_blk, n, (const uint8_t *)ctx->len_tab.p,
                            intervals, (u64 *)ctx->chunk_bits.p);
         TRY(scan_u64(ctx, (const u64 *)ctx->chunk_bits.p, nchunks, (u64 *)ctx->chunk_off.p, sm + SM_TOTAL_BITS));
-        hipLaunchKernelGGL(k_encode, dim3((unsigned)nchunks), dim3(256), 0, st, (const uint16_t *)d_blk, n, (const u64 *)ctx->code_tab.p,
+        hipLaunchKernelGGL(k_encode, dim3((unsigned)((nchunks + SZH_ENC_PER - 1) / SZH_ENC_PER)), dim3(256), 0, st, (const uint16_t *)d_blk, n, (const u64 *)ctx->code_tab.p,
                            (const uint8_t *)ctx->len_tab.p, intervals, (const u64 *)ctx->chunk_off.p, (u64)(hdr_len + unpred_bytes) * 8,
                            (unsigned *)d_stream);
         HIPCHK(hipGetLastError());
@@ -1402,10 +1402,10 @@ int compress14_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t
         const int64_t nchunks = (n + SZH_ENC_CHUNK - 1) / SZH_ENC_CHUNK;
         TRY(ensure(ctx, ctx->chunk_bits, (size_t)nchunks * 8));
         TRY(ensure(ctx, ctx->chunk_off, (size_t)nchunks * 8));
-        hipLaunchKernelGGL(k_chunk_bits, dim3((unsigned)nchunks), dim3(256), 0, st, (const uint16_t *)d_codes, n, (const uint8_t *)ctx->len_tab.p,
+        hipLaunchKernelGGL(k_chunk_bits, dim3((unsigned)((nchunks + SZH_CB_PER - 1) / SZH_CB_PER)), dim3(256), 0, st, (const uint16_t *)d_codes, n, (const uint8_t *)ctx->len_tab.p,
                            intervals, (u64 *)ctx->chunk_bits.p);
         TRY(scan_u64(ctx, (const u64 *)ctx->chunk_bits.p, nchunks, (u64 *)ctx->chunk_off.p, sm + SM_TOTAL_BITS));
-        hipLaunchKernelGGL(k_encode, dim3((unsigned)nchunks), dim3(256), 0, st, (const uint16_t *)d_codes, n, (const u64 *)ctx->code_tab.p,
+        hipLaunchKernelGGL(k_encode, dim3((unsigned)((nchunks + SZH_ENC_PER - 1) / SZH_ENC_PER)), dim3(256), 0, st, (const uint16_t *)d_codes, n, (const u64 *)ctx->code_tab.p,
                            (const uint8_t *)ctx->len_tab.p, intervals, (const u64 *)ctx->chunk_off.p, (u64)hdr_len * 8, (unsigned *)d_stream);
         HIPCHK(hipGetLastError());
     }
@@ -1784,10 +1784,10 @@ int compress_fast_impl(szhip_ctx *ctx, const void *data, int data_on_device, siz
         HIPCHK(hipGetLastError());
     }
     if (total_bits > 0) {
-        hipLaunchKernelGGL(k_chunk_bits, dim3((unsigned)nchunks), dim3(256), 0, st, (const uint16_t *)d_codes, n, (const uint8_t *)ctx->len_tab.p,
+        hipLaunchKernelGGL(k_chunk_bits, dim3((unsigned)((nchunks + SZH_CB_PER - 1) / SZH_CB_PER)), dim3(256), 0, st, (const uint16_t *)d_codes, n, (const uint8_t *)ctx->len_tab.p,
                            intervals, (u64 *)ctx->chunk_bits.p);
         TRY(scan_u64(ctx, (const u64 *)ctx->chunk_bits.p, nchunks, (u64 *)ctx->chunk_off.p, sm + SM_TOTAL_BITS));
-        hipLaunchKernelGGL(k_encode, dim3((unsigned)nchunks), dim3(256), 0, st, (const uint16_t *)d_codes, n, (const u64 *)ctx->code_tab.p,
+        hipLaunchKernelGGL(k_encode, dim3((unsigned)((nchunks + SZH_ENC_PER - 1) / SZH_ENC_PER)), dim3(256), 0, st, (const uint16_t *)d_codes, n, (const u64 *)ctx->code_tab.p,
                            (const uint8_t *)ctx->len_tab.p, intervals, (const u64 *)ctx->chunk_off.p, (u64)pay_off * 8, (unsigned *)d_stream);
         HIPCHK(hipGetLastError());
     }

@@ -927,25 +927,42 @@ __device__ __forceinline__ void enc_load8(const uint16_t *__restrict__ codes, in
     if (t0 + 8 <= n) { const uint4 w = *reinterpret_cast<const uint4 *>(codes + t0); __builtin_memcpy(c, &w, 16); }
     else { for (int q = 0; q < 8; ++q) c[q] = t0 + q < n ? codes[t0 + q] : (uint16_t)0; }
 }
+// SZH_CB_PER chunks per workgroup, their code vectors requested together: with one chunk (one 16-byte load per thread) per workgroup the pass
+// was bound by one memory round trip per workgroup residency (90 us for 268 MB)
+#define SZH_CB_PER 4
 __global__ __launch_bounds__(256) void k_chunk_bits(const uint16_t *__restrict__ codes, int64_t n, const uint8_t *__restrict__ len, unsigned nsym,
                                                     u64 *chunk_bits)
 {
-    __shared__ u64 sh[8];
+    __shared__ u64 sh[SZH_CB_PER][4];
     __shared__ uint8_t llen[SZH_ENC_TAB];
     const bool tab_lds = nsym <= SZH_ENC_TAB;
     if (tab_lds) { for (unsigned i = threadIdx.x; i < nsym; i += 256) llen[i] = len[i]; __syncthreads(); }
-    const int64_t t0 = (int64_t)blockIdx.x * SZH_ENC_CHUNK + threadIdx.x * 8;
-    uint16_t c[8];
-    enc_load8(codes, t0, n, c);
-    unsigned s = 0;
-    for (int q = 0; q < 8; ++q) if (t0 + q < n) s += tab_lds ? llen[c[q]] : len[c[q]];
-    u64 ws = wave_sum_u64((u64)s);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ws;
+    const int64_t chunk0 = (int64_t)blockIdx.x * SZH_CB_PER;
+    const int64_t nchunks = (n + SZH_ENC_CHUNK - 1) / SZH_ENC_CHUNK;
+    uint16_t c[SZH_CB_PER][8];
+#pragma unroll
+    for (int q = 0; q < SZH_CB_PER; ++q) {
+        const int64_t t0 = (chunk0 + q) * SZH_ENC_CHUNK + threadIdx.x * 8;
+        if (t0 < n) enc_load8(codes, t0, n, c[q]);
+        else { for (int e = 0; e < 8; ++e) c[q][e] = 0; }
+    }
+#pragma unroll
+    for (int q = 0; q < SZH_CB_PER; ++q) {
+        const int64_t t0 = (chunk0 + q) * SZH_ENC_CHUNK + threadIdx.x * 8;
+        unsigned s = 0;
+        for (int e = 0; e < 8; ++e) if (t0 + e < n) s += tab_lds ? llen[c[q][e]] : len[c[q][e]];
+        const u64 ws = wave_sum_u64((u64)s);
+        if ((threadIdx.x & 63) == 0) sh[q][threadIdx.x >> 6] = ws;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) chunk_bits[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+    if (threadIdx.x < SZH_CB_PER && chunk0 + threadIdx.x < nchunks) chunk_bits[chunk0 + threadIdx.x] = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
 }
 
 // out32: 4-byte aligned base of the stream buffer; bit0: bit position of the payload start in that buffer
+// SZH_ENC_PER consecutive chunks per workgroup: the code vectors and bit offsets of all of them are requested before the first is packed,
+// the code tables are staged once, and the chunks are packed one after the other through the same LDS buffer.  (One chunk per workgroup
+// paid a table stage and a memory round trip per 4 KB of codes.)
+#define SZH_ENC_PER 4
 __global__ __launch_bounds__(256) void k_encode(const uint16_t *__restrict__ codes, int64_t n, const u64 *__restrict__ code,
                                                 const uint8_t *__restrict__ len, unsigned nsym, const u64 *__restrict__ chunk_off, u64 bit0,
                                                 unsigned *out32)
@@ -955,40 +972,55 @@ __global__ __launch_bounds__(256) void k_encode(const uint16_t *__restrict__ cod
     __shared__ u64 lcode[SZH_ENC_TAB];
     __shared__ uint8_t llen[SZH_ENC_TAB];
     const bool tab_lds = nsym <= SZH_ENC_TAB;
-    if (tab_lds) { for (unsigned i = threadIdx.x; i < nsym; i += 256) { lcode[i] = code[i]; llen[i] = len[i]; } __syncthreads(); }
-    const u64 gbit = bit0 + chunk_off[blockIdx.x];
-    const unsigned lead = (unsigned)(gbit & 31);
-    const int64_t t0 = (int64_t)blockIdx.x * SZH_ENC_CHUNK + threadIdx.x * 8;
-    uint16_t c[8]; unsigned l[8]; unsigned s = 0;
-    enc_load8(codes, t0, n, c);
-    for (int q = 0; q < 8; ++q) {
-        l[q] = t0 + q < n ? (tab_lds ? (unsigned)llen[c[q]] : (unsigned)len[c[q]]) : 0u;
-        s += l[q];
+    if (tab_lds) { for (unsigned i = threadIdx.x; i < nsym; i += 256) { lcode[i] = code[i]; llen[i] = len[i]; } }
+    const int64_t nchunks = (n + SZH_ENC_CHUNK - 1) / SZH_ENC_CHUNK;
+    const int64_t chunk0 = (int64_t)blockIdx.x * SZH_ENC_PER;
+    uint16_t cc[SZH_ENC_PER][8]; u64 goff[SZH_ENC_PER];
+#pragma unroll
+    for (int k = 0; k < SZH_ENC_PER; ++k) {
+        const int64_t t0 = (chunk0 + k) * SZH_ENC_CHUNK + threadIdx.x * 8;
+        if (t0 < n) enc_load8(codes, t0, n, cc[k]);
+        else { for (int q = 0; q < 8; ++q) cc[k][q] = 0; }
+        goff[k] = chunk0 + k < nchunks ? chunk_off[chunk0 + k] : 0;
     }
-    u64 tot;
-    const u64 ex = block_excl_scan_256((u64)s, sh, &tot);
-    // only the words this chunk fills are cleared (a chunk of the S-field fills ~160 of the 4098)
-    for (unsigned w = threadIdx.x; w < (unsigned)((lead + tot + 31) >> 5) + 1; w += 256) buf[w] = 0;
     __syncthreads();
-    // a thread's eight codes are consecutive in the stream: they are concatenated in a register and reach LDS as one or two ORs
-    // (one atomic per code meant a dozen lanes hitting the same word)
-    unsigned pos = lead + (unsigned)ex;
-    u64 acc = 0; int accn = 0;
-    for (int q = 0; q < 8; ++q) {
-        if (!l[q]) continue;
-        const u64 cw = tab_lds ? lcode[c[q]] : code[c[q]];
-        if (accn + (int)l[q] > 64) { lds_put_bits(buf, pos, acc, accn); pos += accn; acc = 0; accn = 0; }
-        acc = l[q] == 64 ? cw : ((acc << l[q]) | (cw & ((1ull << l[q]) - 1)));
-        accn += (int)l[q];
-    }
-    if (accn) lds_put_bits(buf, pos, acc, accn);
-    __syncthreads();
-    const unsigned nwords = (unsigned)((lead + tot + 31) >> 5);
-    const u64 w0 = gbit >> 5;
-    for (unsigned w = threadIdx.x; w < nwords; w += 256) {
-        const unsigned v = __builtin_bswap32(buf[w]);
-        if (w == 0 || w == nwords - 1) { if (v) atomicOr(&out32[w0 + w], v); }
-        else out32[w0 + w] = v;
+#pragma unroll
+    for (int k = 0; k < SZH_ENC_PER; ++k) {
+        if (chunk0 + k >= nchunks) break;                         // uniform
+        const u64 gbit = bit0 + goff[k];
+        const unsigned lead = (unsigned)(gbit & 31);
+        const int64_t t0 = (chunk0 + k) * SZH_ENC_CHUNK + threadIdx.x * 8;
+        unsigned l[8]; unsigned s = 0;
+        for (int q = 0; q < 8; ++q) {
+            l[q] = t0 + q < n ? (tab_lds ? (unsigned)llen[cc[k][q]] : (unsigned)len[cc[k][q]]) : 0u;
+            s += l[q];
+        }
+        u64 tot;
+        const u64 ex = block_excl_scan_256((u64)s, sh, &tot);     // (its barriers also separate this chunk's clear from the previous chunk's reads)
+        // only the words this chunk fills are cleared (a chunk of the S-field fills ~160 of the 4098)
+        for (unsigned w = threadIdx.x; w < (unsigned)((lead + tot + 31) >> 5) + 1; w += 256) buf[w] = 0;
+        __syncthreads();
+        // a thread's eight codes are consecutive in the stream: they are concatenated in a register and reach LDS as one or two ORs
+        // (one atomic per code meant a dozen lanes hitting the same word)
+        unsigned pos = lead + (unsigned)ex;
+        u64 acc = 0; int accn = 0;
+        for (int q = 0; q < 8; ++q) {
+            if (!l[q]) continue;
+            const u64 cw = tab_lds ? lcode[cc[k][q]] : code[cc[k][q]];
+            if (accn + (int)l[q] > 64) { lds_put_bits(buf, pos, acc, accn); pos += accn; acc = 0; accn = 0; }
+            acc = l[q] == 64 ? cw : ((acc << l[q]) | (cw & ((1ull << l[q]) - 1)));
+            accn += (int)l[q];
+        }
+        if (accn) lds_put_bits(buf, pos, acc, accn);
+        __syncthreads();
+        const unsigned nwords = (unsigned)((lead + tot + 31) >> 5);
+        const u64 w0 = gbit >> 5;
+        for (unsigned w = threadIdx.x; w < nwords; w += 256) {
+            const unsigned v = __builtin_bswap32(buf[w]);
+            if (w == 0 || w == nwords - 1) { if (v) atomicOr(&out32[w0 + w], v); }
+            else out32[w0 + w] = v;
+        }
+        __syncthreads();                                          // the buffer is read out before the next chunk clears it
     }
 }
 
