@@ -353,7 +353,7 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
     if not args.no_cpu_baseline and world == 1:
         cpu, cpu_mt = cpu_baselines(host, n, size)
 
-    line = {"metric": "compression GB/s (input), 512^3 float32 ABS 1e-4", "value": round(value, 3), "unit": "GB/s",
+    line = {"metric": f"compression GB/s (input), {n}^3 float32 ABS 1e-4", "value": round(value, 3), "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{n}x{n}x{n} float32 S-field (smooth sinusoid) per GPU, ABS 1e-4, SZ 2.1 path with adaptive Lorenzo+regression "
