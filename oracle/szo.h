@@ -49,8 +49,10 @@ typedef struct szo_params {
                                         SZ_compress_args never copies its relBoundRatio ARGUMENT into the config struct
                                         (sz_float.c:2815-2820), so the header carries the configured value. */
     double   pw_rel_bound_ratio;     /* pwRelBoundRatio argument of the PW_REL-type modes (10..14); the log-domain form
-                                        (accelerate_pw_rel_compression = 0) is the one restated, szo_pwr_impl.h */
+                                        (accelerate_pw_rel_compression = 0) is restated in szo_pwr_impl.h */
     int      segment_size;           /* confparams_cpr->segment_size, recorded in a PW_REL header (default 36, conf.c:128) */
+    int      accelerate_pw_rel;      /* accelerate_pw_rel_compression (conf.c:125, default 1): mode PW_REL in its table-driven form,
+                                        szo_msst_impl.h */
 } szo_params;
 
 void szo_default_params(szo_params *p);

@@ -49,6 +49,7 @@ void szo_default_params(szo_params *p)
     p->conf_rel_bound_ratio = 1E-4; /* conf.c:123 */
     p->pw_rel_bound_ratio = 1E-3;   /* conf.c:127 */
     p->segment_size = 36;           /* conf.c:128 */
+    p->accelerate_pw_rel = 1;       /* conf.c:125 */
 }
 
 void szo_free_stages(szo_stages *s)
@@ -93,7 +94,7 @@ static float szo_get_be_f32(const unsigned char *b) { uint32_t u = szo_get_u32be
 static double szo_get_be_f64(const unsigned char *b) { uint64_t u = szo_get_u64be(b); double v; memcpy(&v, &u, 8); return v; }
 
 /* the extra container fields of a point-wise-relative stream */
-typedef struct szo_pwr_extra { size_t segment_size; const unsigned char *blob; size_t blob_size; double min_log_value; } szo_pwr_extra;
+typedef struct szo_pwr_extra { size_t segment_size; const unsigned char *blob; size_t blob_size; double min_log_value; int msst19, plus_bits; } szo_pwr_extra;
 
 /* zstd for the sign bytes of the PW_REL path, loaded at run time (the image has libzstd.so.1 but no headers) */
 #include <dlfcn.h>
@@ -137,6 +138,7 @@ static unsigned char *szo_zstd_decompress(const unsigned char *src, size_t len, 
 #define IS_F64 0
 #include "szo_sz21_impl.h"
 #include "szo_sz14_impl.h"
+#include "szo_msst_impl.h"
 #include "szo_pwr_impl.h"
 #undef T
 #undef SUF
@@ -149,6 +151,7 @@ static unsigned char *szo_zstd_decompress(const unsigned char *src, size_t len, 
 #define IS_F64 1
 #include "szo_sz21_impl.h"
 #include "szo_sz14_impl.h"
+#include "szo_msst_impl.h"
 #include "szo_pwr_impl.h"
 #undef T
 #undef SUF
@@ -291,7 +294,15 @@ unsigned char *szo_compress_args(const szo_params *p, int data_type, const void 
         /* every mode >= PW_REL goes to the _pwr_pre_log functions with pwRelBoundRatio alone (sz_float.c:2888-2996); 4-D as (r4*r3, r2, r1) */
         size_t s0 = dim >= 3 ? (dim == 4 ? r4 * r3 : r3) : 1, s1 = dim >= 2 ? r2 : 1;
         meta[3] = 0x40 | 0x20 | (p->protect_value_range ? 0x04 : 0);
-        if (data_type == SZO_FLOAT)
+        /* the table-driven form: mode PW_REL alone, the switch on, a ratio of at least 1e-5 (sz_float.c:2837-2838, :2890) */
+        const int msst19 = err_mode == SZO_PW_REL && p->accelerate_pw_rel && !(p->pw_rel_bound_ratio < 0.000009999) && p->max_quant_intervals <= 65536;
+        if (msst19) {
+            meta[3] |= 0x08;                                     /* TightDataPointStorageF.c:608-609 */
+            if (data_type == SZO_FLOAT)
+                out = szo_msst_compress_f32(p, meta, 4 + meta_len, (const float *)data, s0, s1, r1, p->pw_rel_bound_ratio, (float)vmax, (size_t)p->segment_size, &osz, stages);
+            else
+                out = szo_msst_compress_f64(p, meta, 4 + meta_len, (const double *)data, s0, s1, r1, p->pw_rel_bound_ratio, vmax, (size_t)p->segment_size, &osz, stages);
+        } else if (data_type == SZO_FLOAT)
             out = szo_pwr_compress_f32(p, meta, 4 + meta_len, (const float *)data, s0, s1, r1, p->pw_rel_bound_ratio, (float)vmin, (float)vmax, (size_t)p->segment_size, &osz);
         else
             out = szo_pwr_compress_f64(p, meta, 4 + meta_len, (const double *)data, s0, s1, r1, p->pw_rel_bound_ratio, vmin, vmax, (size_t)p->segment_size, &osz);
@@ -371,6 +382,11 @@ void *szo_decompress(int data_type, const unsigned char *bytes, size_t byte_len,
             if (data_type == SZO_FLOAT) ((float *)out)[i] = szo_get_be_f32(body);
             else ((double *)out)[i] = szo_get_be_f64(body);
         }
+    } else if ((same & 0x20) && (same & 0x08) && dim <= 4) {     /* point-wise relative, table-driven form (szd_float.c:2714, :2755, :2796, :2836) */
+        size_t s0 = dim >= 3 ? (dim == 4 ? r4 * r3 : r3) : 1, s1 = dim >= 2 ? r2 : 1;
+        int rc = data_type == SZO_FLOAT ? szo_msst_decompress_f32((float *)out, s0, s1, r1, body, byte_len - (size_t)(body - bytes))
+                                        : szo_msst_decompress_f64((double *)out, s0, s1, r1, body, byte_len - (size_t)(body - bytes));
+        if (rc) { free(out); return NULL; }
     } else if ((same & 0x20) && !(same & 0x08) && dim <= 4) {    /* point-wise relative, log-domain form (szd_float.c:2716, :2757, :2798, :2838) */
         size_t s0 = dim >= 3 ? (dim == 4 ? r4 * r3 : r3) : 1, s1 = dim >= 2 ? r2 : 1;
         int rc = data_type == SZO_FLOAT ? szo_pwr_decompress_f32((float *)out, s0, s1, r1, body, byte_len - (size_t)(body - bytes))

@@ -214,6 +214,83 @@ static inline int FN(szo_sz14_point)(FN(szo_exact) *E, T x, T pred, T eb, T reci
     return 0;
 }
 
+/* everything after the quantiser: type-array blob, exact-value arrays, container.  `median_stored` is the container's median field
+ * (the MSST19 form stores another number there than the one its exact values are taken against, sz_float_pwr.c:2060-2062) */
+static unsigned char *FN(szo_sz14_pack)(const szo_params *p, const unsigned char *meta, size_t meta_len, size_t n, unsigned intervals, int *type,
+                                        FN(szo_exact) *Ep, double eb_field, T median_stored, size_t *out_size, szo_stages *st, const szo_pwr_extra *pw)
+{
+#define E (*Ep)
+
+    /* type array blob (Huffman.c:790-816): nodeCount | stateNum/2 | tree | payload */
+    szo_huff *h = szo_huff_from_symbols(2 * (int)intervals, type, n);
+    size_t node_count = szo_huff_node_count(h);
+    unsigned char *tree = NULL;
+    size_t tree_bytes = szo_huff_tree_to_bytes(h, &tree);
+    unsigned char *payload = (unsigned char *)calloc(n * sizeof(int) + 16, 1);
+    size_t huff_bytes = szo_huff_encode(h, type, n, payload);
+    const size_t type_size = 8 + tree_bytes + huff_bytes;
+
+    /* 2-bit lead array (TypeManager.c:134-175) and residual bits, MSB first (:377-415) */
+    const size_t lead_size = (E.n * 2 + 7) / 8;
+    const size_t resi_size = E.resi_bits ? (E.n * (size_t)E.resi_bits + 7) / 8 : 0;
+
+    /* container (TightDataPointStorageF.c:379-479): sizes are 8 bytes (SZ_SIZE_TYPE) */
+    const size_t total = meta_len + 8 + 4 + 4 + NBYTES + 1 + 8 + 8 + 8 + 8 + type_size + lead_size + E.nmid + resi_size
+                       + (pw ? 1 + 8 + 4 + NBYTES + pw->blob_size + (pw->msst19 ? 2 : 0) : 0);
+    unsigned char *out = (unsigned char *)calloc(total + 8, 1);
+    unsigned char *q = out;
+    memcpy(q, meta, meta_len); q += meta_len;
+    szo_put_u64be(q, n); q += 8;
+    szo_put_u32be(q, p->max_quant_intervals); q += 4;
+    if (pw) { *q++ = 0; /* radExpo */ szo_put_u64be(q, (uint64_t)pw->segment_size); q += 8; szo_put_u32be(q, (uint32_t)pw->blob_size); q += 4; }
+    szo_put_u32be(q, intervals); q += 4;
+    FN(szo_put_be)(q, median_stored); q += NBYTES;
+    *q++ = (unsigned char)E.req_len;
+    if (pw && pw->msst19) {                      /* plus_bits, max_bits (TightDataPointStorageF.c:431-435; max_bits: Huffman.c:828-833) */
+        int max_bits = 0;
+        for (unsigned i = 0; i < 2 * intervals; i++) if (h->len[i] > max_bits) max_bits = h->len[i];
+        *q++ = (unsigned char)pw->plus_bits; *q++ = (unsigned char)max_bits;
+    }
+    szo_put_be_f64(q, eb_field); q += 8;
+    szo_put_u64be(q, type_size); q += 8;
+    szo_put_u64be(q, E.n); q += 8;
+    szo_put_u64be(q, E.nmid); q += 8;
+    if (pw) { FN(szo_put_be)(q, (T)pw->min_log_value); q += NBYTES; }
+    szo_put_u32be(q, (uint32_t)node_count); szo_put_u32be(q + 4, intervals);
+    memcpy(q + 8, tree, tree_bytes); memcpy(q + 8 + tree_bytes, payload, huff_bytes); q += type_size;
+    if (pw && pw->blob_size) { memcpy(q, pw->blob, pw->blob_size); q += pw->blob_size; }
+    for (size_t i = 0; i < E.n; i++) q[i >> 2] |= (unsigned char)(E.lead[i] << (6 - 2 * (i & 3)));
+    q += lead_size;
+    memcpy(q, E.mid, E.nmid); q += E.nmid;
+    if (E.resi_bits) {
+        size_t bit = 0;
+        for (size_t i = 0; i < E.n; i++, bit += (size_t)E.resi_bits) {
+            unsigned v = (unsigned)E.resi[i] << (16 - E.resi_bits - (bit & 7));      /* at most 7 bits, spans at most 2 bytes */
+            q[bit >> 3] |= (unsigned char)(v >> 8);
+            q[(bit >> 3) + 1] |= (unsigned char)v;                                   /* out has 8 spare bytes */
+        }
+        q += resi_size;
+    }
+    *out_size = (size_t)(q - out);
+
+    if (st) {
+        memset(st, 0, sizeof(*st));
+        st->num_elements = n; st->total_unpred = E.n; st->intervals = intervals; st->eb = eb_field; st->mean = (double)median_stored;
+        st->codes = type; type = NULL;
+        st->num_blocks = E.nmid;                 /* SZ 1.4: number of mid bytes */
+        st->use_mean = E.req_len;                /* SZ 1.4: reqLength */
+        st->indicator = E.lead; E.lead = NULL;   /* SZ 1.4: lead numbers, one per exact value */
+        st->unpred = E.mid; E.mid = NULL;        /* SZ 1.4: mid bytes */
+        st->code_len = (unsigned char *)malloc(2 * (size_t)intervals);
+        memcpy(st->code_len, h->len, 2 * (size_t)intervals);
+        st->tree_bytes = tree_bytes; st->node_count = node_count; st->huff_bytes = huff_bytes;
+    }
+    free(type); free(tree); free(payload); szo_huff_free(h);
+    free(E.lead); free(E.mid); free(E.resi);
+    return out;
+#undef E
+}
+
 /* r1 slowest ... r3 fastest (callee convention of sz_float.c:946).  `meta` = version bytes, flag byte and parameter bytes.
  * r1 == 1 is the 2-D compressor SZ_compress_float_2D_MDQ (sz_float.c:610-894; inverse szd_float.c:284-598): its predictors are
  * exactly those of layer 0 below (:686, :727, :772, :814); only its optimiser walks another lattice.  Pinned by the recorded
@@ -314,69 +391,7 @@ static unsigned char *FN(szo_sz14_compress_3d)(const szo_params *p, const unsign
     }
 pack:
     free(P0); free(P1);
-
-    /* type array blob (Huffman.c:790-816): nodeCount | stateNum/2 | tree | payload */
-    szo_huff *h = szo_huff_from_symbols(2 * (int)intervals, type, n);
-    size_t node_count = szo_huff_node_count(h);
-    unsigned char *tree = NULL;
-    size_t tree_bytes = szo_huff_tree_to_bytes(h, &tree);
-    unsigned char *payload = (unsigned char *)calloc(n * sizeof(int) + 16, 1);
-    size_t huff_bytes = szo_huff_encode(h, type, n, payload);
-    const size_t type_size = 8 + tree_bytes + huff_bytes;
-
-    /* 2-bit lead array (TypeManager.c:134-175) and residual bits, MSB first (:377-415) */
-    const size_t lead_size = (E.n * 2 + 7) / 8;
-    const size_t resi_size = E.resi_bits ? (E.n * (size_t)E.resi_bits + 7) / 8 : 0;
-
-    /* container (TightDataPointStorageF.c:379-479): sizes are 8 bytes (SZ_SIZE_TYPE) */
-    const size_t total = meta_len + 8 + 4 + 4 + NBYTES + 1 + 8 + 8 + 8 + 8 + type_size + lead_size + E.nmid + resi_size
-                       + (pw ? 1 + 8 + 4 + NBYTES + pw->blob_size : 0);
-    unsigned char *out = (unsigned char *)calloc(total + 8, 1);
-    unsigned char *q = out;
-    memcpy(q, meta, meta_len); q += meta_len;
-    szo_put_u64be(q, n); q += 8;
-    szo_put_u32be(q, p->max_quant_intervals); q += 4;
-    if (pw) { *q++ = 0; /* radExpo */ szo_put_u64be(q, (uint64_t)pw->segment_size); q += 8; szo_put_u32be(q, (uint32_t)pw->blob_size); q += 4; }
-    szo_put_u32be(q, intervals); q += 4;
-    FN(szo_put_be)(q, E.median); q += NBYTES;
-    *q++ = (unsigned char)E.req_len;
-    szo_put_be_f64(q, (double)eb); q += 8;
-    szo_put_u64be(q, type_size); q += 8;
-    szo_put_u64be(q, E.n); q += 8;
-    szo_put_u64be(q, E.nmid); q += 8;
-    if (pw) { FN(szo_put_be)(q, (T)pw->min_log_value); q += NBYTES; }
-    szo_put_u32be(q, (uint32_t)node_count); szo_put_u32be(q + 4, intervals);
-    memcpy(q + 8, tree, tree_bytes); memcpy(q + 8 + tree_bytes, payload, huff_bytes); q += type_size;
-    if (pw && pw->blob_size) { memcpy(q, pw->blob, pw->blob_size); q += pw->blob_size; }
-    for (size_t i = 0; i < E.n; i++) q[i >> 2] |= (unsigned char)(E.lead[i] << (6 - 2 * (i & 3)));
-    q += lead_size;
-    memcpy(q, E.mid, E.nmid); q += E.nmid;
-    if (E.resi_bits) {
-        size_t bit = 0;
-        for (size_t i = 0; i < E.n; i++, bit += (size_t)E.resi_bits) {
-            unsigned v = (unsigned)E.resi[i] << (16 - E.resi_bits - (bit & 7));      /* at most 7 bits, spans at most 2 bytes */
-            q[bit >> 3] |= (unsigned char)(v >> 8);
-            q[(bit >> 3) + 1] |= (unsigned char)v;                                   /* out has 8 spare bytes */
-        }
-        q += resi_size;
-    }
-    *out_size = (size_t)(q - out);
-
-    if (st) {
-        memset(st, 0, sizeof(*st));
-        st->num_elements = n; st->total_unpred = E.n; st->intervals = intervals; st->eb = (double)eb; st->mean = (double)E.median;
-        st->codes = type; type = NULL;
-        st->num_blocks = E.nmid;                 /* SZ 1.4: number of mid bytes */
-        st->use_mean = E.req_len;                /* SZ 1.4: reqLength */
-        st->indicator = E.lead; E.lead = NULL;   /* SZ 1.4: lead numbers, one per exact value */
-        st->unpred = E.mid; E.mid = NULL;        /* SZ 1.4: mid bytes */
-        st->code_len = (unsigned char *)malloc(2 * (size_t)intervals);
-        memcpy(st->code_len, h->len, 2 * (size_t)intervals);
-        st->tree_bytes = tree_bytes; st->node_count = node_count; st->huff_bytes = huff_bytes;
-    }
-    free(type); free(tree); free(payload); szo_huff_free(h);
-    free(E.lead); free(E.mid); free(E.resi);
-    return out;
+    return FN(szo_sz14_pack)(p, meta, meta_len, n, intervals, type, &E, (double)eb, E.median, out_size, st, pw);
 }
 
 /* ---- decompressor (szd_float.c:600-1138).  `b` points at the max_quant_intervals field (just after the element count) ---- */
@@ -408,8 +423,12 @@ static T FN(szo_exact_next)(FN(szo_exact_rd) *R)
     return v + R->median;
 }
 
+static void FN(szo_msst_reconstruct)(T *out, size_t r1, size_t r2, size_t r3, const int *type, FN(szo_exact_rd) *R, unsigned intervals,
+                                     double ratio, int plus_bits);        /* szo_msst_impl.h */
+
 static int FN(szo_sz14_decompress_3d)(T *out, size_t r1, size_t r2, size_t r3, const unsigned char *b, size_t avail, szo_pwr_extra *pw)
-{   /* pw != NULL: a point-wise-relative stream; its extra fields are skipped here and handed back */
+{   /* pw != NULL: a point-wise-relative stream; its extra fields are skipped here and handed back.  pw->msst19 (set by the caller from
+     * flag 0x08): the table-driven form -- two more header bytes, another reconstruction (szo_msst_impl.h) */
     const size_t n = r1 * r2 * r3, r23 = r2 * r3;
     const unsigned char *q = b;
     q += 4;                                              /* max_quant_intervals */
@@ -418,7 +437,10 @@ static int FN(szo_sz14_decompress_3d)(T *out, size_t r1, size_t r2, size_t r3, c
     FN(szo_exact_rd) R; memset(&R, 0, sizeof(R));
     R.median = FN(szo_get_be)(q); q += NBYTES;
     int req_len = *q++;
-    T eb = (T)szo_get_be_f64(q); q += 8;                 /* `float realPrecision = tdps->realPrecision`, szd_float.c:610 */
+    const int msst19 = pw && pw->msst19;
+    if (msst19) { pw->plus_bits = q[0]; q += 2; R.median = 0; }         /* plus_bits, max_bits (TightDataPointStorageF.c:164-168) */
+    const double eb_field = szo_get_be_f64(q);
+    T eb = (T)eb_field; q += 8;                          /* `float realPrecision = tdps->realPrecision`, szd_float.c:610 */
     size_t type_size = (size_t)szo_get_u64be(q); q += 8;
     size_t exact_n = (size_t)szo_get_u64be(q); q += 8;
     size_t mid_n = (size_t)szo_get_u64be(q); q += 8;
@@ -442,6 +464,7 @@ static int FN(szo_sz14_decompress_3d)(T *out, size_t r1, size_t r2, size_t r3, c
     R.req_bytes = req_len / 8; R.resi_bits = req_len % 8;
     const int radius = (int)intervals / 2;
 
+    if (msst19) { FN(szo_msst_reconstruct)(out, r1, r2, r3, type, &R, intervals, eb_field, pw->plus_bits); free(type); free(resi_pad); return 0; }
 #define SZO_DEC(IDX, PRED) do { int t_ = type[IDX]; out[IDX] = t_ ? (T)((PRED) + 2 * (t_ - radius) * eb) : FN(szo_exact_next)(&R); } while (0)
     if (r1 == 1 && r2 == 1) {   /* decompressDataSeries_float_1D (szd_float.c:185-282): codes 0 at positions 0 and 1 by construction */
         for (size_t i = 0; i < n; i++) { T pred = i ? out[i - 1] : 0; SZO_DEC(i, pred); }

@@ -18,7 +18,8 @@ class Params(ctypes.Structure):
                 ("with_regression", ctypes.c_int), ("sz_mode", ctypes.c_int), ("gzip_mode", ctypes.c_int),
                 ("protect_value_range", ctypes.c_int), ("data_endian", ctypes.c_int), ("sol_id", ctypes.c_int),
                 ("psnr", ctypes.c_double), ("norm_err", ctypes.c_double), ("conf_rel_bound_ratio", ctypes.c_double),
-                ("pw_rel_bound_ratio", ctypes.c_double), ("segment_size", ctypes.c_int)]
+                ("pw_rel_bound_ratio", ctypes.c_double), ("segment_size", ctypes.c_int),
+                ("accelerate_pw_rel", ctypes.c_int)]
 
 
 class Stages(ctypes.Structure):

@@ -79,16 +79,17 @@ def _zstd_decompress(blob, n):
 
 
 def _pwr_parts(stream, dtype, n):
-    """A log-form PW_REL stream cut at its sign bytes (TightDataPointStorageF.c:133-250): (everything else with the 4-byte size field
+    """A PW_REL stream (either form) cut at its sign bytes (TightDataPointStorageF.c:133-250): (everything else with the 4-byte size field
     of the sign bytes zeroed, the sign bytes decoded).  The sign bytes are zstd output, i.e. a property of the zstd build."""
     es, meta = (4, 28) if np.dtype(dtype) == np.float32 else (8, 36)
     body = 4 + meta + 8
     if stream[3] & 0x10 or not stream[3] & 0x20:        # raw copy / constant: nothing to cut
         return stream, b""
     size_at = body + 4 + 1 + 8
+    x = 2 if stream[3] & 0x08 else 0                    # the table-driven form: plus_bits, max_bits after reqLength (:164-168)
     blob_size = int.from_bytes(stream[size_at:size_at + 4], "big")
-    type_size = int.from_bytes(stream[size_at + 4 + 4 + es + 1 + 8:size_at + 4 + 4 + es + 1 + 8 + 8], "big")
-    blob_off = body + 4 + 1 + 8 + 4 + 4 + es + 1 + 8 + 8 + 8 + 8 + es + type_size
+    type_size = int.from_bytes(stream[size_at + 4 + 4 + es + 1 + x + 8:size_at + 4 + 4 + es + 1 + x + 8 + 8], "big")
+    blob_off = body + 4 + 1 + 8 + 4 + 4 + es + 1 + x + 8 + 8 + 8 + 8 + es + type_size
     rest = stream[:size_at] + b"\0\0\0\0" + stream[size_at + 4:blob_off] + stream[blob_off + blob_size:]
     return rest, (_zstd_decompress(stream[blob_off:blob_off + blob_size], n) if blob_size else b"")
 
@@ -110,10 +111,11 @@ def _pwr_oracle_params(oracle, c):
     p = _oracle_params(oracle, c)
     p.pw_rel_bound_ratio = c["pwr"]
     p.segment_size = int(c["conf"].get("segment_size", 0))       # a config file without the key reads 0 (conf.c:356), SZ_Init(NULL) 36
+    p.accelerate_pw_rel = int(c["conf"].get("accelerate_pw_rel_compression", 1))
     return p
 
 
-@pytest.mark.parametrize("c", PWRLOG, ids=[c["name"] for c in PWRLOG])
+@pytest.mark.parametrize("c", PWRLOG + MSST19, ids=[c["name"] for c in PWRLOG + MSST19])
 def test_oracle_reproduces_recorded_reference_pw_rel_output(oracle, c):
     d, r = _data(c)
     stream, _ = oracle.compress(d, c["mode"], c["abs"], c["rel"], params=_pwr_oracle_params(oracle, c))
