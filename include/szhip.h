@@ -137,9 +137,15 @@ int szhip_decompress_sz14(szhip_ctx *ctx, int dtype, const unsigned char *stream
  *   szhip_sz14_pwr_locate   (host only) where a PW_REL stream keeps its sign bytes, and its minLogValue;
  *   szhip_decompress_sz14_pwr  the SZ 1.4 inverse on a stream with those fields, then x = exp2(l) (0 below minLogValue), signs applied
  *                           (`signs_host`: n bytes or NULL).
- * The default form of the reference (accelerate_pw_rel_compression = 1: the table-driven "MSST19" quantiser, sz_float.c:1824-2725) is
- * not implemented: this build writes the log-domain form whatever that switch says (a valid stream for every stock reader, flagged as
- * such in its header) and refuses to decode MSST19 streams.
+ * The reference's DEFAULT form of mode PW_REL (accelerate_pw_rel_compression = 1, ratio >= 1e-5: the table-driven "MSST19" quantiser,
+ * sz_float.c:1824-2725, dispatch :2838, :2890; inverse szd_float.c:1702-2700, szd_float_pwr.c:1425-1528; stream flag 0x08):
+ *   szhip_msst_prepare      the scan of computeRangeSize_float_MSST19 (dataCompression.c:121-166: sign bytes from element 1 on, nearZero) and
+ *                           a device copy of the array with its zeros replaced by nearZero * (1+ratio)^-3.0001 (*d_prepared, owned by the
+ *                           context); the header's median (sqrt|nearZero * vmax|) and minLogValue (nearZero / (1+ratio)^2).
+ *   szhip_compress_sz14_pwr with pwr->msst19 = 1, `eb` = the ratio and `data` = *d_prepared: multiplicative Lorenzo predictor on the
+ *                           reconstruction, codes from the look-up table of MultiLevelCacheTableWideInterval.c:53-107 (built on the host).
+ *   szhip_decompress_sz14_pwr  recognises the form by the stream's flag byte.
+ * The mapping is a plain hyperplane sweep (one launch per plane; 1-D: one lane) -- bit-exact, not fast.
  */
 typedef struct szhip_pwr {
     uint64_t segment_size;             /* confparams_cpr->segment_size, recorded in the header */
@@ -147,10 +153,15 @@ typedef struct szhip_pwr {
     uint32_t signs_blob_size;
     double min_log_value;
     unsigned char rad_expo;            /* 0 on this path */
+    unsigned char msst19;              /* 1: the table-driven form (below); `eb` of szhip_compress_sz14_pwr is then the ratio itself */
+    unsigned char plus_bits;           /* confparams_cpr->plus_bits (3, conf.c:97), recorded in an MSST19 header */
+    double median_stored;              /* MSST19: the header's median field, sqrt|nearZero * max| (sz_float_pwr.c:2060) */
 } szhip_pwr;
 int szhip_pwr_prepare(szhip_ctx *ctx, int dtype, const void *data, int data_on_device, size_t n, double vmin, double vmax, double pwr_ratio,
                       void **d_log, unsigned char *signs_host, int *positive, double *real_precision, double *value_range, double *median,
                       double *min_log_value);
+int szhip_msst_prepare(szhip_ctx *ctx, int dtype, const void *data, int data_on_device, size_t n, double vmax, double pwr_ratio,
+                       void **d_prepared, unsigned char *signs_host, int *positive, double *near_zero, double *median_log, double *min_log_value);
 int szhip_compress_sz14_pwr(szhip_ctx *ctx, int dtype, const void *data, int data_on_device,
                             size_t r0, size_t r1, size_t r2, double eb, double value_range, double median,
                             const szhip_params *params, const unsigned char *meta, size_t meta_len, const szhip_pwr *pwr,

@@ -356,17 +356,31 @@ static int compress_fp(int dataType, int withRegression, unsigned char **newByte
     if (errBoundMode >= PW_REL) {
         /* Point-wise relative bounds: log2|x| through the SZ 1.4 quantiser with an absolute bound in the log domain -- the `_pwr_pre_log`
          * form (sz_float_pwr.c:1791-1975; dispatch sz_float.c:2888-2996: every mode >= PW_REL takes it, and only pwRelBoundRatio counts).
-         * The reference prefers its table-driven MSST19 form when accelerate_pw_rel_compression is set (its default) and the ratio is
-         * >= 1e-5; this build always writes the log-domain form, which every stock reader decodes (flag 0x20 without 0x08). */
+         * Mode PW_REL itself takes the table-driven MSST19 form instead when accelerate_pw_rel_compression is set (the default) and
+         * the ratio is >= 1e-5 (sz_float.c:2838, :2890; szh_msst.h). */
         if (!(pwRelBoundRatio > 0)) { printf("Error: pw_relBoundRatio must be positive.\n"); return SZ_BERR; }
         const int dt = dataType == SZ_FLOAT ? SZHIP_F32 : SZHIP_F64;
+        /* the table-driven form: mode PW_REL alone, the switch on (sticky off below a ratio of 1e-5, sz_float.c:2837-2838), at most 65536
+         * intervals (:2890).  The other modes >= PW_REL reach the _MSST19 functions in the reference too, but without their sign scan
+         * (:2838 tests `== PW_REL`), which loses the signs: they take the log-domain form here. */
+        if (pwRelBoundRatio < 0.000009999) confparams_cpr->accelerate_pw_rel_compression = 0;
+        const int msst19 = errBoundMode == PW_REL && confparams_cpr->accelerate_pw_rel_compression && confparams_cpr->maxRangeRadius <= 32768;
         unsigned char *signs = (unsigned char *)malloc(dataLength);
         if (!signs) return SZ_NSCS;
         void *d_log = NULL; int positive = 1; double rp = 0, lrange = 0, lmedian = 0, minlog = 0;
-        int prc = szhip_pwr_prepare(ctx, dt, d_in, 1, dataLength, vmin, vmax, pwRelBoundRatio, &d_log, signs, &positive, &rp, &lrange, &lmedian, &minlog);
-        if (prc != SZHIP_OK) { printf("Error: szhip_pwr_prepare failed (%d): %s\n", prc, szhip_last_error(ctx)); free(signs); return SZ_NSCS; }
-        if (!(rp > 0)) { printf("Error: pw_relBoundRatio %g leaves no room below the rounding margin of this data.\n", pwRelBoundRatio); free(signs); return SZ_BERR; }
         szhip_pwr pw; memset(&pw, 0, sizeof(pw));
+        if (msst19) {
+            double near_zero = 0, median_log = 0;
+            const double ref_max = dataType == SZ_FLOAT ? (double)confparams_cpr->fmax : confparams_cpr->dmax;     /* `max = min + valueRangeSize` */
+            int prc = szhip_msst_prepare(ctx, dt, d_in, 1, dataLength, ref_max, pwRelBoundRatio, &d_log, signs, &positive, &near_zero, &median_log, &minlog);
+            if (prc != SZHIP_OK) { printf("Error: szhip_msst_prepare failed (%d): %s\n", prc, szhip_last_error(ctx)); free(signs); return SZ_NSCS; }
+            pw.msst19 = 1; pw.plus_bits = (unsigned char)confparams_cpr->plus_bits; pw.median_stored = median_log;
+            rp = pwRelBoundRatio;
+        } else {
+            int prc = szhip_pwr_prepare(ctx, dt, d_in, 1, dataLength, vmin, vmax, pwRelBoundRatio, &d_log, signs, &positive, &rp, &lrange, &lmedian, &minlog);
+            if (prc != SZHIP_OK) { printf("Error: szhip_pwr_prepare failed (%d): %s\n", prc, szhip_last_error(ctx)); free(signs); return SZ_NSCS; }
+            if (!(rp > 0)) { printf("Error: pw_relBoundRatio %g leaves no room below the rounding margin of this data.\n", pwRelBoundRatio); free(signs); return SZ_BERR; }
+        }
         pw.segment_size = (uint64_t)confparams_cpr->segment_size; pw.min_log_value = minlog;
         unsigned char *blob = NULL;
         if (!positive) {                                           /* sz_lossless_compress(ZSTD_COMPRESSOR, 3, signs, ...) (utility.c:174-195) */
@@ -374,12 +388,17 @@ static int compress_fp(int dataType, int withRegression, unsigned char **newByte
             size_t est = dataLength < 100 ? 200 : (size_t)(dataLength * 1.2);
             blob = (unsigned char *)malloc(est);
             if (!blob) { free(signs); return SZ_NSCS; }
-            size_t zs = g_zstd.compress(blob, est, signs, dataLength, 3);
+            /* the 2-D/3-D MSST19 wrappers pass (losslessCompressor, gzipMode) (sz_float_pwr.c:2030, :2068) while every reader decodes the sign
+             * bytes with zstd (szd_float_pwr.c:1438): zstd it is, at that level when zstd is the configured compressor */
+            int level = 3;
+            if (msst19 && dim >= 2 && confparams_cpr->losslessCompressor == ZSTD_COMPRESSOR) level = confparams_cpr->gzipMode;
+            size_t zs = g_zstd.compress(blob, est, signs, dataLength, level);
             if (g_zstd.iserr(zs) || zs > 0xffffffffu) { printf("Error: ZSTD_compress failed on the sign bytes.\n"); free(blob); free(signs); return SZ_NSCS; }
             pw.signs_blob = blob; pw.signs_blob_size = (uint32_t)zs;
         }
         free(signs);
-        unsigned char pflags = 0x40 | 0x20;                        /* TightDataPointStorageF.c:600-611: isPW_REL, no MSST19 bit */
+        unsigned char pflags = 0x40 | 0x20;                        /* TightDataPointStorageF.c:600-611: isPW_REL */
+        if (msst19) pflags |= 0x08;                                /* :608-609 */
         if (confparams_cpr->protectValueRange) pflags |= 0x04;
         szhost_write_meta(&m, pflags, meta);
         szhip_params php; memset(&php, 0, sizeof(php));
@@ -614,8 +633,10 @@ static void *decompress_fp(int dataType, unsigned char *cmpBytes, size_t cmpSize
         }
     } else {
         int dim = computeDimension(r5, r4, r3, r2, r1);
-        if ((same & 0x20) && !(same & (0x08 | 0x02 | 0x80)) && dim >= 1 && dim <= 4 && st == 8 && confparams_dec->sol_ID == SZ) {
-            /* point-wise relative, log-domain form: decompressDataSeries_float_{1D,2D,3D}_pwr_pre_log (szd_float_pwr.c:1353-1422; 4-D as
+        if ((same & 0x20) && !(same & (0x02 | 0x80)) && dim >= 1 && dim <= 4 && st == 8 && confparams_dec->sol_ID == SZ) {
+            /* point-wise relative: flag 0x08 set = the table-driven form, decompressDataSeries_float_{1D,2D,3D}_pwr_pre_log_MSST19
+             * (szd_float_pwr.c:1425-1528; the library tells them apart); else the
+             * log-domain form: decompressDataSeries_float_{1D,2D,3D}_pwr_pre_log (szd_float_pwr.c:1353-1422; 4-D as
              * (r4*r3, r2, r1), szd_float.c:2838) */
             szhip_ctx *ctx = get_ctx();
             const int dt = dataType == SZ_FLOAT ? SZHIP_F32 : SZHIP_F64;
@@ -636,9 +657,9 @@ static void *decompress_fp(int dataType, unsigned char *cmpBytes, size_t cmpSize
                 if (rc != SZHIP_OK) { printf("Error: szhip_decompress_sz14_pwr failed (%d): %s\n", rc, szhip_last_error(ctx)); ok = 0; }
             }
             free(signs);
-        } else if ((same & (0x20 | 0x08 | 0x02)) || !(dim >= 1 && dim <= 4) || (!(same & 0x80) && dim == 4) || ((same & 0x80) && dim == 1) || st != 8 || confparams_dec->sol_ID != SZ) {
+        } else if ((same & (0x20 | 0x02)) || !(dim >= 1 && dim <= 4) || (!(same & 0x80) && dim == 4) || ((same & 0x80) && dim == 1) || st != 8 || confparams_dec->sol_ID != SZ) {
             printf("Error: the MI355X build decodes SZ 2.1 regression-type streams of 2-D/3-D/4-D arrays and SZ 1.4 streams of 1-D/2-D/3-D arrays "
-                   "(float/double; point-wise-relative streams in their log-domain form only, no MSST19 and no random-access form); this stream (flags 0x%02x, dim %d) is not covered yet.\n", same, dim);
+                   "(float/double; point-wise-relative streams in both forms; no random-access form); this stream (flags 0x%02x, dim %d) is not covered yet.\n", same, dim);
             ok = 0;
         } else if (!(same & 0x80)) {   /* SZ 1.4 container: getSnapshotData_float_3D -> decompressDataSeries_float_3D (szd_float.c:146,600) */
             szhip_ctx *ctx = get_ctx();

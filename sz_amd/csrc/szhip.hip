@@ -40,7 +40,7 @@ struct szhip_ctx {
     // workspaces (grow-only)
     DevBuf lor_bits, reg_flags, reg_rank, coef_compact, in, out, codes_nat, codes_blk, coef, blk_lor, faceI, faceJ, progress, trace, order, small, hist, col_zeros, col_zeros64,
         col_off, partial, samples, unpred, stream_buf, chunk_bits, chunk_off, code_tab, len_tab, dec_tab,
-        starts, ends, counts, offs, dirty, zcnt, zpos, pwr_log, pwr_signs, pwr_small, coef_dec;
+        starts, ends, counts, offs, dirty, zcnt, zpos, pwr_log, pwr_signs, pwr_small, coef_dec, msst_ptab, msst_cells, msst_rec, msst_pe;
     void *pinned = nullptr; size_t pinned_cap = 0;
     void *pinned2 = nullptr; size_t pinned2_cap = 0;   // target of the second stream's copies (indicator bits, regression-block count)
     // bulk copies between the caller's pageable arrays and the device: SZH_STAGE_T host threads, two pinned buffers + events each
@@ -1200,6 +1200,166 @@ int launch_pencil14(szhip_ctx *ctx, const szh_geom3 &G, u64 *sm, bool dec, const
     return SZHIP_OK;
 }
 
+
+// =====================================================================================================================
+// Point-wise relative bounds, table-driven ("MSST19") form: host tables and the sweep (szh_msst.h)
+// =====================================================================================================================
+struct MsstHostTab { std::vector<double> ptab; std::vector<uint16_t> cells; u64 base = 0, range = 0; int bits = 0; };
+static inline u64 f64_bits(double v) { u64 u; memcpy(&u, &v, 8); return u; }
+// precisionTable (sz_float.c:2288-2293) and MultiLevelCacheTableWideIntervalBuild (MultiLevelCacheTableWideInterval.c:53-107); pow is the host's
+static int msst_build_tab(MsstHostTab &t, double precision, unsigned count, int plus_bits, bool want_cells)
+{
+    const int radius = (int)count / 2;
+    t.ptab.resize(count);
+    const double inv = 2.0 - pow(2, -plus_bits);
+    for (unsigned i = 0; i < count; ++i) t.ptab[i] = pow(1 + precision, inv * ((int)i - radius));
+    if (!want_cells) return 0;
+    const uint16_t bits = (uint16_t)((uint16_t)(-((f64_bits(precision) >> 52) - 1023)) + plus_bits);
+    if (bits < 1 || bits > 24) return -1;
+    t.bits = bits;
+    const double bottom = t.ptab[1] / (1 + precision), top = t.ptab[count - 1] / (1 - precision);
+    const uint16_t base = (uint16_t)(f64_bits(bottom) >> 52), topi = (uint16_t)(f64_bits(top) >> 52);
+    if (topi < base || (u64)(topi - base + 1) << bits > (1ull << 28)) return -1;
+    t.base = base; t.range = (u64)(topi - base);
+    t.cells.assign((size_t)(t.range + 1) << bits, 0);
+    auto rebuild = [&](uint16_t expo, u64 manti) { u64 u = (u64)expo << 52; u += manti << (52 - bits); double r; memcpy(&r, &u, 8); return r; };
+    uint32_t index = 0; bool flag = false;
+    for (uint32_t i = 0; i <= (uint32_t)(topi - base); ++i) {
+        const uint16_t expo = (uint16_t)(i + base);
+        for (uint32_t j = 0; j < (1u << bits); ++j) {
+            const double sb = rebuild(expo, j), stp = rebuild(expo, (u64)j + 1);
+            const double bb = t.ptab[index] / (1 + precision), tb = t.ptab[index] / (1 - precision);
+            uint16_t &cell = t.cells[((size_t)i << bits) + j];
+            if (stp < tb && sb > bb) { cell = (uint16_t)index; flag = true; }
+            else if (flag && index < count - 1) { ++index; cell = (uint16_t)index; }
+            else cell = 0;
+        }
+    }
+    return 0;
+}
+// the histogram bin of one sample: `radiusIndex = (uint64_t)fabs(log2(pred_err)/divider+0.5)` with gcc's x86-64 double -> uint64 sequence
+static inline u64 msst_radius_index(double pe, double divider)
+{
+    const double v = fabs(log2(pe) / divider + 0.5);
+    if (v != v) return 0x8000000000000000ull;
+    if (v >= 9223372036854775808.0) { const double w = v - 9223372036854775808.0; return (w < 9223372036854775808.0 ? (u64)(int64_t)w : 0x8000000000000000ull) ^ 0x8000000000000000ull; }
+    return (u64)(int64_t)v;
+}
+static unsigned msst_pick_intervals(const std::vector<u64> &hist, u64 total, float pred_threshold, unsigned floor_)
+{
+    const unsigned max_radius = (unsigned)hist.size();
+    const size_t target = (size_t)((float)total * pred_threshold);
+    size_t sum = 0; unsigned i = 0;
+    for (; i < max_radius; ++i) { sum += hist[i]; if (sum > target) break; }
+    if (i >= max_radius) i = max_radius - 1;
+    unsigned p2 = 2 * (i + 1); p2 -= 1; p2 |= p2 >> 1; p2 |= p2 >> 2; p2 |= p2 >> 4; p2 |= p2 >> 8; p2 |= p2 >> 16; p2 += 1;
+    return p2 < floor_ ? floor_ : p2;
+}
+// optimize_intervals_float_{1,2,3}D_opt_MSST19 (sz_float.c:4468, :4518, :4578; doubles sz_double.c:4163-).  The quotients come from the device
+// (k_msst_sample: IEEE adds and divisions, the same bits as the host's), the logarithm and the bin from the host (glibc's log2, as in the reference).
+// The reference's walk skips samples that are zero WITHOUT advancing its column counter; zeros are left only when the array's first element is zero
+// (nearZero = 0: nothing replaces them) -- then the walk is done here, on a host copy of the array.
+template <class T>
+int msst_intervals(szhip_ctx *ctx, const szh_geom3 &G, int ndim, const T *d_in, const szhip_params *prm, double precision, bool zeros_left, unsigned *out)
+{
+    hipStream_t st = ctx->stream;
+    const unsigned max_radius = prm->max_quant_intervals / 2;
+    const int sd = prm->sample_distance;
+    const double divider = (double)(T)(log2(1 + precision) * 2);
+    std::vector<u64> hist(max_radius, 0);
+    u64 total = 0;
+    auto add = [&](double pe) { u64 ri = msst_radius_index(pe, divider); if (ri >= max_radius) ri = max_radius - 1; ++hist[ri]; ++total; };
+    const int64_t n = G.n, r2 = G.g2.count;
+    if (zeros_left) {
+        std::vector<T> h((size_t)n);
+        HIPCHK(hipMemcpyAsync(h.data(), d_in, (size_t)n * sizeof(T), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        const T *d = h.data();
+        const int64_t r3 = r2, r23 = ndim == 3 ? G.d0 : 0, rows = ndim == 3 ? G.g1.count : 0;
+        if (ndim == 1) {
+            for (int64_t pos = 2; pos < n; pos += sd) { if (d[pos] == 0) continue; add(fabs((double)d[pos] / (double)d[pos - 1])); }
+        } else if (ndim == 2) {
+            int64_t oc = sd - 1, n1 = 1, pos = r3 + oc;
+            while (pos < n) {
+                if (d[pos] == 0) { pos += sd; continue; }
+                const T pv = d[pos - 1] + d[pos - r3] - d[pos - r3 - 1];
+                add(fabs((double)(T)(pv / d[pos])));
+                oc += sd;
+                if (oc >= r3) { ++n1; const int64_t oc2 = n1 % sd; pos += (r3 + sd - oc) + (sd - oc2); oc = sd - oc2; if (oc == 0) ++oc; }
+                else pos += sd;
+            }
+        } else {
+            int64_t oc = sd - 2, n1 = 1, n2 = 1, pos = r23 + r3 + oc;
+            while (pos < n) {
+                if (d[pos] == 0) { pos += sd; continue; }
+                const T pv = d[pos - 1] + d[pos - r3] + d[pos - r23] - d[pos - 1 - r23] - d[pos - r3 - 1] - d[pos - r3 - r23] + d[pos - r3 - r23 - 1];
+                add(fabs((double)(T)(d[pos] / pv)));
+                oc += sd;
+                if (oc >= r3) {
+                    ++n2;
+                    if (n2 == rows) { ++n1; n2 = 1; pos += r3; }
+                    const int64_t oc2 = (n1 + n2) % sd;
+                    pos += (r3 + sd - oc) + (sd - oc2); oc = sd - oc2; if (oc == 0) ++oc;
+                } else pos += sd;
+            }
+        }
+    } else {
+        const int64_t nrows = ndim == 1 ? 0 : szh_sample_row_limit(G, sd);
+        const int per_row = (int)(r2 / sd + 2);
+        const int64_t slots = ndim == 1 ? (n > 2 ? (n - 2 + sd - 1) / sd : 0) : nrows * per_row;
+        if (slots > 0) {
+            TRY(ensure(ctx, ctx->msst_pe, (size_t)slots * 8));
+            const int64_t work = ndim == 1 ? slots : nrows;
+            const int grid = (int)std::min<int64_t>((work + 255) / 256, 4096);
+            hipLaunchKernelGGL((k_msst_sample<T>), dim3(grid), dim3(256), 0, st, G, ndim, d_in, nrows, sd, per_row, (double *)ctx->msst_pe.p);
+            HIPCHK(hipGetLastError());
+            std::vector<double> pe((size_t)slots);
+            HIPCHK(hipMemcpyAsync(pe.data(), ctx->msst_pe.p, (size_t)slots * 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            for (int64_t k = 0; k < slots; ++k) { if (f64_bits(pe[(size_t)k]) == 0x7ff8000000000001ull) continue; add(pe[(size_t)k]); }
+        }
+    }
+    *out = msst_pick_intervals(hist, total, prm->pred_threshold, sizeof(T) == 8 ? 64u : 32u);
+    return SZHIP_OK;
+}
+// the sweep: one launch per hyperplane (1-D: the one-lane chain).  codes: u16 per element; rec: the reconstruction (DEC: in place)
+template <class T>
+int msst_sweep(szhip_ctx *ctx, const szh_geom3 &G, int ndim, bool dec, const T *d_in, T *d_rec, uint16_t *d_codes, const MsstHostTab &ht, unsigned intervals,
+               int ign_bits)
+{
+    hipStream_t st = ctx->stream;
+    TRY(ensure(ctx, ctx->msst_ptab, (size_t)intervals * 8));
+    HIPCHK(hipMemcpyAsync(ctx->msst_ptab.p, ht.ptab.data(), (size_t)intervals * 8, hipMemcpyHostToDevice, st));
+    msst_tab tb; memset(&tb, 0, sizeof(tb));
+    tb.ptab = (const double *)ctx->msst_ptab.p;
+    if (!dec) {
+        TRY(ensure(ctx, ctx->msst_cells, ht.cells.size() * 2 + 16));
+        HIPCHK(hipMemcpyAsync(ctx->msst_cells.p, ht.cells.data(), ht.cells.size() * 2, hipMemcpyHostToDevice, st));
+        tb.cells = (const uint16_t *)ctx->msst_cells.p; tb.base = ht.base; tb.range = ht.range; tb.bits = ht.bits;
+    }
+    HIPCHK(hipStreamSynchronize(st));                        // the host vectors are pageable: the copies must be over before they go away
+    HIPCHK(hipEventRecord(ctx->ev[2], st));
+    if (ndim == 1) {
+        const size_t lds = (size_t)intervals * 8 + (dec ? 0 : ht.cells.size() * 2);
+        const int in_lds = lds <= 60 * 1024;
+        if (dec) hipLaunchKernelGGL((k_msst_chain_1d<T, true>), dim3(1), dim3(64), in_lds ? lds : 0, st, (const T *)nullptr, d_rec, d_codes, G.n, tb, (int)intervals, (int64_t)0, ign_bits, in_lds);
+        else hipLaunchKernelGGL((k_msst_chain_1d<T, false>), dim3(1), dim3(64), in_lds ? lds : 0, st, d_in, (T *)nullptr, d_codes, G.n, tb, (int)intervals, (int64_t)ht.cells.size(), ign_bits, in_lds);
+        HIPCHK(hipGetLastError());
+    } else {
+        const int r0 = ndim == 3 ? G.g0.count : 1, r1 = G.g1.count, r2 = G.g2.count;
+        for (int d = 0; d <= (r0 - 1) + (r1 - 1) + (r2 - 1); ++d) {
+            const int a_lo = std::max(0, d - (r1 - 1) - (r2 - 1)), a_hi = std::min(d, r0 - 1);
+            const int64_t threads = (int64_t)(a_hi - a_lo + 1) * r1;
+            const unsigned grid = (unsigned)((threads + 255) / 256);
+            if (dec) hipLaunchKernelGGL((k_msst_plane<T, true>), dim3(grid), dim3(256), 0, st, r0, r1, r2, ndim, d, (const T *)nullptr, d_rec, d_codes, tb, ign_bits);
+            else hipLaunchKernelGGL((k_msst_plane<T, false>), dim3(grid), dim3(256), 0, st, r0, r1, r2, ndim, d, d_in, d_rec, d_codes, tb, ign_bits);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(ctx->ev[3], st));
+    return SZHIP_OK;
+}
+
 template <class T>
 int compress14_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r0, size_t r1, size_t r2, double eb_in, double range_in,
                     double median_in, const szhip_params *prm, const unsigned char *meta, size_t meta_len, const szhip_pwr *pw, int out_on_device,
@@ -1212,6 +1372,10 @@ int compress14_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t
     // r0 == 0 and r1 == 0: the 1-D compressor SZ_compress_float_1D_MDQ (sz_float.c:353): a chain through the previous reconstructed
     // value, walked by k_chain_1d; the container and everything after the code array are the same
     const bool one_d = r0 == 0 && r1 == 0;
+    // pw->msst19: the table-driven form of PW_REL (szh_msst.h): `data` has its zeros replaced, eb_in is the RATIO; another optimiser, another
+    // quantiser, exact values taken against 0, two more header bytes -- the entropy stage and the container are the same
+    const bool msst = pw && pw->msst19;
+    const int ndim = one_d ? 1 : r0 == 0 ? 2 : 3;
     const szh_geom3 G = one_d ? szh_make_geom2(1, (int)r2) : r0 == 0 ? szh_make_geom2((int)r1, (int)r2) : szh_make_geom3((int)r0, (int)r1, (int)r2);
     const int64_t n = G.n;
     const T eb = (T)eb_in;                                     // `float realPrecision` parameter of sz_float.c:946 (:353 for 1-D)
@@ -1234,7 +1398,11 @@ int compress14_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t
 
     // ---- interval optimiser (optimize_intervals_float_3D_opt, sz_float.c:4644): the SZ 2.1 sample lattice, radius histogram only
     unsigned intervals = prm->quantization_intervals;
-    if (intervals == 0) {
+    if (intervals == 0 && msst) {
+        bool zeros_left = false;                                // only when the array's first element is zero (szhip_msst_prepare)
+        { T first; HIPCHK(hipMemcpyAsync(&first, d_in, sizeof(T), hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st)); zeros_left = first == 0; }
+        TRY(msst_intervals<T>(ctx, G, ndim, d_in, prm, eb_in, zeros_left, &intervals));
+    } else if (intervals == 0) {
         const unsigned max_radius = prm->max_quant_intervals / 2;
         TRY(ensure(ctx, ctx->hist, (size_t)(max_radius + 8192) * 4 + 64));
         TRY(ensure_pinned(ctx, (size_t)(max_radius + 8192) * 4 + 64));
@@ -1269,7 +1437,18 @@ int compress14_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t
     if (intervals > 65536 || intervals < 4) FAIL(SZHIP_ERR_UNSUP, "quantization interval count %u outside [4,65536]", intervals);
     S.intervals = intervals;
     T median = (T)median_in;
-    const int req_len = req_length<T>((double)eb, (T)range_in, &median);
+    int req_len_ = 0;
+    if (msst) {
+        // computeReqLength_float_MSST19 = 9 - exponent of (float)ratio (sz_float.c:58-62), the double rule 12 - exponent (sz_double.c:57-61) --
+        // which the FLOAT 2-D quantiser also uses (sz_float.c:2041); exact values are the values themselves (no median)
+        const int e64 = (int)((f64_bits(eb_in) & 0x7FF0000000000000ull) >> 52) - 1023;
+        const float pf = (float)eb_in; unsigned u32; memcpy(&u32, &pf, 4);
+        const int e32 = (int)((u32 & 0x7F800000u) >> 23) - 127;
+        req_len_ = (is_double || ndim == 2) ? 12 - e64 : 9 - e32;
+        median = 0;
+        if (req_len_ < 9 || req_len_ > (int)sizeof(T) * 8) FAIL(SZHIP_ERR_UNSUP, "point-wise ratio %g needs %d leading bits per exact value", eb_in, req_len_);
+    } else req_len_ = req_length<T>((double)eb, (T)range_in, &median);
+    const int req_len = req_len_;
     const int req_bytes = req_len / 8, resi_bits = req_len % 8, ign_bits = (int)sizeof(T) * 8 - req_len;
     HIPCHK(hipEventRecord(ctx->ev[1], st));
 
@@ -1277,7 +1456,15 @@ int compress14_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t
     TRY(ensure(ctx, ctx->codes_nat, (size_t)n * 2 + 64));
     uint16_t *d_codes = (uint16_t *)ctx->codes_nat.p;
     S.quant_kernel_launches = 1;
-    if (one_d) {
+    if (msst) {
+        MsstHostTab ht;
+        double hb = now_ms();
+        if (msst_build_tab(ht, eb_in, intervals, pw->plus_bits, true)) FAIL(SZHIP_ERR_UNSUP, "point-wise ratio %g with %u intervals: look-up table too large", eb_in, intervals);
+        host_ms += now_ms() - hb;
+        TRY(ensure(ctx, ctx->msst_rec, (size_t)n * sizeof(T)));
+        TRY(msst_sweep<T>(ctx, G, ndim, false, d_in, (T *)ctx->msst_rec.p, d_codes, ht, intervals, ign_bits));
+        S.quant_kernel_launches = ndim == 1 ? 1 : (unsigned)((ndim == 3 ? G.g0.count : 1) + G.g1.count + G.g2.count - 2);
+    } else if (one_d) {
         // the chain cut at its certain restarts, one thread per segment; a segment whose successor turns out not to restart raises
         // the flag, and the array is then walked by the one-wavefront kernel (same result, by construction; SZ_HIP_1D_SERIAL=1 forces it)
         HIPCHK(hipEventRecord(ctx->ev[2], st));
@@ -1357,7 +1544,7 @@ int compress14_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t
     h0 = now_ms();
     const size_t type_size = 8 + tree_bytes + pay_bytes;
     const size_t blob = pw ? (size_t)pw->signs_blob_size : 0;
-    const size_t hdr_len = meta_len + 8 + 4 + (pw ? 1 + 8 + 4 : 0) + 4 + sizeof(T) + 1 + 8 + 8 + 8 + 8 + (pw ? sizeof(T) : 0) + 8 + tree_bytes; // ... up to the Huffman payload
+    const size_t hdr_len = meta_len + 8 + 4 + (pw ? 1 + 8 + 4 : 0) + 4 + sizeof(T) + 1 + (msst ? 2 : 0) + 8 + 8 + 8 + 8 + (pw ? sizeof(T) : 0) + 8 + tree_bytes; // ... up to the Huffman payload
     const size_t total_len = hdr_len + pay_bytes + blob + lead_size + (size_t)nmid + resi_size;
     std::vector<unsigned char> hdr(hdr_len, 0);
     {
@@ -1371,10 +1558,16 @@ int compress14_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t
             szhost_put_u32be(q, pw->signs_blob_size); q += 4;
         }
         szhost_put_u32be(q, intervals); q += 4;
-        if (is_double) szhost_put_f64be(q, (double)median); else szhost_put_f32be(q, (float)median);
+        const T median_field = msst ? (T)pw->median_stored : median;
+        if (is_double) szhost_put_f64be(q, (double)median_field); else szhost_put_f32be(q, (float)median_field);
         q += sizeof(T);
         *q++ = (unsigned char)req_len;
-        szhost_put_f64be(q, (double)eb); q += 8;
+        if (msst) {                                              // plus_bits, max_bits (TightDataPointStorageF.c:431-435; Huffman.c:828-833)
+            int max_bits = 0;
+            for (unsigned s2 = 0; s2 < intervals; ++s2) if (tab_len[s2] > max_bits) max_bits = tab_len[s2];
+            *q++ = pw->plus_bits; *q++ = (unsigned char)max_bits;
+        }
+        szhost_put_f64be(q, msst ? eb_in : (double)eb); q += 8;
         szhost_put_u64be(q, (uint64_t)type_size); q += 8;
         szhost_put_u64be(q, (uint64_t)E); q += 8;
         szhost_put_u64be(q, (uint64_t)nmid); q += 8;
@@ -1447,11 +1640,13 @@ int compress14_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t
 
 // `body_off`: offset of the max_quant_intervals field (4 + 28|36 + 8)
 template <class T>
-int decompress14_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_on_device, size_t stream_len, size_t body_off, bool pwr,
+int decompress14_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_on_device, size_t stream_len, size_t body_off, int pwr,
                       size_t r0, size_t r1, size_t r2, void *out, int out_on_device, szhip_stats *stats)
 {
     const int is_double = sizeof(T) == 8;
     const bool one_d = r0 == 0 && r1 == 0;                     // decompressDataSeries_float_1D (szd_float.c:185)
+    const bool msst = pwr == 2;                                // pwr: 0 plain, 1 PW_REL log-domain form, 2 PW_REL table-driven form (szh_msst.h)
+    const int ndim = one_d ? 1 : r0 == 0 ? 2 : 3;
     const szh_geom3 G = one_d ? szh_make_geom2(1, (int)r2) : r0 == 0 ? szh_make_geom2((int)r1, (int)r2) : szh_make_geom3((int)r0, (int)r1, (int)r2);
     const int64_t n = G.n;
     const double t_begin = now_ms();
@@ -1469,7 +1664,7 @@ int decompress14_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream
 
     // ---- header + tree on the host (TightDataPointStorageF.c:54-265); a device-resident stream hands over a prefix
     double h0 = now_ms();
-    const size_t fixed = 4 + (pwr ? 1 + 8 + 4 : 0) + 4 + sizeof(T) + 1 + 8 + 8 + 8 + 8 + (pwr ? sizeof(T) : 0) + 8;
+    const size_t fixed = 4 + (pwr ? 1 + 8 + 4 : 0) + 4 + sizeof(T) + 1 + (msst ? 2 : 0) + 8 + 8 + 8 + 8 + (pwr ? sizeof(T) : 0) + 8;
     if (body_off + fixed > stream_len) FAIL(SZHIP_ERR_STREAM, "truncated stream");
     std::vector<unsigned char> hbuf;
     const unsigned char *hs = stream_in;
@@ -1487,9 +1682,12 @@ int decompress14_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream
     size_t blob = 0;
     if (pwr) { q += 1 + 8; blob = szhost_get_u32be(q); q += 4; }   // radExpo, segment_size, size of the sign bytes (TightDataPointStorageF.c:137-148)
     const unsigned intervals = szhost_get_u32be(q); q += 4;
-    const T median = is_double ? (T)szhost_get_f64be(q) : (T)szhost_get_f32be(q); q += sizeof(T);
+    T median = is_double ? (T)szhost_get_f64be(q) : (T)szhost_get_f32be(q); q += sizeof(T);
     const int req_len = *q++;
-    const T eb = (T)szhost_get_f64be(q); q += 8;                   // `float realPrecision = tdps->realPrecision`, szd_float.c:610
+    int plus_bits = 0;
+    if (msst) { plus_bits = q[0]; q += 2; median = 0; }           // plus_bits, max_bits (TightDataPointStorageF.c:164-168); exact values carry no median
+    const double eb_field = szhost_get_f64be(q);
+    const T eb = (T)eb_field; q += 8;                              // `float realPrecision = tdps->realPrecision`, szd_float.c:610
     const uint64_t type_size = szhost_get_u64be(q); q += 8;
     const uint64_t E = szhost_get_u64be(q); q += 8;
     const uint64_t nmid = szhost_get_u64be(q); q += 8;
@@ -1570,7 +1768,12 @@ int decompress14_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream
     HIPCHK(hipEventRecord(ctx->ev[1], st));
 
     // ---- reconstruct
-    if (one_d) {
+    if (msst) {
+        if (!(eb_field > 0 && eb_field < 1) || plus_bits > 16) FAIL(SZHIP_ERR_STREAM, "bad point-wise ratio / table parameters");
+        MsstHostTab ht;
+        msst_build_tab(ht, eb_field, intervals, plus_bits, false);
+        TRY(msst_sweep<T>(ctx, G, ndim, true, nullptr, d_out, d_codes, ht, intervals, 0));
+    } else if (one_d) {
         HIPCHK(hipEventRecord(ctx->ev[2], st));
         if (tune_int("SZ_HIP_1D_SERIAL", 0))
             hipLaunchKernelGGL((k_chain_1d<T, true>), dim3(1), dim3(64), 0, st, (const T *)nullptr, d_out, d_codes, n, eb, (T)(1 / eb), (int)intervals, median, 0);
@@ -1655,15 +1858,69 @@ int pwr_prepare_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_
     return SZHIP_OK;
 }
 
+
+// computeRangeSize_float_MSST19 (dataCompression.c:121-166) and the zero replacement of the _MSST19 wrappers (sz_float_pwr.c:2053-2062), on a COPY
+// (the reference overwrites the caller's zeros).  nearZero: the first value of least non-zero magnitude -- or 0 when element 0 is zero (the scan
+// starts from it and nothing is smaller in magnitude than 0); signs: from element 1 on, as the reference's loop.
+template <class T>
+int msst_prepare_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t n, double vmax, double ratio, void **d_prep_out,
+                      unsigned char *signs_host, int *positive, double *near_zero_out, double *median_log, double *min_log_value)
+{
+    hipStream_t st = ctx->stream;
+    const T *d_in = (const T *)data;
+    if (!data_on_device) {
+        TRY(ensure(ctx, ctx->in, n * sizeof(T)));
+        TRY(staged_copy(ctx, ctx->in.p, data, (size_t)n * sizeof(T), true));
+        d_in = (const T *)ctx->in.p;
+    }
+    TRY(ensure(ctx, ctx->pwr_log, n * sizeof(T)));
+    TRY(ensure(ctx, ctx->pwr_signs, n));
+    TRY(ensure(ctx, ctx->pwr_small, PWR_RED * 8));
+    T *d_prep = (T *)ctx->pwr_log.p;
+    u64 *red = (u64 *)ctx->pwr_small.p;
+    const u64 init[MS_RED] = {~0ull, ~0ull, 0ull, 0ull};
+    HIPCHK(hipMemcpyAsync(red, init, sizeof(init), hipMemcpyHostToDevice, st));
+    const int grid = (int)std::min<int64_t>(((int64_t)n + 255) / 256, 4096);
+    hipLaunchKernelGGL((k_msst_scan<T>), dim3(grid), dim3(256), 0, st, d_in, (int64_t)n, (unsigned char *)ctx->pwr_signs.p, red);
+    HIPCHK(hipGetLastError());
+    u64 res[MS_RED]; T first = 0;
+    HIPCHK(hipMemcpyAsync(res, red, sizeof(res), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&first, d_in, sizeof(T), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    T near_zero = 0;
+    if (first != 0 && res[MS_MINMAG] != ~0ull) {
+        hipLaunchKernelGGL((k_msst_minidx<T>), dim3(grid), dim3(256), 0, st, d_in, (int64_t)n, res[MS_MINMAG], red);
+        HIPCHK(hipGetLastError());
+        u64 idx = 0;
+        HIPCHK(hipMemcpyAsync(&idx, red + MS_MINIDX, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (idx >= n) FAIL(SZHIP_ERR_INTERNAL, "nearZero position out of range");
+        HIPCHK(hipMemcpyAsync(&near_zero, d_in + idx, sizeof(T), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    const T multiplier = (T)pow(1 + ratio, -3.0001);
+    const T zval = (T)(near_zero * multiplier);
+    hipLaunchKernelGGL((k_msst_fill<T>), dim3(grid), dim3(256), 0, st, d_in, (int64_t)n, d_prep, zval);
+    HIPCHK(hipGetLastError());
+    *near_zero_out = (double)near_zero;
+    *median_log = (double)(T)sqrt(fabs((double)(T)(near_zero * (T)vmax)));
+    *min_log_value = (double)(T)((double)near_zero / ((1 + ratio) * (1 + ratio)));
+    *positive = res[MS_NEG] ? 0 : 1;
+    if (res[MS_NEG] && signs_host) HIPCHK(hipMemcpyAsync(signs_host, ctx->pwr_signs.p, n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    *d_prep_out = d_prep;
+    return SZHIP_OK;
+}
+
 template <class T>
 int decompress14_pwr_impl(szhip_ctx *ctx, const unsigned char *stream, int stream_on_device, size_t stream_len, size_t body_off,
-                          size_t r0, size_t r1, size_t r2, const unsigned char *signs_host, double threshold, void *out, int out_on_device, szhip_stats *stats)
+                          size_t r0, size_t r1, size_t r2, const unsigned char *signs_host, double threshold, bool msst, void *out, int out_on_device, szhip_stats *stats)
 {
     const size_t n = (r0 ? r0 : 1) * (r1 ? r1 : 1) * r2;
     hipStream_t st = ctx->stream;
     TRY(ensure(ctx, ctx->pwr_log, n * sizeof(T)));
     T *d_log = (T *)ctx->pwr_log.p;
-    TRY(decompress14_impl<T>(ctx, stream, stream_on_device, stream_len, body_off, true, r0, r1, r2, d_log, 1, stats));
+    TRY(decompress14_impl<T>(ctx, stream, stream_on_device, stream_len, body_off, msst ? 2 : 1, r0, r1, r2, d_log, 1, stats));
     const unsigned char *d_signs = nullptr;
     if (signs_host) {
         TRY(ensure(ctx, ctx->pwr_signs, n));
@@ -1673,7 +1930,8 @@ int decompress14_pwr_impl(szhip_ctx *ctx, const unsigned char *stream, int strea
     T *d_out = (T *)out;
     if (!out_on_device) { TRY(ensure(ctx, ctx->out, n * sizeof(T))); d_out = (T *)ctx->out.p; }
     const int grid = (int)std::min<int64_t>(((int64_t)n + 255) / 256, 4096);
-    hipLaunchKernelGGL((k_pwr_exp<T>), dim3(grid), dim3(256), 0, st, (const T *)d_log, (int64_t)n, (T)threshold, d_signs, d_out);
+    if (msst) hipLaunchKernelGGL((k_msst_post<T>), dim3(grid), dim3(256), 0, st, (const T *)d_log, (int64_t)n, (T)threshold, d_signs, d_out);
+    else hipLaunchKernelGGL((k_pwr_exp<T>), dim3(grid), dim3(256), 0, st, (const T *)d_log, (int64_t)n, (T)threshold, d_signs, d_out);
     HIPCHK(hipGetLastError());
     if (!out_on_device) TRY(staged_copy(ctx, out, d_out, n * sizeof(T), false));
     HIPCHK(hipStreamSynchronize(st));
@@ -1979,7 +2237,7 @@ void szhip_destroy(szhip_ctx *ctx)
                       &ctx->order, &ctx->small, &ctx->hist, &ctx->col_zeros, &ctx->col_zeros64, &ctx->col_off, &ctx->partial,
                       &ctx->samples, &ctx->unpred, &ctx->stream_buf, &ctx->chunk_bits, &ctx->chunk_off, &ctx->code_tab,
                       &ctx->len_tab, &ctx->dec_tab, &ctx->starts, &ctx->ends, &ctx->counts, &ctx->offs, &ctx->dirty, &ctx->zcnt, &ctx->zpos,
-                      &ctx->pwr_log, &ctx->pwr_signs, &ctx->pwr_small, &ctx->coef_dec};
+                      &ctx->pwr_log, &ctx->pwr_signs, &ctx->pwr_small, &ctx->coef_dec, &ctx->msst_ptab, &ctx->msst_cells, &ctx->msst_rec, &ctx->msst_pe};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
     if (ctx->pinned) hipHostFree(ctx->pinned);
     if (ctx->pinned2) hipHostFree(ctx->pinned2);
@@ -2051,8 +2309,8 @@ int szhip_decompress_sz14(szhip_ctx *ctx, int dtype, const unsigned char *stream
     if ((r0 != 0 && r0 < 2) || (r1 < 2 && !(r0 == 0 && r1 == 0)) || r2 < 2 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff) return SZHIP_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
     const int rc = dtype == SZHIP_F32
-               ? decompress14_impl<float>(ctx, stream, stream_on_device, stream_len, body_off, false, r0, r1, r2, out, out_on_device, stats)
-               : decompress14_impl<double>(ctx, stream, stream_on_device, stream_len, body_off, false, r0, r1, r2, out, out_on_device, stats);
+               ? decompress14_impl<float>(ctx, stream, stream_on_device, stream_len, body_off, 0, r0, r1, r2, out, out_on_device, stats)
+               : decompress14_impl<double>(ctx, stream, stream_on_device, stream_len, body_off, 0, r0, r1, r2, out, out_on_device, stats);
     if (rc != SZHIP_OK) { hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream); }
     return rc;
 }
@@ -2066,6 +2324,18 @@ int szhip_pwr_prepare(szhip_ctx *ctx, int dtype, const void *data, int data_on_d
     const int rc = dtype == SZHIP_F32
         ? pwr_prepare_impl<float>(ctx, data, data_on_device, n, vmin, vmax, pwr_ratio, d_log, signs_host, positive, real_precision, value_range, median, min_log_value)
         : pwr_prepare_impl<double>(ctx, data, data_on_device, n, vmin, vmax, pwr_ratio, d_log, signs_host, positive, real_precision, value_range, median, min_log_value);
+    if (rc != SZHIP_OK) hipStreamSynchronize(ctx->stream);
+    return rc;
+}
+
+int szhip_msst_prepare(szhip_ctx *ctx, int dtype, const void *data, int data_on_device, size_t n, double vmax, double pwr_ratio, void **d_prepared,
+                       unsigned char *signs_host, int *positive, double *near_zero, double *median_log, double *min_log_value)
+{
+    if (!ctx || !data || !d_prepared || !positive || !near_zero || !median_log || !min_log_value || n == 0 || !(pwr_ratio > 0)) return SZHIP_ERR_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
+    const int rc = dtype == SZHIP_F32
+        ? msst_prepare_impl<float>(ctx, data, data_on_device, n, vmax, pwr_ratio, d_prepared, signs_host, positive, near_zero, median_log, min_log_value)
+        : msst_prepare_impl<double>(ctx, data, data_on_device, n, vmax, pwr_ratio, d_prepared, signs_host, positive, near_zero, median_log, min_log_value);
     if (rc != SZHIP_OK) hipStreamSynchronize(ctx->stream);
     return rc;
 }
@@ -2089,10 +2359,12 @@ int szhip_sz14_pwr_locate(int dtype, const unsigned char *stream, size_t stream_
 {
     if (!stream || !blob_off || !blob_size || !min_log_value) return SZHIP_ERR_ARG;
     const size_t es = dtype == SZHIP_F32 ? 4 : 8;
-    const size_t fixed = 4 + 1 + 8 + 4 + 4 + es + 1 + 8 + 8 + 8 + 8 + es;          // ... up to the type array (TightDataPointStorageF.c:133-240)
+    if (stream_len < 4) return SZHIP_ERR_STREAM;
+    const size_t x = (stream[3] & 0x08) ? 2 : 0;                                    // table-driven form: plus_bits, max_bits after reqLength (:164-168)
+    const size_t fixed = 4 + 1 + 8 + 4 + 4 + es + 1 + x + 8 + 8 + 8 + 8 + es;      // ... up to the type array (TightDataPointStorageF.c:133-240)
     if (body_off + fixed > stream_len) return SZHIP_ERR_STREAM;
     const unsigned char *q = stream + body_off + 4 + 1 + 8;
-    *blob_size = szhost_get_u32be(q); q += 4 + 4 + es + 1 + 8;
+    *blob_size = szhost_get_u32be(q); q += 4 + 4 + es + 1 + x + 8;
     const uint64_t type_size = szhost_get_u64be(q); q += 8 + 8 + 8;
     *min_log_value = dtype == SZHIP_F32 ? (double)szhost_get_f32be(q) : szhost_get_f64be(q);
     if (type_size > stream_len || *blob_size > stream_len || body_off + fixed + type_size + *blob_size > stream_len) return SZHIP_ERR_STREAM;
@@ -2108,9 +2380,10 @@ int szhip_decompress_sz14_pwr(szhip_ctx *ctx, int dtype, const unsigned char *st
     if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
     size_t bo, bs; double thr;
     if (szhip_sz14_pwr_locate(dtype, stream, stream_len, body_off, &bo, &bs, &thr) != SZHIP_OK) return SZHIP_ERR_STREAM;
+    const bool msst = (stream[3] & 0x08) != 0;                   // TightDataPointStorageF.c:81
     const int rc = dtype == SZHIP_F32
-               ? decompress14_pwr_impl<float>(ctx, stream, 0, stream_len, body_off, r0, r1, r2, signs_host, thr, out, out_on_device, stats)
-               : decompress14_pwr_impl<double>(ctx, stream, 0, stream_len, body_off, r0, r1, r2, signs_host, thr, out, out_on_device, stats);
+               ? decompress14_pwr_impl<float>(ctx, stream, 0, stream_len, body_off, r0, r1, r2, signs_host, thr, msst, out, out_on_device, stats)
+               : decompress14_pwr_impl<double>(ctx, stream, 0, stream_len, body_off, r0, r1, r2, signs_host, thr, msst, out, out_on_device, stats);
     if (rc != SZHIP_OK) { hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream); }
     return rc;
 }
