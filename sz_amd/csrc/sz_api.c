@@ -403,7 +403,9 @@ static int compress_fp(int dataType, int withRegression, unsigned char **newByte
         szhost_write_meta(&m, pflags, meta);
         szhip_params php; memset(&php, 0, sizeof(php));
         php.sample_distance = confparams_cpr->sampleDistance; php.pred_threshold = confparams_cpr->predThreshold;
-        php.max_quant_intervals = confparams_cpr->maxRangeRadius * 2;
+        /* the optimiser's range is maxRangeRadius; the header records confparams_cpr->max_quant_intervals (TightDataPointStorageF.c:399), which a
+         * fixed quantization_intervals overwrites while leaving maxRangeRadius alone (conf.c:193-197) */
+        php.max_quant_intervals = exe_params->optQuantMode == 1 ? confparams_cpr->maxRangeRadius * 2 : confparams_cpr->max_quant_intervals;
         php.quantization_intervals = exe_params->optQuantMode == 1 ? 0 : (unsigned)exe_params->intvCapacity;
         unsigned char *ptmp = NULL; size_t ptmpSize = 0;
         int crc = szhip_compress_sz14_pwr(ctx, dt, d_log, 1, dim == 4 ? r4 * r3 : r3, r2, r1, rp, lrange, lmedian, &php, meta, 4 + meta_len, &pw, 0,
@@ -452,7 +454,7 @@ static int compress_fp(int dataType, int withRegression, unsigned char **newByte
     szhip_params hp; memset(&hp, 0, sizeof(hp));
     hp.flags = fuse_range ? SZHIP_RANGE_FROM_DATA : 0;
     hp.sample_distance = confparams_cpr->sampleDistance; hp.pred_threshold = confparams_cpr->predThreshold;
-    hp.max_quant_intervals = confparams_cpr->maxRangeRadius * 2;
+    hp.max_quant_intervals = exe_params->optQuantMode == 1 ? confparams_cpr->maxRangeRadius * 2 : confparams_cpr->max_quant_intervals;   /* as above */
     hp.quantization_intervals = exe_params->optQuantMode == 1 ? 0 : (unsigned)exe_params->intvCapacity;
     size_t s0 = dim == 4 ? r4 * r3 : r3;   /* 2-D: r3 == 0 tells the HIP layer so (sz_float.c:2942 passes (r2, r1)) */
     unsigned char *tmp = NULL; size_t tmpSize = 0;

@@ -1,5 +1,7 @@
 """development: differential fuzzing of the HIP path against the oracle (streams byte for byte, decode bit for bit).
-usage: python tools/gpu_fuzz.py [cases] [seed] [sz14 | pwr]
+usage: python tools/gpu_fuzz.py [cases] [seed] [sz14 | pwr | msst | fast]
+  msst: point-wise relative bounds in the reference's default table-driven form: streams byte for byte, decode bit for bit (both dtypes:
+       no transcendental on the device); the bound itself is the reference's business there -- the largest excess is reported
   pwr: point-wise relative bounds (log-domain form): positive / sign-changing data with zeros, streams byte for byte (both sides code the
        sign bytes with the system zstd), float decode bit for bit, double decode to 1 ulp (exp2 of the libm vs the GPU's)"""
 import os, sys, time
@@ -14,11 +16,14 @@ assert sz_amd.SZ_Init(os.path.join(ROOT, "tests", "golden", "sz_speed.config")) 
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 sz14 = len(sys.argv) > 3 and sys.argv[3] == "sz14"      # withLinearRegression = NO: the SZ 1.4 path
-pwr = len(sys.argv) > 3 and sys.argv[3] == "pwr"
+msst = len(sys.argv) > 3 and sys.argv[3] == "msst"
+pwr = len(sys.argv) > 3 and sys.argv[3] in ("pwr", "msst")
+worst_excess = 0.0
 fast = len(sys.argv) > 3 and sys.argv[3] == "fast"        # the opt-in fast mode against oracle/szo_fast.c
 fctx = sz_amd.HipContext(0) if fast else None
 oparams = O.default_params(with_regression=0) if sz14 else None
 if sz14: sz_amd.conf_params().withRegression = 0
+if pwr: sz_amd.conf_params().accelerate_pw_rel_compression = 1 if msst else 0
 fails = 0
 t_start = time.time()
 for c in range(ncases):
@@ -84,16 +89,23 @@ for c in range(ncases):
         if rng.random() < 0.5: dd[rng.random(d.shape) < 0.03] = 0.0
         d = np.ascontiguousarray(dd.astype(dt))
         ratio = float(10.0 ** rng.uniform(-4, -1))
-        po = O.default_params(); po.pw_rel_bound_ratio = ratio; po.segment_size = 0
+        if msst and rng.random() < 0.15: d.reshape(-1)[0] = 0          # nearZero = 0: the zeros stay (computeRangeSize_float_MSST19 starts from element 0)
+        po = O.default_params(); po.pw_rel_bound_ratio = ratio; po.segment_size = 0; po.accelerate_pw_rel = 1 if msst else 0
         try:
             ref, _ = O.compress(d, O.PW_REL, 0.0, 0.0, params=po)
             got = sz_amd.SZ_compress_args(d, sz_amd.PW_REL, 0.0, 0.0, ratio)
             back = sz_amd.SZ_decompress(ref, d.shape, d.dtype)
             dec = O.decompress(ref, d.shape, d.dtype)
-            if dt == np.float32: okd = np.array_equal(back.view(np.uint32), dec.view(np.uint32))
+            if msst:
+                assert ref[3] & 0x08 or ref[3] & 0x10
+                okd = np.array_equal(back.view(np.uint8), dec.view(np.uint8))
+            elif dt == np.float32: okd = np.array_equal(back.view(np.uint32), dec.view(np.uint32))
             else: okd = bool(np.all((back >= np.nextafter(dec, -np.inf)) & (back <= np.nextafter(dec, np.inf))) and np.array_equal(np.signbit(back), np.signbit(dec)))
             x = d.astype(np.float64); nzm = x != 0
             okb = (not nzm.any()) or float((np.abs(back.astype(np.float64)[nzm] - x[nzm]) / np.abs(x[nzm])).max()) <= ratio
+            if msst:
+                if nzm.any() and np.isfinite(back).all(): worst_excess = max(worst_excess, float((np.abs(back.astype(np.float64)[nzm] - x[nzm]) / np.abs(x[nzm])).max()) / ratio)
+                okb = True
             if dt == np.float64 and got != ref and len(got) == len(ref) and okd and okb:
                 soft = globals().get("soft", 0) + 1; globals()["soft"] = soft      # log2 of a double: the GPU's and glibc's last bit differ on a few values
                 continue
@@ -125,4 +137,4 @@ for c in range(ncases):
         st = sz_amd.SZ_hip_last_stats()
         print(f"FAIL case={c} seed0={seed0} dtype={np.dtype(dt).name} shape={shape} kind={kind} mode={mode} abs={abs_b:.3e} rel={rel_b:.3e} "
               f"stream_ok={ok_stream} dec_ok={ok_dec} len ref/gpu {len(ref)}/{len(got) if 'got' in dir() else -1} intervals={st.intervals} reg={st.n_reg_blocks} unpred={st.n_unpred}")
-print(f"fuzz: {ncases} cases, {fails} failures, {time.time() - t_start:.0f} s" + (f" ({globals().get('soft', 0)} float64 streams of equal length differ in log2's last bit)" if pwr else ""))
+print(f"fuzz: {ncases} cases, {fails} failures, {time.time() - t_start:.0f} s" + (f" (largest point-wise error / ratio, the reference's own: {worst_excess:.4f})" if msst else f" ({globals().get('soft', 0)} float64 streams of equal length differ in log2's last bit)" if pwr else ""))
