@@ -128,7 +128,7 @@ def test_unsupported_calls_fail_loudly(sz):
         sz.SZ_compress_args(np.random.default_rng(0).random((8, 9, 10), dtype=np.float32), sz.PW_REL, 0, 0, 0.0)       # a point-wise ratio of 0
     with pytest.raises(sz_amd.SZError):
         sz.SZ_decompress(b"\x02\x01\x0c\xc0" + b"\x00" * 60, (8, 9, 10), np.float32)
-    with pytest.raises(sz_amd.SZError):                                                                             # an MSST19 point-wise-relative stream
+    with pytest.raises(sz_amd.SZError):                                                                             # a point-wise-relative (MSST19-flagged) stream of zeros
         sz.SZ_decompress(b"\x02\x01\x0c\x68" + b"\x00" * 200, (8, 9, 10), np.float32)
 
 
@@ -515,7 +515,7 @@ def test_differential_fuzz_sz14_against_the_oracle(built):
 
 
 def test_fuzz_pw_rel_and_fast_mode(built):
-    """random differential cases for the two paths added in round 2: point-wise relative bounds (log-domain form) and the opt-in fast mode"""
+    """random differential cases for two paths added in round 2: point-wise relative bounds (log-domain form; the MSST19 form has tests/test_msst19.py) and the opt-in fast mode"""
     import subprocess
     for args in (("300", "41", "pwr"), ("300", "43", "fast")):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_fuzz.py"), *args], capture_output=True, text=True, timeout=600)
