@@ -96,7 +96,7 @@ struct msst_tab {
     const double *ptab;          // precisionTable[intervals]
     const uint16_t *cells;       // [(range + 1) << bits]   (compress only)
     u64 base, range;
-    int bits;
+    int bits, intervals;
 };
 __device__ __forceinline__ int msst_state(const msst_tab &t, double quotient)
 {
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void k_msst_plane(int r0, int r1, int r2, int 
     }
     if (DEC) {
         const int t = codes[idx];
-        if (t) rec[idx] = (T)(fabs((double)pred) * tb.ptab[t]);
+        if (t) rec[idx] = (T)(fabs((double)pred) * tb.ptab[t < tb.intervals ? t : 0]);          // a code beyond the table: a broken stream
     } else {
         const T v = x[idx];
         const int state = msst_state(tb, (double)(T)(v / pred));
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(64) void k_msst_chain_1d(const T *__restrict__ x, T
             if (u >= m) break;
             const int64_t i = base + u;
             if (DEC) {
-                if (cv[u]) { pred = (T)(fabs((double)pred) * t.ptab[cv[u]]); out[i] = pred; }
+                if (cv[u]) { pred = (T)(fabs((double)pred) * t.ptab[cv[u] < intervals ? cv[u] : 0]); out[i] = pred; }
                 else pred = xv[u];
             } else {
                 int state = 0;

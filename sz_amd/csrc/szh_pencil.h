@@ -55,8 +55,16 @@ template <class T> struct szh_qargs {
                               // wavefront polls these words and then fetches only granules that exist
     int fmt;                  // 0: SZ 2.1 block path; 1: SZ 1.4 whole-array Lorenzo (sz_float.c:946): no blocks, capacity = intervals,
                               //    interval number through double, lossy "exact" values, second-order predictor on the first row
+                              // 2: the table-driven point-wise-relative form ("MSST19", sz_float.c:2270-2730): multiplicative Lorenzo predictor,
+                              //    code = table[exponent, leading mantissa bits of x / prediction], reconstruction |prediction| * ptab[code]
     T median;                 // fmt 1: exact values are kept as reqLength leading bits of (x - median)
-    int ign_bits;             // fmt 1: 8*sizeof(T) - reqLength, >= 0
+    int ign_bits;             // fmt 1, 2: 8*sizeof(T) - reqLength, >= 0
+    const double *ptab;       // fmt 2: precisionTable[cap]
+    const uint16_t *cells;    // fmt 2, compress: [(trange + 1) << tbits] (MultiLevelCacheTableWideInterval.c:53-107, built on the host)
+    szh_u64 tbase, trange;    // fmt 2: exponent field of the first sub-table, number of sub-tables - 1
+    int tbits;                // fmt 2: mantissa bits per sub-table
+    int f32arith;             // fmt 2: 1 = the float 2-D quantiser, whose products are float (sz_float.c:2091, :2152); else products in double
+    int ndim3;                // fmt 2: 1 = a 3-D array (one boundary case of ITS compressor has no fabs, sz_float.c:2459)
     int backoff;              // FILL wavefront: sleep units between two rounds that delivered nothing
     int wide;                 // 1: the granule rows of a tile lie within 4 GB of the tile's first row: 16-byte buffer accesses with 32-bit offsets
     int trace_tile;           // development: (TI << 16) | TJ of the tile whose left-hand hand-off is logged round by round (SZH_TRACE_LOG)
@@ -173,6 +181,31 @@ SZH_HD int szh_quant_sel14(T x, T pred, T eb, T recip, int capacity, int radius,
     return ok ? q + radius : 0;
 }
 
+// the MSST19 flavour: an exact value is the leading bits of the value itself (compressSingleFloatValue_MSST19, dataCompression.c:479-501)
+SZH_HD float szh_keep_bits_msst(float x, int ign)
+{
+    int32_t s; __builtin_memcpy(&s, &x, 4);
+    s = (int32_t)((uint32_t)(s >> ign) << ign);
+    float kept; __builtin_memcpy(&kept, &s, 4);
+    return kept;
+}
+SZH_HD double szh_keep_bits_msst(double x, int ign)
+{
+    int64_t s; __builtin_memcpy(&s, &x, 8);
+    s = (int64_t)((uint64_t)(s >> ign) << ign);
+    double kept; __builtin_memcpy(&kept, &s, 8);
+    return kept;
+}
+// the table look-up of the MSST19 quantisers (sz_float.c:2409-2415): 0 = no entry (the value is stored "exactly")
+template <class T>
+SZH_HD int szh_msst_state(const szh_qargs<T> &a, double quotient)
+{
+    szh_u64 u; __builtin_memcpy(&u, &quotient, 8);
+    const szh_u64 e = ((u & 0x7fffffffffffffffull) >> 52) - a.tbase;
+    if (e > a.trange) return 0;
+    return (int)a.cells[(size_t)(e << a.tbits) + (size_t)((u & 0x000fffffffffffffull) >> (52 - a.tbits))];
+}
+
 // B: back end. Requires: NL, lane(l), shfl_up(dst,src,d), shfl_up1(dst,src) (d = 1; lanes with lane % 8 == 0 may receive anything),
 //    readlane(src,lane), all(pred), lds_order(), touch(v) (the value must be in its register here),
 //    ld_gran(p), st_gran(p,v), ld_flag(p), st_flag(p,v), backoff(n), nap(), clock(), where(),
@@ -218,7 +251,7 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
 
     // ---- per-lane constants ----
     int il[NL], jl[NL], skew[NL], askew[NL], hsk[NL], hrd[NL], st1[NL], st2[NL], cidx[NL], ctrash[NL];
-    bool inb[NL], corner[NL];
+    bool inb[NL], corner[NL], top[NL], left[NL];
     int64_t rowoff[NL], blkrow[NL];
     T fii[NL], fjj[NL];
     constexpr int NEVER = -(1 << 30);          // as a skew: (unsigned)(t - NEVER) < r2 never holds
@@ -227,6 +260,7 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
         il[l] = lane >> 3; jl[l] = lane & 7;
         const int i = 8 * I + il[l], j = 8 * J + jl[l];
         inb[l] = (i < r0) && (j < r1);
+        top[l] = i == 0; left[l] = j == 0;     // fmt 2: no neighbour in dim 0 / dim 1 (the multiplicative stencil takes 1 there, below)
         const int ic = i < r0 ? i : r0 - 1, jc = j < r1 ? j : r1 - 1;
         const int b0 = szh_blk_of(G.g0, ic), b1 = szh_blk_of(G.g1, jc);
         fii[l] = (T)(ic - szh_blk_start(G.g0, b0));
@@ -425,7 +459,7 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
     // rolling neighbour state (values at the previous step)
     T cur[NL], A1[NL], B1[NL], C1[NL], cur2[NL];
     SZH_FORL { cur[l] = 0; A1[l] = 0; B1[l] = 0; C1[l] = 0; cur2[l] = 0; }
-    const bool first_pencil = FMT == 1 && I == 0 && J == 0;   // holds the array's first row (its lane 0)
+    const bool first_pencil = FMT >= 1 && I == 0 && J == 0;   // holds the array's first row (its lane 0)
 
     const int tsteps = r2 + 14;
     int flushed = 0, filled = 0;   // code-ring columns already written back (compress) / already brought in (decompress)
@@ -511,6 +545,22 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
                 // (SZ 1.4 subtracts [-s0-s1] before [-s0-1], sz_float.c:1311; its first row predicts 2P[k-1] - P[k-2] from k = 2 on)
                 T pred = FMT == 1 ? cur[l] + nA + nB - A1[l] - nC - B1[l] + C1[l] : cur[l] + nA + nB - A1[l] - B1[l] - nC + C1[l];
                 if (FMT == 1 && first_pencil && lane == 0 && k >= 2) pred = (T)2 * cur[l] - cur2[l];
+                bool nofabs = false; (void)nofabs;
+                if (FMT == 2) {
+                    // [-1] * [-s1] * [-s0] * [-s0-s1-1] / ([-s1-1] * [-s0-s1] * [-s0-1]) in double, left to right (sz_float.c:2654-2656); on the
+                    // array's faces and edges the reference spells the 2-D / 1-D forms out (:2403-2620) -- they ARE this form with 1 in place
+                    // of every neighbour that does not exist (a factor of exactly 1 changes no bit) -- except on the very first row, where it is
+                    // P[k-1]^2 / P[k-2] from k = 2 on (:2403).  The float 2-D quantiser multiplies in float ((a * b) / c, :2091, :2152).
+                    const bool k0 = k == 0;
+                    const T one = (T)1;
+                    const T mc = k0 ? one : cur[l], mA = left[l] ? one : nA, mB = top[l] ? one : nB;
+                    const T mA1 = (left[l] || k0) ? one : A1[l], mB1 = (top[l] || k0) ? one : B1[l];
+                    const T mC = (top[l] || left[l]) ? one : nC, mC1 = (top[l] || left[l] || k0) ? one : C1[l];
+                    if (top[l] && left[l] && k >= 2) pred = a.f32arith ? (T)((T)(cur[l] * cur[l]) / cur2[l]) : (T)((double)cur[l] * (double)cur[l] / (double)cur2[l]);
+                    else if (a.f32arith) pred = (T)((T)(mc * mA) / mA1);
+                    else pred = (T)((double)mc * (double)mA * (double)mB * (double)mC1 / ((double)mA1 * (double)mC * (double)mB1));
+                    nofabs = !DEC && a.ndim3 && top[l] && !left[l] && k0;          // the compressor multiplies the signed prediction here (:2459)
+                }
                 T predr = 0;
                 if (HASREG) predr = pbase[l] + cc[l] * (T)kk[l] + cd[l];
                 const bool is_lor = HASREG ? lor[l] : true;
@@ -518,7 +568,13 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
                 if (!DEC) {
                     const T x = xr[s][l];
                     T rcl;
-                    int code = FMT == 1 ? szh_quant_sel14<T>(x, pred, eb, recip, cap_reg, radius, a.median, a.ign_bits,
+                    int code;
+                    if (FMT == 2) {
+                        code = szh_msst_state<T>(a, (double)(T)(x / pred));
+                        if (first_pencil && lane == 0 && k == 0) code = 0;          // the array's first value is always exact
+                        rcl = code ? (T)((nofabs ? (double)pred : (double)szh_abs(pred)) * a.ptab[code]) : szh_keep_bits_msst(x, a.ign_bits);
+                    } else
+                    code = FMT == 1 ? szh_quant_sel14<T>(x, pred, eb, recip, cap_reg, radius, a.median, a.ign_bits,
                                                              first_pencil && lane == 0 && k == 0, &rcl)
                                         : szh_quant_sel<T>(x, pred, eb, recip, cap_lor, radius, &rcl);
                     if (USEMEAN) {
@@ -544,6 +600,7 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
                         if (is_lor && c != 0 && c < radius) c += 1;                 // szd_float.c:3784
                     }
                     nv = p + (T)(2 * (c - radius)) * eb;
+                    if (FMT == 2) nv = (T)((double)szh_abs(pred) * a.ptab[c < cap_reg ? c : 0]);   // szd_float.c:2927 (a code beyond the table: a broken stream)
                     if (USEMEAN && is_mean) nv = mean;
                     if (act && c0 == 0) nv = xr[s][l];                              // pre-scattered unpredictable value (read at the top of the trip)
                     xr[s][l] = nv;
@@ -554,8 +611,8 @@ SZH_HD void szh_pencil_body(const szh_qargs<T> &a, int I, int J, const szh_tile_
                 // roll the neighbour state.  Lanes outside the k range must hand on ZEROS (the reference's zero halo).  With
                 // Lorenzo-only data they produce zeros by themselves (zero input, zero neighbours); the mean shortcut, stale
                 // pre-scattered values and a regression plane (non-zero prediction at k < 0) need the mask.
-                if (FMT == 1) cur2[l] = cur[l];
-                cur[l] = (USEMEAN || DEC || HASREG || FMT == 1) ? (act ? nv : (T)0) : nv;
+                if (FMT >= 1) cur2[l] = cur[l];
+                cur[l] = (USEMEAN || DEC || HASREG || FMT >= 1) ? (act ? nv : (T)0) : nv;
                 A1[l] = nA; B1[l] = nB; C1[l] = nC;
                 // advance along dim2
                 if (HASREG && act) {
@@ -639,6 +696,7 @@ template <class T, bool DEC, class B>
 SZH_HD void szh_pencil_run(const szh_qargs<T> &a, int I, int J, const szh_tile_lds<T> &L)
 {
     if (a.fmt == 1) { szh_pencil_body<T, DEC, false, false, B, 1>(a, I, J, L); return; }
+    if (a.fmt == 2) { szh_pencil_body<T, DEC, false, false, B, 2>(a, I, J, L); return; }
 #ifdef SZH_EXP_NOREG
     const bool hasreg = false;
 #else

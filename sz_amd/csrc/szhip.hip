@@ -1177,8 +1177,8 @@ template <> int req_length<double>(double eb, double range, double *median)
 
 template <class T>
 int launch_pencil14(szhip_ctx *ctx, const szh_geom3 &G, u64 *sm, bool dec, const T *d_in, T *d_out, uint16_t *d_codes, T eb, unsigned intervals,
-                    T median, int ign_bits)
-{
+                    T median, int ign_bits, const msst_tab *mt = nullptr, int ndim = 3)
+{   // mt != nullptr: the table-driven point-wise-relative quantiser (fmt 2) instead of the SZ 1.4 one
     hipStream_t st = ctx->stream;
     int nI, nJ, ntiles;
     using TS = szh_tile_shape<T>;
@@ -1187,6 +1187,10 @@ int launch_pencil14(szhip_ctx *ctx, const szh_geom3 &G, u64 *sm, bool dec, const
     a.G = G; a.data = d_in; a.out = d_out; a.codes = d_codes; a.blk_lor = nullptr; a.coef = nullptr; a.coef_stride = 0;
     a.eb = eb; a.recip = 1 / eb; a.mean = 0; a.cap = (int)intervals; a.radius = (int)intervals / 2; a.use_mean = 0;
     a.fmt = 1; a.median = median; a.ign_bits = ign_bits;
+    if (mt) {
+        a.fmt = 2; a.ptab = mt->ptab; a.cells = mt->cells; a.tbase = mt->base; a.trange = mt->range; a.tbits = mt->bits;
+        a.f32arith = (sizeof(T) == 4 && ndim == 2) ? 1 : 0; a.ndim3 = ndim == 3 ? 1 : 0;
+    }
     a.faceI = (szh_u64 *)ctx->faceI.p; a.faceJ = (szh_u64 *)ctx->faceJ.p; a.epoch = ++ctx->epoch;
     a.nI = nI; a.nJ = nJ; a.order = (const unsigned *)ctx->order.p;
     a.ticket = (unsigned *)(sm + SM_TICKET); a.err = (unsigned *)(sm + SM_ERR);
@@ -1322,22 +1326,29 @@ int msst_intervals(szhip_ctx *ctx, const szh_geom3 &G, int ndim, const T *d_in, 
     *out = msst_pick_intervals(hist, total, prm->pred_threshold, sizeof(T) == 8 ? 64u : 32u);
     return SZHIP_OK;
 }
+static int msst_upload(szhip_ctx *ctx, const MsstHostTab &ht, unsigned intervals, bool dec, msst_tab *tb)
+{
+    hipStream_t st = ctx->stream;
+    memset(tb, 0, sizeof(*tb));
+    TRY(ensure(ctx, ctx->msst_ptab, (size_t)intervals * 8));
+    HIPCHK(hipMemcpyAsync(ctx->msst_ptab.p, ht.ptab.data(), (size_t)intervals * 8, hipMemcpyHostToDevice, st));
+    tb->ptab = (const double *)ctx->msst_ptab.p; tb->intervals = (int)intervals;
+    if (!dec) {
+        TRY(ensure(ctx, ctx->msst_cells, ht.cells.size() * 2 + 16));
+        HIPCHK(hipMemcpyAsync(ctx->msst_cells.p, ht.cells.data(), ht.cells.size() * 2, hipMemcpyHostToDevice, st));
+        tb->cells = (const uint16_t *)ctx->msst_cells.p; tb->base = ht.base; tb->range = ht.range; tb->bits = ht.bits;
+    }
+    HIPCHK(hipStreamSynchronize(st));                        // the host vectors are pageable: the copies must be over before they go away
+    return SZHIP_OK;
+}
 // the sweep: one launch per hyperplane (1-D: the one-lane chain).  codes: u16 per element; rec: the reconstruction (DEC: in place)
 template <class T>
 int msst_sweep(szhip_ctx *ctx, const szh_geom3 &G, int ndim, bool dec, const T *d_in, T *d_rec, uint16_t *d_codes, const MsstHostTab &ht, unsigned intervals,
                int ign_bits)
 {
     hipStream_t st = ctx->stream;
-    TRY(ensure(ctx, ctx->msst_ptab, (size_t)intervals * 8));
-    HIPCHK(hipMemcpyAsync(ctx->msst_ptab.p, ht.ptab.data(), (size_t)intervals * 8, hipMemcpyHostToDevice, st));
-    msst_tab tb; memset(&tb, 0, sizeof(tb));
-    tb.ptab = (const double *)ctx->msst_ptab.p;
-    if (!dec) {
-        TRY(ensure(ctx, ctx->msst_cells, ht.cells.size() * 2 + 16));
-        HIPCHK(hipMemcpyAsync(ctx->msst_cells.p, ht.cells.data(), ht.cells.size() * 2, hipMemcpyHostToDevice, st));
-        tb.cells = (const uint16_t *)ctx->msst_cells.p; tb.base = ht.base; tb.range = ht.range; tb.bits = ht.bits;
-    }
-    HIPCHK(hipStreamSynchronize(st));                        // the host vectors are pageable: the copies must be over before they go away
+    msst_tab tb;
+    TRY(msst_upload(ctx, ht, intervals, dec, &tb));
     HIPCHK(hipEventRecord(ctx->ev[2], st));
     if (ndim == 1) {
         const size_t lds = (size_t)intervals * 8 + (dec ? 0 : ht.cells.size() * 2);
@@ -1461,9 +1472,15 @@ int compress14_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t
         double hb = now_ms();
         if (msst_build_tab(ht, eb_in, intervals, pw->plus_bits, true)) FAIL(SZHIP_ERR_UNSUP, "point-wise ratio %g with %u intervals: look-up table too large", eb_in, intervals);
         host_ms += now_ms() - hb;
-        TRY(ensure(ctx, ctx->msst_rec, (size_t)n * sizeof(T)));
-        TRY(msst_sweep<T>(ctx, G, ndim, false, d_in, (T *)ctx->msst_rec.p, d_codes, ht, intervals, ign_bits));
-        S.quant_kernel_launches = ndim == 1 ? 1 : (unsigned)((ndim == 3 ? G.g0.count : 1) + G.g1.count + G.g2.count - 2);
+        if (ndim >= 2 && !tune_int("SZ_HIP_MSST_SWEEP", 0)) {     // the wavefront kernel with its third quantiser (szh_pencil.h, fmt 2)
+            msst_tab tb;
+            TRY(msst_upload(ctx, ht, intervals, false, &tb));
+            TRY(launch_pencil14<T>(ctx, G, sm, false, d_in, nullptr, d_codes, eb, intervals, (T)0, ign_bits, &tb, ndim));
+        } else {                                                  // the plane-by-plane sweep (1-D: the one-lane chain); SZ_HIP_MSST_SWEEP=1 forces it
+            TRY(ensure(ctx, ctx->msst_rec, (size_t)n * sizeof(T)));
+            TRY(msst_sweep<T>(ctx, G, ndim, false, d_in, (T *)ctx->msst_rec.p, d_codes, ht, intervals, ign_bits));
+            S.quant_kernel_launches = ndim == 1 ? 1 : (unsigned)((ndim == 3 ? G.g0.count : 1) + G.g1.count + G.g2.count - 2);
+        }
     } else if (one_d) {
         // the chain cut at its certain restarts, one thread per segment; a segment whose successor turns out not to restart raises
         // the flag, and the array is then walked by the one-wavefront kernel (same result, by construction; SZ_HIP_1D_SERIAL=1 forces it)
@@ -1772,7 +1789,12 @@ int decompress14_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream
         if (!(eb_field > 0 && eb_field < 1) || plus_bits > 16) FAIL(SZHIP_ERR_STREAM, "bad point-wise ratio / table parameters");
         MsstHostTab ht;
         msst_build_tab(ht, eb_field, intervals, plus_bits, false);
-        TRY(msst_sweep<T>(ctx, G, ndim, true, nullptr, d_out, d_codes, ht, intervals, 0));
+        if (ndim >= 2 && !tune_int("SZ_HIP_MSST_SWEEP", 0)) {
+            msst_tab tb;
+            TRY(msst_upload(ctx, ht, intervals, true, &tb));
+            TRY(launch_pencil14<T>(ctx, G, sm, true, nullptr, d_out, d_codes, eb, intervals, (T)0, 0, &tb, ndim));
+        } else
+            TRY(msst_sweep<T>(ctx, G, ndim, true, nullptr, d_out, d_codes, ht, intervals, 0));
     } else if (one_d) {
         HIPCHK(hipEventRecord(ctx->ev[2], st));
         if (tune_int("SZ_HIP_1D_SERIAL", 0))

@@ -33,8 +33,12 @@ def _cases():
 
 
 @pytest.mark.slow
+@pytest.mark.parametrize("sweep", [0, 1], ids=["wavefront-kernel", "plane-sweep"])
 @pytest.mark.parametrize("c,d,ratio,iv", _cases(), ids=[f"{c}-{d.dtype.name}-{'x'.join(map(str, d.shape))}" for c, d, _, _ in _cases()])
-def test_product_code_on_cpu_shim_matches_oracle(built, oracle, c, d, ratio, iv, tmp_path):
+def test_product_code_on_cpu_shim_matches_oracle(built, oracle, c, d, ratio, iv, sweep, tmp_path, monkeypatch):
+    """both mappings of the quantiser: the wavefront kernel's third quantiser (szh_pencil.h, fmt 2; the default for 2-D/3-D arrays) and the
+    plane-by-plane sweep (szh_msst.h; SZ_HIP_MSST_SWEEP=1), which share nothing but the host-built tables"""
+    monkeypatch.setenv("SZ_HIP_MSST_SWEEP", str(sweep))
     import sim_lib
     import sz_amd
     from sz_amd import api
@@ -62,10 +66,13 @@ def test_product_code_on_cpu_shim_matches_oracle(built, oracle, c, d, ratio, iv,
 
 
 @pytest.mark.gpu
-def test_fuzz_msst19_against_oracle(built):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_fuzz.py"), "300", "47", "msst"], capture_output=True, text=True, timeout=900)
+@pytest.mark.parametrize("sweep", [0, 1], ids=["wavefront-kernel", "plane-sweep"])
+def test_fuzz_msst19_against_oracle(built, sweep):
+    env = dict(os.environ, SZ_HIP_MSST_SWEEP=str(sweep))
+    n = "300" if sweep == 0 else "150"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_fuzz.py"), n, "47", "msst"], capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert "300 cases, 0 failures" in out.stdout, out.stdout[-3000:]
+    assert f"{n} cases, 0 failures" in out.stdout, out.stdout[-3000:]
 
 
 @pytest.mark.gpu

@@ -14,8 +14,9 @@ cases = [("3-D f32", (np.abs(s_field(edge, edge, edge, np.float64)) + 0.05).asty
          ("2-D f32", (np.abs(s_field(1, 4096, 4096, np.float64))[0] + 0.05).astype(np.float32)),
          ("1-D f32", np.exp(np.cumsum(rng.standard_normal(1 << 20)) * 1e-3).astype(np.float32))]
 assert sz_amd.SZ_Init(os.path.join(ROOT, "tests", "golden", "sz_speed.config")) == 0
-for form in (1, 0):
-    sz_amd.conf_params().accelerate_pw_rel_compression = form
+for form in (1, 2, 0):                     # 1: MSST19 on the wavefront kernel, 2: MSST19 plane sweep, 0: log-domain form
+    os.environ["SZ_HIP_MSST_SWEEP"] = "1" if form == 2 else "0"
+    sz_amd.conf_params().accelerate_pw_rel_compression = 1 if form else 0
     for name, d in cases:
         d = np.ascontiguousarray(d)
         best = None
@@ -29,6 +30,6 @@ for form in (1, 0):
             best = rec if best is None else tuple(min(a, b) for a, b in zip(best, rec))      # the least of three, metric by metric
         x = d.astype(np.float64); y = b.astype(np.float64)
         err = float((np.abs(y - x) / np.abs(x)).max())
-        print(f"{'MSST19' if form else 'log   '} {name} {d.shape}: compress {best[0]*1e3:8.1f} ms ({d.nbytes/best[0]/1e9:6.2f} GB/s; quantise {best[2]:.1f}, entropy {best[3]:.1f}, host {best[4]:.1f}) "
+        print(f"{('log   ', 'MSST19', 'MSST19-sweep')[form]} {name} {d.shape}: compress {best[0]*1e3:8.1f} ms ({d.nbytes/best[0]/1e9:6.2f} GB/s; quantise {best[2]:.1f}, entropy {best[3]:.1f}, host {best[4]:.1f}) "
               f"decompress {best[1]*1e3:8.1f} ms ({d.nbytes/best[1]/1e9:6.2f} GB/s; reconstruct {best[5]:.1f})  ratio {d.nbytes/len(s):.2f}  max rel err {err:.3e}", flush=True)
 sz_amd.SZ_Finalize()
