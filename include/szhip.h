@@ -145,7 +145,8 @@ int szhip_decompress_sz14(szhip_ctx *ctx, int dtype, const unsigned char *stream
  *   szhip_compress_sz14_pwr with pwr->msst19 = 1, `eb` = the ratio and `data` = *d_prepared: multiplicative Lorenzo predictor on the
  *                           reconstruction, codes from the look-up table of MultiLevelCacheTableWideInterval.c:53-107 (built on the host).
  *   szhip_decompress_sz14_pwr  recognises the form by the stream's flag byte.
- * The mapping is a plain hyperplane sweep (one launch per plane; 1-D: one lane) -- bit-exact, not fast.
+ * 2-D and 3-D arrays run on the wavefront kernel (szh_pencil.h, fmt 2); SZ_HIP_MSST_SWEEP=1 selects the plane-by-plane sweep of szh_msst.h
+ * instead (second mapping, same bits); 1-D arrays are a one-lane chain.
  */
 typedef struct szhip_pwr {
     uint64_t segment_size;             /* confparams_cpr->segment_size, recorded in the header */

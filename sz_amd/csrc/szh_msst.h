@@ -4,12 +4,12 @@
 //   range scan   sz/src/dataCompression.c:121-166 (computeRangeSize_float_MSST19), zeros sz_float_pwr.c:2053-2058
 //   optimisers   sz/src/sz_float.c:4468, :4518, :4578
 // The predictor is a multiplicative Lorenzo stencil on RECONSTRUCTED values, the code the entry of a table indexed by the exponent and
-// leading mantissa bits of value / prediction (MultiLevelCacheTableWideInterval.c:53-107, built on the host).  Every point depends on
-// its seven predecessors, so the array is swept hyperplane by hyperplane (i + j + k = d), one launch per plane: the dependency is
-// the launch order.  This is a first, plain mapping of the path (the reconstructed array travels through HBM, neighbouring threads
-// touch strided addresses); it is here so that the reference's default PW_REL streams are written and read bit for bit, not for speed.
-// The three reference quantisers spell their arithmetic differently -- the float 3-D one multiplies in double, the 2-D one in float,
-// one boundary case of the 3-D compressor has no fabs where its inverse has one -- and each is followed as written.
+// leading mantissa bits of value / prediction (MultiLevelCacheTableWideInterval.c:53-107, built on the host).
+// Here: the element-wise passes around the quantiser, the 1-D chain, and the SECOND mapping of the 2-D / 3-D quantiser -- a sweep hyperplane
+// by hyperplane (i + j + k = d), one launch per plane, the dependency being the launch order (SZ_HIP_MSST_SWEEP=1).  The first mapping is the
+// wavefront kernel's third quantiser (szh_pencil.h, fmt 2); the two share only the host-built tables and the tests hold them against each
+// other through the oracle.  The three reference quantisers spell their arithmetic differently -- the float 3-D one multiplies in double,
+// the 2-D one in float, one boundary case of the 3-D compressor has no fabs where its inverse has one -- and each is followed as written.
 #pragma once
 
 enum { MS_MINMAG = 0, MS_MINIDX = 1, MS_NEG = 2, MS_RED = 4 };
