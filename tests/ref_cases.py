@@ -71,6 +71,21 @@ def _signed_with_zeros(shape, dtype, seed=13):
     return np.ascontiguousarray(d.astype(dtype))
 
 
+def _pwr_mix(shape, dtype, seed, zeros=0.05, signed=True, first=0.37, neg_near_zero=False):
+    """point-wise-relative data whose FIRST element is not zero (computeRangeSize_float_MSST19 starts nearZero from it: with a zero there
+    nothing replaces the zeros): magnitudes over a few decades, optional sign changes and zeros, optionally a negative value of least magnitude"""
+    r = np.random.default_rng(seed)
+    sh3 = shape if len(shape) == 3 else (1,) * (3 - len(shape)) + tuple(shape) if len(shape) < 3 else (shape[0] * shape[1],) + tuple(shape[2:])
+    base = s_field(*sh3, np.float64).reshape(shape)
+    d = np.exp(2.0 * base + 0.05 * r.standard_normal(shape))
+    if signed: d = d * np.sign(base + 0.15)
+    d[d == 0] = 1.0
+    if zeros: d[r.random(shape) < zeros] = 0.0
+    d.reshape(-1)[0] = first
+    if neg_near_zero: d.reshape(-1)[d.size // 3] = -1e-3
+    return np.ascontiguousarray(d.astype(dtype))
+
+
 def case(name, data, mode=ABS, abs=1e-4, rel=0.0, pwr=0.0, **conf):
     return dict(name=name, data=data, mode=mode, abs=abs, rel=rel, pwr=pwr, conf=conf)
 
@@ -152,6 +167,18 @@ CASES = [
     case("pwr-pos-1D-f32", lambda: _pos((20000,), f32), mode=PW_REL, pwr=1e-2),
     case("pwr-pos-1D-f64", lambda: _pos((20000,), f64), mode=PW_REL, pwr=1e-3),
     case("pwr-negative-3D-f32", lambda: -_pos((16, 20, 24), f32, 17), mode=PW_REL, pwr=1e-2),
+    # ... the same form with zeros that ARE replaced (first element non-zero; the "signed-zeros" cases above start with a zero, which leaves
+    # nearZero = 0 and the zeros in place), a negative value of least magnitude, a negative first element, a fixed interval count, 4-D, other knobs
+    case("pwr-zeros-pos-3D-f32", lambda: _pwr_mix((18, 22, 26), f32, 21, signed=False), mode=PW_REL, pwr=1e-2),
+    case("pwr-zeros-signed-3D-f64", lambda: _pwr_mix((16, 20, 24), f64, 22), mode=PW_REL, pwr=1e-3),
+    case("pwr-zeros-signed-2D-f32", lambda: _pwr_mix((56, 70), f32, 23), mode=PW_REL, pwr=1e-2),
+    case("pwr-zeros-signed-1D-f64", lambda: _pwr_mix((12000,), f64, 24), mode=PW_REL, pwr=1e-3),
+    case("pwr-neg-nearzero-3D-f32", lambda: _pwr_mix((16, 20, 24), f32, 25, neg_near_zero=True), mode=PW_REL, pwr=1e-2),
+    case("pwr-first-negative-3D-f32", lambda: _pwr_mix((16, 20, 24), f32, 26, first=-0.6), mode=PW_REL, pwr=1e-2),
+    case("pwr-intervals256-3D-f32", lambda: _pwr_mix((18, 22, 26), f32, 27, zeros=0), mode=PW_REL, pwr=1e-3, quantization_intervals=256),
+    case("pwr-4D-f32", lambda: _pwr_mix((3, 20, 24), f32, 28).reshape(3, 4, 5, 24), mode=PW_REL, pwr=1e-2),
+    case("pwr-sd10-3D-f64", lambda: _pwr_mix((16, 20, 24), f64, 29, zeros=0.02), mode=PW_REL, pwr=1e-2, sampleDistance=10),
+    case("pwr-ratio0.1-2D-f64", lambda: _pwr_mix((48, 64), f64, 30, zeros=0), mode=PW_REL, pwr=1e-1),
     case("pwr-noaccel-3D-f32", lambda: _pos((20, 24, 28), f32), mode=PW_REL, pwr=1e-2, accelerate_pw_rel_compression=0),
     # the log-domain form (accelerate_pw_rel_compression = 0, or a ratio below 1e-5: sz_float.c:2837-2838) -- the one the MI355X build writes
     case("pwrlog-pos-3D-f64", lambda: _pos((20, 24, 28), f64), mode=PW_REL, pwr=1e-3, accelerate_pw_rel_compression=0),

@@ -49,7 +49,8 @@ def _oracle_params(oracle, c):
     conf.update(c["conf"])
     return oracle.default_params(
         sample_distance=int(conf["sampleDistance"]), pred_threshold=float(conf["predThreshold"]),
-        max_quant_intervals=int(conf["max_quant_intervals"]), quantization_intervals=int(conf["quantization_intervals"]),
+        # a fixed interval count is also what the config reader leaves in max_quant_intervals (conf.c:193-197)
+        max_quant_intervals=int(conf["quantization_intervals"]) or int(conf["max_quant_intervals"]), quantization_intervals=int(conf["quantization_intervals"]),
         with_regression=1 if conf["withLinearRegression"] == "YES" else 0, sz_mode=0,
         protect_value_range=1 if conf["protectValueRange"] == "YES" else 0, psnr=float(conf["psnr"]), norm_err=float(conf["normErr"]),
         conf_rel_bound_ratio=float(conf["relBoundRatio"]))
