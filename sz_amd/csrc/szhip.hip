@@ -44,8 +44,8 @@ struct szhip_ctx {
     void *pinned = nullptr; size_t pinned_cap = 0;
     void *pinned2 = nullptr; size_t pinned2_cap = 0;   // target of the second stream's copies (indicator bits, regression-block count)
     // bulk copies between the caller's pageable arrays and the device: SZH_STAGE_T host threads, two pinned buffers + events each
-    void *stage_buf[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
-    hipEvent_t stage_ev[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+    void *stage_buf[8][2] = {};
+    hipEvent_t stage_ev[8][2] = {};
     void *pinned3 = nullptr; size_t pinned3_cap = 0;
     int streams_independent = -1;                      // -1 not probed yet; 1: work on stream2 proceeds while a kernel on stream is running
     void *coh = nullptr; size_t coh_cap = 0;           // host-coherent (uncached on the GPU) pinned memory the wavefront kernel reads while the host writes   // the regression coefficients on their way to the host chain and back
@@ -161,7 +161,7 @@ int probe_streams(szhip_ctx *ctx)
 // host threads each own two pinned buffers and take every SZH_STAGE_T-th chunk: memcpy into (out of) a pinned buffer, asynchronous DMA on
 // the context's stream, the other buffer meanwhile.  The call returns when the last byte has arrived.
 int tune_int(const char *name, int def);
-constexpr int SZH_STAGE_T = 4;
+constexpr int SZH_STAGE_T = 4, SZH_STAGE_TMAX = 8;     // default / most threads (SZ_HIP_STAGE_THREADS)
 constexpr size_t SZH_STAGE_CHUNK = 8u << 20;
 int staged_copy(szhip_ctx *ctx, void *dst, const void *src, size_t bytes, bool to_device)
 {
@@ -173,7 +173,8 @@ int staged_copy(szhip_ctx *ctx, void *dst, const void *src, size_t bytes, bool t
         HIPCHK(hipStreamSynchronize(st));
         return SZHIP_OK;
     }
-    for (int w = 0; w < SZH_STAGE_T; ++w)
+    const int nthr = std::min(SZH_STAGE_TMAX, std::max(1, tune_int("SZ_HIP_STAGE_THREADS", SZH_STAGE_T)));
+    for (int w = 0; w < nthr; ++w)
         for (int k = 0; k < 2; ++k)
             if (!ctx->stage_buf[w][k]) {
                 HIPCHK(hipHostMalloc(&ctx->stage_buf[w][k], SZH_STAGE_CHUNK, hipHostMallocDefault));
@@ -188,7 +189,7 @@ int staged_copy(szhip_ctx *ctx, void *dst, const void *src, size_t bytes, bool t
         size_t pend_off[2] = {0, 0}, pend_len[2] = {0, 0};        // device-to-host: the chunk in flight into buffer k
         bool pend[2] = {false, false};
         int k = 0;
-        for (size_t c = (size_t)w; c < nchunks && !failed; c += SZH_STAGE_T, k ^= 1) {
+        for (size_t c = (size_t)w; c < nchunks && !failed; c += (size_t)nthr, k ^= 1) {
             const size_t off = c * chunk, len = std::min(chunk, bytes - off);
             if (to_device) {
                 if (pend[k] && hipEventSynchronize(ctx->stage_ev[w][k]) != hipSuccess) { failed = 1; return; }   // buffer k is free again
@@ -213,7 +214,7 @@ int staged_copy(szhip_ctx *ctx, void *dst, const void *src, size_t bytes, bool t
         }
     };
     std::vector<std::thread> th;
-    for (int w = 1; w < SZH_STAGE_T; ++w) th.emplace_back(worker, w);
+    for (int w = 1; w < nthr; ++w) th.emplace_back(worker, w);
     worker(0);
     for (auto &t : th) t.join();
     if (failed) FAIL(SZHIP_ERR_NODEVICE, "staged %s copy failed", to_device ? "host-to-device" : "device-to-host");
@@ -2265,7 +2266,7 @@ void szhip_destroy(szhip_ctx *ctx)
     if (ctx->pinned2) hipHostFree(ctx->pinned2);
     if (ctx->pinned3) hipHostFree(ctx->pinned3);
     if (ctx->coh) hipHostFree(ctx->coh);
-    for (int w = 0; w < 4; ++w) for (int k = 0; k < 2; ++k) { if (ctx->stage_buf[w][k]) hipHostFree(ctx->stage_buf[w][k]); if (ctx->stage_ev[w][k]) hipEventDestroy(ctx->stage_ev[w][k]); }
+    for (int w = 0; w < SZH_STAGE_TMAX; ++w) for (int k = 0; k < 2; ++k) { if (ctx->stage_buf[w][k]) hipHostFree(ctx->stage_buf[w][k]); if (ctx->stage_ev[w][k]) hipEventDestroy(ctx->stage_ev[w][k]); }
     for (int i = 0; i < 6; ++i) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
     if (ctx->ev_in) hipEventDestroy(ctx->ev_in);
     if (ctx->ev_fit) hipEventDestroy(ctx->ev_fit);
