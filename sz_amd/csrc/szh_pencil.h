@@ -692,11 +692,13 @@ SZH_HD bool szh_pencil_has_reg(const szh_qargs<T> &a, int I, int J)
 }
 
 // L: this pencil's view of its tile's LDS (HIP) / plain memory (simulator); face rings and step counters must be zero at launch
-template <class T, bool DEC, class B>
+// MS: the kernel instance of the table-driven point-wise-relative quantiser (fmt 2) -- a kernel of its own, so that the code of the other
+// formats stays what it is without it (measured: with fmt 2 inside the same kernel the 512^3 ABS headline ran 1.5-5 % slower)
+template <class T, bool DEC, class B, bool MS = false>
 SZH_HD void szh_pencil_run(const szh_qargs<T> &a, int I, int J, const szh_tile_lds<T> &L)
 {
+    if (MS) { szh_pencil_body<T, DEC, false, false, B, 2>(a, I, J, L); return; }
     if (a.fmt == 1) { szh_pencil_body<T, DEC, false, false, B, 1>(a, I, J, L); return; }
-    if (a.fmt == 2) { szh_pencil_body<T, DEC, false, false, B, 2>(a, I, J, L); return; }
 #ifdef SZH_EXP_NOREG
     const bool hasreg = false;
 #else

@@ -1198,7 +1198,9 @@ int launch_pencil14(szhip_ctx *ctx, const szh_geom3 &G, u64 *sm, bool dec, const
     a.progress = (szh_u64 *)ctx->progress.p; a.backoff = tune_int("SZ_HIP_BACKOFF", 4); a.wide = tune_int("SZ_HIP_WIDE", 1) && (double)TS::TPI * nJ * 9.0 * (double)G.g2.count * szh_gran<T>::NW * 8.0 < 4.0e9 && (double)TS::TPJ * 9.0 * (double)G.g2.count * szh_gran<T>::NW * 8.0 < 4.0e9;
     a.trace = nullptr; a.dbg = 0;
     HIPCHK(hipEventRecord(ctx->ev[2], st));
-    if (dec) hipLaunchKernelGGL((k_pencil<T, true>), dim3((unsigned)ntiles), dim3((TS::TPI * TS::TPJ + 2) * 64), 0, st, a);
+    if (mt && dec) hipLaunchKernelGGL((k_pencil<T, true, true>), dim3((unsigned)ntiles), dim3((TS::TPI * TS::TPJ + 2) * 64), 0, st, a);
+    else if (mt) hipLaunchKernelGGL((k_pencil<T, false, true>), dim3((unsigned)ntiles), dim3((TS::TPI * TS::TPJ + 2) * 64), 0, st, a);
+    else if (dec) hipLaunchKernelGGL((k_pencil<T, true>), dim3((unsigned)ntiles), dim3((TS::TPI * TS::TPJ + 2) * 64), 0, st, a);
     else hipLaunchKernelGGL((k_pencil<T, false>), dim3((unsigned)ntiles), dim3((TS::TPI * TS::TPJ + 2) * 64), 0, st, a);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[3], st));

@@ -227,9 +227,9 @@ template <> struct szh_tile_shape<float> { static constexpr int TPI = SZH_TPI_F3
 #endif
 template <> struct szh_tile_shape<double> { static constexpr int TPI = SZH_TPI_F64, TPJ = SZH_TPJ_F64, RL = SZH_RL_F64; };
 
-template <class T, bool DEC>
+template <class T, bool DEC, bool MS = false>
 __global__ __launch_bounds__((szh_tile_shape<T>::TPI * szh_tile_shape<T>::TPJ + 2) * 64) void k_pencil(szh_qargs<T> a)
-{
+{   // MS = true: the instance for a.fmt == 2 (szh_pencil_run)
     using S = szh_tile_shape<T>;
     using B = GpuBackend<S::TPI, S::TPJ, S::RL>;
     constexpr int NP = S::TPI * S::TPJ, NV = S::TPI + S::TPJ, NT = (NP + 2) * 64;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__((szh_tile_shape<T>::TPI * szh_tile_shape<T>::TPJ + 
     if (w < NP) {
         const int I = TI * S::TPI + w / S::TPJ, J = TJ * S::TPJ + w % S::TPJ;
         if (I >= a.nI || J >= a.nJ) return;         // ragged tile: this wavefront has no pencil
-        szh_pencil_run<T, DEC, B>(a, I, J, L);
+        szh_pencil_run<T, DEC, B, MS>(a, I, J, L);
     } else if (w == NP) szh_tile_store<T, B>(a, TI, TJ, L);
     else szh_tile_fill<T, B>(a, TI, TJ, L);
 }
