@@ -48,6 +48,7 @@ template <class T> struct szh_qargs {
     int nI, nJ;
     const unsigned *order;    // ticket -> (tile row << 16) | tile column, anti-diagonal order over the tiles
     unsigned *ticket;
+    int ticket_mode;          // 0: atomic ticket + order table; 1: blockIdx.x as the ticket (+ table); 2: blockIdx.x and the tile computed (szh_pencil_order_at)
     unsigned *err;            // set to 1 if a halo wait timed out
     const szh_u64 *coef_progress; // compress, optional: number of blocks (scan order) whose decoded coefficients have arrived in `coef`;
                               // the host's coefficient chain runs NEXT TO this kernel and ships them as it goes (nullptr: all there)
@@ -994,6 +995,32 @@ SZH_HD void szh_tile_fill(const szh_qargs<T> &a, int TI, int TJ, const szh_tile_
             B::backoff(a.backoff);
         } else idle = 0;
     }
+}
+
+// the t-th entry of szh_fill_pencil_order(nI, nJ), computed: no table, no memory round trip in front of a tile's start
+SZH_HD unsigned szh_pencil_order_at(int nI, int nJ, unsigned t)
+{
+    const int m = nI < nJ ? nI : nJ, M = nI < nJ ? nJ : nI;
+    const unsigned tri = (unsigned)m * (unsigned)(m - 1) / 2;         // diagonals 0 .. m-2 (lengths 1 .. m-1)
+    const unsigned mid = (unsigned)(M - m + 1) * (unsigned)m;         // diagonals m-1 .. M-1, m tiles each
+    int d; unsigned off;
+    if (t < tri) {
+        d = (int)((__builtin_sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        while ((unsigned)(d + 1) * (unsigned)(d + 2) / 2 <= t) ++d;
+        while ((unsigned)d * (unsigned)(d + 1) / 2 > t) --d;
+        off = t - (unsigned)d * (unsigned)(d + 1) / 2;
+    } else if (t < tri + mid) { d = m - 1 + (int)((t - tri) / (unsigned)m); off = (t - tri) % (unsigned)m; }
+    else {                                                            // the shrinking part, counted from the end
+        const unsigned total = (unsigned)nI * (unsigned)nJ, r = total - 1 - t;
+        int e = (int)((__builtin_sqrtf(8.0f * (float)r + 1.0f) - 1.0f) * 0.5f);
+        while ((unsigned)(e + 1) * (unsigned)(e + 2) / 2 <= r) ++e;
+        while ((unsigned)e * (unsigned)(e + 1) / 2 > r) --e;
+        d = nI + nJ - 2 - e;
+        off = (unsigned)e - (r - (unsigned)e * (unsigned)(e + 1) / 2);
+    }
+    int lo = d - (nJ - 1); if (lo < 0) lo = 0;
+    const int I = lo + (int)off;
+    return ((unsigned)I << 16) | (unsigned)(d - I);
 }
 
 // anti-diagonal start order (of the tiles): every dependency has a smaller ticket

@@ -599,7 +599,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         a.eb = eb; a.recip = 1 / eb; a.mean = mean; a.cap = (int)intervals; a.radius = (int)intervals / 2; a.use_mean = use_mean;
         a.faceI = (szh_u64 *)ctx->faceI.p; a.faceJ = (szh_u64 *)ctx->faceJ.p; a.epoch = ++ctx->epoch;
         a.nI = nI; a.nJ = nJ; a.order = (const unsigned *)ctx->order.p;
-        a.ticket = (unsigned *)(sm + SM_TICKET); a.err = (unsigned *)(sm + SM_ERR);
+        a.ticket = (unsigned *)(sm + SM_TICKET); a.err = (unsigned *)(sm + SM_ERR); a.ticket_mode = tune_int("SZ_HIP_TICKET_MODE", 2);
         a.progress = (szh_u64 *)ctx->progress.p; a.backoff = tune_int("SZ_HIP_BACKOFF", 4); a.wide = tune_int("SZ_HIP_WIDE", 1) && (double)TS::TPI * nJ * 9.0 * (double)G.g2.count * szh_gran<T>::NW * 8.0 < 4.0e9 && (double)TS::TPJ * 9.0 * (double)G.g2.count * szh_gran<T>::NW * 8.0 < 4.0e9;
         a.trace = tune_int("SZ_HIP_TRACE", 0) ? (szh_u64 *)ctx->trace.p : nullptr;
         a.dbg = tune_int("SZ_HIP_DBG", 0); a.trace_tile = tune_int("SZ_HIP_TRACE_TILE", 1);
@@ -1122,7 +1122,7 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
         a.eb = eb; a.recip = 1 / eb; a.mean = mean; a.cap = (int)intervals; a.radius = (int)intervals / 2; a.use_mean = use_mean;
         a.faceI = (szh_u64 *)ctx->faceI.p; a.faceJ = (szh_u64 *)ctx->faceJ.p; a.epoch = ++ctx->epoch;
         a.nI = nI; a.nJ = nJ; a.order = (const unsigned *)ctx->order.p;
-        a.ticket = (unsigned *)(sm + SM_TICKET); a.err = (unsigned *)(sm + SM_ERR);
+        a.ticket = (unsigned *)(sm + SM_TICKET); a.err = (unsigned *)(sm + SM_ERR); a.ticket_mode = tune_int("SZ_HIP_TICKET_MODE", 2);
         a.progress = (szh_u64 *)ctx->progress.p; a.backoff = tune_int("SZ_HIP_BACKOFF", 4); a.wide = tune_int("SZ_HIP_WIDE", 1) && (double)TS::TPI * nJ * 9.0 * (double)G.g2.count * szh_gran<T>::NW * 8.0 < 4.0e9 && (double)TS::TPJ * 9.0 * (double)G.g2.count * szh_gran<T>::NW * 8.0 < 4.0e9;
         a.trace = tune_int("SZ_HIP_TRACE", 0) ? (szh_u64 *)ctx->trace.p : nullptr;
         a.dbg = tune_int("SZ_HIP_DBG", 0); a.trace_tile = tune_int("SZ_HIP_TRACE_TILE", 1);
@@ -1194,7 +1194,7 @@ int launch_pencil14(szhip_ctx *ctx, const szh_geom3 &G, u64 *sm, bool dec, const
     }
     a.faceI = (szh_u64 *)ctx->faceI.p; a.faceJ = (szh_u64 *)ctx->faceJ.p; a.epoch = ++ctx->epoch;
     a.nI = nI; a.nJ = nJ; a.order = (const unsigned *)ctx->order.p;
-    a.ticket = (unsigned *)(sm + SM_TICKET); a.err = (unsigned *)(sm + SM_ERR);
+    a.ticket = (unsigned *)(sm + SM_TICKET); a.err = (unsigned *)(sm + SM_ERR); a.ticket_mode = tune_int("SZ_HIP_TICKET_MODE", 2);
     a.progress = (szh_u64 *)ctx->progress.p; a.backoff = tune_int("SZ_HIP_BACKOFF", 4); a.wide = tune_int("SZ_HIP_WIDE", 1) && (double)TS::TPI * nJ * 9.0 * (double)G.g2.count * szh_gran<T>::NW * 8.0 < 4.0e9 && (double)TS::TPJ * 9.0 * (double)G.g2.count * szh_gran<T>::NW * 8.0 < 4.0e9;
     a.trace = nullptr; a.dbg = 0;
     HIPCHK(hipEventRecord(ctx->ev[2], st));

@@ -245,16 +245,21 @@ __global__ __launch_bounds__((szh_tile_shape<T>::TPI * szh_tile_shape<T>::TPJ + 
     __shared__ unsigned tk_s;
     if (threadIdx.x < NP + NV) cstep[threadIdx.x] = 0;
     if (threadIdx.x < NP) { spubJ[threadIdx.x] = 0; spubI[threadIdx.x] = 0; }
-    if (threadIdx.x == 0) tk_s = atomicAdd(a.ticket, 1u);
+    if (threadIdx.x == 0) {
+        // which tile: by default an atomic ticket into the anti-diagonal order table.  ticket_mode 1/2: the workgroup index IS the ticket
+        // (workgroups of one XCD start in index order, so the lowest unfinished tile always runs), mode 2 computes the tile instead of loading it
+        const unsigned t = a.ticket_mode ? blockIdx.x : atomicAdd(a.ticket, 1u);
+        tk_s = a.ticket_mode == 2 ? szh_pencil_order_at((a.nI + S::TPI - 1) / S::TPI, (a.nJ + S::TPJ - 1) / S::TPJ, t) : a.order[t];
+    }
     __syncthreads();
     (void)NT;
     // wavefront-uniform by construction: say so (readfirstlane), so that slots, ring bases, publish flags and the wait loops of the
     // sweep live in scalar registers and branch on the scalar unit instead of through exec masks
 #ifdef SZH_HIPSIM
-    const unsigned ij = a.order[tk_s];
+    const unsigned ij = tk_s;
     const int w = (int)(threadIdx.x >> 6);
 #else
-    const unsigned ij = (unsigned)__builtin_amdgcn_readfirstlane((int)a.order[tk_s]);
+    const unsigned ij = (unsigned)__builtin_amdgcn_readfirstlane((int)tk_s);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 #endif
     const int TI = (int)(ij >> 16), TJ = (int)(ij & 0xffffu);
