@@ -48,6 +48,7 @@ template <class T> struct szh_qargs {
     int nI, nJ;
     const unsigned *order;    // ticket -> (tile row << 16) | tile column, anti-diagonal order over the tiles
     unsigned *ticket;
+    int no_reg;               // 1: the caller knows that no block is a regression block (the per-pencil scan of blk_lor in front of the sweep is skipped)
     int ticket_mode;          // 0: atomic ticket + order table; 1: blockIdx.x as the ticket (+ table); 2: blockIdx.x and the tile computed (szh_pencil_order_at)
     unsigned *err;            // set to 1 if a halo wait timed out
     const szh_u64 *coef_progress; // compress, optional: number of blocks (scan order) whose decoded coefficients have arrived in `coef`;
@@ -703,7 +704,7 @@ SZH_HD void szh_pencil_run(const szh_qargs<T> &a, int I, int J, const szh_tile_l
 #ifdef SZH_EXP_NOREG
     const bool hasreg = false;
 #else
-    const bool hasreg = szh_pencil_has_reg<T, B>(a, I, J);
+    const bool hasreg = a.no_reg ? false : szh_pencil_has_reg<T, B>(a, I, J);
 #endif
     if (!DEC && hasreg && a.coef_progress) {
         // the decoded coefficients are still arriving (the host's chain runs next to this launch): wait until the last block this pencil

@@ -598,7 +598,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         a.G = G; a.data = d_in; a.out = nullptr; a.codes = d_nat; a.blk_lor = d_lor; a.coef = d_coef; a.coef_stride = nb;
         a.eb = eb; a.recip = 1 / eb; a.mean = mean; a.cap = (int)intervals; a.radius = (int)intervals / 2; a.use_mean = use_mean;
         a.faceI = (szh_u64 *)ctx->faceI.p; a.faceJ = (szh_u64 *)ctx->faceJ.p; a.epoch = ++ctx->epoch;
-        a.nI = nI; a.nJ = nJ; a.order = (const unsigned *)ctx->order.p;
+        a.nI = nI; a.nJ = nJ; a.order = (const unsigned *)ctx->order.p; a.no_reg = reg_count == 0 && tune_int("SZ_HIP_NO_REG_HINT", 1);
         a.ticket = (unsigned *)(sm + SM_TICKET); a.err = (unsigned *)(sm + SM_ERR); a.ticket_mode = tune_int("SZ_HIP_TICKET_MODE", 2);
         a.progress = (szh_u64 *)ctx->progress.p; a.backoff = tune_int("SZ_HIP_BACKOFF", 4); a.wide = tune_int("SZ_HIP_WIDE", 1) && (double)TS::TPI * nJ * 9.0 * (double)G.g2.count * szh_gran<T>::NW * 8.0 < 4.0e9 && (double)TS::TPJ * 9.0 * (double)G.g2.count * szh_gran<T>::NW * 8.0 < 4.0e9;
         a.trace = tune_int("SZ_HIP_TRACE", 0) ? (szh_u64 *)ctx->trace.p : nullptr;
@@ -1121,7 +1121,7 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
         a.G = G; a.data = nullptr; a.out = d_out; a.codes = d_nat; a.blk_lor = (const uint8_t *)ctx->blk_lor.p; a.coef = (const T *)ctx->coef.p; a.coef_stride = nb;
         a.eb = eb; a.recip = 1 / eb; a.mean = mean; a.cap = (int)intervals; a.radius = (int)intervals / 2; a.use_mean = use_mean;
         a.faceI = (szh_u64 *)ctx->faceI.p; a.faceJ = (szh_u64 *)ctx->faceJ.p; a.epoch = ++ctx->epoch;
-        a.nI = nI; a.nJ = nJ; a.order = (const unsigned *)ctx->order.p;
+        a.nI = nI; a.nJ = nJ; a.order = (const unsigned *)ctx->order.p; a.no_reg = reg_count == 0 && tune_int("SZ_HIP_NO_REG_HINT", 1);
         a.ticket = (unsigned *)(sm + SM_TICKET); a.err = (unsigned *)(sm + SM_ERR); a.ticket_mode = tune_int("SZ_HIP_TICKET_MODE", 2);
         a.progress = (szh_u64 *)ctx->progress.p; a.backoff = tune_int("SZ_HIP_BACKOFF", 4); a.wide = tune_int("SZ_HIP_WIDE", 1) && (double)TS::TPI * nJ * 9.0 * (double)G.g2.count * szh_gran<T>::NW * 8.0 < 4.0e9 && (double)TS::TPJ * 9.0 * (double)G.g2.count * szh_gran<T>::NW * 8.0 < 4.0e9;
         a.trace = tune_int("SZ_HIP_TRACE", 0) ? (szh_u64 *)ctx->trace.p : nullptr;
