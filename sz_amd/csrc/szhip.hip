@@ -50,6 +50,10 @@ struct szhip_ctx {
     int streams_independent = -1;                      // -1 not probed yet; 1: work on stream2 proceeds while a kernel on stream is running
     void *coh = nullptr; size_t coh_cap = 0;           // host-coherent (uncached on the GPU) pinned memory the wavefront kernel reads while the host writes   // the regression coefficients on their way to the host chain and back
     int order_nI = -1, order_nJ = -1;
+    // tile tickets: by default a workgroup's index is its ticket (SZ_HIP_TICKET_MODE=2), which assumes that the workgroups of one XCD start in index
+    // order AND that every XCD gets to run; if a wavefront-kernel wait ever times out the call is repeated once with the atomic ticket, which
+    // assumes neither (a GPU shared with other work), and the context keeps that mode
+    bool wave_timeout = false, ticket_atomic = false;
 };
 
 namespace {
@@ -599,7 +603,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         a.eb = eb; a.recip = 1 / eb; a.mean = mean; a.cap = (int)intervals; a.radius = (int)intervals / 2; a.use_mean = use_mean;
         a.faceI = (szh_u64 *)ctx->faceI.p; a.faceJ = (szh_u64 *)ctx->faceJ.p; a.epoch = ++ctx->epoch;
         a.nI = nI; a.nJ = nJ; a.order = (const unsigned *)ctx->order.p; a.no_reg = reg_count == 0 && tune_int("SZ_HIP_NO_REG_HINT", 1);
-        a.ticket = (unsigned *)(sm + SM_TICKET); a.err = (unsigned *)(sm + SM_ERR); a.ticket_mode = tune_int("SZ_HIP_TICKET_MODE", 2);
+        a.ticket = (unsigned *)(sm + SM_TICKET); a.err = (unsigned *)(sm + SM_ERR); a.ticket_mode = ctx->ticket_atomic ? 0 : tune_int("SZ_HIP_TICKET_MODE", 2);
         a.progress = (szh_u64 *)ctx->progress.p; a.backoff = tune_int("SZ_HIP_BACKOFF", 4); a.wide = tune_int("SZ_HIP_WIDE", 1) && (double)TS::TPI * nJ * 9.0 * (double)G.g2.count * szh_gran<T>::NW * 8.0 < 4.0e9 && (double)TS::TPJ * 9.0 * (double)G.g2.count * szh_gran<T>::NW * 8.0 < 4.0e9;
         a.trace = tune_int("SZ_HIP_TRACE", 0) ? (szh_u64 *)ctx->trace.p : nullptr;
         a.dbg = tune_int("SZ_HIP_DBG", 0); a.trace_tile = tune_int("SZ_HIP_TRACE_TILE", 1);
@@ -821,7 +825,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     // after the final synchronisation: the wavefront kernel's error flag; the shuffled bit count and the device's count of zero codes
     // must match what the histogram predicted
     if ((unsigned)h_small[SM_ERR] == 2) FAIL(SZHIP_ERR_INTERNAL, "wavefront kernel: the regression coefficients did not arrive");
-    if ((unsigned)h_small[SM_ERR] != 0) FAIL(SZHIP_ERR_INTERNAL, "wavefront kernel: halo wait timed out");
+    if ((unsigned)h_small[SM_ERR] != 0) { ctx->wave_timeout = true; FAIL(SZHIP_ERR_INTERNAL, "wavefront kernel: halo wait timed out"); }
     if ((total_bits > 0 && h_small[SM_TOTAL_BITS] != total_bits) || h_small[SM_TOTAL_UNPRED] != total_unpred)
         FAIL(SZHIP_ERR_INTERNAL, "entropy stage mismatch (bits %llu vs %llu, unpredictable %llu vs %llu)", (unsigned long long)h_small[SM_TOTAL_BITS],
              (unsigned long long)total_bits, (unsigned long long)h_small[SM_TOTAL_UNPRED], (unsigned long long)total_unpred);
@@ -1122,7 +1126,7 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
         a.eb = eb; a.recip = 1 / eb; a.mean = mean; a.cap = (int)intervals; a.radius = (int)intervals / 2; a.use_mean = use_mean;
         a.faceI = (szh_u64 *)ctx->faceI.p; a.faceJ = (szh_u64 *)ctx->faceJ.p; a.epoch = ++ctx->epoch;
         a.nI = nI; a.nJ = nJ; a.order = (const unsigned *)ctx->order.p; a.no_reg = reg_count == 0 && tune_int("SZ_HIP_NO_REG_HINT", 1);
-        a.ticket = (unsigned *)(sm + SM_TICKET); a.err = (unsigned *)(sm + SM_ERR); a.ticket_mode = tune_int("SZ_HIP_TICKET_MODE", 2);
+        a.ticket = (unsigned *)(sm + SM_TICKET); a.err = (unsigned *)(sm + SM_ERR); a.ticket_mode = ctx->ticket_atomic ? 0 : tune_int("SZ_HIP_TICKET_MODE", 2);
         a.progress = (szh_u64 *)ctx->progress.p; a.backoff = tune_int("SZ_HIP_BACKOFF", 4); a.wide = tune_int("SZ_HIP_WIDE", 1) && (double)TS::TPI * nJ * 9.0 * (double)G.g2.count * szh_gran<T>::NW * 8.0 < 4.0e9 && (double)TS::TPJ * 9.0 * (double)G.g2.count * szh_gran<T>::NW * 8.0 < 4.0e9;
         a.trace = tune_int("SZ_HIP_TRACE", 0) ? (szh_u64 *)ctx->trace.p : nullptr;
         a.dbg = tune_int("SZ_HIP_DBG", 0); a.trace_tile = tune_int("SZ_HIP_TRACE_TILE", 1);
@@ -1137,7 +1141,7 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
     if (!out_on_device) TRY(staged_copy(ctx, out, d_out, (size_t)n * sizeof(T), false));
     HIPCHK(hipEventRecord(ctx->ev[4], st));
     HIPCHK(hipStreamSynchronize(st));
-    if (kerr) FAIL(SZHIP_ERR_INTERNAL, "wavefront kernel: halo wait timed out");
+    if (kerr) { ctx->wave_timeout = true; FAIL(SZHIP_ERR_INTERNAL, "wavefront kernel: halo wait timed out"); }
     float ms = 0;
     hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); S.ms_entropy = ms;
     hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); S.ms_quant = ms;
@@ -1194,7 +1198,7 @@ int launch_pencil14(szhip_ctx *ctx, const szh_geom3 &G, u64 *sm, bool dec, const
     }
     a.faceI = (szh_u64 *)ctx->faceI.p; a.faceJ = (szh_u64 *)ctx->faceJ.p; a.epoch = ++ctx->epoch;
     a.nI = nI; a.nJ = nJ; a.order = (const unsigned *)ctx->order.p;
-    a.ticket = (unsigned *)(sm + SM_TICKET); a.err = (unsigned *)(sm + SM_ERR); a.ticket_mode = tune_int("SZ_HIP_TICKET_MODE", 2);
+    a.ticket = (unsigned *)(sm + SM_TICKET); a.err = (unsigned *)(sm + SM_ERR); a.ticket_mode = ctx->ticket_atomic ? 0 : tune_int("SZ_HIP_TICKET_MODE", 2);
     a.progress = (szh_u64 *)ctx->progress.p; a.backoff = tune_int("SZ_HIP_BACKOFF", 4); a.wide = tune_int("SZ_HIP_WIDE", 1) && (double)TS::TPI * nJ * 9.0 * (double)G.g2.count * szh_gran<T>::NW * 8.0 < 4.0e9 && (double)TS::TPJ * 9.0 * (double)G.g2.count * szh_gran<T>::NW * 8.0 < 4.0e9;
     a.trace = nullptr; a.dbg = 0;
     HIPCHK(hipEventRecord(ctx->ev[2], st));
@@ -1529,7 +1533,7 @@ int compress14_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t
     u64 h_small[SM_COUNT];
     HIPCHK(hipMemcpyAsync(h_small, sm, SM_COUNT * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if ((unsigned)h_small[SM_ERR] != 0) FAIL(SZHIP_ERR_INTERNAL, "wavefront kernel: halo wait timed out");
+    if ((unsigned)h_small[SM_ERR] != 0) { ctx->wave_timeout = true; FAIL(SZHIP_ERR_INTERNAL, "wavefront kernel: halo wait timed out"); }
     const u64 E = h_small[SM_TOTAL_UNPRED];
     S.n_unpred = E;
     double h0 = now_ms();
@@ -1817,7 +1821,7 @@ int decompress14_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream
     if (!out_on_device) TRY(staged_copy(ctx, out, d_out, (size_t)n * sizeof(T), false));
     HIPCHK(hipEventRecord(ctx->ev[4], st));
     HIPCHK(hipStreamSynchronize(st));
-    if (kerr) FAIL(SZHIP_ERR_INTERNAL, "wavefront kernel: halo wait timed out");
+    if (kerr) { ctx->wave_timeout = true; FAIL(SZHIP_ERR_INTERNAL, "wavefront kernel: halo wait timed out"); }
     float ms = 0;
     hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); S.ms_entropy = ms;
     hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); S.ms_quant = ms;
@@ -2203,6 +2207,22 @@ int decompress_fast_impl(szhip_ctx *ctx, const unsigned char *stream_in, int str
 
 } // namespace
 
+// runs one call; a wavefront-kernel wait that timed out under the index ticket is answered by ONE repetition with the atomic ticket (see szhip_ctx)
+template <class F>
+static int with_ticket_fallback(szhip_ctx *ctx, F &&run)
+{
+    ctx->wave_timeout = false;
+    int rc = run();
+    if (rc == SZHIP_OK && !ctx->ticket_atomic && tune_int("SZ_HIP_TEST_TICKET_FALLBACK", 0)) { ctx->wave_timeout = true; rc = SZHIP_ERR_INTERNAL; }   // tests: exercise the repetition
+    if (rc == SZHIP_ERR_INTERNAL && ctx->wave_timeout && !ctx->ticket_atomic) {
+        hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream);
+        ctx->ticket_atomic = true;
+        rc = run();
+    }
+    return rc;
+}
+
+
 extern "C" {
 
 int szhip_is_fast_stream(const unsigned char *stream, size_t stream_len) { return stream && stream_len >= SZF_HDR_FIXED && memcmp(stream, "SZHF", 4) == 0; }
@@ -2305,9 +2325,9 @@ int szhip_compress(szhip_ctx *ctx, int dtype, const void *data, int data_on_devi
     if ((r0 != 0 && r0 < 2) || r1 < 2 || r2 < 2 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff) return SZHIP_ERR_ARG;
     if (!(eb > 0)) return SZHIP_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
-    const int rc = dtype == SZHIP_F32
+    const int rc = with_ticket_fallback(ctx, [&]() { return dtype == SZHIP_F32
                ? compress_impl<float>(ctx, data, data_on_device, r0, r1, r2, eb, params, meta, meta_len, out_on_device, out, out_size, stats)
-               : compress_impl<double>(ctx, data, data_on_device, r0, r1, r2, eb, params, meta, meta_len, out_on_device, out, out_size, stats);
+               : compress_impl<double>(ctx, data, data_on_device, r0, r1, r2, eb, params, meta, meta_len, out_on_device, out, out_size, stats); });
     if (rc != SZHIP_OK) { hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream); } // an early exit must not leave work in flight
     return rc;
 }
@@ -2320,9 +2340,9 @@ int szhip_compress_sz14(szhip_ctx *ctx, int dtype, const void *data, int data_on
     if ((r0 != 0 && r0 < 2) || (r1 < 2 && !(r0 == 0 && r1 == 0)) || r2 < 2 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff) return SZHIP_ERR_ARG;
     if (!(eb > 0)) return SZHIP_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
-    const int rc = dtype == SZHIP_F32
+    const int rc = with_ticket_fallback(ctx, [&]() { return dtype == SZHIP_F32
                ? compress14_impl<float>(ctx, data, data_on_device, r0, r1, r2, eb, value_range, median, params, meta, meta_len, nullptr, out_on_device, out, out_size, stats)
-               : compress14_impl<double>(ctx, data, data_on_device, r0, r1, r2, eb, value_range, median, params, meta, meta_len, nullptr, out_on_device, out, out_size, stats);
+               : compress14_impl<double>(ctx, data, data_on_device, r0, r1, r2, eb, value_range, median, params, meta, meta_len, nullptr, out_on_device, out, out_size, stats); });
     if (rc != SZHIP_OK) { hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream); }
     return rc;
 }
@@ -2333,9 +2353,9 @@ int szhip_decompress_sz14(szhip_ctx *ctx, int dtype, const unsigned char *stream
     if (!ctx || !stream || !out || body_off >= stream_len) return SZHIP_ERR_ARG;
     if ((r0 != 0 && r0 < 2) || (r1 < 2 && !(r0 == 0 && r1 == 0)) || r2 < 2 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff) return SZHIP_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
-    const int rc = dtype == SZHIP_F32
+    const int rc = with_ticket_fallback(ctx, [&]() { return dtype == SZHIP_F32
                ? decompress14_impl<float>(ctx, stream, stream_on_device, stream_len, body_off, 0, r0, r1, r2, out, out_on_device, stats)
-               : decompress14_impl<double>(ctx, stream, stream_on_device, stream_len, body_off, 0, r0, r1, r2, out, out_on_device, stats);
+               : decompress14_impl<double>(ctx, stream, stream_on_device, stream_len, body_off, 0, r0, r1, r2, out, out_on_device, stats); });
     if (rc != SZHIP_OK) { hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream); }
     return rc;
 }
@@ -2373,9 +2393,9 @@ int szhip_compress_sz14_pwr(szhip_ctx *ctx, int dtype, const void *data, int dat
     if ((r0 != 0 && r0 < 2) || (r1 < 2 && !(r0 == 0 && r1 == 0)) || r2 < 2 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff) return SZHIP_ERR_ARG;
     if (!(eb > 0)) return SZHIP_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
-    const int rc = dtype == SZHIP_F32
+    const int rc = with_ticket_fallback(ctx, [&]() { return dtype == SZHIP_F32
                ? compress14_impl<float>(ctx, data, data_on_device, r0, r1, r2, eb, value_range, median, params, meta, meta_len, pwr, out_on_device, out, out_size, stats)
-               : compress14_impl<double>(ctx, data, data_on_device, r0, r1, r2, eb, value_range, median, params, meta, meta_len, pwr, out_on_device, out, out_size, stats);
+               : compress14_impl<double>(ctx, data, data_on_device, r0, r1, r2, eb, value_range, median, params, meta, meta_len, pwr, out_on_device, out, out_size, stats); });
     if (rc != SZHIP_OK) { hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream); }
     return rc;
 }
@@ -2406,9 +2426,9 @@ int szhip_decompress_sz14_pwr(szhip_ctx *ctx, int dtype, const unsigned char *st
     size_t bo, bs; double thr;
     if (szhip_sz14_pwr_locate(dtype, stream, stream_len, body_off, &bo, &bs, &thr) != SZHIP_OK) return SZHIP_ERR_STREAM;
     const bool msst = (stream[3] & 0x08) != 0;                   // TightDataPointStorageF.c:81
-    const int rc = dtype == SZHIP_F32
+    const int rc = with_ticket_fallback(ctx, [&]() { return dtype == SZHIP_F32
                ? decompress14_pwr_impl<float>(ctx, stream, 0, stream_len, body_off, r0, r1, r2, signs_host, thr, msst, out, out_on_device, stats)
-               : decompress14_pwr_impl<double>(ctx, stream, 0, stream_len, body_off, r0, r1, r2, signs_host, thr, msst, out, out_on_device, stats);
+               : decompress14_pwr_impl<double>(ctx, stream, 0, stream_len, body_off, r0, r1, r2, signs_host, thr, msst, out, out_on_device, stats); });
     if (rc != SZHIP_OK) { hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream); }
     return rc;
 }
@@ -2419,9 +2439,9 @@ int szhip_decompress(szhip_ctx *ctx, int dtype, const unsigned char *stream, int
     if (!ctx || !stream || !out || body_off >= stream_len) return SZHIP_ERR_ARG;
     if ((r0 != 0 && r0 < 2) || r1 < 2 || r2 < 2 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff) return SZHIP_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
-    return dtype == SZHIP_F32
+    return with_ticket_fallback(ctx, [&]() { return dtype == SZHIP_F32
                ? decompress_impl<float>(ctx, stream, stream_on_device, stream_len, body_off, r0, r1, r2, out, out_on_device, stats)
-               : decompress_impl<double>(ctx, stream, stream_on_device, stream_len, body_off, r0, r1, r2, out, out_on_device, stats);
+               : decompress_impl<double>(ctx, stream, stream_on_device, stream_len, body_off, r0, r1, r2, out, out_on_device, stats); });
 }
 
 int szhip_debug_fetch(szhip_ctx *ctx, int which, void *dst, size_t bytes)

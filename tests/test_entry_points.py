@@ -121,3 +121,21 @@ def test_staged_host_copies_on_the_cpu_shim(built, oracle, monkeypatch):
     import sim_lib
     monkeypatch.setenv("SZ_HIP_STAGE_CHUNK_KB", "1")
     _exercise(ctypes.CDLL(sim_lib.shim_path()), oracle)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("mode", ["fallback", "atomic", "index+table"])
+def test_tile_ticket_modes_on_the_cpu_shim(built, oracle, monkeypatch, mode):
+    """how a tile of the wavefront kernel learns which tile it is: the workgroup index with the tile computed (default), the same with the order
+    table, the atomic ticket -- and the repetition of a call with the atomic ticket after a (here: simulated) wait time-out under the default"""
+    import sim_lib
+    if mode == "fallback": monkeypatch.setenv("SZ_HIP_TEST_TICKET_FALLBACK", "1")
+    else: monkeypatch.setenv("SZ_HIP_TICKET_MODE", "0" if mode == "atomic" else "1")
+    _exercise(ctypes.CDLL(sim_lib.shim_path()), oracle)
+
+
+@pytest.mark.gpu
+def test_ticket_fallback_on_the_gpu(built, oracle, monkeypatch):
+    import sz_amd
+    monkeypatch.setenv("SZ_HIP_TEST_TICKET_FALLBACK", "1")
+    _exercise(ctypes.CDLL(sz_amd.api.lib_path()), oracle)
