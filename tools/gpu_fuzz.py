@@ -103,6 +103,11 @@ for c in range(ncases):
             else: okd = bool(np.all((back >= np.nextafter(dec, -np.inf)) & (back <= np.nextafter(dec, np.inf))) and np.array_equal(np.signbit(back), np.signbit(dec)))
             x = d.astype(np.float64); nzm = x != 0
             okb = (not nzm.any()) or float((np.abs(back.astype(np.float64)[nzm] - x[nzm]) / np.abs(x[nzm])).max()) <= ratio
+            if not msst and not okb and got == ref and okd:
+                # the reference's own stream, decoded to the reference's own values: what is left is the float rounding of ITS exp2 / narrowing
+                # (seen: 1.00002 x the ratio) -- not this library's to fix; anything larger still fails
+                okb = float((np.abs(back.astype(np.float64)[nzm] - x[nzm]) / np.abs(x[nzm])).max()) <= ratio * (1 + 1e-4)
+                globals()["ref_round"] = globals().get("ref_round", 0) + 1
             if msst:
                 if nzm.any() and np.isfinite(back).all(): worst_excess = max(worst_excess, float((np.abs(back.astype(np.float64)[nzm] - x[nzm]) / np.abs(x[nzm])).max()) / ratio)
                 okb = True
@@ -137,4 +142,4 @@ for c in range(ncases):
         st = sz_amd.SZ_hip_last_stats()
         print(f"FAIL case={c} seed0={seed0} dtype={np.dtype(dt).name} shape={shape} kind={kind} mode={mode} abs={abs_b:.3e} rel={rel_b:.3e} "
               f"stream_ok={ok_stream} dec_ok={ok_dec} len ref/gpu {len(ref)}/{len(got) if 'got' in dir() else -1} intervals={st.intervals} reg={st.n_reg_blocks} unpred={st.n_unpred}")
-print(f"fuzz: {ncases} cases, {fails} failures, {time.time() - t_start:.0f} s" + (f" (largest point-wise error / ratio, the reference's own: {worst_excess:.4f})" if msst else f" ({globals().get('soft', 0)} float64 streams of equal length differ in log2's last bit)" if pwr else ""))
+print(f"fuzz: {ncases} cases, {fails} failures, {time.time() - t_start:.0f} s" + (f" (largest point-wise error / ratio, the reference's own: {worst_excess:.4f})" if msst else f" ({globals().get('soft', 0)} float64 streams of equal length differ in log2's last bit; {globals().get('ref_round', 0)} cases where the reference's own decoded values pass the ratio by < 1e-4 of it)" if pwr else ""))
