@@ -145,6 +145,10 @@ CASES = [
     case("sz14-2D-plane-70x90-f32", lambda: plane_field(70, 90), withLinearRegression="NO"),
     case("sz14-2D-S-64x80-f64", lambda: s_field(1, 64, 80, f64)[0], abs=1e-6, withLinearRegression="NO"),
     case("sz14-S-rel-f32", lambda: s_field(20, 24, 40), mode=REL, rel=1e-3, withLinearRegression="NO"),
+    # a fixed interval count in the SZ 1.4 container: the header's max_quant_intervals field then holds that count (conf.c:193-197)
+    case("sz14-S-intervals256-f32", lambda: s_field(20, 24, 40), withLinearRegression="NO", quantization_intervals=256),
+    case("sz14-2D-plane-intervals64-f32", lambda: plane_field(70, 90), withLinearRegression="NO", quantization_intervals=64),
+    case("1D-walk-intervals128-f32", lambda: _walk(30000, f32), quantization_intervals=128),
     # ---- 1-D (sz_float.c:353, sz_double.c:260)
     case("1D-walk-30000-f32", lambda: _walk(30000, f32)),
     case("1D-walk-30000-f64", lambda: _walk(30000, f64), abs=1e-5),
