@@ -276,7 +276,7 @@ unsigned char *szo_compress_args(const szo_params *p, int data_type, const void 
     if (range <= eb) {
         /* constant data: SZ_compress_args_float_withinRange (sz_float.c:2728) -> header + first value */
         unsigned char same = 0x01 | 0x40;
-        if (p->protect_value_range) same |= 0x04;
+        if (p->protect_value_range && data_type == SZO_FLOAT) same |= 0x04;   /* TightDataPointStorageF.c:610; the double writer has no such line (TightDataPointStorageD.c:596-608) */
         meta[3] = same;
         unsigned char *o = (unsigned char *)malloc(4 + meta_len + 8 + esz);
         memcpy(o, meta, 4 + meta_len);
@@ -293,7 +293,7 @@ unsigned char *szo_compress_args(const szo_params *p, int data_type, const void 
     if (err_mode >= SZO_PW_REL && dim <= 4) {
         /* every mode >= PW_REL goes to the _pwr_pre_log functions with pwRelBoundRatio alone (sz_float.c:2888-2996); 4-D as (r4*r3, r2, r1) */
         size_t s0 = dim >= 3 ? (dim == 4 ? r4 * r3 : r3) : 1, s1 = dim >= 2 ? r2 : 1;
-        meta[3] = 0x40 | 0x20 | (p->protect_value_range ? 0x04 : 0);
+        meta[3] = 0x40 | 0x20 | (p->protect_value_range && data_type == SZO_FLOAT ? 0x04 : 0);   /* float container only, as above */
         /* the table-driven form: mode PW_REL alone, the switch on, a ratio of at least 1e-5 (sz_float.c:2837-2838, :2890) */
         const int msst19 = err_mode == SZO_PW_REL && p->accelerate_pw_rel && !(p->pw_rel_bound_ratio < 0.000009999) && p->max_quant_intervals <= 65536;
         if (msst19) {
@@ -320,7 +320,7 @@ unsigned char *szo_compress_args(const szo_params *p, int data_type, const void 
         /* SZ 1.4 path: SZ_compress_args_float_NoCkRngeNoGzip_3D / _2D (sz_float.c:1422, :896), flag byte TightDataPointStorageF.c:600-611 */
         size_t s0 = dim == 3 ? r3 : 1;
         if (dim == 1) r2 = 1;
-        meta[3] = 0x40 | (p->protect_value_range ? 0x04 : 0);
+        meta[3] = 0x40 | (p->protect_value_range && data_type == SZO_FLOAT ? 0x04 : 0);          /* float container only, as above */
         if (data_type == SZO_FLOAT)
             out = szo_sz14_compress_3d_f32(p, meta, 4 + meta_len, (const float *)data, s0, r2, r1, (float)eb, (float)range, (float)median, &osz, stages, NULL);
         else

@@ -257,7 +257,8 @@ static int constant_stream(int dataType, const szhost_meta *m, const void *oriDa
     const size_t esz = dataType == SZ_FLOAT ? 4 : 8, meta_len = dataType == SZ_FLOAT ? MetaDataByteLength : MetaDataByteLength_double;
     unsigned char meta[4 + MetaDataByteLength_double];
     unsigned char same = 0x01 | 0x40;
-    if (confparams_cpr->protectValueRange) same |= 0x04;
+    /* the float container records protectValueRange (TightDataPointStorageF.c:610); the double one does not (TightDataPointStorageD.c:596-608) */
+    if (confparams_cpr->protectValueRange && dataType == SZ_FLOAT) same |= 0x04;
     szhost_write_meta(m, same, meta);
     size_t tot = 4 + meta_len + 8 + esz;
     unsigned char *o = (unsigned char *)malloc(tot);
@@ -415,7 +416,7 @@ static int compress_fp(int dataType, int withRegression, unsigned char **newByte
         free(signs);
         unsigned char pflags = 0x40 | 0x20;                        /* TightDataPointStorageF.c:600-611: isPW_REL */
         if (msst19) pflags |= 0x08;                                /* :608-609 */
-        if (confparams_cpr->protectValueRange) pflags |= 0x04;
+        if (confparams_cpr->protectValueRange && dataType == SZ_FLOAT) pflags |= 0x04;   /* not in the double container (TightDataPointStorageD.c:596-608) */
         szhost_write_meta(&m, pflags, meta);
         szhip_params php; memset(&php, 0, sizeof(php));
         php.sample_distance = confparams_cpr->sampleDistance; php.pred_threshold = confparams_cpr->predThreshold;
@@ -465,7 +466,7 @@ static int compress_fp(int dataType, int withRegression, unsigned char **newByte
         }
     }
     unsigned char flags = sz14 ? 0x40 : (0x80 | 0x40);        /* TightDataPointStorageF.c:600-611 / sz_float.c:7396 */
-    if (confparams_cpr->protectValueRange) flags |= 0x04;
+    if (confparams_cpr->protectValueRange && !(sz14 && dataType == SZ_DOUBLE)) flags |= 0x04;   /* the double TightDataPointStorage writer leaves it out (TightDataPointStorageD.c:596-608) */
     szhost_write_meta(&m, flags, meta);
     szhip_params hp; memset(&hp, 0, sizeof(hp));
     hp.flags = fuse_range ? SZHIP_RANGE_FROM_DATA : 0;

@@ -145,6 +145,11 @@ CASES = [
     case("sz14-2D-plane-70x90-f32", lambda: plane_field(70, 90), withLinearRegression="NO"),
     case("sz14-2D-S-64x80-f64", lambda: s_field(1, 64, 80, f64)[0], abs=1e-6, withLinearRegression="NO"),
     case("sz14-S-rel-f32", lambda: s_field(20, 24, 40), mode=REL, rel=1e-3, withLinearRegression="NO"),
+    # protectValueRange in the TightDataPointStorage container: the float writer records it (TightDataPointStorageF.c:610), the double one does not
+    case("sz14-S-protect-f32", lambda: s_field(20, 24, 40), withLinearRegression="NO", protectValueRange="YES"),
+    case("sz14-S-protect-f64", lambda: s_field(20, 24, 40, f64), withLinearRegression="NO", protectValueRange="YES"),
+    case("const-protect-f64", lambda: np.full((9, 11, 13), -2.5, f64), abs=1e-3, protectValueRange="YES"),
+    case("const-protect-f32", lambda: np.full((9, 11, 13), 3.25, f32), abs=1e-3, protectValueRange="YES"),
     # a fixed interval count in the SZ 1.4 container: the header's max_quant_intervals field then holds that count (conf.c:193-197)
     case("sz14-S-intervals256-f32", lambda: s_field(20, 24, 40), withLinearRegression="NO", quantization_intervals=256),
     case("sz14-2D-plane-intervals64-f32", lambda: plane_field(70, 90), withLinearRegression="NO", quantization_intervals=64),
@@ -183,6 +188,8 @@ CASES = [
     case("pwr-4D-f32", lambda: _pwr_mix((3, 20, 24), f32, 28).reshape(3, 4, 5, 24), mode=PW_REL, pwr=1e-2),
     case("pwr-sd10-3D-f64", lambda: _pwr_mix((16, 20, 24), f64, 29, zeros=0.02), mode=PW_REL, pwr=1e-2, sampleDistance=10),
     case("pwr-ratio0.1-2D-f64", lambda: _pwr_mix((48, 64), f64, 30, zeros=0), mode=PW_REL, pwr=1e-1),
+    case("pwr-wrapped-zstd-3D-f32", lambda: _pwr_mix((18, 22, 26), f32, 31), mode=PW_REL, pwr=1e-2, szMode="SZ_BEST_COMPRESSION"),
+    case("pwr-protect-3D-f64", lambda: _pwr_mix((16, 20, 24), f64, 32), mode=PW_REL, pwr=1e-2, protectValueRange="YES"),
     case("pwr-noaccel-3D-f32", lambda: _pos((20, 24, 28), f32), mode=PW_REL, pwr=1e-2, accelerate_pw_rel_compression=0),
     # the log-domain form (accelerate_pw_rel_compression = 0, or a ratio below 1e-5: sz_float.c:2837-2838) -- the one the MI355X build writes
     case("pwrlog-pos-3D-f64", lambda: _pos((20, 24, 28), f64), mode=PW_REL, pwr=1e-3, accelerate_pw_rel_compression=0),

@@ -63,8 +63,8 @@ def _is_log_form(c):
 
 
 PLAIN = [c for c in ref_cases.CASES if c["mode"] < PW_REL and not _wrapped(c)]
-PWRLOG = [c for c in ref_cases.CASES if _is_log_form(c)]
-MSST19 = [c for c in ref_cases.CASES if c["mode"] >= PW_REL and not _is_log_form(c)]
+PWRLOG = [c for c in ref_cases.CASES if _is_log_form(c) and not _wrapped(c)]
+MSST19 = [c for c in ref_cases.CASES if c["mode"] >= PW_REL and not _is_log_form(c) and not _wrapped(c)]
 WRAPPED = [c for c in ref_cases.CASES if _wrapped(c)]
 
 
