@@ -11,7 +11,7 @@
  * PARITY PIN: the reference cannot be compiled in this image without writing a
  * stand-in for its generated config.h (sz/src/sz.c:11, dataCompression.c:10), so no
  * oracle/_ref build exists.  The oracle is pinned against outputs of the UNMODIFIED
- * reference: 103 cases (3-D, 2-D, 1-D, SZ 1.4, use_mean, f64, every bound mode, the
+ * reference: 115 cases (3-D, 2-D, 1-D, SZ 1.4, use_mean, f64, every bound mode, the
  * sz.config knobs, point-wise relative bounds in both of the reference's forms) recorded
  * through the public C API of the survey's build of the reference by
  * tools/record_reference_outputs.py into tests/golden/ref_recorded.json and replayed

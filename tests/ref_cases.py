@@ -166,6 +166,18 @@ CASES = [
     case("const-f64", lambda: np.full((9, 11, 13), -2.5, f64), abs=1e-3),
     case("tiny-2x3x3-f32", lambda: np.arange(18, dtype=f32).reshape(2, 3, 3), abs=1e-3),
     case("noise-raw-f32", lambda: np.random.default_rng(1).standard_normal((16, 16, 16)).astype(f32), abs=1e-7),
+    # dimensions of 1 are dropped before the dispatch (filterDimension, sz.c:128-200): 3-D shapes that are 2-D, 4-D shapes that are 2-D, 27 values
+    case("dim1-1x40x50-f32", lambda: _walk(2000, f32, seed=41).reshape(1, 40, 50), abs=1e-3),
+    case("dim1-40x1x50-f64", lambda: _walk(2000, f64, seed=42).reshape(40, 1, 50), abs=1e-3),
+    case("dim1-7x1x1x40-f32", lambda: _walk(280, f32, seed=43).reshape(7, 1, 1, 40), abs=1e-3),
+    case("tiny-3x3x3-f32", lambda: _walk(27, f32, seed=44).reshape(3, 3, 3), abs=1e-3),
+    # more mode x shape x type combinations (recorded at the end of round 2)
+    case("4D-3x4x20x24-rel-f64", lambda: s_field(12, 20, 24, f64).reshape(3, 4, 20, 24), mode=REL, rel=1e-3),
+    case("1D-rel-f64", lambda: _walk_sine(20000, f64), mode=REL, rel=1e-4),
+    case("1D-psnr70-f32", lambda: _walk_sine(20000, f32), mode=PSNR, psnr=70),
+    case("sz14-norm-f32", lambda: s_field(20, 24, 40), mode=NORM, normErr=0.05, withLinearRegression="NO"),
+    case("2D-abs-and-rel-f64", lambda: s_field(1, 64, 80, f64)[0], mode=ABS_AND_REL, abs=1e-4, rel=1e-3),
+    case("S-gzip-default-f64", lambda: s_field(20, 24, 40, f64), szMode="SZ_DEFAULT_COMPRESSION", losslessCompressor="GZIP_COMPRESSOR"),
     # ---- point-wise relative bounds (sz_float_pwr.c / sz_double_pwr.c; dispatch sz_float.c:2888-2893)
     case("pwr-pos-3D-f32", lambda: _pos((20, 24, 28), f32), mode=PW_REL, pwr=1e-2),
     case("pwr-pos-3D-f64", lambda: _pos((20, 24, 28), f64), mode=PW_REL, pwr=1e-3),
@@ -203,6 +215,8 @@ CASES = [
     case("pwrlog-tight-3D-f32", lambda: _pos((20, 24, 28), f32), mode=PW_REL, pwr=5e-6),
     case("pwrlog-abs-and-pwr-3D-f32", lambda: _pos((20, 24, 28), f32), mode=ABS_AND_PW_REL, abs=1e-3, pwr=1e-2, accelerate_pw_rel_compression=0,
          pw_relBoundRatio=1e-2),
+    case("pwrlog-rel-or-pwr-2D-f64", lambda: _pwr_mix((48, 64), f64, 33), mode=REL_OR_PW_REL, rel=1e-3, pwr=1e-3, accelerate_pw_rel_compression=0, pw_relBoundRatio=1e-3),
+    case("pwrlog-abs-or-pwr-1D-f32", lambda: _pwr_mix((9000,), f32, 34), mode=ABS_OR_PW_REL, abs=1e-3, pwr=1e-2, accelerate_pw_rel_compression=0, pw_relBoundRatio=1e-2),
     case("pwrlog-4D-f32", lambda: _pos((3, 20, 24), f32).reshape(3, 4, 5, 24), mode=PW_REL, pwr=1e-2, accelerate_pw_rel_compression=0),
     # ---- lossless back end (utility.c:156-214): the wrapped bytes depend on the zstd/zlib build, the decoded values do not
     case("C1-zstd", lambda: _c1(f32), szMode="SZ_BEST_COMPRESSION"),
