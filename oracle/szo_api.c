@@ -347,9 +347,23 @@ unsigned char *szo_compress_args(const szo_params *p, int data_type, const void 
         o[3] = 80;
         szo_put_u64be(o + 4 + meta_len, n);
         unsigned char *q = o + 4 + meta_len + 8;
+        /* the MSST19 wrappers have by now overwritten the zeros of the array they store (sz_float_pwr.c:2053-2058, :2077): the raw copy holds
+         * nearZero * (1+ratio)^-3.0001 in their place (and decodes to that) */
+        float zf = 0; double zd = 0;
+        if (meta[3] & 0x08) {
+            if (data_type == SZO_FLOAT) {
+                const float *x = (const float *)data; float nz = x[0];
+                for (size_t i = 1; i < n; i++) if (x[i] != 0 && fabsf(x[i]) < fabsf(nz)) nz = x[i];
+                zf = nz * (float)pow(1 + p->pw_rel_bound_ratio, -3.0001);
+            } else {
+                const double *x = (const double *)data; double nz = x[0];
+                for (size_t i = 1; i < n; i++) if (x[i] != 0 && fabs(x[i]) < fabs(nz)) nz = x[i];
+                zd = nz * pow(1 + p->pw_rel_bound_ratio, -3.0001);
+            }
+        }
         for (size_t i = 0; i < n; i++, q += esz) {
-            if (data_type == SZO_FLOAT) szo_put_be_f32(q, ((const float *)data)[i]);
-            else szo_put_be_f64(q, ((const double *)data)[i]);
+            if (data_type == SZO_FLOAT) { float v = ((const float *)data)[i]; szo_put_be_f32(q, v == 0 ? zf : v); }
+            else { double v = ((const double *)data)[i]; szo_put_be_f64(q, v == 0 ? zd : v); }
         }
         free(out); out = o; osz = tot;
     }

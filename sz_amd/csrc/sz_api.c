@@ -384,7 +384,7 @@ static int compress_fp(int dataType, int withRegression, unsigned char **newByte
         const int msst19 = errBoundMode == PW_REL && confparams_cpr->accelerate_pw_rel_compression && confparams_cpr->maxRangeRadius <= 32768;
         unsigned char *signs = (unsigned char *)malloc(dataLength);
         if (!signs) return SZ_NSCS;
-        void *d_log = NULL; int positive = 1; double rp = 0, lrange = 0, lmedian = 0, minlog = 0;
+        void *d_log = NULL; int positive = 1; double rp = 0, lrange = 0, lmedian = 0, minlog = 0, msst_near_zero = 0;
         szhip_pwr pw; memset(&pw, 0, sizeof(pw));
         if (msst19) {
             double near_zero = 0, median_log = 0;
@@ -392,7 +392,7 @@ static int compress_fp(int dataType, int withRegression, unsigned char **newByte
             int prc = szhip_msst_prepare(ctx, dt, d_in, 1, dataLength, ref_max, pwRelBoundRatio, &d_log, signs, &positive, &near_zero, &median_log, &minlog);
             if (prc != SZHIP_OK) { printf("Error: szhip_msst_prepare failed (%d): %s\n", prc, szhip_last_error(ctx)); free(signs); return SZ_NSCS; }
             pw.msst19 = 1; pw.plus_bits = (unsigned char)confparams_cpr->plus_bits; pw.median_stored = median_log;
-            rp = pwRelBoundRatio;
+            rp = pwRelBoundRatio; msst_near_zero = near_zero;
         } else {
             int prc = szhip_pwr_prepare(ctx, dt, d_in, 1, dataLength, vmin, vmax, pwRelBoundRatio, &d_log, signs, &positive, &rp, &lrange, &lmedian, &minlog);
             if (prc != SZHIP_OK) { printf("Error: szhip_pwr_prepare failed (%d): %s\n", prc, szhip_last_error(ctx)); free(signs); return SZ_NSCS; }
@@ -437,8 +437,13 @@ static int compress_fp(int dataType, int withRegression, unsigned char **newByte
             o[3] = 80;
             szhost_put_u64be(o + 4 + meta_len, dataLength);
             unsigned char *q = o + 4 + meta_len + 8;
+            /* the reference's MSST19 wrappers store the array whose zeros they have overwritten (sz_float_pwr.c:2053-2058, :2077): the raw copy
+             * holds nearZero * (1+ratio)^-3.0001 in their place */
+            const float zf = msst19 ? (float)msst_near_zero * (float)pow(1 + pwRelBoundRatio, -3.0001) : 0.0f;
+            const double zd = msst19 ? msst_near_zero * pow(1 + pwRelBoundRatio, -3.0001) : 0.0;
             for (size_t i = 0; i < dataLength; i++, q += esz) {
-                if (dataType == SZ_FLOAT) szhost_put_f32be(q, ((float *)oriData)[i]); else szhost_put_f64be(q, ((double *)oriData)[i]);
+                if (dataType == SZ_FLOAT) { const float v = ((float *)oriData)[i]; szhost_put_f32be(q, v == 0 ? zf : v); }
+                else { const double v = ((double *)oriData)[i]; szhost_put_f64be(q, v == 0 ? zd : v); }
             }
             free(ptmp); ptmp = o; ptmpSize = tot;
         }

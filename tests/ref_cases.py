@@ -202,6 +202,8 @@ CASES = [
     case("pwr-ratio0.1-2D-f64", lambda: _pwr_mix((48, 64), f64, 30, zeros=0), mode=PW_REL, pwr=1e-1),
     case("pwr-wrapped-zstd-3D-f32", lambda: _pwr_mix((18, 22, 26), f32, 31), mode=PW_REL, pwr=1e-2, szMode="SZ_BEST_COMPRESSION"),
     case("pwr-protect-3D-f64", lambda: _pwr_mix((16, 20, 24), f64, 32), mode=PW_REL, pwr=1e-2, protectValueRange="YES"),
+    # MSST19 falling back to the raw copy: the reference stores the array whose zeros it has already overwritten (sz_float_pwr.c:2053-2058, :2077)
+    case("pwr-raw-zeros-2D-f32", lambda: _pwr_mix((14, 80), f32, 35, zeros=0.05, signed=False) * np.random.default_rng(36).random((14, 80)).astype(f32), mode=PW_REL, pwr=2e-5),
     case("pwr-noaccel-3D-f32", lambda: _pos((20, 24, 28), f32), mode=PW_REL, pwr=1e-2, accelerate_pw_rel_compression=0),
     # the log-domain form (accelerate_pw_rel_compression = 0, or a ratio below 1e-5: sz_float.c:2837-2838) -- the one the MI355X build writes
     case("pwrlog-pos-3D-f64", lambda: _pos((20, 24, 28), f64), mode=PW_REL, pwr=1e-3, accelerate_pw_rel_compression=0),
