@@ -42,13 +42,16 @@ with tempfile.TemporaryDirectory() as td:
         n = int(np.prod(shape))
         if n <= 20: continue
         skip4 = nd == 4
-        kind = int(rng.integers(0, 5))
+        kind = int(rng.integers(0, 8))
         sh3 = (1, 1, n) if nd == 1 else (1,) + shape if nd == 2 else shape if nd == 3 else (shape[0] * shape[1], shape[2], shape[3])
         if kind == 0: d = s_field(*sh3, dt)
         elif kind == 1: d = l_field(*sh3, dt, n_for_hash=max(sh3[2], 8))
         elif kind == 2: d = rng.random(sh3).astype(dt)
         elif kind == 3: d = (s_field(*sh3, dt) + (rng.random(sh3) - 0.5).astype(dt) * dt(10.0 ** rng.integers(-5, -1)))
-        else: d = (np.cumsum(rng.standard_normal(n)) * 0.01).astype(dt).reshape(sh3)
+        elif kind == 4: d = (np.cumsum(rng.standard_normal(n)) * 0.01).astype(dt).reshape(sh3)
+        elif kind == 5: d = s_field(*sh3, dt); d[np.abs(d) < 0.6] = 0                     # mostly one value: the mean shortcut
+        elif kind == 6: d = np.full(sh3, dt(rng.standard_normal()), dt)                   # constant
+        else: d = (s_field(*sh3, dt) * dt(1e-3) + dt(7.5))                                # small range on a large offset
         mode = int(rng.choice([0, 0, 0, 1, 2, 3, 4, 5, 10, 10]))
         if mode == 10:
             mag = np.exp(2.0 * d.astype(np.float64) / max(float(np.abs(d).max()), 1e-30) + 0.05 * rng.standard_normal(sh3))
