@@ -674,7 +674,14 @@ static void *decompress_fp(int dataType, unsigned char *cmpBytes, size_t cmpSize
                 else if (!signs) ok = 0;
                 else {
                     size_t got = g_zstd.decompress(signs, dataLength, sz + bo, bs);
-                    if (g_zstd.iserr(got) || got != dataLength) { printf("Error: the sign bytes of this PW_REL stream do not decode to %zu bytes.\n", dataLength); ok = 0; }
+                    if (g_zstd.iserr(got) || got != dataLength) {
+                        /* the reference's 2-D / 3-D MSST19 wrappers code the sign bytes with the CONFIGURED back end (sz_float_pwr.c:2030, :2068) while its
+                         * readers always ask zstd (szd_float_pwr.c:1438), i.e. it cannot read its own gzip-configured streams; zlib is tried here */
+                        unsigned long zl = (unsigned long)dataLength;
+                        if (!(zlib_load() && g_zlib.uncompress(signs, &zl, sz + bo, (unsigned long)bs) == 0 && zl == dataLength)) {
+                            printf("Error: the sign bytes of this PW_REL stream do not decode to %zu bytes.\n", dataLength); ok = 0;
+                        }
+                    }
                 }
             }
             if (ok) {

@@ -73,6 +73,9 @@ with tempfile.TemporaryDirectory() as td:
                 "sampleDistance": int(rng.choice([100, 100, 10, 37])), "predThreshold": float(rng.choice([0.99, 0.9, 0.999])),
                 "max_quant_intervals": int(rng.choice([65536, 65536, 4096])), "accelerate_pw_rel_compression": int(rng.random() < 0.6),
                 "protectValueRange": "YES" if rng.random() < 0.15 else "NO", "psnr": float(rng.choice([60, 80])), "normErr": 0.05}
+        if product and rng.random() < 0.35:        # the lossless back ends: bytes depend on the zstd / zlib build, so only sizes and DECODED values are compared -- both ways
+            conf["szMode"] = str(rng.choice(["SZ_BEST_COMPRESSION", "SZ_DEFAULT_COMPRESSION"]))
+            conf["losslessCompressor"] = str(rng.choice(["ZSTD_COMPRESSOR", "GZIP_COMPRESSOR"]))
         rngv = max(float(d.max()) - float(d.min()), 1e-6)
         case = dict(name=f"fuzz{c}", data=None, mode=mode, abs=float(10.0 ** rng.uniform(-5, -2)) * rngv, rel=float(10.0 ** rng.uniform(-5, -2)),
                     pwr=float(10.0 ** rng.uniform(-4, -1)), conf=conf)
@@ -102,7 +105,30 @@ with tempfile.TemporaryDirectory() as td:
                 odec = O.decompress(ref, shape, d.dtype)
         except Exception as e:
             bad += 1; print("EXC", c, np.dtype(dt).name, shape, mode, conf, repr(e)); continue
+        wrapped = conf.get("szMode", "SZ_BEST_SPEED") != "SZ_BEST_SPEED"
+        if mode == 10 and conf["accelerate_pw_rel_compression"] and nd >= 2 and conf.get("losslessCompressor") == "GZIP_COMPRESSOR" and (d < 0).any():
+            # the reference codes these sign bytes with zlib and reads them back with zstd (sz_float_pwr.c:2030 / szd_float_pwr.c:1438): it cannot decode its own
+            # stream (signs from an uninitialised buffer).  The product reads it (zlib fallback) -- checked against the INPUT instead
+            x64 = d.astype(np.float64); nzm = x64 != 0; nzm.reshape(-1)[0] = False
+            if odec is None or not np.array_equal(np.sign(odec.astype(np.float64)[nzm]), np.sign(x64[nzm])): bad += 1; print("SIGNS LOST", c)
+            done += 1; continue
+        if product:                                  # the reference decodes the product's stream
+            assert L.SZ_Init(cfg.encode()) == 0
+            buf2 = ctypes.create_string_buffer(got, len(got))
+            q2 = L.SZ_decompress(0 if dt == np.float32 else 1, buf2, len(got), *dims5(shape))
+            xdec = np.ctypeslib.as_array(ctypes.cast(q2, ctypes.POINTER(ctypes.c_float if dt == np.float32 else ctypes.c_double)), shape=(n,)).copy().reshape(shape) if q2 else None
+            if q2: libc.free(q2)
+            L.SZ_Finalize()
+            if xdec is None or not np.array_equal(xdec.view(np.uint8), rdec.view(np.uint8)):
+                if not (mode == 10 and ((got[3] & 0x10) != (ref[3] & 0x10))):
+                    bad += 1; print("CROSS-DECODE DIFF", c, np.dtype(dt).name, shape, "mode", mode, conf)
         a, b = bytearray(got), bytearray(ref)
+        if wrapped:
+            done += 1
+            okd = odec is not None and np.array_equal(odec.view(np.uint8), rdec.view(np.uint8))
+            if not okd or abs(len(a) - len(b)) > 0.03 * len(b) + 64:
+                bad += 1; print("DIFF(wrapped)", c, np.dtype(dt).name, shape, "mode", mode, len(got), len(ref), "decode", okd, conf)
+            continue
         if len(a) > 19 and len(b) > 19 and not (b[3] & 0x80): a[19] = 0; b[19] = 0
         same = bytes(a) == bytes(b)
         if not same and mode == 10:
