@@ -43,7 +43,7 @@ with tempfile.TemporaryDirectory() as td:
         nd = int(rng.choice([1, 2, 3, 3, 3, 4]))
         if nd == 1: shape = (int(rng.integers(21, 6000)),)
         elif nd == 2: shape = (int(rng.integers(2, 70)), int(rng.integers(2, 110)))
-        elif nd == 3: shape = tuple(int(x) for x in rng.integers(2, 30, size=3))
+        elif nd == 3: shape = tuple(int(x) for x in rng.integers(2, 72 if os.environ.get("FUZZ_BIG") else 30, size=3))
         else: shape = (int(rng.integers(2, 4)), int(rng.integers(2, 5)), int(rng.integers(2, 16)), int(rng.integers(2, 24)))
         n = int(np.prod(shape))
         if n <= 20: continue
