@@ -346,7 +346,7 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
         sz_amd.SZ_Finalize()
         e2e = {"compress_GBps": round(nbytes_in / float(np.median(tcs)) / 1e9, 2), "decompress_GBps": round(nbytes_in / float(np.median(tds)) / 1e9, 2),
                "what": "SZ_compress_args / SZ_decompress (the C entry points) on a pageable host array: 512 MiB staged to the device in 8 MiB chunks through "
-                       "pinned buffers by four host threads + the stream back, and the reverse into a freshly malloc'd array; median of 3",
+                       "pinned buffers by four host threads + the stream back, and the reverse into a freshly malloc'd array (transparent huge pages requested for it); median of 3",
                "stream_identical_to_device_path": bool(s2len == size)}
 
     cpu, cpu_mt = (None, None)

@@ -69,9 +69,12 @@ with tempfile.TemporaryDirectory() as td:
             if rng.random() < 0.2: mag.reshape(-1)[0] = 0.0
             d = mag.astype(dt)
         d = np.ascontiguousarray(d.reshape(shape))
-        conf = {"withLinearRegression": "YES" if rng.random() < 0.6 else "NO", "quantization_intervals": int(rng.choice([0, 0, 0, 64, 1024])),
-                "sampleDistance": int(rng.choice([100, 100, 10, 37])), "predThreshold": float(rng.choice([0.99, 0.9, 0.999])),
-                "max_quant_intervals": int(rng.choice([65536, 65536, 4096])), "accelerate_pw_rel_compression": int(rng.random() < 0.6),
+        wide = bool(os.environ.get("FUZZ_WIDE"))          # the corners of the knobs
+        conf = {"withLinearRegression": "YES" if rng.random() < 0.6 else "NO",
+                "quantization_intervals": int(rng.choice([0, 0, 0, 32, 64, 1024, 65536] if wide else [0, 0, 0, 64, 1024])),
+                "sampleDistance": int(rng.choice([1, 2, 3, 5, 10, 37, 100, 500] if wide else [100, 100, 10, 37])),
+                "predThreshold": float(rng.choice([0.5, 0.9, 0.97, 0.99, 0.999, 1.0] if wide else [0.99, 0.9, 0.999])),
+                "max_quant_intervals": int(rng.choice([32, 64, 256, 4096, 65536] if wide else [65536, 65536, 4096])), "accelerate_pw_rel_compression": int(rng.random() < 0.6),
                 "protectValueRange": "YES" if rng.random() < 0.15 else "NO", "psnr": float(rng.choice([60, 80])), "normErr": 0.05}
         if product and rng.random() < 0.35:        # the lossless back ends: bytes depend on the zstd / zlib build, so only sizes and DECODED values are compared -- both ways
             conf["szMode"] = str(rng.choice(["SZ_BEST_COMPRESSION", "SZ_DEFAULT_COMPRESSION"]))
