@@ -17,7 +17,7 @@
  * tools/record_reference_outputs.py into tests/golden/ref_recorded.json and replayed
  * by tests/test_ref_recorded.py (stream length + md5, decoded md5); plus the survey's
  * own scalar anchors (tests/test_oracle_pins.py).  In the build container the oracle was also run against the
- * reference library itself on random inputs and configurations (tools/ref_diff_fuzz.py: 3 360 cases, streams and decoded
+ * reference library itself on random inputs and configurations (tools/ref_diff_fuzz.py: 4 100 cases, streams and decoded
  * arrays identical).  Not pinned: szo_fast.c, which
  * restates this repository's own opt-in fast mode and has no reference counterpart.
  */
