@@ -38,7 +38,7 @@ struct szhip_ctx {
     char err[512] = {0};
     unsigned epoch = 0;
     // workspaces (grow-only)
-    DevBuf lor_bits, reg_flags, reg_rank, coef_compact, in, out, codes_nat, codes_blk, coef, blk_lor, faceI, faceJ, progress, trace, order, small, hist, col_zeros, col_zeros64,
+    DevBuf lor_bits, reg_flags, reg_rank, coef_compact, in, out, codes_nat, codes_blk, coef, blk_lor, faceI, faceJ, rb_down, rb_right, progress, trace, order, small, hist, col_zeros, col_zeros64,
         col_off, partial, samples, unpred, stream_buf, chunk_bits, chunk_off, code_tab, len_tab, dec_tab,
         starts, ends, counts, offs, dirty, zcnt, zpos, pwr_log, pwr_signs, pwr_small, coef_dec, msst_ptab, msst_cells, msst_rec, msst_pe;
     void *pinned = nullptr; size_t pinned_cap = 0;
@@ -285,6 +285,36 @@ int prepare_pencil(szhip_ctx *ctx, const szh_geom3 &G, int nw, int tpi, int tpj,
         ctx->order_nI = nTI; ctx->order_nJ = nTJ;
     }
     *nI_out = nI; *nJ_out = nJ; *ntiles_out = nTI * nTJ;
+    return SZHIP_OK;
+}
+
+// ---- the ribbon mapping of the wavefront kernel (szh_ribbon.h): 3-D arrays whose block map is Lorenzo-only
+// does it cover this call?  (SZ_HIP_RIBBON=0 sends everything to k_pencil)
+template <class T> bool ribbon_applies(const szh_geom3 &G, size_t reg_count)
+{
+    using RS = szh_rb_shape<T>;
+    if (!tune_int("SZ_HIP_RIBBON", 1)) return false;
+    if (G.ndim != 3 || reg_count != 0) return false;
+    if ((double)RS::W * RS::R * (double)G.d0 * sizeof(T) >= 2.0e9) return false;      // a tile's rows are addressed by 32-bit buffer offsets
+    const int nTI = (G.g0.count + RS::W * RS::R - 1) / (RS::W * RS::R), nTJ = (G.g1.count + 63) / 64;
+    return nTI <= 65535 && nTJ <= 65535;
+}
+// granule rows of the tile hand-offs + the launch; `a` carries everything that does not depend on the mapping
+template <class T, bool DEC>
+int launch_ribbon(szhip_ctx *ctx, const szh_geom3 &G, szh_qargs<T> a, hipStream_t st)
+{
+    using RS = szh_rb_shape<T>;
+    constexpr int WR = RS::W * RS::R, NW = szh_gran<T>::NW;
+    const int nTI = (G.g0.count + WR - 1) / WR, nTJ = (G.g1.count + 63) / 64;
+    const size_t NT = (size_t)szh_rb_steps_of<T>(G.g2.count), tiles = (size_t)nTI * nTJ;
+    TRY(ensure(ctx, ctx->rb_down, tiles * NT * NW * 64 * sizeof(u64) + 64, true));
+    TRY(ensure(ctx, ctx->rb_right, tiles * NT * NW * WR * sizeof(u64) + 64, true));
+    a.faceI = (szh_u64 *)ctx->rb_down.p; a.faceJ = (szh_u64 *)ctx->rb_right.p;
+    a.nI = nTI; a.nJ = nTJ;
+    if (a.ticket_mode == 2) a.ticket_mode = 1;          // (the tile is always computed from the ticket here; 0 = atomic ticket)
+    if (a.use_mean) hipLaunchKernelGGL((k_ribbon<T, DEC, true>), dim3((unsigned)tiles), dim3((RS::W + 3) * 64), 0, st, a);
+    else hipLaunchKernelGGL((k_ribbon<T, DEC, false>), dim3((unsigned)tiles), dim3((RS::W + 3) * 64), 0, st, a);
+    HIPCHK(hipGetLastError());
     return SZHIP_OK;
 }
 
@@ -591,7 +621,17 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     TP("ev1");
 
     // ---- predict + quantise: the wavefront kernel
-    TRY(ensure(ctx, ctx->codes_nat, (size_t)n * 2 + 64));
+    // (the ribbon mapping writes its codes in its own order, szh_ribbon.h: tiles x steps x 1024 entries, a few per cent more than n)
+    const bool use_ribbon = !overlap && ribbon_applies<T>(G, reg_count);
+    szh_rb_layout rbl = {0, 0, 0, 0, 0, 0};
+    size_t nat_elems = (size_t)n;
+    if (use_ribbon) {
+        using RS = szh_rb_shape<T>;
+        rbl.on = 1; rbl.nTJ = (G.g1.count + 63) / 64; rbl.NT = szh_rb_steps_of<T>(G.g2.count); rbl.W = RS::W; rbl.R = RS::R; rbl.U = RS::U;
+        const size_t tiles = (size_t)((G.g0.count + RS::W * RS::R - 1) / (RS::W * RS::R)) * rbl.nTJ;
+        nat_elems = tiles * (size_t)szh_rb_tile_elems(rbl);
+    }
+    TRY(ensure(ctx, ctx->codes_nat, nat_elems * 2 + 64));
     TRY(ensure(ctx, ctx->codes_blk, (size_t)n * 2 + 64));
     uint16_t *d_nat = (uint16_t *)ctx->codes_nat.p, *d_blk = (uint16_t *)ctx->codes_blk.p;
     int nI, nJ, ntiles;
@@ -629,8 +669,11 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
             a.coef = dec; a.coef_stride = nbp;
         }
         HIPCHK(hipEventRecord(ctx->ev[2], st));
+        if (use_ribbon) { TRY((launch_ribbon<T, false>(ctx, G, a, st))); S.quant_kernel = 1; }
+        else {
         hipLaunchKernelGGL((k_pencil<T, false>), dim3((unsigned)ntiles), dim3((TS::TPI * TS::TPJ + 2) * 64), 0, st, a);
         HIPCHK(hipGetLastError());
+        }
         HIPCHK(hipEventRecord(ctx->ev[3], st));
         TP("pencil launched");
         S.quant_kernel_launches = 1;
@@ -679,19 +722,21 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     unsigned *d_hist = (unsigned *)ctx->hist.p;
     TRY(ensure_pinned(ctx, (size_t)intervals * 4 + 64));
     unsigned *h_hist = (unsigned *)ctx->pinned;
-    HIPCHK(hipEventRecord(ctx->ev_in, st));                    // codes complete
-    HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_in, 0));
-    HIPCHK(hipMemsetAsync(d_hist, 0, (size_t)intervals * 4, ctx->stream2));
-    {
+    auto launch_hist = [&](const uint16_t *codes) -> int {
+        HIPCHK(hipEventRecord(ctx->ev_in, st));                    // codes complete
+        HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_in, 0));
+        HIPCHK(hipMemsetAsync(d_hist, 0, (size_t)intervals * 4, ctx->stream2));
         int rshift = 0; int use_lds = intervals <= 16384;
         if (use_lds) { while ((intervals << (rshift + 1)) <= 16384u && rshift < 6) ++rshift; }
         const size_t lds = use_lds ? ((size_t)intervals << rshift) * 4 : 16;
         int grid = (int)std::min<int64_t>((n / 8 + 255) / 256 + 1, 2048);
-        hipLaunchKernelGGL(k_hist_u16, dim3(grid), dim3(256), lds, ctx->stream2, (const uint16_t *)d_nat, n, intervals, rshift, use_lds, d_hist);
+        hipLaunchKernelGGL(k_hist_u16, dim3(grid), dim3(256), lds, ctx->stream2, codes, n, intervals, rshift, use_lds, d_hist);
         HIPCHK(hipGetLastError());
-    }
-    HIPCHK(hipMemcpyAsync(h_hist, d_hist, (size_t)intervals * 4, hipMemcpyDeviceToHost, ctx->stream2));
-    HIPCHK(hipEventRecord(ctx->ev_fit, ctx->stream2));
+        HIPCHK(hipMemcpyAsync(h_hist, d_hist, (size_t)intervals * 4, hipMemcpyDeviceToHost, ctx->stream2));
+        HIPCHK(hipEventRecord(ctx->ev_fit, ctx->stream2));
+        return SZHIP_OK;
+    };
+    if (!use_ribbon) TRY(launch_hist((const uint16_t *)d_nat));    // natural order: next to the block-ordering pass
     TRY(ensure(ctx, ctx->col_zeros, (size_t)ncols * 4));
     TRY(ensure(ctx, ctx->col_zeros64, (size_t)ncols * 8));
     TRY(ensure(ctx, ctx->col_off, (size_t)ncols * 8));
@@ -703,10 +748,11 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         TRY(ensure(ctx, ctx->zcnt, (size_t)ncols * nseg * 4));
         TRY(ensure(ctx, ctx->zpos, (size_t)ncols * nseg * SZH_ZCAP * 4));
         hipLaunchKernelGGL((k_permute<0>), dim3(ncols, nseg), dim3(256), tile_bytes(G, segb, 2), st, G, (const uint16_t *)d_nat,
-                           d_blk, (unsigned *)ctx->col_zeros.p, segb, (unsigned *)ctx->zcnt.p, (unsigned *)ctx->zpos.p);
+                           d_blk, (unsigned *)ctx->col_zeros.p, segb, (unsigned *)ctx->zcnt.p, (unsigned *)ctx->zpos.p, rbl);
         perm_segb = segb; perm_nseg = nseg;
         HIPCHK(hipGetLastError());
     }
+    if (use_ribbon) TRY(launch_hist((const uint16_t *)d_blk));     // ribbon order holds padding: the histogram reads the block-ordered array
     hipLaunchKernelGGL(k_u32_to_u64, dim3((ncols + 255) / 256), dim3(256), 0, st, (const unsigned *)ctx->col_zeros.p, (int64_t)ncols,
                        (u64 *)ctx->col_zeros64.p);
     TRY(scan_u64(ctx, (const u64 *)ctx->col_zeros64.p, ncols, (u64 *)ctx->col_off.p, sm + SM_TOTAL_UNPRED));
@@ -1072,7 +1118,7 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
         TRY(ensure(ctx, ctx->zcnt, (size_t)ncols * nseg * 4));
         TRY(ensure(ctx, ctx->zpos, (size_t)ncols * nseg * SZH_ZCAP * 4));
         hipLaunchKernelGGL((k_permute<1>), dim3(ncols, nseg), dim3(256), tile_bytes(G, segb, 2), st, G, (const uint16_t *)d_blk, d_nat,
-                           (unsigned *)ctx->col_zeros.p, segb, (unsigned *)ctx->zcnt.p, (unsigned *)ctx->zpos.p);
+                           (unsigned *)ctx->col_zeros.p, segb, (unsigned *)ctx->zcnt.p, (unsigned *)ctx->zpos.p, szh_rb_layout{0, 0, 0, 0, 0, 0});
         perm_segb = segb; perm_nseg = nseg;
         HIPCHK(hipGetLastError());
     }
@@ -1131,8 +1177,13 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
         a.trace = tune_int("SZ_HIP_TRACE", 0) ? (szh_u64 *)ctx->trace.p : nullptr;
         a.dbg = tune_int("SZ_HIP_DBG", 0); a.trace_tile = tune_int("SZ_HIP_TRACE_TILE", 1);
         HIPCHK(hipEventRecord(ctx->ev[2], st));
+        // (the inverse keeps k_pencil by default: its output rows leave the ribbon kernel as 2-byte-skewed 64-byte pieces of 64 different
+        //  rows per store, which costs it more than it gains -- 2.9 against 1.4 ms at 512^3; SZ_HIP_RIBBON_DEC=1 selects it)
+        if (tune_int("SZ_HIP_RIBBON_DEC", 0) && ribbon_applies<T>(G, reg_count)) { TRY((launch_ribbon<T, true>(ctx, G, a, st))); S.quant_kernel = 1; }
+        else {
         hipLaunchKernelGGL((k_pencil<T, true>), dim3((unsigned)ntiles), dim3((TS::TPI * TS::TPJ + 2) * 64), 0, st, a);
         HIPCHK(hipGetLastError());
+        }
         HIPCHK(hipEventRecord(ctx->ev[3], st));
         S.quant_kernel_launches = 1;
     }
@@ -2278,7 +2329,7 @@ void szhip_destroy(szhip_ctx *ctx)
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->lor_bits, &ctx->reg_flags, &ctx->reg_rank, &ctx->coef_compact, &ctx->in, &ctx->out, &ctx->codes_nat, &ctx->codes_blk, &ctx->coef, &ctx->blk_lor, &ctx->faceI, &ctx->faceJ, &ctx->progress, &ctx->trace,
+    DevBuf *bufs[] = {&ctx->lor_bits, &ctx->reg_flags, &ctx->reg_rank, &ctx->coef_compact, &ctx->in, &ctx->out, &ctx->codes_nat, &ctx->codes_blk, &ctx->coef, &ctx->blk_lor, &ctx->faceI, &ctx->faceJ, &ctx->rb_down, &ctx->rb_right, &ctx->progress, &ctx->trace,
                       &ctx->order, &ctx->small, &ctx->hist, &ctx->col_zeros, &ctx->col_zeros64, &ctx->col_off, &ctx->partial,
                       &ctx->samples, &ctx->unpred, &ctx->stream_buf, &ctx->chunk_bits, &ctx->chunk_off, &ctx->code_tab,
                       &ctx->len_tab, &ctx->dec_tab, &ctx->starts, &ctx->ends, &ctx->counts, &ctx->offs, &ctx->dirty, &ctx->zcnt, &ctx->zpos,
@@ -2449,7 +2500,7 @@ int szhip_debug_fetch(szhip_ctx *ctx, int which, void *dst, size_t bytes)
     if (!ctx || !dst) return SZHIP_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
     DevBuf *bufs[] = {&ctx->coef, &ctx->blk_lor, &ctx->codes_nat, &ctx->codes_blk, &ctx->hist, &ctx->col_zeros, &ctx->col_off,
-                      &ctx->unpred, &ctx->stream_buf, &ctx->trace};
+                      &ctx->unpred, &ctx->stream_buf, &ctx->trace, &ctx->rb_down, &ctx->rb_right};
     if (which < 0 || which >= (int)(sizeof(bufs) / sizeof(bufs[0]))) return SZHIP_ERR_ARG;
     if (!bufs[which]->p || bufs[which]->cap < bytes) return SZHIP_ERR_ARG;
     HIPCHK(hipStreamSynchronize(ctx->stream));

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include "szh_core.h"
 #include "szh_pencil.h"
+#include "szh_ribbon.h"
 
 typedef unsigned long long u64;
 
@@ -650,8 +651,8 @@ __global__ __launch_bounds__(256) void k_hist_u16(const uint16_t *__restrict__ c
 #define SZH_ZCAP 128
 template <int DIR>
 __global__ __launch_bounds__(256) void k_permute(szh_geom3 G, const uint16_t *__restrict__ src, uint16_t *__restrict__ dst,
-                                                 unsigned *col_zeros, int segb, unsigned *zcnt, unsigned *zpos)
-{
+                                                 unsigned *col_zeros, int segb, unsigned *zcnt, unsigned *zpos, szh_rb_layout rb)
+{   // rb.on (DIR 0 only): `src` is in the ribbon order of szh_ribbon.h
     __shared__ unsigned zc_s, zp_s[SZH_ZCAP];
     if (threadIdx.x == 0) zc_s = 0;
     __syncthreads();
@@ -680,7 +681,24 @@ __global__ __launch_bounds__(256) void k_permute(szh_geom3 G, const uint16_t *__
         else { const int e2 = e - eregion; const int bl = e2 / lsz; const int rem = e2 - bl * lsz; s2 = G.g2.late; koff = nE * G.g2.early + bl * s2; row = rem / s2; kk = rem - row * s2; }
     };
     unsigned zeros = 0;
-    if (DIR == 0) {
+    if (DIR == 0 && rb.on) {
+        // gather from ribbon order: the codes of a row lie in groups of 8 consecutive k (16 aligned bytes), one group per 8 steps
+        // of the wavefront that made them; one thread per (row, group)
+        const int ng = klen / 8 + 2, WR = rb.W * rb.R;
+        for (int p = threadIdx.x; p < rows * ng; p += 256) {
+            const int r = p / ng, gl = p - r * ng;
+            const int i = o0 + r / s1, j = o1 + r % s1;
+            const int TI = i / WR, q = i - TI * WR, w = q / rb.R, rr = q - w * rb.R, TJ = j >> 6, ln = j & 63;
+            const int off = w * (rb.R - 1) + ln + rr;                       // shifted step of k = 0
+            const int tt8 = ((kbeg + off) >> 3) + gl;                        // group number along the sweep
+            const int k0 = tt8 * 8 - off;
+            if (k0 >= kend) continue;
+            const uint4 wv = *reinterpret_cast<const uint4 *>(src + szh_rb_group_index(rb, (int64_t)TI * rb.nTJ + TJ, w, rr, tt8 * 8) + ln * 8);
+            uint16_t v[8]; __builtin_memcpy(v, &wv, 16);
+            for (int e = 0; e < 8; ++e) { const int k = k0 + e; if (k >= kbeg && k < kend) tile[r * kp + kshift + (k - kbeg)] = v[e]; }
+        }
+        __syncthreads();
+    } else if (DIR == 0) {
         for (int r = wid; r < rows; r += 4) {
             const int i = r / s1, j = r - i * s1;
             const uint16_t *srow = src + (int64_t)(o0 + i) * G.d0 + (int64_t)(o1 + j) * G.d1 + ka;
