@@ -7,9 +7,13 @@
  * line it mirrors).  The implementation behind it (sz_amd/csrc/sz_api.c, C) derives the absolute
  * bound, frames the stream and calls the HIP layer declared in szhip.h.
  *
- * Covered: SZ_FLOAT / SZ_DOUBLE, 3-D and 4-D arrays (4-D is folded to 3-D as the reference does),
- * error-bound modes ABS, REL/VR_REL, ABS_AND_REL, ABS_OR_REL, PSNR, NORM, withRegression = YES.
- * Anything else returns NULL / SZ_NSCS after printing why (no silent CPU fallback).
+ * Covered: SZ_FLOAT / SZ_DOUBLE; 1-D, 2-D, 3-D arrays and 4-D arrays on the SZ 2.1 path (folded to 3-D as
+ * the reference does); withRegression = YES (SZ 2.1 stream) and NO (SZ 1.4 TightDataPointStorage
+ * container, 1-D .. 3-D); error-bound modes ABS, REL/VR_REL, ABS_AND_REL, ABS_OR_REL, PSNR, NORM and
+ * the point-wise relative family PW_REL, ABS_AND/OR_PW_REL, REL_AND/OR_PW_REL in both of the
+ * reference's forms; the zstd / gzip lossless stage of szMode; protectValueRange.
+ * Not covered (an explicit error, never a silent CPU fallback): integer types, the time-step and
+ * random-access modes, withRegression = NO for 4-D arrays.
  */
 #ifndef _SZ_H
 #define _SZ_H

@@ -31,6 +31,8 @@ extern "C" {
 #define SZHIP_ERR_UNSUP    -3   /* valid SZ input this layer does not cover yet */
 #define SZHIP_ERR_STREAM   -4   /* malformed compressed stream */
 #define SZHIP_ERR_INTERNAL -5   /* kernel-side timeout or inconsistency */
+#define SZHIP_CONSTANT      1   /* szhip_compress with SZHIP_RANGE_FROM_DATA: max - min <= eb, nothing was encoded (stats.vmin / vmax are
+                                   set, *out stays NULL): the caller writes the reference's constant-data stream (sz_float.c:2861) */
 
 #define SZHIP_F32 0
 #define SZHIP_F64 1

@@ -269,6 +269,8 @@ class HipContext:
         rc = lib().szhip_compress(self._h, 0 if np.dtype(dtype) == np.float32 else 1, ptr, int(on_device), shape3[0], shape3[1],
                                   shape3[2], eb, ctypes.byref(p), meta, len(meta), int(out_on_device), ctypes.byref(out),
                                   ctypes.byref(n), ctypes.byref(st))
+        if rc == 1:                      # SZHIP_CONSTANT (range-from-data): nothing encoded, st.vmin / st.vmax say why
+            return None, 0, st
         if rc:
             self._err(rc, "szhip_compress")
         if out_on_device:

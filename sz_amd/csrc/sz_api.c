@@ -433,6 +433,7 @@ static int compress_fp(int dataType, int withRegression, unsigned char **newByte
         if (ptmpSize > 3 + meta_len + exe_params->SZ_SIZE_TYPE + 1 + esz * dataLength) {     /* sz_float_pwr.c:1971 */
             size_t tot = 3 + meta_len + 8 + 1 + esz * dataLength;
             unsigned char *o = (unsigned char *)malloc(tot);
+            if (!o) { printf("Error: out of memory (%zu bytes for the raw copy)\n", tot); free(ptmp); return SZ_NSCS; }
             memcpy(o, meta, 4 + meta_len);
             o[3] = 80;
             szhost_put_u64be(o + 4 + meta_len, dataLength);
@@ -488,12 +489,23 @@ static int compress_fp(int dataType, int withRegression, unsigned char **newByte
     } else
         rc = szhip_compress(ctx, dataType == SZ_FLOAT ? SZHIP_F32 : SZHIP_F64, d_in, 1, s0, r2, r1, realPrecision, &hp,
                             meta, 4 + meta_len, 0, &tmp, &tmpSize, &g_last_stats);
-    if (rc != SZHIP_OK) { printf("Error: szhip_compress failed (%d): %s\n", rc, szhip_last_error(ctx)); return SZ_NSCS; }
+    if (rc != SZHIP_OK && rc != SZHIP_CONSTANT && fuse_range) {
+        /* the fused pass failed: a constant array must still come out as the reference's constant stream -- settle that with the plain range scan */
+        if (szhip_minmax(ctx, dataType == SZ_FLOAT ? SZHIP_F32 : SZHIP_F64, d_in, 1, dataLength, &vmin, &vmax) == SZHIP_OK) {
+            set_range(dataType, vmin, vmax, &valueRangeSize);
+            if (valueRangeSize <= realPrecision) {
+                fill_meta(&m, confparams_cpr, dataType);
+                int crc = constant_stream(dataType, &m, oriData, dataLength, newByteData, outSize);
+                return crc == SZ_SCES ? status : crc;
+            }
+        }
+    }
+    if (rc != SZHIP_OK && rc != SZHIP_CONSTANT) { printf("Error: szhip_compress failed (%d): %s\n", rc, szhip_last_error(ctx)); return SZ_NSCS; }
     if (fuse_range) {   /* the range arrived with the stream: record it where the reference's callers look for it, and settle the constant case */
         set_range(dataType, g_last_stats.vmin, g_last_stats.vmax, &valueRangeSize);
         fill_meta(&m, confparams_cpr, dataType);
         szhost_write_meta(&m, flags, meta);
-        if (valueRangeSize <= realPrecision) {
+        if (rc == SZHIP_CONSTANT || valueRangeSize <= realPrecision) {   /* (the HIP layer stops after its fit pass when it sees this: SZHIP_CONSTANT) */
             free(tmp);
             int crc = constant_stream(dataType, &m, oriData, dataLength, newByteData, outSize);
             return crc == SZ_SCES ? status : crc;
@@ -506,6 +518,7 @@ static int compress_fp(int dataType, int withRegression, unsigned char **newByte
     if (tmpSize + (sz14 && dim != 1 ? 0 : 1) > dataLength * esz + 3 + meta_len + exe_params->SZ_SIZE_TYPE + 1) {
         size_t tot = 3 + meta_len + 8 + 1 + esz * dataLength;
         unsigned char *o = (unsigned char *)malloc(tot);
+        if (!o) { printf("Error: out of memory (%zu bytes for the raw copy)\n", tot); free(tmp); return SZ_NSCS; }
         memcpy(o, meta, 4 + meta_len);
         o[3] = 80;
         szhost_put_u64be(o + 4 + meta_len, dataLength);
@@ -616,12 +629,14 @@ static void *decompress_fp(int dataType, unsigned char *cmpBytes, size_t cmpSize
         const int fdim = computeDimension(r5, r4, r3, r2, r1);
         const size_t f0 = fdim >= 3 ? (fdim == 4 ? r4 * r3 : r3) : 1, f1 = fdim >= 2 ? r2 : 1;
         void *fo = malloc(dataLength * esz + 1);
-        int frc = fctx && fo ? szhip_decompress_fast(fctx, dataType == SZ_FLOAT ? SZHIP_F32 : SZHIP_F64, cmpBytes, 0, cmpSize, f0, f1, r1, fo, 0, &g_last_stats) : SZHIP_ERR_NODEVICE;
+        if (!fo) { printf("Error: out of memory (%zu bytes for the decompressed array)\n", dataLength * esz); return NULL; }
+        int frc = fctx ? szhip_decompress_fast(fctx, dataType == SZ_FLOAT ? SZHIP_F32 : SZHIP_F64, cmpBytes, 0, cmpSize, f0, f1, r1, fo, 0, &g_last_stats) : SZHIP_ERR_NODEVICE;
         if (frc != SZHIP_OK) { printf("Error: szhip_decompress_fast failed (%d): %s\n", frc, fctx ? szhip_last_error(fctx) : "no device"); free(fo); return NULL; }
         return fo;
     }
     if (dataLength <= MIN_NUM_OF_ELEMENTS) { /* raw copy written by SZ_skip_compress */
         void *o = malloc(dataLength * esz != 0 ? dataLength * esz : 1);
+        if (!o) { printf("Error: out of memory\n"); if (owned) free(sz); return NULL; }
         memcpy(o, sz, dataLength * esz);
         if (owned) free(sz);
         return o;

@@ -74,6 +74,14 @@ namespace {
         fprintf(stderr, "szhip: %s\n", ctx->err);                                                      \
         return (code);                                                                                 \
     } while (0)
+// a failure found AFTER the stream has been handed to the caller's pointer: a host copy that this call malloc'd is released again
+#define FAIL_PUBLISHED(code, ...)                                                                      \
+    do {                                                                                               \
+        if (!out_on_device && out && *out) { free(*out); *out = nullptr; }                              \
+        if (out_size) *out_size = 0;                                                                   \
+        FAIL(code, __VA_ARGS__);                                                                       \
+    } while (0)
+
 
 int ensure(szhip_ctx *ctx, DevBuf &b, size_t bytes, bool zero_new = false)
 {
@@ -510,6 +518,13 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         if (is_double) { szhost_put_f64be(q, (double)lo); szhost_put_f64be(q + 8, (double)top); }
         else { szhost_put_f32be(q, (float)lo); szhost_put_f32be(q + 4, (float)top); }
         S.vmin = (double)lo; S.vmax = (double)hi;
+        if ((double)range <= eb_in) {          // constant within the bound: the caller's business (a full compression would be thrown away)
+            HIPCHK(hipStreamSynchronize(ctx->stream2)); HIPCHK(hipStreamSynchronize(st));
+            *out = nullptr; *out_size = 0;
+            S.ms_total = now_ms() - t_begin;
+            if (stats) *stats = S;
+            return SZHIP_CONSTANT;
+        }
     }
     meta = meta_own.data();
     // ---- regression coefficient chain (a serial recurrence with reconstruction feedback: host) and its Huffman streams.
@@ -870,10 +885,10 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     if (tp_on) { for (int i = 0; i < tp_k; ++i) fprintf(stderr, "%s %.2f | ", tp_n[i], tp_t[i]); fprintf(stderr, "\n"); }
     // after the final synchronisation: the wavefront kernel's error flag; the shuffled bit count and the device's count of zero codes
     // must match what the histogram predicted
-    if ((unsigned)h_small[SM_ERR] == 2) FAIL(SZHIP_ERR_INTERNAL, "wavefront kernel: the regression coefficients did not arrive");
-    if ((unsigned)h_small[SM_ERR] != 0) { ctx->wave_timeout = true; FAIL(SZHIP_ERR_INTERNAL, "wavefront kernel: halo wait timed out"); }
+    if ((unsigned)h_small[SM_ERR] == 2) FAIL_PUBLISHED(SZHIP_ERR_INTERNAL, "wavefront kernel: the regression coefficients did not arrive");
+    if ((unsigned)h_small[SM_ERR] != 0) { ctx->wave_timeout = true; FAIL_PUBLISHED(SZHIP_ERR_INTERNAL, "wavefront kernel: halo wait timed out"); }
     if ((total_bits > 0 && h_small[SM_TOTAL_BITS] != total_bits) || h_small[SM_TOTAL_UNPRED] != total_unpred)
-        FAIL(SZHIP_ERR_INTERNAL, "entropy stage mismatch (bits %llu vs %llu, unpredictable %llu vs %llu)", (unsigned long long)h_small[SM_TOTAL_BITS],
+        FAIL_PUBLISHED(SZHIP_ERR_INTERNAL, "entropy stage mismatch (bits %llu vs %llu, unpredictable %llu vs %llu)", (unsigned long long)h_small[SM_TOTAL_BITS],
              (unsigned long long)total_bits, (unsigned long long)h_small[SM_TOTAL_UNPRED], (unsigned long long)total_unpred);
     float ms = 0;
     hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); S.ms_prequant = ms;
@@ -1702,7 +1717,7 @@ int compress14_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t
     {
         u64 tb = 0;
         if (total_bits > 0) { HIPCHK(hipMemcpy(&tb, sm + SM_TOTAL_BITS, 8, hipMemcpyDeviceToHost)); }
-        if (tb != total_bits) FAIL(SZHIP_ERR_INTERNAL, "encoded bit count mismatch (%llu vs %llu)", (unsigned long long)tb, (unsigned long long)total_bits);
+        if (tb != total_bits) FAIL_PUBLISHED(SZHIP_ERR_INTERNAL, "encoded bit count mismatch (%llu vs %llu)", (unsigned long long)tb, (unsigned long long)total_bits);
     }
     float ms = 0;
     hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); S.ms_prequant = ms;
@@ -2147,7 +2162,7 @@ int compress_fast_impl(szhip_ctx *ctx, const void *data, int data_on_device, siz
     }
     *out_size = total_len;
     if ((total_bits > 0 && h_small[SM_TOTAL_BITS] != total_bits) || h_small[SM_TOTAL_UNPRED] != nA || h_small[SM_SCRATCH] != nB)
-        FAIL(SZHIP_ERR_INTERNAL, "fast mode: entropy stage mismatch");
+        FAIL_PUBLISHED(SZHIP_ERR_INTERNAL, "fast mode: entropy stage mismatch");
     float ms = 0;
     hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); S.ms_quant = ms;
     hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]); S.ms_entropy = ms;

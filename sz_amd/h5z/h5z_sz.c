@@ -167,11 +167,18 @@ static size_t h5z_sz_filter(unsigned int flags, size_t cd_nelmts, const unsigned
     if (cd_nelmts == 0) return nbytes;
     const int with_err = checkCDValuesWithErrors(cd_nelmts, cd_values);
     if (with_err < 0) return 0;
+    /* the form with error bounds carries exactly nine words behind the dimensions: anything else would be read out of bounds below */
+    if (with_err && cd_nelmts != (size_t)words_of_dims((int)cd_values[0]) + 9) return 0;
+    if (!with_err && cd_nelmts < (size_t)words_of_dims((int)cd_values[0])) return 0;
     size_t r1, r2, r3, r4, r5;
     int dim, dataType, mode = 0;
     double abs_e = 0, rel_e = 0, pwr_e = 0, psnr = 0;
     if (with_err) SZ_cdArrayToMetaDataErr(cd_nelmts, cd_values, &dim, &dataType, &r5, &r4, &r3, &r2, &r1, &mode, &abs_e, &rel_e, &pwr_e, &psnr);
     else SZ_cdArrayToMetaData(cd_nelmts, cd_values, &dim, &dataType, &r5, &r4, &r3, &r2, &r1);
+    if (with_err && !(flags & H5Z_FLAG_REVERSE)) {                 /* bit patterns from a file: no NaN, infinite or negative bounds */
+        const double b[4] = {abs_e, rel_e, pwr_e, psnr};
+        for (int i = 0; i < 4; ++i) if (!(b[i] == b[i]) || b[i] < 0 || b[i] > 1.0e300) return 0;
+    }
     const size_t n = computeDataLength(r5, r4, r3, r2, r1);
     if (n < 20) return nbytes;                                     /* H5Z_SZ.c:566 */
     if (dataType != SZ_FLOAT && dataType != SZ_DOUBLE) return 0;
