@@ -64,13 +64,41 @@ def _mt_worker(args):
     return time.perf_counter() - t, len(s)
 
 
+def _time_reference(sample, cfg_path):
+    """oracle/_ref/libSZ.so (the unmodified reference, oracle/build_ref.sh) through its public C API: SZ_Init(config) once, then
+    SZ_compress_args on the sample, szMode = SZ_BEST_SPEED (the protocol of example/sz.c:355-375 without the file I/O)."""
+    import ctypes
+    so = os.path.join(ROOT, "oracle", "_ref", "libSZ.so")
+    if not os.path.exists(so):
+        return None
+    L = ctypes.CDLL(so)
+    szt = ctypes.c_size_t
+    L.SZ_Init.argtypes = [ctypes.c_char_p]
+    L.SZ_compress_args.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(szt), ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double] + [szt] * 5
+    L.SZ_compress_args.restype = ctypes.c_void_p
+    libc = ctypes.CDLL(None); libc.free.argtypes = [ctypes.c_void_p]
+    if L.SZ_Init(cfg_path.encode()) != 0:
+        return None
+    times, size = [], 0
+    for _ in range(3):
+        n = szt(0)
+        t1 = time.perf_counter()
+        p = L.SZ_compress_args(0, sample.ctypes.data, ctypes.byref(n), 0, EB, 0.0, 0.0, 0, 0, sample.shape[0], sample.shape[1], sample.shape[2])
+        times.append(time.perf_counter() - t1)
+        size = n.value
+        libc.free(p)
+    L.SZ_Finalize()
+    return float(np.median(times)), size
+
+
 def cpu_baselines(host, n, gpu_size):
-    """The oracle timed on the host cores of this box: pinned to one core (median of 3 passes over the whole array), and P
-    independent slabs in P processes (what the slab decomposition gives a multi-core CPU)."""
+    """The CPU beside the GPU number, on the host cores of this box, pinned to one core, median of 3 passes over the whole array:
+    the unmodified reference library (oracle/_ref, kind "reference") when it is there, and the oracle (its restatement, kind "port");
+    then P independent slabs in P processes (what the slab decomposition gives a multi-core CPU)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as O  # the checker, timed here as the CPU baseline ("port" of the reference loops)
+    import oracle_lib as O  # the checker, timed here as a CPU baseline ("port" of the reference loops)
     model, ncpu = cpu_info()
-    sample = host if n <= 512 else host[:512]
+    sample = np.ascontiguousarray(host if n <= 512 else host[:512])
     old = None
     try:
         old = os.sched_getaffinity(0)
@@ -82,16 +110,26 @@ def cpu_baselines(host, n, gpu_size):
         t1 = time.perf_counter()
         ref, _ = O.compress(sample, O.ABS, EB)
         times.append(time.perf_counter() - t1)
+    refrun = None
+    try:
+        refrun = _time_reference(sample, os.path.join(ROOT, "tests", "golden", "sz_speed.config"))
+    except Exception as e:  # noqa: BLE001 -- a baseline, not the product
+        refrun = None
     if old is not None:
         os.sched_setaffinity(0, old)
     tc = float(np.median(times))
-    one = {"value": round(sample.nbytes / tc / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
-           "sample": f"median of 3 compress passes over the full {sample.shape[0]}x{n}x{n} float32 S-field by oracle/liboracle.so, pinned to one "
-                     f"core ({tc:.2f} s per pass)",
-           "cpu_model": model, "nproc": ncpu, "stream_bytes": len(ref), "gpu_stream_identical": bool(len(ref) == gpu_size),
-           "note": "the port is the same loops restated type-generically with one strip buffer; the survey timed the unmodified reference "
-                   "binary at 0.10 GB/s on this array (SURVEY.md section 6, shared 8-core container), i.e. the port is about 2x faster "
-                   "than the reference itself"}
+    port = {"value": round(sample.nbytes / tc / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": f"median of 3 compress passes over the full {sample.shape[0]}x{n}x{n} float32 S-field by oracle/liboracle.so, pinned to one "
+                      f"core ({tc:.2f} s per pass)", "stream_bytes": len(ref), "gpu_stream_identical": bool(len(ref) == gpu_size)}
+    if refrun is not None:
+        tr, rsize = refrun
+        one = {"value": round(sample.nbytes / tr / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "reference",
+               "sample": f"median of 3 SZ_compress_args passes over the full {sample.shape[0]}x{n}x{n} float32 S-field by oracle/_ref/libSZ.so (the "
+                         f"unmodified reference, gcc -O3, szMode = SZ_BEST_SPEED), pinned to one core ({tr:.2f} s per pass)",
+               "cpu_model": model, "nproc": ncpu, "stream_bytes": int(rsize), "gpu_stream_identical": bool(rsize == gpu_size), "port": port}
+    else:
+        one = dict(port, cpu_model=model, nproc=ncpu,
+                   note="oracle/_ref/libSZ.so is not in the tree (oracle/build_ref.sh builds it where /root/reference exists): the port is timed")
     mt = None
     try:
         import multiprocessing as mp

@@ -34,9 +34,13 @@ def dims5(shape):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--lib", default="/tmp/szbuild/sz/libSZ.so")
+    ap.add_argument("--lib", default=os.path.join(ROOT, "oracle", "_ref", "libSZ.so"), help="the reference library: oracle/build_ref.sh builds it")
     ap.add_argument("--only", default=None)
+    ap.add_argument("--check", action="store_true", help="do not write: compare what the library gives with tests/golden/ref_recorded.json")
     args = ap.parse_args()
+    if not os.path.exists(args.lib):
+        import subprocess
+        subprocess.check_call(["bash", os.path.join(ROOT, "oracle", "build_ref.sh")])
     L = ctypes.CDLL(args.lib)
     sz = ctypes.c_size_t
     L.SZ_Init.argtypes = [ctypes.c_char_p]
@@ -53,8 +57,10 @@ def main():
     sdir = os.path.join(ROOT, "tests", "golden", "ref_streams")
     os.makedirs(sdir, exist_ok=True)
     rec = {}
-    if args.only and os.path.exists(out_path):
+    if (args.only or args.check) and os.path.exists(out_path):
         rec = json.load(open(out_path))["cases"]
+    old = dict(rec)
+    diffs = []
     with tempfile.TemporaryDirectory() as td:
         for c in ref_cases.CASES:
             if args.only and args.only not in c["name"]:
@@ -96,13 +102,27 @@ def main():
             L.SZ_Finalize()
             # point-wise-relative streams are kept too: their sign bytes went through the reference's bundled zstd, which the tests cannot redo
             if len(stream) <= 16384 or (wrapped or (len(stream) > 3 and stream[3] & 0x20)) and len(stream) <= 65536:
-                with open(os.path.join(sdir, c["name"] + ".sz"), "wb") as f:
-                    f.write(stream)
+                if not args.check:
+                    with open(os.path.join(sdir, c["name"] + ".sz"), "wb") as f:
+                        f.write(stream)
                 r["stream_file"] = "ref_streams/" + c["name"] + ".sz"
+            if args.check:
+                o = old.get(c["name"])
+                # a zstd / zlib frame around the stream carries the reference's uninitialised parameter byte 15 inside the frame: sizes and
+                # what decodes from it are compared there, not the frame's bytes
+                keys = ["shape", "dtype", "input_md5", "stream_bytes", "decoded_md5", "flags"] + ([] if wrapped else ["stream_md5"])
+                bad = [k for k in keys if o is None or o.get(k) != r.get(k)]
+                if bad:
+                    diffs.append((c["name"], bad))
+                continue
             rec[c["name"]] = r
             print(f"{c['name']:34s} {len(stream):9d} B  flags {r['flags']}  max err {r.get('max_abs_err', -1):.4g}  max rel {r.get('max_rel_err', -1):.4g}")
-    prov = ("Outputs of the UNMODIFIED reference (szcompressor/sz 2.1.12.4; the survey's Release build of /root/reference by the "
-            "reference's own CMake, gcc 11.4 x86-64: /tmp/szbuild/sz/libSZ.so, the build SURVEY.md section 6 quotes), recorded through its "
+    if args.check:
+        print("checked", len(ref_cases.CASES) if not args.only else "some", "cases against", out_path, ":", "identical" if not diffs else diffs)
+        sys.exit(1 if diffs else 0)
+    prov = ("Outputs of the UNMODIFIED reference (szcompressor/sz 2.1.12.4, /root/reference compiled where it lies by oracle/build_ref.sh: "
+            "one gcc -O3 line, baseline x86-64, vendored zstd and zlib; oracle/_ref/libSZ.so -- bit-identical to the reference's own CMake "
+            "Release build they were first recorded from, tools/record_reference_outputs.py --check), recorded through its "
             "public C API by tools/record_reference_outputs.py.  Inputs and sz.config keys of each case: tests/ref_cases.py.")
     json.dump({"_provenance": prov, "cases": rec}, open(out_path, "w"), indent=1, sort_keys=True)
     print("wrote", out_path, len(rec), "cases")

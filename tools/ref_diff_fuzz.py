@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """development, build container only: random differential run of the ORACLE against the unmodified reference library itself
-(/tmp/szbuild/sz/libSZ.so, the survey's build -- see tools/record_reference_outputs.py): random shapes (1-D .. 4-D), types, bound modes,
+(oracle/_ref/libSZ.so, built from /root/reference by oracle/build_ref.sh): random shapes (1-D .. 4-D), types, bound modes,
 sz.config knobs; streams compared byte for byte (byte 19 masked where the reference leaves it undefined; sign bytes of PW_REL streams
 compared decoded), decoded arrays bit for bit.  Nothing of this travels; what it finds becomes a recorded case in tests/ref_cases.py.
 
     python tools/ref_diff_fuzz.py [cases] [seed] [product]
 product: the PRODUCT code (host C + HIP layer on the CPU shim of tests/sim, reading the same sz.config file) instead of the oracle"""
-import ctypes, hashlib, os, sys, tempfile
+import ctypes
+import os, hashlib, os, sys, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -15,7 +16,7 @@ import ref_cases
 import test_ref_recorded as T
 from sz_amd.fields import l_field, s_field
 
-L = ctypes.CDLL("/tmp/szbuild/sz/libSZ.so")
+L = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libSZ.so"))
 sz = ctypes.c_size_t
 L.SZ_Init.argtypes = [ctypes.c_char_p]
 L.SZ_compress_args.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(sz), ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double] + [sz] * 5
