@@ -151,6 +151,11 @@ def cpu_baselines(host, n, gpu_size):
     return one, mt
 
 
+def _sync(torch):
+    if torch.cuda.is_available():
+        _sync(torch)
+
+
 def run_headline(args, torch, dist, world, rank, local_rank, dev):
     import ctypes
     import sz_amd
@@ -162,7 +167,7 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
     host = s_field(n, n, n, np.float32, z0=rank * n)
     x = torch.from_numpy(host).to(dev)
     nbytes_in = host.nbytes
-    ctx = sz_amd.HipContext(local_rank)
+    ctx = sz_amd.HipContext(0 if getattr(args, "dry_run", False) else local_rank)     # (the CPU shim of --dry-run has one "device")
     out_cap = nbytes_in // 2 + (1 << 20)
     out_bufs = [torch.empty(out_cap, dtype=torch.uint8, device=dev) for _ in range(2)]   # alternate: a gather may still read the other
     gather = slab.StreamGather() if world > 1 else None
@@ -198,10 +203,10 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
             gather.end(pending.pop(0))
 
     def sync_all():
-        torch.cuda.synchronize()
+        _sync(torch)
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        _sync(torch)
 
     for _ in range(args.warmup):
         one_step()
@@ -230,10 +235,10 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
     mse = float((err * err).double().sum().item()) / x.numel()
     psnr = 20 * np.log10(float((x.max() - x.min()).item())) - 10 * np.log10(mse)
     del err
-    torch.cuda.synchronize(); td = time.perf_counter()
+    _sync(torch); td = time.perf_counter()
     for _ in range(3):
         ctx.decompress(ob.data_ptr(), True, size, 4 + 28 + 8, (n, n, n), np.float32, dec.data_ptr(), True)
-    torch.cuda.synchronize(); td = (time.perf_counter() - td) / 3
+    _sync(torch); td = (time.perf_counter() - td) / 3
 
     if rank != 0:
         if world > 1:
@@ -241,7 +246,7 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
         return
 
     quant_avg_ms = float(np.mean(quant_ms))
-    achieved = nbytes_in / (quant_avg_ms * 1e-3) / 1e9
+    achieved = nbytes_in / (quant_avg_ms * 1e-3) / 1e9 if quant_avg_ms > 0 else 0.0     # (the CPU shim of --dry-run has no device events)
     # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside the timed process);
     # only valid for the workload it was measured on
     traffic, traffic_src = None, None
@@ -267,9 +272,9 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
         msteps = max(3, min(args.steps, 5))
         tms = []
         for _ in range(msteps):                                   # each step timed on its own (7 ms: the sync is negligible); median reported
-            torch.cuda.synchronize(); t1 = time.perf_counter()
+            _sync(torch); t1 = time.perf_counter()
             msize, mst, mob = one_step(xm)
-            torch.cuda.synchronize(); tms.append(time.perf_counter() - t1)
+            _sync(torch); tms.append(time.perf_counter() - t1)
         tm = float(np.median(tms))
         mdec = torch.empty_like(xm)
         ctx.decompress(mob.data_ptr(), True, msize, 4 + 28 + 8, (n, n, n), np.float32, mdec.data_ptr(), True)
@@ -285,18 +290,18 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
         fob = out_bufs[0]
         for _ in range(2):
             ctx.compress_fast(x.data_ptr(), True, (n, n, n), np.float32, EB, 0, fob.data_ptr(), out_cap)
-        torch.cuda.synchronize(); tf = time.perf_counter()
+        _sync(torch); tf = time.perf_counter()
         fq = []
         for _ in range(args.steps):
             _, fsize, fst = ctx.compress_fast(x.data_ptr(), True, (n, n, n), np.float32, EB, 0, fob.data_ptr(), out_cap)
             fq.append(fst.ms_quant)
-        torch.cuda.synchronize(); tf = (time.perf_counter() - tf) / args.steps
+        _sync(torch); tf = (time.perf_counter() - tf) / args.steps
         fdst = ctx.decompress_fast(fob.data_ptr(), True, fsize, (n, n, n), np.float32, dec.data_ptr(), True)
         ferr = float((dec - x).abs().max().item())
-        torch.cuda.synchronize(); tfd = time.perf_counter()
+        _sync(torch); tfd = time.perf_counter()
         for _ in range(3):
             ctx.decompress_fast(fob.data_ptr(), True, fsize, (n, n, n), np.float32, dec.data_ptr(), True)
-        torch.cuda.synchronize(); tfd = (time.perf_counter() - tfd) / 3
+        _sync(torch); tfd = (time.perf_counter() - tfd) / 3
         fq_ms = float(np.mean(fq))
         falg = nbytes_in + 2 * x.numel()
         fast = {"mode": "SZ_HIP_MODE=fast (szhip_compress_fast): q = rint(x/2eb), integer Lorenzo on q, same Huffman stage; container 'SZHF', "
@@ -317,10 +322,10 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
     other = None
     if args.other_paths and world == 1 and n == EDGE:
         def timed(fn, reps=3):
-            fn(); torch.cuda.synchronize(); t = time.perf_counter()
+            fn(); _sync(torch); t = time.perf_counter()
             for _ in range(reps):
                 r = fn()
-            torch.cuda.synchronize()
+            _sync(torch)
             return (time.perf_counter() - t) / reps, r
 
         def run(fn_name, ptr, dims, extra, mbytes, eb=EB):
@@ -424,7 +429,7 @@ def run_c4(args, torch, dist, world, rank, local_rank, dev):
     host = s_field(planes, N, N, np.float64, z0=z0)
     x = torch.from_numpy(host).to(dev)
     nbytes_in = host.nbytes
-    ctx = sz_amd.HipContext(local_rank)
+    ctx = sz_amd.HipContext(0 if getattr(args, "dry_run", False) else local_rank)     # (the CPU shim of --dry-run has one "device")
     out_cap = nbytes_in // 2 + (1 << 20)
     out_bufs = [torch.empty(out_cap, dtype=torch.uint8, device=dev) for _ in range(2)]
     gather = slab.StreamGather() if world > 1 else None
@@ -451,10 +456,10 @@ def run_c4(args, torch, dist, world, rank, local_rank, dev):
         return nn.value, st, ob
 
     def sync_all():
-        torch.cuda.synchronize()
+        _sync(torch)
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        _sync(torch)
 
     for _ in range(args.warmup):
         one_step()
@@ -473,9 +478,9 @@ def run_c4(args, torch, dist, world, rank, local_rank, dev):
     eb = eb_box[0]
     dec = torch.empty_like(x)
     src = ob if parts is None else parts[0][rank].contiguous()
-    torch.cuda.synchronize(); td = time.perf_counter()
+    _sync(torch); td = time.perf_counter()
     ctx.decompress(src.data_ptr(), True, size, 4 + 36 + 8, (planes, N, N), np.float64, dec.data_ptr(), True)
-    torch.cuda.synchronize(); td = time.perf_counter() - td
+    _sync(torch); td = time.perf_counter() - td
     max_err = float((dec - x).abs().max().item())
     stats_t = torch.tensor([elapsed, max_err, float(size), td], dtype=torch.float64, device=dev)
     if world > 1:
@@ -513,6 +518,7 @@ def main():
     ap.add_argument("--other-paths", action="store_true", help="also time the SZ 1.4 container, a 2-D array and a 1-D series (one line each)")
     ap.add_argument("--no-fast", action="store_true", help="skip the opt-in fast-mode object")
     ap.add_argument("--no-m-field", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the entry on gloo + the HIP-on-CPU shim (tests only)")
     args = ap.parse_args()
 
     import torch
@@ -521,8 +527,29 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if args.gpus > 1 and world == 1:
+        # `python bench.py --gpus N` (the shape of the N = 1 command): start the N ranks here, one per GPU, exactly as
+        # `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...` would
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+    if args.dry_run:
+        # CPU rehearsal of the multi-rank entry (tests/test_distributed_cpu.py): gloo + the product's code on the HIP-on-CPU shim, tiny
+        # arrays, no GPU.  Nothing it prints is a measurement.
+        if not os.environ.get("SZ_AMD_LIB"):
+            raise SystemExit("--dry-run needs SZ_AMD_LIB = tests/sim/libszhip_sim.so")
+        dev = torch.device("cpu")
+        args.no_cpu_baseline = args.no_fast = args.no_m_field = True
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        run_headline(args, torch, dist, world, rank, local_rank, dev)
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU fallback)")
     torch.cuda.set_device(local_rank)

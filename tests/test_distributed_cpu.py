@@ -130,3 +130,73 @@ def test_config4_flow_world2_on_the_product_code_path(oracle):
         assert abs(eb - 1e-3 * (float(whole.max()) - float(whole.min()))) < 1e-15
         ref, _ = oracle.compress(whole[z0:z1], oracle.ABS, eb)      # each sub-stream is the reference's stream for that slab
         assert stream == ref
+
+
+def test_c_slab_container_equals_the_python_one_and_round_trips(oracle):
+    """include/sz_slab.h on the product's code (HIP layer on the CPU shim): the container a C caller gets from sz_slab_compress is, byte
+    for byte, what sz_amd/slab.py packs from the per-slab SZ_compress_args streams; sz_slab_decompress reads it back within the bound."""
+    import ctypes
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import sim_lib
+    import sz_amd
+    from sz_amd import api, slab
+    from sz_amd.fields import s_field
+    saved = api._lib
+    try:
+        L = ctypes.CDLL(sim_lib.shim_path())
+        api._lib = api._bind(L)
+        assert sz_amd.SZ_Init(os.path.join(ROOT, "tests", "golden", "sz_speed.config")) == 0
+        szt = ctypes.c_size_t
+        L.sz_slab_compress.restype = ctypes.c_void_p
+        L.sz_slab_compress.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(szt), ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, szt, szt, szt, ctypes.c_int]
+        L.sz_slab_decompress.restype = ctypes.c_void_p
+        L.sz_slab_decompress.argtypes = [ctypes.c_void_p, szt, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(szt * 3)]
+        L.sz_slab_bounds.argtypes = [szt, ctypes.c_int, ctypes.c_int, ctypes.POINTER(szt)]
+        libc = ctypes.CDLL(None); libc.free.argtypes = [ctypes.c_void_p]
+        for (n0, world, dt, mode, absb, rel) in ((38, 3, np.float32, sz_amd.ABS, 1e-3, 0.0), (25, 2, np.float64, sz_amd.REL, 0.0, 1e-3), (7, 4, np.float32, sz_amd.ABS, 1e-2, 0.0)):
+            whole = s_field(n0, 21, 40, dt)
+            bb = (szt * (2 * world))()
+            L.sz_slab_bounds(n0, world, 6, bb)
+            bounds = [(int(bb[2 * r]), int(bb[2 * r + 1])) for r in range(world)]
+            assert bounds == slab.slab_bounds(n0, world)
+            eb = absb if mode == sz_amd.ABS else rel * float(whole.max() - whole.min())
+            streams = [sz_amd.SZ_compress_args(np.ascontiguousarray(whole[z0:z1]), sz_amd.ABS, eb) if z1 > z0 else b"" for z0, z1 in bounds]
+            for (z0, z1), st in zip(bounds, streams):        # every sub-stream is the reference's stream of that slab
+                if z1 > z0:
+                    assert st == oracle.compress(np.ascontiguousarray(whole[z0:z1]), oracle.ABS, eb)[0]
+            want = slab.pack_container(dt, whole.shape, bounds, streams)
+            n = szt(0)
+            p = L.sz_slab_compress(0 if dt == np.float32 else 1, whole.ctypes.data, ctypes.byref(n), mode, absb, rel, 0.0, *whole.shape, world)
+            assert p
+            got = ctypes.string_at(p, n.value)
+            libc.free(p)
+            assert got == want
+            dtc = ctypes.c_int(-1); dims = (szt * 3)()
+            q = L.sz_slab_decompress(got, len(got), ctypes.byref(dtc), ctypes.byref(dims))
+            assert q and tuple(dims) == whole.shape and dtc.value == (0 if dt == np.float32 else 1)
+            back = np.ctypeslib.as_array(ctypes.cast(q, ctypes.POINTER(ctypes.c_float if dt == np.float32 else ctypes.c_double)), shape=(whole.size,)).copy().reshape(whole.shape)
+            libc.free(q)
+            assert float(np.abs(back.astype(np.float64) - whole).max()) <= eb
+            assert L.sz_slab_decompress(got[:50], 50, ctypes.byref(dtc), ctypes.byref(dims)) is None     # a truncated container is refused
+        sz_amd.SZ_Finalize()
+    finally:
+        api._lib = saved
+
+
+@pytest.mark.slow
+def test_bench_entry_starts_its_own_ranks_for_gpus_gt_1():
+    """`python bench.py --gpus 2 ...` -- the shape of the driver's N = 1 command -- must start the two ranks itself and print ONE JSON
+    line with n_gpus = 2.  Rehearsed on the CPU: gloo + the product's code on the HIP-on-CPU shim (--dry-run), tiny arrays."""
+    import json
+    import subprocess
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import sim_lib
+    env = dict(os.environ, SZ_AMD_LIB=sim_lib.shim_path())
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run", "--edge", "24"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["out_bytes"] > 0

@@ -38,6 +38,12 @@ def test_library_exports_every_declared_symbol(L):
     assert len(rw) >= 4
     for n in sorted(rw):
         assert hasattr(L, n), f"{n} is declared in rw.h but not exported"
+    # include/sz_slab.h: the slab container of the multi-GPU path for C callers
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "sz_slab.h")).read(), flags=re.S)
+    sl = set(re.findall(r"\b(sz_slab_[A-Za-z0-9_]+)\s*\(", text))
+    assert len(sl) == 5
+    for n in sorted(sl):
+        assert hasattr(L, n), f"{n} is declared in sz_slab.h but not exported"
 
 
 def test_hdf5_plugin_exports_every_declared_symbol(built):
