@@ -153,7 +153,7 @@ def cpu_baselines(host, n, gpu_size):
 
 def _sync(torch):
     if torch.cuda.is_available():
-        _sync(torch)
+        torch.cuda.synchronize()
 
 
 def run_headline(args, torch, dist, world, rank, local_rank, dev):
@@ -208,18 +208,44 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
             dist.barrier()
         _sync(torch)
 
-    for _ in range(args.warmup):
-        one_step()
-    drain()
-    sync_all()
-    t0 = time.perf_counter()
-    quant_ms, stats, size, ob = [], None, 0, None
-    for _ in range(args.steps):
-        size, stats, ob = one_step()
-        quant_ms.append(stats.ms_quant)
-    drain()
-    sync_all()
-    elapsed = time.perf_counter() - t0
+    # ---- the timed region: EXACTLY args.steps full compressions of the array, `inflight` of them in flight on this GPU at a time
+    # (szhip_pool: one context + one host thread per lane; the passes around one array's sweep run beside the sweep of the next).
+    # Every call is a complete szhip_compress of the same input into its own output buffer; the streams are byte-identical.
+    inflight = max(1, args.inflight)
+    pool_bufs = [torch.empty(out_cap, dtype=torch.uint8, device=dev) for _ in range(inflight + 1)]
+    pools = {}
+
+    def run_steps(k_lanes, nsteps, gather_too):
+        """nsteps compressions with k_lanes in flight; returns (elapsed, per-call stats, (size, buffer) of the last call)."""
+        if k_lanes not in pools:
+            pools[k_lanes] = sz_amd.HipPool(0 if getattr(args, "dry_run", False) else local_rank, k_lanes)
+        pool = pools[k_lanes]
+        meta = sz_amd.make_meta(np.float32, err_mode=sz_amd.ABS, abs_bound=EB, vmin=0.0, vmax=0.0)
+        prm = sz_amd.szhip_params(100, 0.99, 65536, 0, 1)
+        sync_all()
+        t_begin = time.perf_counter()
+        live, stats_all, last = [], [], None
+        for i in range(nsteps + k_lanes):
+            if i >= k_lanes or i >= nsteps:                 # collect the oldest call (also drains the tail)
+                if live:
+                    tk, ob_ = live.pop(0)
+                    sz_, st_ = pool.wait(tk)
+                    stats_all.append(st_); last = (sz_, ob_)
+                    if gather_too and world > 1:
+                        pending.append(gather.begin(ob_, sz_))
+                        if len(pending) > 1:
+                            gather.end(pending.pop(0))
+            if i < nsteps:
+                ob_ = pool_bufs[i % (k_lanes + 1)] if k_lanes + 1 <= len(pool_bufs) else pool_bufs[i % len(pool_bufs)]
+                live.append((pool.submit(x.data_ptr(), True, (n, n, n), np.float32, EB, meta, prm, ob_.data_ptr(), out_cap), ob_))
+        drain()
+        sync_all()
+        return time.perf_counter() - t_begin, stats_all, last
+
+    run_steps(inflight, max(args.warmup, inflight), True)
+    elapsed, stats_all, (size, ob) = run_steps(inflight, args.steps, True)
+    quant_ms = [st.ms_quant for st in stats_all]
+    stats = stats_all[-1]
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -259,9 +285,32 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
                 break
         except (OSError, KeyError, ValueError):
             pass
-    roofline = {"bound": "hbm", "kernel": "k_pencil<float,false>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    kname = "k_ribbon<float,false,false>" if getattr(stats, "quant_kernel", 0) == 1 else "k_pencil<float,false>"
+    roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": nbytes_in, "avg_kernel_ms": round(quant_avg_ms, 4)}
+
+    # ---- arrays in flight: the same args.steps compressions with 1 / 2 / 4 lanes (outside the timed region), with the sweep kernel's own
+    # time per K so that interference is visible; and every stream of the last run against the one a single blocking call gives
+    concurrent = None
+    if world == 1 and not getattr(args, "dry_run", False):
+        ref_size, _, ref_ob = one_step()
+        _sync(torch)
+        ref_bytes = ref_ob[:ref_size].clone()
+        concurrent = {"what": "szhip_pool: K contexts + host threads on this GPU, K full szhip_compress calls of the same array in flight; "
+                              "GB/s over args.steps calls; quant_ms = average duration of the predict+quantise kernel inside those calls", "K": {}}
+        for K in (1, 2, 4):
+            if K + 1 > len(pool_bufs):
+                pool_bufs.extend(torch.empty(out_cap, dtype=torch.uint8, device=dev) for _ in range(K + 1 - len(pool_bufs)))
+            run_steps(K, max(2, K), False)
+            el, sts, _ = run_steps(K, args.steps, False)
+            same = all(bool(torch.equal(pool_bufs[i][:ref_size], ref_bytes)) for i in range(min(K + 1, args.steps)))
+            concurrent["K"][str(K)] = {"GB/s": round(nbytes_in / (el / args.steps) / 1e9, 2), "ms_per_array": round(el / args.steps * 1e3, 4),
+                                       "quant_ms": round(float(np.mean([t.ms_quant for t in sts])), 4),
+                                       "prequant_ms": round(float(np.mean([t.ms_prequant for t in sts])), 4),
+                                       "entropy_ms": round(float(np.mean([t.ms_entropy for t in sts])), 4), "streams_identical": same}
+        concurrent["timed_region_lanes"] = inflight
+        del ref_bytes
 
     # ---- BASELINE configs[2]: the adaptive case proper -- 512^3 M-field, half of the blocks regression (single GPU, outside the timed region)
     mfield = None
@@ -401,15 +450,16 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{n}x{n}x{n} float32 S-field (smooth sinusoid) per GPU, ABS 1e-4, SZ 2.1 path with adaptive Lorenzo+regression "
                                    "selection per block (on this field every block chooses Lorenzo; m_field is the mixed case), stream "
-                                   "bit-identical to the reference; value-range reduction included in the step (fused into the fit pass); input and output resident in HBM",
-                       "error_bound_mode": "ABS", "abs_err_bound": EB, "slabs": world},
+                                   "bit-identical to the reference; value-range reduction included in the step (fused into the fit pass); input and output resident in HBM; "
+                                   f"{inflight} compressions of the array in flight per GPU (szhip_pool, one context per lane; `concurrent` gives 1 / 2 / 4)",
+                       "error_bound_mode": "ABS", "abs_err_bound": EB, "slabs": world, "arrays_in_flight": inflight},
             "ratio": round(nbytes_in / size, 6), "out_bytes": size, "max_abs_err": max_abs_err, "psnr": round(psnr, 6),
             "intervals": stats.intervals, "reg_blocks": stats.n_reg_blocks, "unpredictable": stats.n_unpred,
             "decompress_GBps": round(nbytes_in / td / 1e9, 3),
             "phase_ms": {"caller_glue": round(ms_per_step - stats.ms_total, 3), "prequant": round(stats.ms_prequant, 3), "quant": round(stats.ms_quant, 3),
                          "entropy": round(stats.ms_entropy, 3), "host_glue": round(stats.ms_host, 3), "compress_call_total": round(stats.ms_total, 3),
                          "decompress_quant": round(dst.ms_quant, 3), "decompress_total": round(dst.ms_total, 3)},
-            "roofline": roofline, "m_field": mfield, "fast_mode": fast, "other_paths": other, "e2e": e2e, "cpu_baseline": cpu, "cpu_baseline_mt": cpu_mt}
+            "roofline": roofline, "concurrent": concurrent, "m_field": mfield, "fast_mode": fast, "other_paths": other, "e2e": e2e, "cpu_baseline": cpu, "cpu_baseline_mt": cpu_mt}
     print(json.dumps(line))
     if world > 1:
         dist.barrier(); dist.destroy_process_group()
@@ -519,6 +569,7 @@ def main():
     ap.add_argument("--no-fast", action="store_true", help="skip the opt-in fast-mode object")
     ap.add_argument("--no-m-field", action="store_true")
     ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the entry on gloo + the HIP-on-CPU shim (tests only)")
+    ap.add_argument("--inflight", type=int, default=2, help="arrays in flight per GPU in the timed region (szhip_pool lanes); 1 = one blocking call after the other")
     args = ap.parse_args()
 
     import torch
@@ -545,6 +596,7 @@ def main():
             raise SystemExit("--dry-run needs SZ_AMD_LIB = tests/sim/libszhip_sim.so")
         dev = torch.device("cpu")
         args.no_cpu_baseline = args.no_fast = args.no_m_field = True
+        args.inflight = 1                      # (the shim executes one launch at a time)
         if world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group("gloo", rank=rank, world_size=world)

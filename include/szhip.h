@@ -70,6 +70,21 @@ typedef struct szhip_stats {
 } szhip_stats;
 
 int  szhip_create(szhip_ctx **ctx, int device);
+/* ---- several arrays in flight on one GPU (additive; the reference's API is one blocking call per array, sz/src/sz.c:294-391).
+ * The predict+quantise sweep is bound by its dependency chain, not by the chip: the passes in front of it (fit, sampling) and
+ * behind it (block ordering, histogram, Huffman packing) of one array fit beside the sweep of another.  A pool owns `lanes`
+ * contexts and as many host threads; szhip_pool_submit queues one szhip_compress call (same arguments, which must stay valid
+ * until the wait returns) and returns a ticket at once; szhip_pool_wait blocks until that call has finished and hands out what
+ * szhip_compress would have returned.  Streams are byte for byte those of szhip_compress.  HDF5 chunks (one SZ call per chunk,
+ * hdf5-filter/H5Z-SZ/src/H5Z_SZ.c:542-828) and time steps are the natural users. */
+typedef struct szhip_pool szhip_pool;
+int  szhip_pool_create(szhip_pool **pool, int device, int lanes);
+void szhip_pool_destroy(szhip_pool *pool);
+int  szhip_pool_submit(szhip_pool *pool, int dtype, const void *data, int data_on_device, size_t r0, size_t r1, size_t r2, double eb,
+                       const szhip_params *params, const unsigned char *meta, size_t meta_len, int out_on_device,
+                       unsigned char *out_buf, size_t out_cap, int *ticket);      /* out_on_device 2: into out_buf (capacity out_cap) */
+int  szhip_pool_wait(szhip_pool *pool, int ticket, unsigned char **out, size_t *out_size, szhip_stats *stats);   /* the call's return code */
+
 void szhip_destroy(szhip_ctx *ctx);
 const char *szhip_last_error(szhip_ctx *ctx);
 

@@ -12,5 +12,5 @@ from .api import (  # noqa: F401
     SZ_SCES, SZ_NSCS, sz_params, szhip_stats, szhip_params,
     lib, lib_path, build_library, SZError,
     SZ_Init, SZ_Init_Params, SZ_Finalize, SZ_compress, SZ_compress_args, SZ_decompress, SZ_hip_last_stats,
-    conf_params, HipContext, make_meta,
+    conf_params, HipContext, HipPool, make_meta,
 )

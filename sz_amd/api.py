@@ -111,6 +111,14 @@ def _bind(L):
                                  ctypes.POINTER(szhip_params), ctypes.c_char_p, sz, ctypes.c_int,
                                  ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(sz), ctypes.POINTER(szhip_stats)]
     L.szhip_compress.restype = ctypes.c_int
+    if hasattr(L, "szhip_pool_create"):
+        L.szhip_pool_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int]; L.szhip_pool_create.restype = ctypes.c_int
+        L.szhip_pool_destroy.argtypes = [ctypes.c_void_p]; L.szhip_pool_destroy.restype = None
+        L.szhip_pool_submit.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, sz, sz, sz, ctypes.c_double,
+                                        ctypes.POINTER(szhip_params), ctypes.c_char_p, sz, ctypes.c_int, ctypes.c_void_p, sz, ctypes.POINTER(ctypes.c_int)]
+        L.szhip_pool_submit.restype = ctypes.c_int
+        L.szhip_pool_wait.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(sz), ctypes.POINTER(szhip_stats)]
+        L.szhip_pool_wait.restype = ctypes.c_int
     L.szhip_decompress.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, sz, sz, sz, sz, sz,
                                    ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(szhip_stats)]
     L.szhip_decompress.restype = ctypes.c_int
@@ -227,6 +235,50 @@ def make_meta(dtype, err_mode=ABS, abs_bound=0.0, rel_ratio=0.0, vmin=0.0, vmax=
     flags = 0x80 | 0x40 | (0x04 if protect_value_range else 0)
     n = lib().szhost_write_meta(ctypes.byref(m), flags, buf)
     return buf.raw[:n]
+
+
+class HipPool:
+    """szhip_pool (include/szhip.h): `lanes` contexts and host threads on one GPU; submit() queues one szhip_compress call and returns
+    a ticket, wait() blocks for it.  The arguments of a call (input, parameter bytes, output buffer) must stay alive until its wait()."""
+
+    def __init__(self, device=0, lanes=2):
+        self._h = ctypes.c_void_p()
+        self.lanes = lanes
+        rc = lib().szhip_pool_create(ctypes.byref(self._h), device, lanes)
+        if rc != 0:
+            raise SZError(f"szhip_pool_create failed ({rc})")
+        self._keep = {}
+
+    def close(self):
+        if self._h:
+            lib().szhip_pool_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def submit(self, ptr, on_device, shape3, dtype, eb, meta, params, out_ptr, out_cap):
+        """Stream into the caller's device buffer (out_ptr, out_cap).  Returns the ticket."""
+        t = ctypes.c_int(-1)
+        p = params or szhip_params(100, 0.99, 65536, 0)
+        rc = lib().szhip_pool_submit(self._h, 0 if np.dtype(dtype) == np.float32 else 1, ptr, int(on_device), shape3[0], shape3[1], shape3[2], eb,
+                                     ctypes.byref(p), meta, len(meta), 2, out_ptr, out_cap, ctypes.byref(t))
+        if rc != 0:
+            raise SZError(f"szhip_pool_submit failed ({rc})")
+        self._keep[t.value] = (p, meta)
+        return t.value
+
+    def wait(self, ticket):
+        """Returns (size, stats); raises if the call failed."""
+        out = ctypes.c_void_p(); n = ctypes.c_size_t(0); st = szhip_stats()
+        rc = lib().szhip_pool_wait(self._h, ticket, ctypes.byref(out), ctypes.byref(n), ctypes.byref(st))
+        self._keep.pop(ticket, None)
+        if rc != 0:
+            raise SZError(f"pooled szhip_compress failed ({rc})")
+        return n.value, st
 
 
 class HipContext:

@@ -10,7 +10,10 @@
 #include <atomic>
 #include <chrono>
 #include <ctime>
+#include <condition_variable>
+#include <deque>
 #include <future>
+#include <mutex>
 #include <thread>
 #include <vector>
 #include "../../include/szhip.h"
@@ -2364,6 +2367,97 @@ void szhip_destroy(szhip_ctx *ctx)
 }
 
 const char *szhip_last_error(szhip_ctx *ctx) { return ctx ? ctx->err : "no context"; }
+
+// ---- several arrays in flight (szhip.h): `lanes` contexts, one host thread each, one queue
+struct szhip_pool_job {
+    int dtype; const void *data; int on_dev; size_t r0, r1, r2; double eb; szhip_params prm; const unsigned char *meta; size_t meta_len;
+    int out_on_device; unsigned char *out; size_t out_size; szhip_stats stats; int rc; bool done;
+};
+struct szhip_pool {
+    std::vector<szhip_ctx *> ctx;
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::deque<int> queue;                      // tickets waiting for a lane
+    std::vector<szhip_pool_job> jobs;           // ring of tickets
+    std::vector<bool> used;
+    bool stop = false;
+};
+static void szhip_pool_worker(szhip_pool *p, int lane)
+{
+    for (;;) {
+        int t;
+        {
+            std::unique_lock<std::mutex> lk(p->mu);
+            p->cv_work.wait(lk, [&] { return p->stop || !p->queue.empty(); });
+            if (p->queue.empty()) return;
+            t = p->queue.front(); p->queue.pop_front();
+        }
+        szhip_pool_job &j = p->jobs[t];
+        j.rc = szhip_compress(p->ctx[lane], j.dtype, j.data, j.on_dev, j.r0, j.r1, j.r2, j.eb, &j.prm, j.meta, j.meta_len, j.out_on_device,
+                              &j.out, &j.out_size, &j.stats);
+        { std::lock_guard<std::mutex> lk(p->mu); j.done = true; }
+        p->cv_done.notify_all();
+    }
+}
+int szhip_pool_create(szhip_pool **out, int device, int lanes)
+{
+    if (!out || lanes < 1 || lanes > 16) return SZHIP_ERR_ARG;
+    szhip_pool *p = new szhip_pool();
+    for (int i = 0; i < lanes; ++i) {
+        szhip_ctx *c = nullptr;
+        const int rc = szhip_create(&c, device);
+        if (rc != SZHIP_OK) { for (szhip_ctx *x : p->ctx) szhip_destroy(x); delete p; return rc; }
+        p->ctx.push_back(c);
+    }
+    p->jobs.resize(64); p->used.assign(64, false);
+    for (int i = 0; i < lanes; ++i) p->workers.emplace_back(szhip_pool_worker, p, i);
+    *out = p;
+    return SZHIP_OK;
+}
+void szhip_pool_destroy(szhip_pool *p)
+{
+    if (!p) return;
+    { std::lock_guard<std::mutex> lk(p->mu); p->stop = true; }
+    p->cv_work.notify_all();
+    for (auto &w : p->workers) if (w.joinable()) w.join();
+    for (szhip_ctx *c : p->ctx) szhip_destroy(c);
+    delete p;
+}
+int szhip_pool_submit(szhip_pool *p, int dtype, const void *data, int data_on_device, size_t r0, size_t r1, size_t r2, double eb,
+                      const szhip_params *params, const unsigned char *meta, size_t meta_len, int out_on_device,
+                      unsigned char *out_buf, size_t out_cap, int *ticket)
+{
+    if (!p || !data || !params || !meta || !ticket) return SZHIP_ERR_ARG;
+    std::lock_guard<std::mutex> lk(p->mu);
+    int t = -1;
+    for (size_t i = 0; i < p->used.size(); ++i) if (!p->used[i]) { t = (int)i; break; }
+    if (t < 0) return SZHIP_ERR_ARG;                         // 64 calls waiting to be collected: wait for some first
+    szhip_pool_job &j = p->jobs[t];
+    j = szhip_pool_job();
+    j.dtype = dtype; j.data = data; j.on_dev = data_on_device; j.r0 = r0; j.r1 = r1; j.r2 = r2; j.eb = eb; j.prm = *params;
+    j.meta = meta; j.meta_len = meta_len; j.out_on_device = out_on_device; j.out = out_on_device == 2 ? out_buf : nullptr;
+    j.out_size = out_on_device == 2 ? out_cap : 0; j.rc = SZHIP_ERR_INTERNAL; j.done = false;
+    p->used[t] = true;
+    p->queue.push_back(t);
+    *ticket = t;
+    p->cv_work.notify_one();
+    return SZHIP_OK;
+}
+int szhip_pool_wait(szhip_pool *p, int ticket, unsigned char **out, size_t *out_size, szhip_stats *stats)
+{
+    if (!p || ticket < 0 || ticket >= (int)p->jobs.size()) return SZHIP_ERR_ARG;
+    std::unique_lock<std::mutex> lk(p->mu);
+    if (!p->used[ticket]) return SZHIP_ERR_ARG;
+    p->cv_done.wait(lk, [&] { return p->jobs[ticket].done; });
+    szhip_pool_job &j = p->jobs[ticket];
+    if (out) *out = j.out;
+    if (out_size) *out_size = j.out_size;
+    if (stats) *stats = j.stats;
+    p->used[ticket] = false;
+    return j.rc;
+}
+
 
 int szhip_stage_input(szhip_ctx *ctx, const void *host_data, size_t bytes, void **device_ptr)
 {
