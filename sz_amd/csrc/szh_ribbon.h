@@ -50,9 +50,18 @@ template <class T> struct szh_rb_shape;
 // R rows per lane, W compute wavefronts per tile; ring lengths (steps): RL between wavefronts of a tile, RLU the up ring of wavefront 0
 // (filled from granules: bursty), RLL the left rings (the left tile runs >= 64 steps ahead), RLR the right rings; U steps per trip (a
 // trip's inputs sit in registers: 2 x R x U values).  RL >= 2 U: a wavefront checks the ring space of a whole trip at its top
-template <> struct szh_rb_shape<float> { static constexpr int R = SZH_RB_R_F32, W = SZH_RB_W_F32, U = 16, RL = 32, RLU = 64, RLL = 128, RLR = 32; };
+#ifndef SZH_RB_RL_F32
+#define SZH_RB_RL_F32 32
+#endif
+template <> struct szh_rb_shape<float> { static constexpr int R = SZH_RB_R_F32, W = SZH_RB_W_F32, U = 16, RL = SZH_RB_RL_F32, RLU = 64, RLL = 128, RLR = 32; };
 template <> struct szh_rb_shape<double> { static constexpr int R = SZH_RB_R_F64, W = SZH_RB_W_F64, U = 8, RL = 16, RLU = 32, RLL = 128, RLR = 32; };
 #define SZH_RB_INF (1 << 30)
+#ifndef SZH_RB_KD
+#define SZH_RB_KD 4            /* DRAIN: steps per face and round */
+#endif
+#ifndef SZH_RB_DRAIN_NAP
+#define SZH_RB_DRAIN_NAP 2     /* DRAIN: s_sleep units between rounds */
+#endif
 
 // number of (shifted) steps every wavefront of a launch runs, a multiple of the trip length
 SZH_HD int szh_rb_steps(int r2, int R, int W, int U) { return (r2 + 62 + R + (W - 1) * (R - 1) + U - 1) / U * U; }
@@ -556,7 +565,7 @@ template <class T>
 __device__ __forceinline__ void drain(const szh_qargs<T> &a, int TI, int TJ, const lds_t<T> &L)
 {
     using S = szh_rb_shape<T>;
-    constexpr int W = S::W, R = S::R, WR = W * R, NW = szh_gran<T>::NW, KD = 4;
+    constexpr int W = S::W, R = S::R, WR = W * R, NW = szh_gran<T>::NW, KD = SZH_RB_KD;
     const int lane = (int)(threadIdx.x & 63);
     const int NT = szh_rb_steps_of<T>(a.G.g2.count);
     SZH_LDS unsigned *const mine = L.P + 2 * (W + 1);
@@ -615,7 +624,7 @@ __device__ __forceinline__ void drain(const szh_qargs<T> &a, int TI, int TJ, con
             if (++idle > (1u << 22)) { st_flag(a.err, 1u); break; }
             if ((idle & 1023u) == 0 && uni((int)ld_flag(a.err)) != 0) break;
         } else idle = 0;
-        nap(2);
+        nap(SZH_RB_DRAIN_NAP);
     }
     if (trc && lane == 0) { trc[2] = rb_wall(); trc[3] = rounds; trc[4] = empty; trc[7] = (szh_u64)nd; }
 }

@@ -747,14 +747,18 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         int rshift = 0; int use_lds = intervals <= 16384;
         if (use_lds) { while ((intervals << (rshift + 1)) <= 16384u && rshift < 6) ++rshift; }
         const size_t lds = use_lds ? ((size_t)intervals << rshift) * 4 : 16;
-        int grid = (int)std::min<int64_t>((n / 8 + 255) / 256 + 1, 2048);
-        hipLaunchKernelGGL(k_hist_u16, dim3(grid), dim3(256), lds, ctx->stream2, codes, n, intervals, rshift, use_lds, d_hist);
+        const int64_t nh = use_ribbon ? (int64_t)nat_elems : n;          // ribbon order: the whole padded array, positions outside skipped by geometry
+        int grid = (int)std::min<int64_t>((nh / 8 + 255) / 256 + 1, 2048);
+        hipLaunchKernelGGL(k_hist_u16, dim3(grid), dim3(256), lds, ctx->stream2, codes, nh, intervals, rshift, use_lds, d_hist, rbl, G.g0.count, G.g1.count, G.g2.count);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(h_hist, d_hist, (size_t)intervals * 4, hipMemcpyDeviceToHost, ctx->stream2));
         HIPCHK(hipEventRecord(ctx->ev_fit, ctx->stream2));
         return SZHIP_OK;
     };
-    if (!use_ribbon) TRY(launch_hist((const uint16_t *)d_nat));    // natural order: next to the block-ordering pass
+    // (SZ_HIP_FUSE_HIST=1 takes the histogram inside k_permute instead: measured equal in kernel time -- 393 against 322 + 69 us -- and
+    //  without the overlap, so it is off)
+    bool fuse_hist = intervals <= 4096 && tune_int("SZ_HIP_FUSE_HIST", 0);
+    if (!fuse_hist) TRY(launch_hist((const uint16_t *)d_nat));    // next to the block-ordering pass (ribbon order: padding skipped by geometry)
     TRY(ensure(ctx, ctx->col_zeros, (size_t)ncols * 4));
     TRY(ensure(ctx, ctx->col_zeros64, (size_t)ncols * 8));
     TRY(ensure(ctx, ctx->col_off, (size_t)ncols * 8));
@@ -765,12 +769,21 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         const int nseg = (G.g2.num + segb - 1) / segb;
         TRY(ensure(ctx, ctx->zcnt, (size_t)ncols * nseg * 4));
         TRY(ensure(ctx, ctx->zpos, (size_t)ncols * nseg * SZH_ZCAP * 4));
-        hipLaunchKernelGGL((k_permute<0>), dim3(ncols, nseg), dim3(256), tile_bytes(G, segb, 2), st, G, (const uint16_t *)d_nat,
-                           d_blk, (unsigned *)ctx->col_zeros.p, segb, (unsigned *)ctx->zcnt.p, (unsigned *)ctx->zpos.p, rbl);
+        // the histogram is taken inside the block-ordering pass when its bins fit behind the tile in LDS (SZ_HIP_FUSE_HIST=0: the
+        // separate pass, which is also what large alphabets get)
+        fuse_hist = intervals <= 4096 && tune_int("SZ_HIP_FUSE_HIST", 0);
+        const size_t tb = tile_bytes(G, segb, 2), tile_el = (tb + 1) / 2;
+        if (fuse_hist) HIPCHK(hipMemsetAsync(d_hist, 0, (size_t)intervals * 4, st));
+        hipLaunchKernelGGL((k_permute<0>), dim3(ncols, nseg), dim3(256), ((tile_el + 1) & ~(size_t)1) * 2 + (fuse_hist ? (size_t)intervals * 4 : 0) + 16, st, G, (const uint16_t *)d_nat,
+                           d_blk, (unsigned *)ctx->col_zeros.p, segb, (unsigned *)ctx->zcnt.p, (unsigned *)ctx->zpos.p, rbl,
+                           d_hist, fuse_hist ? intervals : 0u, (int)tile_el);
+        if (fuse_hist) {
+            HIPCHK(hipMemcpyAsync(h_hist, d_hist, (size_t)intervals * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipEventRecord(ctx->ev_fit, st));
+        }
         perm_segb = segb; perm_nseg = nseg;
         HIPCHK(hipGetLastError());
     }
-    if (use_ribbon) TRY(launch_hist((const uint16_t *)d_blk));     // ribbon order holds padding: the histogram reads the block-ordered array
     hipLaunchKernelGGL(k_u32_to_u64, dim3((ncols + 255) / 256), dim3(256), 0, st, (const unsigned *)ctx->col_zeros.p, (int64_t)ncols,
                        (u64 *)ctx->col_zeros64.p);
     TRY(scan_u64(ctx, (const u64 *)ctx->col_zeros64.p, ncols, (u64 *)ctx->col_off.p, sm + SM_TOTAL_UNPRED));
@@ -1136,7 +1149,7 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
         TRY(ensure(ctx, ctx->zcnt, (size_t)ncols * nseg * 4));
         TRY(ensure(ctx, ctx->zpos, (size_t)ncols * nseg * SZH_ZCAP * 4));
         hipLaunchKernelGGL((k_permute<1>), dim3(ncols, nseg), dim3(256), tile_bytes(G, segb, 2), st, G, (const uint16_t *)d_blk, d_nat,
-                           (unsigned *)ctx->col_zeros.p, segb, (unsigned *)ctx->zcnt.p, (unsigned *)ctx->zpos.p, szh_rb_layout{0, 0, 0, 0, 0, 0});
+                           (unsigned *)ctx->col_zeros.p, segb, (unsigned *)ctx->zcnt.p, (unsigned *)ctx->zpos.p, szh_rb_layout{0, 0, 0, 0, 0, 0}, (unsigned *)nullptr, 0u, 0);
         perm_segb = segb; perm_nseg = nseg;
         HIPCHK(hipGetLastError());
     }
@@ -1590,7 +1603,7 @@ int compress14_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t
         if (use_lds) { while ((intervals << (rshift + 1)) <= 16384u && rshift < 6) ++rshift; }
         const size_t lds = use_lds ? ((size_t)intervals << rshift) * 4 : 16;
         int grid = (int)std::min<int64_t>((n / 8 + 255) / 256 + 1, 2048);
-        hipLaunchKernelGGL(k_hist_u16, dim3(grid), dim3(256), lds, st, (const uint16_t *)d_codes, n, intervals, rshift, use_lds, d_hist);
+        hipLaunchKernelGGL(k_hist_u16, dim3(grid), dim3(256), lds, st, (const uint16_t *)d_codes, n, intervals, rshift, use_lds, d_hist, szh_rb_layout{0, 0, 0, 0, 0, 0}, 0, 0, 0);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipMemcpyAsync(h_hist, d_hist, (size_t)intervals * 4, hipMemcpyDeviceToHost, st));
@@ -2087,7 +2100,7 @@ int compress_fast_impl(szhip_ctx *ctx, const void *data, int data_on_device, siz
         if (use_lds) { while ((intervals << (rshift + 1)) <= 16384u && rshift < 6) ++rshift; }
         const size_t lds = use_lds ? ((size_t)intervals << rshift) * 4 : 16;
         int grid = (int)std::min<int64_t>((n / 8 + 255) / 256 + 1, 2048);
-        hipLaunchKernelGGL(k_hist_u16, dim3(grid), dim3(256), lds, st, (const uint16_t *)d_codes, n, intervals, rshift, use_lds, d_hist);
+        hipLaunchKernelGGL(k_hist_u16, dim3(grid), dim3(256), lds, st, (const uint16_t *)d_codes, n, intervals, rshift, use_lds, d_hist, szh_rb_layout{0, 0, 0, 0, 0, 0}, 0, 0, 0);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipMemcpyAsync(h_hist, d_hist, (size_t)intervals * 4, hipMemcpyDeviceToHost, st));

@@ -595,8 +595,10 @@ __global__ __launch_bounds__(256) void k_chain_seg_1d(const T *__restrict__ data
 
 // ------------------------------------------------------------------ code histogram (order independent)
 // LDS-privatised with R replicas per bin to spread same-symbol atomics over banks.
+// rb.on: `codes` is in the ribbon order of szh_ribbon.h (n = its length, padding included): a group of 8 codes is 8 consecutive k of
+// one row; positions outside the array are skipped by geometry (r0, r1, r2 = the array's extents)
 __global__ __launch_bounds__(256) void k_hist_u16(const uint16_t *__restrict__ codes, int64_t n, unsigned nbins, int rshift,
-                                                  int use_lds, unsigned *hist)
+                                                  int use_lds, unsigned *hist, szh_rb_layout rb, int r0, int r1, int r2)
 {
     SZH_DYN_SMEM(smem);
     unsigned *sh = reinterpret_cast<unsigned *>(smem);
@@ -617,15 +619,31 @@ __global__ __launch_bounds__(256) void k_hist_u16(const uint16_t *__restrict__ c
         for (int u = 0; u < 4; ++u) {
             if (i + u * stride >= nvec) break;
             const unsigned wv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            int klo = 0, khi = 8;                                 // which of the group's 8 codes count
+            if (rb.on) {
+                // group g of the ribbon order: [tile][trip][w][r][v][lane] -> k of its first code, row and column of the array
+                int64_t g = i + u * stride;
+                const int ln = (int)(g & 63); g >>= 6;
+                const int gv = rb.U / 8, vv = (int)(g % gv); g /= gv;
+                const int rr = (int)(g % rb.R); g /= rb.R;
+                const int w = (int)(g % rb.W); g /= rb.W;
+                const int ntr = rb.NT / rb.U, trip = (int)(g % ntr); g /= ntr;
+                const int TJ = (int)(g % rb.nTJ), TI = (int)(g / rb.nTJ);
+                const int row = (TI * rb.W + w) * rb.R + rr, col = TJ * 64 + ln;
+                const int k0 = trip * rb.U + vv * 8 - w * (rb.R - 1) - ln - rr;
+                if (row >= r0 || col >= r1) khi = 0;
+                else { klo = k0 < 0 ? -k0 : 0; khi = r2 - k0 < 8 ? r2 - k0 : 8; }
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const unsigned c0 = wv[q] & 0xffffu, c1 = wv[q] >> 16;
-                if (use_lds) { atomicAdd(&sh[(c0 << rshift) + rep], 1u); atomicAdd(&sh[(c1 << rshift) + rep], 1u); }
-                else { atomicAdd(&hist[c0], 1u); atomicAdd(&hist[c1], 1u); }
+                const bool t0 = 2 * q >= klo && 2 * q < khi, t1 = 2 * q + 1 >= klo && 2 * q + 1 < khi;
+                if (use_lds) { if (t0) atomicAdd(&sh[(c0 << rshift) + rep], 1u); if (t1) atomicAdd(&sh[(c1 << rshift) + rep], 1u); }
+                else { if (t0) atomicAdd(&hist[c0], 1u); if (t1) atomicAdd(&hist[c1], 1u); }
             }
         }
     }
-    if (blockIdx.x == 0) {
+    if (blockIdx.x == 0 && !rb.on) {
         for (int64_t i = nvec * 8 + threadIdx.x; i < n; i += 256) {
             const unsigned c = codes[i];
             if (use_lds) atomicAdd(&sh[(c << rshift) + rep], 1u); else atomicAdd(&hist[c], 1u);
@@ -651,8 +669,12 @@ __global__ __launch_bounds__(256) void k_hist_u16(const uint16_t *__restrict__ c
 #define SZH_ZCAP 128
 template <int DIR>
 __global__ __launch_bounds__(256) void k_permute(szh_geom3 G, const uint16_t *__restrict__ src, uint16_t *__restrict__ dst,
-                                                 unsigned *col_zeros, int segb, unsigned *zcnt, unsigned *zpos, szh_rb_layout rb)
+                                                 unsigned *col_zeros, int segb, unsigned *zcnt, unsigned *zpos, szh_rb_layout rb,
+                                                 unsigned *hist, unsigned hist_bins, int tile_elems)
 {   // rb.on (DIR 0 only): `src` is in the ribbon order of szh_ribbon.h
+    // hist (DIR 0 only, hist_bins > 0): the code histogram of Huffman.c:165-174 is taken here, while the codes sit in LDS anyway (one
+    // pass over the code array less): per workgroup in LDS behind the tile, the peak symbol (radius = hist_bins / 2, most of a smooth
+    // field) counted by ballot instead of by atomics, non-empty bins added to the global histogram at the end
     __shared__ unsigned zc_s, zp_s[SZH_ZCAP];
     if (threadIdx.x == 0) zc_s = 0;
     __syncthreads();
@@ -681,6 +703,11 @@ __global__ __launch_bounds__(256) void k_permute(szh_geom3 G, const uint16_t *__
         else { const int e2 = e - eregion; const int bl = e2 / lsz; const int rem = e2 - bl * lsz; s2 = G.g2.late; koff = nE * G.g2.early + bl * s2; row = rem / s2; kk = rem - row * s2; }
     };
     unsigned zeros = 0;
+    unsigned *const lh = reinterpret_cast<unsigned *>(tile + ((tile_elems + 1) & ~1));
+    const bool do_hist = DIR == 0 && hist_bins > 0;
+    const unsigned peak = hist_bins / 2;
+    unsigned peak_cnt = 0;
+    if (do_hist) { for (unsigned b = threadIdx.x; b < hist_bins; b += 256) lh[b] = 0; }
     if (DIR == 0 && rb.on) {
         // gather from ribbon order: the codes of a row lie in groups of 8 consecutive k (16 aligned bytes), one group per 8 steps
         // of the wavefront that made them; one thread per (row, group)
@@ -725,6 +752,7 @@ __global__ __launch_bounds__(256) void k_permute(szh_geom3 G, const uint16_t *__
                 const int ti = row * kp + kshift + koff + kk;
                 if (DIR == 0) v[e - e0] = tile[ti]; else tile[ti] = v[e - e0];
                 if (v[e - e0] == 0) { ++zeros; const unsigned q = atomicAdd(&zc_s, 1u); if (q < SZH_ZCAP) zp_s[q] = (unsigned)e; }
+                if (do_hist) { const unsigned c = v[e - e0]; if (c == peak) ++peak_cnt; else if (c < hist_bins) atomicAdd(&lh[c], 1u); }
                 if (++kk == s2) { kk = 0; if (++row == rows && e + 1 < ehi) locate(e + 1, row, kk, s2, koff); }
             }
             if (DIR == 0) {
@@ -749,7 +777,12 @@ __global__ __launch_bounds__(256) void k_permute(szh_geom3 G, const uint16_t *__
     }
     zeros = wave_sum_u32(zeros);
     if ((threadIdx.x & 63) == 0 && zeros) atomicAdd(&col_zeros[col], zeros);
+    if (do_hist) {
+        peak_cnt = wave_sum_u32(peak_cnt);
+        if ((threadIdx.x & 63) == 0 && peak_cnt) atomicAdd(&lh[peak], peak_cnt);
+    }
     __syncthreads();
+    if (do_hist) { for (unsigned b = threadIdx.x; b < hist_bins; b += 256) { const unsigned c = lh[b]; if (c) atomicAdd(&hist[b], c); } }
     const unsigned zc = zc_s;
     const size_t slot = (size_t)col * gridDim.y + blockIdx.y;
     if (threadIdx.x == 0) zcnt[slot] = zc;
