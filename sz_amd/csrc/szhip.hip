@@ -41,7 +41,7 @@ struct szhip_ctx {
     char err[512] = {0};
     unsigned epoch = 0;
     // workspaces (grow-only)
-    DevBuf lor_bits, reg_flags, reg_rank, coef_compact, in, out, codes_nat, codes_blk, coef, blk_lor, faceI, faceJ, rb_down, rb_right, progress, trace, order, small, hist, col_zeros, col_zeros64,
+    DevBuf lor_bits, reg_flags, reg_rank, coef_compact, in, out, codes_nat, codes_blk, coef, blk_lor, faceI, faceJ, rb_down, rb_right, fast_slots, fast_units, progress, trace, order, small, hist, col_zeros, col_zeros64,
         col_off, partial, samples, unpred, stream_buf, chunk_bits, chunk_off, code_tab, len_tab, dec_tab,
         starts, ends, counts, offs, dirty, zcnt, zpos, pwr_log, pwr_signs, pwr_small, coef_dec, msst_ptab, msst_cells, msst_rec, msst_pe;
     void *pinned = nullptr; size_t pinned_cap = 0;
@@ -2079,42 +2079,86 @@ int compress_fast_impl(szhip_ctx *ctx, const void *data, int data_on_device, siz
     TRY(ensure(ctx, ctx->small, SM_COUNT * 8));
     u64 *sm = (u64 *)ctx->small.p;
     HIPCHK(hipMemsetAsync(sm, 0, SM_COUNT * 8, st));
-    TRY(ensure(ctx, ctx->codes_nat, (size_t)n * 2 + 64));
-    uint16_t *d_codes = (uint16_t *)ctx->codes_nat.p;
-    const unsigned ntiles = (unsigned)((int64_t)g.n0 * g.n1 * g.n2);
-    HIPCHK(hipEventRecord(ctx->ev[0], st));
-    HIPCHK(hipEventRecord(ctx->ev[1], st));
-    HIPCHK(hipEventRecord(ctx->ev[2], st));
-    hipLaunchKernelGGL((k_fast_quant<T>), dim3((ntiles + 7) / 8 * 8), dim3(256), 0, st, g, d_in, d_codes, eb, (int)intervals / 2);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(ctx->ev[3], st));
-    S.quant_kernel_launches = 1;
-    // histogram -> host code book; side-list counts meanwhile
+    // Two-pass form (szh_fast.h, round 3; SZ_HIP_FAST2=1): the codes are recomputed instead of stored -- pass A (statistics) here, pass B
+    // (packing) and pass C (compaction) below.  Measured at 512^3 f32 it is the slower of the two end to end (1.12 ms against 0.96 ms:
+    // the per-unit slots of pass B and their compaction cost more than the 2 N-byte code array they replace), so the code-array form
+    // stays the default; a code longer than 32 bits takes the code-array form in any case.
+    const szg_geom gg = szg_make_geom(r0, r1, r2);
+    bool two_pass = tune_int("SZ_HIP_FAST2", 0) != 0 && gg.ntiles < 0x7fffffff;
+    const int64_t nunits = (int64_t)r0 * (int64_t)r1 * gg.n2;
     TRY(ensure(ctx, ctx->hist, (size_t)(65536 + 8192) * 4 + 64));
     unsigned *d_hist = (unsigned *)ctx->hist.p;
     TRY(ensure_pinned(ctx, (size_t)intervals * 4 + 64));
     unsigned *h_hist = (unsigned *)ctx->pinned;
-    HIPCHK(hipMemsetAsync(d_hist, 0, (size_t)intervals * 4, st));
-    {
-        int rshift = 0; int use_lds = intervals <= 16384;
-        if (use_lds) { while ((intervals << (rshift + 1)) <= 16384u && rshift < 6) ++rshift; }
-        const size_t lds = use_lds ? ((size_t)intervals << rshift) * 4 : 16;
-        int grid = (int)std::min<int64_t>((n / 8 + 255) / 256 + 1, 2048);
-        hipLaunchKernelGGL(k_hist_u16, dim3(grid), dim3(256), lds, st, (const uint16_t *)d_codes, n, intervals, rshift, use_lds, d_hist, szh_rb_layout{0, 0, 0, 0, 0, 0}, 0, 0, 0);
-        HIPCHK(hipGetLastError());
-    }
-    HIPCHK(hipMemcpyAsync(h_hist, d_hist, (size_t)intervals * 4, hipMemcpyDeviceToHost, st));
+    uint16_t *d_codes = nullptr;
+    u64 *d_ucnt = nullptr, *d_uoffc = nullptr, *d_ubits = nullptr, *d_uoff = nullptr;
     const int64_t nchunks = (n + 2047) / 2048;
-    TRY(ensure(ctx, ctx->col_zeros64, (size_t)nchunks * 8)); TRY(ensure(ctx, ctx->col_off, (size_t)nchunks * 8));
-    TRY(ensure(ctx, ctx->reg_flags, (size_t)nchunks * 8)); TRY(ensure(ctx, ctx->reg_rank, (size_t)nchunks * 8));
-    TRY(ensure(ctx, ctx->chunk_bits, (size_t)nchunks * 8)); TRY(ensure(ctx, ctx->chunk_off, (size_t)nchunks * 8));
-    hipLaunchKernelGGL(k_fast_count, dim3((unsigned)nchunks), dim3(256), 0, st, (const uint16_t *)d_codes, n, (u64 *)ctx->col_zeros64.p, (u64 *)ctx->reg_flags.p);
-    TRY(scan_u64(ctx, (const u64 *)ctx->col_zeros64.p, nchunks, (u64 *)ctx->col_off.p, sm + SM_TOTAL_UNPRED));
-    TRY(scan_u64(ctx, (const u64 *)ctx->reg_flags.p, nchunks, (u64 *)ctx->reg_rank.p, sm + SM_SCRATCH));
+    HIPCHK(hipEventRecord(ctx->ev[0], st));
+    HIPCHK(hipEventRecord(ctx->ev[1], st));
+    auto code_array_front = [&]() -> int {
+        TRY(ensure(ctx, ctx->codes_nat, (size_t)n * 2 + 64));
+        d_codes = (uint16_t *)ctx->codes_nat.p;
+        const unsigned ntiles = (unsigned)((int64_t)g.n0 * g.n1 * g.n2);
+        HIPCHK(hipEventRecord(ctx->ev[2], st));
+        hipLaunchKernelGGL((k_fast_quant<T>), dim3((ntiles + 7) / 8 * 8), dim3(256), 0, st, g, d_in, d_codes, eb, (int)intervals / 2);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(ctx->ev[3], st));
+        // histogram -> host code book; side-list counts meanwhile
+        HIPCHK(hipMemsetAsync(d_hist, 0, (size_t)intervals * 4, st));
+        {
+            int rshift = 0; int use_lds = intervals <= 16384;
+            if (use_lds) { while ((intervals << (rshift + 1)) <= 16384u && rshift < 6) ++rshift; }
+            const size_t lds = use_lds ? ((size_t)intervals << rshift) * 4 : 16;
+            int grid = (int)std::min<int64_t>((n / 8 + 255) / 256 + 1, 2048);
+            hipLaunchKernelGGL(k_hist_u16, dim3(grid), dim3(256), lds, st, (const uint16_t *)d_codes, n, intervals, rshift, use_lds, d_hist, szh_rb_layout{0, 0, 0, 0, 0, 0}, 0, 0, 0);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipMemcpyAsync(h_hist, d_hist, (size_t)intervals * 4, hipMemcpyDeviceToHost, st));
+        TRY(ensure(ctx, ctx->col_zeros64, (size_t)nchunks * 8)); TRY(ensure(ctx, ctx->col_off, (size_t)nchunks * 8));
+        TRY(ensure(ctx, ctx->reg_flags, (size_t)nchunks * 8)); TRY(ensure(ctx, ctx->reg_rank, (size_t)nchunks * 8));
+        TRY(ensure(ctx, ctx->chunk_bits, (size_t)nchunks * 8)); TRY(ensure(ctx, ctx->chunk_off, (size_t)nchunks * 8));
+        hipLaunchKernelGGL(k_fast_count, dim3((unsigned)nchunks), dim3(256), 0, st, (const uint16_t *)d_codes, n, (u64 *)ctx->col_zeros64.p, (u64 *)ctx->reg_flags.p);
+        TRY(scan_u64(ctx, (const u64 *)ctx->col_zeros64.p, nchunks, (u64 *)ctx->col_off.p, sm + SM_TOTAL_UNPRED));
+        TRY(scan_u64(ctx, (const u64 *)ctx->reg_flags.p, nchunks, (u64 *)ctx->reg_rank.p, sm + SM_SCRATCH));
+        return SZHIP_OK;
+    };
+    if (two_pass) {
+        TRY(ensure(ctx, ctx->fast_units, (size_t)nunits * 8 * 4 + 64));
+        TRY(ensure(ctx, ctx->fast_slots, (size_t)nunits * SZG_SLOT_WORDS * 4 + 64));
+        d_ucnt = (u64 *)ctx->fast_units.p; d_uoffc = d_ucnt + nunits; d_ubits = d_uoffc + nunits; d_uoff = d_ubits + nunits;
+        HIPCHK(hipMemsetAsync(d_hist, 0, (size_t)intervals * 4, st));
+        HIPCHK(hipMemsetAsync(d_ucnt, 0, (size_t)nunits * 8, st));          // k_fast_stat adds to the few units that have side-list entries
+        HIPCHK(hipEventRecord(ctx->ev[2], st));
+        {   // persistent: exactly the workgroups that are resident at once (a second, half-empty round cost 40 % at 768 over 512)
+            static int per_cu = 0;
+            if (!per_cu) { int nb = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast_stat<T>, 256, 0) != hipSuccess || nb < 1) nb = 2; per_cu = nb; }
+            static int cus = 0;
+            if (!cus) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || v < 1) v = 256; cus = v; }
+            const int wgs = tune_int("SZ_HIP_FAST_STAT_WGS", per_cu * cus);
+            hipLaunchKernelGGL((k_fast_stat<T>), dim3((unsigned)std::min<int64_t>(gg.ntiles, wgs)), dim3(256), 0, st, gg, d_in, eb, (int)intervals / 2, intervals, d_hist, d_ucnt, (unsigned *)(sm + SM_TICKET));
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(ctx->ev[3], st));
+        HIPCHK(hipMemcpyAsync(h_hist, d_hist, (size_t)intervals * 4, hipMemcpyDeviceToHost, st));
+        TRY(scan_u64(ctx, (const u64 *)d_ucnt, nunits, d_uoffc, sm + SM_TOTAL_UNPRED));     // both side-list ranks in one scan (low / high half)
+    } else TRY(code_array_front());
     HIPCHK(hipStreamSynchronize(st));
     double h0 = now_ms();
     szhost_huff *hf = szhost_huff_build(2 * (int)intervals, h_hist, nullptr, intervals);
     if (!hf) FAIL(SZHIP_ERR_INTERNAL, "Huffman build failed");
+    if (two_pass) {
+        unsigned maxlen = 0;
+        for (unsigned s2 = 0; s2 < intervals; ++s2) if (hf->len[s2] > maxlen) maxlen = hf->len[s2];
+        if (maxlen > 32) {                                  // a unit's slot holds 64 x 32 bits: take the code-array form (same histogram, same tree)
+            szhost_huff_free(hf);
+            two_pass = false;
+            HIPCHK(hipMemsetAsync(sm, 0, SM_COUNT * 8, st));
+            TRY(code_array_front());
+            HIPCHK(hipStreamSynchronize(st));
+            hf = szhost_huff_build(2 * (int)intervals, h_hist, nullptr, intervals);
+            if (!hf) FAIL(SZHIP_ERR_INTERNAL, "Huffman build failed");
+        }
+    }
     const u64 nA = h_hist[0], nB = h_hist[1];
     S.n_unpred = nA + nB;
     const size_t tree_bytes = szhost_huff_tree_size(hf);
@@ -2147,6 +2191,25 @@ int compress_fast_impl(szhip_ctx *ctx, const void *data, int data_on_device, siz
     unsigned char *d_stream = (unsigned char *)ctx->stream_buf.p;
     HIPCHK(hipMemsetAsync(d_stream, 0, total_len + 64, st));
     HIPCHK(hipMemcpyAsync(d_stream, hdr.data(), hdr.size(), hipMemcpyHostToDevice, st));
+    if (two_pass) {
+        {
+            static int per_cu = 0, cus = 0;
+            if (!per_cu) { int nb = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast_pack<T>, 256, 0) != hipSuccess || nb < 1) nb = 2; per_cu = nb; }
+            if (!cus) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || v < 1) v = 256; cus = v; }
+            const int wgs = tune_int("SZ_HIP_FAST_PACK_WGS", per_cu * cus);
+            hipLaunchKernelGGL((k_fast_pack<T>), dim3((unsigned)std::min<int64_t>(gg.ntiles, wgs)), dim3(256), 0, st, gg, d_in, eb, (int)intervals / 2, intervals,
+                               (const u64 *)ctx->code_tab.p, (const uint8_t *)ctx->len_tab.p, (const u64 *)d_uoffc,
+                               (int32_t *)(d_stream + offA), (int32_t *)(d_stream + offBd), (T *)(d_stream + offB), d_ubits, (unsigned *)ctx->fast_slots.p,
+                               (unsigned *)(sm + SM_TICKET) + 1);
+        }
+        HIPCHK(hipGetLastError());
+        TRY(scan_u64(ctx, (const u64 *)d_ubits, nunits, d_uoff, sm + SM_TOTAL_BITS));
+        if (total_bits > 0) {
+            hipLaunchKernelGGL(k_fast_compact, dim3((unsigned)((nunits + 255) / 256)), dim3(256), 0, st, nunits, (const u64 *)d_ubits, (const u64 *)d_uoff,
+                               (const unsigned *)ctx->fast_slots.p, (u64)pay_off * 8, (unsigned *)d_stream);
+            HIPCHK(hipGetLastError());
+        }
+    } else {
     if (nA + nB > 0) {
         hipLaunchKernelGGL((k_fast_lists<T>), dim3((unsigned)nchunks), dim3(256), 0, st, g, (const uint16_t *)d_codes, (const u64 *)ctx->col_off.p,
                            (const u64 *)ctx->reg_rank.p, d_in, eb, (int32_t *)(d_stream + offA), (int32_t *)(d_stream + offBd), (T *)(d_stream + offB));
@@ -2159,6 +2222,7 @@ int compress_fast_impl(szhip_ctx *ctx, const void *data, int data_on_device, siz
         hipLaunchKernelGGL(k_encode, dim3((unsigned)((nchunks + SZH_ENC_PER - 1) / SZH_ENC_PER)), dim3(256), 0, st, (const uint16_t *)d_codes, n, (const u64 *)ctx->code_tab.p,
                            (const uint8_t *)ctx->len_tab.p, intervals, (const u64 *)ctx->chunk_off.p, (u64)pay_off * 8, (unsigned *)d_stream);
         HIPCHK(hipGetLastError());
+    }
     }
     HIPCHK(hipEventRecord(ctx->ev[4], st));
     u64 h_small[SM_COUNT];
@@ -2177,7 +2241,10 @@ int compress_fast_impl(szhip_ctx *ctx, const void *data, int data_on_device, siz
         *out = h;
     }
     *out_size = total_len;
-    if ((total_bits > 0 && h_small[SM_TOTAL_BITS] != total_bits) || h_small[SM_TOTAL_UNPRED] != nA || h_small[SM_SCRATCH] != nB)
+    S.quant_kernel = two_pass ? 2 : 0;                         // 2: the two-pass form of the fast mode
+    const bool counts_ok = two_pass ? ((h_small[SM_TOTAL_UNPRED] & 0xffffffffull) == nA && (h_small[SM_TOTAL_UNPRED] >> 32) == nB)
+                                    : (h_small[SM_TOTAL_UNPRED] == nA && h_small[SM_SCRATCH] == nB);
+    if ((total_bits > 0 && h_small[SM_TOTAL_BITS] != total_bits) || !counts_ok)
         FAIL_PUBLISHED(SZHIP_ERR_INTERNAL, "fast mode: entropy stage mismatch");
     float ms = 0;
     hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); S.ms_quant = ms;
@@ -2360,7 +2427,7 @@ void szhip_destroy(szhip_ctx *ctx)
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->lor_bits, &ctx->reg_flags, &ctx->reg_rank, &ctx->coef_compact, &ctx->in, &ctx->out, &ctx->codes_nat, &ctx->codes_blk, &ctx->coef, &ctx->blk_lor, &ctx->faceI, &ctx->faceJ, &ctx->rb_down, &ctx->rb_right, &ctx->progress, &ctx->trace,
+    DevBuf *bufs[] = {&ctx->lor_bits, &ctx->reg_flags, &ctx->reg_rank, &ctx->coef_compact, &ctx->in, &ctx->out, &ctx->codes_nat, &ctx->codes_blk, &ctx->coef, &ctx->blk_lor, &ctx->faceI, &ctx->faceJ, &ctx->rb_down, &ctx->rb_right, &ctx->fast_slots, &ctx->fast_units, &ctx->progress, &ctx->trace,
                       &ctx->order, &ctx->small, &ctx->hist, &ctx->col_zeros, &ctx->col_zeros64, &ctx->col_off, &ctx->partial,
                       &ctx->samples, &ctx->unpred, &ctx->stream_buf, &ctx->chunk_bits, &ctx->chunk_off, &ctx->code_tab,
                       &ctx->len_tab, &ctx->dec_tab, &ctx->starts, &ctx->ends, &ctx->counts, &ctx->offs, &ctx->dirty, &ctx->zcnt, &ctx->zpos,

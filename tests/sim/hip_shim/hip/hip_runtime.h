@@ -122,6 +122,9 @@ enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDevi
 inline const char *hipGetErrorString(hipError_t) { return "hipsim"; }
 inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 0 };
+inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 4; return hipSuccess; }
+template <class K> inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *nb, K, int, size_t) { *nb = 2; return hipSuccess; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, int) { *s = (void *)1; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }

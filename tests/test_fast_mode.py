@@ -35,7 +35,7 @@ def _small_cases():
     rng = np.random.default_rng(6)
     spike = s_field(8, 10, 70)
     spike[3, 4, 5] = 1e30; spike[7, 2, 66] = np.nan; spike[0, 0, 0] = -3e38
-    return [("odd-9x18x38", s_field(9, 18, 38), 1e-3, 64), ("S-f64", s_field(6, 17, 66, np.float64), 1e-6, 0), ("raw-points", spike, 1e-4, 0),
+    return [("interior-tile-9x17x70", s_field(9, 17, 70), 1e-4, 0), ("odd-9x18x38", s_field(9, 18, 38), 1e-3, 64), ("S-f64", s_field(6, 17, 66, np.float64), 1e-6, 0), ("raw-points", spike, 1e-4, 0),
             ("2D", s_field(1, 30, 70)[0], 1e-4, 0), ("1D", np.cumsum(rng.standard_normal(2100)).astype(np.float32) * np.float32(0.01), 1e-3, 0)]
 
 
@@ -80,9 +80,12 @@ def test_product_fast_mode_on_cpu_shim_matches_oracle(oracle, built):
         ctx = sz_amd.HipContext(0)
         for name, d, eb, iv in _small_cases():
             d3 = d.reshape((1,) * (3 - d.ndim) + d.shape)
-            got, n, st = ctx.compress_fast(d3.ctypes.data, False, d3.shape, d.dtype, eb, iv)
             ref = oracle.fast_compress(d, eb, iv)
-            assert got == ref, name
+            for form in ("0", "1"):                      # the code-array form (default) and the two-pass form (szh_fast.h, round 3)
+                os.environ["SZ_HIP_FAST2"] = form
+                got, n, st = ctx.compress_fast(d3.ctypes.data, False, d3.shape, d.dtype, eb, iv)
+                assert got == ref, (name, form)
+                assert st.quant_kernel == (2 if form == "1" else 0), (name, form)
             out = np.empty_like(d3)
             buf = ctypes.create_string_buffer(ref, len(ref))
             ctx.decompress_fast(ctypes.addressof(buf), False, len(ref), d3.shape, d.dtype, out.ctypes.data, False)
@@ -100,6 +103,7 @@ def test_product_fast_mode_on_cpu_shim_matches_oracle(oracle, built):
         sz_amd.SZ_Finalize()
     finally:
         os.environ.pop("SZ_HIP_MODE", None)
+        os.environ.pop("SZ_HIP_FAST2", None)
         api._lib = saved
 
 
@@ -109,9 +113,14 @@ def test_hip_fast_mode_matches_oracle(oracle, built):
     ctx = sz_amd.HipContext(0)
     for name, d, eb, iv in _cases():
         d3 = np.ascontiguousarray(d.reshape((1,) * (3 - d.ndim) + d.shape))
-        got, n, st = ctx.compress_fast(d3.ctypes.data, False, d3.shape, d.dtype, eb, iv)
         ref = oracle.fast_compress(d, eb, iv)
-        assert got == ref, name
+        try:
+            for form in ("0", "1"):                          # the code-array form (default) and the two-pass form
+                os.environ["SZ_HIP_FAST2"] = form
+                got, n, st = ctx.compress_fast(d3.ctypes.data, False, d3.shape, d.dtype, eb, iv)
+                assert got == ref, (name, form)
+        finally:
+            os.environ.pop("SZ_HIP_FAST2", None)
         out = np.empty_like(d3)
         buf = ctypes.create_string_buffer(ref, len(ref))
         ctx.decompress_fast(ctypes.addressof(buf), False, len(ref), d3.shape, d.dtype, out.ctypes.data, False)
