@@ -917,7 +917,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
 
 // Huffman decode of `n` symbols on the device (self-synchronising sub-sequence decode, k_hdec_*): `d_bits` points at the payload,
 // `dtab` is the host-built decode table of the tree, `single_symbol` >= 0 for the one-leaf tree (zero payload bits).
-int huff_decode_device(szhip_ctx *ctx, u64 *sm, const unsigned char *d_bits, u64 total_bits, const std::vector<uint32_t> &dtab, int n_nodes,
+int huff_decode_device(szhip_ctx *ctx, u64 *sm, const unsigned char *d_bits, unsigned bytes_before, u64 total_bits, const std::vector<uint32_t> &dtab, int n_nodes,
                        int single_symbol, int64_t n, uint16_t *d_out_codes, u64 *total_sym_host)
 {
     // *total_sym_host receives the number of symbols the payload holds ASYNCHRONOUSLY: the caller compares it with n after its next
@@ -930,35 +930,40 @@ int huff_decode_device(szhip_ctx *ctx, u64 *sm, const unsigned char *d_bits, u64
     } else {
         const int64_t nsub = (int64_t)((total_bits + SZH_SUBSEQ_BITS - 1) / SZH_SUBSEQ_BITS);
         if (nsub == 0) FAIL(SZHIP_ERR_STREAM, "empty Huffman payload");
-        TRY(ensure(ctx, ctx->dec_tab, dtab.size() * 4));
+        const size_t lut_off = (dtab.size() * 4 + 63) / 64 * 64;
+        TRY(ensure(ctx, ctx->dec_tab, lut_off + SZH_LUT_BYTES));
         HIPCHK(hipMemcpyAsync(ctx->dec_tab.p, dtab.data(), dtab.size() * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_hdec_build_lut, dim3(SZH_LUT_SIZE / 256), dim3(256), 0, st, (const unsigned *)ctx->dec_tab.p, (uint4 *)((char *)ctx->dec_tab.p + lut_off));
         TRY(ensure(ctx, ctx->starts, (size_t)nsub * 8)); TRY(ensure(ctx, ctx->ends, (size_t)nsub * 8));
         TRY(ensure(ctx, ctx->counts, (size_t)nsub * 8)); TRY(ensure(ctx, ctx->offs, (size_t)nsub * 8));
         TRY(ensure(ctx, ctx->dirty, (size_t)nsub));
         szh_hdec_args a;
-        a.bits = d_bits; a.total_bits = total_bits; a.table = (const unsigned *)ctx->dec_tab.p; a.n_nodes = n_nodes;
-        a.table_in_lds = (size_t)n_nodes * 8 <= 48 * 1024; a.nsub = nsub;
+        a.bits = d_bits; a.total_bits = total_bits; a.bytes_before = bytes_before; a.table = (const unsigned *)ctx->dec_tab.p; a.n_nodes = n_nodes;
+        a.table_in_lds = (size_t)n_nodes * 8 <= 13 * 1024; a.nsub = nsub;      // (the write pass: 33 KB of bits + 16 KB of table + this <= 64 KB)
+        a.lut = (const uint4 *)((char *)ctx->dec_tab.p + lut_off);
         a.starts = (u64 *)ctx->starts.p; a.ends = (u64 *)ctx->ends.p; a.counts = (u64 *)ctx->counts.p;
         a.dirty = (unsigned char *)ctx->dirty.p; a.changed = (unsigned *)(sm + SM_CHANGED);
-        const size_t lds = a.table_in_lds ? (size_t)n_nodes * 8 : 16;
+        const size_t lds_tab = a.table_in_lds ? (size_t)n_nodes * 8 : 16;
+        const size_t lds_pass = SZH_HDEC_LDS + SZH_LUT_SIZE * 4 + lds_tab, lds_write = SZH_HDEC_LDS + SZH_LUT_SIZE * 16 + lds_tab;
         const unsigned gsub = (unsigned)((nsub + 255) / 256);
         hipLaunchKernelGGL(k_hdec_init, dim3(gsub), dim3(256), 0, st, a);
         int64_t iter = 0;
         for (;;) {
-            hipLaunchKernelGGL(k_hdec_pass, dim3(gsub), dim3(256), lds, st, a);
+            a.warmup = iter == 0;                                  // the first round finds its own starts (k_hdec_pass)
+            hipLaunchKernelGGL(k_hdec_pass, dim3(gsub), dim3(256), lds_pass, st, a);
             HIPCHK(hipMemsetAsync(sm + SM_CHANGED, 0, 8, st));
             hipLaunchKernelGGL(k_hdec_update, dim3(gsub), dim3(256), 0, st, a);
             HIPCHK(hipGetLastError());
-            if (iter == 0 && nsub > 1) { ++iter; continue; }     // the first propagation always moves guesses: no need to ask
             unsigned changed = 0;
             HIPCHK(hipMemcpyAsync(&changed, sm + SM_CHANGED, 4, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
+            if (tune_int("SZ_HIP_HDEC_TRACE", 0)) fprintf(stderr, "[szhip] Huffman decode round %lld: %u of %lld sub-sequence starts moved\n", (long long)iter, changed, (long long)nsub);
             if (!changed) break;
             if (++iter > nsub + 2) FAIL(SZHIP_ERR_INTERNAL, "Huffman decode did not converge");
         }
         TRY(scan_u64(ctx, (const u64 *)ctx->counts.p, nsub, (u64 *)ctx->offs.p, sm + SM_TOTAL_SYM));
         HIPCHK(hipMemcpyAsync(total_sym_host, sm + SM_TOTAL_SYM, 8, hipMemcpyDeviceToHost, st));
-        hipLaunchKernelGGL(k_hdec_write, dim3(gsub), dim3(256), lds, st, a, (const u64 *)ctx->offs.p, d_out_codes, n);
+        hipLaunchKernelGGL(k_hdec_write, dim3(gsub), dim3(256), lds_write, st, a, (const u64 *)ctx->offs.p, d_out_codes, n);
         HIPCHK(hipGetLastError());
     }
 
@@ -1134,7 +1139,7 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
 
     // ---- Huffman decode of the type array
     u64 total_sym = 0;
-    TRY(huff_decode_device(ctx, sm, d_stream + pay_off, total_bits, dtab, n_nodes, single_symbol, n, d_blk, &total_sym));
+    TRY(huff_decode_device(ctx, sm, d_stream + pay_off, (unsigned)std::min<size_t>(pay_off, 4096), total_bits, dtab, n_nodes, single_symbol, n, d_blk, &total_sym));
 
     // ---- natural order, unpredictable values into the output array
     const int ncols = G.g0.num * G.g1.num;
@@ -1829,7 +1834,7 @@ int decompress14_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream
     TRY(ensure(ctx, ctx->codes_nat, (size_t)n * 2 + 64));
     uint16_t *d_codes = (uint16_t *)ctx->codes_nat.p;
     u64 total_sym = 0;
-    TRY(huff_decode_device(ctx, sm, d_stream + pay_off, total_bits, dtab, n_nodes, single_symbol, n, d_codes, &total_sym));
+    TRY(huff_decode_device(ctx, sm, d_stream + pay_off, (unsigned)std::min<size_t>(pay_off, 4096), total_bits, dtab, n_nodes, single_symbol, n, d_codes, &total_sym));
 
     // ---- exact values back into the output array
     const int64_t nlin = (n + SZH_LIN_CHUNK - 1) / SZH_LIN_CHUNK;
@@ -2312,7 +2317,7 @@ int decompress_fast_impl(szhip_ctx *ctx, const unsigned char *stream_in, int str
     TRY(ensure(ctx, ctx->codes_nat, (size_t)n * 2 + 64));
     uint16_t *d_codes = (uint16_t *)ctx->codes_nat.p;
     u64 total_sym = 0;
-    TRY(huff_decode_device(ctx, sm, d_stream + pay_off, (u64)pay_bytes * 8, dtab, n_nodes, single_symbol, n, d_codes, &total_sym));
+    TRY(huff_decode_device(ctx, sm, d_stream + pay_off, (unsigned)std::min<size_t>(pay_off, 4096), (u64)pay_bytes * 8, dtab, n_nodes, single_symbol, n, d_codes, &total_sym));
     const int64_t nchunks = (n + 2047) / 2048;
     TRY(ensure(ctx, ctx->col_zeros64, (size_t)nchunks * 8)); TRY(ensure(ctx, ctx->col_off, (size_t)nchunks * 8));
     TRY(ensure(ctx, ctx->reg_flags, (size_t)nchunks * 8)); TRY(ensure(ctx, ctx->reg_rank, (size_t)nchunks * 8));
@@ -2689,7 +2694,7 @@ int szhip_debug_fetch(szhip_ctx *ctx, int which, void *dst, size_t bytes)
     if (!ctx || !dst) return SZHIP_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
     DevBuf *bufs[] = {&ctx->coef, &ctx->blk_lor, &ctx->codes_nat, &ctx->codes_blk, &ctx->hist, &ctx->col_zeros, &ctx->col_off,
-                      &ctx->unpred, &ctx->stream_buf, &ctx->trace, &ctx->rb_down, &ctx->rb_right};
+                      &ctx->unpred, &ctx->stream_buf, &ctx->trace, &ctx->rb_down, &ctx->rb_right, &ctx->small};
     if (which < 0 || which >= (int)(sizeof(bufs) / sizeof(bufs[0]))) return SZHIP_ERR_ARG;
     if (!bufs[which]->p || bufs[which]->cap < bytes) return SZHIP_ERR_ARG;
     HIPCHK(hipStreamSynchronize(ctx->stream));

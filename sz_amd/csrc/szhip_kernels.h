@@ -1087,100 +1087,290 @@ __global__ __launch_bounds__(256) void k_encode(const uint16_t *__restrict__ cod
 // resynchronise after a few symbols, subsequence 0 is right by construction, and a fixed point of
 // the propagation is the sequential decode.
 #define SZH_SUBSEQ_BITS 1024
+#define SZH_WARMUP_BITS 128     /* < SZH_SUBSEQ_BITS */
 struct szh_hdec_args {
     const unsigned char *bits; u64 total_bits;
+    unsigned bytes_before;         // readable bytes in front of `bits` (the stream's header etc.; staging aligns its start downwards)
     const unsigned *table; int n_nodes; int table_in_lds;
+    const uint4 *lut;              // SZH_LUT_BITS-bit look-up table built from `table` on the device (k_hdec_build_lut)
+    int warmup;                    // k_hdec_pass: first round (see there)
     int64_t nsub;
     u64 *starts; u64 *ends; u64 *counts; unsigned char *dirty; unsigned *changed;
 };
 
-// big-endian 64-bit window starting at byte `byte` (the stream buffer is padded, so reading a few bytes past the end is safe)
-__device__ __forceinline__ u64 hdec_window(const unsigned char *__restrict__ bits, u64 byte)
+// ---- round 3: a workgroup's 256 sub-sequences are one contiguous 32 KB stretch of the stream.  It is copied into LDS once
+// (coalesced 16-byte loads, byte-swapped: LDS word i holds bits 32 i .. 32 i + 31 of the stretch, first bit on top) and decoded from
+// there with 32-bit positions: the window at a bit position is two adjacent words and one funnel shift.  The earlier form kept a
+// 64-bit big-endian window per lane refilled from global memory (three loads, three byte swaps, 64-bit shifts): ~60 instructions per
+// look-up, and the passes were bound by instruction issue (0.20 ms and 0.42 ms at 512^3), not by memory.
+// The stretch is staged with SZH_HDEC_MARGIN bytes either side: the warm-up (SZH_WARMUP_BITS) reaches back, the last codeword of a
+// sub-sequence reaches forward (a code has at most 128 bits: szhost_huff / Huffman.c code[2]).
+#define SZH_HDEC_MARGIN 32
+#define SZH_HDEC_STAGE (256 * SZH_SUBSEQ_BITS / 8 + 2 * SZH_HDEC_MARGIN + 32)     /* bytes staged at most, slack word included (a multiple of 16) */
+// LDS word of stream word i.  The lanes of a wavefront walk streams 32 words (one sub-sequence) apart at about the same pace, so
+// without the extra word per 32 all 64 of them read the same one or two banks: measured 2 078 cycles per look-up per wavefront,
+// the look-up itself being ~35 instructions and two LDS reads.
+#define SZH_HDEC_SWZ(i) ((i) + ((i) >> 5))
+#define SZH_HDEC_LDS ((SZH_HDEC_STAGE + SZH_HDEC_STAGE / 32 + 31) / 16 * 16)           /* bytes of LDS for the staged words */
+struct szh_hdec_src {
+    const SZH_LDS unsigned *l;     // the staged words (LDS address space: ds_read, not flat loads)
+    int64_t bit0;                  // stream bit position of l[0]'s top bit (may be negative: the stretch begins in front of the payload)
+    unsigned nbits;                // staged bits
+};
+// 32 bits from local bit position q (q + 32 <= nbits + 32: one word of slack is staged)
+__device__ __forceinline__ unsigned hdec_w32(const SZH_LDS unsigned *l, unsigned q)
 {
-    const unsigned char *p = bits + byte;
-    const unsigned mis = (unsigned)((uintptr_t)p & 3u);
-    const unsigned *w = reinterpret_cast<const unsigned *>(p - mis);
-    const u64 a = __builtin_bswap32(w[0]), b = __builtin_bswap32(w[1]), c = __builtin_bswap32(w[2]);
-    const u64 hi = (a << 32) | b;                 // 8 bytes from the aligned address
-    return mis ? ((hi << (8 * mis)) | (c >> (32 - 8 * mis))) : hi;
+    const unsigned i = q >> 5, sh = q & 31u;
+    const unsigned a = l[SZH_HDEC_SWZ(i)], b = l[SZH_HDEC_SWZ(i + 1)];
+    return (unsigned)((((u64)a << 32) | b) >> (32u - sh));      // one 64-bit shift (v_alignbit_b32 cannot shift by 32: sh = 0)
 }
 
-// decodes from bit `pos` to the first codeword boundary at or after `limit`.  WRITE: symbols go to out[o], out[o+1], ... (< n)
-// through a 16-byte register buffer: a thread's output is a contiguous run, so apart from its ragged ends it is written as
-// aligned 8-symbol vectors (a 2-byte store per symbol per lane was 8x the memory requests).
-template <bool WRITE>
-__device__ __forceinline__ unsigned hdec_run(const unsigned char *__restrict__ bits, u64 total_bits, const unsigned *tab,
-                                             u64 pos, u64 limit, u64 *endpos, uint16_t *out, int64_t o, int64_t n)
+// ---- the tree walk, SZH_LUT_BITS bits at a time.  One bit per step is one dependent LDS read per bit: 1024 round trips per
+// sub-sequence.  Entry `idx` of the table says what the tree does with the next SZH_LUT_BITS bits idx: the symbols of the (at
+// most 4) codewords that END inside them (x, y: four 16-bit symbols, unused ones zero) and w = nsym | nbits << 4 | node << 8 --
+// nbits = where the last of them ends; nsym = 0 when the first codeword is longer than the window: `node` is where the walk
+// stands after all SZH_LUT_BITS bits.  Smooth fields spend ~2 bits per symbol, so a look-up yields 3 - 4 symbols.  The counting
+// pass reads a second table of the w words alone (4 KB instead of 16: fewer LDS bank conflicts among 64 random indices).
+// The look-ups stop SZH_LUT_BITS bits before `limit`; the last few symbols go bit by bit, which keeps "the first codeword boundary
+// at or after limit" exactly what it is in a plain walk -- the fixed point of the propagation is the sequential decode.
+#define SZH_LUT_BITS 10
+#define SZH_LUT_SIZE (1 << SZH_LUT_BITS)
+#define SZH_LUT_BYTES (SZH_LUT_SIZE * 16 + SZH_LUT_SIZE * 4)      /* uint4 entries, then the w words */
+__global__ __launch_bounds__(256) void k_hdec_build_lut(const unsigned *__restrict__ table, uint4 *lut)
 {
-    unsigned cnt = 0, node = 0;
-    u64 p = pos, last_boundary = pos;
-    bool done = false;
-    u64 lo = 0, hi = 0;            // symbols [oi & ~7, oi) of the current 8-symbol group
+    const unsigned idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= SZH_LUT_SIZE) return;
+    unsigned node = 0, nsym = 0, nbits = 0, sy[4] = {0, 0, 0, 0};
+    for (int b = 0; b < SZH_LUT_BITS; ++b) {
+        const unsigned nx = table[2 * node + ((idx >> (SZH_LUT_BITS - 1 - b)) & 1u)];
+        if (nx & 0x80000000u) {
+            sy[nsym++] = nx & 0xffffu; nbits = (unsigned)b + 1; node = 0;
+            if (nsym == 4) break;
+        } else node = nx;
+    }
+    uint4 e;
+    e.x = sy[0] | (sy[1] << 16); e.y = sy[2] | (sy[3] << 16); e.z = 0;
+    e.w = nsym ? (nsym | (nbits << 4)) : ((unsigned)SZH_LUT_BITS << 4 | (node << 8));
+    lut[idx] = e;
+    reinterpret_cast<unsigned *>(lut + SZH_LUT_SIZE)[idx] = e.w;
+}
+// decodes from LOCAL bit `pos` to the first codeword boundary at or after `limit` (never past `total`, the stream's end in local
+// bits); *endpos = that boundary; returns the number of symbols.
+// WRITE: the thread's symbols are the run out[o, oend), assembled as aligned groups of 8 in two 64-bit registers (lo: slots 0-3,
+// hi: slots 4-7) and stored 16 bytes at a time; a look-up's symbols are appended with two shifts.  Measured alternatives at 512^3:
+// one 2-byte-aligned 16-byte store per look-up 0.67 ms (unaligned stores are split), a 128-bit accumulator with six symbols per
+// look-up 0.42 ms, one symbol at a time with the bit-by-bit walk 0.50 ms.
+#ifdef SZH_DBG_HDEC_TIME
+__device__ unsigned hdec_dbg_lookups_dummy;
+#define hdec_dbg_lookups hdec_dbg_lookups_v
+#endif
+template <bool WRITE>
+__device__ __forceinline__ unsigned hdec_run_lut(const SZH_LDS unsigned *l, unsigned total, const SZH_LDS unsigned *ltab, const unsigned *gtab, const SZH_LDS void *lut,
+                                                 unsigned pos, unsigned limit, unsigned *endpos, uint16_t *out, int64_t o, int64_t oend, bool enabled = true)
+{   // enabled = false: nothing to decode (the lane only keeps its wavefront company)
+    unsigned cnt = 0, p = pos, last_boundary = pos;
+#ifdef SZH_DBG_HDEC_TIME
+    unsigned hdec_dbg_lookups_v = 0;
+#endif
+    bool done = !enabled;
     int64_t oi = o;                // next output index
-    auto flush_partial = [&](int64_t from, int64_t to) { // scalar stores of buffered symbols [from, to), same group
-        for (int64_t i = from; i < to; ++i) {
-            const int q = (int)(i & 7);
-            out[i] = (uint16_t)(q < 4 ? (lo >> (16 * q)) : (hi >> (16 * (q - 4))));
+    u64 lo = 0, hi = 0;            // the group of oi: symbols [oi & ~7, oi) at their slots
+    auto store_slots = [&](int64_t g0, int64_t from, int64_t to) {
+        // NOT to be vectorised: hipcc turns the 2-byte stores into wider stores at 2-byte alignment, and those are not safe beside the
+        // neighbouring thread's symbols in the same dword (measured: ~1600 of 134 M symbols corrupted per call, different ones each time)
+#ifndef SZH_HIPSIM
+#pragma clang loop vectorize(disable) unroll(disable)
+#endif
+        for (int64_t i = from; i < to; ++i) { const int k = (int)(i - g0); out[i] = (uint16_t)(k < 4 ? lo >> (16 * k) : hi >> (16 * (k - 4))); }
+    };
+    auto put = [&](u64 E, unsigned ns) {                  // ns (1 .. 4) symbols, 16 bits each from bit 0 of E, nothing above them
+        if (!WRITE) return;
+        if (oi + (int64_t)ns > oend) { if (oi >= oend) return; ns = (unsigned)(oend - oi); E &= ~0ull >> (64 - 16 * ns); }
+        const unsigned q = (unsigned)(oi & 7);
+        u64 carry = 0;
+        if (q < 4) { lo |= E << (16 * q); if (q) hi |= E >> (64 - 16 * q); }
+        else { hi |= E << (16 * (q - 4)); if (q > 4) carry = E >> (128 - 16 * q); }
+        oi += ns;
+        if (q + ns >= 8) {
+            const int64_t g0 = oi - (q + ns);
+            if (g0 >= o) { uint4 w; w.x = (unsigned)lo; w.y = (unsigned)(lo >> 32); w.z = (unsigned)hi; w.w = (unsigned)(hi >> 32);
+                           *reinterpret_cast<uint4 *>(out + g0) = w; }
+            else store_slots(g0, o, g0 + 8);
+            lo = carry; hi = 0;
         }
     };
-    while (p < total_bits && !done) {
-        u64 win = hdec_window(bits, p >> 3) << (p & 7);
-        int avail = 64 - (int)(p & 7);
-        if ((u64)avail > total_bits - p) avail = (int)(total_bits - p);
+    const unsigned lim = limit < total ? limit : total;
+    // one step of the tree (LDS copy of the node table when there is one: a flat load costs several times a ds_read, and with 64 lanes
+    // and 3 - 4 symbols per look-up some lane meets a code longer than the window in every other iteration)
+    auto step = [&](unsigned node, unsigned b) -> unsigned { return ltab ? ltab[2 * node + b] : gtab[2 * node + b]; };
+    // (a wavefront-wide loop with masked updates instead of this per-lane exit was measured slower: 0.20 ms against 0.18 for the pass)
+    while (!done && p + SZH_LUT_BITS <= lim) {
+#ifdef SZH_DBG_HDEC_TIME
+        ++hdec_dbg_lookups;
+#endif
+        unsigned win = hdec_w32(l, p);
+        const unsigned idx = win >> (32 - SZH_LUT_BITS);
+        unsigned w;
+        if (WRITE) {
+            const szh_rb::v4u e = reinterpret_cast<const SZH_LDS szh_rb::v4u *>(lut)[idx];
+            w = e.w;
+            if (w & 15u) put((u64)e.x | ((u64)e.y << 32), w & 15u);
+        } else w = reinterpret_cast<const SZH_LDS unsigned *>(lut)[idx];
+        const unsigned ns = w & 15u;
+        p += (w >> 4) & 15u;
+        if (ns) { cnt += ns; last_boundary = p; if (p >= limit) done = true; continue; }
+        // a codeword longer than the window: on from the node the table names, bit by bit -- first through the 22 bits still in `win`
+        unsigned node = w >> 8;
+        win <<= SZH_LUT_BITS;
+        unsigned have = 32 - SZH_LUT_BITS;
+        while (p < total) {
+            if (have == 0) { win = hdec_w32(l, p); have = 32; }
+            const unsigned b = win >> 31;
+            win <<= 1; --have; ++p;
+            const unsigned nx = step(node, b);
+            if (nx & 0x80000000u) { put((u64)(nx & 0xffffu), 1); ++cnt; last_boundary = p; node = 0; break; }
+            node = nx;
+        }
+        if (node != 0 || p >= limit) done = true;          // (node != 0: the stream ended inside a codeword)
+    }
+    // the last stretch before `limit` (and before the end of the stream) bit by bit
+    unsigned node = 0;
+    while (p < total && !done) {
+        unsigned win = hdec_w32(l, p);
+        unsigned avail = total - p < 32u ? total - p : 32u;
         for (; avail > 0; --avail) {
-            const unsigned b = (unsigned)(win >> 63);
+            const unsigned b = win >> 31;
             win <<= 1; ++p;
-            const unsigned nx = tab[2 * node + b];
+            const unsigned nx = step(node, b);
             if (nx & 0x80000000u) {
-                if (WRITE && oi < n) {
-                    const int q = (int)(oi & 7);
-                    const u64 sym = (u64)(nx & 0xffffu);
-                    if (q < 4) lo |= sym << (16 * q); else hi |= sym << (16 * (q - 4));
-                    ++oi;
-                    if (q == 7) {
-                        if (oi - 8 >= o) { uint4 w; w.x = (unsigned)lo; w.y = (unsigned)(lo >> 32); w.z = (unsigned)hi; w.w = (unsigned)(hi >> 32);
-                                           *reinterpret_cast<uint4 *>(out + oi - 8) = w; }
-                        else flush_partial(o, oi);
-                        lo = 0; hi = 0;
-                    }
-                }
+                put((u64)(nx & 0xffffu), 1);
                 ++cnt; node = 0; last_boundary = p;
                 if (p >= limit) { done = true; break; }
             } else node = nx;
         }
     }
-    if (WRITE && (oi & 7)) { const int64_t g0 = oi & ~(int64_t)7; flush_partial(g0 > o ? g0 : o, oi); }
+    if (WRITE && (oi & 7)) { const int64_t g0 = oi & ~(int64_t)7; store_slots(g0, g0 > o ? g0 : o, oi); }
     *endpos = last_boundary;
+#ifdef SZH_DBG_HDEC_TIME
+    if (!WRITE) atomicAdd(&hdec_dbg_lookups_dummy, hdec_dbg_lookups_v);
+#endif
     return cnt;
 }
 
+// n16 16-byte vectors global -> LDS, four loads in flight per thread (a plain loop waits for every load before the next: the tables
+// and the stretch are ~50 KB per workgroup, 25 dependent round trips)
+template <bool SWAP>
+__device__ __forceinline__ void hdec_copy16(uint4 *dst, const uint4 *__restrict__ src, int n16)
+{
+    for (int base = 0; base < n16; base += 1024) {
+        uint4 r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int i = base + k * 256 + (int)threadIdx.x; r[k] = i < n16 ? src[i] : make_uint4(0, 0, 0, 0); }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = base + k * 256 + (int)threadIdx.x;
+            if (i >= n16) continue;
+            uint4 v = r[k];
+            if (SWAP) { v.x = __builtin_bswap32(v.x); v.y = __builtin_bswap32(v.y); v.z = __builtin_bswap32(v.z); v.w = __builtin_bswap32(v.w); }
+            dst[i] = v;
+        }
+    }
+}
+// the stretch itself: byte-swapped words to their swizzled places (four loads in flight per thread as above)
+__device__ __forceinline__ void hdec_stage16(unsigned *dst, const uint4 *__restrict__ src, int n16)
+{
+    for (int base = 0; base < n16; base += 1024) {
+        uint4 r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int i = base + k * 256 + (int)threadIdx.x; r[k] = i < n16 ? src[i] : make_uint4(0, 0, 0, 0); }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = base + k * 256 + (int)threadIdx.x;
+            if (i >= n16) continue;
+            unsigned *d = dst + SZH_HDEC_SWZ(4 * i);                    // (words 4 i .. 4 i + 3 lie in one group of 32)
+            d[0] = __builtin_bswap32(r[k].x); d[1] = __builtin_bswap32(r[k].y); d[2] = __builtin_bswap32(r[k].z); d[3] = __builtin_bswap32(r[k].w);
+        }
+    }
+}
+// dynamic LDS of the decoding kernels: [staged words SZH_HDEC_LDS][look-up table: WRITE 16 KB of uint4, counting 4 KB of w words]
+// [the node table when a.table_in_lds (its size rounded up to 16 bytes)]
+template <bool WRITE>
+__device__ __forceinline__ szh_hdec_src hdec_prologue(const szh_hdec_args &a, char *smem, int64_t blk, const SZH_LDS void *&lut, const SZH_LDS unsigned *&ltab)
+{
+    char *q = smem + SZH_HDEC_LDS;
+    lut = (const SZH_LDS void *)q;
+    if (WRITE) { hdec_copy16<false>(reinterpret_cast<uint4 *>(q), a.lut, SZH_LUT_SIZE); q += SZH_LUT_SIZE * 16; }
+    else { hdec_copy16<false>(reinterpret_cast<uint4 *>(q), a.lut + SZH_LUT_SIZE, SZH_LUT_SIZE / 4); q += SZH_LUT_SIZE * 4; }
+    ltab = nullptr;
+    if (a.table_in_lds) { hdec_copy16<false>(reinterpret_cast<uint4 *>(q), reinterpret_cast<const uint4 *>(a.table), (2 * a.n_nodes + 3) / 4); ltab = (const SZH_LDS unsigned *)q; }
+    // the stretch: from a 16-byte aligned ADDRESS at or below its first byte minus the margin
+    szh_hdec_src S;
+    int64_t lo = blk * (256 * SZH_SUBSEQ_BITS / 8) - SZH_HDEC_MARGIN;
+    lo -= (int64_t)((uintptr_t)(a.bits + lo) & 15u);
+    if (lo < -(int64_t)a.bytes_before) lo += ((-(int64_t)a.bytes_before - lo) + 15) / 16 * 16;     // (not in front of the buffer the payload lies in)
+    int64_t hi = lo + SZH_HDEC_STAGE - 16;                                            // (the last 16 bytes of the LDS area: the slack word)
+    const int64_t end = (int64_t)((a.total_bits + 7) / 8) + 32;                       // the buffer is padded by 64 bytes
+    if (hi > end) hi = lo + (end - lo) / 16 * 16;
+    if (hi < lo) hi = lo;
+    hdec_stage16(reinterpret_cast<unsigned *>(smem), reinterpret_cast<const uint4 *>(a.bits + lo), (int)((hi - lo) / 16));
+    S.l = (const SZH_LDS unsigned *)smem; S.bit0 = lo * 8; S.nbits = (unsigned)((hi - lo) * 8);
+    return S;
+}
 __global__ __launch_bounds__(256) void k_hdec_pass(szh_hdec_args a)
 {
     SZH_DYN_SMEM(smem);
-    unsigned *lt = reinterpret_cast<unsigned *>(smem);
-    const unsigned *tab = a.table;
-    if (a.table_in_lds) {
-        for (int i = threadIdx.x; i < 2 * a.n_nodes; i += 256) lt[i] = a.table[i];
-        __syncthreads();
-        tab = lt;
-    }
+    __shared__ unsigned hflag;
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (s >= a.nsub || !a.dirty[s]) return;
-    a.dirty[s] = 0;
-    const u64 limit = (u64)(s + 1) * SZH_SUBSEQ_BITS;
-    u64 endp;
-    const u64 st = a.starts[s];
-    unsigned cnt = 0;
-    if (st >= limit) endp = st; // the previous codeword swallowed this whole subsequence
-    else cnt = hdec_run<false>(a.bits, a.total_bits, tab, st, limit, &endp, nullptr, 0, 0);
-    a.ends[s] = endp; a.counts[s] = cnt;
+    const bool mine = s < a.nsub && a.dirty[s];
+    if (threadIdx.x == 0) hflag = 0u;
+    __syncthreads();
+    if (mine) hflag = 1u;
+    __syncthreads();
+    if (!hflag) return;                                       // (later rounds: most workgroups have nothing to redo)
+#ifdef SZH_DBG_HDEC_TIME
+    const long long t0 = clock64();
+#endif
+    const SZH_LDS void *lut; const SZH_LDS unsigned *ltab;
+    const szh_hdec_src S = hdec_prologue<false>(a, smem, blockIdx.x, lut, ltab);
+    __syncthreads();
+#ifdef SZH_DBG_HDEC_TIME
+    const long long t1 = clock64();
+#endif
+    if (mine) a.dirty[s] = 0;
+    const u64 total_g = a.total_bits;
+    const unsigned total = (unsigned)((int64_t)total_g - S.bit0 < (int64_t)S.nbits ? (int64_t)total_g - S.bit0 : (int64_t)S.nbits);
+    const u64 first_g = (u64)s * SZH_SUBSEQ_BITS, limit_g = first_g + SZH_SUBSEQ_BITS;
+    const unsigned first = mine ? (unsigned)((int64_t)first_g - S.bit0) : SZH_WARMUP_BITS, limit = first + SZH_SUBSEQ_BITS;
+    u64 st_g = mine ? a.starts[s] : 0;
+    unsigned endl;
+    if (a.warmup) {
+        // first round: instead of guessing that a codeword starts at the sub-sequence's first bit (it rarely does, so that the first
+        // propagation moved every start and the whole pass ran twice), decode SZH_WARMUP_BITS ahead of it: Huffman codes fall into
+        // step after a few symbols, so the first boundary at or after the sub-sequence's first bit is almost always the true start
+        // (84 of 287 393 were not at 512^3; they are redone in a second round)
+        const bool wu = mine && s > 0;
+        hdec_run_lut<false>(S.l, total, ltab, a.table, lut, first - SZH_WARMUP_BITS, first, &endl, nullptr, 0, 0, wu);
+        if (wu) {
+            if (endl < first) endl = first;                  // (only at the very end of the stream)
+            st_g = (u64)(S.bit0 + (int64_t)endl);
+            a.starts[s] = st_g;
+        }
+    }
+    // a start beyond the staged stretch: only when the previous codeword swallowed this whole sub-sequence (st >= limit)
+    const bool run = mine && st_g < limit_g;
+    const unsigned cnt = hdec_run_lut<false>(S.l, total, ltab, a.table, lut, run ? (unsigned)((int64_t)st_g - S.bit0) : 0u, limit, &endl, nullptr, 0, 0, run);
+    if (mine) { a.ends[s] = run ? (u64)(S.bit0 + (int64_t)endl) : st_g; a.counts[s] = run ? cnt : 0u; }
+#ifdef SZH_DBG_HDEC_TIME
+    if ((threadIdx.x & 63) == 0) { u64 *dbg = (u64 *)a.changed + 4; atomicAdd((unsigned long long *)&dbg[0], (unsigned long long)(t1 - t0)); atomicAdd((unsigned long long *)&dbg[1], (unsigned long long)(clock64() - t1)); atomicAdd((unsigned long long *)&dbg[2], 1ull); }
+    if (threadIdx.x == 0 && blockIdx.x == 0) ((u64 *)a.changed)[7] = hdec_dbg_lookups_dummy;
+#endif
 }
 __global__ __launch_bounds__(256) void k_hdec_update(szh_hdec_args a)
 {
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (s < 1 || s >= a.nsub) return;
     const u64 ns = a.ends[s - 1];
-    if (a.starts[s] != ns) { a.starts[s] = ns; a.dirty[s] = 1; *a.changed = 1u; }
+    if (a.starts[s] != ns) { a.starts[s] = ns; a.dirty[s] = 1; atomicAdd(a.changed, 1u); }       // (a count: the host only asks whether it is zero)
 }
 __global__ __launch_bounds__(256) void k_hdec_init(szh_hdec_args a)
 {
@@ -1191,20 +1381,19 @@ __global__ __launch_bounds__(256) void k_hdec_init(szh_hdec_args a)
 __global__ __launch_bounds__(256) void k_hdec_write(szh_hdec_args a, const u64 *__restrict__ offs, uint16_t *out, int64_t n)
 {
     SZH_DYN_SMEM(smem);
-    unsigned *lt = reinterpret_cast<unsigned *>(smem);
-    const unsigned *tab = a.table;
-    if (a.table_in_lds) {
-        for (int i = threadIdx.x; i < 2 * a.n_nodes; i += 256) lt[i] = a.table[i];
-        __syncthreads();
-        tab = lt;
-    }
+    const SZH_LDS void *lut; const SZH_LDS unsigned *ltab;
+    const szh_hdec_src S = hdec_prologue<true>(a, smem, blockIdx.x, lut, ltab);
+    __syncthreads();
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (s >= a.nsub) return;
-    const u64 limit = (u64)(s + 1) * SZH_SUBSEQ_BITS, st = a.starts[s];
-    const int64_t o = (int64_t)offs[s];
-    if (st >= limit || o >= n) return;
-    u64 endp;
-    hdec_run<true>(a.bits, a.total_bits, tab, st, limit, &endp, out, o, n);
+    const bool in = s < a.nsub;
+    const u64 limit_g = (u64)(s + 1) * SZH_SUBSEQ_BITS, st_g = in ? a.starts[s] : limit_g;
+    const int64_t o = in ? (int64_t)offs[s] : n;
+    const bool run = st_g < limit_g && o < n;
+    int64_t oend = run ? o + (int64_t)a.counts[s] : o;
+    if (oend > n) oend = n;
+    const unsigned total = (unsigned)((int64_t)a.total_bits - S.bit0 < (int64_t)S.nbits ? (int64_t)a.total_bits - S.bit0 : (int64_t)S.nbits);
+    unsigned endl;
+    hdec_run_lut<true>(S.l, total, ltab, a.table, lut, run ? (unsigned)((int64_t)st_g - S.bit0) : 0u, run ? (unsigned)((int64_t)limit_g - S.bit0) : 0u, &endl, out, o, oend, run);
 }
 __global__ __launch_bounds__(256) void k_fill_u16(uint16_t *p, int64_t n, uint16_t v)
 {
