@@ -280,8 +280,9 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
     achieved = nbytes_in / (quant_avg_ms * 1e-3) / 1e9 if quant_avg_ms > 0 else 0.0     # (the CPU shim of --dry-run has no device events)
     # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside the timed process);
     # only valid for the workload it was measured on
+    kname = "k_ribbon<float,false,false>" if getattr(stats, "quant_kernel", 0) == 1 else "k_pencil<float,false>"
     traffic, traffic_src = None, None
-    for name in ("r02_pmc_traffic_pencil.json", "r01_pmc_traffic_pencil.json"):
+    for name in (("r03_pmc_traffic_ribbon.json",) if kname.startswith("k_ribbon") else ("r02_pmc_traffic_pencil.json", "r01_pmc_traffic_pencil.json")):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", name)))
             if n == EDGE:
@@ -290,7 +291,6 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
                 break
         except (OSError, KeyError, ValueError):
             pass
-    kname = "k_ribbon<float,false,false>" if getattr(stats, "quant_kernel", 0) == 1 else "k_pencil<float,false>"
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": nbytes_in, "avg_kernel_ms": round(quant_avg_ms, 4)}
@@ -298,7 +298,7 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
     # ---- arrays in flight: the same args.steps compressions with 1 / 2 / 4 lanes (outside the timed region), with the sweep kernel's own
     # time per K so that interference is visible; and every stream of the last run against the one a single blocking call gives
     concurrent = None
-    if world == 1 and not getattr(args, "dry_run", False):
+    if world == 1 and not getattr(args, "dry_run", False) and not args.timed_only:
         ref_size, _, ref_ob = one_step()
         _sync(torch)
         ref_bytes = ref_ob[:ref_size].clone()
@@ -447,7 +447,7 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
 
     # ---- host-pointer API, PCIe included (never the headline value)
     e2e = None
-    if world == 1 and n == EDGE:
+    if world == 1 and n == EDGE and not args.timed_only:
         assert sz_amd.SZ_Init(os.path.join(ROOT, "tests", "golden", "sz_speed.config")) == 0
         L = sz_amd.lib()
         dims = (0, 0, n, n, n)
@@ -604,6 +604,8 @@ def main():
     ap.add_argument("--other-paths", action="store_true", help="also time the SZ 1.4 container, a 2-D array and a 1-D series (one line each)")
     ap.add_argument("--no-fast", action="store_true", help="skip the opt-in fast-mode object")
     ap.add_argument("--no-m-field", action="store_true")
+    ap.add_argument("--timed-only", action="store_true", help="only the headline: priming, warm-up, the timed steps, one decompression (for "
+                    "rocprofv3 --stats: every launch of the sweep kernel then runs as in the timed region)")
     ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the entry on gloo + the HIP-on-CPU shim (tests only)")
     ap.add_argument("--inflight", type=int, default=2, help="arrays in flight per GPU in the timed region (szhip_pool lanes); 1 = one blocking call after the other")
     args = ap.parse_args()
@@ -625,6 +627,8 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))
+    if args.timed_only:
+        args.no_cpu_baseline = args.no_fast = args.no_m_field = True
     if args.dry_run:
         # CPU rehearsal of the multi-rank entry (tests/test_distributed_cpu.py): gloo + the product's code on the HIP-on-CPU shim, tiny
         # arrays, no GPU.  Nothing it prints is a measurement.
