@@ -30,8 +30,8 @@
 // Longest dependency path of a launch (512^3 float, R = 2, W = 8): r2 + 8 * 64 lane steps along dim 1 + 256 ring hand-offs + 32 + 8
 // tile hand-offs, against 1536 steps + 128 pencil hops before; a step is ~60 instructions for 128 points.
 //
-// Codes leave in NATURAL order as before (k_permute does the block ordering): each lane packs the 16 codes of a trip and its row into
-// eight registers and stores them as two 16-byte vectors (2-byte aligned: gfx950 takes them, tools/ubench/ub_mem.hip).
+// Codes: compression leaves them in RIBBON ORDER (below: one coalesced 1 KB store per instruction; k_permute<0> gathers the block
+// order from it); decompression reads natural-order codes and writes natural-order values.
 //
 // Covers: 3-D arrays, float / double, compress / decompress, with / without the mean shortcut, Lorenzo-only block maps
 // (`no_reg`; the host sends everything else to k_pencil).
