@@ -143,3 +143,36 @@ def test_hip_fast_mode_512_round_trip_and_api_switch(built):
         sz_amd.SZ_Finalize()
     finally:
         os.environ.pop("SZ_HIP_MODE", None)
+
+
+def test_huffman_decoder_blocks_long_codes_and_repair_rounds_on_cpu_shim(oracle, built):
+    """The round-3 Huffman decoder (look-up table over LDS-staged bits, szhip_kernels.h `k_hdec_*`) through the product code on the CPU
+    shim, on payloads that span several workgroup blocks (256 sub-sequences = 32 KB each), with codes longer than the 10-bit window
+    (wide symbol distributions) and with warm-up guesses that need the repair round: decoded values must be the oracle decoder's bit
+    for bit, for the exact SZ 2.1 path and for the fast-mode container."""
+    import sim_lib
+    import sz_amd
+    from sz_amd import api
+    saved = api._lib
+    rng = np.random.default_rng(11)
+    cases = [("noise-wide", rng.standard_normal((40, 48, 64)).astype(np.float32), 2e-4),            # ~12 bits per symbol: long codes, 6 blocks
+             ("smooth+noise", (s_field(30, 64, 96) + 0.003 * rng.standard_normal((30, 64, 96))).astype(np.float32), 1e-4),
+             ("two-symbols", np.where(rng.random((24, 40, 70)) < 0.03, 1.0, 0.0).astype(np.float32), 1e-3)]   # 1-bit codes: 4 symbols per look-up
+    try:
+        api._lib = api._bind(ctypes.CDLL(sim_lib.shim_path()))
+        assert sz_amd.SZ_Init(os.path.join(ROOT, "tests", "golden", "sz_speed.config")) == 0
+        ctx = sz_amd.HipContext(0)
+        for name, d, eb in cases:
+            ref_stream, _ = oracle.compress(d, oracle.ABS, eb)
+            ref_dec = oracle.decompress(ref_stream, d.shape, d.dtype)
+            got = sz_amd.SZ_decompress(ref_stream, d.shape, d.dtype)
+            assert np.array_equal(got.view(np.uint32), ref_dec.view(np.uint32)), name
+            fs = oracle.fast_compress(d, eb)
+            out = np.empty_like(d)
+            buf = ctypes.create_string_buffer(fs, len(fs))
+            ctx.decompress_fast(ctypes.addressof(buf), False, len(fs), d.shape, d.dtype, out.ctypes.data, False)
+            assert np.array_equal(out.view(np.uint32), oracle.fast_decompress(fs, d.shape, d.dtype).view(np.uint32)), name
+        ctx.close()
+        sz_amd.SZ_Finalize()
+    finally:
+        api._lib = saved
