@@ -172,7 +172,15 @@ def test_huffman_decoder_blocks_long_codes_and_repair_rounds_on_cpu_shim(oracle,
             buf = ctypes.create_string_buffer(fs, len(fs))
             ctx.decompress_fast(ctypes.addressof(buf), False, len(fs), d.shape, d.dtype, out.ctypes.data, False)
             assert np.array_equal(out.view(np.uint32), oracle.fast_decompress(fs, d.shape, d.dtype).view(np.uint32)), name
+        # the decoder runs two rounds without asking the device in between; a call whose starts were still moving is repeated with a
+        # synchronisation per round (with_ticket_fallback): forced here
+        os.environ["SZ_HIP_TEST_HDEC_FALLBACK"] = "1"
+        name, d, eb = cases[1]
+        ref_stream, _ = oracle.compress(d, oracle.ABS, eb)
+        got = sz_amd.SZ_decompress(ref_stream, d.shape, d.dtype)
+        assert np.array_equal(got.view(np.uint32), oracle.decompress(ref_stream, d.shape, d.dtype).view(np.uint32))
         ctx.close()
         sz_amd.SZ_Finalize()
     finally:
+        os.environ.pop("SZ_HIP_TEST_HDEC_FALLBACK", None)
         api._lib = saved
