@@ -223,6 +223,7 @@ template <class T> struct lds_t {
                         //              cnt[W + 1] = steps DRAIN has forwarded (of ring W and of every right ring); left[w] = indices of
                         //              the left rings complete for wavefront w
     SZH_LDS int *scratch; // [64]: FILL_L (per-row values for a per-wavefront minimum)
+    SZH_LDS T *tbuf;    // inverse only: [W][64][U + 4]: a trip's results of one row, transposed on their way to memory (store_trip)
 };
 
 // bounded wait until an LDS word reaches `need` (a lost hand-off must end the launch, not hang the GPU)
@@ -297,9 +298,11 @@ __device__ __forceinline__ void ribbon_body(const szh_qargs<T> &a, const int TI,
     const uint64_t span_x = (uint64_t)rest * sizeof(T), span_c = (uint64_t)rest * 2 + 8;
     const rsrc_t rsx = make_rsrc((DEC ? (const T *)a.out : a.data) + tile_base, span_x > 0x7ffffff0ull ? 0x7ffffff0u : (unsigned)span_x);
     // codes: natural order for the inverse; ribbon order (this tile's region) for compression
-    const rsrc_t rsc = DEC ? make_rsrc(a.codes + tile_base, span_c > 0x7ffffff0ull ? 0x7ffffff0u : (unsigned)span_c)
+    const bool crb = !DEC || a.codes_ribbon;                   // (uniform)
+    const rsrc_t rsc = !crb ? make_rsrc(a.codes + tile_base, span_c > 0x7ffffff0ull ? 0x7ffffff0u : (unsigned)span_c)
                            : make_rsrc(a.codes + ((int64_t)TI * a.nJ + TJ) * ((int64_t)NT * WR * 64), (unsigned)((size_t)NT * WR * 64 * 2));
-    bool rowok[R];
+    bool rowok[R], iok[R];
+    int reli[R];             // the dim-0 part of rowrel (the same for every lane)
     int rowrel[R];           // element offset of (row, column 0 of dim 2) from the tile base
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -307,6 +310,7 @@ __device__ __forceinline__ void ribbon_body(const szh_qargs<T> &a, const int TI,
         rowok[r] = i < r0 && j < r1;
         const int ic = i < r0 ? i : r0 - 1, jc = j < r1 ? j : r1 - 1;
         rowrel[r] = (int)((int64_t)(ic - TI * WR) * G.d0 + (int64_t)jc * G.d1);
+        reli[r] = (int)((int64_t)(ic - TI * WR) * G.d0); iok[r] = i < r0;
     }
     // LDS addresses
     const SZH_LDS T *const rin = L.ring + (w == 0 ? 0 : S::RLU * 64 + (w - 1) * S::RL * 64) + lane;     // ring w: read
@@ -357,10 +361,13 @@ __device__ __forceinline__ void ribbon_body(const szh_qargs<T> &a, const int TI,
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int k0 = tt0 - sh - lane - r;
-            const unsigned off = (unsigned)((rowrel[r] + k0) * 2);
+            // ribbon order (the layout compression stores, below): one coalesced 1 KB load per instruction; natural order: 16-byte pieces
+            // of 64 different rows at 2-byte alignment (split by the memory pipeline: the 2.9 ms of the first inverse)
+            const unsigned off = crb ? (unsigned)(((((tt0 / U) * W + w) * R + r) * (U / 8)) * 1024 + lane * 16) : (unsigned)((rowrel[r] + k0) * 2);
+            const unsigned pitch = crb ? 1024u : 16u;
 #pragma unroll
             for (int v = 0; v < U / 8; ++v) {
-                const v4u q = bload16(rsc, off + 16u * v);
+                const v4u q = bload16(rsc, off + pitch * v);
                 c[r][4 * v] = q.x; c[r][4 * v + 1] = q.y; c[r][4 * v + 2] = q.z; c[r][4 * v + 3] = q.w;
             }
         }
@@ -376,19 +383,37 @@ __device__ __forceinline__ void ribbon_body(const szh_qargs<T> &a, const int TI,
                 for (int v = 0; v < U / 8; ++v) { v4u q = {c[r][4 * v], c[r][4 * v + 1], c[r][4 * v + 2], c[r][4 * v + 3]}; bstore16(rsc, off + 1024u * v, q); }
                 continue;
             }
+            if (DEC && !edge) {
+                // The trip's U values of this row are U * sizeof(T) contiguous bytes per lane -- in 64 different rows of the array.  Stored
+                // straight from the registers, every instruction writes 16 bytes to each of 64 rows (measured: those stores cost
+                // 1.5 ms of the 2.5 ms the first inverse took, 0.59 ms being the sweep itself).  Through LDS the block is transposed
+                // so that NVEC neighbouring lanes write one row's bytes: an instruction covers 64 / NVEC rows with whole 64-byte pieces.
+                // (LDS executes a wavefront's accesses in order: no wait between the writes and the reads of the other lanes' words.)
+                constexpr int TP = U + 4;
+                SZH_LDS T *const tb = L.tbuf + w * 64 * TP;
+#pragma unroll
+                for (int v = 0; v < NVEC; ++v) {
+                    T tmp[VPT];
+#pragma unroll
+                    for (int e = 0; e < VPT; ++e) tmp[e] = x[r][v * VPT + e];
+                    v4u q; __builtin_memcpy(&q, tmp, 16);
+                    *(SZH_LDS v4u *)(tb + lane * TP + v * VPT) = q;
+                }
+                lds_order();
+                const int seg = lane % NVEC, jl = lane / NVEC;
+#pragma unroll
+                for (int q4 = 0; q4 < NVEC; ++q4) {
+                    const int jj = jl + (64 / NVEC) * q4;                    // the lane (= column of dim 1) whose values these are
+                    const v4u q = *(const SZH_LDS v4u *)(tb + jj * TP + seg * VPT);
+                    const int jg = TJ * 64 + jj;
+                    const unsigned off = (unsigned)((reli[r] + jg * (int)G.d1 + (tt0 - sh - jj - r) + seg * VPT) * (int)sizeof(T));
+                    if (iok[r] && jg < r1) bstore16(rsx, off, q);
+                }
+                lds_order();                                                 // (the next row's words go to the same place)
+                continue;
+            }
             if (!rowok[r]) continue;
             if (!edge) {
-                if (DEC) {
-                    const unsigned off = (unsigned)((rowrel[r] + k0) * (int)sizeof(T));
-#pragma unroll
-                    for (int v = 0; v < NVEC; ++v) {
-                        T tmp[VPT];
-#pragma unroll
-                        for (int e = 0; e < VPT; ++e) tmp[e] = x[r][v * VPT + e];
-                        v4u q; __builtin_memcpy(&q, tmp, 16);
-                        bstore16(rsx, off + 16u * v, q);
-                    }
-                }
             } else {
 #pragma unroll
                 for (int s = 0; s < U; ++s) {
@@ -768,6 +793,7 @@ __global__ __launch_bounds__((szh_rb_shape<T>::W + 3) * 64) void k_ribbon(szh_qa
     __shared__ T rr[S::RLR * WR];
     __shared__ unsigned P[2 * (W + 2)];
     __shared__ int scratch[64];
+    __shared__ __attribute__((aligned(16))) T tbuf[DEC ? W * 64 * (S::U + 4) : 4];
     __shared__ unsigned tk_s;
     if (threadIdx.x < 2 * (W + 2)) P[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
@@ -778,7 +804,7 @@ __global__ __launch_bounds__((szh_rb_shape<T>::W + 3) * 64) void k_ribbon(szh_qa
     const unsigned ij = (unsigned)uni((int)tk_s);
     const int w = uni((int)(threadIdx.x >> 6));
     const int TI = (int)(ij >> 16), TJ = (int)(ij & 0xffffu);
-    const lds_t<T> L{(SZH_LDS T *)ring, (SZH_LDS T *)lr, (SZH_LDS T *)rr, (SZH_LDS unsigned *)P, (SZH_LDS int *)scratch};
+    const lds_t<T> L{(SZH_LDS T *)ring, (SZH_LDS T *)lr, (SZH_LDS T *)rr, (SZH_LDS unsigned *)P, (SZH_LDS int *)scratch, (SZH_LDS T *)tbuf};
 #ifndef SZH_RB_PRIO
 #define SZH_RB_PRIO 1
 #endif

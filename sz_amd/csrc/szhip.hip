@@ -1164,7 +1164,21 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
     TRY(ensure(ctx, ctx->small, SM_COUNT * 8));
     u64 *sm = (u64 *)ctx->small.p;
     HIPCHK(hipMemsetAsync(sm, 0, SM_COUNT * 8, st));
-    TRY(ensure(ctx, ctx->codes_nat, (size_t)n * 2 + 64));
+    // the inverse sweep: k_pencil on natural-order codes by default.  SZ_HIP_RIBBON_DEC=1: k_ribbon where it applies (3-D, no regression
+    // block), fed with ribbon-order codes by k_permute<1>, its results transposed through LDS into 64-byte pieces -- correct and tested, but
+    // 2.2 ms against 1.4 ms at 512^3: the sweep itself is 0.59 ms, its result stores cost 1.5 ms and its loads 1.0 (they share the one
+    // vmcnt counter, so every wait for a trip's inputs also waits for the previous trip's scattered stores); the next step there is a
+    // helper wavefront that does the stores, as DRAIN does for the granules
+    szh_rb_layout rbl = {0, 0, 0, 0, 0, 0};
+    size_t nat_elems = (size_t)n;
+    const bool dec_ribbon = tune_int("SZ_HIP_RIBBON_DEC", 0) != 0 && ribbon_applies<T>(G, reg_count);
+    if (dec_ribbon) {
+        using RS = szh_rb_shape<T>;
+        rbl.on = 1; rbl.nTJ = (G.g1.count + 63) / 64; rbl.NT = szh_rb_steps_of<T>(G.g2.count); rbl.W = RS::W; rbl.R = RS::R; rbl.U = RS::U;
+        const size_t tiles = (size_t)((G.g0.count + RS::W * RS::R - 1) / (RS::W * RS::R)) * rbl.nTJ;
+        nat_elems = tiles * (size_t)szh_rb_tile_elems(rbl);
+    }
+    TRY(ensure(ctx, ctx->codes_nat, nat_elems * 2 + 64));
     TRY(ensure(ctx, ctx->codes_blk, (size_t)n * 2 + 64));
     uint16_t *d_nat = (uint16_t *)ctx->codes_nat.p, *d_blk = (uint16_t *)ctx->codes_blk.p;
 
@@ -1185,7 +1199,7 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
         TRY(ensure(ctx, ctx->zcnt, (size_t)ncols * nseg * 4));
         TRY(ensure(ctx, ctx->zpos, (size_t)ncols * nseg * SZH_ZCAP * 4));
         hipLaunchKernelGGL((k_permute<1>), dim3(ncols, nseg), dim3(256), tile_bytes(G, segb, 2), st, G, (const uint16_t *)d_blk, d_nat,
-                           (unsigned *)ctx->col_zeros.p, segb, (unsigned *)ctx->zcnt.p, (unsigned *)ctx->zpos.p, szh_rb_layout{0, 0, 0, 0, 0, 0}, (unsigned *)nullptr, 0u, 0);
+                           (unsigned *)ctx->col_zeros.p, segb, (unsigned *)ctx->zcnt.p, (unsigned *)ctx->zpos.p, rbl, (unsigned *)nullptr, 0u, 0);
         perm_segb = segb; perm_nseg = nseg;
         HIPCHK(hipGetLastError());
     }
@@ -1246,9 +1260,7 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
         a.trace = tune_int("SZ_HIP_TRACE", 0) ? (szh_u64 *)ctx->trace.p : nullptr;
         a.dbg = tune_int("SZ_HIP_DBG", 0); a.trace_tile = tune_int("SZ_HIP_TRACE_TILE", 1);
         HIPCHK(hipEventRecord(ctx->ev[2], st));
-        // (the inverse keeps k_pencil by default: its output rows leave the ribbon kernel as 2-byte-skewed 64-byte pieces of 64 different
-        //  rows per store, which costs it more than it gains -- 2.9 against 1.4 ms at 512^3; SZ_HIP_RIBBON_DEC=1 selects it)
-        if (tune_int("SZ_HIP_RIBBON_DEC", 0) && ribbon_applies<T>(G, reg_count)) { TRY((launch_ribbon<T, true>(ctx, G, a, st))); S.quant_kernel = 1; }
+        if (dec_ribbon) { a.codes_ribbon = 1; TRY((launch_ribbon<T, true>(ctx, G, a, st))); S.quant_kernel = 1; }
         else {
         hipLaunchKernelGGL((k_pencil<T, true>), dim3((unsigned)ntiles), dim3((TS::TPI * TS::TPJ + 2) * 64), 0, st, a);
         HIPCHK(hipGetLastError());

@@ -671,7 +671,7 @@ template <int DIR>
 __global__ __launch_bounds__(256) void k_permute(szh_geom3 G, const uint16_t *__restrict__ src, uint16_t *__restrict__ dst,
                                                  unsigned *col_zeros, int segb, unsigned *zcnt, unsigned *zpos, szh_rb_layout rb,
                                                  unsigned *hist, unsigned hist_bins, int tile_elems)
-{   // rb.on (DIR 0 only): `src` is in the ribbon order of szh_ribbon.h
+{   // rb.on: the natural-order side (`src` for DIR 0, `dst` for DIR 1) is in the ribbon order of szh_ribbon.h
     // hist (DIR 0 only, hist_bins > 0): the code histogram of Huffman.c:165-174 is taken here, while the codes sit in LDS anyway (one
     // pass over the code array less): per workgroup in LDS behind the tile, the peak symbol (radius = hist_bins / 2, most of a smooth
     // field) counted by ballot instead of by atomics, non-empty bins added to the global histogram at the end
@@ -761,7 +761,34 @@ __global__ __launch_bounds__(256) void k_permute(szh_geom3 G, const uint16_t *__
             }
         }
     }
-    if (DIR == 1) {
+    if (DIR == 1 && rb.on) {
+        // into ribbon order (the inverse sweep of szh_ribbon.h reads its codes the way the forward sweep writes them): one thread per
+        // (row, group of 8 consecutive k); a group that straddles the segment is completed by the neighbouring workgroup, so its
+        // part goes out as 2-byte stores
+        __syncthreads();
+        const int ng = klen / 8 + 2, WR = rb.W * rb.R;
+        for (int p = threadIdx.x; p < rows * ng; p += 256) {
+            const int r = p / ng, gl = p - r * ng;
+            const int i = o0 + r / s1, j = o1 + r % s1;
+            const int TI = i / WR, q = i - TI * WR, w = q / rb.R, rr = q - w * rb.R, TJ = j >> 6, ln = j & 63;
+            const int off = w * (rb.R - 1) + ln + rr;                       // shifted step of k = 0
+            const int tt8 = ((kbeg + off) >> 3) + gl;                        // group number along the sweep
+            const int k0 = tt8 * 8 - off;
+            if (k0 >= kend) continue;
+            uint16_t *d = dst + szh_rb_group_index(rb, (int64_t)TI * rb.nTJ + TJ, w, rr, tt8 * 8) + ln * 8;
+            if (k0 >= kbeg && k0 + 8 <= kend) {
+                uint16_t v[8];
+                for (int e = 0; e < 8; ++e) v[e] = tile[r * kp + kshift + (k0 + e - kbeg)];
+                uint4 wv; __builtin_memcpy(&wv, v, 16);
+                *reinterpret_cast<uint4 *>(d) = wv;
+            } else {
+#ifndef SZH_HIPSIM
+#pragma clang loop vectorize(disable) unroll(disable)
+#endif
+                for (int e = 0; e < 8; ++e) { const int k = k0 + e; if (k >= kbeg && k < kend) d[e] = tile[r * kp + kshift + (k - kbeg)]; }
+            }
+        }
+    } else if (DIR == 1) {
         __syncthreads();
         for (int r = wid; r < rows; r += 4) {
             const int i = r / s1, j = r - i * s1;

@@ -33,6 +33,13 @@ for it in range(3):
         b, sz, st = ctx.compress(d.ctypes.data, False, d.shape, np.float32, 1e-4, meta)
     except Exception as e:
         print("compress failed:", e); failed = True; break
+if os.environ.get("RB_DEC") and not failed:          # the inverse sweep instead: decompress the stream, the trace is of that launch
+    out = np.empty_like(d)
+    import ctypes
+    buf = ctypes.create_string_buffer(b, len(b))
+    for it in range(2):
+        st = ctx.decompress(ctypes.addressof(buf), False, len(b), 4 + 28 + 8, d.shape, np.float32, out.ctypes.data, False)
+    print("INVERSE sweep: max err", float(np.abs(out - d).max()))
 nTI, nTJ = (n + W * R - 1) // (W * R), (n + 63) // 64
 raw = ctx.debug_fetch(9, nTI * nTJ * (W + 4) * 8 + nTI * 4 * 48, np.uint64).astype(np.int64)
 tl = raw[nTI * nTJ * (W + 4) * 8:].reshape(nTI, 4, 48)
