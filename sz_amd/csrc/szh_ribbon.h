@@ -55,6 +55,8 @@ template <class T> struct szh_rb_shape;
 #endif
 template <> struct szh_rb_shape<float> { static constexpr int R = SZH_RB_R_F32, W = SZH_RB_W_F32, U = 16, RL = SZH_RB_RL_F32, RLU = 64, RLL = 128, RLR = 32; };
 template <> struct szh_rb_shape<double> { static constexpr int R = SZH_RB_R_F64, W = SZH_RB_W_F64, U = 8, RL = 16, RLU = 32, RLL = 128, RLR = 32; };
+// inverse: rows of a trip per hand-over to the STORE wavefront (LDS: W x HB x 64 x U values; double has room for one row only)
+template <class T> struct szh_rb_hb { static constexpr int HB = sizeof(T) == 4 ? szh_rb_shape<T>::R : 1; };
 #define SZH_RB_INF (1 << 30)
 #ifndef SZH_RB_KD
 #define SZH_RB_KD 4            /* DRAIN: steps per face and round */
@@ -223,7 +225,8 @@ template <class T> struct lds_t {
                         //              cnt[W + 1] = steps DRAIN has forwarded (of ring W and of every right ring); left[w] = indices of
                         //              the left rings complete for wavefront w
     SZH_LDS int *scratch; // [64]: FILL_L (per-row values for a per-wavefront minimum)
-    SZH_LDS T *tbuf;    // inverse only: [W][64][U + 4]: a trip's results of one row, transposed on their way to memory (store_trip)
+    SZH_LDS T *tbuf;    // inverse only: [W][HB][64][U]: a trip's results on their way to the STORE wavefront (store_trip, store_out)
+    SZH_LDS unsigned *Q; // inverse only: [W][2]: {trips wavefront w has put into tbuf, trips STORE has taken out}
 };
 
 // bounded wait until an LDS word reaches `need` (a lost hand-off must end the launch, not hang the GPU)
@@ -333,9 +336,10 @@ __device__ __forceinline__ void ribbon_body(const szh_qargs<T> &a, const int TI,
     T Uprev = 0, Fprev = 0;
     int have_up = 0, have_left = 0;       // progress of the producers as last seen
     int room_dn = 0, room_rt = 0;         // the consumers' progress as last seen (ring space): the wavefront below / DRAIN
+    int blocks_out = 0;                   // inverse: blocks STORE has taken out of this wavefront's tbuf, as last seen
     szh_u64 *const trc = rb_trace_slot(a, TI, TJ, w);
     szh_u64 *const tln = (w == 0 || w == W - 1) ? rb_timeline(a, TI, TJ, w == 0 ? 0 : 1) : nullptr;
-    szh_u64 tw_up = 0, tw_left = 0, tw_room = 0;
+    szh_u64 tw_up = 0, tw_left = 0, tw_room = 0, tw_store = 0;
     if (trc && lane == 0) { trc[0] = rb_wall(); trc[6] = rb_xcc(); }
 
     typedef T xbuf_t[R][U];
@@ -383,33 +387,27 @@ __device__ __forceinline__ void ribbon_body(const szh_qargs<T> &a, const int TI,
                 for (int v = 0; v < U / 8; ++v) { v4u q = {c[r][4 * v], c[r][4 * v + 1], c[r][4 * v + 2], c[r][4 * v + 3]}; bstore16(rsc, off + 1024u * v, q); }
                 continue;
             }
-            if (DEC && !edge) {
+            if (DEC) {
                 // The trip's U values of this row are U * sizeof(T) contiguous bytes per lane -- in 64 different rows of the array.  Stored
-                // straight from the registers, every instruction writes 16 bytes to each of 64 rows (measured: those stores cost
-                // 1.5 ms of the 2.5 ms the first inverse took, 0.59 ms being the sweep itself).  Through LDS the block is transposed
-                // so that NVEC neighbouring lanes write one row's bytes: an instruction covers 64 / NVEC rows with whole 64-byte pieces.
-                // (LDS executes a wavefront's accesses in order: no wait between the writes and the reads of the other lanes' words.)
-                constexpr int TP = U + 4;
-                SZH_LDS T *const tb = L.tbuf + w * 64 * TP;
+                // from here they cost 1.5 ms of the 2.5 ms the first inverse took (the sweep itself: 0.59 ms): this wavefront's one
+                // memory counter makes every wait for a trip's inputs wait for the previous trip's scattered stores as well.  So the
+                // trip's results (both rows: one hand-over per trip) go to LDS and the STORE wavefront (store_out) writes them,
+                // transposed: NVEC neighbouring lanes write one row's bytes, an instruction covers 64 / NVEC rows with whole
+                // 64-byte pieces.  This wavefront issues loads only.  tbuf: [w][r][lane][U], the 16-byte pieces of a lane XOR-swizzled
+                // by the lane so that both sides are free of bank conflicts without padding (LDS is full: 159 KB with this buffer).
+                constexpr int HB = szh_rb_hb<T>::HB;
+                SZH_LDS T *const tb = L.tbuf + (w * HB + r % HB) * 64 * U;
+                const int n = (tt0 / U) * (R / HB) + r / HB;                  // hand-over number
+                if (r % HB == 0 && blocks_out < n) { const szh_u64 c0 = trc ? rb_cyc() : 0; blocks_out = wait_word(L.Q + 2 * w + 1, n, a.err); if (trc) tw_store += rb_cyc() - c0; }
 #pragma unroll
                 for (int v = 0; v < NVEC; ++v) {
                     T tmp[VPT];
 #pragma unroll
                     for (int e = 0; e < VPT; ++e) tmp[e] = x[r][v * VPT + e];
                     v4u q; __builtin_memcpy(&q, tmp, 16);
-                    *(SZH_LDS v4u *)(tb + lane * TP + v * VPT) = q;
+                    *(SZH_LDS v4u *)(tb + lane * U + ((v ^ (lane % NVEC)) * VPT)) = q;
                 }
-                lds_order();
-                const int seg = lane % NVEC, jl = lane / NVEC;
-#pragma unroll
-                for (int q4 = 0; q4 < NVEC; ++q4) {
-                    const int jj = jl + (64 / NVEC) * q4;                    // the lane (= column of dim 1) whose values these are
-                    const v4u q = *(const SZH_LDS v4u *)(tb + jj * TP + seg * VPT);
-                    const int jg = TJ * 64 + jj;
-                    const unsigned off = (unsigned)((reli[r] + jg * (int)G.d1 + (tt0 - sh - jj - r) + seg * VPT) * (int)sizeof(T));
-                    if (iok[r] && jg < r1) bstore16(rsx, off, q);
-                }
-                lds_order();                                                 // (the next row's words go to the same place)
+                if (r % HB == HB - 1) { lds_fence(); if (lane == 0) lds_st(L.Q + 2 * w, (unsigned)(n + 1)); }
                 continue;
             }
             if (!rowok[r]) continue;
@@ -574,7 +572,7 @@ __device__ __forceinline__ void ribbon_body(const szh_qargs<T> &a, const int TI,
         if (tln && lane == 0 && tt0 / U < 48) tln[tt0 / U] = rb_wall();
     }
     if (!dbg_nost) store_trip(NT - U, is_edge(NT - U), xc, cc);
-    if (trc && lane == 0) { trc[2] = rb_wall(); trc[3] = tw_up; trc[4] = tw_left; trc[5] = tw_room; trc[7] = timed_out ? (szh_u64)(1000000 + to_step) : (szh_u64)NT; }
+    if (trc && lane == 0) { trc[2] = rb_wall(); trc[3] = tw_up; trc[4] = tw_left; trc[5] = tw_room + (tw_store << 32); trc[7] = timed_out ? (szh_u64)(1000000 + to_step) : (szh_u64)NT; }
     if (timed_out) st_flag(a.err, 1u);
 }
 
@@ -779,11 +777,107 @@ __device__ __forceinline__ void fill_left(const szh_qargs<T> &a, int TI, int TJ,
         } else idle = 0;
     }
 }
+// STORE (inverse only): writes the trips' results the compute wavefronts leave in tbuf to the output array.  Stores only.
+// One wavefront serves the W compute wavefronts of the tile, so a hand-over must cost it little: the acknowledged counts live in
+// registers (the loop over w is unrolled), all W request words are read with one LDS access, everything per lane is computed once,
+// and a hand-over carries both rows of a trip.  (Row by row it took 0.5 us per row and the compute wavefronts spent a third of their
+// time waiting for it: tools/gpu_rb_trace.py, `store` column and STORE line.)
+template <class T> __device__ __forceinline__ void store_out(const szh_qargs<T> &a, const int TI, const int TJ, const lds_t<T> &L)
+{
+    using S = szh_rb_shape<T>;
+    constexpr int R = S::R, W = S::W, U = S::U, WR = W * R, HB = szh_rb_hb<T>::HB;
+    constexpr int VPT = 16 / (int)sizeof(T), NVEC = U / VPT;
+    const szh_geom3 &G = a.G;
+    const int r0 = G.g0.count, r1 = G.g1.count, r2 = G.g2.count;
+    const int lane = (int)(threadIdx.x & 63);
+    const int NT = szh_rb_steps_of<T>(r2), ntrips = NT / U * (R / HB);       // hand-overs per wavefront
+    const int64_t tile_base = (int64_t)TI * WR * G.d0;
+    const uint64_t span_x = (uint64_t)(G.n - tile_base) * sizeof(T);
+    const rsrc_t rsx = make_rsrc((T *)a.out + tile_base, span_x > 0x7ffffff0ull ? 0x7ffffff0u : (unsigned)span_x);
+    const int seg = lane % NVEC, jl = lane / NVEC;
+    // per lane and piece q4: the column of dim 1 it belongs to, where that column's row starts, the position offset of the piece
+    int ldsoff[NVEC], eloff[NVEC]; bool colok[NVEC];
+#pragma unroll
+    for (int q4 = 0; q4 < NVEC; ++q4) {
+        const int jj = jl + (64 / NVEC) * q4, jg = TJ * 64 + jj;
+        ldsoff[q4] = jj * U + ((seg ^ (jj % NVEC)) * VPT);
+        colok[q4] = jg < r1;
+        eloff[q4] = (jg < r1 ? jg : r1 - 1) * (int)G.d1 - jj + seg * VPT;      // + the row's start + (tt0 - sh - r) = the element offset of the piece
+    }
+    int done[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) done[w] = 0;
+    unsigned idle = 0;
+    szh_u64 *const trc = rb_trace_slot(a, TI, TJ, W + 3);
+    szh_u64 t_busy = 0, n_scan = 0, n_blk = 0;
+    if (trc && lane == 0) trc[0] = rb_wall();
+    for (;;) {
+        bool any = false, left = false;
+        const szh_u64 c0 = trc ? rb_cyc() : 0;
+        ++n_scan;
+        const unsigned reqs = lds_ld(L.Q + 2 * (lane < W ? lane : 0));
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            if (done[w] >= ntrips) continue;
+            left = true;
+#ifdef SZH_HIPSIM
+            const int req = (int)__shfl(reqs, w, 64);
+#else
+            const int req = __builtin_amdgcn_readlane((int)reqs, w);
+#endif
+            if (req <= done[w]) continue;
+            any = true;
+            const int n = done[w], tt0 = (n / (R / HB)) * U, rb0 = (n % (R / HB)) * HB, sh = w * (R - 1);
+            v4u q[HB][NVEC];
+#pragma unroll
+            for (int r = 0; r < HB; ++r) {
+                const SZH_LDS T *const tb = L.tbuf + (w * HB + r) * 64 * U;
+#pragma unroll
+                for (int q4 = 0; q4 < NVEC; ++q4) q[r][q4] = *(const SZH_LDS v4u *)(tb + ldsoff[q4]);
+            }
+            lds_fence();                                                  // the words are in registers: the buffer may be overwritten
+            done[w] = n + 1; ++n_blk;
+            if (lane == 0) lds_st(L.Q + 2 * w + 1, (unsigned)(n + 1));
+#pragma unroll
+            for (int rr = 0; rr < HB; ++rr) {
+                const int r = rb0 + rr;
+                const int i = TI * WR + w * R + r;
+                if (i >= r0) continue;
+                const int kb = tt0 - sh - r;                               // position of lane 0's first value of the trip
+                const int base = (int)((int64_t)(i - TI * WR) * G.d0) + kb;
+                if (kb - 63 >= 0 && kb + U <= r2) {                        // every position of the row's block lies inside the row
+#pragma unroll
+                    for (int q4 = 0; q4 < NVEC; ++q4) if (colok[q4]) bstore16(rsx, (unsigned)((base + eloff[q4]) * (int)sizeof(T)), q[rr][q4]);
+                } else {
+#pragma unroll
+                    for (int q4 = 0; q4 < NVEC; ++q4) {
+                        if (!colok[q4]) continue;
+                        const int jj = jl + (64 / NVEC) * q4, k = kb - jj + seg * VPT;
+                        const unsigned off = (unsigned)((base + eloff[q4]) * (int)sizeof(T));
+                        if (k >= 0 && k + VPT <= r2) bstore16(rsx, off, q[rr][q4]);
+                        else {
+                            T tmp[VPT]; __builtin_memcpy(tmp, &q[rr][q4], 16);
+#pragma unroll
+                            for (int e = 0; e < VPT; ++e) if ((unsigned)(k + e) < (unsigned)r2) bstoreT(rsx, off + (unsigned)(e * (int)sizeof(T)), tmp[e]);
+                        }
+                    }
+                }
+            }
+        }
+        if (trc && any) t_busy += rb_cyc() - c0;
+        if (!left) break;
+        if (!any) {
+            if ((++idle & 1023u) == 0 && uni((int)ld_flag(a.err)) != 0) break;      // a compute wavefront gave up: the launch is lost anyway
+            nap(1);
+        } else idle = 0;
+    }
+    if (trc && lane == 0) { trc[2] = rb_wall(); trc[3] = t_busy; trc[4] = n_scan; trc[5] = n_blk; }
+}
 } // namespace szh_rb
 
 // a.nI x a.nJ = the TILE grid here; a.faceI / a.faceJ = the down- / right-face granule rows
 template <class T, bool DEC, bool USEMEAN>
-__global__ __launch_bounds__((szh_rb_shape<T>::W + 3) * 64) void k_ribbon(szh_qargs<T> a)
+__global__ __launch_bounds__((szh_rb_shape<T>::W + 3 + (DEC ? 1 : 0)) * 64) void k_ribbon(szh_qargs<T> a)
 {
     using S = szh_rb_shape<T>;
     using namespace szh_rb;
@@ -793,9 +887,11 @@ __global__ __launch_bounds__((szh_rb_shape<T>::W + 3) * 64) void k_ribbon(szh_qa
     __shared__ T rr[S::RLR * WR];
     __shared__ unsigned P[2 * (W + 2)];
     __shared__ int scratch[64];
-    __shared__ __attribute__((aligned(16))) T tbuf[DEC ? W * 64 * (S::U + 4) : 4];
+    __shared__ __attribute__((aligned(16))) T tbuf[DEC ? W * szh_rb_hb<T>::HB * 64 * S::U : 4];
+    __shared__ unsigned Q[2 * W];
     __shared__ unsigned tk_s;
     if (threadIdx.x < 2 * (W + 2)) P[threadIdx.x] = 0;
+    if (threadIdx.x < 2 * W) Q[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
         const unsigned t = a.ticket_mode ? blockIdx.x : atomicAdd(a.ticket, 1u);
         tk_s = szh_pencil_order_at(a.nI, a.nJ, t);
@@ -804,7 +900,7 @@ __global__ __launch_bounds__((szh_rb_shape<T>::W + 3) * 64) void k_ribbon(szh_qa
     const unsigned ij = (unsigned)uni((int)tk_s);
     const int w = uni((int)(threadIdx.x >> 6));
     const int TI = (int)(ij >> 16), TJ = (int)(ij & 0xffffu);
-    const lds_t<T> L{(SZH_LDS T *)ring, (SZH_LDS T *)lr, (SZH_LDS T *)rr, (SZH_LDS unsigned *)P, (SZH_LDS int *)scratch, (SZH_LDS T *)tbuf};
+    const lds_t<T> L{(SZH_LDS T *)ring, (SZH_LDS T *)lr, (SZH_LDS T *)rr, (SZH_LDS unsigned *)P, (SZH_LDS int *)scratch, (SZH_LDS T *)tbuf, (SZH_LDS unsigned *)Q};
 #ifndef SZH_RB_PRIO
 #define SZH_RB_PRIO 1
 #endif
@@ -812,6 +908,7 @@ __global__ __launch_bounds__((szh_rb_shape<T>::W + 3) * 64) void k_ribbon(szh_qa
     if (w < W) ribbon_body<T, DEC, USEMEAN>(a, TI, TJ, w, L);
     else if (w == W) drain<T>(a, TI, TJ, L);
     else if (w == W + 1) fill_up<T>(a, TI, TJ, L);
-    else fill_left<T>(a, TI, TJ, L);
+    else if (w == W + 2) fill_left<T>(a, TI, TJ, L);
+    else store_out<T>(a, TI, TJ, L);
 }
 #endif

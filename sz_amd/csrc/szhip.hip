@@ -1,3 +1,10 @@
+    // the inverse sweep: k_pencil on natural-order codes by default.  SZ_HIP_RIBBON_DEC=1: k_ribbon where it applies (3-D, no regression
+    // block), fed with ribbon-order codes by k_permute<1>; its results leave through LDS and a STORE wavefront (szh_ribbon.h store_out).
+    // Correct and tested, but 1.7 ms against 1.4 ms at 512^3.  What was measured on the way (tools/gpu_dec_dbg.sh, tools/gpu_rb_trace.py
+    // with RB_DEC=1): the sweep alone 0.59 ms, with loads 1.03 ms; result stores issued by the compute wavefronts 2.5 ms (their one
+    // memory counter makes every wait for a trip's inputs wait for the previous trip's scattered stores), transposed into 64-byte
+    // pieces 2.2 ms, through the STORE wavefront 1.6 - 1.7 ms -- that wavefront is then busy 85 % of the time: a store instruction that
+    // touches 16 rows takes it ~280 cycles, and a second STORE wavefront does not fit (12 wavefronts x 168 VGPRs fill the CU)
 // szhip.hip -- C-ABI HIP layer (include/szhip.h): owns device buffers, launches the kernels of
 // szhip_kernels.h in stream order and calls the short serial host pieces of szhost.c between them.
 // gfx950 only; no CPU fallback: every entry point returns an error if the HIP runtime/device is missing.
@@ -333,8 +340,8 @@ int launch_ribbon(szhip_ctx *ctx, const szh_geom3 &G, szh_qargs<T> a, hipStream_
     a.faceI = (szh_u64 *)ctx->rb_down.p; a.faceJ = (szh_u64 *)ctx->rb_right.p;
     a.nI = nTI; a.nJ = nTJ;
     if (a.ticket_mode == 2) a.ticket_mode = 1;          // (the tile is always computed from the ticket here; 0 = atomic ticket)
-    if (a.use_mean) hipLaunchKernelGGL((k_ribbon<T, DEC, true>), dim3((unsigned)tiles), dim3((RS::W + 3) * 64), 0, st, a);
-    else hipLaunchKernelGGL((k_ribbon<T, DEC, false>), dim3((unsigned)tiles), dim3((RS::W + 3) * 64), 0, st, a);
+    if (a.use_mean) hipLaunchKernelGGL((k_ribbon<T, DEC, true>), dim3((unsigned)tiles), dim3((RS::W + 3 + (DEC ? 1 : 0)) * 64), 0, st, a);
+    else hipLaunchKernelGGL((k_ribbon<T, DEC, false>), dim3((unsigned)tiles), dim3((RS::W + 3 + (DEC ? 1 : 0)) * 64), 0, st, a);
     HIPCHK(hipGetLastError());
     return SZHIP_OK;
 }

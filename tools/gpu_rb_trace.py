@@ -79,9 +79,10 @@ for (TI, TJ) in [(0, 0), (0, 1), (1, 0), (1, 1), (0, nTJ - 1), (nTI // 2, nTJ //
     print("tile (%d,%d) xcc %d" % (TI, TJ, tr[TI, TJ, 0, 6]))
     for w in (0, 1, W - 1):
         r = tr[TI, TJ, w]
-        print("   wave %d: start %.1f trip0 end %.1f end %.1f (dur %.1f us, %.3f us/step)  waits us: up %.1f left %.1f room %.1f" %
-              (w, us(r[0]), us(r[1]), us(r[2]), (r[2] - r[0]) / 100.0, (r[2] - r[0]) / 100.0 / max(1, r[7]), r[3] / cyc, r[4] / cyc, r[5] / cyc))
+        print("   wave %d: start %.1f trip0 end %.1f end %.1f (dur %.1f us, %.3f us/step)  waits us: up %.1f left %.1f room %.1f store %.1f" %
+              (w, us(r[0]), us(r[1]), us(r[2]), (r[2] - r[0]) / 100.0, (r[2] - r[0]) / 100.0 / max(1, r[7]), r[3] / cyc, r[4] / cyc, (r[5] & 0xffffffff) / cyc, (r[5] >> 32) / cyc))
     r = tr[TI, TJ, W]; print("   DRAIN  : end %.1f rounds %d empty %d steps %d" % (us(r[2]), r[3], r[4], r[7]))
+    r = tr[TI, TJ, W + 3]; print("   STORE  : start %.1f end %.1f busy %.1f us, scans %d, blocks %d" % (us(r[0]), us(r[2]), r[3] / cyc, r[4], r[5]))
     r = tr[TI, TJ, W + 2]; print("   FILL_U : end %.1f rounds %d empty %d noroom %d steps %d" % (us(r[2]), r[3], r[4], r[5], r[7]))
 e0 = tr[:, :, 0, 2]; eL = tr[:, :, W - 1, 2]
 print("end of wave 0 per tile row (col 0):", " ".join("%.0f" % us(x) for x in e0[:, 0]))
@@ -91,7 +92,7 @@ print("end lag between tile cols (wave 0, row 0) us: median %.1f" % np.median(np
 print("in-tile end lag wave w -> w+1 us: median %.2f" % np.median((tr[:, :, 1:W, 2] - tr[:, :, :W - 1, 2]) / 100.0))
 dur = (tr[:, :, :W, 2] - tr[:, :, :W, 0]) / 100.0
 print("compute wavefront duration us: min %.1f median %.1f max %.1f" % (dur.min(), np.median(dur), dur.max()))
-wt = tr[:, :, :W, 3:6] / cyc
+wt = tr[:, :, :W, 3:6].copy(); wt[:, :, :, 2] &= 0xffffffff; wt = wt / cyc
 print("median waits us: up %.1f left %.1f room %.1f" % tuple(np.median(wt.reshape(-1, 3), axis=0)))
 np.save(os.path.join(ROOT, "gpurun_out", "rb_trace_%d.npy" % n), tr)
 
