@@ -944,7 +944,8 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
 // `dtab` is the host-built decode table of the tree, `single_symbol` >= 0 for the one-leaf tree (zero payload bits).
 // after the synchronisation that follows huff_decode_device: did its two unsynchronised rounds settle every start?
 #define HDEC_CHECK(ctx) do { if ((ctx)->hdec_res[1] != 0 || (tune_int("SZ_HIP_TEST_HDEC_FALLBACK", 0) && !(ctx)->hdec_sync_rounds)) { (ctx)->hdec_unconverged = true; \
-        FAIL(SZHIP_ERR_INTERNAL, "Huffman decode: %llu start guesses still moving after two rounds", (ctx)->hdec_res[1]); } } while (0)
+        /* (no message on stderr: the caller's wrapper repeats the call with a synchronisation per round) */ \
+        snprintf((ctx)->err, sizeof((ctx)->err), "Huffman decode: %llu start guesses still moving after two rounds", (ctx)->hdec_res[1]); return SZHIP_ERR_INTERNAL; } } while (0)
 int huff_decode_device(szhip_ctx *ctx, u64 *sm, const unsigned char *d_bits, unsigned bytes_before, u64 total_bits, const std::vector<uint32_t> &dtab, int n_nodes,
                        int single_symbol, int64_t n, uint16_t *d_out_codes, u64 *total_sym_host)
 {
