@@ -979,6 +979,10 @@ int huff_decode_device(szhip_ctx *ctx, u64 *sm, const unsigned char *d_bits, uns
         const unsigned gsub = (unsigned)((nsub + 255) / 256);
         hipLaunchKernelGGL(k_hdec_init, dim3(gsub), dim3(256), 0, st, a);
         const bool optimistic = !ctx->hdec_sync_rounds && tune_int("SZ_HIP_HDEC_OPTIMISTIC", 1) != 0;
+        // rounds without a host round trip: round 0 (warm-up guesses), then repair rounds that only touch the sub-sequences whose start
+        // moved (a workgroup without one returns at once: ~10 us per idle round).  Smooth fields settle in round 1; wide code books
+        // (codes longer than the look-up window resynchronise slowly) sometimes need a third
+        const int64_t opt_rounds = std::max(2, tune_int("SZ_HIP_HDEC_ROUNDS", 3));
         int64_t iter = 0;
         for (;;) {
             a.warmup = iter == 0;                                  // the first round finds its own starts (k_hdec_pass)
@@ -988,8 +992,8 @@ int huff_decode_device(szhip_ctx *ctx, u64 *sm, const unsigned char *d_bits, uns
             HIPCHK(hipGetLastError());
             if (optimistic) {
                 // round 0 repairs nearly every guess (84 of 287 393 wrong at 512^3), round 1 the rest; whether anything still moved after
-                // round 1 is read with the caller's next synchronisation (two host round trips of ~35 us less per call)
-                if (iter == 0 && nsub > 1) { ++iter; continue; }
+                // the last round is read with the caller's next synchronisation (two host round trips of ~35 us less per call)
+                if (iter + 1 < opt_rounds && nsub > 1) { ++iter; continue; }
                 HIPCHK(hipMemcpyAsync(&ctx->hdec_res[1], sm + SM_CHANGED, 8, hipMemcpyDeviceToHost, st));
                 break;
             }
