@@ -890,25 +890,35 @@ __global__ __launch_bounds__((szh_rb_shape<T>::W + 3 + (DEC ? 1 : 0)) * 64) void
     __shared__ __attribute__((aligned(16))) T tbuf[DEC ? W * szh_rb_hb<T>::HB * 64 * S::U : 4];
     __shared__ unsigned Q[2 * W];
     __shared__ unsigned tk_s;
-    if (threadIdx.x < 2 * (W + 2)) P[threadIdx.x] = 0;
-    if (threadIdx.x < 2 * W) Q[threadIdx.x] = 0;
-    if (threadIdx.x == 0) {
-        const unsigned t = a.ticket_mode ? blockIdx.x : atomicAdd(a.ticket, 1u);
-        tk_s = szh_pencil_order_at(a.nI, a.nJ, t);
-    }
-    __syncthreads();
-    const unsigned ij = (unsigned)uni((int)tk_s);
-    const int w = uni((int)(threadIdx.x >> 6));
-    const int TI = (int)(ij >> 16), TJ = (int)(ij & 0xffffu);
+    // PERSISTENT: gridDim.x workgroups walk the tiles in ticket order (the order of szh_pencil_order_at: a tile's predecessors have
+    // smaller tickets, so the workgroup on the smallest unfinished ticket can always run -- no deadlock as long as the grid is
+    // resident, one workgroup per CU).  With one workgroup per tile, 85 % of the resident workgroups were polling for predecessors that
+    // had not started: ~40 of 256 tiles are active at a time (the dependency front), the others held their CU's LDS and registers
+    // against the other arrays in flight and read granule rows over and over.
     const lds_t<T> L{(SZH_LDS T *)ring, (SZH_LDS T *)lr, (SZH_LDS T *)rr, (SZH_LDS unsigned *)P, (SZH_LDS int *)scratch, (SZH_LDS T *)tbuf, (SZH_LDS unsigned *)Q};
+    const int w = uni((int)(threadIdx.x >> 6));
 #ifndef SZH_RB_PRIO
 #define SZH_RB_PRIO 1
 #endif
     if (SZH_RB_PRIO) prio(w >= W ? 3 : (w == 0 ? 2 : (w < 3 ? 1 : 0)));
-    if (w < W) ribbon_body<T, DEC, USEMEAN>(a, TI, TJ, w, L);
-    else if (w == W) drain<T>(a, TI, TJ, L);
-    else if (w == W + 1) fill_up<T>(a, TI, TJ, L);
-    else if (w == W + 2) fill_left<T>(a, TI, TJ, L);
-    else store_out<T>(a, TI, TJ, L);
+    const unsigned ntiles = (unsigned)(a.nI * a.nJ);
+    for (unsigned it = 0;; ++it) {
+        __syncthreads();                                             // the previous tile is finished by every wavefront
+        if (threadIdx.x < 2 * (W + 2)) P[threadIdx.x] = 0;
+        if (threadIdx.x < 2 * W) Q[threadIdx.x] = 0;
+        if (threadIdx.x == 0) {
+            const unsigned t = a.ticket_mode ? blockIdx.x + it * gridDim.x : atomicAdd(a.ticket, 1u);
+            tk_s = t < ntiles ? szh_pencil_order_at(a.nI, a.nJ, t) : 0xffffffffu;
+        }
+        __syncthreads();
+        const unsigned ij = (unsigned)uni((int)tk_s);
+        if (ij == 0xffffffffu) break;
+        const int TI = (int)(ij >> 16), TJ = (int)(ij & 0xffffu);
+        if (w < W) ribbon_body<T, DEC, USEMEAN>(a, TI, TJ, w, L);
+        else if (w == W) drain<T>(a, TI, TJ, L);
+        else if (w == W + 1) fill_up<T>(a, TI, TJ, L);
+        else if (w == W + 2) fill_left<T>(a, TI, TJ, L);
+        else store_out<T>(a, TI, TJ, L);
+    }
 }
 #endif

@@ -340,8 +340,12 @@ int launch_ribbon(szhip_ctx *ctx, const szh_geom3 &G, szh_qargs<T> a, hipStream_
     a.faceI = (szh_u64 *)ctx->rb_down.p; a.faceJ = (szh_u64 *)ctx->rb_right.p;
     a.nI = nTI; a.nJ = nTJ;
     if (a.ticket_mode == 2) a.ticket_mode = 1;          // (the tile is always computed from the ticket here; 0 = atomic ticket)
-    if (a.use_mean) hipLaunchKernelGGL((k_ribbon<T, DEC, true>), dim3((unsigned)tiles), dim3((RS::W + 3 + (DEC ? 1 : 0)) * 64), 0, st, a);
-    else hipLaunchKernelGGL((k_ribbon<T, DEC, false>), dim3((unsigned)tiles), dim3((RS::W + 3 + (DEC ? 1 : 0)) * 64), 0, st, a);
+    // persistent workgroups (k_ribbon): no more than one per CU, or the ticket order could wait for a workgroup that is not resident.
+    // A lone context takes every CU (512^3: sweep 1.02 ms with 256 workgroups, 1.18 with 96); a lane of a pool leaves half of them to
+    // the other lanes' kernels (two arrays in flight, 40-step runs: 324 GB/s with 256, 351 - 354 with 128 or 112, 346 with 96, 326 with 64)
+    const unsigned wgs = (unsigned)std::min<size_t>(tiles, (size_t)std::max(1, std::min(tune_int("SZ_HIP_RB_WGS", ctx->gate ? 128 : 256), 256)));
+    if (a.use_mean) hipLaunchKernelGGL((k_ribbon<T, DEC, true>), dim3(wgs), dim3((RS::W + 3 + (DEC ? 1 : 0)) * 64), 0, st, a);
+    else hipLaunchKernelGGL((k_ribbon<T, DEC, false>), dim3(wgs), dim3((RS::W + 3 + (DEC ? 1 : 0)) * 64), 0, st, a);
     HIPCHK(hipGetLastError());
     return SZHIP_OK;
 }
