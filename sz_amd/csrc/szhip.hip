@@ -340,6 +340,11 @@ int launch_ribbon(szhip_ctx *ctx, const szh_geom3 &G, szh_qargs<T> a, hipStream_
     a.faceI = (szh_u64 *)ctx->rb_down.p; a.faceJ = (szh_u64 *)ctx->rb_right.p;
     a.nI = nTI; a.nJ = nTJ;
     if (a.ticket_mode == 2) a.ticket_mode = 1;          // (the tile is always computed from the ticket here; 0 = atomic ticket)
+    // Persistent workgroups with a FIXED share of the tickets (mode 1) need the whole grid resident at once.  A lone context has the
+    // chip to itself; the lanes of a pool compete for CUs, and workgroups of different launches that wait for tiles of their own,
+    // not yet resident, workgroups could block each other.  A pool lane therefore draws its tickets from the launch's counter: a
+    // workgroup holds a ticket only while it runs the tile, so the smallest unfinished ticket always belongs to a running workgroup.
+    if (ctx->gate && tune_int("SZ_HIP_RB_POOL_ATOMIC", 1)) a.ticket_mode = 0;
     // persistent workgroups (k_ribbon): no more than one per CU, or the ticket order could wait for a workgroup that is not resident.
     // A lone context takes every CU (512^3: sweep 1.02 ms with 256 workgroups, 1.18 with 96); a lane of a pool leaves half of them to
     // the other lanes' kernels (two arrays in flight, 40-step runs: 324 GB/s with 256, 351 - 354 with 128 or 112, 346 with 96, 326 with 64)
