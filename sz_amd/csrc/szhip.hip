@@ -328,6 +328,15 @@ template <class T> bool ribbon_applies(const szh_geom3 &G, size_t reg_count)
     return nTI <= 65535 && nTJ <= 65535;
 }
 // granule rows of the tile hand-offs + the launch; `a` carries everything that does not depend on the mapping
+// k_pencil's grid: one workgroup per tile (a lone context: the inverse sweep at 512^3 takes 1.47 ms either way), or that many persistent
+// workgroups drawing tiles from the ticket counter (a pool lane: fewer workgroups that only poll for their predecessors -- two M-field
+// arrays in flight 111 -> 136 GB/s with 512, 127 with 256).  SZ_HIP_PENCIL_WGS overrides (0 = one per tile).
+template <class QA> static unsigned pencil_grid(szhip_ctx *ctx, QA &a, int ntiles)
+{
+    const int cap = tune_int("SZ_HIP_PENCIL_WGS", ctx->gate ? 512 : 0);
+    a.persist = cap > 0 && cap < ntiles;
+    return (unsigned)(a.persist ? cap : ntiles);
+}
 template <class T, bool DEC>
 int launch_ribbon(szhip_ctx *ctx, const szh_geom3 &G, szh_qargs<T> a, hipStream_t st)
 {
@@ -721,7 +730,8 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         HIPCHK(hipEventRecord(ctx->ev[2], st));
         if (use_ribbon) { TRY((launch_ribbon<T, false>(ctx, G, a, st))); S.quant_kernel = 1; }
         else {
-        hipLaunchKernelGGL((k_pencil<T, false>), dim3((unsigned)ntiles), dim3((TS::TPI * TS::TPJ + 2) * 64), 0, st, a);
+        const unsigned pgrid = pencil_grid(ctx, a, ntiles);
+        hipLaunchKernelGGL((k_pencil<T, false>), dim3(pgrid), dim3((TS::TPI * TS::TPJ + 2) * 64), 0, st, a);
         HIPCHK(hipGetLastError());
         }
         HIPCHK(hipEventRecord(ctx->ev[3], st));
@@ -1283,7 +1293,8 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
         HIPCHK(hipEventRecord(ctx->ev[2], st));
         if (dec_ribbon) { a.codes_ribbon = 1; TRY((launch_ribbon<T, true>(ctx, G, a, st))); S.quant_kernel = 1; }
         else {
-        hipLaunchKernelGGL((k_pencil<T, true>), dim3((unsigned)ntiles), dim3((TS::TPI * TS::TPJ + 2) * 64), 0, st, a);
+        const unsigned pgrid = pencil_grid(ctx, a, ntiles);
+        hipLaunchKernelGGL((k_pencil<T, true>), dim3(pgrid), dim3((TS::TPI * TS::TPJ + 2) * 64), 0, st, a);
         HIPCHK(hipGetLastError());
         }
         HIPCHK(hipEventRecord(ctx->ev[3], st));
@@ -1355,10 +1366,11 @@ int launch_pencil14(szhip_ctx *ctx, const szh_geom3 &G, u64 *sm, bool dec, const
     a.progress = (szh_u64 *)ctx->progress.p; a.backoff = tune_int("SZ_HIP_BACKOFF", 4); a.wide = tune_int("SZ_HIP_WIDE", 1) && (double)TS::TPI * nJ * 9.0 * (double)G.g2.count * szh_gran<T>::NW * 8.0 < 4.0e9 && (double)TS::TPJ * 9.0 * (double)G.g2.count * szh_gran<T>::NW * 8.0 < 4.0e9;
     a.trace = nullptr; a.dbg = 0;
     HIPCHK(hipEventRecord(ctx->ev[2], st));
-    if (mt && dec) hipLaunchKernelGGL((k_pencil<T, true, true>), dim3((unsigned)ntiles), dim3((TS::TPI * TS::TPJ + 2) * 64), 0, st, a);
-    else if (mt) hipLaunchKernelGGL((k_pencil<T, false, true>), dim3((unsigned)ntiles), dim3((TS::TPI * TS::TPJ + 2) * 64), 0, st, a);
-    else if (dec) hipLaunchKernelGGL((k_pencil<T, true>), dim3((unsigned)ntiles), dim3((TS::TPI * TS::TPJ + 2) * 64), 0, st, a);
-    else hipLaunchKernelGGL((k_pencil<T, false>), dim3((unsigned)ntiles), dim3((TS::TPI * TS::TPJ + 2) * 64), 0, st, a);
+    const unsigned pgrid = pencil_grid(ctx, a, ntiles);
+    if (mt && dec) hipLaunchKernelGGL((k_pencil<T, true, true>), dim3(pgrid), dim3((TS::TPI * TS::TPJ + 2) * 64), 0, st, a);
+    else if (mt) hipLaunchKernelGGL((k_pencil<T, false, true>), dim3(pgrid), dim3((TS::TPI * TS::TPJ + 2) * 64), 0, st, a);
+    else if (dec) hipLaunchKernelGGL((k_pencil<T, true>), dim3(pgrid), dim3((TS::TPI * TS::TPJ + 2) * 64), 0, st, a);
+    else hipLaunchKernelGGL((k_pencil<T, false>), dim3(pgrid), dim3((TS::TPI * TS::TPJ + 2) * 64), 0, st, a);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[3], st));
     return SZHIP_OK;

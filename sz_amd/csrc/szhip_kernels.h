@@ -244,28 +244,11 @@ __global__ __launch_bounds__((szh_tile_shape<T>::TPI * szh_tile_shape<T>::TPJ + 
     if (a.backoff == -12345) lds_pad[threadIdx.x] = 1;
 #endif
     __shared__ unsigned tk_s;
-    if (threadIdx.x < NP + NV) cstep[threadIdx.x] = 0;
-    if (threadIdx.x < NP) { spubJ[threadIdx.x] = 0; spubI[threadIdx.x] = 0; }
-    if (threadIdx.x == 0) {
-        // which tile: by default an atomic ticket into the anti-diagonal order table.  ticket_mode 1/2: the workgroup index IS the ticket
-        // (workgroups of one XCD start in index order, so the lowest unfinished tile always runs), mode 2 computes the tile instead of loading it
-        const unsigned t = a.ticket_mode ? blockIdx.x : atomicAdd(a.ticket, 1u);
-        tk_s = a.ticket_mode == 2 ? szh_pencil_order_at((a.nI + S::TPI - 1) / S::TPI, (a.nJ + S::TPJ - 1) / S::TPJ, t) : a.order[t];
-    }
-    __syncthreads();
     (void)NT;
-    // wavefront-uniform by construction: say so (readfirstlane), so that slots, ring bases, publish flags and the wait loops of the
-    // sweep live in scalar registers and branch on the scalar unit instead of through exec masks
 #ifdef SZH_HIPSIM
-    const unsigned ij = tk_s;
     const int w = (int)(threadIdx.x >> 6);
 #else
-    const unsigned ij = (unsigned)__builtin_amdgcn_readfirstlane((int)tk_s);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-#endif
-    const int TI = (int)(ij >> 16), TJ = (int)(ij & 0xffffu);
-    const szh_tile_lds<T> L{cring, faces, (NP + NV) * (S::RL + 2) * SZH_FROWS, cstep, spubJ, spubI, scratch};
-#ifndef SZH_HIPSIM
     // issue priority: the helpers (light, latency-critical) first, then the pencils in dependency order, so that the chain
     // of hand-offs advances at single-wavefront speed while the downstream pencils fill the issue gaps
     {
@@ -275,12 +258,40 @@ __global__ __launch_bounds__((szh_tile_shape<T>::TPI * szh_tile_shape<T>::TPJ + 
         else if (d <= 3) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
     }
 #endif
-    if (w < NP) {
-        const int I = TI * S::TPI + w / S::TPJ, J = TJ * S::TPJ + w % S::TPJ;
-        if (I >= a.nI || J >= a.nJ) return;         // ragged tile: this wavefront has no pencil
-        szh_pencil_run<T, DEC, B, MS>(a, I, J, L);
-    } else if (w == NP) szh_tile_store<T, B>(a, TI, TJ, L);
-    else szh_tile_fill<T, B>(a, TI, TJ, L);
+    const szh_tile_lds<T> L{cring, faces, (NP + NV) * (S::RL + 2) * SZH_FROWS, cstep, spubJ, spubI, scratch};
+    const unsigned ntiles = (unsigned)(((a.nI + S::TPI - 1) / S::TPI) * ((a.nJ + S::TPJ - 1) / S::TPJ));
+    // One workgroup per tile (gridDim.x == ntiles, a.persist == 0: rounds 1 - 2) or PERSISTENT workgroups that draw tile after tile from
+    // the launch's ticket counter (round 3, as k_ribbon): a workgroup holds a ticket only while it runs the tile, so the smallest
+    // unfinished ticket always belongs to a running workgroup whatever else occupies the CUs.
+    for (unsigned it = 0;; ++it) {
+        if (it) __syncthreads();                                     // the previous tile is finished by every wavefront
+        if (threadIdx.x < NP + NV) cstep[threadIdx.x] = 0;
+        if (threadIdx.x < NP) { spubJ[threadIdx.x] = 0; spubI[threadIdx.x] = 0; }
+        if (threadIdx.x == 0) {
+            // which tile: an atomic ticket into the anti-diagonal order, or (ticket_mode 1 / 2, one workgroup per tile) the workgroup index IS
+            // the ticket (workgroups of one XCD start in index order, so the lowest unfinished tile always runs); mode 2 computes the tile
+            // instead of loading it from the table
+            const unsigned t = (a.ticket_mode && !a.persist) ? blockIdx.x : atomicAdd(a.ticket, 1u);
+            tk_s = t >= ntiles ? 0xffffffffu
+                 : (a.ticket_mode == 2 || a.persist) ? szh_pencil_order_at((a.nI + S::TPI - 1) / S::TPI, (a.nJ + S::TPJ - 1) / S::TPJ, t) : a.order[t];
+        }
+        __syncthreads();
+        // wavefront-uniform by construction: say so (readfirstlane), so that slots, ring bases, publish flags and the wait loops of the
+        // sweep live in scalar registers and branch on the scalar unit instead of through exec masks
+#ifdef SZH_HIPSIM
+        const unsigned ij = tk_s;
+#else
+        const unsigned ij = (unsigned)__builtin_amdgcn_readfirstlane((int)tk_s);
+#endif
+        if (ij == 0xffffffffu) break;
+        const int TI = (int)(ij >> 16), TJ = (int)(ij & 0xffffu);
+        if (w < NP) {
+            const int I = TI * S::TPI + w / S::TPJ, J = TJ * S::TPJ + w % S::TPJ;
+            if (I < a.nI && J < a.nJ) szh_pencil_run<T, DEC, B, MS>(a, I, J, L);       // (ragged tile: this wavefront has no pencil)
+        } else if (w == NP) szh_tile_store<T, B>(a, TI, TJ, L);
+        else szh_tile_fill<T, B>(a, TI, TJ, L);
+        if (!a.persist) break;
+    }
 }
 
 // ------------------------------------------------------------------ per-block stage (fit + select)
