@@ -2664,7 +2664,8 @@ int szhip_compress(szhip_ctx *ctx, int dtype, const void *data, int data_on_devi
     if ((r0 != 0 && r0 < 2) || r1 < 2 || r2 < 2 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff) return SZHIP_ERR_ARG;
     if (!(eb > 0)) return SZHIP_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
-    const int rc = with_ticket_fallback(ctx, [&]() { return dtype == SZHIP_F32
+    unsigned char *const out0 = *out; const size_t cap0 = *out_size;     // (a failed first attempt clears them: the repetition starts from the caller's values)
+    const int rc = with_ticket_fallback(ctx, [&]() { *out = out0; *out_size = cap0; return dtype == SZHIP_F32
                ? compress_impl<float>(ctx, data, data_on_device, r0, r1, r2, eb, params, meta, meta_len, out_on_device, out, out_size, stats)
                : compress_impl<double>(ctx, data, data_on_device, r0, r1, r2, eb, params, meta, meta_len, out_on_device, out, out_size, stats); });
     if (rc != SZHIP_OK) { hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream); } // an early exit must not leave work in flight
@@ -2679,7 +2680,8 @@ int szhip_compress_sz14(szhip_ctx *ctx, int dtype, const void *data, int data_on
     if ((r0 != 0 && r0 < 2) || (r1 < 2 && !(r0 == 0 && r1 == 0)) || r2 < 2 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff) return SZHIP_ERR_ARG;
     if (!(eb > 0)) return SZHIP_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
-    const int rc = with_ticket_fallback(ctx, [&]() { return dtype == SZHIP_F32
+    unsigned char *const out0 = *out; const size_t cap0 = *out_size;     // (a failed first attempt clears them: the repetition starts from the caller's values)
+    const int rc = with_ticket_fallback(ctx, [&]() { *out = out0; *out_size = cap0; return dtype == SZHIP_F32
                ? compress14_impl<float>(ctx, data, data_on_device, r0, r1, r2, eb, value_range, median, params, meta, meta_len, nullptr, out_on_device, out, out_size, stats)
                : compress14_impl<double>(ctx, data, data_on_device, r0, r1, r2, eb, value_range, median, params, meta, meta_len, nullptr, out_on_device, out, out_size, stats); });
     if (rc != SZHIP_OK) { hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream); }
@@ -2732,7 +2734,8 @@ int szhip_compress_sz14_pwr(szhip_ctx *ctx, int dtype, const void *data, int dat
     if ((r0 != 0 && r0 < 2) || (r1 < 2 && !(r0 == 0 && r1 == 0)) || r2 < 2 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff) return SZHIP_ERR_ARG;
     if (!(eb > 0)) return SZHIP_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
-    const int rc = with_ticket_fallback(ctx, [&]() { return dtype == SZHIP_F32
+    unsigned char *const out0 = *out; const size_t cap0 = *out_size;     // (a failed first attempt clears them: the repetition starts from the caller's values)
+    const int rc = with_ticket_fallback(ctx, [&]() { *out = out0; *out_size = cap0; return dtype == SZHIP_F32
                ? compress14_impl<float>(ctx, data, data_on_device, r0, r1, r2, eb, value_range, median, params, meta, meta_len, pwr, out_on_device, out, out_size, stats)
                : compress14_impl<double>(ctx, data, data_on_device, r0, r1, r2, eb, value_range, median, params, meta, meta_len, pwr, out_on_device, out, out_size, stats); });
     if (rc != SZHIP_OK) { hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream); }
