@@ -240,6 +240,29 @@ def test_context_reuse_and_device_resident_entry_points(sz, oracle):
     ctx.close()
 
 
+def test_pool_lanes_give_the_oracle_streams(sz, oracle):
+    """szhip_pool (include/szhip.h): K arrays in flight on one GPU -- persistent sweep workgroups on atomic tickets, one context per lane.
+    Every stream must be the oracle's, whatever shares the chip: S-fields (k_ribbon), M-fields (k_pencil next to the host coefficient
+    chain), a double array and a ragged shape, interleaved over two and three lanes."""
+    import torch
+    from sz_amd.fields import m_field, s_field
+    cases = [(s_field(96, 128, 160), 1e-4), (m_field(96), 1e-4), (s_field(40, 70, 90, np.float64), 1e-6), (s_field(33, 65, 130), 1e-3), (m_field(64), 1e-4)]
+    refs, xs, metas = [], [], []
+    for d, eb in cases:
+        ref, _ = oracle.compress(d, oracle.ABS, eb)
+        refs.append(ref); xs.append(torch.from_numpy(d).cuda()); metas.append(ref[:4 + (28 if d.dtype == np.float32 else 36)])
+    for lanes in (2, 3):
+        pool = sz.HipPool(0, lanes)
+        outs = [torch.empty(len(r) + (1 << 16), dtype=torch.uint8, device="cuda") for r in refs]
+        for rounds in range(3):
+            tks = [pool.submit(xs[i].data_ptr(), True, cases[i][0].shape, cases[i][0].dtype, cases[i][1], metas[i], None, outs[i].data_ptr(), outs[i].numel())
+                   for i in range(len(cases))]
+            for i, tk in enumerate(tks):
+                n, st = pool.wait(tk)
+                assert n == len(refs[i]) and bytes(outs[i][:n].cpu().numpy()) == refs[i], (lanes, rounds, i)
+        pool.close()
+
+
 def test_baseline_size_properties(sz, anchors):
     """512^3 float32 S-field, ABS 1e-4 (BASELINE.json configs[1]/[4]): stream size and PSNR equal the reference's recorded
     numbers; every point within the bound; compress(decompress(x)) of the lossy output is a fixed point of the decoder."""
