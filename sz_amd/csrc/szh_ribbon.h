@@ -83,6 +83,16 @@ SZH_HD int64_t szh_rb_group_index(const szh_rb_layout &y, int64_t tile, int w, i
     return tile * szh_rb_tile_elems(y) + ((((int64_t)trip * y.W + w) * y.R + r) * (y.U / 8) + v) * 512;
 }
 
+// RIBBON ORDER of a VALUE array (inverse, mode 2): as for the codes, but in groups of g = 16 / sizeof(T) values (one 16-byte vector per lane):
+//   [tile][trip][wavefront w][row r][group v of g steps][lane][g values]
+// index of point (i, j, k) of the array
+SZH_HD int64_t szh_rb_value_index(const szh_rb_layout &y, int g, int i, int j, int k)
+{
+    const int WR = y.W * y.R, TI = i / WR, q = i - TI * WR, w = q / y.R, r = q - w * y.R, TJ = j >> 6, ln = j & 63;
+    const int tt = k + w * (y.R - 1) + ln + r, trip = tt / y.U, s = tt - trip * y.U, v = s / g, e = s - v * g;
+    return ((int64_t)TI * y.nTJ + TJ) * szh_rb_tile_elems(y) + (((((int64_t)trip * y.W + w) * y.R + r) * (y.U / g) + v) * 64 + ln) * g + e;
+}
+
 #if defined(__HIPCC__) || defined(SZH_HIPSIM)
 namespace szh_rb {
 #ifdef SZH_HIPSIM
@@ -299,7 +309,9 @@ __device__ __forceinline__ void ribbon_body(const szh_qargs<T> &a, const int TI,
     // (the range check of a buffer access is per dword: the code array's last dword may hold one code -- the host allocates 64 bytes of
     //  slack behind it; offsets below the base wrap to >= 2^31: the record count stays below that)
     const uint64_t span_x = (uint64_t)rest * sizeof(T), span_c = (uint64_t)rest * 2 + 8;
-    const rsrc_t rsx = make_rsrc((DEC ? (const T *)a.out : a.data) + tile_base, span_x > 0x7ffffff0ull ? 0x7ffffff0u : (unsigned)span_x);
+    const bool xrb = DEC && a.codes_ribbon == 2;               // (uniform) inverse, mode 2: the value array is in ribbon order as well
+    const rsrc_t rsx = xrb ? make_rsrc((T *)a.out + ((int64_t)TI * a.nJ + TJ) * ((int64_t)NT * WR * 64), (unsigned)((size_t)NT * WR * 64 * sizeof(T)))
+                           : make_rsrc((DEC ? (const T *)a.out : a.data) + tile_base, span_x > 0x7ffffff0ull ? 0x7ffffff0u : (unsigned)span_x);
     // codes: natural order for the inverse; ribbon order (this tile's region) for compression
     const bool crb = !DEC || a.codes_ribbon;                   // (uniform)
     const rsrc_t rsc = !crb ? make_rsrc(a.codes + tile_base, span_c > 0x7ffffff0ull ? 0x7ffffff0u : (unsigned)span_c)
@@ -351,10 +363,11 @@ __device__ __forceinline__ void ribbon_body(const szh_qargs<T> &a, const int TI,
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int k0 = tt0 - sh - lane - r;
-            const unsigned off = (unsigned)((rowrel[r] + k0) * (int)sizeof(T));
+            const unsigned off = xrb ? (unsigned)(((((tt0 / U) * W + w) * R + r) * NVEC) * 1024 + lane * 16) : (unsigned)((rowrel[r] + k0) * (int)sizeof(T));
+            const unsigned pitch = xrb ? 1024u : 16u;
 #pragma unroll
             for (int v = 0; v < NVEC; ++v) {
-                const v4u q = bload16(rsx, off + 16u * v);
+                const v4u q = bload16(rsx, off + pitch * v);
                 T tmp[VPT]; __builtin_memcpy(tmp, &q, 16);
 #pragma unroll
                 for (int e = 0; e < VPT; ++e) x[r][v * VPT + e] = tmp[e];
@@ -385,6 +398,18 @@ __device__ __forceinline__ void ribbon_body(const szh_qargs<T> &a, const int TI,
                 const unsigned off = (unsigned)(((((tt0 / U) * W + w) * R + r) * (U / 8)) * 1024 + lane * 16);
 #pragma unroll
                 for (int v = 0; v < U / 8; ++v) { v4u q = {c[r][4 * v], c[r][4 * v + 1], c[r][4 * v + 2], c[r][4 * v + 3]}; bstore16(rsc, off + 1024u * v, q); }
+                continue;
+            }
+            if (DEC && xrb) {            // mode 2: back into the ribbon-order value array, 64 lanes x 16 contiguous bytes per store
+                const unsigned off = (unsigned)(((((tt0 / U) * W + w) * R + r) * NVEC) * 1024 + lane * 16);
+#pragma unroll
+                for (int v = 0; v < NVEC; ++v) {
+                    T tmp[VPT];
+#pragma unroll
+                    for (int e = 0; e < VPT; ++e) tmp[e] = x[r][v * VPT + e];
+                    v4u q; __builtin_memcpy(&q, tmp, 16);
+                    bstore16(rsx, off + 1024u * v, q);
+                }
                 continue;
             }
             if (DEC) {
@@ -784,6 +809,7 @@ __device__ __forceinline__ void fill_left(const szh_qargs<T> &a, int TI, int TJ,
 // time waiting for it: tools/gpu_rb_trace.py, `store` column and STORE line.)
 template <class T> __device__ __forceinline__ void store_out(const szh_qargs<T> &a, const int TI, const int TJ, const lds_t<T> &L)
 {
+    if (a.codes_ribbon == 2) return;                 // (the compute wavefronts store ribbon-order results themselves: coalesced)
     using S = szh_rb_shape<T>;
     constexpr int R = S::R, W = S::W, U = S::U, WR = W * R, HB = szh_rb_hb<T>::HB;
     constexpr int VPT = 16 / (int)sizeof(T), NVEC = U / VPT;

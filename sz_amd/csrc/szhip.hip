@@ -1,10 +1,3 @@
-    // the inverse sweep: k_pencil on natural-order codes by default.  SZ_HIP_RIBBON_DEC=1: k_ribbon where it applies (3-D, no regression
-    // block), fed with ribbon-order codes by k_permute<1>; its results leave through LDS and a STORE wavefront (szh_ribbon.h store_out).
-    // Correct and tested, but 1.7 ms against 1.4 ms at 512^3.  What was measured on the way (tools/gpu_dec_dbg.sh, tools/gpu_rb_trace.py
-    // with RB_DEC=1): the sweep alone 0.59 ms, with loads 1.03 ms; result stores issued by the compute wavefronts 2.5 ms (their one
-    // memory counter makes every wait for a trip's inputs wait for the previous trip's scattered stores), transposed into 64-byte
-    // pieces 2.2 ms, through the STORE wavefront 1.6 - 1.7 ms -- that wavefront is then busy 85 % of the time: a store instruction that
-    // touches 16 rows takes it ~280 cycles, and a second STORE wavefront does not fit (12 wavefronts x 168 VGPRs fill the CU)
 // szhip.hip -- C-ABI HIP layer (include/szhip.h): owns device buffers, launches the kernels of
 // szhip_kernels.h in stream order and calls the short serial host pieces of szhost.c between them.
 // gfx950 only; no CPU fallback: every entry point returns an error if the HIP runtime/device is missing.
@@ -58,7 +51,7 @@ struct szhip_ctx {
     hipEvent_t ev_gate = nullptr;
     unsigned long long *hdec_res = nullptr;      // pinned: {symbols the payload holds, starts still moving after round 1}, copied asynchronously
     // workspaces (grow-only)
-    DevBuf lor_bits, reg_flags, reg_rank, coef_compact, in, out, codes_nat, codes_blk, coef, blk_lor, faceI, faceJ, rb_down, rb_right, fast_slots, fast_units, progress, trace, order, small, hist, col_zeros, col_zeros64,
+    DevBuf lor_bits, reg_flags, reg_rank, coef_compact, in, out, codes_nat, codes_blk, coef, blk_lor, faceI, faceJ, rb_down, rb_right, rb_vals, fast_slots, fast_units, progress, trace, order, small, hist, col_zeros, col_zeros64,
         col_off, partial, samples, unpred, stream_buf, chunk_bits, chunk_off, code_tab, len_tab, dec_tab,
         starts, ends, counts, offs, dirty, zcnt, zpos, pwr_log, pwr_signs, pwr_small, coef_dec, msst_ptab, msst_cells, msst_rec, msst_pe;
     void *pinned = nullptr; size_t pinned_cap = 0;
@@ -1195,14 +1188,20 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
     TRY(ensure(ctx, ctx->small, SM_COUNT * 8));
     u64 *sm = (u64 *)ctx->small.p;
     HIPCHK(hipMemsetAsync(sm, 0, SM_COUNT * 8, st));
-    // the inverse sweep: k_pencil on natural-order codes by default.  SZ_HIP_RIBBON_DEC=1: k_ribbon where it applies (3-D, no regression
-    // block), fed with ribbon-order codes by k_permute<1>, its results transposed through LDS into 64-byte pieces -- correct and tested, but
-    // 2.2 ms against 1.4 ms at 512^3: the sweep itself is 0.59 ms, its result stores cost 1.5 ms and its loads 1.0 (they share the one
-    // vmcnt counter, so every wait for a trip's inputs also waits for the previous trip's scattered stores); the next step there is a
-    // helper wavefront that does the stores, as DRAIN does for the granules
+    // The inverse sweep.  Where k_ribbon applies (3-D, no regression block) it runs in RIBBON ORDER throughout (SZ_HIP_RIBBON_DEC=2, the
+    // default): k_permute<1> writes the codes the way the forward sweep does, k_unpred<1> drops the unpredictable values into a ribbon-order
+    // value array (the rest of it stays uninitialised: the sweep only looks at a value where the code says so), the sweep reads and writes
+    // 64 lanes x 16 contiguous bytes per instruction, and k_unribbon turns the result into the array (LDS transposition, 256-byte runs).
+    // 512^3 float: 0.86 + 0.37 ms against k_pencil's 1.47 - 1.53.  What led there (tools/gpu_dec_dbg.sh, tools/gpu_rb_trace.py RB_DEC=1):
+    // the sweep alone takes 0.59 ms, with natural-order loads 1.03 ms; natural-order result stores from the compute wavefronts 2.5 ms
+    // (their one memory counter makes every wait for a trip's inputs wait for the previous trip's scattered stores), transposed into
+    // 64-byte pieces 2.2 ms, through a STORE helper wavefront 1.6 - 1.7 ms (= SZ_HIP_RIBBON_DEC=1, kept and tested: that wavefront is busy
+    // 85 % of the time -- a store instruction that touches 16 rows takes it ~280 cycles -- and a second one does not fit the register file).
+    // SZ_HIP_RIBBON_DEC=0: k_pencil on natural-order codes (rounds 1 - 2; still the path of arrays with regression blocks, 2-D, SZ 1.4).
     szh_rb_layout rbl = {0, 0, 0, 0, 0, 0};
     size_t nat_elems = (size_t)n;
-    const bool dec_ribbon = tune_int("SZ_HIP_RIBBON_DEC", 0) != 0 && ribbon_applies<T>(G, reg_count);
+    const int dec_ribbon_mode = ribbon_applies<T>(G, reg_count) ? tune_int("SZ_HIP_RIBBON_DEC", 2) : 0;     // 1: natural-order values through the STORE wavefront
+    const bool dec_ribbon = dec_ribbon_mode != 0;                                                            // 2: ribbon-order values + k_unribbon
     if (dec_ribbon) {
         using RS = szh_rb_shape<T>;
         rbl.on = 1; rbl.nTJ = (G.g1.count + 63) / 64; rbl.NT = szh_rb_steps_of<T>(G.g2.count); rbl.W = RS::W; rbl.R = RS::R; rbl.U = RS::U;
@@ -1247,12 +1246,14 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
                                           (unsigned long long)total_unpred, (unsigned long long)zeros_found);
     T *d_out = (T *)out;
     if (!out_on_device) { TRY(ensure(ctx, ctx->out, (size_t)n * sizeof(T))); d_out = (T *)ctx->out.p; }
+    T *d_sweep = d_out;                        // what the inverse sweep works on: the output array, or (mode 2) a ribbon-order value array
+    if (dec_ribbon_mode == 2) { TRY(ensure(ctx, ctx->rb_vals, nat_elems * sizeof(T) + 64)); d_sweep = (T *)ctx->rb_vals.p; }
     if (total_unpred > 0) {
         TRY(ensure(ctx, ctx->unpred, (size_t)total_unpred * sizeof(T)));
         HIPCHK(hipMemcpyAsync(ctx->unpred.p, d_stream + unpred_off, (size_t)total_unpred * sizeof(T), hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL((k_unpred<T, 1>), dim3(ncols), dim3(256), 0, st, G, (const uint16_t *)d_blk, (const unsigned *)ctx->col_zeros.p,
-                           (const u64 *)ctx->col_off.p, (const T *)nullptr, (T *)ctx->unpred.p, d_out, (const unsigned *)ctx->zcnt.p,
-                           (const unsigned *)ctx->zpos.p, perm_segb, perm_nseg);
+                           (const u64 *)ctx->col_off.p, (const T *)nullptr, (T *)ctx->unpred.p, d_sweep, (const unsigned *)ctx->zcnt.p,
+                           (const unsigned *)ctx->zpos.p, perm_segb, perm_nseg, dec_ribbon_mode == 2 ? rbl : szh_rb_layout{0, 0, 0, 0, 0, 0});
         HIPCHK(hipGetLastError());
     }
     TRY(ensure(ctx, ctx->coef, (size_t)nb * 4 * sizeof(T)));
@@ -1291,7 +1292,18 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
         a.trace = tune_int("SZ_HIP_TRACE", 0) ? (szh_u64 *)ctx->trace.p : nullptr;
         a.dbg = tune_int("SZ_HIP_DBG", 0); a.trace_tile = tune_int("SZ_HIP_TRACE_TILE", 1);
         HIPCHK(hipEventRecord(ctx->ev[2], st));
-        if (dec_ribbon) { a.codes_ribbon = 1; TRY((launch_ribbon<T, true>(ctx, G, a, st))); S.quant_kernel = 1; }
+        if (dec_ribbon) {
+            a.codes_ribbon = dec_ribbon_mode == 2 ? 2 : 1;
+            if (dec_ribbon_mode == 2) a.out = d_sweep;
+            TRY((launch_ribbon<T, true>(ctx, G, a, st)));
+            S.quant_kernel = 1;
+            if (dec_ribbon_mode == 2) {            // the results into the array
+                const int nchunk = (rbl.NT + SZH_UR_STEPS - 1) / SZH_UR_STEPS;
+                const size_t tiles = (size_t)((G.g0.count + rbl.W * rbl.R - 1) / (rbl.W * rbl.R)) * rbl.nTJ;
+                hipLaunchKernelGGL((k_unribbon<T>), dim3((unsigned)(tiles * (rbl.W * rbl.R / 4) * nchunk)), dim3(256), 0, st, G, rbl, (const T *)d_sweep, d_out);
+                HIPCHK(hipGetLastError());
+            }
+        }
         else {
         const unsigned pgrid = pencil_grid(ctx, a, ntiles);
         hipLaunchKernelGGL((k_pencil<T, true>), dim3(pgrid), dim3((TS::TPI * TS::TPJ + 2) * 64), 0, st, a);

@@ -837,8 +837,9 @@ __global__ __launch_bounds__(256) void k_permute(szh_geom3 G, const uint16_t *__
 template <class T, int DIR>
 __global__ __launch_bounds__(256) void k_unpred(szh_geom3 G, const uint16_t *__restrict__ codes_blk, const unsigned *__restrict__ col_zeros,
                                                 const u64 *__restrict__ col_off, const T *data, T *unpred, T *out,
-                                                const unsigned *__restrict__ zcnt, const unsigned *__restrict__ zpos, int segb, int nseg)
-{
+                                                const unsigned *__restrict__ zcnt, const unsigned *__restrict__ zpos, int segb, int nseg,
+                                                szh_rb_layout rb = szh_rb_layout{0, 0, 0, 0, 0, 0})
+{   // rb.on (DIR 1 only): `out` is a value array in the ribbon order of szh_ribbon.h (szh_rb_value_index)
     __shared__ u64 sh[8];
     __shared__ u64 keys[SZH_ZMAX];
     __shared__ int use_list;
@@ -860,6 +861,7 @@ __global__ __launch_bounds__(256) void k_unpred(szh_geom3 G, const uint16_t *__r
         else { const int64_t e2 = e - eregion; const int64_t bl = e2 / lsz; rem = e2 - bl * lsz; s2 = G.g2.late; o2 = G.g2.split * G.g2.early + (int)bl * G.g2.late; }
         const int row = (int)(rem / s2), kk = (int)(rem - (int64_t)row * s2);
         const int ii = row / s1, jj = row - ii * s1;
+        if (DIR == 1 && rb.on) return szh_rb_value_index(rb, 16 / (int)sizeof(T), o0 + ii, o1 + jj, o2 + kk);
         return (int64_t)(o0 + ii) * G.d0 + (int64_t)(o1 + jj) * G.d1 + o2 + kk;
     };
     // the positions k_permute noted, if every segment's note is complete: order them (they are few) and move the values
@@ -1436,6 +1438,56 @@ __global__ __launch_bounds__(256) void k_hdec_write(szh_hdec_args a, const u64 *
     unsigned endl;
     hdec_run_lut<true>(S.l, total, ltab, a.table, lut, run ? (unsigned)((int64_t)st_g - S.bit0) : 0u, run ? (unsigned)((int64_t)limit_g - S.bit0) : 0u, &endl, out, o, oend, run);
 }
+// ------------------------------------------------------------------ ribbon-order values -> the array (inverse, mode 2)
+// The inverse sweep of szh_ribbon.h leaves its results in ribbon order (coalesced stores); this pass writes them where they belong.
+// A wavefront takes one (tile, wavefront w, row r) and SZH_UR_STEPS steps of it: 64 lanes x SZH_UR_STEPS values = 64 row pieces of
+// SZH_UR_STEPS * sizeof(T) contiguous bytes.  It reads them as the sweep wrote them (64 lanes x 16 bytes per load), turns the block
+// in LDS and writes every row piece with neighbouring lanes (SZH_UR_STEPS / g lanes per row: 256-byte runs for float).
+#define SZH_UR_STEPS 64
+template <class T>
+__global__ __launch_bounds__(256) void k_unribbon(szh_geom3 G, szh_rb_layout rb, const T *__restrict__ xr, T *__restrict__ out)
+{
+    constexpr int g = 16 / (int)sizeof(T), NV = SZH_UR_STEPS / g, PITCH = SZH_UR_STEPS + g;      // (+ g: rows start in different banks)
+    __shared__ __attribute__((aligned(16))) T tile[4][64 * PITCH];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int WR = rb.W * rb.R, nchunk = (rb.NT + SZH_UR_STEPS - 1) / SZH_UR_STEPS;
+    // blockIdx.x -> (tile, group of 4 (w, r) pairs, chunk of steps)
+    const int64_t b = blockIdx.x;
+    const int chunk = (int)(b % nchunk); const int64_t b1 = b / nchunk;
+    const int grp = (int)(b1 % (WR / 4)); const int64_t tile_id = b1 / (WR / 4);
+    const int TI = (int)(tile_id / rb.nTJ), TJ = (int)(tile_id - (int64_t)TI * rb.nTJ);
+    const int q = grp * 4 + wv, w = q / rb.R, r = q - w * rb.R;
+    const int i = TI * WR + q;
+    const int tt0 = chunk * SZH_UR_STEPS;
+    T *const tb = tile[wv];
+    // read: vector v of the chunk = steps tt0 + g v ..; in the ribbon array vector (trip, vv) of (w, r) is 64 lanes x 16 bytes
+    const int64_t tbase = tile_id * szh_rb_tile_elems(rb);
+#pragma unroll 4
+    for (int v = 0; v < NV; ++v) {
+        const int tt = tt0 + v * g;
+        if (tt >= rb.NT) break;
+        const int trip = tt / rb.U, vv = (tt - trip * rb.U) / g;
+        const uint4 val = *reinterpret_cast<const uint4 *>(xr + tbase + (((((int64_t)trip * rb.W + w) * rb.R + r) * (rb.U / g) + vv) * 64 + lane) * g);
+        *reinterpret_cast<uint4 *>(tb + lane * PITCH + v * g) = val;
+    }
+    __syncthreads();
+    if (i >= G.g0.count) return;
+    // write: NV lanes per row; row ln holds positions k = tt - sh - ln - r
+    const int sh = w * (rb.R - 1), seg = lane % NV, rl = lane / NV;
+    for (int rr = 0; rr < 64; rr += 64 / NV) {
+        const int ln = rr + rl, j = TJ * 64 + ln;
+        if (j >= G.g1.count) continue;
+        const int k = tt0 + seg * g - sh - ln - r;
+        const uint4 val = *reinterpret_cast<const uint4 *>(tb + ln * PITCH + seg * g);
+        T *dst = out + (int64_t)i * G.d0 + (int64_t)j * G.d1 + k;
+        if (k >= 0 && k + g <= G.g2.count && tt0 + seg * g + g <= rb.NT) __builtin_memcpy(dst, &val, 16);      // (4- / 8-byte aligned: one 16-byte store on gfx950)
+        else {
+            T tmp[g]; __builtin_memcpy(tmp, &val, 16);
+            for (int e = 0; e < g; ++e) if (k + e >= 0 && k + e < G.g2.count && tt0 + seg * g + e < rb.NT) dst[e] = tmp[e];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_fill_u16(uint16_t *p, int64_t n, uint16_t v)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;

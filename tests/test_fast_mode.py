@@ -197,15 +197,16 @@ def test_opt_in_ribbon_inverse_on_cpu_shim(oracle, built):
     import sz_amd
     from sz_amd import api
     saved = api._lib
-    os.environ["SZ_HIP_RIBBON_DEC"] = "1"
     try:
         api._lib = api._bind(ctypes.CDLL(sim_lib.shim_path()))
         assert sz_amd.SZ_Init(os.path.join(ROOT, "tests", "golden", "sz_speed.config")) == 0
-        for name, d, eb in _ribbon_inverse_cases():
-            ref_stream, _ = oracle.compress(d, oracle.ABS, eb)
-            got = sz_amd.SZ_decompress(ref_stream, d.shape, d.dtype)
-            iv = np.uint32 if d.dtype == np.float32 else np.uint64
-            assert np.array_equal(got.view(iv), oracle.decompress(ref_stream, d.shape, d.dtype).view(iv)), name
+        for mode in ("1", "2"):           # 1: results through the STORE wavefront; 2: ribbon-order value array + k_unribbon
+            os.environ["SZ_HIP_RIBBON_DEC"] = mode
+            for name, d, eb in _ribbon_inverse_cases():
+                ref_stream, _ = oracle.compress(d, oracle.ABS, eb)
+                got = sz_amd.SZ_decompress(ref_stream, d.shape, d.dtype)
+                iv = np.uint32 if d.dtype == np.float32 else np.uint64
+                assert np.array_equal(got.view(iv), oracle.decompress(ref_stream, d.shape, d.dtype).view(iv)), (name, mode)
         sz_amd.SZ_Finalize()
     finally:
         os.environ.pop("SZ_HIP_RIBBON_DEC", None)
@@ -215,14 +216,15 @@ def test_opt_in_ribbon_inverse_on_cpu_shim(oracle, built):
 @pytest.mark.gpu
 def test_opt_in_ribbon_inverse_on_gpu(oracle, built):
     import sz_amd
-    os.environ["SZ_HIP_RIBBON_DEC"] = "1"
     try:
         assert sz_amd.SZ_Init(os.path.join(ROOT, "tests", "golden", "sz_speed.config")) == 0
-        for name, d, eb in _ribbon_inverse_cases() + [("S-100x200x300", s_field(100, 200, 300), 1e-4)]:
-            ref_stream, _ = oracle.compress(d, oracle.ABS, eb)
-            got = sz_amd.SZ_decompress(ref_stream, d.shape, d.dtype)
-            iv = np.uint32 if d.dtype == np.float32 else np.uint64
-            assert np.array_equal(got.view(iv), oracle.decompress(ref_stream, d.shape, d.dtype).view(iv)), name
+        for mode in ("1", "2"):
+            os.environ["SZ_HIP_RIBBON_DEC"] = mode
+            for name, d, eb in _ribbon_inverse_cases() + [("S-100x200x300", s_field(100, 200, 300), 1e-4)]:
+                ref_stream, _ = oracle.compress(d, oracle.ABS, eb)
+                got = sz_amd.SZ_decompress(ref_stream, d.shape, d.dtype)
+                iv = np.uint32 if d.dtype == np.float32 else np.uint64
+                assert np.array_equal(got.view(iv), oracle.decompress(ref_stream, d.shape, d.dtype).view(iv)), (name, mode)
         sz_amd.SZ_Finalize()
     finally:
         os.environ.pop("SZ_HIP_RIBBON_DEC", None)
