@@ -1443,11 +1443,14 @@ __global__ __launch_bounds__(256) void k_hdec_write(szh_hdec_args a, const u64 *
 // A wavefront takes one (tile, wavefront w, row r) and SZH_UR_STEPS steps of it: 64 lanes x SZH_UR_STEPS values = 64 row pieces of
 // SZH_UR_STEPS * sizeof(T) contiguous bytes.  It reads them as the sweep wrote them (64 lanes x 16 bytes per load), turns the block
 // in LDS and writes every row piece with neighbouring lanes (SZH_UR_STEPS / g lanes per row: 256-byte runs for float).
+#ifndef SZH_UR_STEPS
 #define SZH_UR_STEPS 64
+#endif
 template <class T>
 __global__ __launch_bounds__(256) void k_unribbon(szh_geom3 G, szh_rb_layout rb, const T *__restrict__ xr, T *__restrict__ out)
 {
     constexpr int g = 16 / (int)sizeof(T), NV = SZH_UR_STEPS / g, PITCH = SZH_UR_STEPS + g;      // (+ g: rows start in different banks)
+    static_assert(64 % NV == 0 && (szh_rb_shape<T>::W * szh_rb_shape<T>::R) % 4 == 0, "a wavefront writes whole rows; a workgroup takes four (w, r) pairs");
     __shared__ __attribute__((aligned(16))) T tile[4][64 * PITCH];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int WR = rb.W * rb.R, nchunk = (rb.NT + SZH_UR_STEPS - 1) / SZH_UR_STEPS;
