@@ -1200,7 +1200,9 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
     // SZ_HIP_RIBBON_DEC=0: k_pencil on natural-order codes (rounds 1 - 2; still the path of arrays with regression blocks, 2-D, SZ 1.4).
     szh_rb_layout rbl = {0, 0, 0, 0, 0, 0};
     size_t nat_elems = (size_t)n;
-    const int dec_ribbon_mode = ribbon_applies<T>(G, reg_count) ? tune_int("SZ_HIP_RIBBON_DEC", 2) : 0;     // 1: natural-order values through the STORE wavefront
+    int dec_ribbon_mode = ribbon_applies<T>(G, reg_count) ? tune_int("SZ_HIP_RIBBON_DEC", 2) : 0;           // 1: natural-order values through the STORE wavefront
+    if (dec_ribbon_mode == 2 && (double)szh_rb_steps_of<T>(G.g2.count) * szh_rb_shape<T>::W * szh_rb_shape<T>::R * 64.0 * sizeof(T) >= 2.0e9)
+        dec_ribbon_mode = 0;                   // (a tile's stretch of the value array is addressed with 32-bit offsets)
     const bool dec_ribbon = dec_ribbon_mode != 0;                                                            // 2: ribbon-order values + k_unribbon
     if (dec_ribbon) {
         using RS = szh_rb_shape<T>;
