@@ -138,6 +138,7 @@ static unsigned char *szo_zstd_decompress(const unsigned char *src, size_t len, 
 #define IS_F64 0
 #include "szo_sz21_impl.h"
 #include "szo_sz14_impl.h"
+#include "szo_omp_impl.h"
 #include "szo_msst_impl.h"
 #include "szo_pwr_impl.h"
 #undef T
@@ -151,6 +152,7 @@ static unsigned char *szo_zstd_decompress(const unsigned char *src, size_t len, 
 #define IS_F64 1
 #include "szo_sz21_impl.h"
 #include "szo_sz14_impl.h"
+#include "szo_omp_impl.h"
 #include "szo_msst_impl.h"
 #include "szo_pwr_impl.h"
 #undef T
@@ -453,3 +455,16 @@ void *szo_decompress(int data_type, const unsigned char *bytes, size_t byte_len,
     }
 SZO_METRICS(szo_metrics_f32, float)
 SZO_METRICS(szo_metrics_f64, double)
+
+/* ---- the reference's OpenMP container (szo_omp_impl.h): 3-D arrays cut into thread_num independent boxes.  meta: the stream's first
+ * 4 + MetaDataByteLength bytes (from the configuration state of the writing library); decompress takes the stream without them. */
+unsigned char *szo_omp_compress(const szo_params *p, int data_type, const void *data, size_t r1, size_t r2, size_t r3, double eb, int thread_num,
+                                const unsigned char *meta, size_t meta_len, size_t *out_size)
+{
+    return data_type == 0 ? szo_omp_compress_f32(p, (const float *)data, r1, r2, r3, (float)eb, thread_num, meta, meta_len, out_size)
+                          : szo_omp_compress_f64(p, (const double *)data, r1, r2, r3, eb, thread_num, meta, meta_len, out_size);
+}
+void *szo_omp_decompress(int data_type, const unsigned char *bytes, size_t r1, size_t r2, size_t r3)
+{
+    return data_type == 0 ? (void *)szo_omp_decompress_f32(bytes, r1, r2, r3) : (void *)szo_omp_decompress_f64(bytes, r1, r2, r3);
+}

@@ -57,6 +57,10 @@ def lib():
         L.szo_fast_compress.argtypes = [ctypes.c_int, ctypes.c_void_p] + [ctypes.c_size_t] * 3 + [ctypes.c_double, ctypes.c_uint, ctypes.POINTER(ctypes.c_size_t)]
         L.szo_fast_decompress.restype = ctypes.c_void_p
         L.szo_fast_decompress.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t] + [ctypes.c_size_t] * 3
+        L.szo_omp_compress.restype = ctypes.POINTER(ctypes.c_ubyte)
+        L.szo_omp_compress.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p] + [ctypes.c_size_t] * 3 + [ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+        L.szo_omp_decompress.restype = ctypes.c_void_p
+        L.szo_omp_decompress.argtypes = [ctypes.c_int, ctypes.c_void_p] + [ctypes.c_size_t] * 3
         L.szo_free_stages.argtypes = [ctypes.c_void_p]
         L.free.argtypes = [ctypes.c_void_p]
         _lib = L
@@ -171,6 +175,31 @@ def fast_decompress(stream, shape, dtype):
     r = L.szo_fast_decompress(SZ_FLOAT if np.dtype(dtype) == np.float32 else SZ_DOUBLE, buf, len(stream), *_dims3(shape))
     if not r:
         raise RuntimeError("oracle fast decompress failed")
+    n = int(np.prod(shape))
+    a = np.ctypeslib.as_array(ctypes.cast(r, ctypes.POINTER(np.ctypeslib.as_ctypes_type(np.dtype(dtype)))), shape=(n,)).copy()
+    L.free(r)
+    return a.reshape(shape)
+
+
+def omp_compress(data, eb, threads, meta, params=None):
+    """The reference's OpenMP container for a 3-D array (oracle/szo_omp_impl.h; sz/src/sz_omp.c:63-358).  meta: the stream's first
+    4 + MetaDataByteLength bytes (configuration state of the writing library)."""
+    L = lib()
+    data = np.ascontiguousarray(data)
+    assert data.ndim == 3
+    p = params or default_params()
+    n = ctypes.c_size_t(0)
+    mb = ctypes.create_string_buffer(bytes(meta), len(meta))
+    out = L.szo_omp_compress(ctypes.byref(p), SZ_FLOAT if data.dtype == np.float32 else SZ_DOUBLE, data.ctypes.data, *data.shape, eb, threads, mb, len(meta), ctypes.byref(n))
+    b = bytes(out[:n.value])
+    L.free(out)
+    return b
+
+
+def omp_decompress(stream, meta_len, shape, dtype):
+    L = lib()
+    buf = ctypes.create_string_buffer(stream[meta_len:], len(stream) - meta_len)
+    r = L.szo_omp_decompress(SZ_FLOAT if np.dtype(dtype) == np.float32 else SZ_DOUBLE, buf, *shape)
     n = int(np.prod(shape))
     a = np.ctypeslib.as_array(ctypes.cast(r, ctypes.POINTER(np.ctypeslib.as_ctypes_type(np.dtype(dtype)))), shape=(n,)).copy()
     L.free(r)
