@@ -33,6 +33,10 @@ double now_ms()
 } // namespace
 
 struct szhip_sweep_gate { std::mutex m; hipEvent_t last = nullptr; };
+// compress calls of this process that are inside the library right now, whatever their context: the chain / kernel overlap of an array with
+// regression blocks is only taken by a call that starts alone (see compress_impl)
+static std::atomic<int> g_compress_calls{0};
+struct compress_call_guard { compress_call_guard() { g_compress_calls.fetch_add(1); } ~compress_call_guard() { g_compress_calls.fetch_sub(1); } };
 struct szhip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -614,8 +618,9 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
 #ifndef SZH_SYNC_LAUNCH
         // (not in a pool lane: with several contexts at work the hand-off of coefficients to the running kernel failed 5 - 6 times in 480
         //  rounds of tools/gpu_pool_dbg.py -- errors, not wrong streams; none in 480 rounds with the serial order.  The lanes overlap one
-        //  array's chain with the other's kernels anyway.)
-        overlap = !two_d && !ctx->gate && tune_int("SZ_HIP_CHAIN_THREADS", 1) && tune_int("SZ_HIP_CHAIN_OVERLAP", 1);
+        //  array's chain with the other's kernels anyway.
+        //  A lone context takes the overlap only when no other compress call of the process is under way as this one starts.)
+        overlap = !two_d && !ctx->gate && g_compress_calls.load() <= 1 && tune_int("SZ_HIP_CHAIN_THREADS", 1) && tune_int("SZ_HIP_CHAIN_OVERLAP", 1);
         if (overlap) { TRY(probe_streams(ctx)); overlap = ctx->streams_independent == 1; }
 #endif
         TRY(ensure_pinned3(ctx, reg_count * 4 * sizeof(T) + (overlap ? ((size_t)nb + 64) * 4 * sizeof(T) + 256 : 0)));
@@ -2681,6 +2686,7 @@ int szhip_compress(szhip_ctx *ctx, int dtype, const void *data, int data_on_devi
     if ((r0 != 0 && r0 < 2) || r1 < 2 || r2 < 2 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff) return SZHIP_ERR_ARG;
     if (!(eb > 0)) return SZHIP_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
+    const compress_call_guard in_flight;
     unsigned char *const out0 = *out; const size_t cap0 = *out_size;     // (a failed first attempt clears them: the repetition starts from the caller's values)
     const int rc = with_ticket_fallback(ctx, [&]() { *out = out0; *out_size = cap0; return dtype == SZHIP_F32
                ? compress_impl<float>(ctx, data, data_on_device, r0, r1, r2, eb, params, meta, meta_len, out_on_device, out, out_size, stats)
@@ -2697,6 +2703,7 @@ int szhip_compress_sz14(szhip_ctx *ctx, int dtype, const void *data, int data_on
     if ((r0 != 0 && r0 < 2) || (r1 < 2 && !(r0 == 0 && r1 == 0)) || r2 < 2 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff) return SZHIP_ERR_ARG;
     if (!(eb > 0)) return SZHIP_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
+    const compress_call_guard in_flight;
     unsigned char *const out0 = *out; const size_t cap0 = *out_size;     // (a failed first attempt clears them: the repetition starts from the caller's values)
     const int rc = with_ticket_fallback(ctx, [&]() { *out = out0; *out_size = cap0; return dtype == SZHIP_F32
                ? compress14_impl<float>(ctx, data, data_on_device, r0, r1, r2, eb, value_range, median, params, meta, meta_len, nullptr, out_on_device, out, out_size, stats)
@@ -2751,6 +2758,7 @@ int szhip_compress_sz14_pwr(szhip_ctx *ctx, int dtype, const void *data, int dat
     if ((r0 != 0 && r0 < 2) || (r1 < 2 && !(r0 == 0 && r1 == 0)) || r2 < 2 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff) return SZHIP_ERR_ARG;
     if (!(eb > 0)) return SZHIP_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
+    const compress_call_guard in_flight;
     unsigned char *const out0 = *out; const size_t cap0 = *out_size;     // (a failed first attempt clears them: the repetition starts from the caller's values)
     const int rc = with_ticket_fallback(ctx, [&]() { *out = out0; *out_size = cap0; return dtype == SZHIP_F32
                ? compress14_impl<float>(ctx, data, data_on_device, r0, r1, r2, eb, value_range, median, params, meta, meta_len, pwr, out_on_device, out, out_size, stats)
