@@ -142,6 +142,26 @@ int szhip_decompress_sz14(szhip_ctx *ctx, int dtype, const unsigned char *stream
                           size_t body_off, size_t r0, size_t r1, size_t r2, void *out, int out_on_device, szhip_stats *stats);
 
 /*
+ * The reference's OpenMP container for 3-D arrays -- replaces SZ_compress_float_3D_MDQ_openmp (sz/src/sz_omp.c:63-358; double :578-863; box
+ * quantiser SZ_compress_float_3D_MDQ_RA_block, sz/src/sz_float.c:4704-5012) and decompressDataSeries_float_3D_openmp (sz_omp.c:366-566):
+ * the array is cut into the box grid of `thread_num` (sz_omp.c:88-117; what an OpenMP build takes from omp_get_max_threads()), every box is
+ * quantised on its own from its own reconstructed neighbours, one Huffman code book covers all boxes, every box has a byte-aligned payload.
+ * A stock OpenMP build of SZ reads the stream; the box count is in it.  `meta`: the 4 + MetaDataByteLength bytes the reference writes in
+ * front (version, flag byte, parameter bytes); `eb`: the absolute bound (`realPrecision`).  params->quantization_intervals == 0: the
+ * interval optimiser of the SZ 1.4 path over the whole array (optimize_intervals_float_3D_opt, sz_omp.c:73-82).
+ * Restrictions (SZHIP_ERR_UNSUP otherwise): the box grid must divide the array (on an uneven grid the reference's code book depends on
+ * uninitialised memory), a box face (dim 0 x dim 1 of a box) has at most 1024 rows -- thread_num 4096 cuts 512^3 into 32^3 boxes.
+ * `body_off` of the inverse: offset of the thread_num field (4 + MetaDataByteLength).
+ * Status: parity with the oracle (oracle/szo_omp_impl.h, pinned against the reference built with -fopenmp) on the CPU shim; written after
+ * round 3's GPU minutes were spent, so not yet run on hardware.
+ */
+int szhip_compress_omp(szhip_ctx *ctx, int dtype, const void *data, int data_on_device, size_t r0, size_t r1, size_t r2, double eb,
+                       int thread_num, const szhip_params *params, const unsigned char *meta, size_t meta_len,
+                       int out_on_device, unsigned char **out, size_t *out_size, szhip_stats *stats);
+int szhip_decompress_omp(szhip_ctx *ctx, int dtype, const unsigned char *stream, int stream_on_device, size_t stream_len,
+                         size_t body_off, size_t r0, size_t r1, size_t r2, void *out, int out_on_device, szhip_stats *stats);
+
+/*
  * Point-wise relative bounds (PW_REL and its AND/OR combinations) in their log-domain form: the `_pwr_pre_log` functions of
  * sz/src/sz_float_pwr.c:1791-1975 / sz_double_pwr.c:1781-1965 (dispatch sz_float.c:2888-2996) and their inverses
  * szd_float_pwr.c:1353-1422.  Three steps, the sign bytes being compressed on the host (zstd) in between:

@@ -136,6 +136,14 @@ def _bind(L):
                                         ctypes.POINTER(szhip_stats)]
     L.szhip_decompress_fast.restype = ctypes.c_int
     L.szhip_debug_fetch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, sz]; L.szhip_debug_fetch.restype = ctypes.c_int
+    if hasattr(L, "szhip_compress_omp"):
+        L.szhip_compress_omp.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, sz, sz, sz, ctypes.c_double, ctypes.c_int,
+                                         ctypes.POINTER(szhip_params), ctypes.c_char_p, sz, ctypes.c_int,
+                                         ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(sz), ctypes.POINTER(szhip_stats)]
+        L.szhip_compress_omp.restype = ctypes.c_int
+        L.szhip_decompress_omp.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, sz, sz, sz, sz, sz,
+                                           ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(szhip_stats)]
+        L.szhip_decompress_omp.restype = ctypes.c_int
     L.szhost_write_meta.argtypes = [ctypes.POINTER(szhost_meta), ctypes.c_ubyte, ctypes.c_char_p]
     L.szhost_write_meta.restype = sz
     L.free.argtypes = [ctypes.c_void_p]
@@ -353,6 +361,31 @@ class HipContext:
                                          shape3[0], shape3[1], shape3[2], out_ptr, int(out_on_device), ctypes.byref(st))
         if rc:
             self._err(rc, "szhip_decompress_fast")
+        return st
+
+    def compress_omp(self, ptr, on_device, shape3, dtype, eb, thread_num, meta, params=None, out_on_device=False):
+        """The reference's OpenMP container (szhip_compress_omp; sz/src/sz_omp.c:63-358).  Returns (bytes | device pointer int, size, stats)."""
+        p = params or szhip_params(100, 0.99, 65536, 0)
+        out = ctypes.c_void_p()
+        n = ctypes.c_size_t(0)
+        st = szhip_stats()
+        rc = lib().szhip_compress_omp(self._h, 0 if np.dtype(dtype) == np.float32 else 1, ptr, int(on_device), shape3[0], shape3[1], shape3[2],
+                                      eb, thread_num, ctypes.byref(p), meta, len(meta), int(out_on_device), ctypes.byref(out), ctypes.byref(n),
+                                      ctypes.byref(st))
+        if rc:
+            self._err(rc, "szhip_compress_omp")
+        if out_on_device:
+            return out.value, n.value, st
+        b = ctypes.string_at(out.value, n.value)
+        lib().free(out)
+        return b, n.value, st
+
+    def decompress_omp(self, stream_ptr, stream_on_device, stream_len, body_off, shape3, dtype, out_ptr, out_on_device):
+        st = szhip_stats()
+        rc = lib().szhip_decompress_omp(self._h, 0 if np.dtype(dtype) == np.float32 else 1, stream_ptr, int(stream_on_device), stream_len,
+                                        body_off, shape3[0], shape3[1], shape3[2], out_ptr, int(out_on_device), ctypes.byref(st))
+        if rc:
+            self._err(rc, "szhip_decompress_omp")
         return st
 
     def debug_fetch(self, which, count, dtype):

@@ -1,0 +1,322 @@
+// szh_omp.h -- the reference's OpenMP container for 3-D arrays on the GPU: the array is cut into thread_num boxes, every box is
+// quantised on its own (no value crosses a box face), ONE Huffman code book covers all boxes, every box has its own byte-aligned payload.
+//   container, box grid   sz/src/sz_omp.c:63-358    SZ_compress_float_3D_MDQ_openmp          (double: :578-863)
+//   box quantiser         sz/src/sz_float.c:4704-5012  SZ_compress_float_3D_MDQ_RA_block      (double: sz_double.c, same name)
+//   inverse               sz/src/sz_omp.c:366-566   decompressDataSeries_float_3D_openmp,  szd_float.c decompressDataSeries_float_3D_RA_block
+// Why it is on the hot path: thousands of independent boxes instead of ONE dependency front (k_ribbon / k_pencil: ~40 of 256 tiles are
+// on the front at a time), and a stock OpenMP build of SZ reads the stream.
+//
+// The box quantiser predicts from RECONSTRUCTED neighbours (left, above, previous plane), so inside a box the points of one hyperplane
+// k + i + j = t are independent and the hyperplanes follow each other.  A workgroup takes a box; thread (k, i) owns the ROW (k, i, :)
+// and walks it along j, one point per step, at step t = k + i + j:
+//   * its own two previous reconstructions stay in registers (the left neighbours);
+//   * the three neighbours of other rows -- (k, i-1, j), (k-1, i, j), (k-1, i-1, j) -- were written at steps t-1, t-1, t-2 into a ring of
+//     four values per row in LDS; their predecessors along j are what the thread read one step earlier (registers again).  A value j is
+//     read at steps t+1 and t+2 and its ring place is overwritten at t+4: ONE barrier per step is enough;
+//   * the row is read with 16-byte loads (one per 16 / sizeof(T) steps) and its codes leave as 8-byte stores (four codes): every lane of
+//     a wavefront works on another row, so narrower accesses would spend a full line transfer per 4 (2) bytes.
+// Box faces of up to 1024 rows (c0 * c1 <= 1024: a 32^3 box is 1024 rows of 32), the box grid must divide the array (on an uneven grid
+// the reference counts Huffman frequencies over uninitialised gaps of its code array: nothing to be identical to).
+// NOT YET RUN ON HARDWARE (written after round 3's GPU budget was spent): parity is proven on the CPU shim only (tests/test_omp_hip.py).
+#pragma once
+
+struct szh_omp_geom {
+    int nx, ny, nz;            // boxes along dim 0 / 1 / 2
+    int c0, c1, c2;            // points of a box along dim 0 / 1 / 2
+    int64_t d0, d1;            // pitches of the array
+    int nb, bel;               // boxes, points per box
+    int cpb;                   // chunks of SZH_ENC_CHUNK codes per box (the last one may be short)
+    int vec;                   // rows may be read / written 16 bytes at a time, codes 8 bytes at a time
+};
+#define SZH_OMP_MAX_ROWS 1024
+
+template <class T> struct szh_omp_vec { static constexpr int NV = 16 / (int)sizeof(T); struct alignas(16) type { T v[NV]; }; };
+
+__device__ __forceinline__ const void *szh_omp_box_origin_bytes(const szh_omp_geom &g, int b, size_t elem, const void *data)
+{
+    const int bi = b / (g.ny * g.nz), bj = (b / g.nz) % g.ny, bk = b % g.nz;
+    return (const char *)data + ((int64_t)bi * g.c0 * g.d0 + (int64_t)bj * g.c1 * g.d1 + (int64_t)bk * g.c2) * (int64_t)elem;
+}
+
+// the predictor by position (sz_float.c:4749-4990), all from reconstructed values, left to right as the reference adds them:
+//   plane 0: (0,0,0) the box's first value, (0,0,1) the left neighbour, (0,0,j>=2) 2 left - left-left, (0,i>=1,0) the value above,
+//            elsewhere left + above - above-left;
+//   plane k>=1: (k,0,0) the previous plane's value, first row / first column the 2-D form with the previous plane, elsewhere the 7-point form
+template <class T>
+__device__ __forceinline__ T szh_omp_predict(int k, int i, int j, T first, T l1, T l2, T A, T Ap, T B, T Bp, T C, T Cp)
+{
+    if (k == 0) {
+        if (i == 0) return j == 0 ? first : j == 1 ? l1 : 2 * l1 - l2;
+        return j == 0 ? A : l1 + A - Ap;
+    }
+    if (i == 0) return j == 0 ? B : l1 + B - Bp;
+    if (j == 0) return A + B - C;
+    return l1 + A + B - Ap - C - Bp + Cp;
+}
+
+// DEC = false: data -> codes (0 = the value is kept verbatim), the count of such values per box, the box's first value
+// DEC = true : codes + the box's verbatim values (in the box's row-major order) + its first value -> data
+template <class T, bool DEC>
+__global__ __launch_bounds__(1024) void k_omp_box(szh_omp_geom g, const T *__restrict__ data, T *__restrict__ out, T eb, T recip, int intervals,
+                                                  uint16_t *__restrict__ codes, unsigned *__restrict__ ucount, u64 *__restrict__ ucount64, T *__restrict__ first,
+                                                  const T *__restrict__ unpred, const u64 *__restrict__ uoff)
+{
+    SZH_DYN_SMEM(smem);
+    T *ring = reinterpret_cast<T *>(smem);                  // [4][rows]
+    __shared__ unsigned s_un;
+    __shared__ unsigned s_scan[SZH_OMP_MAX_ROWS];
+    constexpr int NV = szh_omp_vec<T>::NV;
+    typedef typename szh_omp_vec<T>::type vecT;
+    const int b = blockIdx.x, tid = threadIdx.x, rows = g.c0 * g.c1;
+    const bool live = tid < rows;
+    const int k = live ? tid / g.c1 : 0, i = live ? tid - k * g.c1 : 0;
+    const int64_t row_off = (int64_t)k * g.d0 + (int64_t)i * g.d1;
+    const T *row_in = DEC ? nullptr : reinterpret_cast<const T *>(szh_omp_box_origin_bytes(g, b, sizeof(T), data)) + row_off;
+    T *row_out = DEC ? reinterpret_cast<T *>(const_cast<void *>(szh_omp_box_origin_bytes(g, b, sizeof(T), out))) + row_off : nullptr;
+    uint16_t *crow = codes + (int64_t)b * g.bel + (int64_t)tid * g.c2;
+    const int radius = intervals / 2;
+    if (tid == 0) s_un = 0u;
+    T first_v;
+    unsigned urank = 0;
+    if (DEC) {
+        // rank of the row's first verbatim value among the box's: zeros of the rows before it (row-major order = row order)
+        unsigned z = 0;
+        if (live) for (int j = 0; j < g.c2; ++j) z += crow[j] == 0;
+        s_scan[tid] = z;
+        __syncthreads();
+        for (int o = 1; o < (int)blockDim.x; o <<= 1) {
+            const unsigned add = tid >= o ? s_scan[tid - o] : 0u;
+            __syncthreads();
+            s_scan[tid] += add;
+            __syncthreads();
+        }
+        urank = s_scan[tid] - z;
+        first_v = first[b];
+    } else {
+        first_v = *reinterpret_cast<const T *>(szh_omp_box_origin_bytes(g, b, sizeof(T), data));
+        __syncthreads();
+    }
+    const T *ub = DEC ? unpred + uoff[b] : nullptr;
+    T l1 = 0, l2 = 0, Ap = 0, Bp = 0, Cp = 0;
+    unsigned nun = 0;
+    vecT vin; for (int e = 0; e < NV; ++e) vin.v[e] = 0;
+    vecT vout; for (int e = 0; e < NV; ++e) vout.v[e] = 0;
+    u64 cacc = 0;
+    const int steps = g.c0 + g.c1 + g.c2 - 2;
+    for (int t = 0; t < steps; ++t) {
+        const int j = t - k - i;
+        if (live && j >= 0 && j < g.c2) {
+            const int slot = (j & 3) * rows;
+            T A = 0, B = 0, C = 0;
+            if (i > 0) A = ring[slot + tid - 1];
+            if (k > 0) B = ring[slot + tid - g.c1];
+            if (i > 0 && k > 0) C = ring[slot + tid - g.c1 - 1];
+            const T pred = szh_omp_predict<T>(k, i, j, first_v, l1, l2, A, Ap, B, Bp, C, Cp);
+            T rec;
+            if (!DEC) {
+                T cur;
+                if (g.vec) {
+                    if ((j & (NV - 1)) == 0) vin = *reinterpret_cast<const vecT *>(row_in + j);
+                    cur = vin.v[0];
+#pragma unroll
+                    for (int e = 1; e < NV; ++e) if ((j & (NV - 1)) == e) cur = vin.v[e];
+                } else cur = row_in[j];
+                // sz_float.c:4762-4783: |diff| / eb + 1 against the interval count, truncation, the bound verified on the result
+                const T diff = cur - pred;
+                T itv = (diff < 0 ? -diff : diff) * recip + 1;
+                int tc = 0;
+                rec = cur;
+                if (itv < (T)intervals) {
+                    if (diff < 0) itv = -itv;
+                    tc = (int)(itv / 2) + radius;
+                    const T r = pred + (T)(2 * (tc - radius)) * eb;
+                    const T err = cur - r;
+                    if ((err < 0 ? -err : err) > eb) tc = 0; else rec = r;
+                }
+                if (tc == 0) ++nun;
+                if (g.vec) {
+                    cacc |= (u64)(unsigned)tc << (16 * (j & 3));
+                    if ((j & 3) == 3) { *reinterpret_cast<u64 *>(crow + (j - 3)) = cacc; cacc = 0; }
+                } else crow[j] = (uint16_t)tc;
+            } else {
+                unsigned tc;
+                if (g.vec) {
+                    if ((j & 3) == 0) cacc = *reinterpret_cast<const u64 *>(crow + j);
+                    tc = (unsigned)(cacc >> (16 * (j & 3))) & 0xffffu;
+                } else tc = crow[j];
+                if (tc) rec = pred + (T)(2 * ((int)tc - radius)) * eb;
+                else rec = ub[urank + nun++];
+                if (g.vec) {
+#pragma unroll
+                    for (int e = 0; e < NV; ++e) if ((j & (NV - 1)) == e) vout.v[e] = rec;
+                    if ((j & (NV - 1)) == NV - 1) *reinterpret_cast<vecT *>(row_out + (j - (NV - 1))) = vout;
+                } else row_out[j] = rec;
+            }
+            ring[slot + tid] = rec;
+            l2 = l1; l1 = rec; Ap = A; Bp = B; Cp = C;
+        }
+        __syncthreads();
+    }
+    if (!DEC) {
+        if (nun) atomicAdd(&s_un, nun);
+        __syncthreads();
+        if (tid == 0) { ucount[b] = s_un; ucount64[b] = s_un; first[b] = first_v; }
+    }
+}
+
+// the values the quantiser kept verbatim, in the box's row-major order, behind those of the boxes before it (sz_omp.c:246-262)
+template <class T>
+__global__ __launch_bounds__(256) void k_omp_gather(szh_omp_geom g, const T *__restrict__ data, const uint16_t *__restrict__ codes,
+                                                    const unsigned *__restrict__ ucount, const u64 *__restrict__ uoff, T *__restrict__ unpred)
+{
+    __shared__ u64 sh[8];
+    const int b = blockIdx.x;
+    if (ucount[b] == 0) return;                               // uniform
+    const T *box = reinterpret_cast<const T *>(szh_omp_box_origin_bytes(g, b, sizeof(T), data));
+    const uint16_t *cb = codes + (int64_t)b * g.bel;
+    T *dst = unpred + uoff[b];
+    u64 done = 0;
+    for (int base = 0; base < g.bel; base += 256 * 8) {
+        const int p0 = base + (int)threadIdx.x * 8;
+        unsigned mask = 0;
+        for (int e = 0; e < 8; ++e) if (p0 + e < g.bel && cb[p0 + e] == 0) mask |= 1u << e;
+        u64 tot;
+        u64 rank = done + block_excl_scan_256((u64)__builtin_popcount(mask), sh, &tot);
+        for (int e = 0; e < 8; ++e) if (mask >> e & 1u) {
+            const int p = p0 + e, k = p / (g.c1 * g.c2), r = p - k * (g.c1 * g.c2), i = r / g.c2, j = r - i * g.c2;
+            dst[rank++] = box[(int64_t)k * g.d0 + (int64_t)i * g.d1 + j];
+        }
+        done += tot;
+    }
+}
+
+// ---- Huffman packing with one byte-aligned payload per box (sz_omp.c:300-330: `encode` per box into its own buffer, then memcpy)
+__device__ __forceinline__ void omp_load8(const uint16_t *__restrict__ cb, int p0, int bel, bool aligned, uint16_t (&c)[8])
+{
+    if (aligned && p0 + 8 <= bel) { const uint4 w = *reinterpret_cast<const uint4 *>(cb + p0); __builtin_memcpy(c, &w, 16); }
+    else { for (int q = 0; q < 8; ++q) c[q] = p0 + q < bel ? cb[p0 + q] : (uint16_t)0; }
+}
+// bits of chunk q of box b -> chunk_bits[b * cpb + q]
+__global__ __launch_bounds__(256) void k_omp_chunk_bits(szh_omp_geom g, const uint16_t *__restrict__ codes, const uint8_t *__restrict__ len, u64 *chunk_bits)
+{
+    __shared__ u64 sh[4];
+    const int c = blockIdx.x, b = c / g.cpb, q = c - b * g.cpb;
+    const uint16_t *cb = codes + (int64_t)b * g.bel;
+    const int p0 = q * SZH_ENC_CHUNK + (int)threadIdx.x * 8;
+    uint16_t cc[8];
+    omp_load8(cb, p0, g.bel, (g.bel & 7) == 0, cc);
+    unsigned s = 0;
+    for (int e = 0; e < 8; ++e) if (p0 + e < g.bel) s += len[cc[e]];
+    const u64 ws = wave_sum_u64((u64)s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ws;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_bits[c] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+// bytes of box b = its bits rounded up (Huffman.c encode: the last byte is padded with zero bits)
+__global__ __launch_bounds__(256) void k_omp_box_bytes(int nb, int cpb, const u64 *__restrict__ chunk_off, const u64 *__restrict__ total_bits, u64 *box_bytes)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nb) return;
+    const u64 lo = chunk_off[(int64_t)b * cpb], hi = b + 1 < nb ? chunk_off[(int64_t)(b + 1) * cpb] : *total_bits;
+    box_bytes[b] = (hi - lo + 7) >> 3;
+}
+// out32: 4-byte aligned base of the stream buffer (zeroed); bit0: bit position of the first box's payload in it
+__global__ __launch_bounds__(256) void k_omp_encode(szh_omp_geom g, const uint16_t *__restrict__ codes, const u64 *__restrict__ code,
+                                                    const uint8_t *__restrict__ len, const u64 *__restrict__ chunk_off,
+                                                    const u64 *__restrict__ box_off, u64 bit0, unsigned *out32)
+{
+    __shared__ unsigned buf[SZH_ENC_CHUNK * 2 + 2];
+    __shared__ u64 sh[8];
+    const int c = blockIdx.x, b = c / g.cpb, q = c - b * g.cpb;
+    const uint16_t *cb = codes + (int64_t)b * g.bel;
+    const int p0 = q * SZH_ENC_CHUNK + (int)threadIdx.x * 8;
+    uint16_t cc[8];
+    omp_load8(cb, p0, g.bel, (g.bel & 7) == 0, cc);
+    const u64 gbit = bit0 + box_off[b] * 8 + (chunk_off[c] - chunk_off[(int64_t)b * g.cpb]);
+    const unsigned lead = (unsigned)(gbit & 31);
+    unsigned l[8]; unsigned s = 0;
+    for (int e = 0; e < 8; ++e) { l[e] = p0 + e < g.bel ? (unsigned)len[cc[e]] : 0u; s += l[e]; }
+    u64 tot;
+    const u64 ex = block_excl_scan_256((u64)s, sh, &tot);
+    for (unsigned w = threadIdx.x; w < (unsigned)((lead + tot + 31) >> 5) + 1; w += 256) buf[w] = 0;
+    __syncthreads();
+    unsigned pos = lead + (unsigned)ex;
+    u64 acc = 0; int accn = 0;
+    for (int e = 0; e < 8; ++e) {
+        if (!l[e]) continue;
+        const u64 cw = code[cc[e]];
+        if (accn + (int)l[e] > 64) { lds_put_bits(buf, pos, acc, accn); pos += accn; acc = 0; accn = 0; }
+        acc = l[e] == 64 ? cw : ((acc << l[e]) | (cw & ((1ull << l[e]) - 1)));
+        accn += (int)l[e];
+    }
+    if (accn) lds_put_bits(buf, pos, acc, accn);
+    __syncthreads();
+    const unsigned nwords = (unsigned)((lead + tot + 31) >> 5);
+    const u64 w0 = gbit >> 5;
+    for (unsigned w = threadIdx.x; w < nwords; w += 256) {
+        const unsigned v = __builtin_bswap32(buf[w]);
+        if (w == 0 || w == nwords - 1) { if (v) atomicOr(&out32[w0 + w], v); }
+        else out32[w0 + w] = v;
+    }
+}
+
+// ---- Huffman decoding, a workgroup per box.  A box's payload starts at a byte boundary and holds `bel` symbols, so the boxes are
+// independent; inside a box the 256 lanes take equal stretches of its bits and find their first codeword boundary by the
+// self-synchronising rule of k_hdec_pass (a stretch starts where the one before it ends; repeated until no start moves -- the fixed
+// point is the sequential decode, reached after a couple of rounds because Huffman codes fall into step within a few symbols).
+// Bit by bit through the node table (`table[2 node + bit]`: next node, or 0x80000000 | symbol): the simple form first.
+__device__ __forceinline__ unsigned omp_hdec_run(const unsigned char *__restrict__ bits, unsigned total, const unsigned *__restrict__ table,
+                                                 unsigned pos, unsigned limit, unsigned *endpos, uint16_t *out, unsigned o, unsigned oend)
+{
+    unsigned cnt = 0, p = pos, last = pos, node = 0, cur = 0;
+    if (p < total && (p & 7u)) cur = bits[p >> 3];
+    while (p < total) {
+        if ((p & 7u) == 0) cur = bits[p >> 3];
+        const unsigned bit = (cur >> (7u - (p & 7u))) & 1u;
+        ++p;
+        const unsigned nx = table[2 * node + bit];
+        if (nx & 0x80000000u) {
+            if (out && o + cnt < oend) out[o + cnt] = (uint16_t)(nx & 0xffffu);
+            ++cnt; node = 0; last = p;
+            if (p >= limit) break;
+        } else node = nx;
+    }
+    *endpos = last;
+    return cnt;
+}
+__global__ __launch_bounds__(256) void k_omp_hdec(int bel, const unsigned char *__restrict__ payload, const u64 *__restrict__ box_off,
+                                                  const u64 *__restrict__ box_bytes, const unsigned *__restrict__ table, int single_symbol,
+                                                  uint16_t *__restrict__ codes, unsigned *__restrict__ bad)
+{
+    __shared__ unsigned s_start[257], s_flag[2];
+    __shared__ u64 sh[8];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    uint16_t *out = codes + (int64_t)b * bel;
+    if (single_symbol >= 0) { for (int p = tid; p < bel; p += 256) out[p] = (uint16_t)single_symbol; return; }
+    const unsigned char *bits = payload + box_off[b];
+    const unsigned total = (unsigned)(box_bytes[b] * 8);
+    unsigned sb = (total + 255u) / 256u; if (sb < 64u) sb = 64u;
+    const unsigned first = (unsigned)tid * sb, limit = first + sb;
+    unsigned start = first, endp = first, cnt = 0;
+    bool redo = true;
+    if (tid == 0) { s_flag[0] = 0u; s_flag[1] = 0u; }
+    __syncthreads();
+    for (int round = 0; round < 257; ++round) {
+        if (redo) {
+            if (start < limit && start < total) cnt = omp_hdec_run(bits, total, table, start, limit, &endp, nullptr, 0, 0);
+            else { cnt = 0; endp = start; }
+            s_start[tid + 1] = endp;
+        }
+        __syncthreads();
+        if (tid == 0) s_flag[(round + 1) & 1] = 0u;            // (the flag of the NEXT round; this round's is read below, after the barrier)
+        redo = false;
+        if (tid > 0) { const unsigned ns = s_start[tid]; if (ns != start) { start = ns; redo = true; } }
+        if (redo) s_flag[round & 1] = 1u;
+        __syncthreads();
+        if (!s_flag[round & 1]) break;                         // uniform
+    }
+    u64 tot;
+    const unsigned o = (unsigned)block_excl_scan_256((u64)cnt, sh, &tot);
+    if (tot < (u64)bel) { if (tid == 0) atomicAdd(bad, 1u); }   // a payload that holds fewer symbols than the box has points
+    if (cnt && o < (unsigned)bel) { unsigned e; omp_hdec_run(bits, total, table, start, limit, &e, out, o, (unsigned)bel); }
+}

@@ -2463,6 +2463,323 @@ int decompress_fast_impl(szhip_ctx *ctx, const unsigned char *stream_in, int str
     return SZHIP_OK;
 }
 
+
+// =====================================================================================================================
+// The reference's OpenMP container for 3-D arrays (szh_omp.h; sz/src/sz_omp.c:63-358, inverse :366-566).  Stream, behind the caller's
+// 4 + MetaDataByteLength parameter bytes (`meta`):
+//   u32be thread_num | T eb (big endian) | u32be intervals | u32be tree_bytes | u32be nodes | tree
+//   | u32 ucount[nb] | T first[nb] | the boxes' verbatim values, box after box | u64 payload_bytes[nb] | the boxes' Huffman payloads
+// (the tables behind the tree in the host's byte order, as the reference memcpy's them).
+// =====================================================================================================================
+static int omp_box_grid(szhip_ctx *ctx, int thread_num, size_t r0, size_t r1, size_t r2, size_t elem, szh_omp_geom *g)
+{
+    if (thread_num < 1) FAIL(SZHIP_ERR_ARG, "thread_num %d", thread_num);
+    // sz_omp.c:88-117: the exponent of two is spread over the three dimensions, dim 0 first; the rest of thread_num goes to dim 2
+    int order = 0; while ((2 << order) <= thread_num) ++order;
+    const int bb = order / 3;
+    size_t nx, ny;
+    switch (order % 3) { case 0: nx = (size_t)1 << bb; ny = (size_t)1 << bb; break; case 1: nx = (size_t)1 << (bb + 1); ny = (size_t)1 << bb; break; default: nx = (size_t)1 << (bb + 1); ny = (size_t)1 << (bb + 1); }
+    const size_t nz = (size_t)thread_num / (nx * ny);
+    if (r0 == 0 || r1 == 0 || r2 == 0 || r0 * r1 * r2 >= ((size_t)1 << 40)) FAIL(SZHIP_ERR_UNSUP, "OpenMP container: a 3-D array is needed");
+    if (r0 % nx || r1 % ny || r2 % nz)
+        FAIL(SZHIP_ERR_UNSUP, "OpenMP container: the %zu x %zu x %zu box grid of thread_num %d does not divide %zu x %zu x %zu (on an uneven grid the "
+             "reference's code book depends on uninitialised memory)", nx, ny, nz, thread_num, r0, r1, r2);
+    g->nx = (int)nx; g->ny = (int)ny; g->nz = (int)nz;
+    g->c0 = (int)(r0 / nx); g->c1 = (int)(r1 / ny); g->c2 = (int)(r2 / nz);
+    g->d0 = (int64_t)(r1 * r2); g->d1 = (int64_t)r2;
+    g->nb = (int)(nx * ny * nz);
+    const size_t bel = (size_t)g->c0 * g->c1 * g->c2;
+    if ((size_t)g->c0 * g->c1 > SZH_OMP_MAX_ROWS || bel >= ((size_t)1 << 28))
+        FAIL(SZHIP_ERR_UNSUP, "OpenMP container: a box face of %d x %d rows (at most %d; raise thread_num)", g->c0, g->c1, SZH_OMP_MAX_ROWS);
+    g->bel = (int)bel;
+    g->cpb = (int)((bel + SZH_ENC_CHUNK - 1) / SZH_ENC_CHUNK);
+    g->vec = (g->c2 % 4 == 0 && r2 % 4 == 0) ? 1 : 0;          // (the base address is looked at by the caller)
+    (void)elem;
+    return SZHIP_OK;
+}
+
+template <class T>
+int compress_omp_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r0, size_t r1, size_t r2, double eb_in, int thread_num,
+                      const szhip_params *prm, const unsigned char *meta, size_t meta_len, int out_on_device, unsigned char **out, size_t *out_size,
+                      szhip_stats *stats)
+{
+    szh_omp_geom g;
+    TRY(omp_box_grid(ctx, thread_num, r0, r1, r2, sizeof(T), &g));
+    const szh_geom3 G = szh_make_geom3((int)r0, (int)r1, (int)r2);
+    const int64_t n = G.n;
+    const T eb = (T)eb_in;                                     // `float realPrecision` of sz_omp.c:63 (double: :578)
+    if (!(eb > 0)) FAIL(SZHIP_ERR_ARG, "error bound %g", eb_in);
+    const double t_begin = now_ms();
+    double host_ms = 0;
+    hipStream_t st = ctx->stream;
+    szhip_stats S; memset(&S, 0, sizeof(S));
+    S.n_elements = (uint64_t)n; S.n_blocks = (uint64_t)g.nb;
+    const T *d_in = (const T *)data;
+    if (!data_on_device) {
+        TRY(ensure(ctx, ctx->in, (size_t)n * sizeof(T)));
+        TRY(staged_copy(ctx, ctx->in.p, data, (size_t)n * sizeof(T), true));
+        d_in = (const T *)ctx->in.p;
+    }
+    if ((uintptr_t)d_in & 15u) g.vec = 0;
+    TRY(ensure(ctx, ctx->small, SM_COUNT * 8));
+    u64 *sm = (u64 *)ctx->small.p;
+    HIPCHK(hipMemsetAsync(sm, 0, SM_COUNT * 8, st));
+    HIPCHK(hipEventRecord(ctx->ev[0], st));
+    // ---- interval count (sz_omp.c:73-82: optimize_intervals_float_3D_opt over the whole array when it is not fixed)
+    unsigned intervals = prm->quantization_intervals;
+    if (intervals == 0) {
+        const unsigned max_radius = prm->max_quant_intervals / 2;
+        TRY(ensure(ctx, ctx->hist, (size_t)(max_radius + 8192) * 4 + 64));
+        TRY(ensure_pinned(ctx, (size_t)(max_radius + 8192) * 4 + 64));
+        unsigned *d_rh = (unsigned *)ctx->hist.p, *d_fh = d_rh + max_radius;
+        HIPCHK(hipMemsetAsync(d_rh, 0, (size_t)(max_radius + 8192) * 4, st));
+        const int64_t nrows = szh_sample_row_limit(G, prm->sample_distance);
+        if (nrows > 0) {
+            int grid = (int)std::min<int64_t>((nrows + 255) / 256, 1024);
+            hipLaunchKernelGGL((k_sample<T>), dim3(grid), dim3(256), 0, st, G, d_in, nrows, prm->sample_distance, (double)eb, (T)0,
+                               max_radius, d_rh, d_fh, sm + SM_WITHIN);
+            HIPCHK(hipGetLastError());
+        }
+        unsigned *h_rh = (unsigned *)ctx->pinned;
+        HIPCHK(hipMemcpyAsync(h_rh, d_rh, (size_t)max_radius * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        double h0 = now_ms();
+        u64 total = 0;
+        for (unsigned i = 0; i < max_radius; ++i) total += h_rh[i];
+        const size_t target = (size_t)((float)total * prm->pred_threshold);
+        size_t sum = 0; unsigned i = 0;
+        for (; i < max_radius; ++i) { sum += h_rh[i]; if (sum > target) break; }
+        if (i >= max_radius) i = max_radius - 1;
+        unsigned p2 = 2 * (i + 1); p2 -= 1; p2 |= p2 >> 1; p2 |= p2 >> 2; p2 |= p2 >> 4; p2 |= p2 >> 8; p2 |= p2 >> 16; p2 += 1;
+        intervals = p2 < 32 ? 32 : p2;
+        host_ms += now_ms() - h0;
+    }
+    if (intervals > 65536 || intervals < 4) FAIL(SZHIP_ERR_UNSUP, "quantization interval count %u outside [4,65536]", intervals);
+    S.intervals = intervals;
+    HIPCHK(hipEventRecord(ctx->ev[1], st));
+
+    // ---- the boxes: predict + quantise
+    TRY(ensure(ctx, ctx->codes_nat, (size_t)n * 2 + 64));
+    uint16_t *d_codes = (uint16_t *)ctx->codes_nat.p;
+    TRY(ensure(ctx, ctx->zcnt, (size_t)g.nb * 4));
+    TRY(ensure(ctx, ctx->samples, (size_t)g.nb * sizeof(T)));
+    TRY(ensure(ctx, ctx->col_zeros64, (size_t)g.nb * 8)); TRY(ensure(ctx, ctx->col_off, (size_t)g.nb * 8));
+    unsigned *d_ucount = (unsigned *)ctx->zcnt.p; T *d_first = (T *)ctx->samples.p;
+    u64 *d_ucount64 = (u64 *)ctx->col_zeros64.p, *d_uoff = (u64 *)ctx->col_off.p;
+    const int rows = g.c0 * g.c1, box_threads = (rows + 63) / 64 * 64;
+    HIPCHK(hipEventRecord(ctx->ev[2], st));
+    hipLaunchKernelGGL((k_omp_box<T, false>), dim3((unsigned)g.nb), dim3((unsigned)box_threads), (size_t)4 * rows * sizeof(T), st, g, d_in, (T *)nullptr, eb, (T)(1 / eb),
+                       (int)intervals, d_codes, d_ucount, d_ucount64, d_first, (const T *)nullptr, (const u64 *)nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev[3], st));
+    S.quant_kernel_launches = 1;
+
+    // ---- ONE histogram over all boxes -> code book (host); the ranks of the boxes' verbatim values meanwhile
+    TRY(ensure(ctx, ctx->hist, (size_t)(65536 + 8192) * 4 + 64));
+    unsigned *d_hist = (unsigned *)ctx->hist.p;
+    TRY(ensure_pinned(ctx, (size_t)intervals * 4 + 64));
+    unsigned *h_hist = (unsigned *)ctx->pinned;
+    HIPCHK(hipMemsetAsync(d_hist, 0, (size_t)intervals * 4, st));
+    {
+        int rshift = 0; int use_lds = intervals <= 16384;
+        if (use_lds) { while ((intervals << (rshift + 1)) <= 16384u && rshift < 6) ++rshift; }
+        const size_t lds = use_lds ? ((size_t)intervals << rshift) * 4 : 16;
+        int grid = (int)std::min<int64_t>((n / 8 + 255) / 256 + 1, 2048);
+        hipLaunchKernelGGL(k_hist_u16, dim3(grid), dim3(256), lds, st, (const uint16_t *)d_codes, n, intervals, rshift, use_lds, d_hist, szh_rb_layout{0, 0, 0, 0, 0, 0}, 0, 0, 0);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipMemcpyAsync(h_hist, d_hist, (size_t)intervals * 4, hipMemcpyDeviceToHost, st));
+    TRY(scan_u64(ctx, (const u64 *)d_ucount64, g.nb, d_uoff, sm + SM_TOTAL_UNPRED));
+    HIPCHK(hipStreamSynchronize(st));
+    const u64 E = h_hist[0];
+    S.n_unpred = E;
+    double h0 = now_ms();
+    szhost_huff *hf = szhost_huff_build(2 * (int)intervals, h_hist, nullptr, intervals);
+    if (!hf) FAIL(SZHIP_ERR_INTERNAL, "Huffman build failed");
+    const size_t tree_bytes = szhost_huff_tree_size(hf);
+    const u64 total_bits = hf->total_bits;
+    std::vector<u64> tab_code(intervals); std::vector<uint8_t> tab_len(intervals);
+    for (unsigned s2 = 0; s2 < intervals; ++s2) { tab_code[s2] = hf->code[s2]; tab_len[s2] = hf->len[s2]; }
+    // ---- container: everything up to the payloads has a known size now; the payloads take at most a byte of padding per box
+    const size_t hdr_len = meta_len + 4 + sizeof(T) + 4 + 4 + 4 + tree_bytes;
+    const size_t off_ucount = hdr_len, off_first = off_ucount + (size_t)g.nb * 4, off_unpred = off_first + (size_t)g.nb * sizeof(T);
+    const size_t off_sizes = off_unpred + (size_t)E * sizeof(T), off_pay = off_sizes + (size_t)g.nb * 8;
+    const size_t cap_len = off_pay + (size_t)((total_bits + 7) / 8) + (size_t)g.nb;
+    std::vector<unsigned char> hdr(hdr_len, 0);
+    {
+        unsigned char *q = hdr.data();
+        memcpy(q, meta, meta_len); q += meta_len;
+        szhost_put_u32be(q, (uint32_t)g.nb); q += 4;              // (`thread_num` after the grid has been cut: sz_omp.c:122)
+        if (sizeof(T) == 8) szhost_put_f64be(q, (double)eb); else szhost_put_f32be(q, (float)eb);
+        q += sizeof(T);
+        szhost_put_u32be(q, intervals); q += 4;
+        szhost_put_u32be(q, (uint32_t)tree_bytes); q += 4;
+        szhost_put_u32be(q, (uint32_t)hf->n_nodes); q += 4;
+        szhost_huff_tree_write(hf, q);
+    }
+    szhost_huff_free(hf);
+    host_ms += now_ms() - h0;
+    TRY(ensure(ctx, ctx->code_tab, (size_t)intervals * 8));
+    TRY(ensure(ctx, ctx->len_tab, (size_t)intervals));
+    HIPCHK(hipMemcpyAsync(ctx->code_tab.p, tab_code.data(), (size_t)intervals * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->len_tab.p, tab_len.data(), (size_t)intervals, hipMemcpyHostToDevice, st));
+    TRY(ensure(ctx, ctx->stream_buf, cap_len + 64));
+    unsigned char *d_stream = (unsigned char *)ctx->stream_buf.p;
+    HIPCHK(hipMemsetAsync(d_stream, 0, cap_len + 64, st));
+    HIPCHK(hipMemcpyAsync(d_stream, hdr.data(), hdr_len, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_stream + off_ucount, d_ucount, (size_t)g.nb * 4, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_stream + off_first, d_first, (size_t)g.nb * sizeof(T), hipMemcpyDeviceToDevice, st));
+    if (E > 0) {
+        TRY(ensure(ctx, ctx->unpred, (size_t)E * sizeof(T)));
+        hipLaunchKernelGGL((k_omp_gather<T>), dim3((unsigned)g.nb), dim3(256), 0, st, g, d_in, (const uint16_t *)d_codes, (const unsigned *)d_ucount, (const u64 *)d_uoff, (T *)ctx->unpred.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(d_stream + off_unpred, ctx->unpred.p, (size_t)E * sizeof(T), hipMemcpyDeviceToDevice, st));
+    }
+    const int64_t nchunks = (int64_t)g.nb * g.cpb;
+    TRY(ensure(ctx, ctx->chunk_bits, (size_t)nchunks * 8)); TRY(ensure(ctx, ctx->chunk_off, (size_t)nchunks * 8));
+    TRY(ensure(ctx, ctx->reg_flags, (size_t)g.nb * 8)); TRY(ensure(ctx, ctx->reg_rank, (size_t)g.nb * 8));
+    u64 *d_box_bytes = (u64 *)ctx->reg_flags.p, *d_box_off = (u64 *)ctx->reg_rank.p;
+    hipLaunchKernelGGL(k_omp_chunk_bits, dim3((unsigned)nchunks), dim3(256), 0, st, g, (const uint16_t *)d_codes, (const uint8_t *)ctx->len_tab.p, (u64 *)ctx->chunk_bits.p);
+    TRY(scan_u64(ctx, (const u64 *)ctx->chunk_bits.p, nchunks, (u64 *)ctx->chunk_off.p, sm + SM_TOTAL_BITS));
+    hipLaunchKernelGGL(k_omp_box_bytes, dim3((unsigned)((g.nb + 255) / 256)), dim3(256), 0, st, g.nb, g.cpb, (const u64 *)ctx->chunk_off.p, (const u64 *)(sm + SM_TOTAL_BITS), d_box_bytes);
+    TRY(scan_u64(ctx, (const u64 *)d_box_bytes, g.nb, d_box_off, sm + SM_SCRATCH));
+    HIPCHK(hipMemcpyAsync(d_stream + off_sizes, d_box_bytes, (size_t)g.nb * 8, hipMemcpyDeviceToDevice, st));
+    if (total_bits > 0) {
+        hipLaunchKernelGGL(k_omp_encode, dim3((unsigned)nchunks), dim3(256), 0, st, g, (const uint16_t *)d_codes, (const u64 *)ctx->code_tab.p, (const uint8_t *)ctx->len_tab.p,
+                           (const u64 *)ctx->chunk_off.p, (const u64 *)d_box_off, (u64)off_pay * 8, (unsigned *)d_stream);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(ctx->ev[4], st));
+    u64 h_small[SM_COUNT];
+    HIPCHK(hipMemcpyAsync(h_small, sm, SM_COUNT * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (h_small[SM_TOTAL_BITS] != total_bits || h_small[SM_TOTAL_UNPRED] != E) FAIL(SZHIP_ERR_INTERNAL, "OpenMP container: entropy stage mismatch");
+    const size_t total_len = off_pay + (size_t)h_small[SM_SCRATCH];
+    if (total_len > cap_len) FAIL(SZHIP_ERR_INTERNAL, "OpenMP container: payloads larger than their bound");
+    if (out_on_device == 2) {
+        if (!*out || *out_size < total_len) FAIL(SZHIP_ERR_ARG, "caller's device buffer too small (%zu < %zu)", *out_size, total_len);
+        HIPCHK(hipMemcpyAsync(*out, d_stream, total_len, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+    } else if (out_on_device) {
+        *out = d_stream;
+    } else {
+        unsigned char *h = (unsigned char *)malloc(total_len ? total_len : 1);
+        if (!h) FAIL(SZHIP_ERR_INTERNAL, "out of host memory");
+        TRY(staged_copy(ctx, h, d_stream, total_len, false));
+        HIPCHK(hipStreamSynchronize(st));
+        *out = h;
+    }
+    *out_size = total_len;
+    float ms = 0;
+    hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); S.ms_prequant = ms;
+    hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); S.ms_quant = ms;
+    hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]); S.ms_entropy = ms;
+    S.ms_host = host_ms; S.ms_total = now_ms() - t_begin; S.out_bytes = total_len;
+    if (stats) *stats = S;
+    return SZHIP_OK;
+}
+
+// `body_off`: offset of the thread_num field (4 + MetaDataByteLength: what decompressDataSeries_*_3D_openmp is handed)
+template <class T>
+int decompress_omp_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_on_device, size_t stream_len, size_t body_off, size_t r0, size_t r1, size_t r2,
+                        void *out, int out_on_device, szhip_stats *stats)
+{
+    const double t_begin = now_ms();
+    hipStream_t st = ctx->stream;
+    szhip_stats S; memset(&S, 0, sizeof(S));
+    TRY(ensure(ctx, ctx->stream_buf, stream_len + 64));
+    unsigned char *d_stream = (unsigned char *)ctx->stream_buf.p;
+    if (stream_on_device) { if (stream_in != d_stream) HIPCHK(hipMemcpyAsync(d_stream, stream_in, stream_len, hipMemcpyDeviceToDevice, st)); }
+    else TRY(staged_copy(ctx, d_stream, stream_in, stream_len, true));
+    HIPCHK(hipMemsetAsync(d_stream + stream_len, 0, 64, st));
+    HIPCHK(hipEventRecord(ctx->ev[0], st));
+    std::vector<unsigned char> hbuf;
+    const unsigned char *hs = stream_in;
+    auto fetch = [&](size_t want) -> int {                    // the first `want` bytes of the stream on the host
+        if (want > stream_len) FAIL(SZHIP_ERR_STREAM, "truncated stream");
+        if (!stream_on_device) return SZHIP_OK;
+        hbuf.resize(want);
+        HIPCHK(hipMemcpyAsync(hbuf.data(), d_stream, want, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        hs = hbuf.data();
+        return SZHIP_OK;
+    };
+    const size_t fixed = body_off + 4 + sizeof(T) + 12;
+    TRY(fetch(fixed));
+    const unsigned char *q = hs + body_off;
+    const int thread_num = (int)szhost_get_u32be(q); q += 4;
+    const T eb = sizeof(T) == 8 ? (T)szhost_get_f64be(q) : (T)szhost_get_f32be(q); q += sizeof(T);
+    const unsigned intervals = szhost_get_u32be(q); q += 4;
+    const size_t tree_bytes = szhost_get_u32be(q); q += 4;
+    const int node_count = (int)szhost_get_u32be(q); q += 4;
+    if (intervals < 4 || intervals > 65536 || !(eb > 0)) FAIL(SZHIP_ERR_STREAM, "bad OpenMP-container header");
+    if (node_count <= 0 || tree_bytes > stream_len || szhost_huff_serial_size(node_count) > tree_bytes) FAIL(SZHIP_ERR_STREAM, "truncated stream");
+    szh_omp_geom g;
+    TRY(omp_box_grid(ctx, thread_num, r0, r1, r2, sizeof(T), &g));
+    if (g.nb != thread_num) FAIL(SZHIP_ERR_STREAM, "thread_num %d is not a box grid", thread_num);
+    const int64_t n = (int64_t)r0 * r1 * r2;
+    S.n_elements = (uint64_t)n; S.n_blocks = (uint64_t)g.nb; S.intervals = intervals;
+    const size_t off_ucount = fixed + tree_bytes, off_first = off_ucount + (size_t)g.nb * 4, off_unpred = off_first + (size_t)g.nb * sizeof(T);
+    TRY(fetch(off_unpred));
+    szhost_huff *hf = szhost_huff_from_bytes(2 * (int)intervals, hs + fixed, node_count);
+    if (!hf) FAIL(SZHIP_ERR_STREAM, "bad Huffman tree");
+    std::vector<uint32_t> dtab((size_t)hf->n_nodes * 2);
+    szhost_huff_decode_table(hf, dtab.data());
+    const int single_symbol = hf->t[0] ? (int)hf->C[0] : -1;
+    szhost_huff_free(hf);
+    std::vector<u64> uoff((size_t)g.nb + 1, 0);
+    for (int b = 0; b < g.nb; ++b) { uint32_t c; memcpy(&c, hs + off_ucount + (size_t)b * 4, 4); if (c > (uint32_t)g.bel) FAIL(SZHIP_ERR_STREAM, "bad verbatim-value count"); uoff[b + 1] = uoff[b] + c; }
+    const u64 E = uoff[g.nb];
+    S.n_unpred = E;
+    const size_t off_sizes = off_unpred + (size_t)E * sizeof(T), off_pay = off_sizes + (size_t)g.nb * 8;
+    if (off_pay > stream_len) FAIL(SZHIP_ERR_STREAM, "truncated stream");
+    std::vector<u64> bbytes((size_t)g.nb), boff((size_t)g.nb);
+    if (stream_on_device) { HIPCHK(hipMemcpyAsync(bbytes.data(), d_stream + off_sizes, (size_t)g.nb * 8, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st)); }
+    else memcpy(bbytes.data(), stream_in + off_sizes, (size_t)g.nb * 8);
+    u64 acc = 0;
+    for (int b = 0; b < g.nb; ++b) { boff[b] = acc; if (bbytes[b] > stream_len || bbytes[b] >= ((u64)1 << 28)) FAIL(SZHIP_ERR_STREAM, "bad payload size"); acc += bbytes[b]; }
+    if (off_pay + acc > stream_len) FAIL(SZHIP_ERR_STREAM, "truncated stream");
+    // ---- device tables: payload offsets / sizes, ranks of the verbatim values, first values and verbatim values at aligned addresses
+    TRY(ensure(ctx, ctx->small, SM_COUNT * 8));
+    u64 *sm = (u64 *)ctx->small.p;
+    HIPCHK(hipMemsetAsync(sm, 0, SM_COUNT * 8, st));
+    TRY(ensure(ctx, ctx->reg_flags, (size_t)g.nb * 8)); TRY(ensure(ctx, ctx->reg_rank, (size_t)g.nb * 8)); TRY(ensure(ctx, ctx->col_off, (size_t)g.nb * 8 + 8));
+    TRY(ensure(ctx, ctx->samples, (size_t)g.nb * sizeof(T))); TRY(ensure(ctx, ctx->unpred, (size_t)E * sizeof(T) + 16));
+    TRY(ensure(ctx, ctx->dec_tab, dtab.size() * 4 + 16));
+    HIPCHK(hipMemcpyAsync(ctx->reg_flags.p, bbytes.data(), (size_t)g.nb * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->reg_rank.p, boff.data(), (size_t)g.nb * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->col_off.p, uoff.data(), (size_t)g.nb * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->dec_tab.p, dtab.data(), dtab.size() * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->samples.p, d_stream + off_first, (size_t)g.nb * sizeof(T), hipMemcpyDeviceToDevice, st));
+    if (E > 0) HIPCHK(hipMemcpyAsync(ctx->unpred.p, d_stream + off_unpred, (size_t)E * sizeof(T), hipMemcpyDeviceToDevice, st));
+    TRY(ensure(ctx, ctx->codes_nat, (size_t)n * 2 + 64));
+    uint16_t *d_codes = (uint16_t *)ctx->codes_nat.p;
+    hipLaunchKernelGGL(k_omp_hdec, dim3((unsigned)g.nb), dim3(256), 0, st, g.bel, (const unsigned char *)(d_stream + off_pay), (const u64 *)ctx->reg_rank.p,
+                       (const u64 *)ctx->reg_flags.p, (const unsigned *)ctx->dec_tab.p, single_symbol, d_codes, (unsigned *)(sm + SM_ERR));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev[1], st));
+    T *d_out = (T *)out;
+    if (!out_on_device) { TRY(ensure(ctx, ctx->out, (size_t)n * sizeof(T))); d_out = (T *)ctx->out.p; }
+    if ((uintptr_t)d_out & 15u) g.vec = 0;
+    const int rows = g.c0 * g.c1, box_threads = (rows + 63) / 64 * 64;
+    HIPCHK(hipEventRecord(ctx->ev[2], st));
+    hipLaunchKernelGGL((k_omp_box<T, true>), dim3((unsigned)g.nb), dim3((unsigned)box_threads), (size_t)4 * rows * sizeof(T), st, g, (const T *)nullptr, d_out, eb, (T)(1 / eb),
+                       (int)intervals, d_codes, (unsigned *)nullptr, (u64 *)nullptr, (T *)ctx->samples.p, (const T *)ctx->unpred.p, (const u64 *)ctx->col_off.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev[3], st));
+    unsigned bad = 0;
+    HIPCHK(hipMemcpyAsync(&bad, sm + SM_ERR, 4, hipMemcpyDeviceToHost, st));
+    if (!out_on_device) TRY(staged_copy(ctx, out, d_out, (size_t)n * sizeof(T), false));
+    HIPCHK(hipStreamSynchronize(st));
+    if (bad) FAIL(SZHIP_ERR_STREAM, "%u box payloads hold fewer symbols than their boxes have points", bad);
+    float ms = 0;
+    hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); S.ms_entropy = ms;
+    hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); S.ms_quant = ms;
+    S.ms_total = now_ms() - t_begin; S.out_bytes = (uint64_t)n * sizeof(T);
+    if (stats) *stats = S;
+    return SZHIP_OK;
+}
+
 } // namespace
 
 // runs one call; a wavefront-kernel wait that timed out under the index ticket is answered by ONE repetition with the atomic ticket (see szhip_ctx)
@@ -2722,6 +3039,34 @@ int szhip_decompress_sz14(szhip_ctx *ctx, int dtype, const unsigned char *stream
                ? decompress14_impl<float>(ctx, stream, stream_on_device, stream_len, body_off, 0, r0, r1, r2, out, out_on_device, stats)
                : decompress14_impl<double>(ctx, stream, stream_on_device, stream_len, body_off, 0, r0, r1, r2, out, out_on_device, stats); });
     if (rc != SZHIP_OK) { hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream); }
+    return rc;
+}
+
+int szhip_compress_omp(szhip_ctx *ctx, int dtype, const void *data, int data_on_device, size_t r0, size_t r1, size_t r2, double eb, int thread_num,
+                       const szhip_params *params, const unsigned char *meta, size_t meta_len, int out_on_device, unsigned char **out, size_t *out_size,
+                       szhip_stats *stats)
+{
+    if (!ctx || !data || !params || !meta || !out || !out_size) return SZHIP_ERR_ARG;
+    if (r0 < 1 || r1 < 1 || r2 < 1 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff || thread_num < 1) return SZHIP_ERR_ARG;
+    if (!(eb > 0)) return SZHIP_ERR_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
+    const int rc = dtype == SZHIP_F32
+               ? compress_omp_impl<float>(ctx, data, data_on_device, r0, r1, r2, eb, thread_num, params, meta, meta_len, out_on_device, out, out_size, stats)
+               : compress_omp_impl<double>(ctx, data, data_on_device, r0, r1, r2, eb, thread_num, params, meta, meta_len, out_on_device, out, out_size, stats);
+    if (rc != SZHIP_OK) hipStreamSynchronize(ctx->stream);
+    return rc;
+}
+
+int szhip_decompress_omp(szhip_ctx *ctx, int dtype, const unsigned char *stream, int stream_on_device, size_t stream_len, size_t body_off,
+                         size_t r0, size_t r1, size_t r2, void *out, int out_on_device, szhip_stats *stats)
+{
+    if (!ctx || !stream || !out || body_off >= stream_len) return SZHIP_ERR_ARG;
+    if (r0 < 1 || r1 < 1 || r2 < 1 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff) return SZHIP_ERR_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
+    const int rc = dtype == SZHIP_F32
+               ? decompress_omp_impl<float>(ctx, stream, stream_on_device, stream_len, body_off, r0, r1, r2, out, out_on_device, stats)
+               : decompress_omp_impl<double>(ctx, stream, stream_on_device, stream_len, body_off, r0, r1, r2, out, out_on_device, stats);
+    if (rc != SZHIP_OK) hipStreamSynchronize(ctx->stream);
     return rc;
 }
 

@@ -1683,3 +1683,4 @@ __global__ void k_probe_wait(const unsigned long long *flag, unsigned long long 
 #include "szh_fast.h"
 #include "szh_pwr.h"
 #include "szh_msst.h"
+#include "szh_omp.h"
