@@ -97,21 +97,31 @@ __global__ __launch_bounds__(1024) void k_omp_box(szh_omp_geom g, const T *__res
         __syncthreads();
     }
     const T *ub = DEC ? unpred + uoff[b] : nullptr;
+    // The step.  ONE predictor expression serves every row but (0, 0): the 7-point form with the absent neighbours as +0 and the
+    // registers of the j - 1 neighbours starting at +0 --
+    //   row (0, i>=1):  l1 + A + 0 - Ap - 0 - 0 + 0   = left + above - above-left        (j = 0: A)
+    //   row (k>=1, 0):  l1 + 0 + B - 0 - 0 - Bp + 0   = left + back - back-left          (j = 0: B)
+    //   elsewhere:      the reference's own sum, left to right                            (j = 0: 0 + A + B - 0 - C - 0 + 0)
+    // Adding a +0 is exact; it can only turn a -0 SUM into +0, and the sign of a zero prediction reaches neither the code (|cur - pred|,
+    // `diff < 0` is false for both zeros) nor the reconstruction (pred + 2 q eb: q = 0 adds +0 and gives +0 either way).  So the lanes
+    // of a wavefront (rows of every kind) run the same instructions; the lone (0, 0) row of a box keeps its own branch.
+    const bool i0 = i == 0, k0 = k == 0, row00 = live && i0 && k0;
+    const int ia = i0 ? tid : tid - 1, ib = k0 ? tid : tid - g.c1, ic = (i0 || k0) ? tid : tid - g.c1 - 1;     // (own place when absent: read, not used)
     T l1 = 0, l2 = 0, Ap = 0, Bp = 0, Cp = 0;
     unsigned nun = 0;
     vecT vin; for (int e = 0; e < NV; ++e) vin.v[e] = 0;
     vecT vout; for (int e = 0; e < NV; ++e) vout.v[e] = 0;
     u64 cacc = 0;
-    const int steps = g.c0 + g.c1 + g.c2 - 2;
+    const int steps = g.c0 + g.c1 + g.c2 - 2, j_first = -(k + i);
+    const T fint = (T)intervals;
     for (int t = 0; t < steps; ++t) {
-        const int j = t - k - i;
-        if (live && j >= 0 && j < g.c2) {
+        const int j = t + j_first;
+        if (live && (unsigned)j < (unsigned)g.c2) {
             const int slot = (j & 3) * rows;
-            T A = 0, B = 0, C = 0;
-            if (i > 0) A = ring[slot + tid - 1];
-            if (k > 0) B = ring[slot + tid - g.c1];
-            if (i > 0 && k > 0) C = ring[slot + tid - g.c1 - 1];
-            const T pred = szh_omp_predict<T>(k, i, j, first_v, l1, l2, A, Ap, B, Bp, C, Cp);
+            T A = ring[slot + ia], B = ring[slot + ib], C = ring[slot + ic];
+            A = i0 ? (T)0 : A; B = k0 ? (T)0 : B; C = (i0 || k0) ? (T)0 : C;
+            T pred = l1 + A + B - Ap - C - Bp + Cp;
+            if (row00) pred = j == 0 ? first_v : j == 1 ? l1 : 2 * l1 - l2;
             T rec;
             if (!DEC) {
                 T cur;
@@ -119,21 +129,20 @@ __global__ __launch_bounds__(1024) void k_omp_box(szh_omp_geom g, const T *__res
                     if ((j & (NV - 1)) == 0) vin = *reinterpret_cast<const vecT *>(row_in + j);
                     cur = vin.v[0];
 #pragma unroll
-                    for (int e = 1; e < NV; ++e) if ((j & (NV - 1)) == e) cur = vin.v[e];
+                    for (int e = 1; e < NV; ++e) cur = (j & (NV - 1)) == e ? vin.v[e] : cur;
                 } else cur = row_in[j];
                 // sz_float.c:4762-4783: |diff| / eb + 1 against the interval count, truncation, the bound verified on the result
                 const T diff = cur - pred;
-                T itv = (diff < 0 ? -diff : diff) * recip + 1;
-                int tc = 0;
-                rec = cur;
-                if (itv < (T)intervals) {
-                    if (diff < 0) itv = -itv;
-                    tc = (int)(itv / 2) + radius;
-                    const T r = pred + (T)(2 * (tc - radius)) * eb;
-                    const T err = cur - r;
-                    if ((err < 0 ? -err : err) > eb) tc = 0; else rec = r;
-                }
-                if (tc == 0) ++nun;
+                const T mag = (diff < 0 ? -diff : diff) * recip + 1;
+                const T itv = diff < 0 ? -mag : mag;
+                const bool in_range = mag < fint;                         // (false for a NaN)
+                const int q2 = 2 * (int)((in_range ? itv : (T)0) / 2);    // 2 (code - radius)
+                const T r = pred + (T)q2 * eb;
+                const T err = cur - r;
+                const bool ok = in_range && !((err < 0 ? -err : err) > eb);
+                const int tc = ok ? (q2 >> 1) + radius : 0;
+                rec = ok ? r : cur;
+                nun += ok ? 0u : 1u;
                 if (g.vec) {
                     cacc |= (u64)(unsigned)tc << (16 * (j & 3));
                     if ((j & 3) == 3) { *reinterpret_cast<u64 *>(crow + (j - 3)) = cacc; cacc = 0; }
@@ -148,7 +157,7 @@ __global__ __launch_bounds__(1024) void k_omp_box(szh_omp_geom g, const T *__res
                 else rec = ub[urank + nun++];
                 if (g.vec) {
 #pragma unroll
-                    for (int e = 0; e < NV; ++e) if ((j & (NV - 1)) == e) vout.v[e] = rec;
+                    for (int e = 0; e < NV; ++e) vout.v[e] = (j & (NV - 1)) == e ? rec : vout.v[e];
                     if ((j & (NV - 1)) == NV - 1) *reinterpret_cast<vecT *>(row_out + (j - (NV - 1))) = vout;
                 } else row_out[j] = rec;
             }
