@@ -26,11 +26,12 @@ struct szh_omp_geom {
     int64_t d0, d1;            // pitches of the array
     int nb, bel;               // boxes, points per box
     int cpb;                   // chunks of SZH_ENC_CHUNK codes per box (the last one may be short)
-    int vec;                   // rows may be read / written 16 bytes at a time, codes 8 bytes at a time
+    int vec;                   // rows may be read / written 16 bytes at a time, codes 8 bytes at a time (host: picks k_omp_box<.., VEC>)
 };
 #define SZH_OMP_MAX_ROWS 1024
 
-template <class T> struct szh_omp_vec { static constexpr int NV = 16 / (int)sizeof(T); struct alignas(16) type { T v[NV]; }; };
+template <class T> struct szh_omp_chunk { struct alignas(16) type { T x, y, z, w; }; };     // four values of a row: one 16-byte load (float), two (double)
+// (named members, not an array: picking v[j & 3] out of an array member sent the chunks to scratch memory)
 
 __device__ __forceinline__ const void *szh_omp_box_origin_bytes(const szh_omp_geom &g, int b, size_t elem, const void *data)
 {
@@ -56,7 +57,7 @@ __device__ __forceinline__ T szh_omp_predict(int k, int i, int j, T first, T l1,
 
 // DEC = false: data -> codes (0 = the value is kept verbatim), the count of such values per box, the box's first value
 // DEC = true : codes + the box's verbatim values (in the box's row-major order) + its first value -> data
-template <class T, bool DEC>
+template <class T, bool DEC, bool VEC>
 __global__ __launch_bounds__(1024) void k_omp_box(szh_omp_geom g, const T *__restrict__ data, T *__restrict__ out, T eb, T recip, int intervals,
                                                   uint16_t *__restrict__ codes, unsigned *__restrict__ ucount, u64 *__restrict__ ucount64, T *__restrict__ first,
                                                   const T *__restrict__ unpred, const u64 *__restrict__ uoff)
@@ -65,11 +66,10 @@ __global__ __launch_bounds__(1024) void k_omp_box(szh_omp_geom g, const T *__res
     T *ring = reinterpret_cast<T *>(smem);                  // [4][rows]
     __shared__ unsigned s_un;
     __shared__ unsigned s_scan[SZH_OMP_MAX_ROWS];
-    constexpr int NV = szh_omp_vec<T>::NV;
-    typedef typename szh_omp_vec<T>::type vecT;
+    typedef typename szh_omp_chunk<T>::type chunkT;
     const int b = blockIdx.x, tid = threadIdx.x, rows = g.c0 * g.c1;
-    const bool live = tid < rows;
-    const int k = live ? tid / g.c1 : 0, i = live ? tid - k * g.c1 : 0;
+    if ((int)blockDim.x != rows) return;                    // exactly one lane per row (the unconditional stores below have nowhere else to go)
+    const int k = tid / g.c1, i = tid - k * g.c1;
     const int64_t row_off = (int64_t)k * g.d0 + (int64_t)i * g.d1;
     const T *row_in = DEC ? nullptr : reinterpret_cast<const T *>(szh_omp_box_origin_bytes(g, b, sizeof(T), data)) + row_off;
     T *row_out = DEC ? reinterpret_cast<T *>(const_cast<void *>(szh_omp_box_origin_bytes(g, b, sizeof(T), out))) + row_off : nullptr;
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(1024) void k_omp_box(szh_omp_geom g, const T *__res
     if (DEC) {
         // rank of the row's first verbatim value among the box's: zeros of the rows before it (row-major order = row order)
         unsigned z = 0;
-        if (live) for (int j = 0; j < g.c2; ++j) z += crow[j] == 0;
+        for (int j = 0; j < g.c2; ++j) z += crow[j] == 0;
         s_scan[tid] = z;
         __syncthreads();
         for (int o = 1; o < (int)blockDim.x; o <<= 1) {
@@ -105,66 +105,111 @@ __global__ __launch_bounds__(1024) void k_omp_box(szh_omp_geom g, const T *__res
     // Adding a +0 is exact; it can only turn a -0 SUM into +0, and the sign of a zero prediction reaches neither the code (|cur - pred|,
     // `diff < 0` is false for both zeros) nor the reconstruction (pred + 2 q eb: q = 0 adds +0 and gives +0 either way).  So the lanes
     // of a wavefront (rows of every kind) run the same instructions; the lone (0, 0) row of a box keeps its own branch.
-    const bool i0 = i == 0, k0 = k == 0, row00 = live && i0 && k0;
+    //
+    // Memory (VEC): a lane's row is four-value chunks.  The lanes of a wavefront stand at different j, so "load when j % 4 == 0" would
+    // put a partly masked load -- and the wait for it -- into EVERY step.  Instead all lanes load at the same steps (t % 4 == 0): during
+    // the four steps that follow a lane needs the chunks m and m + 1 of its j (v0, v1); chunk m + 2 is requested now (vl) and taken
+    // over four steps later.  A finished chunk of results (four codes / four values) waits for the same steps to be stored.
+    const bool i0 = i == 0, k0 = k == 0, row00 = i0 && k0;
     const int ia = i0 ? tid : tid - 1, ib = k0 ? tid : tid - g.c1, ic = (i0 || k0) ? tid : tid - g.c1 - 1;     // (own place when absent: read, not used)
     T l1 = 0, l2 = 0, Ap = 0, Bp = 0, Cp = 0;
     unsigned nun = 0;
-    vecT vin; for (int e = 0; e < NV; ++e) vin.v[e] = 0;
-    vecT vout; for (int e = 0; e < NV; ++e) vout.v[e] = 0;
-    u64 cacc = 0;
-    const int steps = g.c0 + g.c1 + g.c2 - 2, j_first = -(k + i);
+    const int steps = g.c0 + g.c1 + g.c2 - 2, j_first = -(k + i), nch = g.c2 >> 2;
     const T fint = (T)intervals;
-    for (int t = 0; t < steps; ++t) {
-        const int j = t + j_first;
-        if (live && (unsigned)j < (unsigned)g.c2) {
-            const int slot = (j & 3) * rows;
-            T A = ring[slot + ia], B = ring[slot + ib], C = ring[slot + ic];
-            A = i0 ? (T)0 : A; B = k0 ? (T)0 : B; C = (i0 || k0) ? (T)0 : C;
-            T pred = l1 + A + B - Ap - C - Bp + Cp;
-            if (row00) pred = j == 0 ? first_v : j == 1 ? l1 : 2 * l1 - l2;
-            T rec;
-            if (!DEC) {
-                T cur;
-                if (g.vec) {
-                    if ((j & (NV - 1)) == 0) vin = *reinterpret_cast<const vecT *>(row_in + j);
-                    cur = vin.v[0];
-#pragma unroll
-                    for (int e = 1; e < NV; ++e) cur = (j & (NV - 1)) == e ? vin.v[e] : cur;
-                } else cur = row_in[j];
-                // sz_float.c:4762-4783: |diff| / eb + 1 against the interval count, truncation, the bound verified on the result
-                const T diff = cur - pred;
-                const T mag = (diff < 0 ? -diff : diff) * recip + 1;
-                const T itv = diff < 0 ? -mag : mag;
-                const bool in_range = mag < fint;                         // (false for a NaN)
-                const int q2 = 2 * (int)((in_range ? itv : (T)0) / 2);    // 2 (code - radius)
-                const T r = pred + (T)q2 * eb;
-                const T err = cur - r;
-                const bool ok = in_range && !((err < 0 ? -err : err) > eb);
-                const int tc = ok ? (q2 >> 1) + radius : 0;
-                rec = ok ? r : cur;
-                nun += ok ? 0u : 1u;
-                if (g.vec) {
-                    cacc |= (u64)(unsigned)tc << (16 * (j & 3));
-                    if ((j & 3) == 3) { *reinterpret_cast<u64 *>(crow + (j - 3)) = cacc; cacc = 0; }
-                } else crow[j] = (uint16_t)tc;
-            } else {
-                unsigned tc;
-                if (g.vec) {
-                    if ((j & 3) == 0) cacc = *reinterpret_cast<const u64 *>(crow + j);
-                    tc = (unsigned)(cacc >> (16 * (j & 3))) & 0xffffu;
-                } else tc = crow[j];
-                if (tc) rec = pred + (T)(2 * ((int)tc - radius)) * eb;
-                else rec = ub[urank + nun++];
-                if (g.vec) {
-#pragma unroll
-                    for (int e = 0; e < NV; ++e) vout.v[e] = (j & (NV - 1)) == e ? rec : vout.v[e];
-                    if ((j & (NV - 1)) == NV - 1) *reinterpret_cast<vecT *>(row_out + (j - (NV - 1))) = vout;
-                } else row_out[j] = rec;
-            }
-            ring[slot + tid] = rec;
-            l2 = l1; l1 = rec; Ap = A; Bp = B; Cp = C;
+    chunkT va, vb, vc, vd, vacc, vdone;
+    { const chunkT z = {0, 0, 0, 0}; va = z; vb = z; vc = z; vd = z; vacc = z; vdone = z; }
+    u64 ca = 0, cb = 0, cc = 0, cd = 0, cacc = 0, cdone = 0;
+    int done_j = 0;
+    // (every lane loads, from a chunk index clamped into its row -- rows that do not exist stand on row 0: a load that may or may not
+    //  happen would make the compiler wait for it right where it is issued)
+    auto clampc = [&](int m) { return m < 0 ? 0 : m >= nch ? nch - 1 : m; };
+    const uint16_t *cr = crow;
+    if (VEC) {                                              // the first four steps' chunks, and the one that is in flight during them
+        const int mb = j_first >> 2;
+        if (!DEC) {
+            va = *reinterpret_cast<const chunkT *>(row_in + 4 * clampc(mb));
+            vb = *reinterpret_cast<const chunkT *>(row_in + 4 * clampc(mb + 1));
+            vc = *reinterpret_cast<const chunkT *>(row_in + 4 * clampc(mb + 2));
+        } else {
+            ca = *reinterpret_cast<const u64 *>(cr + 4 * clampc(mb));
+            cb = *reinterpret_cast<const u64 *>(cr + 4 * clampc(mb + 1));
+            cc = *reinterpret_cast<const u64 *>(cr + 4 * clampc(mb + 2));
         }
-        __syncthreads();
+    }
+    // A GROUP of four steps (unrolled) with the chunks m (x0) and m + 1 (x1) of the lane's j; chunk m + 2 was requested at the end of
+    // the group before and is in flight, chunk m + 3 is requested at the end of this one into `xn`.  The four chunk variables take
+    // these roles in turn (the loop below is unrolled by four groups), so no chunk is ever copied: with "v0 = v1; v1 = vl" at a
+    // group's end the compiler placed those copies behind the new load and waited for it on the spot -- a memory round trip in every
+    // group, which is what this arrangement exists to avoid.  Steps past the last one find no lane inside its row.
+    auto group = [&](const int tg, const chunkT &x0, const chunkT &x1, chunkT &xn, const u64 y0, const u64 y1, u64 &yn) __attribute__((always_inline)) {
+        const int mb = (tg + j_first) >> 2;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = tg + u + j_first;
+            if ((unsigned)j < (unsigned)g.c2) {
+                const int slot = (j & 3) * rows;
+                T A = ring[slot + ia], B = ring[slot + ib], C = ring[slot + ic];
+                A = i0 ? (T)0 : A; B = k0 ? (T)0 : B; C = (i0 || k0) ? (T)0 : C;
+                T pred = l1 + A + B - Ap - C - Bp + Cp;
+                if (row00) pred = j == 0 ? first_v : j == 1 ? l1 : 2 * l1 - l2;
+                const bool hi = (j >> 2) != mb;
+                const int e4 = j & 3;
+                T rec;
+                if (!DEC) {
+                    T cur;
+                    if (VEC) {
+                        const T q0 = hi ? x1.x : x0.x, q1 = hi ? x1.y : x0.y, q2v = hi ? x1.z : x0.z, q3 = hi ? x1.w : x0.w;
+                        cur = e4 == 0 ? q0 : e4 == 1 ? q1 : e4 == 2 ? q2v : q3;
+                    } else cur = row_in[j];
+                    // sz_float.c:4762-4783: |diff| / eb + 1 against the interval count, truncation, the bound verified on the result
+                    const T diff = cur - pred;
+                    const T mag = (diff < 0 ? -diff : diff) * recip + 1;
+                    const T itv = diff < 0 ? -mag : mag;
+                    const bool in_range = mag < fint;                         // (false for a NaN)
+                    const int q2 = 2 * (int)((in_range ? itv : (T)0) / 2);    // 2 (code - radius)
+                    const T r = pred + (T)q2 * eb;
+                    const T err = cur - r;
+                    const bool ok = in_range && !((err < 0 ? -err : err) > eb);
+                    const int tc = ok ? (q2 >> 1) + radius : 0;
+                    rec = ok ? r : cur;
+                    nun += ok ? 0u : 1u;
+                    if (VEC) {
+                        cacc |= (u64)(unsigned)tc << (16 * e4);
+                        if (e4 == 3) { cdone = cacc; done_j = j - 3; cacc = 0; }
+                    } else crow[j] = (uint16_t)tc;
+                } else {
+                    unsigned tc;
+                    if (VEC) tc = (unsigned)((hi ? y1 : y0) >> (16 * e4)) & 0xffffu;
+                    else tc = crow[j];
+                    if (tc) rec = pred + (T)(2 * ((int)tc - radius)) * eb;
+                    else rec = ub[urank + nun++];
+                    if (VEC) {
+                        vacc.x = e4 == 0 ? rec : vacc.x; vacc.y = e4 == 1 ? rec : vacc.y; vacc.z = e4 == 2 ? rec : vacc.z; vacc.w = e4 == 3 ? rec : vacc.w;
+                        if (e4 == 3) { vdone = vacc; done_j = j - 3; }
+                    } else row_out[j] = rec;
+                }
+                ring[slot + tid] = rec;
+                l2 = l1; l1 = rec; Ap = A; Bp = B; Cp = C;
+            }
+            __syncthreads();
+        }
+        if (VEC) {
+            if (!DEC) xn = *reinterpret_cast<const chunkT *>(row_in + 4 * clampc(mb + 3));
+            else yn = *reinterpret_cast<const u64 *>(cr + 4 * clampc(mb + 3));
+            // the lane's latest finished chunk of results (one per four steps; a lane that has finished none since the last time writes
+            // the same chunk again, one that has not started yet writes zeros where its first chunk will go: a store that may or may
+            // not happen would leave the compiler unable to count the accesses in flight, and it would wait for all of them)
+            if (!DEC) *reinterpret_cast<u64 *>(crow + done_j) = cdone; else *reinterpret_cast<chunkT *>(row_out + done_j) = vdone;
+        }
+    };
+    // (the first group stands in front of the loop: entered from the prologue's three loads the loop's first group would have to
+    //  assume the fewest accesses in flight, and so wait for the newest one on every later pass too)
+    group(0, va, vb, vd, ca, cb, cd);
+    for (int tg = 4; tg < steps; tg += 16) {
+        group(tg, vb, vc, va, cb, cc, ca);
+        group(tg + 4, vc, vd, vb, cc, cd, cb);
+        group(tg + 8, vd, va, vc, cd, ca, cc);
+        group(tg + 12, va, vb, vd, ca, cb, cd);
     }
     if (!DEC) {
         if (nun) atomicAdd(&s_un, nun);

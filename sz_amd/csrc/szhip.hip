@@ -2566,10 +2566,12 @@ int compress_omp_impl(szhip_ctx *ctx, const void *data, int data_on_device, size
     TRY(ensure(ctx, ctx->col_zeros64, (size_t)g.nb * 8)); TRY(ensure(ctx, ctx->col_off, (size_t)g.nb * 8));
     unsigned *d_ucount = (unsigned *)ctx->zcnt.p; T *d_first = (T *)ctx->samples.p;
     u64 *d_ucount64 = (u64 *)ctx->col_zeros64.p, *d_uoff = (u64 *)ctx->col_off.p;
-    const int rows = g.c0 * g.c1, box_threads = (rows + 63) / 64 * 64;
+    const int rows = g.c0 * g.c1, box_threads = rows;      // one lane per row
     HIPCHK(hipEventRecord(ctx->ev[2], st));
-    hipLaunchKernelGGL((k_omp_box<T, false>), dim3((unsigned)g.nb), dim3((unsigned)box_threads), (size_t)4 * rows * sizeof(T), st, g, d_in, (T *)nullptr, eb, (T)(1 / eb),
-                       (int)intervals, d_codes, d_ucount, d_ucount64, d_first, (const T *)nullptr, (const u64 *)nullptr);
+    if (g.vec) hipLaunchKernelGGL((k_omp_box<T, false, true>), dim3((unsigned)g.nb), dim3((unsigned)box_threads), (size_t)4 * rows * sizeof(T), st, g, d_in, (T *)nullptr, eb, (T)(1 / eb),
+                                  (int)intervals, d_codes, d_ucount, d_ucount64, d_first, (const T *)nullptr, (const u64 *)nullptr);
+    else hipLaunchKernelGGL((k_omp_box<T, false, false>), dim3((unsigned)g.nb), dim3((unsigned)box_threads), (size_t)4 * rows * sizeof(T), st, g, d_in, (T *)nullptr, eb, (T)(1 / eb),
+                            (int)intervals, d_codes, d_ucount, d_ucount64, d_first, (const T *)nullptr, (const u64 *)nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[3], st));
     S.quant_kernel_launches = 1;
@@ -2761,10 +2763,12 @@ int decompress_omp_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stre
     T *d_out = (T *)out;
     if (!out_on_device) { TRY(ensure(ctx, ctx->out, (size_t)n * sizeof(T))); d_out = (T *)ctx->out.p; }
     if ((uintptr_t)d_out & 15u) g.vec = 0;
-    const int rows = g.c0 * g.c1, box_threads = (rows + 63) / 64 * 64;
+    const int rows = g.c0 * g.c1, box_threads = rows;      // one lane per row
     HIPCHK(hipEventRecord(ctx->ev[2], st));
-    hipLaunchKernelGGL((k_omp_box<T, true>), dim3((unsigned)g.nb), dim3((unsigned)box_threads), (size_t)4 * rows * sizeof(T), st, g, (const T *)nullptr, d_out, eb, (T)(1 / eb),
-                       (int)intervals, d_codes, (unsigned *)nullptr, (u64 *)nullptr, (T *)ctx->samples.p, (const T *)ctx->unpred.p, (const u64 *)ctx->col_off.p);
+    if (g.vec) hipLaunchKernelGGL((k_omp_box<T, true, true>), dim3((unsigned)g.nb), dim3((unsigned)box_threads), (size_t)4 * rows * sizeof(T), st, g, (const T *)nullptr, d_out, eb, (T)(1 / eb),
+                                  (int)intervals, d_codes, (unsigned *)nullptr, (u64 *)nullptr, (T *)ctx->samples.p, (const T *)ctx->unpred.p, (const u64 *)ctx->col_off.p);
+    else hipLaunchKernelGGL((k_omp_box<T, true, false>), dim3((unsigned)g.nb), dim3((unsigned)box_threads), (size_t)4 * rows * sizeof(T), st, g, (const T *)nullptr, d_out, eb, (T)(1 / eb),
+                            (int)intervals, d_codes, (unsigned *)nullptr, (u64 *)nullptr, (T *)ctx->samples.p, (const T *)ctx->unpred.p, (const u64 *)ctx->col_off.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[3], st));
     unsigned bad = 0;
