@@ -195,6 +195,16 @@ void* SZ_decompress_customize_threadsafe(const char* cmprName, void* userPara, i
 /* ---- additive entry points of this build (not in the reference) ---- */
 /* device that SZ_* calls run on (default: env SZ_HIP_DEVICE or 0); call before the first compress */
 int SZ_hip_set_device(int device);
+
+/* The reference's OpenMP container for 3-D arrays (sz/include/sz_omp.h:26, :29, :36, :40): same names, arguments and stream as an OpenMP
+ * build of libSZ.  r1 is the slowest dimension here, as in sz_omp.c.  `comp_data` of the inverse: the stream behind its first
+ * 4 + MetaDataByteLength bytes (example/sz_openmp.c:580).  SZ_hip_set_omp_threads: the box count (omp_get_max_threads() of an OpenMP
+ * build; 0 = pick one: boxes of at most 32768 points); the HIP layer's restrictions are in include/szhip.h (szhip_compress_omp). */
+void SZ_hip_set_omp_threads(int thread_num);
+unsigned char *SZ_compress_float_3D_MDQ_openmp(float *oriData, size_t r1, size_t r2, size_t r3, float realPrecision, size_t *comp_size);
+unsigned char *SZ_compress_double_3D_MDQ_openmp(double *oriData, size_t r1, size_t r2, size_t r3, double realPrecision, size_t *comp_size);
+void decompressDataSeries_float_3D_openmp(float **data, size_t r1, size_t r2, size_t r3, unsigned char *comp_data);
+void decompressDataSeries_double_3D_openmp(double **data, size_t r1, size_t r2, size_t r3, unsigned char *comp_data);
 /* per-call measurements of the last SZ_compress_args / SZ_decompress on this thread's context; see szhip.h */
 struct szhip_stats;
 int SZ_hip_last_stats(struct szhip_stats *out);

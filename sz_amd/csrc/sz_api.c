@@ -844,3 +844,99 @@ void *SZ_decompress_customize_threadsafe(const char *cmprName, void *userPara, i
 {
     return SZ_decompress_customize(cmprName, userPara, dataType, bytes, byteLength, r5, r4, r3, r2, r1, status);
 }
+
+/* ---- the reference's OpenMP container for 3-D arrays (sz/include/sz_omp.h:26, :29, :36, :40; sz/src/sz_omp.c:63-358, :366-566, :578-863, :871-).
+ * Same names, arguments and stream as an OpenMP build of libSZ; the box count an OpenMP build takes from omp_get_max_threads() (it is
+ * written into the stream) comes from SZ_hip_set_omp_threads / SZ_HIP_OMP_THREADS, by default the smallest power of two whose box grid
+ * divides the array into boxes of at most 32768 points with a dim-0 x dim-1 face of at most 1024 rows (4096 boxes of 32^3 at 512^3). */
+static int g_omp_threads = 0;
+void SZ_hip_set_omp_threads(int thread_num) { g_omp_threads = thread_num; }
+
+static void omp_grid(int thread_num, size_t *nx, size_t *ny, size_t *nz)
+{   /* sz_omp.c:88-117 */
+    int order = 0; while ((2 << order) <= thread_num) ++order;
+    const int b = order / 3;
+    switch (order % 3) { case 0: *nx = (size_t)1 << b; *ny = (size_t)1 << b; break; case 1: *nx = (size_t)1 << (b + 1); *ny = (size_t)1 << b; break;
+                         default: *nx = (size_t)1 << (b + 1); *ny = (size_t)1 << (b + 1); }
+    *nz = (size_t)thread_num / (*nx * *ny);
+}
+static int omp_pick_threads(size_t r1, size_t r2, size_t r3)
+{
+    int t = g_omp_threads;
+    if (t <= 0) { const char *e = getenv("SZ_HIP_OMP_THREADS"); if (e) t = atoi(e); }
+    if (t > 0) return t;
+    for (int o = 0; o <= 30; ++o) {
+        size_t nx, ny, nz; omp_grid(1 << o, &nx, &ny, &nz);
+        if (nx > r1 || ny > r2 || nz > r3) break;
+        if (r1 % nx || r2 % ny || r3 % nz) continue;
+        const size_t c0 = r1 / nx, c1 = r2 / ny, c2 = r3 / nz;
+        if (c0 * c1 <= 1024 && c0 * c1 * c2 <= 32768) return 1 << o;
+    }
+    return 0;
+}
+static unsigned char *omp_compress(int dataType, const void *oriData, size_t r1, size_t r2, size_t r3, double realPrecision, size_t *comp_size)
+{
+    if (comp_size) *comp_size = 0;
+    if (!oriData || !comp_size) return NULL;
+    if (confparams_cpr == NULL) SZ_Init(NULL);
+    szhip_ctx *ctx = get_ctx();
+    if (!ctx) return NULL;
+    const int threads = omp_pick_threads(r1, r2, r3);
+    if (threads <= 0) { printf("Error: no power-of-two box grid divides %zu x %zu x %zu into boxes the MI355X build takes; set SZ_HIP_OMP_THREADS.\n", r1, r2, r3); return NULL; }
+    /* initRandomAccessBytes (dataCompression.c:686-708): version, flag byte, parameter bytes of confparams_cpr->dataType */
+    const int meta_type = confparams_cpr->dataType == SZ_DOUBLE ? SZ_DOUBLE : SZ_FLOAT;
+    const size_t meta_len = meta_type == SZ_FLOAT ? MetaDataByteLength : MetaDataByteLength_double;
+    szhost_meta m; fill_meta(&m, confparams_cpr, meta_type);
+    unsigned char meta[4 + MetaDataByteLength_double];
+    unsigned char flags = 0x80 | (exe_params->SZ_SIZE_TYPE == 8 ? 0x40 : 0);
+    if (confparams_cpr->randomAccess) flags |= 0x02;
+    if (confparams_cpr->protectValueRange) flags |= 0x04;
+    szhost_write_meta(&m, flags, meta);
+    szhip_params hp; memset(&hp, 0, sizeof(hp));
+    hp.sample_distance = confparams_cpr->sampleDistance; hp.pred_threshold = confparams_cpr->predThreshold;
+    hp.max_quant_intervals = exe_params->optQuantMode == 1 ? confparams_cpr->maxRangeRadius * 2 : confparams_cpr->max_quant_intervals;
+    hp.quantization_intervals = exe_params->optQuantMode == 1 ? 0 : (unsigned)exe_params->intvCapacity;
+    unsigned char *out = NULL; size_t n = 0;
+    const int rc = szhip_compress_omp(ctx, dataType == SZ_FLOAT ? SZHIP_F32 : SZHIP_F64, oriData, 0, r1, r2, r3, realPrecision, threads, &hp,
+                                      meta, 4 + meta_len, 0, &out, &n, &g_last_stats);
+    if (rc != SZHIP_OK) { printf("Error: szhip_compress_omp failed (%d): %s\n", rc, szhip_last_error(ctx)); return NULL; }
+    *comp_size = n;
+    return out;
+}
+/* `comp_data`: the stream behind its 4 + MetaDataByteLength leading bytes, as the reference's callers pass it (example/sz_openmp.c:580);
+ * there is no length argument, so the extent is read off the stream's own tables */
+static void omp_decompress(int dataType, void **data, size_t r1, size_t r2, size_t r3, unsigned char *comp_data)
+{
+    if (!data) return;
+    *data = NULL;
+    if (!comp_data) return;
+    szhip_ctx *ctx = get_ctx();
+    if (!ctx) return;
+    const size_t esz = dataType == SZ_FLOAT ? 4 : 8;
+    const unsigned char *q = comp_data;
+    const unsigned thread_num = szhost_get_u32be(q);
+    const size_t tree_bytes = szhost_get_u32be(q + 4 + esz + 4);
+    if (thread_num == 0 || thread_num > (1u << 30)) { printf("Error: not an OpenMP-container stream.\n"); return; }
+    size_t nx, ny, nz; omp_grid((int)thread_num, &nx, &ny, &nz);
+    const size_t nb = nx * ny * nz;
+    q += 4 + esz + 12 + tree_bytes;
+    size_t total_un = 0;
+    for (size_t b = 0; b < nb; ++b) { uint32_t c; memcpy(&c, q + b * 4, 4); total_un += c; }
+    q += nb * 4 + nb * esz + total_un * esz;
+    size_t pay = 0;
+    for (size_t b = 0; b < nb; ++b) { uint64_t s; memcpy(&s, q + b * 8, 8); pay += (size_t)s; }
+    const size_t total = (size_t)(q - comp_data) + nb * 8 + pay;
+    void *out = malloc(r1 * r2 * r3 * esz ? r1 * r2 * r3 * esz : 1);
+    if (!out) return;
+    const int rc = szhip_decompress_omp(ctx, dataType == SZ_FLOAT ? SZHIP_F32 : SZHIP_F64, comp_data, 0, total, 0, r1, r2, r3, out, 0, &g_last_stats);
+    if (rc != SZHIP_OK) { printf("Error: szhip_decompress_omp failed (%d): %s\n", rc, szhip_last_error(ctx)); free(out); return; }
+    *data = out;
+}
+unsigned char *SZ_compress_float_3D_MDQ_openmp(float *oriData, size_t r1, size_t r2, size_t r3, float realPrecision, size_t *comp_size)
+{ return omp_compress(SZ_FLOAT, oriData, r1, r2, r3, (double)realPrecision, comp_size); }
+unsigned char *SZ_compress_double_3D_MDQ_openmp(double *oriData, size_t r1, size_t r2, size_t r3, double realPrecision, size_t *comp_size)
+{ return omp_compress(SZ_DOUBLE, oriData, r1, r2, r3, realPrecision, comp_size); }
+void decompressDataSeries_float_3D_openmp(float **data, size_t r1, size_t r2, size_t r3, unsigned char *comp_data)
+{ omp_decompress(SZ_FLOAT, (void **)data, r1, r2, r3, comp_data); }
+void decompressDataSeries_double_3D_openmp(double **data, size_t r1, size_t r2, size_t r3, unsigned char *comp_data)
+{ omp_decompress(SZ_DOUBLE, (void **)data, r1, r2, r3, comp_data); }

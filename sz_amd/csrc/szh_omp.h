@@ -56,7 +56,8 @@ __device__ __forceinline__ T szh_omp_predict(int k, int i, int j, T first, T l1,
 }
 
 // DEC = false: data -> codes (0 = the value is kept verbatim), the count of such values per box, the box's first value
-// DEC = true : codes + the box's verbatim values (in the box's row-major order) + its first value -> data
+// DEC = true : codes + the box's verbatim values (in the box's row-major order, uoff[b] .. uoff[b + 1]) + its first value -> data;
+//              `ucount` is then ONE counter of boxes whose codes and table entry disagree
 template <class T, bool DEC, bool VEC>
 __global__ __launch_bounds__(1024) void k_omp_box(szh_omp_geom g, const T *__restrict__ data, T *__restrict__ out, T eb, T recip, int intervals,
                                                   uint16_t *__restrict__ codes, unsigned *__restrict__ ucount, u64 *__restrict__ ucount64, T *__restrict__ first,
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(1024) void k_omp_box(szh_omp_geom g, const T *__res
     const int radius = intervals / 2;
     if (tid == 0) s_un = 0u;
     T first_v;
-    unsigned urank = 0;
+    unsigned urank = 0, ucap = 0;
     if (DEC) {
         // rank of the row's first verbatim value among the box's: zeros of the rows before it (row-major order = row order)
         unsigned z = 0;
@@ -92,6 +93,10 @@ __global__ __launch_bounds__(1024) void k_omp_box(szh_omp_geom g, const T *__res
         }
         urank = s_scan[tid] - z;
         first_v = first[b];
+        // a damaged stream: the box's codes call for another number of verbatim values than its table entry says (`ucount`: the error
+        // counter here); the reads below stay inside the box's values either way
+        ucap = (unsigned)(uoff[b + 1] - uoff[b]);
+        if (tid == rows - 1 && s_scan[tid] != ucap) atomicAdd(ucount, 1u);
     } else {
         first_v = *reinterpret_cast<const T *>(szh_omp_box_origin_bytes(g, b, sizeof(T), data));
         __syncthreads();
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(1024) void k_omp_box(szh_omp_geom g, const T *__res
                     if (VEC) tc = (unsigned)((hi ? y1 : y0) >> (16 * e4)) & 0xffffu;
                     else tc = crow[j];
                     if (tc) rec = pred + (T)(2 * ((int)tc - radius)) * eb;
-                    else rec = ub[urank + nun++];
+                    else { const unsigned ui = urank + nun++; rec = ui < ucap ? ub[ui] : (T)0; }
                     if (VEC) {
                         vacc.x = e4 == 0 ? rec : vacc.x; vacc.y = e4 == 1 ? rec : vacc.y; vacc.z = e4 == 2 ? rec : vacc.z; vacc.w = e4 == 3 ? rec : vacc.w;
                         if (e4 == 3) { vdone = vacc; done_j = j - 3; }

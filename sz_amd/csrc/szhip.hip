@@ -2750,7 +2750,7 @@ int decompress_omp_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stre
     TRY(ensure(ctx, ctx->dec_tab, dtab.size() * 4 + 16));
     HIPCHK(hipMemcpyAsync(ctx->reg_flags.p, bbytes.data(), (size_t)g.nb * 8, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(ctx->reg_rank.p, boff.data(), (size_t)g.nb * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(ctx->col_off.p, uoff.data(), (size_t)g.nb * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->col_off.p, uoff.data(), ((size_t)g.nb + 1) * 8, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(ctx->dec_tab.p, dtab.data(), dtab.size() * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(ctx->samples.p, d_stream + off_first, (size_t)g.nb * sizeof(T), hipMemcpyDeviceToDevice, st));
     if (E > 0) HIPCHK(hipMemcpyAsync(ctx->unpred.p, d_stream + off_unpred, (size_t)E * sizeof(T), hipMemcpyDeviceToDevice, st));
@@ -2766,16 +2766,16 @@ int decompress_omp_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stre
     const int rows = g.c0 * g.c1, box_threads = rows;      // one lane per row
     HIPCHK(hipEventRecord(ctx->ev[2], st));
     if (g.vec) hipLaunchKernelGGL((k_omp_box<T, true, true>), dim3((unsigned)g.nb), dim3((unsigned)box_threads), (size_t)4 * rows * sizeof(T), st, g, (const T *)nullptr, d_out, eb, (T)(1 / eb),
-                                  (int)intervals, d_codes, (unsigned *)nullptr, (u64 *)nullptr, (T *)ctx->samples.p, (const T *)ctx->unpred.p, (const u64 *)ctx->col_off.p);
+                                  (int)intervals, d_codes, (unsigned *)(sm + SM_ERR), (u64 *)nullptr, (T *)ctx->samples.p, (const T *)ctx->unpred.p, (const u64 *)ctx->col_off.p);
     else hipLaunchKernelGGL((k_omp_box<T, true, false>), dim3((unsigned)g.nb), dim3((unsigned)box_threads), (size_t)4 * rows * sizeof(T), st, g, (const T *)nullptr, d_out, eb, (T)(1 / eb),
-                            (int)intervals, d_codes, (unsigned *)nullptr, (u64 *)nullptr, (T *)ctx->samples.p, (const T *)ctx->unpred.p, (const u64 *)ctx->col_off.p);
+                            (int)intervals, d_codes, (unsigned *)(sm + SM_ERR), (u64 *)nullptr, (T *)ctx->samples.p, (const T *)ctx->unpred.p, (const u64 *)ctx->col_off.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[3], st));
     unsigned bad = 0;
     HIPCHK(hipMemcpyAsync(&bad, sm + SM_ERR, 4, hipMemcpyDeviceToHost, st));
     if (!out_on_device) TRY(staged_copy(ctx, out, d_out, (size_t)n * sizeof(T), false));
     HIPCHK(hipStreamSynchronize(st));
-    if (bad) FAIL(SZHIP_ERR_STREAM, "%u box payloads hold fewer symbols than their boxes have points", bad);
+    if (bad) FAIL(SZHIP_ERR_STREAM, "%u boxes whose payload or verbatim-value count does not fit their codes", bad);
     float ms = 0;
     hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); S.ms_entropy = ms;
     hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); S.ms_quant = ms;
