@@ -457,6 +457,40 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
                  "sz14_1d_16Mi_f32_abs1e-3": {"GB/s": round(s1.numel() * 4 / t1d / 1e9, 2), "ms": round(t1d * 1e3, 3), "out_bytes": size1d}}
         del p2, s1
 
+    # ---- opt-in (--omp-boxes N): the reference's OpenMP container (szh_omp.h) on the same array, its own object; NOT part of the
+    #      default line (the path had not run on hardware when round 3 ended)
+    omp = None
+    if args.omp_boxes and world == 1 and not args.dry_run:
+        meta_o = sz_amd.make_meta(np.float32, err_mode=sz_amd.ABS, abs_bound=EB, vmin=0.0, vmax=0.0)
+        meta_o = bytes([meta_o[0], meta_o[1], meta_o[2], 0xC0]) + bytes(meta_o[4:])
+        y_o = torch.empty_like(x)
+        for _ in range(2):
+            optr, osize, ost = ctx.compress_omp(x.data_ptr(), True, (n, n, n), np.float32, EB, args.omp_boxes, meta_o, out_on_device=True)
+        _sync(torch); t0 = time.perf_counter()
+        oq, oe = [], []
+        for _ in range(args.steps):
+            optr, osize, ost = ctx.compress_omp(x.data_ptr(), True, (n, n, n), np.float32, EB, args.omp_boxes, meta_o, out_on_device=True)
+            oq.append(ost.ms_quant); oe.append(ost.ms_entropy)
+        _sync(torch); to = (time.perf_counter() - t0) / args.steps
+        ctx.decompress_omp(optr, True, osize, len(meta_o), (n, n, n), np.float32, y_o.data_ptr(), True)
+        _sync(torch); t0 = time.perf_counter()
+        for _ in range(args.steps):
+            odst = ctx.decompress_omp(optr, True, osize, len(meta_o), (n, n, n), np.float32, y_o.data_ptr(), True)
+        _sync(torch); tod = (time.perf_counter() - t0) / args.steps
+        oqm = float(np.mean(oq))
+        omp = {"container": "the reference's OpenMP container (SZ_compress_float_3D_MDQ_openmp, sz/src/sz_omp.c:63-358): independent boxes, one code book, "
+                            "a payload per box; a stock OpenMP build of SZ reads it", "boxes": int(ost.n_blocks),
+               "GB/s": round(nbytes_in / to / 1e9, 2), "ms": round(to * 1e3, 3), "decompress_GBps": round(nbytes_in / tod / 1e9, 2),
+               "out_bytes": int(osize), "ratio": round(nbytes_in / osize, 4), "max_abs_err": float((y_o - x).abs().max().item()),
+               "verbatim_values": int(ost.n_unpred), "intervals": int(ost.intervals),
+               "phase_ms": {"prequant": round(ost.ms_prequant, 3), "quant": round(oqm, 3), "entropy": round(float(np.mean(oe)), 3), "host_glue": round(ost.ms_host, 3),
+                            "compress_call_total": round(ost.ms_total, 3), "decompress_entropy": round(odst.ms_entropy, 3), "decompress_quant": round(odst.ms_quant, 3),
+                            "decompress_total": round(odst.ms_total, 3)},
+               "roofline": {"bound": "hbm", "kernel": "k_omp_box<float,false,true>", "achieved": round(6 * x.numel() / (oqm * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(6 * x.numel() / (oqm * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": 6 * x.numel(),
+                            "avg_kernel_ms": round(oqm, 4), "note": "algorithmic bytes = N * (4 read + 2 of codes written)"}}
+        del y_o
+
     # ---- host-pointer API, PCIe included (never the headline value)
     e2e = None
     if world == 1 and n == EDGE and not args.timed_only:
@@ -507,7 +541,7 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
             "phase_ms": {"caller_glue": round(ms_per_step - stats.ms_total, 3), "prequant": round(stats.ms_prequant, 3), "quant": round(stats.ms_quant, 3),
                          "entropy": round(stats.ms_entropy, 3), "host_glue": round(stats.ms_host, 3), "compress_call_total": round(stats.ms_total, 3),
                          "decompress_quant": round(dst.ms_quant, 3), "decompress_total": round(dst.ms_total, 3)},
-            "roofline": roofline, "concurrent": concurrent, "m_field": mfield, "fast_mode": fast, "other_paths": other, "e2e": e2e, "cpu_baseline": cpu, "cpu_baseline_mt": cpu_mt}
+            "roofline": roofline, "concurrent": concurrent, "m_field": mfield, "fast_mode": fast, "other_paths": other, "omp_container": omp, "e2e": e2e, "cpu_baseline": cpu, "cpu_baseline_mt": cpu_mt}
     print(json.dumps(line))
     if world > 1:
         dist.barrier(); dist.destroy_process_group()
@@ -615,6 +649,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--other-paths", action="store_true", help="also time the SZ 1.4 container, a 2-D array and a 1-D series (one line each)")
     ap.add_argument("--no-fast", action="store_true", help="skip the opt-in fast-mode object")
+    ap.add_argument("--omp-boxes", type=int, default=0, help="also time the reference's OpenMP container with that many boxes (thread_num; 4096 = 32^3 boxes at 512^3)")
     ap.add_argument("--no-m-field", action="store_true")
     ap.add_argument("--timed-only", action="store_true", help="only the headline: priming, warm-up, the timed steps, one decompression (for "
                     "rocprofv3 --stats: every launch of the sweep kernel then runs as in the timed region)")

@@ -9,7 +9,7 @@
  * configuration state, not on this function's arguments: the caller passes them in (`meta`), as szhip.h's entry points do.
  * Parity: pinned against oracle/_ref/libSZ_omp.so (tests/test_omp_container.py); "parity unpinned" where that library is absent.
  * Why it is here: this is the reference's own parallel mode -- thousands of independent boxes instead of one dependency front -- and the
- * next row of the hot path; the HIP side does not exist yet. */
+ * next row of the hot path; the HIP side is sz_amd/csrc/szh_omp.h, checked against this file by tests/test_zz_omp_hip.py. */
 
 #ifndef SZO_CAT
 #define SZO_CAT_(a, b) a##_##b

@@ -1,7 +1,7 @@
 """The reference's OpenMP container (sz/src/sz_omp.c: a 3-D array cut into thread_num independent boxes, one Huffman code book, one payload per
-box) -- ORACLE ONLY so far: oracle/szo_omp_impl.h restates it, this file pins the restatement.  It is the next row of the hot path
-(thousands of independent boxes instead of one dependency front, and a stream that a stock OpenMP build of SZ reads);
-the HIP side does not exist yet, so nothing here touches the product.
+box) -- the ORACLE: oracle/szo_omp_impl.h restates it, this file pins the restatement (thousands of independent boxes instead of one
+dependency front, and a stream that a stock OpenMP build of SZ reads: DESIGN section 4h).  The HIP side (sz_amd/csrc/szh_omp.h) is checked
+against this oracle in tests/test_zz_omp_hip.py; nothing here touches the product.
 
 Pin: tests/golden/ref_recorded_omp.json -- outputs of the unmodified reference (oracle/_ref/libSZ_omp.so) recorded by
 tools/record_reference_omp.py: the bytes behind the parameter block and the decoded array must match, md5 for md5.  Where that library is
