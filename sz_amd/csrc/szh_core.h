@@ -160,6 +160,16 @@ SZH_HD int64_t szh_meanwalk_pos(const szh_meanwalk &w, int64_t m) { return m * w
 // further ones while the column is < r2; the walk as a whole stops at the first position >= len.
 // 2-D (sz_float.c:5441-5475): logical row n >= 1 is array row n, first column sd - 1 for n = 1 and sd - (n % sd) after it; the
 // same "at least one sample per row" and "stop at the first position >= len" rules.  `r12` = 0 selects the 3-point stencil.
+// (unsigned long)rq clamped to the table, as the reference's optimisers do it (sz_float.c:4664-4667, :5092-5095).  Outside that type's range the
+// conversion is whatever the x86-64 build of the reference does -- and arrays with fill values (1e30, 9.97e36) get there with ordinary
+// bounds: a NaN becomes 2^63 (clamped to the last bin), a quotient of 2^64 or more, infinity included, becomes 0 (cvttsd2si of
+// x - 2^63 gives 2^63 again, and the xor with 2^63 that completes the unsigned conversion leaves 0): the FIRST bin
+SZH_HD unsigned szh_radius_index(double rq, unsigned max_radius)
+{
+    if (!(rq < 18446744073709551616.0)) return rq != rq ? max_radius - 1 : 0u;
+    return rq >= (double)max_radius ? max_radius - 1 : (unsigned)rq;
+}
+
 template <class T>
 SZH_HD void szh_sample_point(const T *data, int64_t pos, int64_t r2, int64_t r12, double ebD, T mean,
                              unsigned max_radius, unsigned *radius_index, int *freq_index, int *within_eb)
@@ -170,9 +180,7 @@ SZH_HD void szh_sample_point(const T *data, int64_t pos, int64_t r2, int64_t r12
     const T pred_err = szh_abs((T)(pred - *d));
     *within_eb = ((double)pred_err < ebD) ? 1 : 0;
     double rq = ((double)pred_err / ebD + 1) / 2;
-    // the reference converts to size_t; values beyond the table are clamped (also guards inf)
-    unsigned ri = rq >= (double)max_radius ? max_radius - 1 : (unsigned)rq;
-    if (ri >= max_radius) ri = max_radius - 1;
+    const unsigned ri = szh_radius_index(rq, max_radius);
     *radius_index = ri;
     const T mean_diff = *d - mean;
     const double fq = (double)mean_diff / ebD;

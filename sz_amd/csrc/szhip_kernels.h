@@ -322,7 +322,8 @@ __global__ __launch_bounds__(256) void k_fit_select(szh_geom3 G, const T *__rest
         const GlobAcc<T> A{data + (int64_t)szh_blk_start(G.g0, b0) * G.d0 + (int64_t)szh_blk_start(G.g1, b1) * G.d1 + szh_blk_start(G.g2, b2),
                            G.d0, G.d1};
         T c4[4];
-        auto range = [&](T v) { const u64 oe = ord_enc(v); lmin = oe < lmin ? oe : lmin; lmax = oe > lmax ? oe : lmax; };
+        // (a NaN takes no part: `if (min > data) .. else if (max < data) ..` of computeRangeSize_float, dataCompression.c:97-113, is false for it)
+        auto range = [&](T v) { const u64 oe = ord_enc(v); const bool num = v == v; lmin = num && oe < lmin ? oe : lmin; lmax = num && oe > lmax ? oe : lmax; };
         int reg;
         if (G.ndim == 2) {   // plane a*j + b*k + c, carried as {0, a, b, c}
             c4[0] = 0;
@@ -352,7 +353,8 @@ __global__ __launch_bounds__(256) void k_minmax(const T *__restrict__ data, int6
     __shared__ u64 red[8];
     u64 lmin = ~0ull, lmax = 0ull;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const u64 e = ord_enc(data[i]); lmin = e < lmin ? e : lmin; lmax = e > lmax ? e : lmax;
+        const T v = data[i]; const u64 e = ord_enc(v); const bool num = v == v;      // (a NaN takes no part, as in computeRangeSize_float)
+        lmin = num && e < lmin ? e : lmin; lmax = num && e > lmax ? e : lmax;
     }
     lmin = wave_min_u64(lmin); lmax = wave_max_u64(lmax);
     if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = lmin; red[4 + (threadIdx.x >> 6)] = lmax; }
@@ -453,8 +455,7 @@ __global__ __launch_bounds__(256) void k_sample_1d(const T *__restrict__ data, i
         const int64_t pos = 2 + k * sd;
         const T pred_err = szh_abs((T)(data[pos - 1] - data[pos]));
         const double rq = ((double)pred_err / ebD + 1) / 2;
-        unsigned ri = rq >= (double)max_radius ? max_radius - 1 : (unsigned)rq;
-        if (ri >= max_radius) ri = max_radius - 1;
+        const unsigned ri = szh_radius_index(rq, max_radius);
         if (ri < SZH_LDS_RADIUS_BINS) atomicAdd(&sh_r[ri], 1u); else atomicAdd(&radius_hist[ri], 1u);
     }
     __syncthreads();

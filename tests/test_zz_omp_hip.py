@@ -53,6 +53,8 @@ def _cases():
     yield "special-f32", _special((16, 16, 32), np.float32), 1e-3, 8, 0
     yield "special-f64", _special((16, 16, 32), np.float64), 1e-3, 8, 64
     yield "constant", np.full((16, 16, 16), 1.5, dtype=np.float32), 1e-3, 8, 0           # one symbol: empty payloads
+    fill = s_field(16, 16, 32); fill.ravel()[::7] = 1e30
+    yield "fill-values-optimised", fill, 1e-4, 8, 0                                      # quotients beyond 2^64 in the interval optimiser
     yield "wide-codes", (np.random.default_rng(5).standard_normal((16, 16, 32)) * 50).astype(np.float32), 1e-3, 8, 65536
 
 
@@ -254,3 +256,47 @@ def test_hip_omp_container_256_against_oracle_and_512_round_trip(oracle, built):
     ctx.decompress_omp(ctypes.addressof(buf2), False, len(got2), len(META), d.shape, d.dtype, out2.ctypes.data, False)
     assert float(np.abs(out2.astype(np.float64) - out).max()) <= 1e-4
     ctx.close()
+
+
+# ---- inputs with fill values and NaN through the other paths (SZ 2.1 3-D / 2-D, the 1-D chain): found by tools/omp_diff_fuzz.py at the end of
+# round 3 -- the interval optimisers convert (|prediction error| / eb + 1) / 2 to `unsigned long` (sz_float.c:4664, :5092), and outside that type's
+# range the stream depends on what the reference's x86-64 build does (a quotient >= 2^64 lands in the FIRST bin, a NaN in the last); the range
+# scan skips NaN (dataCompression.c:97-113).  Here because the GPU variant has not run on hardware yet.
+def _fill_value_cases():
+    from sz_amd.fields import s_field
+    rng = np.random.default_rng(3)
+    for shape in ((24, 30, 36), (40, 50), (5000,)):
+        for with_nan in (False, True):
+            d = s_field(*((1,) * (3 - len(shape)) + shape)).reshape(shape).copy()
+            f = d.ravel()
+            f[rng.integers(0, f.size, f.size // 7)] = 1e30
+            if with_nan:
+                f[rng.integers(1, f.size, 5)] = np.nan
+            yield shape, with_nan, d
+
+
+def _fill_value_round(oracle):
+    import sz_amd
+    assert sz_amd.SZ_Init(os.path.join(ROOT, "tests", "golden", "sz_speed.config")) == 0
+    try:
+        for shape, with_nan, d in _fill_value_cases():
+            ref, _ = oracle.compress(d, oracle.ABS, 1e-4)
+            assert sz_amd.SZ_compress_args(d, sz_amd.ABS, 1e-4) == ref, (shape, with_nan)
+    finally:
+        sz_amd.SZ_Finalize()
+
+
+def test_fill_values_and_nan_give_the_oracle_streams_on_cpu_shim(oracle, built):
+    import sim_lib
+    from sz_amd import api
+    saved = api._lib
+    api._lib = api._bind(ctypes.CDLL(sim_lib.shim_path()))
+    try:
+        _fill_value_round(oracle)
+    finally:
+        api._lib = saved
+
+
+@pytest.mark.gpu
+def test_hip_fill_values_and_nan_give_the_oracle_streams(oracle, built):
+    _fill_value_round(oracle)
