@@ -300,3 +300,17 @@ def test_fill_values_and_nan_give_the_oracle_streams_on_cpu_shim(oracle, built):
 @pytest.mark.gpu
 def test_hip_fill_values_and_nan_give_the_oracle_streams(oracle, built):
     _fill_value_round(oracle)
+
+
+def test_bench_omp_object_rehearsal_on_cpu_shim(built):
+    """bench.py --omp-boxes (the opt-in object for the first hardware run) rehearsed on the shim: the code path runs and its round trip holds
+    the bound.  Nothing it prints is a measurement."""
+    import subprocess
+    import sim_lib
+    env = dict(os.environ, SZ_AMD_LIB=sim_lib.shim_path())
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--dry-run", "--edge", "32",
+                        "--omp-boxes", "8"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-800:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    o = line["omp_container"]
+    assert o["boxes"] == 8 and o["out_bytes"] > 0 and o["max_abs_err"] <= 1e-4
