@@ -343,17 +343,33 @@ __device__ __forceinline__ unsigned omp_hdec_run(const unsigned char *__restrict
     *endpos = last;
     return cnt;
 }
+// dynamic LDS: [the node table when tab_lds (2 n_nodes words)] [the box's payload when it has at most pay_cap bytes, + 8] -- the walk is one
+// dependent table read and (every eighth step) one payload read per bit; both come from LDS then
 __global__ __launch_bounds__(256) void k_omp_hdec(int bel, const unsigned char *__restrict__ payload, const u64 *__restrict__ box_off,
-                                                  const u64 *__restrict__ box_bytes, const unsigned *__restrict__ table, int single_symbol,
-                                                  uint16_t *__restrict__ codes, unsigned *__restrict__ bad)
+                                                  const u64 *__restrict__ box_bytes, const unsigned *__restrict__ table, int n_nodes, int tab_lds,
+                                                  unsigned pay_cap, int single_symbol, uint16_t *__restrict__ codes, unsigned *__restrict__ bad)
 {
+    SZH_DYN_SMEM(smem);
     __shared__ unsigned s_start[257], s_flag[2];
     __shared__ u64 sh[8];
     const int b = blockIdx.x, tid = threadIdx.x;
     uint16_t *out = codes + (int64_t)b * bel;
     if (single_symbol >= 0) { for (int p = tid; p < bel; p += 256) out[p] = (uint16_t)single_symbol; return; }
     const unsigned char *bits = payload + box_off[b];
-    const unsigned total = (unsigned)(box_bytes[b] * 8);
+    const unsigned nbytes = (unsigned)box_bytes[b];
+    const unsigned total = nbytes * 8;
+    {
+        unsigned *ltab = reinterpret_cast<unsigned *>(smem);
+        if (tab_lds) { for (int i = tid; i < 2 * n_nodes; i += 256) ltab[i] = table[i]; table = ltab; }
+        if (nbytes <= pay_cap && nbytes > 0) {                    // whole words from the word the payload starts in (the stream lies in a padded buffer)
+            unsigned *lpay = ltab + (tab_lds ? 2 * n_nodes : 0);
+            const unsigned lead = (unsigned)((uintptr_t)bits & 3u);
+            const unsigned *src = reinterpret_cast<const unsigned *>(bits - lead);
+            for (unsigned i = tid; i < (lead + nbytes + 3) / 4; i += 256) lpay[i] = src[i];
+            bits = reinterpret_cast<const unsigned char *>(lpay) + lead;
+        }
+        __syncthreads();
+    }
     unsigned sb = (total + 255u) / 256u; if (sb < 64u) sb = 64u;
     const unsigned first = (unsigned)tid * sb, limit = first + sb;
     unsigned start = first, endp = first, cnt = 0;

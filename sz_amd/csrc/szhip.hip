@@ -2728,6 +2728,7 @@ int decompress_omp_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stre
     std::vector<uint32_t> dtab((size_t)hf->n_nodes * 2);
     szhost_huff_decode_table(hf, dtab.data());
     const int single_symbol = hf->t[0] ? (int)hf->C[0] : -1;
+    const int n_nodes_dec = hf->n_nodes;
     szhost_huff_free(hf);
     std::vector<u64> uoff((size_t)g.nb + 1, 0);
     for (int b = 0; b < g.nb; ++b) { uint32_t c; memcpy(&c, hs + off_ucount + (size_t)b * 4, 4); if (c > (uint32_t)g.bel) FAIL(SZHIP_ERR_STREAM, "bad verbatim-value count"); uoff[b + 1] = uoff[b] + c; }
@@ -2756,8 +2757,15 @@ int decompress_omp_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stre
     if (E > 0) HIPCHK(hipMemcpyAsync(ctx->unpred.p, d_stream + off_unpred, (size_t)E * sizeof(T), hipMemcpyDeviceToDevice, st));
     TRY(ensure(ctx, ctx->codes_nat, (size_t)n * 2 + 64));
     uint16_t *d_codes = (uint16_t *)ctx->codes_nat.p;
-    hipLaunchKernelGGL(k_omp_hdec, dim3((unsigned)g.nb), dim3(256), 0, st, g.bel, (const unsigned char *)(d_stream + off_pay), (const u64 *)ctx->reg_rank.p,
-                       (const u64 *)ctx->reg_flags.p, (const unsigned *)ctx->dec_tab.p, single_symbol, d_codes, (unsigned *)(sm + SM_ERR));
+    {
+        u64 max_box = 0;
+        for (int b = 0; b < g.nb; ++b) max_box = std::max(max_box, bbytes[b]);
+        const int tab_lds = dtab.size() * 4 <= 16384;            // node table and payload in LDS when they are small (the usual case: 2 - 3 bits per code)
+        const unsigned pay_cap = (unsigned)std::min<u64>(max_box, 24576);
+        const size_t lds = (tab_lds ? dtab.size() * 4 : 0) + (size_t)pay_cap + 16;
+        hipLaunchKernelGGL(k_omp_hdec, dim3((unsigned)g.nb), dim3(256), lds, st, g.bel, (const unsigned char *)(d_stream + off_pay), (const u64 *)ctx->reg_rank.p,
+                           (const u64 *)ctx->reg_flags.p, (const unsigned *)ctx->dec_tab.p, n_nodes_dec, tab_lds, pay_cap, single_symbol, d_codes, (unsigned *)(sm + SM_ERR));
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[1], st));
     T *d_out = (T *)out;

@@ -56,6 +56,8 @@ def _cases():
     fill = s_field(16, 16, 32); fill.ravel()[::7] = 1e30
     yield "fill-values-optimised", fill, 1e-4, 8, 0                                      # quotients beyond 2^64 in the interval optimiser
     yield "wide-codes", (np.random.default_rng(5).standard_normal((16, 16, 32)) * 50).astype(np.float32), 1e-3, 8, 65536
+    # a payload and a node table too large for the decoder's LDS staging (one box of 32^3, ~14 bits per code)
+    yield "wide-codes-one-box", (np.random.default_rng(6).standard_normal((32, 32, 32)) * 50).astype(np.float32), 1e-3, 1, 65536
 
 
 def _run_cases(ctx, oracle, cases):
