@@ -13,11 +13,13 @@
 //   * the three neighbours of other rows -- (k, i-1, j), (k-1, i, j), (k-1, i-1, j) -- were written at steps t-1, t-1, t-2 into a ring of
 //     four values per row in LDS; their predecessors along j are what the thread read one step earlier (registers again).  A value j is
 //     read at steps t+1 and t+2 and its ring place is overwritten at t+4: ONE barrier per step is enough;
-//   * the row is read with 16-byte loads (one per 16 / sizeof(T) steps) and its codes leave as 8-byte stores (four codes): every lane of
-//     a wavefront works on another row, so narrower accesses would spend a full line transfer per 4 (2) bytes.
+//   * the row is read in chunks of four values (one 16-byte load for float, two for double) and its codes leave as 8-byte stores (four
+//     codes): every lane of a wavefront works on another row, so narrower accesses would spend a full line transfer per 4 (2) bytes.
+//     All lanes load and store at the same steps, two groups of four steps ahead of the use (see the kernel).
 // Box faces of up to 1024 rows (c0 * c1 <= 1024: a 32^3 box is 1024 rows of 32), the box grid must divide the array (on an uneven grid
 // the reference counts Huffman frequencies over uninitialised gaps of its code array: nothing to be identical to).
-// NOT YET RUN ON HARDWARE (written after round 3's GPU budget was spent): parity is proven on the CPU shim only (tests/test_omp_hip.py).
+// NOT YET RUN ON HARDWARE (written after round 3's GPU budget was spent): parity is proven on the CPU shim only (tests/test_zz_omp_hip.py,
+// tools/omp_diff_fuzz.py); tools/gpu_omp_first_run.sh is the first thing to run on a GPU.
 #pragma once
 
 struct szh_omp_geom {
@@ -37,22 +39,6 @@ __device__ __forceinline__ const void *szh_omp_box_origin_bytes(const szh_omp_ge
 {
     const int bi = b / (g.ny * g.nz), bj = (b / g.nz) % g.ny, bk = b % g.nz;
     return (const char *)data + ((int64_t)bi * g.c0 * g.d0 + (int64_t)bj * g.c1 * g.d1 + (int64_t)bk * g.c2) * (int64_t)elem;
-}
-
-// the predictor by position (sz_float.c:4749-4990), all from reconstructed values, left to right as the reference adds them:
-//   plane 0: (0,0,0) the box's first value, (0,0,1) the left neighbour, (0,0,j>=2) 2 left - left-left, (0,i>=1,0) the value above,
-//            elsewhere left + above - above-left;
-//   plane k>=1: (k,0,0) the previous plane's value, first row / first column the 2-D form with the previous plane, elsewhere the 7-point form
-template <class T>
-__device__ __forceinline__ T szh_omp_predict(int k, int i, int j, T first, T l1, T l2, T A, T Ap, T B, T Bp, T C, T Cp)
-{
-    if (k == 0) {
-        if (i == 0) return j == 0 ? first : j == 1 ? l1 : 2 * l1 - l2;
-        return j == 0 ? A : l1 + A - Ap;
-    }
-    if (i == 0) return j == 0 ? B : l1 + B - Bp;
-    if (j == 0) return A + B - C;
-    return l1 + A + B - Ap - C - Bp + Cp;
 }
 
 // DEC = false: data -> codes (0 = the value is kept verbatim), the count of such values per box, the box's first value
@@ -102,7 +88,10 @@ __global__ __launch_bounds__(1024) void k_omp_box(szh_omp_geom g, const T *__res
         __syncthreads();
     }
     const T *ub = DEC ? unpred + uoff[b] : nullptr;
-    // The step.  ONE predictor expression serves every row but (0, 0): the 7-point form with the absent neighbours as +0 and the
+    // The step.  The reference's predictors by position (sz_float.c:4749-4990), all from reconstructed values: plane 0 -- (0,0,0) the box's first
+    // value, (0,0,1) the left neighbour, (0,0,j>=2) 2 left - left-left, (0,i>=1,0) the value above, elsewhere left + above - above-left; plane
+    // k>=1 -- (k,0,0) the previous plane's value, first row / first column the 2-D form with the previous plane, elsewhere the 7-point form.
+    // ONE predictor expression serves every row but (0, 0): the 7-point form with the absent neighbours as +0 and the
     // registers of the j - 1 neighbours starting at +0 --
     //   row (0, i>=1):  l1 + A + 0 - Ap - 0 - 0 + 0   = left + above - above-left        (j = 0: A)
     //   row (k>=1, 0):  l1 + 0 + B - 0 - 0 - Bp + 0   = left + back - back-left          (j = 0: B)
