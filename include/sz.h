@@ -201,6 +201,20 @@ int SZ_hip_set_device(int device);
  * 4 + MetaDataByteLength bytes (example/sz_openmp.c:580).  SZ_hip_set_omp_threads: the box count (omp_get_max_threads() of an OpenMP
  * build; 0 = pick one: boxes of at most 32768 points); the HIP layer's restrictions are in include/szhip.h (szhip_compress_omp). */
 void SZ_hip_set_omp_threads(int thread_num);
+/* sz_omp.h:44-47 of an OpenMP build (sz_omp.c:14-53): sz_set_num_threads sets the box count like SZ_hip_set_omp_threads; the 1-D / 2-D entry
+ * points below are stubs in the reference itself (they return NULL / do nothing, sz_omp.c:56-61, :360-364, :570-576, :866-870) */
+void sz_set_num_threads(int nthreads);
+int sz_get_max_threads(void);
+int sz_get_thread_num(void);
+double sz_wtime(void);
+unsigned char *SZ_compress_float_1D_MDQ_openmp(float *oriData, size_t r1, double realPrecision, size_t *comp_size);
+unsigned char *SZ_compress_float_2D_MDQ_openmp(float *oriData, size_t r1, size_t r2, double realPrecision, size_t *comp_size);
+unsigned char *SZ_compress_double_1D_MDQ_openmp(double *oriData, size_t r1, double realPrecision, size_t *comp_size);
+unsigned char *SZ_compress_double_2D_MDQ_openmp(double *oriData, size_t r1, size_t r2, double realPrecision, size_t *comp_size);
+void decompressDataSeries_float_1D_openmp(float **data, size_t r1, unsigned char *comp_data);
+void decompressDataSeries_float_2D_openmp(float **data, size_t r1, size_t r2, unsigned char *comp_data);
+void decompressDataSeries_double_1D_openmp(double **data, size_t r1, unsigned char *comp_data);
+void decompressDataSeries_double_2D_openmp(double **data, size_t r1, size_t r2, unsigned char *comp_data);
 unsigned char *SZ_compress_float_3D_MDQ_openmp(float *oriData, size_t r1, size_t r2, size_t r3, float realPrecision, size_t *comp_size);
 unsigned char *SZ_compress_double_3D_MDQ_openmp(double *oriData, size_t r1, size_t r2, size_t r3, double realPrecision, size_t *comp_size);
 void decompressDataSeries_float_3D_openmp(float **data, size_t r1, size_t r2, size_t r3, unsigned char *comp_data);

@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <sys/mman.h>
 #include <string.h>
+#include <time.h>
 #include "sz.h"
 #include "szhip.h"
 #include "szhost.h"
@@ -940,3 +941,23 @@ void decompressDataSeries_float_3D_openmp(float **data, size_t r1, size_t r2, si
 { omp_decompress(SZ_FLOAT, (void **)data, r1, r2, r3, comp_data); }
 void decompressDataSeries_double_3D_openmp(double **data, size_t r1, size_t r2, size_t r3, unsigned char *comp_data)
 { omp_decompress(SZ_DOUBLE, (void **)data, r1, r2, r3, comp_data); }
+
+/* the rest of sz/include/sz_omp.h and sz.h's thread helpers, so that callers written for an OpenMP build link unchanged:
+ * sz_set_num_threads (sz_omp.c:49-53) sets the box count as omp_set_num_threads does for an OpenMP build; the 1-D / 2-D entry points
+ * are stubs in the reference itself (sz_omp.c:56-61, :360-364, :570-576, :866-870) and stay stubs here */
+void sz_set_num_threads(int nthreads) { g_omp_threads = nthreads; }
+int sz_get_max_threads(void) { if (g_omp_threads > 0) return g_omp_threads; const char *e = getenv("SZ_HIP_OMP_THREADS"); return e && atoi(e) > 0 ? atoi(e) : 1; }
+int sz_get_thread_num(void) { return 0; }
+double sz_wtime(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + (double)ts.tv_nsec / 1e9; }
+unsigned char *SZ_compress_float_1D_MDQ_openmp(float *oriData, size_t r1, double realPrecision, size_t *comp_size)
+{ (void)oriData; (void)r1; (void)realPrecision; (void)comp_size; return NULL; }
+unsigned char *SZ_compress_float_2D_MDQ_openmp(float *oriData, size_t r1, size_t r2, double realPrecision, size_t *comp_size)
+{ (void)oriData; (void)r1; (void)r2; (void)realPrecision; (void)comp_size; return NULL; }
+unsigned char *SZ_compress_double_1D_MDQ_openmp(double *oriData, size_t r1, double realPrecision, size_t *comp_size)
+{ (void)oriData; (void)r1; (void)realPrecision; (void)comp_size; return NULL; }
+unsigned char *SZ_compress_double_2D_MDQ_openmp(double *oriData, size_t r1, size_t r2, double realPrecision, size_t *comp_size)
+{ (void)oriData; (void)r1; (void)r2; (void)realPrecision; (void)comp_size; return NULL; }
+void decompressDataSeries_float_1D_openmp(float **data, size_t r1, unsigned char *comp_data) { (void)data; (void)r1; (void)comp_data; }
+void decompressDataSeries_float_2D_openmp(float **data, size_t r1, size_t r2, unsigned char *comp_data) { (void)data; (void)r1; (void)r2; (void)comp_data; }
+void decompressDataSeries_double_1D_openmp(double **data, size_t r1, unsigned char *comp_data) { (void)data; (void)r1; (void)comp_data; }
+void decompressDataSeries_double_2D_openmp(double **data, size_t r1, size_t r2, unsigned char *comp_data) { (void)data; (void)r1; (void)r2; (void)comp_data; }
