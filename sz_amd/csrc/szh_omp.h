@@ -68,7 +68,13 @@ __global__ __launch_bounds__(1024) void k_omp_box(szh_omp_geom g, const T *__res
     if (DEC) {
         // rank of the row's first verbatim value among the box's: zeros of the rows before it (row-major order = row order)
         unsigned z = 0;
-        for (int j = 0; j < g.c2; ++j) z += crow[j] == 0;
+        if (VEC) {                                              // (four codes per load, eight loads in flight: one at a time is a memory round trip per code)
+#pragma unroll 8
+            for (int m = 0; m < (g.c2 >> 2); ++m) {
+                const u64 w = *reinterpret_cast<const u64 *>(crow + 4 * m);
+                z += ((w & 0xffffull) == 0) + ((w & 0xffff0000ull) == 0) + ((w & 0xffff00000000ull) == 0) + ((w >> 48) == 0);
+            }
+        } else for (int j = 0; j < g.c2; ++j) z += crow[j] == 0;
         s_scan[tid] = z;
         __syncthreads();
         for (int o = 1; o < (int)blockDim.x; o <<= 1) {
