@@ -29,6 +29,7 @@ struct szh_omp_geom {
     int nb, bel;               // boxes, points per box
     int cpb;                   // chunks of SZH_ENC_CHUNK codes per box (the last one may be short)
     int vec;                   // rows may be read / written 16 bytes at a time, codes 8 bytes at a time (host: picks k_omp_box<.., VEC>)
+    int tile8, pitch;          // lanes of a wavefront = an 8 x 8 tile of rows; line pitch of the LDS ring (k_omp_box)
 };
 #define SZH_OMP_MAX_ROWS 1024
 
@@ -50,17 +51,24 @@ __global__ __launch_bounds__(1024) void k_omp_box(szh_omp_geom g, const T *__res
                                                   const T *__restrict__ unpred, const u64 *__restrict__ uoff)
 {
     SZH_DYN_SMEM(smem);
-    T *ring = reinterpret_cast<T *>(smem);                  // [4][rows]
+    T *ring = reinterpret_cast<T *>(smem);                  // [4][c0 * pitch]
     __shared__ unsigned s_un;
     __shared__ unsigned s_scan[SZH_OMP_MAX_ROWS];
     typedef typename szh_omp_chunk<T>::type chunkT;
     const int b = blockIdx.x, tid = threadIdx.x, rows = g.c0 * g.c1;
     if ((int)blockDim.x != rows) return;                    // exactly one lane per row (the unconditional stores below have nowhere else to go)
-    const int k = tid / g.c1, i = tid - k * g.c1;
+    // lane -> row.  Rows (k, i) start at step k + i, so a wavefront works from the first start of its rows to the last end: with 64
+    // consecutive rows (two lines of 32) that is 32 + 33 of the 94 steps of a 32^3 box, with an 8 x 8 tile of rows 32 + 15 (g.tile8: both
+    // face dimensions multiples of 8).  r: the row's number in the box's row-major order (codes, ranks); rp: its place in the ring, whose
+    // lines are g.pitch apart (a pitch of 8 or 24 modulo 32 spreads the 8 x 8 tile over the LDS banks two lanes deep, the minimum)
+    int k, i;
+    if (g.tile8) { const int w = tid >> 6, l = tid & 63, tpr = g.c1 >> 3; k = (w / tpr) * 8 + (l >> 3); i = (w % tpr) * 8 + (l & 7); }
+    else { k = tid / g.c1; i = tid - k * g.c1; }
+    const int r = k * g.c1 + i, rp = k * g.pitch + i, rstride = g.c0 * g.pitch;
     const int64_t row_off = (int64_t)k * g.d0 + (int64_t)i * g.d1;
     const T *row_in = DEC ? nullptr : reinterpret_cast<const T *>(szh_omp_box_origin_bytes(g, b, sizeof(T), data)) + row_off;
     T *row_out = DEC ? reinterpret_cast<T *>(const_cast<void *>(szh_omp_box_origin_bytes(g, b, sizeof(T), out))) + row_off : nullptr;
-    uint16_t *crow = codes + (int64_t)b * g.bel + (int64_t)tid * g.c2;
+    uint16_t *crow = codes + (int64_t)b * g.bel + (int64_t)r * g.c2;
     const int radius = intervals / 2;
     if (tid == 0) s_un = 0u;
     T first_v;
@@ -75,20 +83,20 @@ __global__ __launch_bounds__(1024) void k_omp_box(szh_omp_geom g, const T *__res
                 z += ((w & 0xffffull) == 0) + ((w & 0xffff0000ull) == 0) + ((w & 0xffff00000000ull) == 0) + ((w >> 48) == 0);
             }
         } else for (int j = 0; j < g.c2; ++j) z += crow[j] == 0;
-        s_scan[tid] = z;
+        s_scan[r] = z;
         __syncthreads();
         for (int o = 1; o < (int)blockDim.x; o <<= 1) {
-            const unsigned add = tid >= o ? s_scan[tid - o] : 0u;
+            const unsigned add = r >= o ? s_scan[r - o] : 0u;
             __syncthreads();
-            s_scan[tid] += add;
+            s_scan[r] += add;
             __syncthreads();
         }
-        urank = s_scan[tid] - z;
+        urank = s_scan[r] - z;
         first_v = first[b];
         // a damaged stream: the box's codes call for another number of verbatim values than its table entry says (`ucount`: the error
         // counter here); the reads below stay inside the box's values either way
         ucap = (unsigned)(uoff[b + 1] - uoff[b]);
-        if (tid == rows - 1 && s_scan[tid] != ucap) atomicAdd(ucount, 1u);
+        if (r == rows - 1 && s_scan[r] != ucap) atomicAdd(ucount, 1u);
     } else {
         first_v = *reinterpret_cast<const T *>(szh_omp_box_origin_bytes(g, b, sizeof(T), data));
         __syncthreads();
@@ -111,7 +119,7 @@ __global__ __launch_bounds__(1024) void k_omp_box(szh_omp_geom g, const T *__res
     // the four steps that follow a lane needs the chunks m and m + 1 of its j (v0, v1); chunk m + 2 is requested now (vl) and taken
     // over four steps later.  A finished chunk of results (four codes / four values) waits for the same steps to be stored.
     const bool i0 = i == 0, k0 = k == 0, row00 = i0 && k0;
-    const int ia = i0 ? tid : tid - 1, ib = k0 ? tid : tid - g.c1, ic = (i0 || k0) ? tid : tid - g.c1 - 1;     // (own place when absent: read, not used)
+    const int ia = i0 ? rp : rp - 1, ib = k0 ? rp : rp - g.pitch, ic = (i0 || k0) ? rp : rp - g.pitch - 1;     // (own place when absent: read, not used)
     T l1 = 0, l2 = 0, Ap = 0, Bp = 0, Cp = 0;
     unsigned nun = 0;
     const int steps = g.c0 + g.c1 + g.c2 - 2, j_first = -(k + i), nch = g.c2 >> 2;
@@ -147,7 +155,7 @@ __global__ __launch_bounds__(1024) void k_omp_box(szh_omp_geom g, const T *__res
         for (int u = 0; u < 4; ++u) {
             const int j = tg + u + j_first;
             if ((unsigned)j < (unsigned)g.c2) {
-                const int slot = (j & 3) * rows;
+                const int slot = (j & 3) * rstride;
                 T A = ring[slot + ia], B = ring[slot + ib], C = ring[slot + ic];
                 A = i0 ? (T)0 : A; B = k0 ? (T)0 : B; C = (i0 || k0) ? (T)0 : C;
                 T pred = l1 + A + B - Ap - C - Bp + Cp;
@@ -188,7 +196,7 @@ __global__ __launch_bounds__(1024) void k_omp_box(szh_omp_geom g, const T *__res
                         if (e4 == 3) { vdone = vacc; done_j = j - 3; }
                     } else row_out[j] = rec;
                 }
-                ring[slot + tid] = rec;
+                ring[slot + rp] = rec;
                 l2 = l1; l1 = rec; Ap = A; Bp = B; Cp = C;
             }
             __syncthreads();

@@ -2494,6 +2494,9 @@ static int omp_box_grid(szhip_ctx *ctx, int thread_num, size_t r0, size_t r1, si
     g->bel = (int)bel;
     g->cpb = (int)((bel + SZH_ENC_CHUNK - 1) / SZH_ENC_CHUNK);
     g->vec = (g->c2 % 4 == 0 && r2 % 4 == 0) ? 1 : 0;          // (the base address is looked at by the caller)
+    g->tile8 = (g->c0 % 8 == 0 && g->c1 % 8 == 0) ? 1 : 0;
+    g->pitch = g->c1;
+    if (g->tile8) while (g->pitch % 16 != 8) ++g->pitch;       // 8 or 24 modulo 32
     (void)elem;
     return SZHIP_OK;
 }
@@ -2568,9 +2571,9 @@ int compress_omp_impl(szhip_ctx *ctx, const void *data, int data_on_device, size
     u64 *d_ucount64 = (u64 *)ctx->col_zeros64.p, *d_uoff = (u64 *)ctx->col_off.p;
     const int rows = g.c0 * g.c1, box_threads = rows;      // one lane per row
     HIPCHK(hipEventRecord(ctx->ev[2], st));
-    if (g.vec) hipLaunchKernelGGL((k_omp_box<T, false, true>), dim3((unsigned)g.nb), dim3((unsigned)box_threads), (size_t)4 * rows * sizeof(T), st, g, d_in, (T *)nullptr, eb, (T)(1 / eb),
+    if (g.vec) hipLaunchKernelGGL((k_omp_box<T, false, true>), dim3((unsigned)g.nb), dim3((unsigned)box_threads), (size_t)4 * g.c0 * g.pitch * sizeof(T), st, g, d_in, (T *)nullptr, eb, (T)(1 / eb),
                                   (int)intervals, d_codes, d_ucount, d_ucount64, d_first, (const T *)nullptr, (const u64 *)nullptr);
-    else hipLaunchKernelGGL((k_omp_box<T, false, false>), dim3((unsigned)g.nb), dim3((unsigned)box_threads), (size_t)4 * rows * sizeof(T), st, g, d_in, (T *)nullptr, eb, (T)(1 / eb),
+    else hipLaunchKernelGGL((k_omp_box<T, false, false>), dim3((unsigned)g.nb), dim3((unsigned)box_threads), (size_t)4 * g.c0 * g.pitch * sizeof(T), st, g, d_in, (T *)nullptr, eb, (T)(1 / eb),
                             (int)intervals, d_codes, d_ucount, d_ucount64, d_first, (const T *)nullptr, (const u64 *)nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[3], st));
@@ -2773,9 +2776,9 @@ int decompress_omp_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stre
     if ((uintptr_t)d_out & 15u) g.vec = 0;
     const int rows = g.c0 * g.c1, box_threads = rows;      // one lane per row
     HIPCHK(hipEventRecord(ctx->ev[2], st));
-    if (g.vec) hipLaunchKernelGGL((k_omp_box<T, true, true>), dim3((unsigned)g.nb), dim3((unsigned)box_threads), (size_t)4 * rows * sizeof(T), st, g, (const T *)nullptr, d_out, eb, (T)(1 / eb),
+    if (g.vec) hipLaunchKernelGGL((k_omp_box<T, true, true>), dim3((unsigned)g.nb), dim3((unsigned)box_threads), (size_t)4 * g.c0 * g.pitch * sizeof(T), st, g, (const T *)nullptr, d_out, eb, (T)(1 / eb),
                                   (int)intervals, d_codes, (unsigned *)(sm + SM_ERR), (u64 *)nullptr, (T *)ctx->samples.p, (const T *)ctx->unpred.p, (const u64 *)ctx->col_off.p);
-    else hipLaunchKernelGGL((k_omp_box<T, true, false>), dim3((unsigned)g.nb), dim3((unsigned)box_threads), (size_t)4 * rows * sizeof(T), st, g, (const T *)nullptr, d_out, eb, (T)(1 / eb),
+    else hipLaunchKernelGGL((k_omp_box<T, true, false>), dim3((unsigned)g.nb), dim3((unsigned)box_threads), (size_t)4 * g.c0 * g.pitch * sizeof(T), st, g, (const T *)nullptr, d_out, eb, (T)(1 / eb),
                             (int)intervals, d_codes, (unsigned *)(sm + SM_ERR), (u64 *)nullptr, (T *)ctx->samples.p, (const T *)ctx->unpred.p, (const u64 *)ctx->col_off.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[3], st));
