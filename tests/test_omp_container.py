@@ -5,7 +5,8 @@ against this oracle in tests/test_zz_omp_hip.py; nothing here touches the produc
 
 Pin: tests/golden/ref_recorded_omp.json -- outputs of the unmodified reference (oracle/_ref/libSZ_omp.so) recorded by
 tools/record_reference_omp.py: the bytes behind the parameter block and the decoded array must match, md5 for md5.  Where that library is
-present (the build container) it is also run live.  float32 only: the reference's double entry point dies with SIGILL in this build."""
+present (the build container) it is also run live.  Two of the cases carry fill values (1e30) and NaN / -inf: they pin what the x86-64 build of
+the reference does with interval-optimiser quotients beyond the range of `unsigned long`.  float32 only: the reference's double entry point dies with SIGILL in this build."""
 import hashlib
 import json
 import os
@@ -36,7 +37,8 @@ def test_oracle_reproduces_recorded_reference_container(oracle, name):
     assert hashlib.md5(s[len(meta):]).hexdigest() == rec["body_md5"]
     dec = oracle.omp_decompress(s, len(meta), d.shape, d.dtype)
     assert hashlib.md5(dec.tobytes()).hexdigest() == rec["decoded_md5"]
-    assert float(np.abs(dec.astype(np.float64) - d.astype(np.float64)).max()) <= rec["eb"]
+    ok = np.isfinite(d)                                       # (the fill-value / NaN cases)
+    assert float(np.abs(dec.astype(np.float64) - d.astype(np.float64))[ok].max()) <= rec["eb"]
 
 
 def test_box_grid_and_uneven_shapes_round_trip(oracle):

@@ -124,7 +124,7 @@ def test_omp_container_on_cpu_shim_matches_oracle(oracle, shim_ctx):
 
 
 def test_omp_container_on_cpu_shim_gives_the_recorded_reference_bytes(oracle, shim_ctx):
-    _recorded(shim_ctx, oracle, ["L-32-f32-t8", "S-64-f32-t64", "S-64x32x96-f32-t16"])
+    _recorded(shim_ctx, oracle, ["L-32-f32-t8", "S-64-f32-t64", "S-64x32x96-f32-t16", "Sfill-64x32x32-f32-t8", "Snan-32-f32-t8"])
 
 
 @pytest.mark.slow
