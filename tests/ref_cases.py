@@ -86,6 +86,15 @@ def _pwr_mix(shape, dtype, seed, zeros=0.05, signed=True, first=0.37, neg_near_z
     return np.ascontiguousarray(d.astype(dtype))
 
 
+def _fill(shape, dtype=np.float32, every=7, value=1e30):
+    """a smooth field with fill values (every 7th value 1e30): with an ordinary bound the interval optimisers' quotient
+    (|prediction error| / eb + 1) / 2 leaves the range of `unsigned long` (sz_float.c:4664, :5092)"""
+    sh3 = (1,) * (3 - len(shape)) + tuple(shape)
+    d = s_field(*sh3, dtype).reshape(shape).copy()
+    d.ravel()[::every] = value
+    return d
+
+
 def case(name, data, mode=ABS, abs=1e-4, rel=0.0, pwr=0.0, **conf):
     return dict(name=name, data=data, mode=mode, abs=abs, rel=rel, pwr=pwr, conf=conf)
 
@@ -226,5 +235,15 @@ CASES = [
     case("M40-f64-zstd-default", lambda: m_field(40, f64), szMode="SZ_DEFAULT_COMPRESSION"),
     case("2D-plane-gzip-best", lambda: plane_field(70, 90), szMode="SZ_BEST_COMPRESSION", losslessCompressor="GZIP_COMPRESSOR",
          gzipMode="Gzip_BEST_COMPRESSION"),
+    # ---- fill values (round 3): interval-optimiser quotients beyond the range of `unsigned long` -- what the reference's x86-64 build does with them
+    # (every 7th value: the stream would be larger than the array, the reference stores the raw values; every 97th: about 8 % of the optimiser's
+    #  samples have a fill value in their stencil)
+    case("fill-1e30-28x30x36-f32", lambda: _fill((28, 30, 36))),
+    case("fill-1e30-sparse-32x40x48-f32", lambda: _fill((32, 40, 48), every=97)),
+    case("fill-1e30-sparse-32x40x48-f64", lambda: _fill((32, 40, 48), f64, every=97)),
+    case("fill-1e30-sparse-sz14-32x40x48-f32", lambda: _fill((32, 40, 48), every=97), withLinearRegression="NO"),
+    case("fill-1e30-sparse-2d-200x300-f32", lambda: _fill((200, 300), every=97)),
+    case("fill-1e30-1d-5000-f32", lambda: _fill((5000,))),
+    case("fill-1e30-sparse-1d-50000-f32", lambda: _fill((50000,), every=97)),
 ]
 BY_NAME = {c["name"]: c for c in CASES}
