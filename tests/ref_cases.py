@@ -95,6 +95,12 @@ def _fill(shape, dtype=np.float32, every=7, value=1e30):
     return d
 
 
+def _nan(shape, dtype=np.float32):
+    d = _fill(shape, dtype, every=197)
+    d.ravel()[5::1001] = np.nan
+    return d
+
+
 def case(name, data, mode=ABS, abs=1e-4, rel=0.0, pwr=0.0, **conf):
     return dict(name=name, data=data, mode=mode, abs=abs, rel=rel, pwr=pwr, conf=conf)
 
@@ -245,5 +251,10 @@ CASES = [
     case("fill-1e30-sparse-2d-200x300-f32", lambda: _fill((200, 300), every=97)),
     case("fill-1e30-1d-5000-f32", lambda: _fill((5000,))),
     case("fill-1e30-sparse-1d-50000-f32", lambda: _fill((50000,), every=97)),
+    # NaN (not in element 0): the range scan skips it (`if (min > data) .. else if (max < data)`, dataCompression.c:97-113), the optimisers
+    # put its quotient into the last bin, the quantisers keep it verbatim
+    case("nan-sparse-32x40x48-f32", lambda: _nan((32, 40, 48))),
+    case("nan-sparse-sz14-32x40x48-f32", lambda: _nan((32, 40, 48)), withLinearRegression="NO"),
+    case("nan-sparse-1d-20000-f32", lambda: _nan((20000,))),
 ]
 BY_NAME = {c["name"]: c for c in CASES}
