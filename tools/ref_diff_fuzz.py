@@ -70,6 +70,11 @@ with tempfile.TemporaryDirectory() as td:
             if rng.random() < 0.2: mag.reshape(-1)[0] = 0.0
             d = mag.astype(dt)
         d = np.ascontiguousarray(d.reshape(shape))
+        if os.environ.get("FUZZ_FILL") and mode != 10:            # fill values (FUZZ_FILL=2: NaN / inf too, never in element 0) at a random density
+            d = d.copy(); f = d.reshape(-1)
+            vals = [1e30, -1e30, 9.96921e36] + ([np.nan, np.inf, -np.inf] if os.environ["FUZZ_FILL"] == "2" else [])
+            k = max(1, int(f.size * 10.0 ** rng.uniform(-3, -1.2)))
+            f[rng.integers(1, f.size, k)] = dt(rng.choice(vals)) if rng.random() < 0.7 else np.asarray(rng.choice(vals, k), dt)
         wide = bool(os.environ.get("FUZZ_WIDE"))          # the corners of the knobs
         conf = {"withLinearRegression": "YES" if rng.random() < 0.6 else "NO",
                 "quantization_intervals": int(rng.choice([0, 0, 0, 32, 64, 1024, 65536] if wide else [0, 0, 0, 64, 1024])),
@@ -80,7 +85,8 @@ with tempfile.TemporaryDirectory() as td:
         if product and rng.random() < 0.35:        # the lossless back ends: bytes depend on the zstd / zlib build, so only sizes and DECODED values are compared -- both ways
             conf["szMode"] = str(rng.choice(["SZ_BEST_COMPRESSION", "SZ_DEFAULT_COMPRESSION"]))
             conf["losslessCompressor"] = str(rng.choice(["ZSTD_COMPRESSOR", "GZIP_COMPRESSOR"]))
-        rngv = max(float(d.max()) - float(d.min()), 1e-6)
+        fin = d[np.isfinite(d) & (np.abs(d) < 1e29)]                                   # (FUZZ_FILL: the bound comes from the numbers, not from the fill values)
+        rngv = max(float(fin.max()) - float(fin.min()), 1e-6) if fin.size else 1.0
         case = dict(name=f"fuzz{c}", data=None, mode=mode, abs=float(10.0 ** rng.uniform(-5, -2)) * rngv, rel=float(10.0 ** rng.uniform(-5, -2)),
                     pwr=float(10.0 ** rng.uniform(-4, -1)), conf=conf)
         if skip4 and conf["withLinearRegression"] == "NO" and mode < 10: continue      # SZ 1.4 for 4-D arrays: not restated
