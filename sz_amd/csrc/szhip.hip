@@ -2670,8 +2670,8 @@ int compress_omp_impl(szhip_ctx *ctx, const void *data, int data_on_device, size
     } else {
         unsigned char *h = (unsigned char *)malloc(total_len ? total_len : 1);
         if (!h) FAIL(SZHIP_ERR_INTERNAL, "out of host memory");
-        TRY(staged_copy(ctx, h, d_stream, total_len, false));
-        HIPCHK(hipStreamSynchronize(st));
+        const int rc_copy = staged_copy(ctx, h, d_stream, total_len, false);
+        if (rc_copy != SZHIP_OK || hipStreamSynchronize(st) != hipSuccess) { free(h); FAIL(rc_copy != SZHIP_OK ? rc_copy : SZHIP_ERR_NODEVICE, "copying the stream to the host failed"); }
         *out = h;
     }
     *out_size = total_len;
