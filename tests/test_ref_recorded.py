@@ -68,6 +68,15 @@ MSST19 = [c for c in ref_cases.CASES if c["mode"] >= PW_REL and not _is_log_form
 WRAPPED = [c for c in ref_cases.CASES if _wrapped(c)]
 
 
+def _new_since_last_hardware_run(c):
+    """cases recorded after round 3's GPU minutes were spent (fill values, NaN): their GPU replay stands in tests/test_zz_omp_hip.py, behind
+    everything that has run on hardware before, until it has run once"""
+    return c["name"].startswith(("fill-1e30", "nan-sparse"))
+
+
+PLAIN_GPU = [c for c in PLAIN if not _new_since_last_hardware_run(c)]
+
+
 def _zstd_decompress(blob, n):
     import ctypes
     z = ctypes.CDLL("libzstd.so.1")
@@ -194,8 +203,16 @@ def test_hip_reproduces_recorded_reference_msst19_output(built, c, tmp_path):
         assert hashlib.md5(back.tobytes()).hexdigest() == r["decoded_md5"], c["name"]
 
 
+def check_hip_reproduces(c, tmp_path):
+    d, r, stream, dec = _hip_roundtrip(c, tmp_path)
+    assert len(stream) == r["stream_bytes"], c["name"]
+    assert hashlib.md5(_mask(stream, r)).hexdigest() == r["stream_md5"], c["name"]
+    if dec is not None:
+        assert hashlib.md5(dec.tobytes()).hexdigest() == r["decoded_md5"], c["name"]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("c", PLAIN, ids=[c["name"] for c in PLAIN])
+@pytest.mark.parametrize("c", PLAIN_GPU, ids=[c["name"] for c in PLAIN_GPU])
 def test_hip_reproduces_recorded_reference_output(built, c, tmp_path):
     d, r, stream, dec = _hip_roundtrip(c, tmp_path)
     assert len(stream) == r["stream_bytes"], c["name"]
@@ -213,7 +230,7 @@ def test_hip_lossless_stage_round_trip(built, c, tmp_path):
     assert abs(len(stream) - r["stream_bytes"]) <= 0.02 * r["stream_bytes"] + 64   # same content through a different zstd/zlib version
 
 
-STORED = [c for c in ref_cases.CASES if "stream_file" in REC[c["name"]] and REC[c["name"]].get("decoded_md5")]
+STORED = [c for c in ref_cases.CASES if "stream_file" in REC[c["name"]] and REC[c["name"]].get("decoded_md5") and not _new_since_last_hardware_run(c)]
 
 
 @pytest.mark.gpu

@@ -316,3 +316,22 @@ def test_bench_omp_object_rehearsal_on_cpu_shim(built):
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1])
     o = line["omp_container"]
     assert o["boxes"] == 8 and o["out_bytes"] > 0 and o["max_abs_err"] <= 1e-4
+
+
+# ---- GPU replay of the reference outputs recorded after the last hardware run (tests/ref_cases.py: fill-1e30-*, nan-sparse-*)
+import ref_cases  # noqa: E402
+import test_ref_recorded as _TR  # noqa: E402
+
+_NEW = [c for c in ref_cases.CASES if _TR._new_since_last_hardware_run(c)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c", _NEW, ids=[c["name"] for c in _NEW])
+def test_hip_reproduces_reference_outputs_recorded_after_the_last_hardware_run(built, c, tmp_path):
+    _TR.check_hip_reproduces(c, tmp_path)
+    r = _TR.REC[c["name"]]
+    if "stream_file" in r and r.get("decoded_md5"):               # and decodes the reference-made stream
+        import sz_amd
+        stream = open(os.path.join(ROOT, "tests", "golden", r["stream_file"]), "rb").read()
+        dec = sz_amd.SZ_decompress(stream, tuple(r["shape"]), np.dtype(r["dtype"]))
+        assert hashlib.md5(dec.tobytes()).hexdigest() == r["decoded_md5"], c["name"]
