@@ -2501,6 +2501,12 @@ static int omp_box_grid(szhip_ctx *ctx, int thread_num, size_t r0, size_t r1, si
     return SZHIP_OK;
 }
 
+// the column-per-lane sweep of szh_ompcol.h serves 32 x 32 box faces (any number of planes), two boxes to a wavefront, rows read 16 bytes at a time
+static bool omp_col_applies(const szh_omp_geom &g, const void *base, size_t row_pitch_bytes)
+{
+    return g.c1 == 32 && g.c2 == 32 && g.nb % 2 == 0 && ((uintptr_t)base & 15u) == 0 && row_pitch_bytes % 16 == 0 && tune_int("SZ_HIP_OMP_COL", 1) != 0;
+}
+
 template <class T>
 int compress_omp_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r0, size_t r1, size_t r2, double eb_in, int thread_num,
                       const szhip_params *prm, const unsigned char *meta, size_t meta_len, int out_on_device, unsigned char **out, size_t *out_size,
@@ -2571,7 +2577,12 @@ int compress_omp_impl(szhip_ctx *ctx, const void *data, int data_on_device, size
     u64 *d_ucount64 = (u64 *)ctx->col_zeros64.p, *d_uoff = (u64 *)ctx->col_off.p;
     const int rows = g.c0 * g.c1, box_threads = rows;      // one lane per row
     HIPCHK(hipEventRecord(ctx->ev[2], st));
-    if (g.vec) hipLaunchKernelGGL((k_omp_box<T, false, true>), dim3((unsigned)g.nb), dim3((unsigned)box_threads), (size_t)4 * g.c0 * g.pitch * sizeof(T), st, g, d_in, (T *)nullptr, eb, (T)(1 / eb),
+    if (omp_col_applies(g, d_in, r2 * sizeof(T))) {        // the column-per-lane sweep (szh_ompcol.h): a wavefront per pair of boxes
+        szh_oc::sweep_args<T> oa;
+        oa.g = g; oa.data = d_in; oa.out = nullptr; oa.eb = eb; oa.recip = (T)(1 / eb); oa.intervals = (int)intervals; oa.codes = d_codes;
+        oa.ucount = d_ucount; oa.ucount64 = d_ucount64; oa.first = d_first; oa.uoff = nullptr;
+        hipLaunchKernelGGL((k_omp_col<T, 32, 32, false>), dim3((unsigned)(g.nb / 2)), dim3(64), 0, st, oa);
+    } else if (g.vec) hipLaunchKernelGGL((k_omp_box<T, false, true>), dim3((unsigned)g.nb), dim3((unsigned)box_threads), (size_t)4 * g.c0 * g.pitch * sizeof(T), st, g, d_in, (T *)nullptr, eb, (T)(1 / eb),
                                   (int)intervals, d_codes, d_ucount, d_ucount64, d_first, (const T *)nullptr, (const u64 *)nullptr);
     else hipLaunchKernelGGL((k_omp_box<T, false, false>), dim3((unsigned)g.nb), dim3((unsigned)box_threads), (size_t)4 * g.c0 * g.pitch * sizeof(T), st, g, d_in, (T *)nullptr, eb, (T)(1 / eb),
                             (int)intervals, d_codes, d_ucount, d_ucount64, d_first, (const T *)nullptr, (const u64 *)nullptr);
@@ -2776,7 +2787,18 @@ int decompress_omp_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stre
     if ((uintptr_t)d_out & 15u) g.vec = 0;
     const int rows = g.c0 * g.c1, box_threads = rows;      // one lane per row
     HIPCHK(hipEventRecord(ctx->ev[2], st));
-    if (g.vec) hipLaunchKernelGGL((k_omp_box<T, true, true>), dim3((unsigned)g.nb), dim3((unsigned)box_threads), (size_t)4 * g.c0 * g.pitch * sizeof(T), st, g, (const T *)nullptr, d_out, eb, (T)(1 / eb),
+    if (omp_col_applies(g, d_out, r2 * sizeof(T))) {
+        // the verbatim values go to their places in the output first (boxes that have any); the sweep picks them up where a code is zero
+        if (E > 0) {
+            hipLaunchKernelGGL((k_omp_scatter<T>), dim3((unsigned)g.nb), dim3(256), 0, st, g, (const uint16_t *)d_codes, (const u64 *)ctx->col_off.p, (const T *)ctx->unpred.p, d_out,
+                               (unsigned *)(sm + SM_ERR));
+            HIPCHK(hipGetLastError());
+        }
+        szh_oc::sweep_args<T> oa;
+        oa.g = g; oa.data = nullptr; oa.out = d_out; oa.eb = eb; oa.recip = (T)(1 / eb); oa.intervals = (int)intervals; oa.codes = d_codes;
+        oa.ucount = (unsigned *)(sm + SM_ERR); oa.ucount64 = nullptr; oa.first = (T *)ctx->samples.p; oa.uoff = (const u64 *)ctx->col_off.p;
+        hipLaunchKernelGGL((k_omp_col<T, 32, 32, true>), dim3((unsigned)(g.nb / 2)), dim3(64), 0, st, oa);
+    } else if (g.vec) hipLaunchKernelGGL((k_omp_box<T, true, true>), dim3((unsigned)g.nb), dim3((unsigned)box_threads), (size_t)4 * g.c0 * g.pitch * sizeof(T), st, g, (const T *)nullptr, d_out, eb, (T)(1 / eb),
                                   (int)intervals, d_codes, (unsigned *)(sm + SM_ERR), (u64 *)nullptr, (T *)ctx->samples.p, (const T *)ctx->unpred.p, (const u64 *)ctx->col_off.p);
     else hipLaunchKernelGGL((k_omp_box<T, true, false>), dim3((unsigned)g.nb), dim3((unsigned)box_threads), (size_t)4 * g.c0 * g.pitch * sizeof(T), st, g, (const T *)nullptr, d_out, eb, (T)(1 / eb),
                             (int)intervals, d_codes, (unsigned *)(sm + SM_ERR), (u64 *)nullptr, (T *)ctx->samples.p, (const T *)ctx->unpred.p, (const u64 *)ctx->col_off.p);

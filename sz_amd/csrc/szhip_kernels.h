@@ -1685,3 +1685,4 @@ __global__ void k_probe_wait(const unsigned long long *flag, unsigned long long 
 #include "szh_pwr.h"
 #include "szh_msst.h"
 #include "szh_omp.h"
+#include "szh_ompcol.h"

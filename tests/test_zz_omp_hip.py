@@ -57,6 +57,20 @@ def _cases():
     yield "fill-values-optimised", fill, 1e-4, 8, 0                                      # quotients beyond 2^64 in the interval optimiser
     yield "wide-codes", (np.random.default_rng(5).standard_normal((16, 16, 32)) * 50).astype(np.float32), 1e-3, 8, 65536
     # a payload and a node table too large for the decoder's LDS staging (one box of 32^3, ~14 bits per code)
+    # 32 x 32 box faces, boxes in pairs: the column-per-lane sweep (szh_ompcol.h, round 4); everything above runs on k_omp_box
+    yield "col-S-64-t8", s_field(64, 64, 64), 1e-4, 8, 0                                # eight 32^3 boxes
+    yield "col-S-8x64x64-t8", s_field(8, 64, 64), 1e-3, 8, 0                            # four planes a box
+    yield "col-S-2x64x64-t8", s_field(2, 64, 64), 1e-3, 8, 0                            # ONE plane a box: first and last line at once
+    yield "col-L-6x64x64-t8-fixed64", l_field(6, 64, 64), 1e-3, 8, 64                   # three planes
+    yield "col-S-f64-8x64x64-t8", s_field(8, 64, 64, np.float64), 1e-5, 8, 0
+    yield "col-S-f64-64x64x32-t4", s_field(64, 64, 32, np.float64), 1e-3, 4, 0          # a 2 x 2 x 1 grid of 32^3 boxes
+    yield "col-M-tight", np.ascontiguousarray(m_field(64)[:8]), 1e-6, 8, 0              # most values verbatim: the inverse with verbatim values
+    yield "col-special-f32", _special((8, 64, 64), np.float32), 1e-3, 8, 0
+    yield "col-special-f64", _special((8, 64, 64), np.float64), 1e-3, 8, 64
+    yield "col-constant", np.full((4, 64, 64), 1.5, dtype=np.float32), 1e-3, 8, 0
+    yield "col-wide-codes", (np.random.default_rng(7).standard_normal((4, 64, 64)) * 50).astype(np.float32), 1e-3, 8, 65536
+    mix = s_field(8, 64, 128); mix[:, :32, 32:64] = (np.random.default_rng(8).standard_normal((8, 32, 32)) * 3).astype(np.float32)
+    yield "col-one-noisy-box-t16", mix, 1e-4, 16, 0                                     # wavefronts with and without verbatim values side by side
     yield "wide-codes-one-box", (np.random.default_rng(6).standard_normal((32, 32, 32)) * 50).astype(np.float32), 1e-3, 1, 65536
 
 
