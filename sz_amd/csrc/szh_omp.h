@@ -398,3 +398,414 @@ __global__ __launch_bounds__(256) void k_omp_hdec(int bel, const unsigned char *
     if (tot < (u64)bel) { if (tid == 0) atomicAdd(bad, 1u); }   // a payload that holds fewer symbols than the box has points
     if (cnt && o < (unsigned)bel) { unsigned e; omp_hdec_run(bits, total, table, start, limit, &e, out, o, (unsigned)bel); }
 }
+
+// =====================================================================================================================
+// Round 4: the entropy stage with ONE pass over the codes on either side of the code book (measured before, 512^3 f32, 4096 boxes:
+// k_hist_u16 0.07-0.2 + k_omp_gather 0.22 + k_omp_chunk_bits 0.10 + two scans + k_omp_encode 0.22 ms; k_omp_hdec 1.96 ms).
+//   k_omp_hist_box   a workgroup per box: the box's histogram (LDS, lane-private copies) -> hist_box[b][*] and the global histogram
+//   k_omp_box_bits   bytes of a box's payload = sum of hist_box[b][s] * len[s], rounded up      (or, large alphabets: from its codes)
+//   k_omp_encode_box a workgroup per box walks the box's chunks with a running bit position (no chunk table, no chunk scan) and
+//                    drops the verbatim values (code 0) into the stream's table on the way (the box's rank table: uoff)
+//   k_omp_hdec_lut   a workgroup per box, the payload staged in LDS, decoded with the multi-symbol look-up table of k_hdec_* (hdec_run_lut)
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void k_omp_hist_box(int bel, const uint16_t *__restrict__ codes, unsigned nbins, int rshift, unsigned *__restrict__ hist_box, unsigned *hist)
+{
+    SZH_DYN_SMEM(smem);
+    unsigned *sh = reinterpret_cast<unsigned *>(smem);
+    const unsigned R = 1u << rshift;
+    for (unsigned i = threadIdx.x; i < nbins * R; i += 256) sh[i] = 0;
+    __syncthreads();
+    const unsigned rep = threadIdx.x & (R - 1);
+    const uint16_t *cb = codes + (int64_t)blockIdx.x * bel;
+    const int nvec = bel / 8;
+    const uint4 *v4 = reinterpret_cast<const uint4 *>(cb);
+    for (int i = (int)threadIdx.x; i < nvec; i += 4 * 256) {         // four loads in flight per thread
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (i + u * 256 < nvec) v[u] = v4[i + u * 256];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i + u * 256 >= nvec) break;
+            const unsigned wv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned c0 = wv[q] & 0xffffu, c1 = wv[q] >> 16;
+                if (c0 < nbins) atomicAdd(&sh[(c0 << rshift) + rep], 1u);
+                if (c1 < nbins) atomicAdd(&sh[(c1 << rshift) + rep], 1u);
+            }
+        }
+    }
+    for (int i = nvec * 8 + (int)threadIdx.x; i < bel; i += 256) { const unsigned c = cb[i]; if (c < nbins) atomicAdd(&sh[(c << rshift) + rep], 1u); }
+    __syncthreads();
+    for (unsigned b = threadIdx.x; b < nbins; b += 256) {
+        unsigned s = 0;
+        for (unsigned r = 0; r < R; ++r) s += sh[(b << rshift) + r];
+        hist_box[(int64_t)blockIdx.x * nbins + b] = s;
+        if (s) atomicAdd(&hist[b], s);
+    }
+}
+// bytes of box b = its bits rounded up (Huffman.c encode: the last byte is padded with zero bits); from the box's histogram ...
+__global__ __launch_bounds__(256) void k_omp_box_bits_h(int nb, unsigned nbins, const unsigned *__restrict__ hist_box, const uint8_t *__restrict__ len, u64 *box_bytes)
+{
+    const int b = blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;        // a wavefront per box
+    if (b >= nb) return;
+    u64 s = 0;
+    for (unsigned i = lane; i < nbins; i += 64) s += (u64)hist_box[(int64_t)b * nbins + i] * len[i];
+    s = wave_sum_u64(s);
+    if (lane == 0) box_bytes[b] = (s + 7) >> 3;
+}
+// ... or from its codes (alphabets too large for per-box histograms)
+__global__ __launch_bounds__(256) void k_omp_box_bits_c(int bel, const uint16_t *__restrict__ codes, const uint8_t *__restrict__ len, u64 *box_bytes)
+{
+    __shared__ u64 sh[4];
+    const uint16_t *cb = codes + (int64_t)blockIdx.x * bel;
+    u64 s = 0;
+    for (int p0 = (int)threadIdx.x * 8; p0 < bel; p0 += 256 * 8) {
+        uint16_t cc[8];
+        omp_load8(cb, p0, bel, (bel & 7) == 0, cc);
+        for (int e = 0; e < 8; ++e) if (p0 + e < bel) s += len[cc[e]];
+    }
+    const u64 ws = wave_sum_u64(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ws;
+    __syncthreads();
+    if (threadIdx.x == 0) box_bytes[blockIdx.x] = (sh[0] + sh[1] + sh[2] + sh[3] + 7) >> 3;
+}
+// out32: 4-byte aligned base of the stream buffer (zeroed); bit0: bit position of the first box's payload in it.  unpred: the verbatim values
+// of all boxes, box after box (uoff), in the box's row-major order (sz_omp.c:246-262).  TAB_LDS: code words and lengths in (dynamic) LDS --
+// [u64 code[nbins]][u8 len[nbins]] -- instead of two dependent global look-ups per code.  The next chunk's codes are requested before the
+// present one is packed (a workgroup walks its box chunk by chunk: every load it waits for is a memory round trip on its critical path).
+template <class T, bool TAB_LDS>
+__global__ __launch_bounds__(256) void k_omp_encode_box(szh_omp_geom g, const T *__restrict__ data, const uint16_t *__restrict__ codes, const u64 *__restrict__ code,
+                                                        const uint8_t *__restrict__ len, unsigned nbins, const u64 *__restrict__ box_off, const u64 *__restrict__ box_bytes,
+                                                        const u64 *__restrict__ uoff, const unsigned *__restrict__ ucount, u64 bit0, unsigned *out32,
+                                                        T *__restrict__ unpred, unsigned *bad)
+{
+    SZH_DYN_SMEM(smem);
+    __shared__ unsigned buf[SZH_ENC_CHUNK * 2 + 2];
+    __shared__ u64 sh[8];
+    const int b = blockIdx.x;
+    const u64 *lcode = code; const uint8_t *llen = len;
+    if (TAB_LDS) {
+        u64 *lc = reinterpret_cast<u64 *>(smem); uint8_t *ll = reinterpret_cast<uint8_t *>(smem) + (size_t)nbins * 8;
+        for (unsigned i = threadIdx.x; i < nbins; i += 256) { lc[i] = code[i]; ll[i] = len[i]; }
+        lcode = lc; llen = ll;
+        __syncthreads();
+    }
+    const uint16_t *cb = codes + (int64_t)b * g.bel;
+    const T *box = reinterpret_cast<const T *>(szh_omp_box_origin_bytes(g, b, sizeof(T), data));
+    const bool aligned = (g.bel & 7) == 0;
+    const u64 gbit0 = bit0 + box_off[b] * 8;
+    u64 done_bits = 0, done_zero = 0;
+    const u64 ubase = uoff[b];
+    uint16_t cn[8];
+    omp_load8(cb, (int)threadIdx.x * 8, g.bel, aligned, cn);
+    for (int q = 0; q < g.cpb; ++q) {
+        const int p0 = q * SZH_ENC_CHUNK + (int)threadIdx.x * 8;
+        uint16_t cc[8];
+        for (int e = 0; e < 8; ++e) cc[e] = cn[e];
+        if (q + 1 < g.cpb) omp_load8(cb, p0 + SZH_ENC_CHUNK, g.bel, aligned, cn);
+        unsigned l[8]; unsigned s = 0, zmask = 0;
+        for (int e = 0; e < 8; ++e) { const bool in = p0 + e < g.bel; l[e] = in ? (unsigned)llen[cc[e]] : 0u; s += l[e]; if (in && cc[e] == 0) zmask |= 1u << e; }
+        u64 tot;
+        const u64 ex2 = block_excl_scan_256(((u64)__builtin_popcount(zmask) << 32) | s, sh, &tot);     // (a chunk: < 2^32 bits)
+        const unsigned ex = (unsigned)ex2, tot_bits = (unsigned)tot;
+        const u64 gbit = gbit0 + done_bits;
+        const unsigned lead = (unsigned)(gbit & 31);
+        for (unsigned w = threadIdx.x; w < ((lead + tot_bits + 31) >> 5) + 1; w += 256) buf[w] = 0;
+        __syncthreads();
+        // verbatim values: requested here, stored at the end of the chunk (they come from HBM: waited for on the spot, every chunk of the
+        // box's walk would carry a memory round trip -- measured, 0.26 ms of this kernel at 512^3)
+        T vals[8];
+        if (zmask) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int p = p0 + e, k = p / (g.c1 * g.c2), r = p - k * (g.c1 * g.c2), i = r / g.c2, j = r - i * g.c2;
+                vals[e] = (zmask >> e & 1u) ? box[(int64_t)k * g.d0 + (int64_t)i * g.d1 + j] : (T)0;
+            }
+        }
+        unsigned pos = lead + ex;
+        u64 acc = 0; int accn = 0;
+        for (int e = 0; e < 8; ++e) {
+            if (!l[e]) continue;
+            const u64 cw = lcode[cc[e]];
+            if (accn + (int)l[e] > 64) { lds_put_bits(buf, pos, acc, accn); pos += accn; acc = 0; accn = 0; }
+            acc = l[e] == 64 ? cw : ((acc << l[e]) | (cw & ((1ull << l[e]) - 1)));
+            accn += (int)l[e];
+        }
+        if (accn) lds_put_bits(buf, pos, acc, accn);
+        __syncthreads();
+        const unsigned nwords = (lead + tot_bits + 31) >> 5;
+        const u64 w0 = gbit >> 5;
+        for (unsigned w = threadIdx.x; w < nwords; w += 256) {
+            const unsigned v = __builtin_bswap32(buf[w]);
+            if (w == 0 || w == nwords - 1) { if (v) atomicOr(&out32[w0 + w], v); }
+            else out32[w0 + w] = v;
+        }
+        if (zmask) {
+            u64 rank = ubase + done_zero + (ex2 >> 32);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (zmask >> e & 1u) unpred[rank++] = vals[e];
+        }
+        done_bits += tot_bits; done_zero += tot >> 32;
+        __syncthreads();                                          // the buffer is read out before the next chunk clears it
+    }
+    if (threadIdx.x == 0 && (((done_bits + 7) >> 3) != box_bytes[b] || done_zero != (u64)ucount[b])) atomicAdd(bad, 1u);
+}
+
+// Everything between the code book and the packing in ONE launch of one workgroup: the boxes' payload sizes (from their histograms), where
+// the payloads and the verbatim values of every box begin (two scans), the totals.  Before: k_omp_box_bits_h + two three-launch scans +
+// their gaps, ~50 us for 4096 boxes.
+__global__ __launch_bounds__(1024) void k_omp_layout(int nb, unsigned nbins, const unsigned *__restrict__ hist_box, const u64 *__restrict__ packed, const u64 *__restrict__ ucount64,
+                                                     u64 *box_bytes, u64 *box_off, u64 *uoff, u64 *total_bytes, u64 *total_unpred)
+{
+    __shared__ u64 sa[16], sb[16];
+    __shared__ unsigned char llen[2048];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (unsigned i = tid; i < nbins; i += 1024) llen[i] = (unsigned char)(packed[i] & 0xffu);
+    __syncthreads();
+    u64 carry_b = 0, carry_u = 0;
+    for (int base = 0; base < nb; base += 1024) {
+        const int b = base + tid;
+        u64 bytes = 0, un = 0;
+        if (b < nb) {
+            u64 bits = 0;
+            const unsigned *h = hist_box + (int64_t)b * nbins;
+            for (unsigned i = 0; i < nbins; ++i) bits += (u64)h[i] * llen[i];
+            bytes = (bits + 7) >> 3; un = ucount64[b];
+            box_bytes[b] = bytes;
+        }
+        u64 ib = bytes, iu = un;
+        for (int o = 1; o < 64; o <<= 1) { const u64 tb = __shfl_up(ib, o, 64), tu = __shfl_up(iu, o, 64); if (lane >= o) { ib += tb; iu += tu; } }
+        if (lane == 63) { sa[wid] = ib; sb[wid] = iu; }
+        __syncthreads();
+        u64 pb = carry_b, pu = carry_u, tb = 0, tu = 0;
+        for (int w = 0; w < 16; ++w) { if (w < wid) { pb += sa[w]; pu += sb[w]; } tb += sa[w]; tu += sb[w]; }
+        if (b < nb) { box_off[b] = pb + ib - bytes; uoff[b] = pu + iu - un; }
+        carry_b += tb; carry_u += tu;
+        __syncthreads();
+    }
+    if (tid == 0) { *total_bytes = carry_b; *total_unpred = carry_u; uoff[nb] = carry_u; }
+}
+
+// Third form (round 4): the two above spend ~50 instructions per code -- eight codes a thread, every one of them an LDS atomic, a block scan
+// and three barriers per 2048 codes.  Here a thread takes 32 CONSECUTIVE codes of a round of 8192 and packs them one after the other
+// through a 64-bit accumulator into the workgroup's LDS window: whole words are plain stores (nobody else owns them), only its first and
+// last word are shared with its neighbours (atomic OR).  One scan and two barriers per 8192 codes.  Needs every code word <= 32 bits
+// (host: else k_omp_encode_box) and packed table entries `code << 8 | len`.  Dynamic LDS: [u64 entry[nbins]][window: 8192 maxlen / 32 + 4 words].
+#define SZH_OMP_R3 8192
+// what the kernel also writes into the stream (every box its own entries; byte stores: the tables lie wherever the tree's size puts them):
+// the header bytes (box 0), ucount[b], first[b], the payload size, the verbatim values -- sz_omp.c:233-262,279-280
+struct szh_omp_tables {
+    unsigned char *stream;             // null: nothing of this (the caller copies the tables)
+    const unsigned char *hdr; unsigned hdr_len;
+    u64 off_ucount, off_first, off_unpred, off_sizes;
+    const void *first;
+};
+__device__ __forceinline__ void omp_put_bytes(unsigned char *dst, const void *src, int n) { const unsigned char *q = (const unsigned char *)src; for (int i = 0; i < n; ++i) dst[i] = q[i]; }
+template <class T>
+__global__ __launch_bounds__(256) void k_omp_encode_box3(szh_omp_geom g, const T *__restrict__ data, const uint16_t *__restrict__ codes, const u64 *__restrict__ packed,
+                                                         unsigned nbins, unsigned maxlen, const u64 *__restrict__ box_off, const u64 *__restrict__ box_bytes,
+                                                         const u64 *__restrict__ uoff, const unsigned *__restrict__ ucount, u64 bit0, unsigned *out32,
+                                                         T *__restrict__ unpred, unsigned *bad, szh_omp_tables tb)
+{
+    SZH_DYN_SMEM(smem);
+    __shared__ u64 sh[8];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    u64 *ltab = reinterpret_cast<u64 *>(smem);
+    unsigned *win = reinterpret_cast<unsigned *>(smem + (size_t)nbins * 8);
+    for (unsigned i = tid; i < nbins; i += 256) ltab[i] = packed[i];
+    const uint16_t *cb = codes + (int64_t)b * g.bel;
+    const T *box = reinterpret_cast<const T *>(szh_omp_box_origin_bytes(g, b, sizeof(T), data));
+    const u64 gbit0 = bit0 + box_off[b] * 8, ubase = uoff[b];
+    u64 done_bits = 0, done_zero = 0;
+    const int rounds = (g.bel + SZH_OMP_R3 - 1) / SZH_OMP_R3;
+    auto load32 = [&](int r, uint4 (&v)[4]) {                      // the thread's 32 codes of round r (bel: a multiple of 8; pieces past the end: 0xffff)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int p = r * SZH_OMP_R3 + tid * 32 + k * 8;
+            v[k] = (r < rounds && p + 8 <= g.bel) ? *reinterpret_cast<const uint4 *>(cb + p) : make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+        }
+    };
+    uint4 vn[4];
+    load32(0, vn);
+    if (tb.stream) {
+        if (tid == 0) {
+            const unsigned uc = ucount[b]; const T fv = reinterpret_cast<const T *>(tb.first)[b]; const u64 bb = box_bytes[b];
+            omp_put_bytes(tb.stream + tb.off_ucount + (u64)b * 4, &uc, 4);
+            omp_put_bytes(tb.stream + tb.off_first + (u64)b * sizeof(T), &fv, (int)sizeof(T));
+            omp_put_bytes(tb.stream + tb.off_sizes + (u64)b * 8, &bb, 8);
+        }
+        if (b == 0) for (unsigned i = tid; i < tb.hdr_len; i += 256) tb.stream[i] = tb.hdr[i];
+    }
+    auto put_val = [&](u64 rank, T val) {
+        if (tb.stream) omp_put_bytes(tb.stream + tb.off_unpred + rank * sizeof(T), &val, (int)sizeof(T)); else unpred[rank] = val;
+    };
+    __syncthreads();                                               // (the table is in LDS)
+    for (int r = 0; r < rounds; ++r) {
+        uint4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = vn[k];
+        load32(r + 1, vn);
+        const int p0 = r * SZH_OMP_R3 + tid * 32;
+        // ---- bits and zero codes of the thread's 32 codes
+        unsigned s = 0, z = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned wv[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+            if (p0 + k * 8 + 8 <= g.bel)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned c0 = wv[q] & 0xffffu, c1 = wv[q] >> 16;
+                    s += (unsigned)(ltab[c0] & 0xffu) + (unsigned)(ltab[c1] & 0xffu); z += (c0 == 0) + (c1 == 0);
+                }
+        }
+        u64 tot;
+        const u64 ex2 = block_excl_scan_256(((u64)z << 32) | s, sh, &tot);
+        const unsigned tot_bits = (unsigned)tot;
+        const u64 gbit = gbit0 + done_bits;
+        const unsigned lead = (unsigned)(gbit & 31);
+        const unsigned nwords = (lead + tot_bits + 31) >> 5;
+        for (unsigned w = tid; w < nwords + 1; w += 256) win[w] = 0;
+        // ---- verbatim values: requested now, stored after the round
+        T vals[4]; unsigned nv = 0;                                 // (a thread with more than four of them takes the slow way below)
+        if (z && z <= 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned wv[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned c = (e & 1) ? wv[e >> 1] >> 16 : wv[e >> 1] & 0xffffu;
+                    if (c == 0 && p0 + k * 8 + 8 <= g.bel) {
+                        const int p = p0 + k * 8 + e, kk = p / (g.c1 * g.c2), rr = p - kk * (g.c1 * g.c2), i = rr / g.c2, j = rr - i * g.c2;
+                        const T val = box[(int64_t)kk * g.d0 + (int64_t)i * g.d1 + j];
+                        if (nv == 0) vals[0] = val; else if (nv == 1) vals[1] = val; else if (nv == 2) vals[2] = val; else vals[3] = val;
+                        ++nv;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- pack: acc holds `nb` pending bits (top-aligned at bit nb - 1); a full word leaves as soon as there are 32
+        if (s) {
+            const unsigned bitpos = lead + (unsigned)ex2;
+            unsigned wpos = bitpos >> 5, nb = bitpos & 31u;
+            u64 acc = 0;
+            bool first = true;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned wv[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+                if (p0 + k * 8 + 8 <= g.bel)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const unsigned c = (e & 1) ? wv[e >> 1] >> 16 : wv[e >> 1] & 0xffffu;
+                        const u64 en = ltab[c];
+                        const unsigned le = (unsigned)(en & 0xffu);
+                        acc = (acc << le) | (en >> 8);
+                        nb += le;
+                        if (nb >= 32) {
+                            const unsigned word = (unsigned)(acc >> (nb - 32));
+                            if (first) { atomicOr(&win[wpos], word); first = false; } else win[wpos] = word;
+                            ++wpos; nb -= 32;
+                        }
+                    }
+            }
+            if (nb) {                                              // the last, partial word (shared with the next thread); a first word that never filled up too
+                const unsigned word = (unsigned)(acc << (32 - nb));
+                // (if `first` is still set the pending bits include the lead-in positions, which are zero in acc: the OR leaves them alone)
+                atomicOr(&win[wpos], word);
+            }
+        }
+        __syncthreads();
+        const u64 w0 = gbit >> 5;
+        for (unsigned w = tid; w < nwords; w += 256) {
+            const unsigned x = __builtin_bswap32(win[w]);
+            if (w == 0 || w == nwords - 1) { if (x) atomicOr(&out32[w0 + w], x); }
+            else out32[w0 + w] = x;
+        }
+        if (z) {
+            u64 rank = ubase + done_zero + (ex2 >> 32);
+            if (z <= 4) {
+                if (nv > 0) put_val(rank, vals[0]);
+                if (nv > 1) put_val(rank + 1, vals[1]);
+                if (nv > 2) put_val(rank + 2, vals[2]);
+                if (nv > 3) put_val(rank + 3, vals[3]);
+            } else {
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned wv[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+                    if (p0 + k * 8 + 8 <= g.bel)
+                        for (int e = 0; e < 8; ++e) {
+                            const unsigned c = (e & 1) ? wv[e >> 1] >> 16 : wv[e >> 1] & 0xffffu;
+                            if (c == 0) {
+                                const int p = p0 + k * 8 + e, kk = p / (g.c1 * g.c2), rr = p - kk * (g.c1 * g.c2), i = rr / g.c2, j = rr - i * g.c2;
+                                put_val(rank++, box[(int64_t)kk * g.d0 + (int64_t)i * g.d1 + j]);
+                            }
+                        }
+                }
+            }
+        }
+        done_bits += tot_bits; done_zero += tot >> 32;
+        __syncthreads();                                          // the window is read out before the next round clears it
+    }
+    if (tid == 0 && (((done_bits + 7) >> 3) != box_bytes[b] || done_zero != (u64)ucount[b])) atomicAdd(bad, 1u);
+}
+
+// ---- decoding with the look-up table of k_hdec_* (szhip_kernels.h: hdec_run_lut, SZH_LUT_BITS bits and up to four symbols a look-up).
+// A workgroup per box; dynamic LDS: [the payload: byte-swapped words, swizzled (SZH_HDEC_SWZ), `stage_bytes` of them + slack]
+// [the look-up table SZH_LUT_BYTES][the node table when tab_lds].  The box's 256 stretches find their starts as in k_omp_hdec.
+__global__ __launch_bounds__(256) void k_omp_hdec_lut(int bel, const unsigned char *__restrict__ payload, unsigned bytes_before, const u64 *__restrict__ box_off,
+                                                      const u64 *__restrict__ box_bytes, const unsigned *__restrict__ table, int n_nodes, int tab_lds,
+                                                      const uint4 *__restrict__ lut, unsigned stage_bytes, uint16_t *__restrict__ codes, unsigned *__restrict__ bad)
+{
+    SZH_DYN_SMEM(smem);
+    __shared__ unsigned s_start[257], s_flag[2];
+    __shared__ u64 sh[8];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    uint16_t *out = codes + (int64_t)b * bel;
+    const unsigned nbytes = (unsigned)box_bytes[b];
+    // ---- staging: from a 16-byte aligned address at or below the payload's first byte
+    const unsigned char *bits = payload + box_off[b];
+    unsigned lead = (unsigned)((uintptr_t)bits & 15u);
+    if ((u64)lead > (u64)bytes_before + box_off[b]) lead = 0;       // (never in front of the buffer; then the loads below are unaligned but valid)
+    const unsigned n16 = (lead + nbytes + 15) / 16;
+    const unsigned lds_words = (stage_bytes + 16) / 4;
+    char *q = smem + ((SZH_HDEC_SWZ(lds_words) * 4 + 15) / 16 * 16);
+    const SZH_LDS void *lutw = (const SZH_LDS void *)(q + SZH_LUT_SIZE * 16);
+    const SZH_LDS void *lut4 = (const SZH_LDS void *)q;
+    hdec_copy16<false>(reinterpret_cast<uint4 *>(q), lut, SZH_LUT_BYTES / 16);
+    q += SZH_LUT_BYTES;
+    const SZH_LDS unsigned *ltab = nullptr;
+    if (tab_lds) { hdec_copy16<false>(reinterpret_cast<uint4 *>(q), reinterpret_cast<const uint4 *>(table), (2 * n_nodes + 3) / 4); ltab = (const SZH_LDS unsigned *)q; }
+    hdec_stage16(reinterpret_cast<unsigned *>(smem), reinterpret_cast<const uint4 *>(bits - lead), (int)n16);
+    if (tid == 0) { reinterpret_cast<unsigned *>(smem)[SZH_HDEC_SWZ(4 * n16)] = 0u; s_flag[0] = 0u; s_flag[1] = 0u; }     // the slack word hdec_w32 may touch
+    __syncthreads();
+    const SZH_LDS unsigned *l = (const SZH_LDS unsigned *)smem;
+    const unsigned base = lead * 8, total = base + nbytes * 8;           // local bit positions: the payload is [base, total)
+    unsigned sb = (nbytes * 8 + 255u) / 256u; if (sb < 64u) sb = 64u;
+    const unsigned first = base + (unsigned)tid * sb, limit = first + sb;
+    unsigned start = first, endp = first, cnt = 0;
+    bool redo = true;
+    for (int round = 0; round < 257; ++round) {
+        const bool run = redo && start < limit && start < total;
+        if (redo) {
+            // (all lanes of a wavefront enter: hdec_run_lut has no wavefront-wide operations, `run` only spares the work)
+            cnt = hdec_run_lut<false>(l, total, ltab, table, lutw, run ? start : 0u, run ? limit : 0u, &endp, nullptr, 0, 0, run);
+            if (!run) { cnt = 0; endp = start; }
+            s_start[tid + 1] = endp;
+        }
+        __syncthreads();
+        if (tid == 0) s_flag[(round + 1) & 1] = 0u;
+        redo = false;
+        if (tid > 0) { const unsigned ns = s_start[tid]; if (ns != start) { start = ns; redo = true; } }
+        if (redo) s_flag[round & 1] = 1u;
+        __syncthreads();
+        if (!s_flag[round & 1]) break;                         // uniform
+    }
+    u64 tot;
+    const unsigned o = (unsigned)block_excl_scan_256((u64)cnt, sh, &tot);
+    if (tot < (u64)bel) { if (tid == 0) atomicAdd(bad, 1u); }   // a payload that holds fewer symbols than the box has points
+    const bool wr = cnt && o < (unsigned)bel;
+    unsigned e;
+    int64_t oend = wr ? (int64_t)o + cnt : (int64_t)o;
+    if (oend > bel) oend = bel;
+    hdec_run_lut<true>(l, total, ltab, table, lut4, wr ? start : 0u, wr ? limit : 0u, &e, out, (int64_t)o, oend, wr);
+}

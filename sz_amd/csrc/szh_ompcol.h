@@ -52,6 +52,7 @@ template <> struct ring_slots<float> { static constexpr int RS = 48; };      // 
 template <> struct ring_slots<double> { static constexpr int RS = 44; };     // 44 x 640 B = 27.5 KB: 5
 
 enum { PH_FIRST = 0, PH_MID = 1, PH_LAST = 2 };
+#define OC_FLAG_WORDS 64
 enum { M_CMP = 0, M_DEC = 1, M_DECV = 2 };     // compress; inverse of boxes without verbatim values; inverse with them (pre-scattered into `out`)
 
 template <class T, int C1, int C2>
@@ -80,6 +81,7 @@ template <class T> struct sweep_args {
     uint16_t *codes;
     unsigned *ucount; szh_u64 *ucount64; T *first;        // M_CMP: written; inverse: `first` read, `ucount` = ONE error counter
     const szh_u64 *uoff;               // inverse: ranks of the boxes' verbatim values (which variant a wavefront runs)
+    const unsigned *vflags; int fw;    // inverse: per box `fw` words, bit (row / RPL) = that group of rows holds a verbatim value (k_omp_scatter); fw = 0: none
 };
 
 template <class T, int C1, int C2, int MODE>
@@ -90,8 +92,10 @@ struct sweep {
     static constexpr int KV = MODE == M_DECV ? S::RPL : 1;
 
     OC_LDS unsigned char *ring;
+    OC_LDS unsigned *fl;               // M_DECV: the flag words of the wavefront's boxes, [NB][OC_FLAG_WORDS]
     const sweep_args<T> &a;
     int lane, b, j;                    // box of the wavefront, column
+    bool use_flags;
     T dl[LINE], lup[LINE];             // delay lines: own results / the left lane's, by step number modulo LINE
     T prev, Lprev, Bold, Bpold;
     T first_v;
@@ -105,7 +109,7 @@ struct sweep {
     unsigned vev_lds, cev_lds, ev_r, cev_r;   // lane parts of the LDS addresses of the events, the lane's row within an event
     int64_t line_bytes, row_bytes;     // one line (k) / one row (i) further in the array, in bytes
 
-    __device__ __forceinline__ sweep(OC_LDS unsigned char *r, const sweep_args<T> &args) : ring(r), a(args) {}
+    __device__ __forceinline__ sweep(OC_LDS unsigned char *r, OC_LDS unsigned *f, const sweep_args<T> &args) : ring(r), fl(f), a(args) {}
 
     // the slot of cell s, s = LINE * L + i1 with i1 < LINE + 16 given as (uniform) `ls` = (LINE * L) mod RS plus a lane-dependent i1
     __device__ __forceinline__ unsigned slot_off(int ls, unsigned i1) const
@@ -117,7 +121,15 @@ struct sweep {
     __device__ __forceinline__ int clampL(int L) const { return L < a.g.c0 ? L : a.g.c0 - 1; }
     __device__ __forceinline__ v4u load_vrows(int L, int e) const
     {
-        const unsigned char *p = (CMP ? vsrc : (const unsigned char *)vdst) + (int64_t)clampL(L) * line_bytes + (int64_t)(S::RPL * e) * row_bytes;
+        const int Lc = clampL(L);
+        const unsigned char *p = (CMP ? vsrc : (const unsigned char *)vdst) + (int64_t)Lc * line_bytes + (int64_t)(S::RPL * e) * row_bytes;
+        if (MODE == M_DECV && use_flags) {
+            // rows without a verbatim value are never looked at: their load goes to one line every lane shares (the load itself stays --
+            // a load that may or may not happen would cost the compiler its count of the accesses in flight)
+            const unsigned bit = (unsigned)(Lc * S::EVL + e);
+            const unsigned wv = fl[b * OC_FLAG_WORDS + (bit >> 5)];
+            p = (wv >> (bit & 31u) & 1u) ? p : (const unsigned char *)vdst;
+        }
         return *reinterpret_cast<const v4u *>(p);
     }
     __device__ __forceinline__ v4u load_crows(int L, int w) const
@@ -252,6 +264,14 @@ struct sweep {
             cev_r = (unsigned)rc; cev_lds = (unsigned)(S::VB + b * S::CROW + pc * 16);
             cptr = (unsigned char *)a.codes + ((int64_t)box * g.bel) * 2 + (int64_t)q * 16;
         }
+        use_flags = false;
+        if (MODE == M_DECV) {
+            use_flags = a.vflags && a.fw > 0 && a.fw <= OC_FLAG_WORDS;          // (uniform)
+            if (use_flags) {
+                for (int i = lane; i < S::NB * a.fw; i += 64) { const int bb = i / a.fw, w = i - bb * a.fw; fl[bb * OC_FLAG_WORDS + w] = a.vflags[(int64_t)((int)blockIdx.x * S::NB + bb) * a.fw + w]; }
+                wave_sync();
+            }
+        }
         for_n<LINE>([&](auto UU) { constexpr int U = decltype(UU)::value; dl[U] = 0; lup[U] = 0; });
         prev = 0; Lprev = 0; Bold = 0; Bpold = 0; nun = 0;
         first_v = CMP ? *reinterpret_cast<const T *>(origin) : a.first[box];
@@ -302,23 +322,30 @@ __global__ __launch_bounds__(64) void k_omp_col(szh_oc::sweep_args<T> a)
 {
     typedef szh_oc::shape<T, C1, C2> S;
     __shared__ __attribute__((aligned(16))) unsigned char ring_raw[S::RS * S::PITCH];
+    __shared__ unsigned flags_raw[DEC ? S::NB * OC_FLAG_WORDS : 1];
     OC_LDS unsigned char *ring = (OC_LDS unsigned char *)ring_raw;
-    if (!DEC) { szh_oc::sweep<T, C1, C2, szh_oc::M_CMP> s(ring, a); s.run(); }
+    OC_LDS unsigned *fl = (OC_LDS unsigned *)flags_raw;
+    if (!DEC) { szh_oc::sweep<T, C1, C2, szh_oc::M_CMP> s(ring, fl, a); s.run(); }
     else {
         const int b0 = (int)blockIdx.x * S::NB;
         const bool verb = a.uoff[b0 + S::NB] != a.uoff[b0];          // (uniform)
-        if (verb) { szh_oc::sweep<T, C1, C2, szh_oc::M_DECV> s(ring, a); s.run(); }
-        else { szh_oc::sweep<T, C1, C2, szh_oc::M_DEC> s(ring, a); s.run(); }
+        if (verb) { szh_oc::sweep<T, C1, C2, szh_oc::M_DECV> s(ring, fl, a); s.run(); }
+        else { szh_oc::sweep<T, C1, C2, szh_oc::M_DEC> s(ring, fl, a); s.run(); }
     }
 }
 
 // inverse, before the sweep: the verbatim values of a box go to their places in `out` (the sweep reads them there when it meets a zero
 // code); boxes without any are skipped (the sweep counts zero codes in those).  `bad`: boxes whose zero codes and table entry disagree
+// `vflags` (or null): per box `fw` words (zeroed by the caller), bit g = rows [g RPL, (g + 1) RPL) of the box, RPL = 16 / sizeof(T), hold a verbatim
+// value -- the only rows of `out` the sweep has to read
 template <class T>
 __global__ __launch_bounds__(256) void k_omp_scatter(szh_omp_geom g, const uint16_t *__restrict__ codes, const u64 *__restrict__ uoff,
-                                                     const T *__restrict__ unpred, T *__restrict__ out, unsigned *bad)
+                                                     const T *__restrict__ unpred, T *__restrict__ out, unsigned *bad, unsigned *vflags, int fw)
 {
     __shared__ u64 sh[8];
+    __shared__ unsigned lflags[OC_FLAG_WORDS];
+    const bool flags = vflags && fw > 0 && fw <= OC_FLAG_WORDS;
+    if (flags) { for (int i = threadIdx.x; i < fw; i += 256) lflags[i] = 0; __syncthreads(); }
     const int b = blockIdx.x;
     const u64 cap = uoff[b + 1] - uoff[b];
     if (cap == 0) return;                                     // uniform
@@ -326,18 +353,24 @@ __global__ __launch_bounds__(256) void k_omp_scatter(szh_omp_geom g, const uint1
     const uint16_t *cb = codes + (int64_t)b * g.bel;
     const T *src = unpred + uoff[b];
     u64 done = 0;
+    const bool aligned = (g.bel & 7) == 0;
+    uint16_t cn[8];
+    omp_load8(cb, (int)threadIdx.x * 8, g.bel, aligned, cn);
     for (int base = 0; base < g.bel; base += 256 * 8) {
         const int p0 = base + (int)threadIdx.x * 8;
         unsigned mask = 0;
-        for (int e = 0; e < 8; ++e) if (p0 + e < g.bel && cb[p0 + e] == 0) mask |= 1u << e;
+        for (int e = 0; e < 8; ++e) if (p0 + e < g.bel && cn[e] == 0) mask |= 1u << e;
+        if (base + 256 * 8 < g.bel) omp_load8(cb, p0 + 256 * 8, g.bel, aligned, cn);      // (the next round's codes are on their way during the scan)
         u64 tot;
         u64 rank = done + block_excl_scan_256((u64)__builtin_popcount(mask), sh, &tot);
         for (int e = 0; e < 8; ++e) if (mask >> e & 1u) {
             const int p = p0 + e, k = p / (g.c1 * g.c2), r = p - k * (g.c1 * g.c2), i = r / g.c2, jj = r - i * g.c2;
             box[(int64_t)k * g.d0 + (int64_t)i * g.d1 + jj] = rank < cap ? src[rank] : (T)0;
             ++rank;
+            if (flags) { const unsigned grp = (unsigned)(k * g.c1 + i) / (unsigned)(16 / sizeof(T)); if (grp < (unsigned)fw * 32u) atomicOr(&lflags[grp >> 5], 1u << (grp & 31u)); }
         }
         done += tot;
     }
+    if (flags) { __syncthreads(); for (int i = threadIdx.x; i < fw; i += 256) vflags[(int64_t)b * fw + i] = lflags[i]; }
     if (threadIdx.x == 0 && done != cap) atomicAdd(bad, 1u);
 }

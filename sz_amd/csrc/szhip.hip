@@ -493,7 +493,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         const int64_t nrows = szh_sample_row_limit(G, prm->sample_distance);
         if (nrows > 0) {
             int grid = (int)std::min<int64_t>((nrows + 255) / 256, 1024);
-            hipLaunchKernelGGL((k_sample<T>), dim3(grid), dim3(256), 0, st, G, d_in, nrows, prm->sample_distance, (double)eb,
+            hipLaunchKernelGGL((k_sample<T, true>), dim3(grid), dim3(256), 0, st, G, d_in, nrows, prm->sample_distance, (double)eb,
                                (T)smean, max_radius, d_rh, d_fh, sm + SM_WITHIN);
             HIPCHK(hipGetLastError());
         }
@@ -1621,7 +1621,7 @@ int compress14_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t
             HIPCHK(hipGetLastError());
         } else if (nrows > 0) {
             int grid = (int)std::min<int64_t>((nrows + 255) / 256, 1024);
-            hipLaunchKernelGGL((k_sample<T>), dim3(grid), dim3(256), 0, st, G, d_in, nrows, prm->sample_distance, (double)eb, (T)0,
+            hipLaunchKernelGGL((k_sample<T, false>), dim3(grid), dim3(256), 0, st, G, d_in, nrows, prm->sample_distance, (double)eb, (T)0,
                                max_radius, d_rh, d_fh, sm + SM_WITHIN);
             HIPCHK(hipGetLastError());
         }
@@ -2545,7 +2545,7 @@ int compress_omp_impl(szhip_ctx *ctx, const void *data, int data_on_device, size
         const int64_t nrows = szh_sample_row_limit(G, prm->sample_distance);
         if (nrows > 0) {
             int grid = (int)std::min<int64_t>((nrows + 255) / 256, 1024);
-            hipLaunchKernelGGL((k_sample<T>), dim3(grid), dim3(256), 0, st, G, d_in, nrows, prm->sample_distance, (double)eb, (T)0,
+            hipLaunchKernelGGL((k_sample<T, false>), dim3(grid), dim3(256), 0, st, G, d_in, nrows, prm->sample_distance, (double)eb, (T)0,
                                max_radius, d_rh, d_fh, sm + SM_WITHIN);
             HIPCHK(hipGetLastError());
         }
@@ -2572,7 +2572,7 @@ int compress_omp_impl(szhip_ctx *ctx, const void *data, int data_on_device, size
     uint16_t *d_codes = (uint16_t *)ctx->codes_nat.p;
     TRY(ensure(ctx, ctx->zcnt, (size_t)g.nb * 4));
     TRY(ensure(ctx, ctx->samples, (size_t)g.nb * sizeof(T)));
-    TRY(ensure(ctx, ctx->col_zeros64, (size_t)g.nb * 8)); TRY(ensure(ctx, ctx->col_off, (size_t)g.nb * 8));
+    TRY(ensure(ctx, ctx->col_zeros64, (size_t)g.nb * 8)); TRY(ensure(ctx, ctx->col_off, (size_t)g.nb * 8 + 8));
     unsigned *d_ucount = (unsigned *)ctx->zcnt.p; T *d_first = (T *)ctx->samples.p;
     u64 *d_ucount64 = (u64 *)ctx->col_zeros64.p, *d_uoff = (u64 *)ctx->col_off.p;
     const int rows = g.c0 * g.c1, box_threads = rows;      // one lane per row
@@ -2580,7 +2580,7 @@ int compress_omp_impl(szhip_ctx *ctx, const void *data, int data_on_device, size
     if (omp_col_applies(g, d_in, r2 * sizeof(T))) {        // the column-per-lane sweep (szh_ompcol.h): a wavefront per pair of boxes
         szh_oc::sweep_args<T> oa;
         oa.g = g; oa.data = d_in; oa.out = nullptr; oa.eb = eb; oa.recip = (T)(1 / eb); oa.intervals = (int)intervals; oa.codes = d_codes;
-        oa.ucount = d_ucount; oa.ucount64 = d_ucount64; oa.first = d_first; oa.uoff = nullptr;
+        oa.ucount = d_ucount; oa.ucount64 = d_ucount64; oa.first = d_first; oa.uoff = nullptr; oa.vflags = nullptr; oa.fw = 0;
         hipLaunchKernelGGL((k_omp_col<T, 32, 32, false>), dim3((unsigned)(g.nb / 2)), dim3(64), 0, st, oa);
     } else if (g.vec) hipLaunchKernelGGL((k_omp_box<T, false, true>), dim3((unsigned)g.nb), dim3((unsigned)box_threads), (size_t)4 * g.c0 * g.pitch * sizeof(T), st, g, d_in, (T *)nullptr, eb, (T)(1 / eb),
                                   (int)intervals, d_codes, d_ucount, d_ucount64, d_first, (const T *)nullptr, (const u64 *)nullptr);
@@ -2590,13 +2590,24 @@ int compress_omp_impl(szhip_ctx *ctx, const void *data, int data_on_device, size
     HIPCHK(hipEventRecord(ctx->ev[3], st));
     S.quant_kernel_launches = 1;
 
-    // ---- ONE histogram over all boxes -> code book (host); the ranks of the boxes' verbatim values meanwhile
+    // ---- ONE histogram over all boxes -> code book (host); the ranks of the boxes' verbatim values meanwhile.  Small alphabets: a
+    // histogram per box on the way (k_omp_hist_box), from which the boxes' payload sizes follow without another pass over the codes
     TRY(ensure(ctx, ctx->hist, (size_t)(65536 + 8192) * 4 + 64));
     unsigned *d_hist = (unsigned *)ctx->hist.p;
     TRY(ensure_pinned(ctx, (size_t)intervals * 4 + 64));
     unsigned *h_hist = (unsigned *)ctx->pinned;
     HIPCHK(hipMemsetAsync(d_hist, 0, (size_t)intervals * 4, st));
-    {
+    const bool lean = tune_int("SZ_HIP_OMP_LEAN", 1) != 0;                     // (0: the entropy stage of round 3, kept for comparison)
+    const bool box_hist = lean && intervals <= 1024 && (size_t)g.nb * intervals * 4 <= ((size_t)64 << 20) && g.bel % 8 == 0;
+    unsigned *d_hist_box = nullptr;
+    if (box_hist) {
+        TRY(ensure(ctx, ctx->chunk_bits, (size_t)g.nb * intervals * 4));
+        d_hist_box = (unsigned *)ctx->chunk_bits.p;
+        int rshift = 0;
+        while ((intervals << (rshift + 1)) <= 8192u && rshift < 6) ++rshift;
+        hipLaunchKernelGGL(k_omp_hist_box, dim3((unsigned)g.nb), dim3(256), ((size_t)intervals << rshift) * 4, st, g.bel, (const uint16_t *)d_codes, intervals, rshift, d_hist_box, d_hist);
+        HIPCHK(hipGetLastError());
+    } else {
         int rshift = 0; int use_lds = intervals <= 16384;
         if (use_lds) { while ((intervals << (rshift + 1)) <= 16384u && rshift < 6) ++rshift; }
         const size_t lds = use_lds ? ((size_t)intervals << rshift) * 4 : 16;
@@ -2605,7 +2616,7 @@ int compress_omp_impl(szhip_ctx *ctx, const void *data, int data_on_device, size
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipMemcpyAsync(h_hist, d_hist, (size_t)intervals * 4, hipMemcpyDeviceToHost, st));
-    TRY(scan_u64(ctx, (const u64 *)d_ucount64, g.nb, d_uoff, sm + SM_TOTAL_UNPRED));
+    if (!box_hist) TRY(scan_u64(ctx, (const u64 *)d_ucount64, g.nb, d_uoff, sm + SM_TOTAL_UNPRED));      // (with per-box histograms: in k_omp_layout, below)
     HIPCHK(hipStreamSynchronize(st));
     const u64 E = h_hist[0];
     S.n_unpred = E;
@@ -2635,13 +2646,69 @@ int compress_omp_impl(szhip_ctx *ctx, const void *data, int data_on_device, size
     }
     szhost_huff_free(hf);
     host_ms += now_ms() - h0;
+    unsigned maxlen = 0;
+    for (unsigned s2 = 0; s2 < intervals; ++s2) maxlen = std::max<unsigned>(maxlen, tab_len[s2]);
+    TRY(ensure(ctx, ctx->stream_buf, cap_len + 64));
+    unsigned char *d_stream = (unsigned char *)ctx->stream_buf.p;
+    HIPCHK(hipMemsetAsync(d_stream, 0, cap_len + 64, st));
+    TRY(ensure(ctx, ctx->reg_flags, (size_t)g.nb * 8)); TRY(ensure(ctx, ctx->reg_rank, (size_t)g.nb * 8));
+    u64 *d_box_bytes = (u64 *)ctx->reg_flags.p, *d_box_off = (u64 *)ctx->reg_rank.p;
+    const size_t lds3 = (size_t)intervals * 8 + ((size_t)SZH_OMP_R3 * maxlen / 32 + 4) * 4 + 16;
+    const bool fast = box_hist && maxlen <= 32 && intervals <= 2048 && lds3 <= 60 * 1024 && tune_int("SZ_HIP_OMP_ENC", 3) == 3;
+    if (fast) {
+        // ---- the usual case (code words of at most 32 bits, a histogram per box): ONE upload -- the header and the packed code table
+        // `code << 8 | len` --, one launch for the boxes' sizes and places (k_omp_layout), one that packs the codes and writes every table
+        // of the stream itself (k_omp_encode_box3).  (Round 4, first form: 8 copies / fills and 8 small launches here, ~0.1 ms of gaps.)
+        const size_t hdr_pad = (hdr_len + 7) / 8 * 8, blob = hdr_pad + (size_t)intervals * 8;
+        TRY(ensure_pinned3(ctx, blob));
+        unsigned char *hb = (unsigned char *)ctx->pinned3;
+        memcpy(hb, hdr.data(), hdr_len);
+        u64 *hp = (u64 *)(hb + hdr_pad);
+        for (unsigned s2 = 0; s2 < intervals; ++s2) hp[s2] = ((tab_code[s2] & (tab_len[s2] >= 64 ? ~0ull : (1ull << tab_len[s2]) - 1)) << 8) | tab_len[s2];
+        TRY(ensure(ctx, ctx->code_tab, blob));
+        HIPCHK(hipMemcpyAsync(ctx->code_tab.p, hb, blob, hipMemcpyHostToDevice, st));
+        const u64 *d_packed = (const u64 *)((const unsigned char *)ctx->code_tab.p + hdr_pad);
+        hipLaunchKernelGGL(k_omp_layout, dim3(1), dim3(1024), 0, st, g.nb, intervals, (const unsigned *)d_hist_box, d_packed, (const u64 *)d_ucount64, d_box_bytes, d_box_off, d_uoff,
+                           sm + SM_SCRATCH, sm + SM_TOTAL_UNPRED);
+        HIPCHK(hipGetLastError());
+        szh_omp_tables tb;
+        tb.stream = d_stream; tb.hdr = (const unsigned char *)ctx->code_tab.p; tb.hdr_len = (unsigned)hdr_len;
+        tb.off_ucount = off_ucount; tb.off_first = off_first; tb.off_unpred = off_unpred; tb.off_sizes = off_sizes; tb.first = d_first;
+        hipLaunchKernelGGL((k_omp_encode_box3<T>), dim3((unsigned)g.nb), dim3(256), lds3, st, g, d_in, (const uint16_t *)d_codes, d_packed, intervals, maxlen, (const u64 *)d_box_off,
+                           (const u64 *)d_box_bytes, (const u64 *)d_uoff, (const unsigned *)d_ucount, (u64)off_pay * 8, (unsigned *)d_stream, (T *)nullptr, (unsigned *)(sm + SM_ERR), tb);
+        HIPCHK(hipGetLastError());
+    } else if (lean) {
+        TRY(ensure(ctx, ctx->code_tab, (size_t)intervals * 8));
+        TRY(ensure(ctx, ctx->len_tab, (size_t)intervals));
+        HIPCHK(hipMemcpyAsync(ctx->code_tab.p, tab_code.data(), (size_t)intervals * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(ctx->len_tab.p, tab_len.data(), (size_t)intervals, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_stream, hdr.data(), hdr_len, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_stream + off_ucount, d_ucount, (size_t)g.nb * 4, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_stream + off_first, d_first, (size_t)g.nb * sizeof(T), hipMemcpyDeviceToDevice, st));
+        if (box_hist) TRY(scan_u64(ctx, (const u64 *)d_ucount64, g.nb, d_uoff, sm + SM_TOTAL_UNPRED));
+        // the boxes' payload sizes (from their histograms, or one more pass over the codes), their places, then ONE pass that packs every
+        // box's codes behind a running bit position and drops its verbatim values into the table on the way
+        TRY(ensure(ctx, ctx->unpred, (size_t)E * sizeof(T) + 16));
+        if (box_hist) hipLaunchKernelGGL(k_omp_box_bits_h, dim3((unsigned)((g.nb + 3) / 4)), dim3(256), 0, st, g.nb, intervals, (const unsigned *)d_hist_box, (const uint8_t *)ctx->len_tab.p, d_box_bytes);
+        else hipLaunchKernelGGL(k_omp_box_bits_c, dim3((unsigned)g.nb), dim3(256), 0, st, g.bel, (const uint16_t *)d_codes, (const uint8_t *)ctx->len_tab.p, d_box_bytes);
+        HIPCHK(hipGetLastError());
+        TRY(scan_u64(ctx, (const u64 *)d_box_bytes, g.nb, d_box_off, sm + SM_SCRATCH));
+        HIPCHK(hipMemcpyAsync(d_stream + off_sizes, d_box_bytes, (size_t)g.nb * 8, hipMemcpyDeviceToDevice, st));
+        if (intervals <= 2048)
+            hipLaunchKernelGGL((k_omp_encode_box<T, true>), dim3((unsigned)g.nb), dim3(256), (size_t)intervals * 9 + 16, st, g, d_in, (const uint16_t *)d_codes, (const u64 *)ctx->code_tab.p,
+                               (const uint8_t *)ctx->len_tab.p, intervals, (const u64 *)d_box_off, (const u64 *)d_box_bytes, (const u64 *)d_uoff, (const unsigned *)d_ucount, (u64)off_pay * 8,
+                               (unsigned *)d_stream, (T *)ctx->unpred.p, (unsigned *)(sm + SM_ERR));
+        else
+            hipLaunchKernelGGL((k_omp_encode_box<T, false>), dim3((unsigned)g.nb), dim3(256), 16, st, g, d_in, (const uint16_t *)d_codes, (const u64 *)ctx->code_tab.p,
+                               (const uint8_t *)ctx->len_tab.p, intervals, (const u64 *)d_box_off, (const u64 *)d_box_bytes, (const u64 *)d_uoff, (const unsigned *)d_ucount, (u64)off_pay * 8,
+                               (unsigned *)d_stream, (T *)ctx->unpred.p, (unsigned *)(sm + SM_ERR));
+        HIPCHK(hipGetLastError());
+        if (E > 0) HIPCHK(hipMemcpyAsync(d_stream + off_unpred, ctx->unpred.p, (size_t)E * sizeof(T), hipMemcpyDeviceToDevice, st));
+    } else {
     TRY(ensure(ctx, ctx->code_tab, (size_t)intervals * 8));
     TRY(ensure(ctx, ctx->len_tab, (size_t)intervals));
     HIPCHK(hipMemcpyAsync(ctx->code_tab.p, tab_code.data(), (size_t)intervals * 8, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(ctx->len_tab.p, tab_len.data(), (size_t)intervals, hipMemcpyHostToDevice, st));
-    TRY(ensure(ctx, ctx->stream_buf, cap_len + 64));
-    unsigned char *d_stream = (unsigned char *)ctx->stream_buf.p;
-    HIPCHK(hipMemsetAsync(d_stream, 0, cap_len + 64, st));
     HIPCHK(hipMemcpyAsync(d_stream, hdr.data(), hdr_len, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_stream + off_ucount, d_ucount, (size_t)g.nb * 4, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(d_stream + off_first, d_first, (size_t)g.nb * sizeof(T), hipMemcpyDeviceToDevice, st));
@@ -2653,11 +2720,11 @@ int compress_omp_impl(szhip_ctx *ctx, const void *data, int data_on_device, size
     }
     const int64_t nchunks = (int64_t)g.nb * g.cpb;
     TRY(ensure(ctx, ctx->chunk_bits, (size_t)nchunks * 8)); TRY(ensure(ctx, ctx->chunk_off, (size_t)nchunks * 8));
-    TRY(ensure(ctx, ctx->reg_flags, (size_t)g.nb * 8)); TRY(ensure(ctx, ctx->reg_rank, (size_t)g.nb * 8));
-    u64 *d_box_bytes = (u64 *)ctx->reg_flags.p, *d_box_off = (u64 *)ctx->reg_rank.p;
     hipLaunchKernelGGL(k_omp_chunk_bits, dim3((unsigned)nchunks), dim3(256), 0, st, g, (const uint16_t *)d_codes, (const uint8_t *)ctx->len_tab.p, (u64 *)ctx->chunk_bits.p);
+    HIPCHK(hipGetLastError());
     TRY(scan_u64(ctx, (const u64 *)ctx->chunk_bits.p, nchunks, (u64 *)ctx->chunk_off.p, sm + SM_TOTAL_BITS));
     hipLaunchKernelGGL(k_omp_box_bytes, dim3((unsigned)((g.nb + 255) / 256)), dim3(256), 0, st, g.nb, g.cpb, (const u64 *)ctx->chunk_off.p, (const u64 *)(sm + SM_TOTAL_BITS), d_box_bytes);
+    HIPCHK(hipGetLastError());
     TRY(scan_u64(ctx, (const u64 *)d_box_bytes, g.nb, d_box_off, sm + SM_SCRATCH));
     HIPCHK(hipMemcpyAsync(d_stream + off_sizes, d_box_bytes, (size_t)g.nb * 8, hipMemcpyDeviceToDevice, st));
     if (total_bits > 0) {
@@ -2665,11 +2732,14 @@ int compress_omp_impl(szhip_ctx *ctx, const void *data, int data_on_device, size
                            (const u64 *)ctx->chunk_off.p, (const u64 *)d_box_off, (u64)off_pay * 8, (unsigned *)d_stream);
         HIPCHK(hipGetLastError());
     }
+    }
     HIPCHK(hipEventRecord(ctx->ev[4], st));
     u64 h_small[SM_COUNT];
     HIPCHK(hipMemcpyAsync(h_small, sm, SM_COUNT * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if (h_small[SM_TOTAL_BITS] != total_bits || h_small[SM_TOTAL_UNPRED] != E) FAIL(SZHIP_ERR_INTERNAL, "OpenMP container: entropy stage mismatch");
+    if ((!lean && h_small[SM_TOTAL_BITS] != total_bits) || h_small[SM_TOTAL_UNPRED] != E || (lean && (unsigned)h_small[SM_ERR] != 0) ||
+        h_small[SM_SCRATCH] < (total_bits + 7) / 8 || h_small[SM_SCRATCH] > (total_bits + 7) / 8 + (u64)g.nb)
+        FAIL(SZHIP_ERR_INTERNAL, "OpenMP container: entropy stage mismatch");
     const size_t total_len = off_pay + (size_t)h_small[SM_SCRATCH];
     if (total_len > cap_len) FAIL(SZHIP_ERR_INTERNAL, "OpenMP container: payloads larger than their bound");
     if (out_on_device == 2) {
@@ -2762,7 +2832,7 @@ int decompress_omp_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stre
     HIPCHK(hipMemsetAsync(sm, 0, SM_COUNT * 8, st));
     TRY(ensure(ctx, ctx->reg_flags, (size_t)g.nb * 8)); TRY(ensure(ctx, ctx->reg_rank, (size_t)g.nb * 8)); TRY(ensure(ctx, ctx->col_off, (size_t)g.nb * 8 + 8));
     TRY(ensure(ctx, ctx->samples, (size_t)g.nb * sizeof(T))); TRY(ensure(ctx, ctx->unpred, (size_t)E * sizeof(T) + 16));
-    TRY(ensure(ctx, ctx->dec_tab, dtab.size() * 4 + 16));
+    TRY(ensure(ctx, ctx->dec_tab, (dtab.size() * 4 + 63) / 64 * 64 + SZH_LUT_BYTES + 16));
     HIPCHK(hipMemcpyAsync(ctx->reg_flags.p, bbytes.data(), (size_t)g.nb * 8, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(ctx->reg_rank.p, boff.data(), (size_t)g.nb * 8, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(ctx->col_off.p, uoff.data(), ((size_t)g.nb + 1) * 8, hipMemcpyHostToDevice, st));
@@ -2774,11 +2844,26 @@ int decompress_omp_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stre
     {
         u64 max_box = 0;
         for (int b = 0; b < g.nb; ++b) max_box = std::max(max_box, bbytes[b]);
+        // the look-up-table decoder (hdec_run_lut) when a box's payload, the table and the node table fit a workgroup's LDS
+        const unsigned stage_bytes = (unsigned)((max_box + 30 + 15) / 16 * 16 + 16);
+        const size_t stage_lds = ((size_t)SZH_HDEC_SWZ((stage_bytes + 16) / 4) * 4 + 15) / 16 * 16;
+        const int tab_lds_lut = (size_t)n_nodes_dec * 8 <= 13 * 1024;
+        const size_t lds_lut = stage_lds + SZH_LUT_BYTES + (tab_lds_lut ? ((size_t)n_nodes_dec * 8 + 15) / 16 * 16 : 0);
+        if (single_symbol < 0 && g.bel % 8 == 0 && lds_lut <= 64 * 1024 && tune_int("SZ_HIP_OMP_LEAN", 1) != 0) {
+            const size_t lut_off = (dtab.size() * 4 + 63) / 64 * 64;
+            TRY(ensure(ctx, ctx->dec_tab, lut_off + SZH_LUT_BYTES));          // (grown before the table went up: see the copy above)
+            hipLaunchKernelGGL(k_hdec_build_lut, dim3(SZH_LUT_SIZE / 256), dim3(256), 0, st, (const unsigned *)ctx->dec_tab.p, (uint4 *)((char *)ctx->dec_tab.p + lut_off));
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL(k_omp_hdec_lut, dim3((unsigned)g.nb), dim3(256), lds_lut, st, g.bel, (const unsigned char *)(d_stream + off_pay), (unsigned)off_pay, (const u64 *)ctx->reg_rank.p,
+                               (const u64 *)ctx->reg_flags.p, (const unsigned *)ctx->dec_tab.p, n_nodes_dec, tab_lds_lut, (const uint4 *)((char *)ctx->dec_tab.p + lut_off), stage_bytes,
+                               d_codes, (unsigned *)(sm + SM_ERR));
+        } else {
         const int tab_lds = dtab.size() * 4 <= 16384;            // node table and payload in LDS when they are small (the usual case: 2 - 3 bits per code)
         const unsigned pay_cap = (unsigned)std::min<u64>(max_box, 24576);
         const size_t lds = (tab_lds ? dtab.size() * 4 : 0) + (size_t)pay_cap + 16;
         hipLaunchKernelGGL(k_omp_hdec, dim3((unsigned)g.nb), dim3(256), lds, st, g.bel, (const unsigned char *)(d_stream + off_pay), (const u64 *)ctx->reg_rank.p,
                            (const u64 *)ctx->reg_flags.p, (const unsigned *)ctx->dec_tab.p, n_nodes_dec, tab_lds, pay_cap, single_symbol, d_codes, (unsigned *)(sm + SM_ERR));
+        }
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[1], st));
@@ -2789,12 +2874,21 @@ int decompress_omp_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stre
     HIPCHK(hipEventRecord(ctx->ev[2], st));
     if (omp_col_applies(g, d_out, r2 * sizeof(T))) {
         // the verbatim values go to their places in the output first (boxes that have any); the sweep picks them up where a code is zero
+        int fw = (g.c0 * g.c1 / (16 / (int)sizeof(T)) + 31) / 32;        // flag words per box: a bit per group of rows one load of the sweep covers
+        unsigned *d_vflags = nullptr;
+        if (fw > OC_FLAG_WORDS) fw = 0;
         if (E > 0) {
+            if (fw > 0) {
+                TRY(ensure(ctx, ctx->chunk_bits, (size_t)g.nb * fw * 4));
+                d_vflags = (unsigned *)ctx->chunk_bits.p;
+                HIPCHK(hipMemsetAsync(d_vflags, 0, (size_t)g.nb * fw * 4, st));
+            }
             hipLaunchKernelGGL((k_omp_scatter<T>), dim3((unsigned)g.nb), dim3(256), 0, st, g, (const uint16_t *)d_codes, (const u64 *)ctx->col_off.p, (const T *)ctx->unpred.p, d_out,
-                               (unsigned *)(sm + SM_ERR));
+                               (unsigned *)(sm + SM_ERR), d_vflags, fw);
             HIPCHK(hipGetLastError());
         }
         szh_oc::sweep_args<T> oa;
+        oa.vflags = d_vflags; oa.fw = fw;
         oa.g = g; oa.data = nullptr; oa.out = d_out; oa.eb = eb; oa.recip = (T)(1 / eb); oa.intervals = (int)intervals; oa.codes = d_codes;
         oa.ucount = (unsigned *)(sm + SM_ERR); oa.ucount64 = nullptr; oa.first = (T *)ctx->samples.p; oa.uoff = (const u64 *)ctx->col_off.p;
         hipLaunchKernelGGL((k_omp_col<T, 32, 32, true>), dim3((unsigned)(g.nb / 2)), dim3(64), 0, st, oa);

@@ -375,14 +375,17 @@ __global__ __launch_bounds__(256) void k_gather_mean(const T *__restrict__ data,
 }
 
 #define SZH_LDS_RADIUS_BINS 4096
-template <class T>
+// FREQ = false: only the radius histogram is wanted (the SZ 1.4 optimiser and the OpenMP container's, sz_float.c:4644) -- 16 KB of LDS
+// instead of 48.  (Round 4 tried one thread per SAMPLE instead of per row: slower -- 0.23 ms against 0.10-0.16 -- the pass is bound by
+// the 64-byte sectors its scattered reads touch, ~0.35 GB at 512^3, not by the five dependent rounds of a row.)
+template <class T, bool FREQ>
 __global__ __launch_bounds__(256) void k_sample(szh_geom3 G, const T *__restrict__ data, int64_t nrows, int sd, double ebD, T mean,
                                                 unsigned max_radius, unsigned *radius_hist, unsigned *freq_hist, u64 *within)
 {
     __shared__ unsigned sh_r[SZH_LDS_RADIUS_BINS];
-    __shared__ unsigned sh_f[8192];
+    __shared__ unsigned sh_f[FREQ ? 8192 : 1];
     for (int i = threadIdx.x; i < SZH_LDS_RADIUS_BINS; i += 256) sh_r[i] = 0;
-    for (int i = threadIdx.x; i < 8192; i += 256) sh_f[i] = 0;
+    if (FREQ) for (int i = threadIdx.x; i < 8192; i += 256) sh_f[i] = 0;
     __syncthreads();
     const int64_t rpp = G.g1.count - 1, r2 = G.g2.count;
     const bool two_d = G.ndim == 2;
@@ -399,7 +402,7 @@ __global__ __launch_bounds__(256) void k_sample(szh_geom3 G, const T *__restrict
             unsigned ri; int fi, we;
             szh_sample_point<T>(data, pos, r2, two_d ? 0 : G.d0, ebD, mean, max_radius, &ri, &fi, &we);
             if (ri < SZH_LDS_RADIUS_BINS) atomicAdd(&sh_r[ri], 1u); else atomicAdd(&radius_hist[ri], 1u);
-            atomicAdd(&sh_f[fi], 1u);
+            if (FREQ) atomicAdd(&sh_f[fi], 1u);
             w += (unsigned)we;
         }
     }
@@ -407,7 +410,7 @@ __global__ __launch_bounds__(256) void k_sample(szh_geom3 G, const T *__restrict
     if ((threadIdx.x & 63) == 0 && w) atomicAdd(within, (u64)w);
     __syncthreads();
     for (int i = threadIdx.x; i < SZH_LDS_RADIUS_BINS; i += 256) if (sh_r[i]) atomicAdd(&radius_hist[i], sh_r[i]);
-    for (int i = threadIdx.x; i < 8192; i += 256) if (sh_f[i]) atomicAdd(&freq_hist[i], sh_f[i]);
+    if (FREQ) for (int i = threadIdx.x; i < 8192; i += 256) if (sh_f[i]) atomicAdd(&freq_hist[i], sh_f[i]);
 }
 
 // sequential (order-preserving) sum of the values within eb of dense_pos: ONE wavefront, every lane
