@@ -91,6 +91,52 @@ def _time_reference(sample, cfg_path):
     return float(np.median(times)), size
 
 
+def _omp_ref_child(n, threads):
+    """child process (OMP_NUM_THREADS is set by the parent before the OpenMP runtime loads): the reference's OpenMP variant on the S-field"""
+    import ctypes
+    from sz_amd.fields import s_field
+    L = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libSZ_omp.so"))
+    szt = ctypes.c_size_t
+    L.SZ_Init.argtypes = [ctypes.c_char_p]
+    assert L.SZ_Init(os.path.join(ROOT, "tests", "golden", "sz_speed.config").encode()) == 0
+    d = s_field(n, n, n, np.float32)
+    fn = L.SZ_compress_float_3D_MDQ_openmp
+    fn.restype = ctypes.c_void_p
+    fn.argtypes = [ctypes.c_void_p, szt, szt, szt, ctypes.c_float, ctypes.POINTER(szt)]
+    libc = ctypes.CDLL(None); libc.free.argtypes = [ctypes.c_void_p]
+    times, size = [], 0
+    for _ in range(3):
+        m = szt(0)
+        t1 = time.perf_counter()
+        p = fn(d.ctypes.data, n, n, n, EB, ctypes.byref(m))
+        times.append(time.perf_counter() - t1)
+        size = m.value
+        libc.free(p)
+    print("OMPREF " + json.dumps({"t": float(np.median(times)), "size": int(size), "times": times}))
+
+
+def _time_reference_omp(n, ncpu):
+    """the reference's OWN multi-thread variant (sz/src/sz_omp.c, oracle/_ref/libSZ_omp.so = the unmodified sources with
+    -fopenmp) on the same array, thread count = the largest power of two <= the cores of this box (at most 64)."""
+    import subprocess
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libSZ_omp.so")) or n % 32:
+        return None
+    P = 1
+    while P * 2 <= min(ncpu or 1, 64):
+        P *= 2
+    env = dict(os.environ, OMP_NUM_THREADS=str(P), OMP_DYNAMIC="false", OMP_PROC_BIND="false")
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--omp-ref-child", str(n), str(P)], env=env, capture_output=True, text=True, timeout=600)
+    line = [l for l in r.stdout.splitlines() if l.startswith("OMPREF ")]
+    if not line:
+        return None
+    o = json.loads(line[0][7:])
+    return {"value": round(n * n * n * 4 / o["t"] / 1e9, 4), "unit": "GB/s", "cores": P, "kind": "reference",
+            "sample": f"median of 3 SZ_compress_float_3D_MDQ_openmp passes over the full {n}^3 float32 S-field by oracle/_ref/libSZ_omp.so (the unmodified "
+                      f"reference built -fopenmp), OMP_NUM_THREADS = {P} = boxes ({o['t']:.2f} s per pass); stream {o['size']} B -- the OpenMP container, "
+                      "the format `omp_container` above writes on the GPU",
+            "stream_bytes": o["size"]}
+
+
 def cpu_baselines(host, n, gpu_size):
     """The CPU beside the GPU number, on the host cores of this box, pinned to one core, median of 3 passes over the whole array:
     the unmodified reference library (oracle/_ref, kind "reference") when it is there, and the oracle (its restatement, kind "port");
@@ -132,6 +178,12 @@ def cpu_baselines(host, n, gpu_size):
                    note="oracle/_ref/libSZ.so is not in the tree (oracle/build_ref.sh builds it where /root/reference exists): the port is timed")
     mt = None
     try:
+        mt = _time_reference_omp(n, ncpu)
+    except Exception as e:  # noqa: BLE001 -- a baseline, not the product
+        mt = None
+    if mt is not None:
+        return one, mt
+    try:
         import multiprocessing as mp
         P = 1
         while P * 2 <= min(ncpu or 1, 8):
@@ -149,6 +201,15 @@ def cpu_baselines(host, n, gpu_size):
     except Exception as e:  # noqa: BLE001 -- a baseline, not the product
         mt = {"error": repr(e)}
     return one, mt
+
+
+def _omp_traffic(n):
+    """HBM bytes per launch of the OpenMP container's sweep from the PMC passes committed under profiles/ (only for the workload measured)"""
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic_omp_col.json")))
+        return pm["traffic_bytes_per_launch"] if n == EDGE else None
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def _sync(torch):
@@ -214,6 +275,15 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
     inflight = max(1, args.inflight)
     pool_bufs = [torch.empty(out_cap, dtype=torch.uint8, device=dev) for _ in range(inflight + 1)]
     pools = {}
+    # every lane compresses its OWN copy of the field (round 4): with all lanes reading one buffer a fraction of a millisecond apart, the
+    # 256 MiB Infinity Cache could serve one lane the lines another had just fetched -- real callers compress different arrays
+    lane_inputs = {id(x): [x]}
+
+    def inputs_for(src, k):
+        copies = lane_inputs.setdefault(id(src), [src])
+        while len(copies) < k:
+            copies.append(src.clone())
+        return copies[:k]
 
     def run_steps(k_lanes, nsteps, gather_too, src=None):
         """nsteps compressions with k_lanes in flight; returns (elapsed, per-call stats, (size, buffer) of the last call)."""
@@ -227,7 +297,7 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
                 tks = [pools[k_lanes].submit(x.data_ptr(), True, (n, n, n), np.float32, EB, meta, prm, pool_bufs[q % len(pool_bufs)].data_ptr(), out_cap) for q in range(k_lanes)]
                 for tk in tks: pools[k_lanes].wait(tk)
         pool = pools[k_lanes]
-        src = x if src is None else src
+        srcs = inputs_for(x if src is None else src, k_lanes)
         sync_all()
         t_begin = time.perf_counter()
         live, stats_all, last = [], [], None
@@ -243,7 +313,7 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
                             gather.end(pending.pop(0))
             if i < nsteps:
                 ob_ = pool_bufs[i % (k_lanes + 1)] if k_lanes + 1 <= len(pool_bufs) else pool_bufs[i % len(pool_bufs)]
-                live.append((pool.submit(src.data_ptr(), True, (n, n, n), np.float32, EB, meta, prm, ob_.data_ptr(), out_cap), ob_))
+                live.append((pool.submit(srcs[i % k_lanes].data_ptr(), True, (n, n, n), np.float32, EB, meta, prm, ob_.data_ptr(), out_cap), ob_))
         drain()
         sync_all()
         return time.perf_counter() - t_begin, stats_all, last
@@ -258,6 +328,18 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
         elapsed = float(tmax.item())
     ms_per_step = elapsed / args.steps * 1e3
     value = world * nbytes_in / (elapsed / args.steps) / 1e9
+    # ---- the same steps as ONE blocking call after the other (what SZ_compress_args is): reported beside `value` in the same line
+    if inflight == 1:
+        single_el, single_stats = elapsed, stats_all
+    else:
+        run_steps(1, 2, True)
+        single_el, single_stats, _ = run_steps(1, args.steps, True)
+        if world > 1:
+            t1 = torch.tensor([single_el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t1, op=dist.ReduceOp.MAX)
+            single_el = float(t1.item())
+    single_call = {"GB/s": round(world * nbytes_in / (single_el / args.steps) / 1e9, 3), "ms": round(single_el / args.steps * 1e3, 4),
+                   "quant_ms": round(float(np.mean([t.ms_quant for t in single_stats])), 4)}
 
     # ---- quality of the result (outside the timed region): decompress on the GPU, compare with the input
     dec = torch.empty_like(x)
@@ -417,7 +499,7 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
     # ---- the other paths of the same library, one line each (optional; outside the timed region; single GPU only): the SZ 1.4 container
     #      (withLinearRegression = NO) on the same array, a 2-D array through the SZ 2.1 path, a 1-D series
     other = None
-    if args.other_paths and world == 1 and n == EDGE:
+    if not args.no_other_paths and not args.timed_only and world == 1 and n == EDGE:
         def timed(fn, reps=3):
             fn(); _sync(torch); t = time.perf_counter()
             for _ in range(reps):
@@ -460,16 +542,20 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
     # ---- opt-in (--omp-boxes N): the reference's OpenMP container (szh_omp.h) on the same array, its own object; NOT part of the
     #      default line (the path had not run on hardware when round 3 ended)
     omp = None
-    if args.omp_boxes and world == 1:
+    omp_boxes = args.omp_boxes
+    if omp_boxes < 0:                                              # default: boxes of 32^3 (4096 at 512^3) when the edge allows
+        nb1 = n // 32
+        omp_boxes = nb1 ** 3 if (n % 32 == 0 and nb1 >= 2 and nb1 & (nb1 - 1) == 0 and not args.no_omp and not getattr(args, "dry_run", False)) else 0
+    if omp_boxes and world == 1:
         meta_o = sz_amd.make_meta(np.float32, err_mode=sz_amd.ABS, abs_bound=EB, vmin=0.0, vmax=0.0)
         meta_o = bytes([meta_o[0], meta_o[1], meta_o[2], 0xC0]) + bytes(meta_o[4:])
         y_o = torch.empty_like(x)
         for _ in range(2):
-            optr, osize, ost = ctx.compress_omp(x.data_ptr(), True, (n, n, n), np.float32, EB, args.omp_boxes, meta_o, out_on_device=True)
+            optr, osize, ost = ctx.compress_omp(x.data_ptr(), True, (n, n, n), np.float32, EB, omp_boxes, meta_o, out_on_device=True)
         _sync(torch); t0 = time.perf_counter()
         oq, oe = [], []
         for _ in range(args.steps):
-            optr, osize, ost = ctx.compress_omp(x.data_ptr(), True, (n, n, n), np.float32, EB, args.omp_boxes, meta_o, out_on_device=True)
+            optr, osize, ost = ctx.compress_omp(x.data_ptr(), True, (n, n, n), np.float32, EB, omp_boxes, meta_o, out_on_device=True)
             oq.append(ost.ms_quant); oe.append(ost.ms_entropy)
         _sync(torch); to = (time.perf_counter() - t0) / args.steps
         ctx.decompress_omp(optr, True, osize, len(meta_o), (n, n, n), np.float32, y_o.data_ptr(), True)
@@ -486,9 +572,12 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
                "phase_ms": {"prequant": round(ost.ms_prequant, 3), "quant": round(oqm, 3), "entropy": round(float(np.mean(oe)), 3), "host_glue": round(ost.ms_host, 3),
                             "compress_call_total": round(ost.ms_total, 3), "decompress_entropy": round(odst.ms_entropy, 3), "decompress_quant": round(odst.ms_quant, 3),
                             "decompress_total": round(odst.ms_total, 3)},
-               "roofline": {"bound": "hbm", "kernel": "k_omp_box<float,false,true>", "achieved": round(6 * x.numel() / (oqm * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(6 * x.numel() / (oqm * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": 6 * x.numel(),
-                            "avg_kernel_ms": round(oqm, 4), "note": "algorithmic bytes = N * (4 read + 2 of codes written)"}}
+               "roofline": {"bound": "hbm", "kernel": "k_omp_col<float,32,32,false>" if n % 32 == 0 and omp_boxes == (n // 32) ** 3 else "k_omp_box<float,false,true>",
+                            "achieved": round(nbytes_in / (oqm * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(nbytes_in / (oqm * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": _omp_traffic(n), "algorithmic_bytes_per_launch": nbytes_in,
+                            "avg_kernel_ms": round(oqm, 4),
+                            "achieved_incl_code_writes": round(6 * x.numel() / (oqm * 1e-3) / 1e9, 2),
+                            "note": "algorithmic bytes = N * sizeof(T) READ (SURVEY 8d); the kernel also writes 2 N bytes of codes: `achieved_incl_code_writes`"}}
         del y_o
 
     # ---- host-pointer API, PCIe included (never the headline value)
@@ -533,12 +622,14 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
             "config": {"workload": f"{n}x{n}x{n} float32 S-field (smooth sinusoid) per GPU, ABS 1e-4, SZ 2.1 path with adaptive Lorenzo+regression "
                                    "selection per block (on this field every block chooses Lorenzo; m_field is the mixed case), stream "
                                    "bit-identical to the reference; value-range reduction included in the step (fused into the fit pass); input and output resident in HBM; "
-                                   f"{inflight} compressions of the array in flight per GPU (szhip_pool, one context per lane; `concurrent` gives 1 / 2 / 4)",
+                                   f"{inflight} compressions in flight per GPU, every lane on its own copy of the field (szhip_pool, one context per lane; "
+                                   "`single_call_GBps` = one blocking call after the other, `concurrent` gives 1 / 2 / 4)",
                        "error_bound_mode": "ABS", "abs_err_bound": EB, "slabs": world, "arrays_in_flight": inflight},
             "ratio": round(nbytes_in / size, 6), "out_bytes": size, "max_abs_err": max_abs_err, "psnr": round(psnr, 6),
             "intervals": stats.intervals, "reg_blocks": stats.n_reg_blocks, "unpredictable": stats.n_unpred,
             "decompress_GBps": round(nbytes_in / td / 1e9, 3),
-            "phase_ms": {"caller_glue": round(ms_per_step - stats.ms_total, 3), "prequant": round(stats.ms_prequant, 3), "quant": round(stats.ms_quant, 3),
+            "single_call_GBps": single_call["GB/s"], "single_call": single_call,
+            "phase_ms": {"prequant": round(stats.ms_prequant, 3), "quant": round(stats.ms_quant, 3),
                          "entropy": round(stats.ms_entropy, 3), "host_glue": round(stats.ms_host, 3), "compress_call_total": round(stats.ms_total, 3),
                          "decompress_quant": round(dst.ms_quant, 3), "decompress_total": round(dst.ms_total, 3)},
             "roofline": roofline, "concurrent": concurrent, "m_field": mfield, "fast_mode": fast, "other_paths": other, "omp_container": omp, "e2e": e2e, "cpu_baseline": cpu, "cpu_baseline_mt": cpu_mt}
@@ -647,15 +738,20 @@ def main():
     ap.add_argument("--edge", type=int, default=EDGE, help="cube edge of the headline config (512 = the BASELINE config)")
     ap.add_argument("--c4-edge", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--other-paths", action="store_true", help="also time the SZ 1.4 container, a 2-D array and a 1-D series (one line each)")
+    ap.add_argument("--other-paths", action="store_true", help="(default since round 4; kept for old command lines)")
+    ap.add_argument("--no-other-paths", action="store_true", help="skip the SZ 1.4 container, the 2-D array and the 1-D series (one line each)")
     ap.add_argument("--no-fast", action="store_true", help="skip the opt-in fast-mode object")
-    ap.add_argument("--omp-boxes", type=int, default=0, help="also time the reference's OpenMP container with that many boxes (thread_num; 4096 = 32^3 boxes at 512^3)")
+    ap.add_argument("--omp-boxes", type=int, default=-1, help="boxes (thread_num) of the OpenMP-container object; default: 32^3 boxes (4096 at 512^3); 0 = skip")
+    ap.add_argument("--no-omp", action="store_true", help="skip the OpenMP-container object")
+    ap.add_argument("--omp-ref-child", nargs=2, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--no-m-field", action="store_true")
     ap.add_argument("--timed-only", action="store_true", help="only the headline: priming, warm-up, the timed steps, one decompression (for "
                     "rocprofv3 --stats: every launch of the sweep kernel then runs as in the timed region)")
     ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the entry on gloo + the HIP-on-CPU shim (tests only)")
     ap.add_argument("--inflight", type=int, default=2, help="arrays in flight per GPU in the timed region (szhip_pool lanes); 1 = one blocking call after the other")
     args = ap.parse_args()
+    if args.omp_ref_child:
+        return _omp_ref_child(int(args.omp_ref_child[0]), int(args.omp_ref_child[1]))
 
     import torch
     import torch.distributed as dist

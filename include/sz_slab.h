@@ -34,10 +34,25 @@ unsigned char *sz_slab_pack(int dataType, const size_t dims[3], int slabs, const
 int sz_slab_unpack(const unsigned char *blob, size_t len, int *dataType, size_t dims[3], int *slabs, sz_slab_entry *entries, int max_entries);
 
 /* compress a 3-D array (r3 slowest .. r1 fastest, the argument order of SZ_compress_args) as `slabs` slabs on the calling
- * process's GPU, one after the other, into one container.  Range-based bound modes use the range of the WHOLE array, as the
- * multi-GPU path does with its all-reduce.  Returns a malloc'd container or NULL. */
+ * process's GPU, one after the other, into one container.  Bounds that depend on the array -- REL, ABS_AND_REL, ABS_OR_REL (value range),
+ * PSNR (value range), NORM (element count) -- are derived from the WHOLE array once, as the multi-GPU path does with its all-reduce, and
+ * every slab is then compressed with that absolute bound.  Returns a malloc'd container or NULL. */
 unsigned char *sz_slab_compress(int dataType, void *data, size_t *outSize, int errBoundMode, double absErrBound, double relBoundRatio,
                                 double pwrBoundRatio, size_t r3, size_t r2, size_t r1, int slabs);
+
+/* The same container from `ndev` GPUs of this node at once (round 4; sz_amd/csrc/sz_slab_multi.cpp): slab s on device devices[s] (NULL:
+ * 0 .. ndev-1), one host thread and one HIP context per device, every slab through the ordinary SZ_compress_args.  Range-based bound modes
+ * all-reduce the slabs' value ranges (ncclAllReduce, min / max); the sub-streams are all-gathered onto every device (ncclAllGather of the
+ * sizes, the payloads by one grouped broadcast per slab) -- RCCL over xGMI, looked up at run time; without librccl.so, or when a device is
+ * named twice, the exchange goes through host memory.  The bytes are those of sz_slab_compress(..., slabs = ndev).  ABS, REL, ABS_AND_REL,
+ * ABS_OR_REL.  `info` (may be NULL) reports what was used. */
+typedef struct sz_slab_multi_info {
+    int devices, used_rccl;             /* used_rccl: 1 = ranges and sub-streams went over RCCL */
+    size_t gathered_bytes;              /* bytes of sub-streams every device held after the all-gather (RCCL only) */
+    double seconds_total, seconds_slowest_slab;
+} sz_slab_multi_info;
+unsigned char *sz_slab_compress_multi(int dataType, void *data, size_t *outSize, int errBoundMode, double absErrBound, double relBoundRatio,
+                                      double pwrBoundRatio, size_t r3, size_t r2, size_t r1, int ndev, const int *devices, sz_slab_multi_info *info);
 
 /* decompress every slab of a container into one malloc'd array of dims[0] x dims[1] x dims[2] values (caller frees); NULL on error */
 void *sz_slab_decompress(const unsigned char *blob, size_t len, int *dataType, size_t dims[3]);

@@ -33,10 +33,25 @@ int SZ_LoadConf(const char *sz_cfgFile); /* sz_conf.c */
 /* ---- one HIP context per process (the library is single-threaded by contract) ---- */
 static szhip_ctx *g_ctx = NULL;
 static int g_device = -1;
-static szhip_stats g_last_stats;
+static __thread szhip_stats g_last_stats;
+
+/* ---- a per-THREAD view of that state, for the one caller that is not single-threaded: sz_slab_compress_multi (sz_slab_multi.cpp) runs a host
+ * thread per GPU, and every thread calls the ordinary SZ_compress_args on its slab.  The library mutates its configuration on every call
+ * (SURVEY 8b "Threading": the reference does too), so each of those threads binds its OWN copy of the two parameter structs and its own
+ * HIP context; everything below this point reaches `confparams_cpr` / `exe_params` / the context through the bound view when there is one.
+ * Threads that bind nothing see the process-wide state exactly as before. */
+static __thread sz_params *t_cpr = NULL;
+static __thread sz_exedata *t_exe = NULL;
+static __thread szhip_ctx *t_ctx = NULL;
+static inline sz_params **cpr_slot(void) { return t_cpr ? &t_cpr : &confparams_cpr; }
+static inline sz_exedata **exe_slot(void) { return t_exe ? &t_exe : &exe_params; }
+void sz_slab_thread_bind(struct szhip_ctx *ctx, sz_params *cpr_copy, sz_exedata *exe_copy) { t_ctx = ctx; t_cpr = cpr_copy; t_exe = exe_copy; }
+#define confparams_cpr (*cpr_slot())
+#define exe_params (*exe_slot())
 
 static szhip_ctx *get_ctx(void)
 {
+    if (t_ctx) return t_ctx;
     if (g_ctx) return g_ctx;
     int dev = g_device;
     if (dev < 0) { const char *e = getenv("SZ_HIP_DEVICE"); dev = e ? atoi(e) : 0; }
@@ -102,6 +117,8 @@ static int zlib_load(void)
     if (!g_zlib.compress2 || !g_zlib.uncompress || !g_zlib.bound) { dlclose(g_zlib.h); g_zlib.h = NULL; return 0; }
     return 1;
 }
+/* both back ends looked up once, before threads start (sz_slab_compress_multi) */
+void sz_slab_preload_lossless(void) { (void)zstd_load(); (void)zlib_load(); }
 
 /* ---- init / finalize ---- */
 int SZ_Init(const char *configFilePath)
@@ -850,7 +867,7 @@ void *SZ_decompress_customize_threadsafe(const char *cmprName, void *userPara, i
  * Same names, arguments and stream as an OpenMP build of libSZ; the box count an OpenMP build takes from omp_get_max_threads() (it is
  * written into the stream) comes from SZ_hip_set_omp_threads / SZ_HIP_OMP_THREADS, by default the smallest power of two whose box grid
  * divides the array into boxes of at most 32768 points with a dim-0 x dim-1 face of at most 1024 rows (4096 boxes of 32^3 at 512^3). */
-static int g_omp_threads = 0;
+static int g_omp_threads = 0, g_omp_last_threads = 0;   /* set by the caller / picked for the last array */
 void SZ_hip_set_omp_threads(int thread_num) { g_omp_threads = thread_num; }
 
 static void omp_grid(int thread_num, size_t *nx, size_t *ny, size_t *nz)
@@ -883,10 +900,14 @@ static unsigned char *omp_compress(int dataType, const void *oriData, size_t r1,
     szhip_ctx *ctx = get_ctx();
     if (!ctx) return NULL;
     const int threads = omp_pick_threads(r1, r2, r3);
+    g_omp_last_threads = threads;
     if (threads <= 0) { printf("Error: no power-of-two box grid divides %zu x %zu x %zu into boxes the MI355X build takes; set SZ_HIP_OMP_THREADS.\n", r1, r2, r3); return NULL; }
     /* initRandomAccessBytes (dataCompression.c:686-708): version, flag byte, parameter bytes of confparams_cpr->dataType */
+    /* The body begins at byte 3 + 1 + MetaDataByteLength = 32 for BOTH types (sz_omp.c:221, :733): with confparams_cpr->dataType == SZ_DOUBLE
+     * initRandomAccessBytes writes 36 parameter bytes and the body then overwrites the last eight of them; callers pass
+     * comp + 4 + MetaDataByteLength to the decompressor either way (example/sz_openmp.c) */
     const int meta_type = confparams_cpr->dataType == SZ_DOUBLE ? SZ_DOUBLE : SZ_FLOAT;
-    const size_t meta_len = meta_type == SZ_FLOAT ? MetaDataByteLength : MetaDataByteLength_double;
+    const size_t meta_len = MetaDataByteLength;
     szhost_meta m; fill_meta(&m, confparams_cpr, meta_type);
     unsigned char meta[4 + MetaDataByteLength_double];
     unsigned char flags = 0x80 | (exe_params->SZ_SIZE_TYPE == 8 ? 0x40 : 0);
@@ -946,7 +967,14 @@ void decompressDataSeries_double_3D_openmp(double **data, size_t r1, size_t r2, 
  * sz_set_num_threads (sz_omp.c:49-53) sets the box count as omp_set_num_threads does for an OpenMP build; the 1-D / 2-D entry points
  * are stubs in the reference itself (sz_omp.c:56-61, :360-364, :570-576, :866-870) and stay stubs here */
 void sz_set_num_threads(int nthreads) { g_omp_threads = nthreads; }
-int sz_get_max_threads(void) { if (g_omp_threads > 0) return g_omp_threads; const char *e = getenv("SZ_HIP_OMP_THREADS"); return e && atoi(e) > 0 ? atoi(e) : 1; }
+/* the box count the next call uses when it is fixed (sz_set_num_threads / SZ_HIP_OMP_THREADS); otherwise the one picked for the last array */
+int sz_get_max_threads(void)
+{
+    if (g_omp_threads > 0) return g_omp_threads;
+    const char *e = getenv("SZ_HIP_OMP_THREADS");
+    if (e && atoi(e) > 0) return atoi(e);
+    return g_omp_last_threads > 0 ? g_omp_last_threads : 1;
+}
 int sz_get_thread_num(void) { return 0; }
 double sz_wtime(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + (double)ts.tv_nsec / 1e9; }
 unsigned char *SZ_compress_float_1D_MDQ_openmp(float *oriData, size_t r1, double realPrecision, size_t *comp_size)

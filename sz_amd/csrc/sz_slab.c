@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
 #include "sz.h"
 #include "sz_slab.h"
 
@@ -82,13 +83,26 @@ unsigned char *sz_slab_compress(int dataType, void *data, size_t *outSize, int e
     /* range-based bounds are derived from the range of the WHOLE array (the all-reduce of the multi-GPU path): turn them into the
      * absolute bound the reference would use (computeABSErrBoundFromABS_REL etc., dataCompression.c:288-332) once, here */
     int mode = errBoundMode; double abs_eb = absErrBound;
-    if (errBoundMode == REL || errBoundMode == ABS_AND_REL || errBoundMode == ABS_OR_REL) {
+    if (confparams_cpr == NULL && SZ_Init(NULL) != SZ_SCES) goto done;
+    const int psnr_mode = confparams_cpr->errorBoundMode == PSNR || errBoundMode == PSNR, norm_mode = !psnr_mode && (confparams_cpr->errorBoundMode == NORM || errBoundMode == NORM);
+    if (norm_mode) {                                     /* conf.c:62-65 on the element count of the whole array */
+        abs_eb = sqrt(3.0 / (double)(r3 * plane)) * confparams_cpr->normErr;
+        mode = ABS; confparams_cpr->errorBoundMode = ABS;
+    }
+    if (errBoundMode == REL || errBoundMode == ABS_AND_REL || errBoundMode == ABS_OR_REL || psnr_mode) {
         double lo, hi;
         const size_t n = r3 * plane;
         if (dataType == SZ_FLOAT) { const float *p = (const float *)data; float a = p[0], b = p[0]; for (size_t i = 1; i < n; i++) { if (p[i] < a) a = p[i]; else if (p[i] > b) b = p[i]; } lo = a; hi = b; }
         else { const double *p = (const double *)data; double a = p[0], b = p[0]; for (size_t i = 1; i < n; i++) { if (p[i] < a) a = p[i]; else if (p[i] > b) b = p[i]; } lo = a; hi = b; }
         const double range = dataType == SZ_FLOAT ? (double)((float)hi - (float)lo) : hi - lo, rel = relBoundRatio * range;
-        abs_eb = errBoundMode == REL ? rel : errBoundMode == ABS_AND_REL ? (absErrBound < rel ? absErrBound : rel) : (absErrBound > rel ? absErrBound : rel);
+        if (psnr_mode) {                                 /* conf.c:54-60 on the range of the whole array */
+            abs_eb = range * pow(10, (confparams_cpr->psnr + 10 * log10(1 - 2.0 / 3.0 * (double)confparams_cpr->predThreshold)) / (-20));
+            confparams_cpr->errorBoundMode = ABS;
+        } else if (errBoundMode == REL) abs_eb = rel;
+        else if (dataType == SZ_FLOAT) {                 /* min_f / max_f narrow both operands to float (dataCompression.c:320-322) */
+            const float fa = (float)absErrBound, fb = (float)rel;
+            abs_eb = errBoundMode == ABS_AND_REL ? (fa < fb ? fa : fb) : (fa > fb ? fa : fb);
+        } else abs_eb = errBoundMode == ABS_AND_REL ? (absErrBound < rel ? absErrBound : rel) : (absErrBound > rel ? absErrBound : rel);
         mode = ABS;
     }
     for (int s = 0; s < slabs; s++) {
@@ -110,14 +124,20 @@ void *sz_slab_decompress(const unsigned char *blob, size_t len, int *dataType, s
     if (sz_slab_unpack(blob, len, &dt, d, &n, NULL, 0) != SZ_SCES) return NULL;
     sz_slab_entry *e = (sz_slab_entry *)malloc((size_t)n * sizeof(sz_slab_entry));
     if (!e || sz_slab_unpack(blob, len, &dt, d, &n, e, n) != SZ_SCES) { free(e); return NULL; }
-    const size_t esz = dt == SZ_FLOAT ? 4 : 8, plane = d[1] * d[2];
+    const size_t esz = dt == SZ_FLOAT ? 4 : 8;
+    /* dimensions from an untrusted container: their product, times the element size, must not wrap (a wrapped `total` would give a
+     * buffer far smaller than what the slabs below copy into it), and the slabs must tile [0, d0) without gaps or overlap (planes no
+     * slab covers would come back as uninitialised memory) */
+    if (d[0] == 0 || d[1] == 0 || d[2] == 0 || d[1] > SIZE_MAX / d[2] || d[0] > SIZE_MAX / (d[1] * d[2]) || d[0] * d[1] * d[2] > SIZE_MAX / esz ||
+        d[0] * d[1] * d[2] >= ((size_t)1 << 46)) { free(e); return NULL; }
+    const size_t plane = d[1] * d[2];
     const size_t total = d[0] * plane * esz;
-    unsigned char *out = (unsigned char *)malloc(total != 0 ? total : 1);
+    { size_t z = 0; for (int s = 0; s < n; s++) { if (e[s].z_begin != z || e[s].z_end < z || e[s].z_end > d[0]) { free(e); return NULL; } z = e[s].z_end; } if (z != d[0]) { free(e); return NULL; } }
+    unsigned char *out = (unsigned char *)malloc(total);
     if (!out) { free(e); return NULL; }
     for (int s = 0; s < n; s++) {
         const size_t h = e[s].z_end - e[s].z_begin;
         if (h == 0) continue;
-        if (e[s].z_end > d[0]) { free(out); free(e); return NULL; }
         void *part = SZ_decompress(dt, (unsigned char *)blob + e[s].offset, e[s].bytes, 0, 0, h, d[1], d[2]);
         if (!part) { free(out); free(e); return NULL; }
         memcpy(out + e[s].z_begin * plane * esz, part, h * plane * esz);

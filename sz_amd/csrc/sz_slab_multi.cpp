@@ -1,0 +1,238 @@
+// sz_slab_multi.cpp -- the multi-GPU path of SURVEY 8(e) for C callers, in ONE process (include/sz_slab.h: sz_slab_compress_multi).
+// One host thread and one HIP context per device; every thread runs the ordinary SZ_compress_args on its slab of the slowest dimension
+// (the streams are therefore exactly those of sz_slab_compress, and the container the bytes of sz_slab_pack).  What crosses devices:
+//   * range-based bound modes need the value range of the WHOLE array (sz_float.c:2845-2866): every device scans its slab (szhip_minmax)
+//     and the two scalars are all-reduced -- ncclAllReduce(ncclMin / ncclMax) over xGMI;
+//   * the sub-streams are concatenated on every device: ncclAllGather of the sizes, then the payloads (one ncclBroadcast per slab inside a
+//     group: slabs differ in size) -- the "single all-gather of the bitstream" of north_star; the host container is assembled from the
+//     threads' own host copies, which SZ_compress_args returns anyway.
+// RCCL is looked up at run time (dlopen("librccl.so"): the library must load on a box without it); without it, or with a device list that
+// names one device twice (tests), the same exchange goes through host memory behind a barrier -- same results, no xGMI.
+// The reference has no counterpart (no multi-device path); the Python twin is sz_amd/slab.py over torch.distributed.
+#include <hip/hip_runtime.h>
+#include <condition_variable>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <dlfcn.h>
+#include <mutex>
+#include <thread>
+#include <vector>
+#include <chrono>
+extern "C" {
+#include "sz.h"
+#include "sz_slab.h"
+#include "szhip.h"
+void sz_slab_thread_bind(struct szhip_ctx *ctx, sz_params *cpr_copy, sz_exedata *exe_copy);     // sz_api.c
+void sz_slab_preload_lossless(void);
+}
+
+namespace {
+
+// ---- RCCL, resolved at run time.  The few declarations needed, as rccl.h has them (ncclDataType_t / ncclRedOp_t values are ABI)
+typedef struct ncclComm *ncclComm_t;
+enum { NCCL_UINT8 = 1, NCCL_UINT64 = 5, NCCL_FLOAT64 = 8 };
+enum { NCCL_MAX = 2, NCCL_MIN = 3 };
+struct rccl_api {
+    void *h = nullptr;
+    int (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Broadcast)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    bool load()
+    {
+#ifdef SZH_HIPSIM
+        return false;
+#else
+        const char *names[] = {"librccl.so", "librccl.so.1", nullptr};
+        for (int i = 0; names[i] && !h; ++i) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+        if (!h) return false;
+        CommInitAll = (decltype(CommInitAll))dlsym(h, "ncclCommInitAll"); CommDestroy = (decltype(CommDestroy))dlsym(h, "ncclCommDestroy");
+        AllReduce = (decltype(AllReduce))dlsym(h, "ncclAllReduce"); AllGather = (decltype(AllGather))dlsym(h, "ncclAllGather");
+        Broadcast = (decltype(Broadcast))dlsym(h, "ncclBroadcast"); GroupStart = (decltype(GroupStart))dlsym(h, "ncclGroupStart"); GroupEnd = (decltype(GroupEnd))dlsym(h, "ncclGroupEnd");
+        return CommInitAll && CommDestroy && AllReduce && AllGather && Broadcast && GroupStart && GroupEnd;
+#endif
+    }
+};
+
+struct barrier_t {
+    std::mutex mu; std::condition_variable cv; int n = 0, waiting = 0; unsigned gen = 0;
+    void wait() { std::unique_lock<std::mutex> lk(mu); const unsigned g = gen; if (++waiting == n) { waiting = 0; ++gen; cv.notify_all(); } else cv.wait(lk, [&] { return gen != g; }); }
+};
+
+struct shared_t {
+    int ndev = 0; bool rccl = false; rccl_api api; std::vector<ncclComm_t> comms;
+    barrier_t bar;
+    std::vector<double> lo, hi;                    // host exchange of the ranges
+    std::vector<unsigned char *> streams; std::vector<size_t> bytes; std::vector<int> rc;
+    std::vector<double> t_compress;
+    std::mutex sim_mu;                             // the CPU shim runs one launch at a time
+    int gather_ok = 1; size_t gathered = 0;
+};
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct job_t {
+    int dataType, mode; double abs_eb, rel, pw; const unsigned char *data; size_t r2, r1; const size_t *bounds; const int *devices;
+    const sz_params *cpr0; const sz_exedata *exe0; bool verify_gather;
+};
+
+void worker(shared_t *S, const job_t *J, int r)
+{
+    const size_t esz = J->dataType == SZ_FLOAT ? 4 : 8, plane = J->r2 * J->r1;
+    const size_t z0 = J->bounds[2 * r], h = J->bounds[2 * r + 1] - z0, count = h * plane;
+    const unsigned char *slab = J->data + z0 * plane * esz;
+    S->rc[r] = SZ_NSCS;
+    szhip_ctx *ctx = nullptr;
+    hipStream_t st = nullptr;
+    bool alive = hipSetDevice(J->devices[r]) == hipSuccess && szhip_create(&ctx, J->devices[r]) == SZHIP_OK && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+    sz_params cpr = *J->cpr0; sz_exedata exe = *J->exe0;
+    sz_slab_thread_bind(ctx, &cpr, &exe);
+    // ---- the range of the whole array (range-based modes): local scan, then min / max over the devices
+    int mode = J->mode; double abs_eb = J->abs_eb;
+    const bool ranged = mode == REL || mode == ABS_AND_REL || mode == ABS_OR_REL;
+    if (ranged) {
+        double lo = 0, hi = 0; bool have = false;
+        if (alive && count) {
+            void *d_in = nullptr;
+#ifdef SZH_HIPSIM
+            std::lock_guard<std::mutex> lk(S->sim_mu);
+#endif
+            have = szhip_stage_input(ctx, slab, count * esz, &d_in) == SZHIP_OK &&
+                   szhip_minmax(ctx, J->dataType == SZ_FLOAT ? SZHIP_F32 : SZHIP_F64, d_in, 1, count, &lo, &hi) == SZHIP_OK;
+            if (!have) alive = false;
+        }
+        if (!have) { lo = 1.0 / 0.0; hi = -1.0 / 0.0; }           // (an empty slab takes no part)
+        if (S->rccl) {
+            double *d = nullptr;
+            if (hipMalloc((void **)&d, 4 * sizeof(double)) == hipSuccess) {
+                const double v[2] = {lo, hi};
+                hipMemcpyAsync(d, v, 16, hipMemcpyHostToDevice, st);
+                S->api.AllReduce(d, d + 2, 1, NCCL_FLOAT64, NCCL_MIN, S->comms[r], st);
+                S->api.AllReduce(d + 1, d + 3, 1, NCCL_FLOAT64, NCCL_MAX, S->comms[r], st);
+                double w[2] = {lo, hi};
+                hipMemcpyAsync(w, d + 2, 16, hipMemcpyDeviceToHost, st);
+                hipStreamSynchronize(st);
+                lo = w[0]; hi = w[1];
+                hipFree(d);
+            }
+        } else {
+            S->lo[r] = lo; S->hi[r] = hi;
+            S->bar.wait();
+            for (int q = 0; q < S->ndev; ++q) { if (S->lo[q] < lo) lo = S->lo[q]; if (S->hi[q] > hi) hi = S->hi[q]; }
+            S->bar.wait();
+        }
+        // getRealPrecision_float / _double on the whole array's range (dataCompression.c:288-332; the float helpers narrow both operands)
+        const double range = J->dataType == SZ_FLOAT ? (double)((float)hi - (float)lo) : hi - lo, rel = J->rel * range;
+        if (mode == REL) abs_eb = rel;
+        else if (J->dataType == SZ_FLOAT) { const float fa = (float)J->abs_eb, fb = (float)rel; abs_eb = mode == ABS_AND_REL ? (fa < fb ? fa : fb) : (fa > fb ? fa : fb); }
+        else abs_eb = mode == ABS_AND_REL ? (J->abs_eb < rel ? J->abs_eb : rel) : (J->abs_eb > rel ? J->abs_eb : rel);
+        mode = ABS;
+    }
+    // ---- this device's slab: the ordinary entry point, on this thread's context and its own copy of the configuration
+    const double t0 = now_s();
+    if (alive) {
+        if (h == 0) { S->streams[r] = (unsigned char *)malloc(1); S->bytes[r] = 0; S->rc[r] = S->streams[r] ? SZ_SCES : SZ_NSCS; }
+        else {
+#ifdef SZH_HIPSIM
+            std::lock_guard<std::mutex> lk(S->sim_mu);
+#endif
+            S->streams[r] = SZ_compress_args(J->dataType, (void *)slab, &S->bytes[r], mode, abs_eb, J->rel, J->pw, 0, 0, h, J->r2, J->r1);
+            S->rc[r] = S->streams[r] ? SZ_SCES : SZ_NSCS;
+        }
+    }
+    S->t_compress[r] = now_s() - t0;
+    // ---- the sub-streams on every device: sizes, then payloads (north_star's all-gather over xGMI).  Every rank takes part even when its
+    // own slab failed (a collective that one rank skips hangs the others): a failed slab contributes an empty stream
+    if (S->rccl) {
+        unsigned long long *d_sizes = nullptr; unsigned char *d_all = nullptr;
+        const unsigned long long mine = S->rc[r] == SZ_SCES ? (unsigned long long)S->bytes[r] : 0ull;
+        std::vector<unsigned long long> sizes((size_t)S->ndev, 0ull);
+        if (hipMalloc((void **)&d_sizes, ((size_t)S->ndev + 1) * 8) == hipSuccess) {
+            hipMemcpyAsync(d_sizes + S->ndev, &mine, 8, hipMemcpyHostToDevice, st);
+            S->api.AllGather(d_sizes + S->ndev, d_sizes, 1, NCCL_UINT64, S->comms[r], st);
+            hipMemcpyAsync(sizes.data(), d_sizes, (size_t)S->ndev * 8, hipMemcpyDeviceToHost, st);
+            hipStreamSynchronize(st);
+        }
+        size_t total = 0, my_off = 0;
+        for (int q = 0; q < S->ndev; ++q) { if (q == r) my_off = total; total += (size_t)sizes[q]; }
+        if (hipMalloc((void **)&d_all, total ? total : 1) == hipSuccess) {
+            if (mine) hipMemcpyAsync(d_all + my_off, S->streams[r], (size_t)mine, hipMemcpyHostToDevice, st);
+            S->api.GroupStart();
+            size_t off = 0;
+            for (int q = 0; q < S->ndev; ++q) { if (sizes[q]) S->api.Broadcast(d_all + off, d_all + off, (size_t)sizes[q], NCCL_UINT8, q, S->comms[r], st); off += (size_t)sizes[q]; }
+            S->api.GroupEnd();
+            hipStreamSynchronize(st);
+            if (r == 0) S->gathered = total;
+            if (J->verify_gather) {                                 // what every device now holds = the slabs' streams back to back
+                std::vector<unsigned char> back(total ? total : 1);
+                hipMemcpy(back.data(), d_all, total, hipMemcpyDeviceToHost);
+                S->bar.wait();                                      // (all host streams are final)
+                size_t o2 = 0; bool ok = true;
+                for (int q = 0; q < S->ndev; ++q) { if (sizes[q] && memcmp(back.data() + o2, S->streams[q], (size_t)sizes[q]) != 0) ok = false; o2 += (size_t)sizes[q]; }
+                if (!ok) { std::lock_guard<std::mutex> lk(S->sim_mu); S->gather_ok = 0; }
+            }
+            hipFree(d_all);
+        }
+        if (d_sizes) hipFree(d_sizes);
+    }
+    sz_slab_thread_bind(nullptr, nullptr, nullptr);
+    if (st) hipStreamDestroy(st);
+    if (ctx) szhip_destroy(ctx);
+}
+
+} // namespace
+
+extern "C" unsigned char *sz_slab_compress_multi(int dataType, void *data, size_t *outSize, int errBoundMode, double absErrBound, double relBoundRatio,
+                                                 double pwrBoundRatio, size_t r3, size_t r2, size_t r1, int ndev, const int *devices, sz_slab_multi_info *info)
+{
+    if (info) memset(info, 0, sizeof(*info));
+    if (!data || !outSize || ndev < 1 || ndev > 64 || r3 < 1 || r2 < 1 || r1 < 1 || (dataType != SZ_FLOAT && dataType != SZ_DOUBLE)) return nullptr;
+    if (errBoundMode == PSNR || errBoundMode == NORM || errBoundMode >= PW_REL) {
+        printf("Error: sz_slab_compress_multi takes ABS, REL, ABS_AND_REL and ABS_OR_REL (PSNR / NORM / point-wise bounds: sz_slab_compress).\n");
+        return nullptr;
+    }
+    if (confparams_cpr == nullptr && SZ_Init(nullptr) != SZ_SCES) return nullptr;
+    sz_slab_preload_lossless();
+    std::vector<int> devs((size_t)ndev);
+    bool distinct = true;
+    for (int r = 0; r < ndev; ++r) { devs[r] = devices ? devices[r] : r; for (int q = 0; q < r; ++q) if (devs[q] == devs[r]) distinct = false; }
+    std::vector<size_t> bounds(2 * (size_t)ndev);
+    sz_slab_bounds(r3, ndev, 6, bounds.data());
+    shared_t S;
+    S.ndev = ndev; S.bar.n = ndev;
+    S.lo.assign(ndev, 0); S.hi.assign(ndev, 0); S.streams.assign(ndev, nullptr); S.bytes.assign(ndev, 0); S.rc.assign(ndev, SZ_NSCS); S.t_compress.assign(ndev, 0);
+    const char *no = getenv("SZ_SLAB_NO_RCCL");
+    if (distinct && !(no && atoi(no)) && S.api.load()) {
+        S.comms.assign(ndev, nullptr);
+        S.rccl = S.api.CommInitAll(S.comms.data(), ndev, devs.data()) == 0;
+        if (!S.rccl) S.comms.clear();
+    }
+    const char *vg = getenv("SZ_SLAB_VERIFY_GATHER");
+    const sz_params cpr0 = *confparams_cpr; const sz_exedata exe0 = *exe_params;
+    job_t J = {dataType, errBoundMode, absErrBound, relBoundRatio, pwrBoundRatio, (const unsigned char *)data, r2, r1, bounds.data(), devs.data(), &cpr0, &exe0, vg && atoi(vg)};
+    const double t0 = now_s();
+    std::vector<std::thread> th;
+    for (int r = 0; r < ndev; ++r) th.emplace_back(worker, &S, &J, r);
+    for (auto &t : th) t.join();
+    const double t1 = now_s();
+    if (S.rccl) for (ncclComm_t c : S.comms) if (c) S.api.CommDestroy(c);
+    unsigned char *out = nullptr;
+    bool ok = S.gather_ok != 0;
+    for (int r = 0; r < ndev; ++r) if (S.rc[r] != SZ_SCES) ok = false;
+    if (ok) {
+        const size_t dims[3] = {r3, r2, r1};
+        out = sz_slab_pack(dataType, dims, ndev, bounds.data(), (const unsigned char *const *)S.streams.data(), S.bytes.data(), outSize);
+    }
+    for (int r = 0; r < ndev; ++r) free(S.streams[r]);
+    if (info) {
+        info->devices = ndev; info->used_rccl = S.rccl ? 1 : 0; info->gathered_bytes = S.gathered; info->seconds_total = t1 - t0;
+        double m = 0; for (double t : S.t_compress) if (t > m) m = t;
+        info->seconds_slowest_slab = m;
+    }
+    return out;
+}

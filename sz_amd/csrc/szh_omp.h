@@ -600,7 +600,19 @@ struct szh_omp_tables {
     const unsigned char *hdr; unsigned hdr_len;
     u64 off_ucount, off_first, off_unpred, off_sizes;
     const void *first;
+    int dbg;                           // development: 1 = no verbatim values, 2 = no packing, 4 = no read-out, 8 = no counting pass (wrong streams: timing only)
 };
+// the e-th point after one at (row offset off0, column j0) of a box, e < 64: over the row's end into the next rows / the next plane
+__device__ __forceinline__ int64_t omp_point_off(const szh_omp_geom &g, int64_t off0, int j0, int e)
+{
+    int j = j0 + e; int64_t off = off0;
+    if (j >= g.c2) {                                                // (rare for boxes 32 wide: a thread's 32 codes are one row)
+        // rows are g.d1 apart; after the last row of a plane comes the first of the next: step row by row
+        int i = (int)((off0 % g.d0) / g.d1);
+        while (j >= g.c2) { j -= g.c2; ++i; off += g.d1; if (i == g.c1) { i = 0; off += g.d0 - (int64_t)g.c1 * g.d1; } }
+    }
+    return off + j;
+}
 __device__ __forceinline__ void omp_put_bytes(unsigned char *dst, const void *src, int n) { const unsigned char *q = (const unsigned char *)src; for (int i = 0; i < n; ++i) dst[i] = q[i]; }
 template <class T>
 __global__ __launch_bounds__(256) void k_omp_encode_box3(szh_omp_geom g, const T *__restrict__ data, const uint16_t *__restrict__ codes, const u64 *__restrict__ packed,
@@ -638,7 +650,7 @@ __global__ __launch_bounds__(256) void k_omp_encode_box3(szh_omp_geom g, const T
         if (b == 0) for (unsigned i = tid; i < tb.hdr_len; i += 256) tb.stream[i] = tb.hdr[i];
     }
     auto put_val = [&](u64 rank, T val) {
-        if (tb.stream) omp_put_bytes(tb.stream + tb.off_unpred + rank * sizeof(T), &val, (int)sizeof(T)); else unpred[rank] = val;
+        if (unpred) unpred[rank] = val; else omp_put_bytes(tb.stream + tb.off_unpred + rank * sizeof(T), &val, (int)sizeof(T));
     };
     __syncthreads();                                               // (the table is in LDS)
     for (int r = 0; r < rounds; ++r) {
@@ -666,27 +678,33 @@ __global__ __launch_bounds__(256) void k_omp_encode_box3(szh_omp_geom g, const T
         const unsigned lead = (unsigned)(gbit & 31);
         const unsigned nwords = (lead + tot_bits + 31) >> 5;
         for (unsigned w = tid; w < nwords + 1; w += 256) win[w] = 0;
-        // ---- verbatim values: requested now, stored after the round
-        T vals[4]; unsigned nv = 0;                                 // (a thread with more than four of them takes the slow way below)
-        if (z && z <= 4) {
+        // ---- verbatim values: requested now, stored after the round (they come from HBM: waited for on the spot, every round of the
+        // box's walk would carry a memory round trip).  The thread's 32 codes are consecutive points of the box: (k, i, j) of the first
+        // one by division, the others by stepping; the zero codes as a bit mask
+        unsigned zm = 0;
+        T vals[4]; int nv = 0;                                      // (a thread with more than four of them fetches the rest at the end)
+        int64_t zoff0 = 0; int zj0 = 0;
+        if (z && !(tb.dbg & 1)) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const unsigned wv[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+                if (p0 + k * 8 + 8 <= g.bel)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const unsigned c = (e & 1) ? wv[e >> 1] >> 16 : wv[e >> 1] & 0xffffu;
-                    if (c == 0 && p0 + k * 8 + 8 <= g.bel) {
-                        const int p = p0 + k * 8 + e, kk = p / (g.c1 * g.c2), rr = p - kk * (g.c1 * g.c2), i = rr / g.c2, j = rr - i * g.c2;
-                        const T val = box[(int64_t)kk * g.d0 + (int64_t)i * g.d1 + j];
-                        if (nv == 0) vals[0] = val; else if (nv == 1) vals[1] = val; else if (nv == 2) vals[2] = val; else vals[3] = val;
-                        ++nv;
-                    }
-                }
+                    for (int e = 0; e < 8; ++e) { const unsigned c = (e & 1) ? wv[e >> 1] >> 16 : wv[e >> 1] & 0xffffu; zm |= (c == 0 ? 1u : 0u) << (k * 8 + e); }
+            }
+            const int kk = p0 / (g.c1 * g.c2), rr = p0 - kk * (g.c1 * g.c2), i = rr / g.c2;
+            zj0 = rr - i * g.c2; zoff0 = (int64_t)kk * g.d0 + (int64_t)i * g.d1;
+            unsigned m = zm;
+            for (int q = 0; q < 4 && m; ++q) {
+                const int e = __builtin_ctz(m); m &= m - 1;
+                const T val = box[omp_point_off(g, zoff0, zj0, e)];
+                if (q == 0) vals[0] = val; else if (q == 1) vals[1] = val; else if (q == 2) vals[2] = val; else vals[3] = val;
+                ++nv;
             }
         }
         __syncthreads();
         // ---- pack: acc holds `nb` pending bits (top-aligned at bit nb - 1); a full word leaves as soon as there are 32
-        if (s) {
+        if (s && !(tb.dbg & 2)) {
             const unsigned bitpos = lead + (unsigned)ex2;
             unsigned wpos = bitpos >> 5, nb = bitpos & 31u;
             u64 acc = 0;
@@ -717,31 +735,21 @@ __global__ __launch_bounds__(256) void k_omp_encode_box3(szh_omp_geom g, const T
         }
         __syncthreads();
         const u64 w0 = gbit >> 5;
-        for (unsigned w = tid; w < nwords; w += 256) {
+        if (!(tb.dbg & 4)) for (unsigned w = tid; w < nwords; w += 256) {
             const unsigned x = __builtin_bswap32(win[w]);
             if (w == 0 || w == nwords - 1) { if (x) atomicOr(&out32[w0 + w], x); }
             else out32[w0 + w] = x;
         }
-        if (z) {
+        if (zm) {
             u64 rank = ubase + done_zero + (ex2 >> 32);
-            if (z <= 4) {
-                if (nv > 0) put_val(rank, vals[0]);
-                if (nv > 1) put_val(rank + 1, vals[1]);
-                if (nv > 2) put_val(rank + 2, vals[2]);
-                if (nv > 3) put_val(rank + 3, vals[3]);
-            } else {
-                for (int k = 0; k < 4; ++k) {
-                    const unsigned wv[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
-                    if (p0 + k * 8 + 8 <= g.bel)
-                        for (int e = 0; e < 8; ++e) {
-                            const unsigned c = (e & 1) ? wv[e >> 1] >> 16 : wv[e >> 1] & 0xffffu;
-                            if (c == 0) {
-                                const int p = p0 + k * 8 + e, kk = p / (g.c1 * g.c2), rr = p - kk * (g.c1 * g.c2), i = rr / g.c2, j = rr - i * g.c2;
-                                put_val(rank++, box[(int64_t)kk * g.d0 + (int64_t)i * g.d1 + j]);
-                            }
-                        }
-                }
-            }
+            if (nv > 0) put_val(rank, vals[0]);
+            if (nv > 1) put_val(rank + 1, vals[1]);
+            if (nv > 2) put_val(rank + 2, vals[2]);
+            if (nv > 3) put_val(rank + 3, vals[3]);
+            unsigned m = zm;
+            for (int q = 0; q < 4 && m; ++q) m &= m - 1;
+            rank += 4;
+            while (m) { const int e = __builtin_ctz(m); m &= m - 1; put_val(rank++, box[omp_point_off(g, zoff0, zj0, e)]); }
         }
         done_bits += tot_bits; done_zero += tot >> 32;
         __syncthreads();                                          // the window is read out before the next round clears it

@@ -2666,6 +2666,7 @@ int compress_omp_impl(szhip_ctx *ctx, const void *data, int data_on_device, size
         u64 *hp = (u64 *)(hb + hdr_pad);
         for (unsigned s2 = 0; s2 < intervals; ++s2) hp[s2] = ((tab_code[s2] & (tab_len[s2] >= 64 ? ~0ull : (1ull << tab_len[s2]) - 1)) << 8) | tab_len[s2];
         TRY(ensure(ctx, ctx->code_tab, blob));
+        TRY(ensure(ctx, ctx->unpred, (size_t)E * sizeof(T) + 16));
         HIPCHK(hipMemcpyAsync(ctx->code_tab.p, hb, blob, hipMemcpyHostToDevice, st));
         const u64 *d_packed = (const u64 *)((const unsigned char *)ctx->code_tab.p + hdr_pad);
         hipLaunchKernelGGL(k_omp_layout, dim3(1), dim3(1024), 0, st, g.nb, intervals, (const unsigned *)d_hist_box, d_packed, (const u64 *)d_ucount64, d_box_bytes, d_box_off, d_uoff,
@@ -2673,10 +2674,14 @@ int compress_omp_impl(szhip_ctx *ctx, const void *data, int data_on_device, size
         HIPCHK(hipGetLastError());
         szh_omp_tables tb;
         tb.stream = d_stream; tb.hdr = (const unsigned char *)ctx->code_tab.p; tb.hdr_len = (unsigned)hdr_len;
-        tb.off_ucount = off_ucount; tb.off_first = off_first; tb.off_unpred = off_unpred; tb.off_sizes = off_sizes; tb.first = d_first;
+        tb.off_ucount = off_ucount; tb.off_first = off_first; tb.off_unpred = off_unpred; tb.off_sizes = off_sizes; tb.first = d_first; tb.dbg = tune_int("SZ_HIP_OMP_DBG", 0);
         hipLaunchKernelGGL((k_omp_encode_box3<T>), dim3((unsigned)g.nb), dim3(256), lds3, st, g, d_in, (const uint16_t *)d_codes, d_packed, intervals, maxlen, (const u64 *)d_box_off,
-                           (const u64 *)d_box_bytes, (const u64 *)d_uoff, (const unsigned *)d_ucount, (u64)off_pay * 8, (unsigned *)d_stream, (T *)nullptr, (unsigned *)(sm + SM_ERR), tb);
+                           (const u64 *)d_box_bytes, (const u64 *)d_uoff, (const unsigned *)d_ucount, (u64)off_pay * 8, (unsigned *)d_stream,
+                           (T *)ctx->unpred.p, (unsigned *)(sm + SM_ERR), tb);
         HIPCHK(hipGetLastError());
+        // (the verbatim values go through an aligned buffer: their table lies at whatever byte offset the tree's size gives it, and byte
+        //  stores from the kernel were half of its 0.1 ms for them)
+        if (E > 0) HIPCHK(hipMemcpyAsync(d_stream + off_unpred, ctx->unpred.p, (size_t)E * sizeof(T), hipMemcpyDeviceToDevice, st));
     } else if (lean) {
         TRY(ensure(ctx, ctx->code_tab, (size_t)intervals * 8));
         TRY(ensure(ctx, ctx->len_tab, (size_t)intervals));

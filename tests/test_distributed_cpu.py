@@ -153,7 +153,8 @@ def test_c_slab_container_equals_the_python_one_and_round_trips(oracle):
         L.sz_slab_decompress.argtypes = [ctypes.c_void_p, szt, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(szt * 3)]
         L.sz_slab_bounds.argtypes = [szt, ctypes.c_int, ctypes.c_int, ctypes.POINTER(szt)]
         libc = ctypes.CDLL(None); libc.free.argtypes = [ctypes.c_void_p]
-        for (n0, world, dt, mode, absb, rel) in ((38, 3, np.float32, sz_amd.ABS, 1e-3, 0.0), (25, 2, np.float64, sz_amd.REL, 0.0, 1e-3), (7, 4, np.float32, sz_amd.ABS, 1e-2, 0.0)):
+        for (n0, world, dt, mode, absb, rel) in ((38, 3, np.float32, sz_amd.ABS, 1e-3, 0.0), (25, 2, np.float64, sz_amd.REL, 0.0, 1e-3), (7, 4, np.float32, sz_amd.ABS, 1e-2, 0.0),
+                                                 (24, 2, np.float32, sz_amd.REL, 0.0, 1e-3)):
             whole = s_field(n0, 21, 40, dt)
             bb = (szt * (2 * world))()
             L.sz_slab_bounds(n0, world, 6, bb)
@@ -178,6 +179,27 @@ def test_c_slab_container_equals_the_python_one_and_round_trips(oracle):
             libc.free(q)
             assert float(np.abs(back.astype(np.float64) - whole).max()) <= eb
             assert L.sz_slab_decompress(got[:50], 50, ctypes.byref(dtc), ctypes.byref(dims)) is None     # a truncated container is refused
+            # damaged tables (untrusted input): dimensions whose product wraps, a gap between two slabs, a slab past the end
+            bad = bytearray(got); bad[16:24] = (1 << 60).to_bytes(8, "little")
+            assert L.sz_slab_decompress(bytes(bad), len(bad), ctypes.byref(dtc), ctypes.byref(dims)) is None
+            if world > 1 and bounds[1][1] > bounds[1][0]:
+                bad = bytearray(got); bad[40 + 24:40 + 32] = (bounds[1][0] + 1).to_bytes(8, "little")      # slab 1 now begins a plane late
+                assert L.sz_slab_decompress(bytes(bad), len(bad), ctypes.byref(dtc), ctypes.byref(dims)) is None
+            bad = bytearray(got); bad[40 + 24 * (world - 1) + 8:40 + 24 * (world - 1) + 16] = (n0 + 5).to_bytes(8, "little")
+            assert L.sz_slab_decompress(bytes(bad), len(bad), ctypes.byref(dtc), ctypes.byref(dims)) is None
+            # the multi-device driver (sz_slab_compress_multi: a host thread + context per "device"; the shim has one device, named
+            # `world` times, so the ranges and the sub-streams travel through host memory): the same bytes
+            class Info(ctypes.Structure):
+                _fields_ = [("devices", ctypes.c_int), ("used_rccl", ctypes.c_int), ("gathered_bytes", szt), ("seconds_total", ctypes.c_double), ("seconds_slowest_slab", ctypes.c_double)]
+            L.sz_slab_compress_multi.restype = ctypes.c_void_p
+            L.sz_slab_compress_multi.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(szt), ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, szt, szt, szt,
+                                                 ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(Info)]
+            info = Info(); n2 = szt(0); devs = (ctypes.c_int * world)(*([0] * world))
+            p2 = L.sz_slab_compress_multi(0 if dt == np.float32 else 1, whole.ctypes.data, ctypes.byref(n2), mode, absb, rel, 0.0, *whole.shape, world, devs, ctypes.byref(info))
+            assert p2 and info.devices == world and info.used_rccl == 0
+            got2 = ctypes.string_at(p2, n2.value)
+            libc.free(p2)
+            assert got2 == want
         sz_amd.SZ_Finalize()
     finally:
         api._lib = saved

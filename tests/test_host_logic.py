@@ -41,7 +41,7 @@ def test_library_exports_every_declared_symbol(L):
     # include/sz_slab.h: the slab container of the multi-GPU path for C callers
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "sz_slab.h")).read(), flags=re.S)
     sl = set(re.findall(r"\b(sz_slab_[A-Za-z0-9_]+)\s*\(", text))
-    assert len(sl) == 5
+    assert len(sl) == 6
     for n in sorted(sl):
         assert hasattr(L, n), f"{n} is declared in sz_slab.h but not exported"
 

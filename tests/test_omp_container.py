@@ -6,7 +6,10 @@ against this oracle in tests/test_zz_omp_hip.py; nothing here touches the produc
 Pin: tests/golden/ref_recorded_omp.json -- outputs of the unmodified reference (oracle/_ref/libSZ_omp.so) recorded by
 tools/record_reference_omp.py: the bytes behind the parameter block and the decoded array must match, md5 for md5.  Where that library is
 present (the build container) it is also run live.  Two of the cases carry fill values (1e30) and NaN / -inf: they pin what the x86-64 build of
-the reference does with interval-optimiser quotients beyond the range of `unsigned long`.  float32 only: the reference's double entry point dies with SIGILL in this build."""
+the reference does with interval-optimiser quotients beyond the range of `unsigned long`.  float64 (round 4): the stream is pinned by the
+same sources built at -O1 (oracle/_ref/libSZ_omp_O1.so; at -O3 the double entry point runs off the end of a function and traps); the reference's
+double DECODER cannot read its own streams (it steps over the 4-byte interval count with sizeof(double), sz_omp.c:940-942), so for float64
+the decoded array is the restatement's alone, checked against the bound."""
 import hashlib
 import json
 import os
@@ -36,7 +39,8 @@ def test_oracle_reproduces_recorded_reference_container(oracle, name):
     assert s[:len(meta)] == meta
     assert hashlib.md5(s[len(meta):]).hexdigest() == rec["body_md5"]
     dec = oracle.omp_decompress(s, len(meta), d.shape, d.dtype)
-    assert hashlib.md5(dec.tobytes()).hexdigest() == rec["decoded_md5"]
+    if rec["decoded_md5"] is not None:                       # (float64: the reference has no working decoder to record from)
+        assert hashlib.md5(dec.tobytes()).hexdigest() == rec["decoded_md5"]
     ok = np.isfinite(d)                                       # (the fill-value / NaN cases)
     assert float(np.abs(dec.astype(np.float64) - d.astype(np.float64))[ok].max()) <= rec["eb"]
 
