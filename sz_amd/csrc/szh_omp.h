@@ -408,7 +408,9 @@ __global__ __launch_bounds__(256) void k_omp_hdec(int bel, const unsigned char *
 //                    drops the verbatim values (code 0) into the stream's table on the way (the box's rank table: uoff)
 //   k_omp_hdec_lut   a workgroup per box, the payload staged in LDS, decoded with the multi-symbol look-up table of k_hdec_* (hdec_run_lut)
 // =====================================================================================================================
-__global__ __launch_bounds__(256) void k_omp_hist_box(int bel, const uint16_t *__restrict__ codes, unsigned nbins, int rshift, unsigned *__restrict__ hist_box, unsigned *hist)
+// ucount / ucount64 (or null): the box's count of verbatim values = its bin 0 (when the sweep did not count them, k_omp_col<.., COUNT = false>)
+__global__ __launch_bounds__(256) void k_omp_hist_box(int bel, const uint16_t *__restrict__ codes, unsigned nbins, int rshift, unsigned *__restrict__ hist_box, unsigned *hist,
+                                                      unsigned *ucount, u64 *ucount64)
 {
     SZH_DYN_SMEM(smem);
     unsigned *sh = reinterpret_cast<unsigned *>(smem);
@@ -442,6 +444,7 @@ __global__ __launch_bounds__(256) void k_omp_hist_box(int bel, const uint16_t *_
         for (unsigned r = 0; r < R; ++r) s += sh[(b << rshift) + r];
         hist_box[(int64_t)blockIdx.x * nbins + b] = s;
         if (s) atomicAdd(&hist[b], s);
+        if (b == 0 && ucount) { ucount[blockIdx.x] = s; ucount64[blockIdx.x] = s; }
     }
 }
 // bytes of box b = its bits rounded up (Huffman.c encode: the last byte is padded with zero bits); from the box's histogram ...
@@ -792,6 +795,7 @@ __global__ __launch_bounds__(256) void k_omp_hdec_lut(int bel, const unsigned ch
     const unsigned first = base + (unsigned)tid * sb, limit = first + sb;
     unsigned start = first, endp = first, cnt = 0;
     bool redo = true;
+    // (the warm-up start of k_hdec_pass -- decoding from 128 bits in front of the stretch -- was tried here in round 4: no gain, 0.53 against 0.51 ms)
     for (int round = 0; round < 257; ++round) {
         const bool run = redo && start < limit && start < total;
         if (redo) {

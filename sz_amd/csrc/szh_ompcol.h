@@ -41,6 +41,45 @@ template <class E> __device__ __forceinline__ void lds_put(OC_LDS unsigned char 
 __device__ __forceinline__ v4u lds_get16(OC_LDS unsigned char *base, unsigned off) { return *(OC_LDS v4u *)(base + off); }
 __device__ __forceinline__ void lds_put16(OC_LDS unsigned char *base, unsigned off, v4u v) { *(OC_LDS v4u *)(base + off) = v; }
 __device__ __forceinline__ void order() { asm volatile("" ::: "memory"); }
+#ifdef SZH_HIPSIM
+static inline void pin(unsigned &) {}
+#else
+__device__ __forceinline__ void pin(unsigned &v) { asm volatile("" : "+v"(v)); }
+#endif
+
+// lane masks: which lanes of the wavefront a condition holds in.  On the GPU a compare already IS such a mask (an SGPR pair): AND-ing it
+// with a compile-time mask is a scalar instruction, counting its bits too -- work the vector unit, which bounds this kernel, never sees
+typedef unsigned long long mask_t;
+#ifdef SZH_HIPSIM
+static inline mask_t lane_mask(bool p) { return __ballot(p ? 1 : 0); }
+static inline bool in_mask(mask_t m) { return (m >> (threadIdx.x & 63u)) & 1ull; }
+#else
+__device__ __forceinline__ mask_t lane_mask(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool in_mask(mask_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+#endif
+// lane l receives v of lane l - 1, lane 0 receives +0 (DPP wave_shr:1 with bound_ctrl: no `old` operand to set up, unlike szh_rb::shr1)
+#ifdef SZH_HIPSIM
+template <class T> static inline T shr1z(T v) { const T s = __shfl_up(v, 1, 64); return (threadIdx.x & 63) == 0 ? (T)0 : s; }
+#else
+__device__ __forceinline__ float shr1z(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x138, 0xf, 0xf, true)); }
+__device__ __forceinline__ double shr1z(double v)
+{
+    const long long s = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_mov_dpp((int)s, 0x138, 0xf, 0xf, true), hi = __builtin_amdgcn_mov_dpp((int)(s >> 32), 0x138, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+#endif
+// the lanes whose cell at position U of the unrolled line is REAL: not the virtual one (lane j = U), in the first line not before the
+// lane's first cell (j < U), in the last not after its last (j > U); the same for every box of the wavefront
+template <int PHASE, int U, int C2> constexpr mask_t keep_mask()
+{
+    mask_t one = 0;
+    for (int j = 0; j < C2; ++j) { const bool k = PHASE == 0 ? U > j : PHASE == 1 ? U != j : U < j; if (k) one |= 1ull << j; }
+    mask_t m = 0;
+    for (int b = 0; b < 64 / C2; ++b) m |= one << (b * C2);
+    return m;
+}
+template <int C2> constexpr mask_t first_col_mask() { mask_t m = 0; for (int b = 0; b < 64 / C2; ++b) m |= 1ull << (b * C2); return m; }
 
 constexpr int fdiv(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
 constexpr int fmod(int a, int b) { return a - fdiv(a, b) * b; }
@@ -84,7 +123,10 @@ template <class T> struct sweep_args {
     const unsigned *vflags; int fw;    // inverse: per box `fw` words, bit (row / RPL) = that group of rows holds a verbatim value (k_omp_scatter); fw = 0: none
 };
 
-template <class T, int C1, int C2, int MODE>
+// COUNT (compress): count the verbatim values of every box here (false: the caller takes them from the boxes' histograms, k_omp_hist_box).
+// (Round 4 also tried the histograms themselves in here -- the commonest code counted in a register per lane, the others by LDS atomics of
+// the lanes that have them: 0.29 ms against 0.16 + 0.08 for the separate pass; the atomics and their exec masks sit in every step.  Removed.)
+template <class T, int C1, int C2, int MODE, bool COUNT = true>
 struct sweep {
     typedef shape<T, C1, C2> S;
     static constexpr int LINE = S::LINE, RS = S::RS, PITCH = S::PITCH;
@@ -96,10 +138,14 @@ struct sweep {
     const sweep_args<T> &a;
     int lane, b, j;                    // box of the wavefront, column
     bool use_flags;
-    T dl[LINE], lup[LINE];             // delay lines: own results / the left lane's, by step number modulo LINE
+    // delay lines, by step number modulo LINE: own results / the left lane's.  TWO of each, read and written in turn line by line (PP): with one
+    // array the value a step overwrites is still needed by the next step, and the compiler bridges that with two register copies per step
+    // (only where the registers allow two wavefronts per SIMD with them: float compression; elsewhere ONE array and the copies)
+    static constexpr bool PPONG = CMP && sizeof(T) == 4;
+    T dl[PPONG ? 2 : 1][LINE], lup[PPONG ? 2 : 1][LINE];
     T prev, Lprev, Bold, Bpold;
     T first_v;
-    unsigned nun;                      // M_CMP: verbatim values of this column; inverse: zero codes met without a verbatim value
+    unsigned nun;                      // M_CMP (COUNT): verbatim values of this column; inverse: zero codes met without a verbatim value
     unsigned vaddr, cdelta;            // LDS: the lane's value in the slot it is at; from there to its code
     v4u gv[S::DV], gc[S::DC], wq;      // loads in flight; rows on their way out
     T cur_next; unsigned tc_next;      // the next step's value / code, read from the ring a step ahead
@@ -117,6 +163,12 @@ struct sweep {
         unsigned x = (unsigned)ls + i1;                  // < 2 RS + 16 (RS > LINE)
         x -= x >= (unsigned)(2 * RS) ? (unsigned)(2 * RS) : x >= (unsigned)RS ? (unsigned)RS : 0u;
         return x * (unsigned)PITCH;
+    }
+    // the value part of the slot of a line's virtual cell (`ls` = (LINE * L) mod RS): zeros, 16 bytes per lane
+    __device__ __forceinline__ void zero_virtual(int ls)
+    {
+        const v4u z = {0u, 0u, 0u, 0u};
+        if (lane < S::VB / 16) lds_put16(ring, (unsigned)ls * (unsigned)PITCH + (unsigned)lane * 16u, z);
     }
     __device__ __forceinline__ int clampL(int L) const { return L < a.g.c0 ? L : a.g.c0 - 1; }
     __device__ __forceinline__ v4u load_vrows(int L, int e) const
@@ -168,6 +220,7 @@ struct sweep {
             if constexpr (fmod(d, LINE) == U) {
                 constexpr int loff = -fdiv(d, LINE);                 // 0 or +1
                 lds_put16(ring, slot_off(ls_of(loff), (unsigned)(S::RPL * e + 1) + ev_r) + vev_lds, gv[e % S::DV]);
+                if constexpr (e == 0) zero_virtual(ls_of(loff));     // (with the line's first rows: its virtual cell reads +0)
                 constexpr int en = (e + S::DV) % S::EVL, ln = (e + S::DV) / S::EVL;
                 gv[e % S::DV] = load_vrows(it + loff + ln, en);
             }
@@ -184,11 +237,12 @@ struct sweep {
 
     __device__ __forceinline__ static T tabs(T v) { return sizeof(T) == 8 ? (T)__builtin_fabs((double)v) : (T)__builtin_fabsf((float)v); }
 
+    __device__ __forceinline__ static T tsign(T mag, T from) { return sizeof(T) == 8 ? (T)__builtin_copysign((double)mag, (double)from) : (T)__builtin_copysignf((float)mag, (float)from); }
+
     // ---- one step: the cell the lane is at (position U - j of the line, modulo LINE)
-    template <int U, int PHASE> __device__ __forceinline__ void step(int radius, T fint)
+    template <int U, int PHASE, int PP> __device__ __forceinline__ void step(int radius, T fint)
     {
-        // the cell is real (not the virtual one, not before the lane's first / after its last)
-        const bool keep = PHASE == PH_FIRST ? U > j : PHASE == PH_MID ? U != j : U < j;
+        constexpr mask_t KM = keep_mask<PHASE, U, C2>();            // the lanes whose cell is real
         // what the NEXT step needs from the ring is requested now (a read and its use in the same step: a wait for the LDS in every step)
         const unsigned y = vaddr + (unsigned)PITCH, y2 = y - (unsigned)(RS * PITCH);
         const unsigned vnext = y < y2 ? y : y2;
@@ -196,55 +250,62 @@ struct sweep {
         const unsigned tc_in = tc_next;
         if (CMP || MODE == M_DECV) cur_next = lds_get<T>(ring, vnext);
         if (!CMP) tc_next = lds_get<uint16_t>(ring, vnext + cdelta);
-        const T cur = keep ? cur_raw : (T)0;                          // (a virtual cell: +0 whatever happens below)
-        const T Lraw = szh_rb::shr1((T)0, prev);
-        const T L = (S::NB > 1 && j == 0) ? (T)0 : Lraw;
-        const T B = dl[U], Bp = lup[U];
-        T pred = L + prev + B - Lprev - Bold - Bp + Bpold;          // sz_float.c:4939-4943: the 7-point sum, left to right
+        // (a virtual cell reads +0: the loader zeroes its slot.  Only in the first line are there lanes that have not started: forced)
+        const T cur = PHASE == PH_FIRST ? (in_mask(KM) ? cur_raw : (T)0) : cur_raw;
+        const T Lraw = shr1z(prev);
+        const T L = S::NB > 1 ? (in_mask(first_col_mask<C2>()) ? (T)0 : Lraw) : Lraw;
+        // (k-1, i, *) and (k-1, i-1, *): what this lane / the left one had at this position and at the one before, a line ago (position -1: the
+        // last of the line before that one, which is the OTHER array's last entry -- written one line earlier still, i.e. by this array's turn)
+        constexpr int RD = PPONG ? PP : 0, WR = PPONG ? PP ^ 1 : 0;
+        const T B = dl[RD][U], Bp = lup[RD][U];
+        const T C = !PPONG ? Bold : U > 0 ? dl[RD][U > 0 ? U - 1 : 0] : dl[WR][LINE - 1], Cp = !PPONG ? Bpold : U > 0 ? lup[RD][U > 0 ? U - 1 : 0] : lup[WR][LINE - 1];
+        T pred = L + prev + B - Lprev - C - Bp + Cp;                // sz_float.c:4939-4943: the 7-point sum, left to right
         if (PHASE == PH_FIRST) {
             // row (0, 0, :) (sz_float.c:4738-4799): the box's first value, then its left neighbour, then 2 left - left-left
-            const T LL = szh_rb::shr1((T)0, Lprev);
+            const T LL = shr1z(Lprev);
             if (U == j + 1) pred = j == 0 ? first_v : j == 1 ? L : 2 * L - LL;
         }
         T rec;
         if (CMP) {
-            // sz_float.c:4762-4783: itv = |diff| / eb + 1 against the interval count; code = (int)(+-itv / 2) + radius; reconstruction
-            // pred + 2 (code - radius) eb, verified against the bound.  The truncation is symmetric, so the sign goes on AFTER it:
-            // (int)(-itv / 2) = -(int)(itv / 2), (float)(-2 q) eb = -((float)(2 q) eb), pred + (-m) = pred - m -- bit for bit.
+            // sz_float.c:4762-4783: itv = |diff| / eb + 1 against the interval count, negated for a negative diff; code = (int)(itv / 2) + radius;
+            // reconstruction pred + 2 (code - radius) eb, verified against the bound.  (The sign comes from diff's sign BIT: for diff = -0 --
+            // where the reference's `diff < 0` is false -- itv is -1, (int)(-0.5) is 0 as for +1: the same code, the same +0 added.)
             const T diff = cur - pred;
-            const bool neg = diff < 0;
             const T mag = tabs(diff) * a.recip + 1;
             const bool in_range = mag < fint;                         // (false for a NaN)
-            const int q = (int)(mag / 2);                             // (out of range: never used)
-            const T m = (T)(2 * q) * a.eb;
-            const T r = pred + (neg ? -m : m);
+            const int q = (int)(tsign(mag, diff) / 2);                // (out of range: never used)
+            const T r = pred + (T)(2 * q) * a.eb;
             const T err = cur - r;
-            const bool ok = in_range && !(tabs(err) > a.eb) && keep;
-            const int tc = ok ? radius + (neg ? -q : q) : 0;
+            const mask_t okm = lane_mask(in_range) & lane_mask(!(tabs(err) > a.eb)) & KM;     // (two compares, two scalar ANDs: a `&&` of them goes through a vector register)
+            const bool ok = in_mask(okm);
+            const int tc = ok ? q + radius : 0;
             rec = ok ? r : cur;
-            nun += (keep && !ok) ? 1u : 0u;
+            if (COUNT) { nun += in_mask(~okm & KM) ? 1u : 0u; pin(nun); }     // real cells kept verbatim (per lane: scalar pop-counts here cost 200 spilled SGPRs)
             lds_put<uint16_t>(ring, vaddr + cdelta, (uint16_t)tc);
         } else {
             const T m = (T)(2 * ((int)tc_in - radius)) * a.eb;        // szd_float.c: pred + 2 (type - radius) eb
             const T r = pred + m;
             const T verb = MODE == M_DECV ? cur : (T)0;
-            rec = (tc_in != 0 && keep) ? r : verb;
-            if (MODE == M_DEC) nun += (keep && tc_in == 0) ? 1u : 0u;   // a zero code in a box whose table entry says "no verbatim values"
+            const mask_t cm = lane_mask(tc_in != 0);
+            rec = in_mask(cm & KM) ? r : verb;
+            if (MODE == M_DEC) nun += in_mask(~cm & KM) ? 1u : 0u;    // a zero code in a box whose table entry says "no verbatim values"
+            if (PHASE == PH_FIRST && MODE != M_DECV) rec = in_mask(KM) ? rec : (T)0;     // (M_DECV: `verb` is already +0 there)
             lds_put<T>(ring, vaddr, rec);
         }
-        dl[U] = rec; lup[U] = L;
-        Bold = B; Bpold = Bp; Lprev = L; prev = rec;
+        dl[WR][U] = rec; lup[WR][U] = L;
+        if (!PPONG) { Bold = B; Bpold = Bp; }
+        Lprev = L; prev = rec;
         vaddr = vnext;
     }
 
-    template <int PHASE> __device__ __forceinline__ void line(int it, int ls_m1, int ls_0, int ls_p1, int radius, T fint)
+    template <int PHASE, int PP> __device__ __forceinline__ void line(int it, int ls_m1, int ls_0, int ls_p1, int radius, T fint)
     {
         for_n<LINE>([&](auto UU) {
             constexpr int U = decltype(UU)::value;
             wave_sync();
             events<U, PHASE>(it, ls_m1, ls_0, ls_p1);
             order();
-            step<U, PHASE>(radius, fint);
+            step<U, PHASE, PP>(radius, fint);
             order();
         });
     }
@@ -272,7 +333,7 @@ struct sweep {
                 wave_sync();
             }
         }
-        for_n<LINE>([&](auto UU) { constexpr int U = decltype(UU)::value; dl[U] = 0; lup[U] = 0; });
+        for_n<LINE>([&](auto UU) { constexpr int U = decltype(UU)::value; dl[0][U] = 0; lup[0][U] = 0; if (PPONG) { dl[PPONG ? 1 : 0][U] = 0; lup[PPONG ? 1 : 0][U] = 0; } });
         prev = 0; Lprev = 0; Bold = 0; Bpold = 0; nun = 0;
         first_v = CMP ? *reinterpret_cast<const T *>(origin) : a.first[box];
         vaddr = (unsigned)(((RS - j) % RS) * PITCH + b * S::ROWB + j * (int)sizeof(T));
@@ -286,6 +347,7 @@ struct sweep {
             constexpr int e = decltype(E)::value;
             if constexpr (S::dvw(e, KV) < 0) {
                 lds_put16(ring, slot_off(0, (unsigned)(S::RPL * e + 1) + ev_r) + vev_lds, gv[e % S::DV]);
+                if constexpr (e == 0) zero_virtual(0);
                 gv[e % S::DV] = load_vrows((e + S::DV) / S::EVL, (e + S::DV) % S::EVL);
             }
         });
@@ -299,33 +361,36 @@ struct sweep {
         { const v4u z = {0u, 0u, 0u, 0u}; wq = z; }
         // ---- the lines: lane 0 is on line `it`, lane j on it or on the one before
         int ls_m1 = (RS - LINE % RS) % RS, ls_0 = 0, ls_p1 = LINE % RS;
-        line<PH_FIRST>(0, ls_m1, ls_0, ls_p1, radius, fint);
-        for (int it = 1; it < g.c0; ++it) {
-            ls_m1 = ls_0; ls_0 = ls_p1; ls_p1 = (ls_p1 + LINE) % RS;
-            line<PH_MID>(it, ls_m1, ls_0, ls_p1, radius, fint);
+        auto next = [&]() { ls_m1 = ls_0; ls_0 = ls_p1; ls_p1 = (ls_p1 + LINE) % RS; };
+        line<PH_FIRST, 0>(0, ls_m1, ls_0, ls_p1, radius, fint);
+        int it = 1;
+        for (; it + 1 < g.c0; it += 2) {                           // lines in pairs: the delay-line arrays change roles line by line
+            next(); line<PH_MID, 1>(it, ls_m1, ls_0, ls_p1, radius, fint);
+            next(); line<PH_MID, 0>(it + 1, ls_m1, ls_0, ls_p1, radius, fint);
         }
-        ls_m1 = ls_0; ls_0 = ls_p1; ls_p1 = (ls_p1 + LINE) % RS;
-        line<PH_LAST>(g.c0, ls_m1, ls_0, ls_p1, radius, fint);
+        if (it < g.c0) {
+            next(); line<PH_MID, 1>(it, ls_m1, ls_0, ls_p1, radius, fint);
+            next(); line<PH_LAST, 0>(g.c0, ls_m1, ls_0, ls_p1, radius, fint);
+        } else { next(); line<PH_LAST, 1>(g.c0, ls_m1, ls_0, ls_p1, radius, fint); }
         // ---- per box: the count of verbatim values, the first value (sz_omp.c:246-262 writes both tables into the stream)
         unsigned tot = nun;
         for (int m = 1; m < C2; m <<= 1) tot += __shfl_xor(tot, m, 64);
-        if (CMP) { if (j == 0) { a.ucount[box] = tot; a.ucount64[box] = tot; a.first[box] = first_v; } }
-        else if (MODE == M_DEC) { if (j == 0 && tot) atomicAdd(a.ucount, 1u); }
+        if (CMP) { if (j == 0) { if (COUNT) { a.ucount[box] = tot; a.ucount64[box] = tot; } a.first[box] = first_v; } }
     }
 };
 
 } // namespace szh_oc
 
 // One wavefront per 64 / C2 boxes.  DEC: the wavefront looks its boxes up in `uoff` and runs the variant with or without verbatim values.
-template <class T, int C1, int C2, bool DEC>
-__global__ __launch_bounds__(64) void k_omp_col(szh_oc::sweep_args<T> a)
+template <class T, int C1, int C2, bool DEC, bool COUNT = true>
+__global__ __launch_bounds__(64, (sizeof(T) == 4 ? 2 : 1)) void k_omp_col(szh_oc::sweep_args<T> a)      // (float: two wavefronts per SIMD -- the register budget the compiler must keep)
 {
     typedef szh_oc::shape<T, C1, C2> S;
     __shared__ __attribute__((aligned(16))) unsigned char ring_raw[S::RS * S::PITCH];
     __shared__ unsigned flags_raw[DEC ? S::NB * OC_FLAG_WORDS : 1];
     OC_LDS unsigned char *ring = (OC_LDS unsigned char *)ring_raw;
     OC_LDS unsigned *fl = (OC_LDS unsigned *)flags_raw;
-    if (!DEC) { szh_oc::sweep<T, C1, C2, szh_oc::M_CMP> s(ring, fl, a); s.run(); }
+    if (!DEC) { szh_oc::sweep<T, C1, C2, szh_oc::M_CMP, COUNT> s(ring, fl, a); s.run(); }
     else {
         const int b0 = (int)blockIdx.x * S::NB;
         const bool verb = a.uoff[b0 + S::NB] != a.uoff[b0];          // (uniform)

@@ -2576,12 +2576,18 @@ int compress_omp_impl(szhip_ctx *ctx, const void *data, int data_on_device, size
     unsigned *d_ucount = (unsigned *)ctx->zcnt.p; T *d_first = (T *)ctx->samples.p;
     u64 *d_ucount64 = (u64 *)ctx->col_zeros64.p, *d_uoff = (u64 *)ctx->col_off.p;
     const int rows = g.c0 * g.c1, box_threads = rows;      // one lane per row
+    const bool lean = tune_int("SZ_HIP_OMP_LEAN", 1) != 0;                     // (0: the entropy stage of round 3, kept for comparison)
+    const bool box_hist = lean && intervals <= 1024 && (size_t)g.nb * intervals * 4 <= ((size_t)64 << 20) && g.bel % 8 == 0;
+    bool sweep_counted = true;
     HIPCHK(hipEventRecord(ctx->ev[2], st));
     if (omp_col_applies(g, d_in, r2 * sizeof(T))) {        // the column-per-lane sweep (szh_ompcol.h): a wavefront per pair of boxes
         szh_oc::sweep_args<T> oa;
         oa.g = g; oa.data = d_in; oa.out = nullptr; oa.eb = eb; oa.recip = (T)(1 / eb); oa.intervals = (int)intervals; oa.codes = d_codes;
         oa.ucount = d_ucount; oa.ucount64 = d_ucount64; oa.first = d_first; oa.uoff = nullptr; oa.vflags = nullptr; oa.fw = 0;
-        hipLaunchKernelGGL((k_omp_col<T, 32, 32, false>), dim3((unsigned)(g.nb / 2)), dim3(64), 0, st, oa);
+        // (with a histogram per box coming anyway, the boxes' counts of verbatim values are its bins 0: the sweep leaves the counting out --
+        //  two vector instructions per step of a kernel that is bound by exactly those)
+        if (box_hist) { sweep_counted = false; hipLaunchKernelGGL((k_omp_col<T, 32, 32, false, false>), dim3((unsigned)(g.nb / 2)), dim3(64), 0, st, oa); }
+        else hipLaunchKernelGGL((k_omp_col<T, 32, 32, false, true>), dim3((unsigned)(g.nb / 2)), dim3(64), 0, st, oa);
     } else if (g.vec) hipLaunchKernelGGL((k_omp_box<T, false, true>), dim3((unsigned)g.nb), dim3((unsigned)box_threads), (size_t)4 * g.c0 * g.pitch * sizeof(T), st, g, d_in, (T *)nullptr, eb, (T)(1 / eb),
                                   (int)intervals, d_codes, d_ucount, d_ucount64, d_first, (const T *)nullptr, (const u64 *)nullptr);
     else hipLaunchKernelGGL((k_omp_box<T, false, false>), dim3((unsigned)g.nb), dim3((unsigned)box_threads), (size_t)4 * g.c0 * g.pitch * sizeof(T), st, g, d_in, (T *)nullptr, eb, (T)(1 / eb),
@@ -2597,15 +2603,14 @@ int compress_omp_impl(szhip_ctx *ctx, const void *data, int data_on_device, size
     TRY(ensure_pinned(ctx, (size_t)intervals * 4 + 64));
     unsigned *h_hist = (unsigned *)ctx->pinned;
     HIPCHK(hipMemsetAsync(d_hist, 0, (size_t)intervals * 4, st));
-    const bool lean = tune_int("SZ_HIP_OMP_LEAN", 1) != 0;                     // (0: the entropy stage of round 3, kept for comparison)
-    const bool box_hist = lean && intervals <= 1024 && (size_t)g.nb * intervals * 4 <= ((size_t)64 << 20) && g.bel % 8 == 0;
     unsigned *d_hist_box = nullptr;
     if (box_hist) {
         TRY(ensure(ctx, ctx->chunk_bits, (size_t)g.nb * intervals * 4));
         d_hist_box = (unsigned *)ctx->chunk_bits.p;
         int rshift = 0;
         while ((intervals << (rshift + 1)) <= 8192u && rshift < 6) ++rshift;
-        hipLaunchKernelGGL(k_omp_hist_box, dim3((unsigned)g.nb), dim3(256), ((size_t)intervals << rshift) * 4, st, g.bel, (const uint16_t *)d_codes, intervals, rshift, d_hist_box, d_hist);
+        hipLaunchKernelGGL(k_omp_hist_box, dim3((unsigned)g.nb), dim3(256), ((size_t)intervals << rshift) * 4, st, g.bel, (const uint16_t *)d_codes, intervals, rshift, d_hist_box, d_hist,
+                           sweep_counted ? (unsigned *)nullptr : d_ucount, sweep_counted ? (u64 *)nullptr : d_ucount64);
         HIPCHK(hipGetLastError());
     } else {
         int rshift = 0; int use_lds = intervals <= 16384;
