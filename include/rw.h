@@ -14,6 +14,11 @@ double *readDoubleData(char *srcFilePath, size_t *nbEle, int *status);
 void writeByteData(unsigned char *bytes, size_t byteLength, char *tgtFilePath, int *status);
 void writeFloatData_inBytes(float *data, size_t nbEle, char *tgtFilePath, int *status);
 void writeDoubleData_inBytes(double *data, size_t nbEle, char *tgtFilePath, int *status);
+/* the text-file helpers of the reference's command-line tool (sz/include/rw.h; sz/src/rw.c:22, :796, :818, :989) */
+int checkFileExistance(char *filePath);
+void writeFloatData(float *data, size_t nbEle, char *tgtFilePath, int *status);
+void writeDoubleData(double *data, size_t nbEle, char *tgtFilePath, int *status);
+void writeStrings(int nbStr, char *str[], char *tgtFilePath, int *status);
 #ifdef __cplusplus
 }
 #endif

@@ -182,6 +182,11 @@ void *SZ_decompress(int dataType, unsigned char *bytes, size_t byteLength, size_
 size_t SZ_decompress_args(int dataType, unsigned char *bytes, size_t byteLength, void* decompressed_array, size_t r5, size_t r4, size_t r3, size_t r2, size_t r1);
 
 sz_metadata* SZ_getMetadata(unsigned char* bytes);
+/* what the reference's command-line tool (example/sz.c:498-845) calls next to the API: sz.c:768, utility.c:156, :216, :236 */
+void SZ_printMetadata(sz_metadata* metadata);
+int is_lossless_compressed_data(unsigned char* compressedBytes, size_t cmpSize);
+uint64_t sz_lossless_decompress65536bytes(int losslessCompressor, unsigned char* compressBytes, uint64_t cmpSize, unsigned char** oriData);
+void* detransposeData(void* data, int dataType, size_t r5, size_t r4, size_t r3, size_t r2, size_t r1);
 void SZ_Finalize(void);
 
 void convertSZParamsToBytes(sz_params* params, unsigned char* result);

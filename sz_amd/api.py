@@ -280,10 +280,13 @@ class HipPool:
         return t.value
 
     def wait(self, ticket):
-        """Returns (size, stats); raises if the call failed."""
+        """Returns (size, stats); raises if the call failed.  SZHIP_CONSTANT (1: the array lies within the bound of one value -- the caller
+        writes the reference's constant stream, as SZ_compress_args does) is a result, not a failure: size 0, stats with the range."""
         out = ctypes.c_void_p(); n = ctypes.c_size_t(0); st = szhip_stats()
         rc = lib().szhip_pool_wait(self._h, ticket, ctypes.byref(out), ctypes.byref(n), ctypes.byref(st))
         self._keep.pop(ticket, None)
+        if rc == 1:
+            return 0, st
         if rc != 0:
             raise SZError(f"pooled szhip_compress failed ({rc})")
         return n.value, st

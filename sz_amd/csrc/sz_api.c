@@ -599,6 +599,91 @@ static int is_zlib_format(unsigned char m1, unsigned char m2) /* callZlib.c:30-4
     return 0;
 }
 
+/* ---- the helpers the reference's command-line tool (example/sz.c) calls next to the API, so that it links against this library unchanged ---- */
+/* utility.c:156-172: which lossless back end wrapped the stream (zstd frame -> ZSTD_COMPRESSOR, zlib header -> GZIP_COMPRESSOR), -1 for none */
+int is_lossless_compressed_data(unsigned char *compressedBytes, size_t cmpSize)
+{
+    if (!compressedBytes || cmpSize < 2) return -1;
+    if (cmpSize >= 4 && zstd_load() && g_zstd.fcs(compressedBytes, cmpSize) != (unsigned long long)-2) return ZSTD_COMPRESSOR;   /* != ZSTD_CONTENTSIZE_ERROR */
+    if (is_zlib_format(compressedBytes[0], compressedBytes[1])) return GZIP_COMPRESSOR;
+    return -1;
+}
+/* utility.c:216-234: the first 65536 bytes of the wrapped stream (its header is all `sz -p` wants), zero-filled behind what there is.  The
+ * reference inflates / decompresses INTO a 64 KiB buffer and stops; here the frame is decompressed whole and cut (same bytes). */
+uint64_t sz_lossless_decompress65536bytes(int losslessCompressor, unsigned char *compressBytes, uint64_t cmpSize, unsigned char **oriData)
+{
+    if (!oriData) return 0;
+    *oriData = (unsigned char *)calloc(65536, 1);
+    if (!*oriData || !compressBytes) return 0;
+    unsigned char *full = NULL; size_t n = 0;
+    if (losslessCompressor == ZSTD_COMPRESSOR && zstd_load()) {
+        const unsigned long long fcs = g_zstd.fcs(compressBytes, cmpSize);
+        if (fcs < ((unsigned long long)1 << 40) && (full = (unsigned char *)malloc(fcs ? (size_t)fcs : 1)) != NULL) {
+            const size_t got = g_zstd.decompress(full, (size_t)fcs, compressBytes, cmpSize);
+            n = g_zstd.iserr(got) ? 0 : got;
+        }
+    } else if (losslessCompressor == GZIP_COMPRESSOR && zlib_load()) {
+        unsigned long cap = 65536 * 4;                              /* grows until the whole stream fits or the front is out */
+        for (int tries = 0; tries < 24 && !n; ++tries, cap *= 4) {
+            free(full); full = (unsigned char *)malloc(cap);
+            if (!full) break;
+            unsigned long got = cap;
+            const int zr = g_zlib.uncompress(full, &got, compressBytes, (unsigned long)cmpSize);
+            if (zr == 0) n = got; else if (zr != -5) break;          /* Z_BUF_ERROR: a larger buffer */
+        }
+    } else printf("Error: Unrecognized lossless compressor\n");
+    if (full && n) memcpy(*oriData, full, n < 65536 ? n : 65536);
+    free(full);
+    return 65536;
+}
+/* sz.c:768-...: print what SZ_getMetadata found */
+void SZ_printMetadata(sz_metadata *metadata)
+{
+    if (!metadata || !metadata->conf_params) return;
+    const sz_params *p = metadata->conf_params;
+    printf("=================SZ Compression Meta Data=================\n");
+    printf("Version:                        \t %d.%d.%d\n", metadata->versionNumber[0], metadata->versionNumber[1], metadata->versionNumber[2]);
+    printf("Constant data?:                 \t %s\n", metadata->isConstant == 1 ? "YES" : "NO");
+    printf("Lossless?:                      \t %s\n", metadata->isLossless == 1 ? "YES" : "NO");
+    printf("Size type (size of # elements): \t %d bytes\n", metadata->sizeType);
+    printf("Num of elements:                \t %zu\n", metadata->dataSeriesLength);
+    printf("compressor Name: \t\t\t %s\n", p->sol_ID == SZ ? "SZ" : p->sol_ID == SZ_Transpose ? "SZ_Transpose" : "Other compressor");
+    if (p->dataType == SZ_FLOAT) printf("Data type:                      \t FLOAT\nmin value of raw data:          \t %f\nmax value of raw data:          \t %f\n", p->fmin, p->fmax);
+    else if (p->dataType == SZ_DOUBLE) printf("Data type:                      \t DOUBLE\nmin value of raw data:          \t %f\nmax value of raw data:          \t %f\n", p->dmin, p->dmax);
+    else printf("Data type:                      \t %d (outside the MI355X build)\n", p->dataType);
+    if (exe_params && exe_params->optQuantMode == 1) {
+        printf("quantization_intervals:         \t 0\n");
+        printf("max_quant_intervals:            \t %u\n", p->max_quant_intervals);
+        printf("actual used # intervals:        \t %d\n", metadata->defactoNBBins);
+    } else printf("quantization_intervals:         \t %u\n", p->quantization_intervals);
+    printf("dataEndianType (prior raw data):\t %s\n", dataEndianType == BIG_ENDIAN_DATA ? "BIG_ENDIAN" : "LITTLE_ENDIAN");
+    printf("sysEndianType (at compression): \t %s\n", sysEndianType == 1 ? "BIG_ENDIAN" : "LITTLE_ENDIAN");
+    printf("sampleDistance:                 \t %d\n", p->sampleDistance);
+    printf("predThreshold:                  \t %f\n", p->predThreshold);
+    printf("szMode:                         \t %s\n", p->szMode == SZ_BEST_SPEED ? "SZ_BEST_SPEED (without Gzip)" : p->szMode == SZ_BEST_COMPRESSION ? "SZ_BEST_COMPRESSION (with Zstd or Gzip)" : "SZ_DEFAULT_COMPRESSION");
+    static const char *modes[] = {"ABS", "REL", "ABS_AND_REL", "ABS_OR_REL", "PSNR", "NORM", "", "", "", "", "PW_REL", "ABS_AND_PW_REL", "ABS_OR_PW_REL", "REL_AND_PW_REL", "REL_OR_PW_REL"};
+    printf("errBoundMode:                   \t %s\n", p->errorBoundMode >= 0 && p->errorBoundMode < 15 ? modes[p->errorBoundMode] : "?");
+    printf("absErrBound:                    \t %g\nrelBoundRatio:                  \t %g\npw_relBoundRatio:               \t %g\n", p->absErrBound, p->relBoundRatio, p->pw_relBoundRatio);
+}
+/* utility.c:236-...: the inverse of the SZ_Transpose solution's axis swap (the reference's tool calls it only for sol_ID = SZ_Transpose, which this
+ * build refuses at SZ_Init; kept for the link and for callers that use it on their own): element s of the input, read in the loop order below,
+ * lands at the transposed index */
+void *detransposeData(void *data, int dataType, size_t r5, size_t r4, size_t r3, size_t r2, size_t r1)
+{
+    const size_t len = computeDataLength(r5, r4, r3, r2, r1), esz = dataType == SZ_DOUBLE ? 8 : 4;
+    const int dim = computeDimension(r5, r4, r3, r2, r1);
+    if ((dataType != SZ_FLOAT && dataType != SZ_DOUBLE) || !data) { printf("Error: Unsupported Datatype by Transpose data\n"); return NULL; }
+    unsigned char *o = (unsigned char *)malloc(len * esz != 0 ? len * esz : 1);
+    const unsigned char *in = (const unsigned char *)data;
+    if (!o) return NULL;
+    size_t s = 0;
+    if (dim <= 1 || dim > 4) memcpy(o, in, len * esz);
+    else if (dim == 2) { for (size_t i = 0; i < r2; i++) for (size_t j = 0; j < r1; j++, s++) memcpy(o + (j * r2 + i) * esz, in + s * esz, esz); }
+    else if (dim == 3) { const size_t B = r1 * r2; for (size_t i = 0; i < r2; i++) for (size_t j = 0; j < r1; j++) for (size_t k = 0; k < r3; k++, s++) memcpy(o + (k * B + i * r1 + j) * esz, in + s * esz, esz); }
+    else { const size_t C = r2 * r1, B = r3 * C; for (size_t i = 0; i < r3; i++) for (size_t j = 0; j < r2; j++) for (size_t k = 0; k < r1; k++) for (size_t w = 0; w < r4; w++, s++) memcpy(o + (w * B + i * C + j * r1 + k) * esz, in + s * esz, esz); }
+    return o;
+}
+
 static void *decompress_fp(int dataType, unsigned char *cmpBytes, size_t cmpSize, size_t r5, size_t r4, size_t r3, size_t r2, size_t r1)
 {
     const size_t esz = dataType == SZ_FLOAT ? 4 : 8;

@@ -2,6 +2,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 #include "sz.h"
 #include "rw.h"
 
@@ -72,4 +73,28 @@ void writeFloatData_inBytes(float *data, size_t nbEle, char *tgtFilePath, int *s
 void writeDoubleData_inBytes(double *data, size_t nbEle, char *tgtFilePath, int *status)
 {
     writeByteData((unsigned char *)data, nbEle * sizeof(double), tgtFilePath, status);
+}
+
+/* the text-file helpers of the reference's tool (rw.c:22-31, :796-838, :989-1009): one value per line, "%.30G" / "%.20G" */
+int checkFileExistance(char *filePath) { return filePath && access(filePath, F_OK) != -1 ? 1 : 0; }
+void writeFloatData(float *data, size_t nbEle, char *tgtFilePath, int *status)
+{
+    FILE *f = fopen(tgtFilePath, "wb");
+    if (!f) { printf("Failed to open input file. 3\n"); *status = SZ_FERR; return; }
+    for (size_t i = 0; i < nbEle; i++) fprintf(f, "%.30G\n", data[i]);
+    fclose(f); *status = SZ_SCES;
+}
+void writeDoubleData(double *data, size_t nbEle, char *tgtFilePath, int *status)
+{
+    FILE *f = fopen(tgtFilePath, "wb");
+    if (!f) { printf("Failed to open input file. 3\n"); *status = SZ_FERR; return; }
+    for (size_t i = 0; i < nbEle; i++) fprintf(f, "%.20G\n", data[i]);
+    fclose(f); *status = SZ_SCES;
+}
+void writeStrings(int nbStr, char *str[], char *tgtFilePath, int *status)
+{
+    FILE *f = fopen(tgtFilePath, "wb");
+    if (!f) { printf("Failed to open input file. 3\n"); *status = SZ_FERR; return; }
+    for (int i = 0; i < nbStr; i++) fprintf(f, "%s\n", str[i]);
+    fclose(f); *status = SZ_SCES;
 }

@@ -39,6 +39,8 @@ static std::atomic<int> g_compress_calls{0};
 struct compress_call_guard { compress_call_guard() { g_compress_calls.fetch_add(1); } ~compress_call_guard() { g_compress_calls.fetch_sub(1); } };
 struct szhip_ctx {
     int device = 0;
+    int fast_stat_per_cu[2] = {0, 0}, fast_pack_per_cu[2] = {0, 0};   // resident workgroups per CU of the fast mode's persistent kernels (float, double)
+    int cus = 256;                               // compute units of `device` (hipDeviceAttributeMultiprocessorCount): persistent kernels launch one workgroup per CU at most
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // the fit + selection pass runs here, concurrently with the interval optimiser's sampling and host decisions
     hipEvent_t ev_in = nullptr, ev_fit = nullptr;
@@ -354,7 +356,13 @@ int launch_ribbon(szhip_ctx *ctx, const szh_geom3 &G, szh_qargs<T> a, hipStream_
     // persistent workgroups (k_ribbon): no more than one per CU, or the ticket order could wait for a workgroup that is not resident.
     // A lone context takes every CU (512^3: sweep 1.02 ms with 256 workgroups, 1.18 with 96); a lane of a pool leaves half of them to
     // the other lanes' kernels (two arrays in flight, 40-step runs: 324 GB/s with 256, 351 - 354 with 128 or 112, 346 with 96, 326 with 64)
-    const unsigned wgs = (unsigned)std::min<size_t>(tiles, (size_t)std::max(1, std::min(tune_int("SZ_HIP_RB_WGS", ctx->gate ? 128 : 256), 256)));
+    // (the device's own CU count, not 256: on a smaller or partitioned GPU workgroups beyond it would not be resident and every call would
+    //  run into the wait bound before the atomic-ticket repetition took over)
+#ifdef SZH_SYNC_LAUNCH
+    const unsigned wgs = (unsigned)tiles;      // (the CPU shim runs workgroups one after the other: a workgroup per tile, or the first would wait for tiles of the second)
+#else
+    const unsigned wgs = (unsigned)std::min<size_t>(tiles, (size_t)std::max(1, std::min(tune_int("SZ_HIP_RB_WGS", ctx->gate ? ctx->cus / 2 : ctx->cus), ctx->cus)));
+#endif
     if (a.use_mean) hipLaunchKernelGGL((k_ribbon<T, DEC, true>), dim3(wgs), dim3((RS::W + 3 + (DEC ? 1 : 0)) * 64), 0, st, a);
     else hipLaunchKernelGGL((k_ribbon<T, DEC, false>), dim3(wgs), dim3((RS::W + 3 + (DEC ? 1 : 0)) * 64), 0, st, a);
     HIPCHK(hipGetLastError());
@@ -2237,11 +2245,10 @@ int compress_fast_impl(szhip_ctx *ctx, const void *data, int data_on_device, siz
         HIPCHK(hipMemsetAsync(d_ucnt, 0, (size_t)nunits * 8, st));          // k_fast_stat adds to the few units that have side-list entries
         HIPCHK(hipEventRecord(ctx->ev[2], st));
         {   // persistent: exactly the workgroups that are resident at once (a second, half-empty round cost 40 % at 768 over 512)
-            static int per_cu = 0;
-            if (!per_cu) { int nb = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast_stat<T>, 256, 0) != hipSuccess || nb < 1) nb = 2; per_cu = nb; }
-            static int cus = 0;
-            if (!cus) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || v < 1) v = 256; cus = v; }
-            const int wgs = tune_int("SZ_HIP_FAST_STAT_WGS", per_cu * cus);
+            // (occupancy and CU count per CONTEXT: function-local statics would keep the first device's values for every other one and be
+            //  written without synchronisation by the threads of a pool)
+            if (!ctx->fast_stat_per_cu[sizeof(T) == 8]) { int nb = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast_stat<T>, 256, 0) != hipSuccess || nb < 1) nb = 2; ctx->fast_stat_per_cu[sizeof(T) == 8] = nb; }
+            const int wgs = tune_int("SZ_HIP_FAST_STAT_WGS", ctx->fast_stat_per_cu[sizeof(T) == 8] * ctx->cus);
             hipLaunchKernelGGL((k_fast_stat<T>), dim3((unsigned)std::min<int64_t>(gg.ntiles, wgs)), dim3(256), 0, st, gg, d_in, eb, (int)intervals / 2, intervals, d_hist, d_ucnt, (unsigned *)(sm + SM_TICKET));
         }
         HIPCHK(hipGetLastError());
@@ -2300,10 +2307,8 @@ int compress_fast_impl(szhip_ctx *ctx, const void *data, int data_on_device, siz
     HIPCHK(hipMemcpyAsync(d_stream, hdr.data(), hdr.size(), hipMemcpyHostToDevice, st));
     if (two_pass) {
         {
-            static int per_cu = 0, cus = 0;
-            if (!per_cu) { int nb = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast_pack<T>, 256, 0) != hipSuccess || nb < 1) nb = 2; per_cu = nb; }
-            if (!cus) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || v < 1) v = 256; cus = v; }
-            const int wgs = tune_int("SZ_HIP_FAST_PACK_WGS", per_cu * cus);
+            if (!ctx->fast_pack_per_cu[sizeof(T) == 8]) { int nb = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast_pack<T>, 256, 0) != hipSuccess || nb < 1) nb = 2; ctx->fast_pack_per_cu[sizeof(T) == 8] = nb; }
+            const int wgs = tune_int("SZ_HIP_FAST_PACK_WGS", ctx->fast_pack_per_cu[sizeof(T) == 8] * ctx->cus);
             hipLaunchKernelGGL((k_fast_pack<T>), dim3((unsigned)std::min<int64_t>(gg.ntiles, wgs)), dim3(256), 0, st, gg, d_in, eb, (int)intervals / 2, intervals,
                                (const u64 *)ctx->code_tab.p, (const uint8_t *)ctx->len_tab.p, (const u64 *)d_uoffc,
                                (int32_t *)(d_stream + offA), (int32_t *)(d_stream + offBd), (T *)(d_stream + offB), d_ubits, (unsigned *)ctx->fast_slots.p,
@@ -2987,6 +2992,7 @@ int szhip_create(szhip_ctx **out, int device)
     if (device < 0 || device >= count) return SZHIP_ERR_ARG;
     szhip_ctx *ctx = new szhip_ctx();
     ctx->device = device;
+    { int c = 0; if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && c > 0) ctx->cus = c; }
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx; return SZHIP_ERR_NODEVICE;
     }
