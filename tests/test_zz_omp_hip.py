@@ -5,11 +5,12 @@ The bar: the stream is byte for byte what oracle/szo_omp_impl.h writes (itself p
 tests/test_omp_container.py), on the recorded reference cases md5 for md5 with the reference's own output; the decoded array is bit for bit
 what the oracle decodes.
 
-(The file sorts last on purpose: its GPU tests have not run on hardware yet and must not stand in front of the ones that have.)
+(The file sorts last for a historical reason: its GPU tests were written after round 3's hardware time was spent.  They have run since --
+driver box at the end of round 3, every GPU call of round 4 -- and are green.)
 
 CPU (-m "not gpu"): the product code through the HIP-on-CPU shim (tests/sim).  GPU (-m gpu): the same cases through the built library, a
-256^3 array against the oracle and the 512^3 array of the bench through the round trip.  STATUS: the GPU tests were written after round 3's GPU
-minutes were spent and have not run on hardware yet."""
+256^3 array against the oracle and the 512^3 array of the bench through the round trip.  The `col-*` cases (32 x 32 box faces) run round 4's
+column-per-lane sweep, per-box entropy stage and look-up-table decoder; the others the first form of the kernels."""
 import ctypes
 import hashlib
 import json
@@ -281,7 +282,7 @@ def test_hip_omp_container_256_against_oracle_and_512_round_trip(oracle, built):
 # ---- inputs with fill values and NaN through the other paths (SZ 2.1 3-D / 2-D, the 1-D chain): found by tools/omp_diff_fuzz.py at the end of
 # round 3 -- the interval optimisers convert (|prediction error| / eb + 1) / 2 to `unsigned long` (sz_float.c:4664, :5092), and outside that type's
 # range the stream depends on what the reference's x86-64 build does (a quotient >= 2^64 lands in the FIRST bin, a NaN in the last); the range
-# scan skips NaN (dataCompression.c:97-113).  Here because the GPU variant has not run on hardware yet.
+# scan skips NaN (dataCompression.c:97-113).  (In this file because the GPU variant was added after round 3's hardware time; green on hardware since.)
 def _fill_value_cases():
     from sz_amd.fields import s_field
     rng = np.random.default_rng(3)
