@@ -705,6 +705,41 @@ def run_c4(args, torch, dist, world, rank, local_rank, dev):
     ctx.decompress(src.data_ptr(), True, size, 4 + 36 + 8, (planes, N, N), np.float64, dec.data_ptr(), True)
     _sync(torch); td = time.perf_counter() - td
     max_err = float((dec - x).abs().max().item())
+    # ---- the same slab through the reference's OpenMP container (outside the timed region, rank 0, hardware only): boxes of
+    #      4 x 32 x 32 (thread_num = the power of two whose grid gives 32 x 32 faces), the same absolute bound
+    omp_c4 = None
+    if rank == 0 and not getattr(args, "dry_run", False) and not args.no_omp and N % 32 == 0:
+        try:
+            # (the slabs of the SZ 2.1 path are cut on multiples of its block edge: 132 planes at N = 1024; the container's boxes need no such
+            #  alignment but must divide the array: its slab is the plain N / 8 = 128 planes -- the first 128 of this rank's)
+            nbx = N // 32
+            po = (N // nslabs) // nbx * nbx if nbx & (nbx - 1) == 0 else 0
+            tn = nbx ** 3 if po >= nbx and po <= planes else 0
+            if tn:
+                xo = x[:po]
+                nbytes_o = xo.numel() * 8
+                deco = torch.empty_like(xo)
+                meta_o = bytes(32)
+                for _ in range(2):
+                    optr, osize, ost = ctx.compress_omp(xo.data_ptr(), True, (po, N, N), np.float64, eb, tn, meta_o, out_on_device=True)
+                _sync(torch); t1 = time.perf_counter()
+                for _ in range(max(3, min(args.steps, 5))):
+                    optr, osize, ost = ctx.compress_omp(xo.data_ptr(), True, (po, N, N), np.float64, eb, tn, meta_o, out_on_device=True)
+                _sync(torch); to = (time.perf_counter() - t1) / max(3, min(args.steps, 5))
+                ctx.decompress_omp(optr, True, osize, len(meta_o), (po, N, N), np.float64, deco.data_ptr(), True)
+                _sync(torch); t1 = time.perf_counter()
+                for _ in range(3):
+                    odst = ctx.decompress_omp(optr, True, osize, len(meta_o), (po, N, N), np.float64, deco.data_ptr(), True)
+                _sync(torch); tod = (time.perf_counter() - t1) / 3
+                oerr = float((deco - xo).abs().max().item())
+                omp_c4 = {"container": f"the reference's OpenMP container on {po}x{N}x{N} of this rank's slab (not part of `value`)", "boxes": int(ost.n_blocks), "GB/s": round(nbytes_o / to / 1e9, 2),
+                          "ms": round(to * 1e3, 3), "decompress_GBps": round(nbytes_o / tod / 1e9, 2), "out_bytes": int(osize), "ratio": round(nbytes_o / osize, 4),
+                          "max_abs_err": oerr, "bound_held": bool(oerr <= eb),
+                          "phase_ms": {"prequant": round(ost.ms_prequant, 3), "quant": round(ost.ms_quant, 3), "entropy": round(ost.ms_entropy, 3),
+                                       "decompress_entropy": round(odst.ms_entropy, 3), "decompress_quant": round(odst.ms_quant, 3)},
+                          "quant_kernel_frac_of_hbm_peak_on_N_sizeof_T": round(nbytes_o / (max(ost.ms_quant, 1e-9) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+        except Exception as e:  # noqa: BLE001 -- an extra object, never the headline
+            omp_c4 = {"error": repr(e)[:200]}
     stats_t = torch.tensor([elapsed, max_err, float(size), td], dtype=torch.float64, device=dev)
     if world > 1:
         allst = [torch.zeros_like(stats_t) for _ in range(world)]
@@ -723,7 +758,8 @@ def run_c4(args, torch, dist, world, rank, local_rank, dev):
                                        "all-gather of the sub-streams inside the step", "slabs_run": world, "slabs_of_array": nslabs},
                 "eb": eb, "max_abs_err": worst, "bound_held": bool(worst <= eb), "out_bytes_all_ranks": int(total_out),
                 "ratio": round(world * nbytes_in / total_out, 4), "decompress_GBps_per_gpu": round(nbytes_in / max(float(s[3]) for s in allst) / 1e9, 2),
-                "phase_ms_rank0": {"prequant": round(st.ms_prequant, 3), "quant": round(st.ms_quant, 3), "entropy": round(st.ms_entropy, 3)}}
+                "phase_ms_rank0": {"prequant": round(st.ms_prequant, 3), "quant": round(st.ms_quant, 3), "entropy": round(st.ms_entropy, 3)},
+                "omp_container": omp_c4}
         print(json.dumps(line))
     if world > 1:
         dist.barrier(); dist.destroy_process_group()

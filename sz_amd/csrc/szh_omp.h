@@ -410,41 +410,45 @@ __global__ __launch_bounds__(256) void k_omp_hdec(int bel, const unsigned char *
 // =====================================================================================================================
 // ucount / ucount64 (or null): the box's count of verbatim values = its bin 0 (when the sweep did not count them, k_omp_col<.., COUNT = false>)
 __global__ __launch_bounds__(256) void k_omp_hist_box(int bel, const uint16_t *__restrict__ codes, unsigned nbins, int rshift, unsigned *__restrict__ hist_box, unsigned *hist,
-                                                      unsigned *ucount, u64 *ucount64)
+                                                      unsigned *ucount, u64 *ucount64, int nb, int per_wg)
 {
     SZH_DYN_SMEM(smem);
     unsigned *sh = reinterpret_cast<unsigned *>(smem);
     const unsigned R = 1u << rshift;
-    for (unsigned i = threadIdx.x; i < nbins * R; i += 256) sh[i] = 0;
-    __syncthreads();
     const unsigned rep = threadIdx.x & (R - 1);
-    const uint16_t *cb = codes + (int64_t)blockIdx.x * bel;
-    const int nvec = bel / 8;
-    const uint4 *v4 = reinterpret_cast<const uint4 *>(cb);
-    for (int i = (int)threadIdx.x; i < nvec; i += 4 * 256) {         // four loads in flight per thread
-        uint4 v[4];
+    // `per_wg` boxes one after the other (small boxes: 32 768 workgroups of two loads per thread were bound by their own dispatch, 0.38 ms)
+    for (int box = (int)blockIdx.x * per_wg; box < nb && box < ((int)blockIdx.x + 1) * per_wg; ++box) {
+        for (unsigned i = threadIdx.x; i < nbins * R; i += 256) sh[i] = 0;
+        __syncthreads();
+        const uint16_t *cb = codes + (int64_t)box * bel;
+        const int nvec = bel / 8;
+        const uint4 *v4 = reinterpret_cast<const uint4 *>(cb);
+        for (int i = (int)threadIdx.x; i < nvec; i += 4 * 256) {         // four loads in flight per thread
+            uint4 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) if (i + u * 256 < nvec) v[u] = v4[i + u * 256];
+            for (int u = 0; u < 4; ++u) if (i + u * 256 < nvec) v[u] = v4[i + u * 256];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (i + u * 256 >= nvec) break;
-            const unsigned wv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            for (int u = 0; u < 4; ++u) {
+                if (i + u * 256 >= nvec) break;
+                const unsigned wv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const unsigned c0 = wv[q] & 0xffffu, c1 = wv[q] >> 16;
-                if (c0 < nbins) atomicAdd(&sh[(c0 << rshift) + rep], 1u);
-                if (c1 < nbins) atomicAdd(&sh[(c1 << rshift) + rep], 1u);
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned c0 = wv[q] & 0xffffu, c1 = wv[q] >> 16;
+                    if (c0 < nbins) atomicAdd(&sh[(c0 << rshift) + rep], 1u);
+                    if (c1 < nbins) atomicAdd(&sh[(c1 << rshift) + rep], 1u);
+                }
             }
         }
-    }
-    for (int i = nvec * 8 + (int)threadIdx.x; i < bel; i += 256) { const unsigned c = cb[i]; if (c < nbins) atomicAdd(&sh[(c << rshift) + rep], 1u); }
-    __syncthreads();
-    for (unsigned b = threadIdx.x; b < nbins; b += 256) {
-        unsigned s = 0;
-        for (unsigned r = 0; r < R; ++r) s += sh[(b << rshift) + r];
-        hist_box[(int64_t)blockIdx.x * nbins + b] = s;
-        if (s) atomicAdd(&hist[b], s);
-        if (b == 0 && ucount) { ucount[blockIdx.x] = s; ucount64[blockIdx.x] = s; }
+        for (int i = nvec * 8 + (int)threadIdx.x; i < bel; i += 256) { const unsigned c = cb[i]; if (c < nbins) atomicAdd(&sh[(c << rshift) + rep], 1u); }
+        __syncthreads();
+        for (unsigned b = threadIdx.x; b < nbins; b += 256) {
+            unsigned s = 0;
+            for (unsigned r = 0; r < R; ++r) s += sh[(b << rshift) + r];
+            hist_box[(int64_t)box * nbins + b] = s;
+            if (s) atomicAdd(&hist[b], s);
+            if (b == 0 && ucount) { ucount[box] = s; ucount64[box] = s; }
+        }
+        __syncthreads();
     }
 }
 // bytes of box b = its bits rounded up (Huffman.c encode: the last byte is padded with zero bits); from the box's histogram ...
@@ -454,6 +458,16 @@ __global__ __launch_bounds__(256) void k_omp_box_bits_h(int nb, unsigned nbins, 
     if (b >= nb) return;
     u64 s = 0;
     for (unsigned i = lane; i < nbins; i += 64) s += (u64)hist_box[(int64_t)b * nbins + i] * len[i];
+    s = wave_sum_u64(s);
+    if (lane == 0) box_bytes[b] = (s + 7) >> 3;
+}
+// the same from the packed table `code << 8 | len` of the fast path
+__global__ __launch_bounds__(256) void k_omp_box_bits_p(int nb, unsigned nbins, const unsigned *__restrict__ hist_box, const u64 *__restrict__ packed, u64 *box_bytes)
+{
+    const int b = blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;        // a wavefront per box
+    if (b >= nb) return;
+    u64 s = 0;
+    for (unsigned i = lane; i < nbins; i += 64) s += (u64)hist_box[(int64_t)b * nbins + i] * (unsigned)(packed[i] & 0xffu);
     s = wave_sum_u64(s);
     if (lane == 0) box_bytes[b] = (s + 7) >> 3;
 }
@@ -558,8 +572,9 @@ __global__ __launch_bounds__(256) void k_omp_encode_box(szh_omp_geom g, const T 
 // Everything between the code book and the packing in ONE launch of one workgroup: the boxes' payload sizes (from their histograms), where
 // the payloads and the verbatim values of every box begin (two scans), the totals.  Before: k_omp_box_bits_h + two three-launch scans +
 // their gaps, ~50 us for 4096 boxes.
+// have_bytes: box_bytes is already there (k_omp_box_bits_p, many boxes: one workgroup reading every box's histogram took 0.22 ms for 32 768 boxes)
 __global__ __launch_bounds__(1024) void k_omp_layout(int nb, unsigned nbins, const unsigned *__restrict__ hist_box, const u64 *__restrict__ packed, const u64 *__restrict__ ucount64,
-                                                     u64 *box_bytes, u64 *box_off, u64 *uoff, u64 *total_bytes, u64 *total_unpred)
+                                                     u64 *box_bytes, u64 *box_off, u64 *uoff, u64 *total_bytes, u64 *total_unpred, int have_bytes)
 {
     __shared__ u64 sa[16], sb[16];
     __shared__ unsigned char llen[2048];
@@ -571,11 +586,15 @@ __global__ __launch_bounds__(1024) void k_omp_layout(int nb, unsigned nbins, con
         const int b = base + tid;
         u64 bytes = 0, un = 0;
         if (b < nb) {
-            u64 bits = 0;
-            const unsigned *h = hist_box + (int64_t)b * nbins;
-            for (unsigned i = 0; i < nbins; ++i) bits += (u64)h[i] * llen[i];
-            bytes = (bits + 7) >> 3; un = ucount64[b];
-            box_bytes[b] = bytes;
+            if (have_bytes) bytes = box_bytes[b];
+            else {
+                u64 bits = 0;
+                const unsigned *h = hist_box + (int64_t)b * nbins;
+                for (unsigned i = 0; i < nbins; ++i) bits += (u64)h[i] * llen[i];
+                bytes = (bits + 7) >> 3;
+                box_bytes[b] = bytes;
+            }
+            un = ucount64[b];
         }
         u64 ib = bytes, iu = un;
         for (int o = 1; o < 64; o <<= 1) { const u64 tb = __shfl_up(ib, o, 64), tu = __shfl_up(iu, o, 64); if (lane >= o) { ib += tb; iu += tu; } }
@@ -765,19 +784,13 @@ __global__ __launch_bounds__(256) void k_omp_encode_box3(szh_omp_geom g, const T
 // [the look-up table SZH_LUT_BYTES][the node table when tab_lds].  The box's 256 stretches find their starts as in k_omp_hdec.
 __global__ __launch_bounds__(256) void k_omp_hdec_lut(int bel, const unsigned char *__restrict__ payload, unsigned bytes_before, const u64 *__restrict__ box_off,
                                                       const u64 *__restrict__ box_bytes, const unsigned *__restrict__ table, int n_nodes, int tab_lds,
-                                                      const uint4 *__restrict__ lut, unsigned stage_bytes, uint16_t *__restrict__ codes, unsigned *__restrict__ bad)
+                                                      const uint4 *__restrict__ lut, unsigned stage_bytes, uint16_t *__restrict__ codes, unsigned *__restrict__ bad, int nb, int per_wg)
 {
     SZH_DYN_SMEM(smem);
     __shared__ unsigned s_start[257], s_flag[2];
     __shared__ u64 sh[8];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    uint16_t *out = codes + (int64_t)b * bel;
-    const unsigned nbytes = (unsigned)box_bytes[b];
-    // ---- staging: from a 16-byte aligned address at or below the payload's first byte
-    const unsigned char *bits = payload + box_off[b];
-    unsigned lead = (unsigned)((uintptr_t)bits & 15u);
-    if ((u64)lead > (u64)bytes_before + box_off[b]) lead = 0;       // (never in front of the buffer; then the loads below are unaligned but valid)
-    const unsigned n16 = (lead + nbytes + 15) / 16;
+    const int tid = threadIdx.x;
+    // the tables once per workgroup; then `per_wg` boxes one after the other (small boxes: 20 KB of tables per 1 KB of payload otherwise)
     const unsigned lds_words = (stage_bytes + 16) / 4;
     char *q = smem + ((SZH_HDEC_SWZ(lds_words) * 4 + 15) / 16 * 16);
     const SZH_LDS void *lutw = (const SZH_LDS void *)(q + SZH_LUT_SIZE * 16);
@@ -786,6 +799,15 @@ __global__ __launch_bounds__(256) void k_omp_hdec_lut(int bel, const unsigned ch
     q += SZH_LUT_BYTES;
     const SZH_LDS unsigned *ltab = nullptr;
     if (tab_lds) { hdec_copy16<false>(reinterpret_cast<uint4 *>(q), reinterpret_cast<const uint4 *>(table), (2 * n_nodes + 3) / 4); ltab = (const SZH_LDS unsigned *)q; }
+    for (int b = (int)blockIdx.x * per_wg; b < nb && b < ((int)blockIdx.x + 1) * per_wg; ++b) {
+    __syncthreads();                                               // (the previous box's payload has been read)
+    uint16_t *out = codes + (int64_t)b * bel;
+    const unsigned nbytes = (unsigned)box_bytes[b];
+    // ---- staging: from a 16-byte aligned address at or below the payload's first byte
+    const unsigned char *bits = payload + box_off[b];
+    unsigned lead = (unsigned)((uintptr_t)bits & 15u);
+    if ((u64)lead > (u64)bytes_before + box_off[b]) lead = 0;       // (never in front of the buffer; then the loads below are unaligned but valid)
+    const unsigned n16 = (lead + nbytes + 15) / 16;
     hdec_stage16(reinterpret_cast<unsigned *>(smem), reinterpret_cast<const uint4 *>(bits - lead), (int)n16);
     if (tid == 0) { reinterpret_cast<unsigned *>(smem)[SZH_HDEC_SWZ(4 * n16)] = 0u; s_flag[0] = 0u; s_flag[1] = 0u; }     // the slack word hdec_w32 may touch
     __syncthreads();
@@ -820,4 +842,5 @@ __global__ __launch_bounds__(256) void k_omp_hdec_lut(int bel, const unsigned ch
     int64_t oend = wr ? (int64_t)o + cnt : (int64_t)o;
     if (oend > bel) oend = bel;
     hdec_run_lut<true>(l, total, ltab, table, lut4, wr ? start : 0u, wr ? limit : 0u, &e, out, (int64_t)o, oend, wr);
+    }
 }

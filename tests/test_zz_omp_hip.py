@@ -142,6 +142,12 @@ def test_omp_container_on_cpu_shim_matches_oracle(oracle, shim_ctx):
     _refusals(shim_ctx)
 
 
+def test_omp_container_many_boxes_layout_on_cpu_shim(oracle, shim_ctx, monkeypatch):
+    """the two-launch form of the boxes' layout (payload sizes by a wavefront per box, then the scans), which arrays of more than 8192 boxes take"""
+    monkeypatch.setenv("SZ_HIP_OMP_MANY", "1")
+    _run_cases(shim_ctx, oracle, [c for c in _cases() if c[0] in ("col-S-8x64x64-t8", "col-S-f64-8x64x64-t8", "col-one-noisy-box-t16")])
+
+
 def test_omp_container_on_cpu_shim_gives_the_recorded_reference_bytes(oracle, shim_ctx):
     _recorded(shim_ctx, oracle, ["L-32-f32-t8", "S-64-f32-t64", "S-64x32x96-f32-t16", "Sfill-64x32x32-f32-t8", "Snan-32-f32-t8", "S-8x64x64-f64-t8", "M-32x64x64-f64-t16"])
 
