@@ -18,8 +18,8 @@
 //     All lanes load and store at the same steps, two groups of four steps ahead of the use (see the kernel).
 // Box faces of up to 1024 rows (c0 * c1 <= 1024: a 32^3 box is 1024 rows of 32), the box grid must divide the array (on an uneven grid
 // the reference counts Huffman frequencies over uninitialised gaps of its code array: nothing to be identical to).
-// NOT YET RUN ON HARDWARE (written after round 3's GPU budget was spent): parity is proven on the CPU shim only (tests/test_zz_omp_hip.py,
-// tools/omp_diff_fuzz.py); tools/gpu_omp_first_run.sh is the first thing to run on a GPU.
+// Round 4: run on hardware (tests/test_zz_omp_hip.py -m gpu, tools/omp_diff_fuzz.py on the GPU); boxes of 32 x 32 columns go through the
+// column sweep of szh_ompcol.h instead of k_omp_box, and the entropy stage through the per-box kernels at the end of this file.
 #pragma once
 
 struct szh_omp_geom {

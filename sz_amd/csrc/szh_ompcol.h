@@ -41,6 +41,32 @@ template <class E> __device__ __forceinline__ void lds_put(OC_LDS unsigned char 
 __device__ __forceinline__ v4u lds_get16(OC_LDS unsigned char *base, unsigned off) { return *(OC_LDS v4u *)(base + off); }
 __device__ __forceinline__ void lds_put16(OC_LDS unsigned char *base, unsigned off, v4u v) { *(OC_LDS v4u *)(base + off) = v; }
 __device__ __forceinline__ void order() { asm volatile("" ::: "memory"); }
+// streaming accesses: every byte is read or written once, so the COMPRESSING sweep marks them non-temporal (measured, round 4, 512^3
+// float: 0.153 -> 0.135 ms; the decompressing sweep reads codes and flags other kernels have just written and lost 0.025 ms with it:
+// plain there).  -DSZH_OC_NT=0 gives the plain form everywhere.
+#ifndef SZH_OC_NT
+#define SZH_OC_NT 1
+#endif
+#ifndef SZH_OC_NT_DEC_LD
+#define SZH_OC_NT_DEC_LD 0
+#endif
+#ifndef SZH_OC_NT_DEC_ST
+#define SZH_OC_NT_DEC_ST 0
+#endif
+template <bool NT> __device__ __forceinline__ v4u ld_stream(const void *p)
+{
+#if !defined(SZH_HIPSIM)
+    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p));
+#endif
+    return *reinterpret_cast<const v4u *>(p);
+}
+template <bool NT> __device__ __forceinline__ void st_stream(void *p, v4u v)
+{
+#if !defined(SZH_HIPSIM)
+    if (NT) { __builtin_nontemporal_store(v, reinterpret_cast<v4u *>(p)); return; }
+#endif
+    *reinterpret_cast<v4u *>(p) = v;
+}
 #ifdef SZH_HIPSIM
 static inline void pin(unsigned &) {}
 #else
@@ -120,6 +146,7 @@ template <class T> struct sweep_args {
     uint16_t *codes;
     unsigned *ucount; szh_u64 *ucount64; T *first;        // M_CMP: written; inverse: `first` read, `ucount` = ONE error counter
     const szh_u64 *uoff;               // inverse: ranks of the boxes' verbatim values (which variant a wavefront runs)
+    int dbg_no_code_stores;            // development (timing only, wrong streams): the sweep without its 2 N bytes of code stores
     const unsigned *vflags; int fw;    // inverse: per box `fw` words, bit (row / RPL) = that group of rows holds a verbatim value (k_omp_scatter); fw = 0: none
 };
 
@@ -131,6 +158,7 @@ struct sweep {
     typedef shape<T, C1, C2> S;
     static constexpr int LINE = S::LINE, RS = S::RS, PITCH = S::PITCH;
     static constexpr bool CMP = MODE == M_CMP, VLOAD = MODE != M_DEC;
+    static constexpr bool NT_LD = SZH_OC_NT && (CMP || SZH_OC_NT_DEC_LD), NT_ST = SZH_OC_NT && (CMP || SZH_OC_NT_DEC_ST);
     static constexpr int KV = MODE == M_DECV ? S::RPL : 1;
 
     OC_LDS unsigned char *ring;
@@ -182,11 +210,11 @@ struct sweep {
             const unsigned wv = fl[b * OC_FLAG_WORDS + (bit >> 5)];
             p = (wv >> (bit & 31u) & 1u) ? p : (const unsigned char *)vdst;
         }
-        return *reinterpret_cast<const v4u *>(p);
+        return ld_stream<NT_LD>(p);
     }
     __device__ __forceinline__ v4u load_crows(int L, int w) const
     {
-        return *reinterpret_cast<const v4u *>(cptr + ((int64_t)clampL(L) * C1 + S::RPC * w) * S::CROW);
+        return ld_stream<NT_LD>(cptr + ((int64_t)clampL(L) * C1 + S::RPC * w) * S::CROW);
     }
     // ---- the events of step (it, U): `ls_*`: (LINE * L) mod RS for L = it - 1, it, it + 1
     template <int U, int PHASE> __device__ __forceinline__ void events(int it, int ls_m1, int ls_0, int ls_p1)
@@ -198,7 +226,7 @@ struct sweep {
             constexpr int w = decltype(W)::value, d = S::dco(w);
             static_assert(fdiv(d, LINE) == 1 && fdiv(d + 1, LINE) == 1, "a finished row leaves during the next iteration");
             if constexpr (PHASE != PH_FIRST && fmod(d + 1, LINE) == U)
-                *reinterpret_cast<v4u *>(cptr + ((int64_t)(it - 1) * C1 + S::RPC * w) * S::CROW) = wq;
+                if (!a.dbg_no_code_stores) st_stream<NT_ST>(cptr + ((int64_t)(it - 1) * C1 + S::RPC * w) * S::CROW, wq);
             if constexpr (PHASE != PH_FIRST && fmod(d, LINE) == U) {
                 constexpr int loff = -fdiv(d, LINE);
                 wq = lds_get16(ring, slot_off(ls_of(loff), (unsigned)(S::RPC * w + 1) + cev_r) + cev_lds);
@@ -208,7 +236,7 @@ struct sweep {
             constexpr int e = decltype(E)::value, d = S::dvo(e);
             static_assert(fdiv(d, LINE) == 1 && fdiv(d + 1, LINE) == 1, "a finished row leaves during the next iteration");
             if constexpr (PHASE != PH_FIRST && fmod(d + 1, LINE) == U)
-                *reinterpret_cast<v4u *>(vdst + (int64_t)(it - 1) * line_bytes + (int64_t)(S::RPL * e) * row_bytes) = wq;
+                st_stream<NT_ST>(vdst + (int64_t)(it - 1) * line_bytes + (int64_t)(S::RPL * e) * row_bytes, wq);
             if constexpr (PHASE != PH_FIRST && fmod(d, LINE) == U) {
                 constexpr int loff = -fdiv(d, LINE);
                 wq = lds_get16(ring, slot_off(ls_of(loff), (unsigned)(S::RPL * e + 1) + ev_r) + vev_lds);

@@ -2588,7 +2588,7 @@ int compress_omp_impl(szhip_ctx *ctx, const void *data, int data_on_device, size
     if (omp_col_applies(g, d_in, r2 * sizeof(T))) {        // the column-per-lane sweep (szh_ompcol.h): a wavefront per pair of boxes
         szh_oc::sweep_args<T> oa;
         oa.g = g; oa.data = d_in; oa.out = nullptr; oa.eb = eb; oa.recip = (T)(1 / eb); oa.intervals = (int)intervals; oa.codes = d_codes;
-        oa.ucount = d_ucount; oa.ucount64 = d_ucount64; oa.first = d_first; oa.uoff = nullptr; oa.vflags = nullptr; oa.fw = 0;
+        oa.ucount = d_ucount; oa.ucount64 = d_ucount64; oa.first = d_first; oa.uoff = nullptr; oa.vflags = nullptr; oa.fw = 0; oa.dbg_no_code_stores = tune_int("SZ_HIP_OMP_DBG_NOSTORE", 0);
         // (with a histogram per box coming anyway, the boxes' counts of verbatim values are its bins 0: the sweep leaves the counting out --
         //  two vector instructions per step of a kernel that is bound by exactly those)
         if (box_hist) { sweep_counted = false; hipLaunchKernelGGL((k_omp_col<T, 32, 32, false, false>), dim3((unsigned)(g.nb / 2)), dim3(64), 0, st, oa); }
@@ -2909,7 +2909,7 @@ int decompress_omp_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stre
             HIPCHK(hipGetLastError());
         }
         szh_oc::sweep_args<T> oa;
-        oa.vflags = d_vflags; oa.fw = fw;
+        oa.vflags = d_vflags; oa.fw = fw; oa.dbg_no_code_stores = 0;
         oa.g = g; oa.data = nullptr; oa.out = d_out; oa.eb = eb; oa.recip = (T)(1 / eb); oa.intervals = (int)intervals; oa.codes = d_codes;
         oa.ucount = (unsigned *)(sm + SM_ERR); oa.ucount64 = nullptr; oa.first = (T *)ctx->samples.p; oa.uoff = (const u64 *)ctx->col_off.p;
         hipLaunchKernelGGL((k_omp_col<T, 32, 32, true>), dim3((unsigned)(g.nb / 2)), dim3(64), 0, st, oa);

@@ -66,8 +66,13 @@ def main():
             c0, c1 = int(rng.integers(8, 33)), int(rng.integers(8, 33))
             if c0 * c1 > 1024:
                 c1 = 1024 // c0
+        if os.environ.get("FUZZ_COL") or rng.integers(0, 4) == 0:
+            # boxes with 32 x 32 faces, in pairs: the column-per-lane sweep, per-box entropy stage and look-up-table decoder of round 4 (szh_ompcol.h)
+            threads = int(rng.choice([2, 4, 8, 16, 32]))
+            nx, ny, nz = grid(threads)
+            c0, c1, c2 = int(rng.choice([1, 2, 3, 4, 5, 8, 13])), 32, 32
         shape = (nx * c0, ny * c1, nz * c2)
-        if shape[0] * shape[1] * shape[2] > 300000:
+        if shape[0] * shape[1] * shape[2] > (600000 if os.environ.get("SZ_FUZZ_GPU") else 300000):
             continue
         dt = np.float32 if rng.integers(0, 2) else np.float64
         d = make(rng, shape, dt)
