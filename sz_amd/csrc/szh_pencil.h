@@ -45,6 +45,8 @@ template <class T> struct szh_qargs {
     int cap, radius, use_mean;
     szh_u64 *faceI, *faceJ;   // granule buffers: faceJ [pencil][8 rows][r2][NW], faceI [pencil][9 rows][r2][NW] (row 8 = forwarded corner column)
     unsigned epoch;
+    unsigned *tile_done;      // k_ribbon, compress, optional (host-coherent memory): [tile] <- epoch once every code of the tile is in device memory
+                              // (the host starts the entropy stage's passes over finished tile rows while the sweep is still running)
     int nI, nJ;
     const unsigned *order;    // ticket -> (tile row << 16) | tile column, anti-diagonal order over the tiles
     unsigned *ticket;

@@ -199,6 +199,7 @@ __device__ __forceinline__ szh_u64 ld_gran(const szh_u64 *p) { return __hip_atom
 __device__ __forceinline__ void st_gran(szh_u64 *p, szh_u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned ld_flag(const unsigned *p) { return __hip_atomic_load(const_cast<unsigned *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_flag(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_done(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void nap(int n) { for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1); }
 
 // development build (SZH_DEV): per-wavefront stamps, [tile][W + 4 wavefronts][8] u64 in a.trace:
@@ -926,10 +927,17 @@ __global__ __launch_bounds__((szh_rb_shape<T>::W + 3 + (DEC ? 1 : 0)) * 64) void
 #ifndef SZH_RB_PRIO
 #define SZH_RB_PRIO 1
 #endif
-    if (SZH_RB_PRIO) prio(w >= W ? 3 : (w == 0 ? 2 : (w < 3 ? 1 : 0)));
+#ifndef SZH_RB_PRIO_MIN
+#define SZH_RB_PRIO_MIN 0            /* priority of the compute wavefronts 3 .. W-1 (other kernels' wavefronts run at 0) */
+#endif
+    if (SZH_RB_PRIO) prio(w >= W ? 3 : (w == 0 ? 2 : (w < 3 ? 1 : SZH_RB_PRIO_MIN)));
     const unsigned ntiles = (unsigned)(a.nI * a.nJ);
+    int prev_tile = -1;
     for (unsigned it = 0;; ++it) {
         __syncthreads();                                             // the previous tile is finished by every wavefront
+        // ... and its codes are published: a release at system scope writes this XCD's L2 back before the word goes to the host, so
+        // a kernel the host launches on seeing it (another XCD, its L2 invalidated at launch) reads them from memory
+        if (!DEC && a.tile_done && prev_tile >= 0 && threadIdx.x == 0) st_done(a.tile_done + prev_tile, a.epoch);
         if (threadIdx.x < 2 * (W + 2)) P[threadIdx.x] = 0;
         if (threadIdx.x < 2 * W) Q[threadIdx.x] = 0;
         if (threadIdx.x == 0) {
@@ -940,6 +948,7 @@ __global__ __launch_bounds__((szh_rb_shape<T>::W + 3 + (DEC ? 1 : 0)) * 64) void
         const unsigned ij = (unsigned)uni((int)tk_s);
         if (ij == 0xffffffffu) break;
         const int TI = (int)(ij >> 16), TJ = (int)(ij & 0xffffu);
+        prev_tile = TI * a.nJ + TJ;
         if (w < W) ribbon_body<T, DEC, USEMEAN>(a, TI, TJ, w, L);
         else if (w == W) drain<T>(a, TI, TJ, L);
         else if (w == W + 1) fill_up<T>(a, TI, TJ, L);

@@ -44,6 +44,8 @@ struct szhip_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // the fit + selection pass runs here, concurrently with the interval optimiser's sampling and host decisions
     hipEvent_t ev_in = nullptr, ev_fit = nullptr;
+    hipStream_t stream3 = nullptr;   // the block-ordering pass of finished tile rows, while the sweep is still running on `stream` (created on first use)
+    hipEvent_t ev_perm = nullptr;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     char err[512] = {0};
     unsigned epoch = 0;
@@ -150,6 +152,7 @@ int ensure_coherent(szhip_ctx *ctx, size_t bytes)
     if (ctx->coh) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipHostFree(ctx->coh)); ctx->coh = nullptr; ctx->coh_cap = 0; }
     size_t cap = bytes + bytes / 4 + 4096;
     HIPCHK(hipHostMalloc(&ctx->coh, cap, hipHostMallocCoherent | hipHostMallocMapped));
+    memset(ctx->coh, 0, cap);                          // (epoch-tagged words live here: none may look current by accident)
     ctx->coh_cap = cap;
     return SZHIP_OK;
 }
@@ -260,14 +263,15 @@ int tune_int(const char *name, int def)
 }
 
 // device-wide exclusive scan of u64 in[0..n) -> out; total to *total_dev (device u64)
-int scan_u64(szhip_ctx *ctx, const u64 *in, int64_t n, u64 *out, u64 *total_dev)
+int scan_u64(szhip_ctx *ctx, const u64 *in, int64_t n, u64 *out, u64 *total_dev, hipStream_t on = nullptr)
 {
+    const hipStream_t sst = on ? on : ctx->stream;
     const int64_t nblk = (n + SZH_SCAN_TILE - 1) / SZH_SCAN_TILE;
     TRY(ensure(ctx, ctx->partial, (size_t)(nblk + 1) * 8));
     u64 *partial = (u64 *)ctx->partial.p;
-    hipLaunchKernelGGL(k_scan_partials, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, in, n, partial);
-    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(256), 0, ctx->stream, partial, nblk, total_dev);
-    hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, in, n, (const u64 *)partial, out);
+    hipLaunchKernelGGL(k_scan_partials, dim3((unsigned)nblk), dim3(256), 0, sst, in, n, partial);
+    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(256), 0, sst, partial, nblk, total_dev);
+    hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nblk), dim3(256), 0, sst, in, n, (const u64 *)partial, out);
     HIPCHK(hipGetLastError());
     return SZHIP_OK;
 }
@@ -699,8 +703,29 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     int nI, nJ, ntiles;
     using TS = szh_tile_shape<T>;
     TRY(prepare_pencil(ctx, G, szh_gran<T>::NW, TS::TPI, TS::TPJ, &nI, &nJ, &ntiles));
+    // The entropy stage's two passes over the code array (histogram, block ordering) start on FINISHED TILE ROWS while the sweep is still
+    // running (round 4): the sweep's last tile row ends ~35 % after its first one (the tile rows follow each other down dim 0), and the
+    // sweep keeps the CUs busy with one workgroup each.  k_ribbon publishes every finished tile in host-coherent memory (a.tile_done);
+    // this thread watches the words and launches the passes of slice after slice on two other streams.  SZ_HIP_SLICES=1: everything
+    // after the sweep, as before.
+    // A lane of a pool (several arrays in flight) does not do it: the other lanes' kernels already fill the sweep's idle CUs, and the
+    // slices' kernels slow every sweep in flight (measured, two lanes at 512^3: 338 GB/s without, 324 with).
+    // Measured (round 4, 512^3 float, one call after the other, same box): 255 GB/s with 1 slice, 276 with 4, 251 - 275 with 8 (the slices'
+    // kernels take 2 - 4 x their lone time beside the sweep and slow it by ~0.1 ms; more slices, more of that).
+    const int slices_req = tune_int("SZ_HIP_SLICES", ctx->gate ? 1 : 4);
+    const int slice_from = tune_int("SZ_HIP_SLICE_FROM", 0);          // per cent of the tile rows that the first slice covers at least
+    const bool sliced = use_ribbon && slices_req > 1 && !tune_int("SZ_HIP_FUSE_HIST", 0);
+    unsigned *tile_done = nullptr;
+    if (sliced) {
+        const size_t tiles = (size_t)((G.g0.count + szh_rb_shape<T>::W * szh_rb_shape<T>::R - 1) / (szh_rb_shape<T>::W * szh_rb_shape<T>::R)) * rbl.nTJ;
+        TRY(ensure_coherent(ctx, 512 + tiles * 4));
+        tile_done = (unsigned *)((char *)ctx->coh + 512);
+        if (!ctx->stream3) HIPCHK(hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
+        if (!ctx->ev_perm) HIPCHK(hipEventCreateWithFlags(&ctx->ev_perm, hipEventDisableTiming));
+    }
     {
         szh_qargs<T> a; memset(&a, 0, sizeof(a));
+        a.tile_done = tile_done;
         a.G = G; a.data = d_in; a.out = nullptr; a.codes = d_nat; a.blk_lor = d_lor; a.coef = d_coef; a.coef_stride = nb;
         a.eb = eb; a.recip = 1 / eb; a.mean = mean; a.cap = (int)intervals; a.radius = (int)intervals / 2; a.use_mean = use_mean;
         a.faceI = (szh_u64 *)ctx->faceI.p; a.faceJ = (szh_u64 *)ctx->faceJ.p; a.epoch = ++ctx->epoch;
@@ -802,7 +827,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         const size_t lds = use_lds ? ((size_t)intervals << rshift) * 4 : 16;
         const int64_t nh = use_ribbon ? (int64_t)nat_elems : n;          // ribbon order: the whole padded array, positions outside skipped by geometry
         int grid = (int)std::min<int64_t>((nh / 8 + 255) / 256 + 1, 2048);
-        hipLaunchKernelGGL(k_hist_u16, dim3(grid), dim3(256), lds, ctx->stream2, codes, nh, intervals, rshift, use_lds, d_hist, rbl, G.g0.count, G.g1.count, G.g2.count);
+        hipLaunchKernelGGL(k_hist_u16, dim3(grid), dim3(256), lds, ctx->stream2, codes, nh, intervals, rshift, use_lds, d_hist, rbl, G.g0.count, G.g1.count, G.g2.count, (int64_t)0);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(h_hist, d_hist, (size_t)intervals * 4, hipMemcpyDeviceToHost, ctx->stream2));
         HIPCHK(hipEventRecord(ctx->ev_fit, ctx->stream2));
@@ -811,12 +836,70 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     // (SZ_HIP_FUSE_HIST=1 takes the histogram inside k_permute instead: measured equal in kernel time -- 393 against 322 + 69 us -- and
     //  without the overlap, so it is off)
     bool fuse_hist = intervals <= 4096 && tune_int("SZ_HIP_FUSE_HIST", 0);
-    if (!fuse_hist) TRY(launch_hist((const uint16_t *)d_nat));    // next to the block-ordering pass (ribbon order: padding skipped by geometry)
+    if (!fuse_hist && !sliced) TRY(launch_hist((const uint16_t *)d_nat));    // next to the block-ordering pass (ribbon order: padding skipped by geometry)
     TRY(ensure(ctx, ctx->col_zeros, (size_t)ncols * 4));
     TRY(ensure(ctx, ctx->col_zeros64, (size_t)ncols * 8));
     TRY(ensure(ctx, ctx->col_off, (size_t)ncols * 8));
-    HIPCHK(hipMemsetAsync(ctx->col_zeros.p, 0, (size_t)ncols * 4, st));
     int perm_segb = 1, perm_nseg = 1;
+    if (sliced) {
+        using RS = szh_rb_shape<T>;
+        constexpr int WR = RS::W * RS::R;
+        const int nTI = (G.g0.count + WR - 1) / WR, nTJ = rbl.nTJ, NS = std::min(slices_req, nTI);
+        const int segb = choose_segb(G, 2, tune_int("SZ_HIP_PERM_TILE_KB", 32) * 1024);
+        const int nseg = (G.g2.num + segb - 1) / segb;
+        TRY(ensure(ctx, ctx->zcnt, (size_t)ncols * nseg * 4));
+        TRY(ensure(ctx, ctx->zpos, (size_t)ncols * nseg * SZH_ZCAP * 4));
+        const size_t tb = tile_bytes(G, segb, 2), tile_el = (tb + 1) / 2;
+        int rshift = 0; const int use_lds = intervals <= 16384;
+        if (use_lds) { while ((intervals << (rshift + 1)) <= 16384u && rshift < 6) ++rshift; }
+        const size_t hist_lds = use_lds ? ((size_t)intervals << rshift) * 4 : 16;
+        HIPCHK(hipMemsetAsync(d_hist, 0, (size_t)intervals * 4, ctx->stream2));
+        HIPCHK(hipMemsetAsync(ctx->col_zeros.p, 0, (size_t)ncols * 4, ctx->stream3));
+        const unsigned ep = ctx->epoch;
+        bool sweep_over = false;                                   // the sweep's end event has been seen: every tile is there
+        int b0_done = 0; int64_t hist_first = 0;
+        for (int sl = 0; sl < NS; ++sl) {
+            const int ti0 = std::min(nTI - 1, (int)((int64_t)nTI * slice_from / 100));       // rows [0, ti0) ride with the first slice
+            const int ti_lo = sl == 0 ? 0 : ti0 + (int)((int64_t)(nTI - ti0) * sl / NS), ti_hi = ti0 + (int)((int64_t)(nTI - ti0) * (sl + 1) / NS);
+            for (int t = ti_lo * nTJ; t < ti_hi * nTJ && !sweep_over; ++t) {
+                unsigned spins = 0;
+                while (__atomic_load_n(&tile_done[t], __ATOMIC_ACQUIRE) != ep) {
+                    if ((++spins & 127u) == 0) {
+                        const hipError_t q = hipEventQuery(ctx->ev[3]);
+                        if (q == hipSuccess) { sweep_over = true; break; }
+                        if (q != hipErrorNotReady) HIPCHK(q);
+                    }
+                }
+            }
+            // histogram of the slice's part of the ribbon order (tile major: one contiguous range)
+            const int64_t hist_end = sl == NS - 1 ? (int64_t)nat_elems : (int64_t)ti_hi * nTJ * szh_rb_tile_elems(rbl);
+            if (hist_end > hist_first) {
+                const int grid = (int)std::min<int64_t>(((hist_end - hist_first) / 8 + 255) / 256 + 1, 2048);
+                hipLaunchKernelGGL(k_hist_u16, dim3(grid), dim3(256), hist_lds, ctx->stream2, (const uint16_t *)d_nat, hist_end, intervals, rshift, use_lds, d_hist, rbl,
+                                   G.g0.count, G.g1.count, G.g2.count, hist_first);
+                hist_first = hist_end;
+            }
+            // block ordering of the block rows that lie inside finished tile rows
+            const int rows_ready = std::min(ti_hi * WR, G.g0.count);
+            int b0_hi = b0_done;
+            if (sl == NS - 1) b0_hi = G.g0.num;
+            else while (b0_hi < G.g0.num && (b0_hi + 1 < G.g0.num ? szh_blk_start(G.g0, b0_hi + 1) : G.g0.count) <= rows_ready) ++b0_hi;
+            if (b0_hi > b0_done) {
+                hipLaunchKernelGGL((k_permute<0>), dim3((unsigned)((b0_hi - b0_done) * G.g1.num), nseg), dim3(256), ((tile_el + 1) & ~(size_t)1) * 2 + 16, ctx->stream3, G,
+                                   (const uint16_t *)d_nat, d_blk, (unsigned *)ctx->col_zeros.p, segb, (unsigned *)ctx->zcnt.p, (unsigned *)ctx->zpos.p, rbl, d_hist, 0u,
+                                   (int)tile_el, b0_done * G.g1.num);
+                b0_done = b0_hi;
+            }
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipMemcpyAsync(h_hist, d_hist, (size_t)intervals * 4, hipMemcpyDeviceToHost, ctx->stream2));
+        HIPCHK(hipEventRecord(ctx->ev_fit, ctx->stream2));
+        hipLaunchKernelGGL(k_u32_to_u64, dim3((ncols + 255) / 256), dim3(256), 0, ctx->stream3, (const unsigned *)ctx->col_zeros.p, (int64_t)ncols, (u64 *)ctx->col_zeros64.p);
+        TRY(scan_u64(ctx, (const u64 *)ctx->col_zeros64.p, ncols, (u64 *)ctx->col_off.p, sm + SM_TOTAL_UNPRED, ctx->stream3));
+        HIPCHK(hipEventRecord(ctx->ev_perm, ctx->stream3));           // `st` waits for it where it first needs the block order (below)
+        perm_segb = segb; perm_nseg = nseg;
+    } else {
+    HIPCHK(hipMemsetAsync(ctx->col_zeros.p, 0, (size_t)ncols * 4, st));
     {
         const int segb = choose_segb(G, 2, tune_int("SZ_HIP_PERM_TILE_KB", 32) * 1024);
         const int nseg = (G.g2.num + segb - 1) / segb;
@@ -829,7 +912,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         if (fuse_hist) HIPCHK(hipMemsetAsync(d_hist, 0, (size_t)intervals * 4, st));
         hipLaunchKernelGGL((k_permute<0>), dim3(ncols, nseg), dim3(256), ((tile_el + 1) & ~(size_t)1) * 2 + (fuse_hist ? (size_t)intervals * 4 : 0) + 16, st, G, (const uint16_t *)d_nat,
                            d_blk, (unsigned *)ctx->col_zeros.p, segb, (unsigned *)ctx->zcnt.p, (unsigned *)ctx->zpos.p, rbl,
-                           d_hist, fuse_hist ? intervals : 0u, (int)tile_el);
+                           d_hist, fuse_hist ? intervals : 0u, (int)tile_el, 0);
         if (fuse_hist) {
             HIPCHK(hipMemcpyAsync(h_hist, d_hist, (size_t)intervals * 4, hipMemcpyDeviceToHost, st));
             HIPCHK(hipEventRecord(ctx->ev_fit, st));
@@ -840,6 +923,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     hipLaunchKernelGGL(k_u32_to_u64, dim3((ncols + 255) / 256), dim3(256), 0, st, (const unsigned *)ctx->col_zeros.p, (int64_t)ncols,
                        (u64 *)ctx->col_zeros64.p);
     TRY(scan_u64(ctx, (const u64 *)ctx->col_zeros64.p, ncols, (u64 *)ctx->col_off.p, sm + SM_TOTAL_UNPRED));
+    }
 
     // ---- Huffman code book (host: heap order decides the codes), built as soon as the histogram has arrived.  This is the only host
     //      round trip of the entropy stage: the number of unpredictable values is the histogram's bin 0, so the header can be written
@@ -904,6 +988,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     unsigned char *d_stream = (unsigned char *)ctx->stream_buf.p;
     HIPCHK(hipMemsetAsync(d_stream, 0, total_len + 64, st));
     HIPCHK(hipMemcpyAsync(d_stream, hdr, hdr_len, hipMemcpyHostToDevice, st));
+    if (sliced) HIPCHK(hipStreamWaitEvent(st, ctx->ev_perm, 0));      // block order and per-column offsets (third stream) from here on
     if (total_unpred > 0) {
         // the unpredictable values are gathered on the second stream while the payload is being encoded on the first (both only read
         // the block-ordered codes); their copy into the stream follows the join below
@@ -1247,7 +1332,7 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
         TRY(ensure(ctx, ctx->zcnt, (size_t)ncols * nseg * 4));
         TRY(ensure(ctx, ctx->zpos, (size_t)ncols * nseg * SZH_ZCAP * 4));
         hipLaunchKernelGGL((k_permute<1>), dim3(ncols, nseg), dim3(256), tile_bytes(G, segb, 2), st, G, (const uint16_t *)d_blk, d_nat,
-                           (unsigned *)ctx->col_zeros.p, segb, (unsigned *)ctx->zcnt.p, (unsigned *)ctx->zpos.p, rbl, (unsigned *)nullptr, 0u, 0);
+                           (unsigned *)ctx->col_zeros.p, segb, (unsigned *)ctx->zcnt.p, (unsigned *)ctx->zpos.p, rbl, (unsigned *)nullptr, 0u, 0, 0);
         perm_segb = segb; perm_nseg = nseg;
         HIPCHK(hipGetLastError());
     }
@@ -1716,7 +1801,7 @@ int compress14_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t
         if (use_lds) { while ((intervals << (rshift + 1)) <= 16384u && rshift < 6) ++rshift; }
         const size_t lds = use_lds ? ((size_t)intervals << rshift) * 4 : 16;
         int grid = (int)std::min<int64_t>((n / 8 + 255) / 256 + 1, 2048);
-        hipLaunchKernelGGL(k_hist_u16, dim3(grid), dim3(256), lds, st, (const uint16_t *)d_codes, n, intervals, rshift, use_lds, d_hist, szh_rb_layout{0, 0, 0, 0, 0, 0}, 0, 0, 0);
+        hipLaunchKernelGGL(k_hist_u16, dim3(grid), dim3(256), lds, st, (const uint16_t *)d_codes, n, intervals, rshift, use_lds, d_hist, szh_rb_layout{0, 0, 0, 0, 0, 0}, 0, 0, 0, (int64_t)0);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipMemcpyAsync(h_hist, d_hist, (size_t)intervals * 4, hipMemcpyDeviceToHost, st));
@@ -2225,7 +2310,7 @@ int compress_fast_impl(szhip_ctx *ctx, const void *data, int data_on_device, siz
             if (use_lds) { while ((intervals << (rshift + 1)) <= 16384u && rshift < 6) ++rshift; }
             const size_t lds = use_lds ? ((size_t)intervals << rshift) * 4 : 16;
             int grid = (int)std::min<int64_t>((n / 8 + 255) / 256 + 1, 2048);
-            hipLaunchKernelGGL(k_hist_u16, dim3(grid), dim3(256), lds, st, (const uint16_t *)d_codes, n, intervals, rshift, use_lds, d_hist, szh_rb_layout{0, 0, 0, 0, 0, 0}, 0, 0, 0);
+            hipLaunchKernelGGL(k_hist_u16, dim3(grid), dim3(256), lds, st, (const uint16_t *)d_codes, n, intervals, rshift, use_lds, d_hist, szh_rb_layout{0, 0, 0, 0, 0, 0}, 0, 0, 0, (int64_t)0);
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipMemcpyAsync(h_hist, d_hist, (size_t)intervals * 4, hipMemcpyDeviceToHost, st));
@@ -2625,7 +2710,7 @@ int compress_omp_impl(szhip_ctx *ctx, const void *data, int data_on_device, size
         if (use_lds) { while ((intervals << (rshift + 1)) <= 16384u && rshift < 6) ++rshift; }
         const size_t lds = use_lds ? ((size_t)intervals << rshift) * 4 : 16;
         int grid = (int)std::min<int64_t>((n / 8 + 255) / 256 + 1, 2048);
-        hipLaunchKernelGGL(k_hist_u16, dim3(grid), dim3(256), lds, st, (const uint16_t *)d_codes, n, intervals, rshift, use_lds, d_hist, szh_rb_layout{0, 0, 0, 0, 0, 0}, 0, 0, 0);
+        hipLaunchKernelGGL(k_hist_u16, dim3(grid), dim3(256), lds, st, (const uint16_t *)d_codes, n, intervals, rshift, use_lds, d_hist, szh_rb_layout{0, 0, 0, 0, 0, 0}, 0, 0, 0, (int64_t)0);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipMemcpyAsync(h_hist, d_hist, (size_t)intervals * 4, hipMemcpyDeviceToHost, st));
@@ -3031,6 +3116,8 @@ void szhip_destroy(szhip_ctx *ctx)
     if (ctx->ev_in) hipEventDestroy(ctx->ev_in);
     if (ctx->ev_fit) hipEventDestroy(ctx->ev_fit);
     if (ctx->stream2) hipStreamDestroy(ctx->stream2);
+    if (ctx->stream3) hipStreamDestroy(ctx->stream3);
+    if (ctx->ev_perm) hipEventDestroy(ctx->ev_perm);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }

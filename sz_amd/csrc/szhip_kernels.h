@@ -612,8 +612,9 @@ __global__ __launch_bounds__(256) void k_chain_seg_1d(const T *__restrict__ data
 // LDS-privatised with R replicas per bin to spread same-symbol atomics over banks.
 // rb.on: `codes` is in the ribbon order of szh_ribbon.h (n = its length, padding included): a group of 8 codes is 8 consecutive k of
 // one row; positions outside the array are skipped by geometry (r0, r1, r2 = the array's extents)
+// first: the pass covers elements [first, n) (a multiple of 8; the histogram of a slice of the ribbon order, taken while the sweep is running)
 __global__ __launch_bounds__(256) void k_hist_u16(const uint16_t *__restrict__ codes, int64_t n, unsigned nbins, int rshift,
-                                                  int use_lds, unsigned *hist, szh_rb_layout rb, int r0, int r1, int r2)
+                                                  int use_lds, unsigned *hist, szh_rb_layout rb, int r0, int r1, int r2, int64_t first)
 {
     SZH_DYN_SMEM(smem);
     unsigned *sh = reinterpret_cast<unsigned *>(smem);
@@ -626,7 +627,7 @@ __global__ __launch_bounds__(256) void k_hist_u16(const uint16_t *__restrict__ c
     const int64_t nvec = n / 8;
     const uint4 *v4 = reinterpret_cast<const uint4 *>(codes);
     const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += 4 * stride) {     // four loads in flight per thread
+    for (int64_t i = first / 8 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += 4 * stride) {     // four loads in flight per thread
         uint4 v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) if (i + u * stride < nvec) v[u] = v4[i + u * stride];
@@ -685,8 +686,9 @@ __global__ __launch_bounds__(256) void k_hist_u16(const uint16_t *__restrict__ c
 template <int DIR>
 __global__ __launch_bounds__(256) void k_permute(szh_geom3 G, const uint16_t *__restrict__ src, uint16_t *__restrict__ dst,
                                                  unsigned *col_zeros, int segb, unsigned *zcnt, unsigned *zpos, szh_rb_layout rb,
-                                                 unsigned *hist, unsigned hist_bins, int tile_elems)
-{   // rb.on: the natural-order side (`src` for DIR 0, `dst` for DIR 1) is in the ribbon order of szh_ribbon.h
+                                                 unsigned *hist, unsigned hist_bins, int tile_elems, int col0)
+{   // col0: the launch covers block columns col0 .. col0 + gridDim.x - 1 (a slice of the array along dim 0)
+    // rb.on: the natural-order side (`src` for DIR 0, `dst` for DIR 1) is in the ribbon order of szh_ribbon.h
     // hist (DIR 0 only, hist_bins > 0): the code histogram of Huffman.c:165-174 is taken here, while the codes sit in LDS anyway (one
     // pass over the code array less): per workgroup in LDS behind the tile, the peak symbol (radius = hist_bins / 2, most of a smooth
     // field) counted by ballot instead of by atomics, non-empty bins added to the global histogram at the end
@@ -697,7 +699,7 @@ __global__ __launch_bounds__(256) void k_permute(szh_geom3 G, const uint16_t *__
     uint16_t *tile = reinterpret_cast<uint16_t *>(smem);
     // (handing XCD x a contiguous run of the (segment, column) list, so that neighbouring columns -- which share the 128-byte lines of
     //  the natural / ribbon-order side -- meet in one L2, measured 1 % slower at 512^3: tools/gpu_ab_lib.sh)
-    const int col = blockIdx.x, segi = blockIdx.y;
+    const int col = (int)blockIdx.x + col0, segi = blockIdx.y;
     const int b0 = col / G.g1.num, b1 = col - b0 * G.g1.num;
     const int bkbeg = segi * segb, bkend = min(bkbeg + segb, G.g2.num);
     const int s0 = szh_blk_size(G.g0, b0), s1 = szh_blk_size(G.g1, b1);
