@@ -290,10 +290,13 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
         meta = sz_amd.make_meta(np.float32, err_mode=sz_amd.ABS, abs_bound=EB, vmin=0.0, vmax=0.0)
         prm = sz_amd.szhip_params(100, 0.99, 65536, 0, 1)
         if k_lanes not in pools:
-            # set-up, not a step: every lane's context allocates its workspaces (and loads its kernels) on its first calls -- two rounds
-            # over the lanes, or the first timed steps pay for it (2.9 ms per step instead of 1.8 with W = 3 and two lanes)
+            # set-up, not a step: every lane's context allocates its workspaces (and loads its kernels) on its first calls, and a new
+            # pool meets ONE stall of ~7 ms somewhere in its first ~10 calls (round 4, tools/gpu_r4_bimodal.sh: the lane's host thread
+            # sits inside the HIP runtime between recording the call's first event and enqueuing its first kernel; once per pool and
+            # process).  With two priming rounds that stall fell into the timed region in 5 of 10 runs on one box (247 instead of 341 GB/s
+            # at 10 steps); with twelve, in 0 of 10.
             pools[k_lanes] = sz_amd.HipPool(0 if getattr(args, "dry_run", False) else local_rank, k_lanes)
-            for _ in range(2 if getattr(args, "dry_run", False) else int(os.environ.get("SZ_BENCH_PRIME_ROUNDS", "2"))):
+            for _ in range(2 if getattr(args, "dry_run", False) else int(os.environ.get("SZ_BENCH_PRIME_ROUNDS", "12"))):
                 tks = [pools[k_lanes].submit(x.data_ptr(), True, (n, n, n), np.float32, EB, meta, prm, pool_bufs[q % len(pool_bufs)].data_ptr(), out_cap) for q in range(k_lanes)]
                 for tk in tks: pools[k_lanes].wait(tk)
         pool = pools[k_lanes]
@@ -398,6 +401,9 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
                                        "prequant_ms": round(float(np.mean([t.ms_prequant for t in sts])), 4),
                                        "entropy_ms": round(float(np.mean([t.ms_entropy for t in sts])), 4), "streams_identical": same}
         concurrent["timed_region_lanes"] = inflight
+        concurrent["timed_region_call_ms"] = [round(float(t.ms_total), 3) for t in stats_all]     # every call of the timed region, host clock inside the library
+        if os.environ.get("SZ_BENCH_CALL_PHASES"):
+            concurrent["timed_region_call_phases"] = [[round(float(v), 2) for v in (t.ms_prequant, t.ms_quant, t.ms_entropy, t.ms_host)] for t in stats_all]
         del ref_bytes
 
     # ---- BASELINE configs[2]: the adaptive case proper -- 512^3 M-field, half of the blocks regression (single GPU, outside the timed region)

@@ -422,8 +422,8 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     const T eb = (T)eb_in;
     const double t_begin = now_ms();
     double host_ms = 0;
-    const int tp_on = tune_int("SZ_HIP_TIMING", 0); double tp_t[24]; const char *tp_n[24]; int tp_k = 0;
-    auto TP = [&](const char *nm) { if (tp_on && tp_k < 24) { tp_t[tp_k] = now_ms() - t_begin; tp_n[tp_k++] = nm; } };
+    const int tp_on = tune_int("SZ_HIP_TIMING", 0); double tp_t[32]; const char *tp_n[32]; int tp_k = 0;
+    auto TP = [&](const char *nm) { if (tp_on && tp_k < 32) { tp_t[tp_k] = now_ms() - t_begin; tp_n[tp_k++] = nm; } };
     hipStream_t st = ctx->stream;
     szhip_stats S; memset(&S, 0, sizeof(S));
     S.n_elements = (uint64_t)n; S.n_blocks = (uint64_t)nb;
@@ -494,7 +494,9 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         hipLaunchKernelGGL((k_gather_mean<T>), dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, d_in, w, M, (T *)ctx->samples.p);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(ctx->pinned, ctx->samples.p, (size_t)M * sizeof(T), hipMemcpyDeviceToHost, st));
+        TP("mean enqueued");
         HIPCHK(hipStreamSynchronize(st));
+        TP("mean on host");
         double h0 = now_ms();
         const double smean = szhost_seq_mean(is_double, ctx->pinned, (size_t)M);
         host_ms += now_ms() - h0;
@@ -513,7 +515,9 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         u64 within = 0;
         HIPCHK(hipMemcpyAsync(h_hist, d_rh, (size_t)(max_radius + 8192) * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(&within, sm + SM_WITHIN, 8, hipMemcpyDeviceToHost, st));
+        TP("sample enqueued");
         HIPCHK(hipStreamSynchronize(st));
+        TP("sample on host");
         h0 = now_ms();
         u64 sample_count = 0;
         for (unsigned i = 0; i < max_radius; ++i) sample_count += h_hist[i];
