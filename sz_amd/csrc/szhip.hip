@@ -44,6 +44,8 @@ struct szhip_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // the fit + selection pass runs here, concurrently with the interval optimiser's sampling and host decisions
     hipEvent_t ev_in = nullptr, ev_fit = nullptr;
+    int settle_probes = 0, settle_rejected = 0;   // settle_streams: queue probes made, streams replaced
+    int side_prio = 0;               // 1: stream2 at the lowest, stream3 at the highest stream priority (create_ctx)
     hipStream_t stream3 = nullptr;   // the block-ordering pass of finished tile rows, while the sweep is still running on `stream` (created on first use)
     hipEvent_t ev_perm = nullptr;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -186,6 +188,75 @@ int probe_streams(szhip_ctx *ctx)
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->streams_independent = waited < 2.0 ? 1 : 0;
     return SZHIP_OK;
+}
+
+int tune_int(const char *name, int def);
+// Do kernels on `b` run while a kernel on `a` is still running?  (As above, with a kernel instead of the copy.)  *shared = 1: no, the two
+// streams sit on one hardware queue.
+static int probe_pair(szhip_ctx *ctx, hipStream_t a, hipStream_t b, int *shared)
+{
+    TRY(ensure_coherent(ctx, 256));
+    TRY(ensure(ctx, ctx->small, SM_COUNT * 8));
+    volatile unsigned long long *flag = (volatile unsigned long long *)((char *)ctx->coh + 128);
+    *flag = 0;
+    HIPCHK(hipStreamSynchronize(a)); HIPCHK(hipStreamSynchronize(b));
+    u64 *sm = (u64 *)ctx->small.p;
+    hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(1), 0, a, (const unsigned long long *)flag, (unsigned long long *)(sm + SM_SCRATCH));
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_probe_touch, dim3(1), dim3(1), 0, b, (unsigned long long *)(sm + SM_SCRATCH + 1));
+    HIPCHK(hipGetLastError());
+    const double t0 = now_ms();
+    HIPCHK(hipStreamSynchronize(b));
+    const double waited = now_ms() - t0;
+    *flag = 1;                                                      // release the kernel
+    HIPCHK(hipStreamSynchronize(a));
+    *shared = waited < 2.0 ? 0 : 1;
+    return SZHIP_OK;
+}
+
+// HIP maps the streams of a process onto a few hardware queues, and two streams on one queue run their kernels one after the other.  Which
+// streams share a queue is the luck of what else the process has created.  Measured (round 4, 512^3 float32, one call after the other):
+// 236 - 241 GB/s when a context's second stream (the fit pass beside the sampling chain, the histogram beside the block ordering) or third stream
+// (the slices' passes beside the sweep) sat on the main stream's queue, 274 - 279 otherwise; two lanes of a pool whose main streams shared a queue:
+// 248 GB/s against 340.  So a new context PROBES: a kernel that waits (bounded, ~4 ms) on the one stream, a trivial kernel on the other; a side
+// stream that does not get through is replaced by a freshly created one (the rejected streams stay alive until the search is over, so that the
+// runtime's next choice is another queue), a few times over.  `mains`: the main streams of the pool's earlier lanes (a lane's streams must
+// not share a queue with those either).  SZ_HIP_SETTLE=0: take the streams as they come.
+static void settle_one(szhip_ctx *ctx, hipStream_t *victim, const std::vector<hipStream_t> &against, std::vector<hipStream_t> &rejected, int *probes)
+{
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        bool clash = false;
+        for (hipStream_t a : against) {
+            if (a == *victim) continue;
+            int shared = 0;
+            ++*probes;
+            if (probe_pair(ctx, a, *victim, &shared) != SZHIP_OK) return;
+            if (shared) { clash = true; break; }
+        }
+        if (!clash) return;
+        hipStream_t fresh = nullptr;
+        if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) return;
+        rejected.push_back(*victim);
+        *victim = fresh;
+    }
+}
+static void settle_streams(szhip_ctx *ctx, const hipStream_t *mains, int n_mains, bool third = true)
+{
+#ifdef SZH_SYNC_LAUNCH
+    (void)ctx; (void)mains; (void)n_mains; (void)third;             // (the CPU shim runs every kernel at its launch)
+#else
+    if (!tune_int("SZ_HIP_SETTLE", 1)) return;
+    std::vector<hipStream_t> rejected, against(mains, mains + n_mains);
+    int probes = 0;
+    if (n_mains) settle_one(ctx, &ctx->stream, against, rejected, &probes);      // this lane's main stream against the earlier lanes'
+    against.push_back(ctx->stream);
+    settle_one(ctx, &ctx->stream2, against, rejected, &probes);
+    if (third && !ctx->stream3 && hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess) ctx->stream3 = nullptr;
+    if (third && ctx->stream3) { against.push_back(ctx->stream2); settle_one(ctx, &ctx->stream3, against, rejected, &probes); }
+    ctx->settle_probes = probes; ctx->settle_rejected = (int)rejected.size();
+    for (hipStream_t r : rejected) hipStreamDestroy(r);
+    if (tune_int("SZ_HIP_SETTLE_LOG", 0)) fprintf(stderr, "szhip: streams settled after %d probes, %d streams replaced\n", probes, (int)rejected.size());
+#endif
 }
 
 // ---- bulk copies between pageable host memory and the device.
@@ -717,14 +788,21 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     // Measured (round 4, 512^3 float, one call after the other, same box): 255 GB/s with 1 slice, 276 with 4, 251 - 275 with 8 (the slices'
     // kernels take 2 - 4 x their lone time beside the sweep and slow it by ~0.1 ms; more slices, more of that).
     const int slices_req = tune_int("SZ_HIP_SLICES", ctx->gate ? 1 : 4);
-    const int slice_from = tune_int("SZ_HIP_SLICE_FROM", 0);          // per cent of the tile rows that the first slice covers at least
+    const int slice_from = tune_int("SZ_HIP_SLICE_FROM", 0);          // even parts: per cent of the tile rows that the first slice covers at least
+    const int slice_geom = tune_int("SZ_HIP_SLICE_GEOM", 0);
     const bool sliced = use_ribbon && slices_req > 1 && !tune_int("SZ_HIP_FUSE_HIST", 0);
     unsigned *tile_done = nullptr;
     if (sliced) {
         const size_t tiles = (size_t)((G.g0.count + szh_rb_shape<T>::W * szh_rb_shape<T>::R - 1) / (szh_rb_shape<T>::W * szh_rb_shape<T>::R)) * rbl.nTJ;
         TRY(ensure_coherent(ctx, 512 + tiles * 4));
         tile_done = (unsigned *)((char *)ctx->coh + 512);
-        if (!ctx->stream3) HIPCHK(hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
+        if (!ctx->stream3) {
+            const int sprio = ctx->side_prio;
+            int plo = 0, phi = 0;
+            if (sprio && hipDeviceGetStreamPriorityRange(&plo, &phi) != hipSuccess) { plo = 0; phi = 0; }
+            if (sprio) HIPCHK(hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, sprio == 2 ? plo : phi));
+            else HIPCHK(hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
+        }
         if (!ctx->ev_perm) HIPCHK(hipEventCreateWithFlags(&ctx->ev_perm, hipEventDisableTiming));
     }
     {
@@ -863,8 +941,16 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         bool sweep_over = false;                                   // the sweep's end event has been seen: every tile is there
         int b0_done = 0; int64_t hist_first = 0;
         for (int sl = 0; sl < NS; ++sl) {
-            const int ti0 = std::min(nTI - 1, (int)((int64_t)nTI * slice_from / 100));       // rows [0, ti0) ride with the first slice
-            const int ti_lo = sl == 0 ? 0 : ti0 + (int)((int64_t)(nTI - ti0) * sl / NS), ti_hi = ti0 + (int)((int64_t)(nTI - ti0) * (sl + 1) / NS);
+            // slice bounds: halving (the first slice takes half of the tile rows, the next half of the rest, ...: the early slices have the
+            // rest of the sweep to hide in, the LAST one runs after the sweep's end and should be small), or even parts (SZ_HIP_SLICE_GEOM=0)
+            auto bound = [&](int k) -> int {                                  // first tile row of slice k (k = NS: nTI)
+                if (k <= 0) return 0;
+                if (k >= NS) return nTI;
+                if (slice_geom) return std::max(k, nTI - std::max(1, nTI >> k));
+                const int ti0 = std::min(nTI - 1, (int)((int64_t)nTI * slice_from / 100));       // rows [0, ti0) ride with the first slice
+                return ti0 + (int)((int64_t)(nTI - ti0) * k / NS);
+            };
+            const int ti_lo = bound(sl), ti_hi = std::max(bound(sl + 1), ti_lo);
             for (int t = ti_lo * nTJ; t < ti_hi * nTJ && !sweep_over; ++t) {
                 unsigned spins = 0;
                 while (__atomic_load_n(&tile_done[t], __ATOMIC_ACQUIRE) != ep) {
@@ -3075,7 +3161,12 @@ int szhip_decompress_fast(szhip_ctx *ctx, int dtype, const unsigned char *stream
     return rc;
 }
 
-int szhip_create(szhip_ctx **out, int device)
+// side_prio: the second / third stream at the lowest / highest priority the device offers.  HIP maps the streams of one priority onto a few
+// hardware queues, and whether two streams of a context share one is the luck of what else the process has created (measured, round 4, one call
+// after the other at 512^3: 236 - 241 GB/s when the fit pass and the sampling chain, or the sweep and the slices' passes, sat on one queue,
+// 274 - 279 otherwise); streams of different priorities never share one.  Lanes of a pool keep equal priorities (a lane whose main stream
+// outranks the other's would always be dispatched first).
+static int create_ctx(szhip_ctx **out, int device, int side_prio, int main_high = 0)
 {
     if (!out) return SZHIP_ERR_ARG;
     int count = 0;
@@ -3088,14 +3179,28 @@ int szhip_create(szhip_ctx **out, int device)
     szhip_ctx *ctx = new szhip_ctx();
     ctx->device = device;
     { int c = 0; if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && c > 0) ctx->cus = c; }
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    int mlo = 0, mhi = 0;
+    if (hipSetDevice(device) != hipSuccess || (main_high && hipDeviceGetStreamPriorityRange(&mlo, &mhi) != hipSuccess) ||
+        (main_high ? hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, mhi) : hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
         delete ctx; return SZHIP_ERR_NODEVICE;
     }
     for (int i = 0; i < 6; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return SZHIP_ERR_NODEVICE; }
-    if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming) != hipSuccess ||
+    // (SZ_HIP_STREAM_PRIO: 0 = equal priorities, 1 = second stream low / third high, 2 = the other way round)
+    const int sprio = tune_int("SZ_HIP_STREAM_PRIO", side_prio);
+    ctx->side_prio = sprio;
+    int plo = 0, phi = 0;
+    if (sprio && hipDeviceGetStreamPriorityRange(&plo, &phi) != hipSuccess) { plo = 0; phi = 0; }
+    if ((sprio ? hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, sprio == 2 ? phi : plo) : hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking)) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fit, hipEventDisableTiming) != hipSuccess) { delete ctx; return SZHIP_ERR_NODEVICE; }
     *out = ctx;
     return SZHIP_OK;
+}
+
+int szhip_create(szhip_ctx **out, int device)
+{
+    const int rc = create_ctx(out, device, 0);
+    if (rc == SZHIP_OK) settle_streams(*out, nullptr, 0);
+    return rc;
 }
 
 void szhip_destroy(szhip_ctx *ctx)
@@ -3167,9 +3272,12 @@ int szhip_pool_create(szhip_pool **out, int device, int lanes)
     szhip_pool *p = new szhip_pool();
     for (int i = 0; i < lanes; ++i) {
         szhip_ctx *c = nullptr;
-        const int rc = szhip_create(&c, device);
+        // (SZ_HIP_LANE_PRIO=1, development: every other lane's main stream at the highest priority, so that two lanes never share a hardware queue)
+        const int rc = create_ctx(&c, device, 0, lanes > 1 && tune_int("SZ_HIP_LANE_PRIO", 0) ? (i & 1) : 0);
         if (rc != SZHIP_OK) { for (szhip_ctx *x : p->ctx) szhip_destroy(x); delete p; return rc; }
         if (lanes > 1) { c->gate = &p->gate; if (hipEventCreateWithFlags(&c->ev_gate, hipEventDisableTiming) != hipSuccess) c->gate = nullptr; }
+        // (against the earlier lanes' main AND second streams: a lane's fit pass behind another lane's sweep is as bad as two sweeps in a row)
+        { std::vector<hipStream_t> mains; for (szhip_ctx *x : p->ctx) { mains.push_back(x->stream); mains.push_back(x->stream2); } settle_streams(c, mains.data(), (int)mains.size(), lanes == 1); }
         p->ctx.push_back(c);
     }
     p->jobs.resize(64); p->used.assign(64, false);

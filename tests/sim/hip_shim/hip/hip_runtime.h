@@ -127,6 +127,8 @@ inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v 
 template <class K> inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *nb, K, int, size_t) { *nb = 2; return hipSuccess; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, int) { *s = (void *)1; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, int, int) { *s = (void *)1; return hipSuccess; }
+inline hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo = 0; *hi = 0; return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (void *)1; return hipSuccess; }
 #define hipEventDisableTiming 2
