@@ -977,7 +977,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
             if (b0_hi > b0_done) {
                 hipLaunchKernelGGL((k_permute<0>), dim3((unsigned)((b0_hi - b0_done) * G.g1.num), nseg), dim3(256), ((tile_el + 1) & ~(size_t)1) * 2 + 16, ctx->stream3, G,
                                    (const uint16_t *)d_nat, d_blk, (unsigned *)ctx->col_zeros.p, segb, (unsigned *)ctx->zcnt.p, (unsigned *)ctx->zpos.p, rbl, d_hist, 0u,
-                                   (int)tile_el, b0_done * G.g1.num);
+                                   (int)tile_el, b0_done * G.g1.num, 0);
                 b0_done = b0_hi;
             }
             HIPCHK(hipGetLastError());
@@ -1000,9 +1000,15 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         fuse_hist = intervals <= 4096 && tune_int("SZ_HIP_FUSE_HIST", 0);
         const size_t tb = tile_bytes(G, segb, 2), tile_el = (tb + 1) / 2;
         if (fuse_hist) HIPCHK(hipMemsetAsync(d_hist, 0, (size_t)intervals * 4, st));
+        // development (timing only): an EXTRA launch in front of the real one that stops early -- 8: after the prologue; 4: after the gather; 5: gather
+        // without its loads; 6: gather without its LDS stores.  It leaves nothing behind that the real launch does not overwrite.
+        if (const int pdbg = tune_int("SZ_HIP_PERM_DBG", 0)) {
+            hipLaunchKernelGGL((k_permute<0>), dim3(ncols, nseg), dim3(256), ((tile_el + 1) & ~(size_t)1) * 2 + 16, st, G, (const uint16_t *)d_nat,
+                               d_blk, (unsigned *)ctx->col_zeros.p, segb, (unsigned *)ctx->zcnt.p, (unsigned *)ctx->zpos.p, rbl, d_hist, 0u, (int)tile_el, 0, (pdbg & 8) ? 8 : (pdbg | 4));
+        }
         hipLaunchKernelGGL((k_permute<0>), dim3(ncols, nseg), dim3(256), ((tile_el + 1) & ~(size_t)1) * 2 + (fuse_hist ? (size_t)intervals * 4 : 0) + 16, st, G, (const uint16_t *)d_nat,
                            d_blk, (unsigned *)ctx->col_zeros.p, segb, (unsigned *)ctx->zcnt.p, (unsigned *)ctx->zpos.p, rbl,
-                           d_hist, fuse_hist ? intervals : 0u, (int)tile_el, 0);
+                           d_hist, fuse_hist ? intervals : 0u, (int)tile_el, 0, 0);
         if (fuse_hist) {
             HIPCHK(hipMemcpyAsync(h_hist, d_hist, (size_t)intervals * 4, hipMemcpyDeviceToHost, st));
             HIPCHK(hipEventRecord(ctx->ev_fit, st));

@@ -627,6 +627,10 @@ __global__ __launch_bounds__(256) void k_hist_u16(const uint16_t *__restrict__ c
     const int64_t nvec = n / 8;
     const uint4 *v4 = reinterpret_cast<const uint4 *>(codes);
     const int64_t stride = (int64_t)gridDim.x * 256;
+    auto is_p2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+    const bool pow2 = rb.on && is_p2(rb.U / 8) && is_p2(rb.R) && is_p2(rb.W) && (nvec >> 6) < (int64_t)0xffffffffll;
+    const int lg_gv = pow2 ? lg(rb.U / 8) : 0, lg_R = pow2 ? lg(rb.R) : 0, lg_W = pow2 ? lg(rb.W) : 0;
     for (int64_t i = first / 8 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += 4 * stride) {     // four loads in flight per thread
         uint4 v[4];
 #pragma unroll
@@ -638,13 +642,18 @@ __global__ __launch_bounds__(256) void k_hist_u16(const uint16_t *__restrict__ c
             int klo = 0, khi = 8;                                 // which of the group's 8 codes count
             if (rb.on) {
                 // group g of the ribbon order: [tile][trip][w][r][v][lane] -> k of its first code, row and column of the array
-                int64_t g = i + u * stride;
-                const int ln = (int)(g & 63); g >>= 6;
-                const int gv = rb.U / 8, vv = (int)(g % gv); g /= gv;
-                const int rr = (int)(g % rb.R); g /= rb.R;
-                const int w = (int)(g % rb.W); g /= rb.W;
-                const int ntr = rb.NT / rb.U, trip = (int)(g % ntr); g /= ntr;
-                const int TJ = (int)(g % rb.nTJ), TI = (int)(g / rb.nTJ);
+                // (32-bit arithmetic: five 64-bit divisions per group were more than half of this pass, 0.16 ms against 0.07 for natural-order
+                //  codes; U / 8, R and W are powers of two in every shape of szh_rb_shape, `pow2` says so)
+                const int64_t g64 = i + u * stride;
+                const int ln = (int)(g64 & 63);
+                unsigned g = (unsigned)(g64 >> 6);
+                const unsigned gv = (unsigned)rb.U / 8;
+                int vv, rr, w;
+                if (pow2) { vv = (int)(g & (gv - 1)); g >>= lg_gv; rr = (int)(g & ((unsigned)rb.R - 1)); g >>= lg_R; w = (int)(g & ((unsigned)rb.W - 1)); g >>= lg_W; }
+                else { vv = (int)(g % gv); g /= gv; rr = (int)(g % (unsigned)rb.R); g /= (unsigned)rb.R; w = (int)(g % (unsigned)rb.W); g /= (unsigned)rb.W; }
+                const unsigned ntr = (unsigned)(rb.NT / rb.U);
+                const unsigned g1 = g / ntr; const int trip = (int)(g - g1 * ntr);
+                const unsigned g2 = g1 / (unsigned)rb.nTJ; const int TJ = (int)(g1 - g2 * (unsigned)rb.nTJ), TI = (int)g2;
                 const int row = (TI * rb.W + w) * rb.R + rr, col = TJ * 64 + ln;
                 const int k0 = trip * rb.U + vv * 8 - w * (rb.R - 1) - ln - rr;
                 if (row >= r0 || col >= r1) khi = 0;
@@ -683,16 +692,22 @@ __global__ __launch_bounds__(256) void k_hist_u16(const uint16_t *__restrict__ c
 // It also notes WHERE the zero codes are (segment-local block-order index, up to SZH_ZCAP per workgroup, unordered), so that
 // k_unpred does not have to read the code array again to find them.
 #define SZH_ZCAP 128
+#define SZH_PERM_ROWS 256   /* rows of a block column whose ribbon-order constants k_permute<0> keeps in LDS */
+#define SZH_PERM_KTAB 1024  /* longest segment along dim 2 whose block-order places it keeps there */
 template <int DIR>
 __global__ __launch_bounds__(256) void k_permute(szh_geom3 G, const uint16_t *__restrict__ src, uint16_t *__restrict__ dst,
                                                  unsigned *col_zeros, int segb, unsigned *zcnt, unsigned *zpos, szh_rb_layout rb,
-                                                 unsigned *hist, unsigned hist_bins, int tile_elems, int col0)
-{   // col0: the launch covers block columns col0 .. col0 + gridDim.x - 1 (a slice of the array along dim 0)
+                                                 unsigned *hist, unsigned hist_bins, int tile_elems, int col0, int dbg = 0)
+{   // dbg (development, timing only): 1 = no loads in the gather, 2 = no LDS stores in the gather, 4 = no block-order side, 8 = return after the prologue
+   // col0: the launch covers block columns col0 .. col0 + gridDim.x - 1 (a slice of the array along dim 0)
     // rb.on: the natural-order side (`src` for DIR 0, `dst` for DIR 1) is in the ribbon order of szh_ribbon.h
     // hist (DIR 0 only, hist_bins > 0): the code histogram of Huffman.c:165-174 is taken here, while the codes sit in LDS anyway (one
     // pass over the code array less): per workgroup in LDS behind the tile, the peak symbol (radius = hist_bins / 2, most of a smooth
     // field) counted by ballot instead of by atomics, non-empty bins added to the global histogram at the end
     __shared__ unsigned zc_s, zp_s[SZH_ZCAP];
+    __shared__ int64_t prm_base[SZH_PERM_ROWS];
+    __shared__ int prm_off[SZH_PERM_ROWS];
+    __shared__ unsigned prm_ktab[SZH_PERM_KTAB];
     if (threadIdx.x == 0) zc_s = 0;
     __syncthreads();
     SZH_DYN_SMEM(smem);
@@ -718,19 +733,80 @@ __global__ __launch_bounds__(256) void k_permute(szh_geom3 G, const uint16_t *__
     int nE = G.g2.split - bkbeg; if (nE < 0) nE = 0; if (nE > bkend - bkbeg) nE = bkend - bkbeg;
     const int esz = rows * G.g2.early, lsz = rows * G.g2.late, eregion = nE * esz;
     // block-order element e of this segment -> tile index
+    // (divisions by the four small workgroup-wide constants as multiplications: e < 2^16 and d < 2^12 make floor(e * ceil(2^28 / d) / 2^28) exact;
+    //  a tile of more than 65535 elements keeps the plain divisions)
+    const bool fdiv_ok0 = total < 65536 && esz > 0 && lsz > 0 && esz < 4096 && lsz < 4096;
+    const bool fdiv_ok = fdiv_ok0 && G.g2.early > 0 && G.g2.late > 0 && G.g2.early < 4096 && G.g2.late < 4096;
+    const unsigned m_esz = fdiv_ok ? (unsigned)(((1u << 28) + (unsigned)esz - 1) / (unsigned)esz) : 0u, m_lsz = fdiv_ok ? (unsigned)(((1u << 28) + (unsigned)lsz - 1) / (unsigned)lsz) : 0u;
+    const unsigned m_e2 = fdiv_ok ? (unsigned)(((1u << 28) + (unsigned)G.g2.early - 1) / (unsigned)G.g2.early) : 0u, m_l2 = fdiv_ok ? (unsigned)(((1u << 28) + (unsigned)G.g2.late - 1) / (unsigned)G.g2.late) : 0u;
+    auto qdiv = [&](int e, int d, unsigned m) -> int { return fdiv_ok ? (int)(((u64)(unsigned)e * m) >> 28) : e / d; };
     auto locate = [&](int e, int &row, int &kk, int &s2, int &koff) {
-        if (e < eregion) { const int bl = e / esz; const int rem = e - bl * esz; s2 = G.g2.early; koff = bl * s2; row = rem / s2; kk = rem - row * s2; }
-        else { const int e2 = e - eregion; const int bl = e2 / lsz; const int rem = e2 - bl * lsz; s2 = G.g2.late; koff = nE * G.g2.early + bl * s2; row = rem / s2; kk = rem - row * s2; }
+        if (e < eregion) { const int bl = qdiv(e, esz, m_esz); const int rem = e - bl * esz; s2 = G.g2.early; koff = bl * s2; row = qdiv(rem, s2, m_e2); kk = rem - row * s2; }
+        else { const int e2 = e - eregion; const int bl = qdiv(e2, lsz, m_lsz); const int rem = e2 - bl * lsz; s2 = G.g2.late; koff = nE * G.g2.early + bl * s2; row = qdiv(rem, s2, m_l2); kk = rem - row * s2; }
     };
+    // place of (row r, k = kbeg + kl) in the segment's block order, and how many codes of its run (this row of this block) start there
+    const int ewid = nE * G.g2.early;
+    auto kpos = [&](int kl, int r, int &left) -> int {
+        if (kl < ewid) { const int bl = qdiv(kl, G.g2.early, m_e2), kk = kl - bl * G.g2.early; left = G.g2.early - kk; return bl * esz + r * G.g2.early + kk; }
+        const int kl2 = kl - ewid, bl = qdiv(kl2, G.g2.late, m_l2), kk = kl2 - bl * G.g2.late; left = G.g2.late - kk; return eregion + bl * lsz + r * G.g2.late + kk;
+    };
+    if (dbg & 8) return;
     unsigned zeros = 0;
     unsigned *const lh = reinterpret_cast<unsigned *>(tile + ((tile_elems + 1) & ~1));
     const bool do_hist = DIR == 0 && hist_bins > 0;
     const unsigned peak = hist_bins / 2;
     unsigned peak_cnt = 0;
     if (do_hist) { for (unsigned b = threadIdx.x; b < hist_bins; b += 256) lh[b] = 0; }
-    if (DIR == 0 && rb.on) {
-        // gather from ribbon order: the codes of a row lie in groups of 8 consecutive k (16 aligned bytes), one group per 8 steps
-        // of the wavefront that made them; one thread per (row, group)
+    const unsigned rb_gv = rb.on ? (unsigned)rb.U / 8 : 1u;
+    // round 4: the fast form of DIR 0 from ribbon order keeps the tile in BLOCK ORDER (element e of the segment at tile[head + e]), so the
+    // per-element work -- which block, which place in it -- is done once, where the gather scatters its 2-byte pieces into LDS anyway, and
+    // the block-order side below is a 16-byte LDS read and a 16-byte store per eight codes.  (Measured before, 0.295 ms in all: 0.078 for the
+    // launch of 21 675 workgroups and their prologue, 0.094 the gather, 0.123 the block-order side with its walk over rows and runs.)
+    const int head = (int)(base & 7);                             // elements of the first 16-byte group that belong to the previous segment
+    const bool blocked = DIR == 0 && rb.on && !do_hist && fdiv_ok && rows <= SZH_PERM_ROWS && (rb_gv & (rb_gv - 1)) == 0 && klen / 8 + 2 <= 256 && klen <= SZH_PERM_KTAB && total + 16 <= tile_elems;
+    if (blocked) {
+        // gather from ribbon order, round 4: what depends on the ROW only (tile, wavefront, lane -> where its groups start, its step
+        // shift) is worked out once per row into LDS, and the threads are laid out as (row, group) with a power-of-two pitch -- the five
+        // divisions per 16-byte group of the form below were most of this pass's instructions (0.33 ms, 45 instructions per code)
+        const int ng = klen / 8 + 2, WR = rb.W * rb.R;
+        int ngp = 1; while (ngp < ng) ngp <<= 1;
+        int lg_gv = 0; while ((1u << lg_gv) < rb_gv) ++lg_gv;
+        const int64_t trip_stride = (int64_t)rb.W * rb.R * rb_gv * 512;
+        for (int r = threadIdx.x; r < rows; r += 256) {
+            const int i = o0 + r / s1, j = o1 + r % s1;
+            const int TI = i / WR, q = i - TI * WR, w = q / rb.R, rr = q - w * rb.R, TJ = j >> 6, ln = j & 63;
+            prm_off[r] = w * (rb.R - 1) + ln + rr;
+            prm_base[r] = ((int64_t)TI * rb.nTJ + TJ) * szh_rb_tile_elems(rb) + (int64_t)(w * rb.R + rr) * rb_gv * 512 + ln * 8;
+        }
+        for (int kl = threadIdx.x; kl < klen; kl += 256) { int left; const int a = kpos(kl, 0, left); prm_ktab[kl] = (unsigned)a | ((unsigned)(kl < ewid ? G.g2.early : G.g2.late) << 16); }
+        __syncthreads();
+        const int gl = threadIdx.x & (ngp - 1), rstep = 256 / ngp;
+        if (gl < ng)
+            for (int r = threadIdx.x / ngp; r < rows; r += rstep) {
+                const int off = prm_off[r];
+                const int tt8 = ((kbeg + off) >> 3) + gl;
+                const int k0 = tt8 * 8 - off;
+                if (k0 >= kend) continue;
+                const uint4 wv = (dbg & 1) ? make_uint4(off, tt8, k0, 1) : *reinterpret_cast<const uint4 *>(src + prm_base[r] + (int64_t)(tt8 >> lg_gv) * trip_stride + (int64_t)(tt8 & (int)(rb_gv - 1)) * 512);
+                uint16_t v[8]; __builtin_memcpy(v, &wv, 16);
+                if (dbg & 2) { if (wv.x == 0xdeadbeefu) tile[0] = 1; continue; }
+                // place of code (r, k): head + A[k - kbeg] + r * width[k - kbeg] (prm_ktab: what depends on k only, once per workgroup)
+                const int kl0 = k0 - kbeg;
+                uint16_t *const trow = tile + head;
+                if (kl0 >= 0 && kl0 + 8 <= klen) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const unsigned t = prm_ktab[kl0 + e]; trow[(t & 0xffffu) + (unsigned)r * (t >> 16)] = v[e]; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int kl = kl0 + e;
+                        if (kl >= 0 && kl < klen) { const unsigned t = prm_ktab[kl]; trow[(t & 0xffffu) + (unsigned)r * (t >> 16)] = v[e]; }
+                    }
+                }
+            }
+        __syncthreads();
+    } else if (DIR == 0 && rb.on) {
+        // (the general form: one thread per (row, group), everything by division)
         const int ng = klen / 8 + 2, WR = rb.W * rb.R;
         for (int p = threadIdx.x; p < rows * ng; p += 256) {
             const int r = p / ng, gl = p - r * ng;
@@ -755,8 +831,25 @@ __global__ __launch_bounds__(256) void k_permute(szh_geom3 G, const uint16_t *__
         __syncthreads();
     }
     // block-order side: the segment is one contiguous range [base, base + total); 16-byte groups by absolute address
-    {
-        const int head = (int)(base & 7);                         // elements of the first group that belong to the previous segment
+    if (blocked && !(dbg & 4)) {
+        const int ngroups = (head + total + 7) / 8;
+        for (int g = threadIdx.x; g < ngroups; g += 256) {
+            const int e0 = g * 8 - head;                           // may be negative in the first group
+            const int elo = e0 < 0 ? 0 : e0, ehi = e0 + 8 > total ? total : e0 + 8;
+            const uint4 w = *reinterpret_cast<const uint4 *>(tile + g * 8);
+            uint16_t v[8]; __builtin_memcpy(v, &w, 16);
+#pragma unroll
+            for (int q8 = 0; q8 < 8; ++q8) {
+                const int e = e0 + q8;
+                if (e >= elo && e < ehi && v[q8] == 0) { ++zeros; const unsigned q = atomicAdd(&zc_s, 1u); if (q < SZH_ZCAP) zp_s[q] = (unsigned)e; }
+            }
+            if (ehi - elo == 8) *reinterpret_cast<uint4 *>(dst + base + e0) = w;
+            else {
+#pragma unroll
+                for (int q8 = 0; q8 < 8; ++q8) { const int e = e0 + q8; if (e >= elo && e < ehi) dst[base + e] = v[q8]; }
+            }
+        }
+    } else if (!(dbg & 4)) {
         const int ngroups = (head + total + 7) / 8;
         for (int g = threadIdx.x; g < ngroups; g += 256) {
             const int e0 = g * 8 - head;                           // may be negative in the first group
