@@ -975,7 +975,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
             if (sl == NS - 1) b0_hi = G.g0.num;
             else while (b0_hi < G.g0.num && (b0_hi + 1 < G.g0.num ? szh_blk_start(G.g0, b0_hi + 1) : G.g0.count) <= rows_ready) ++b0_hi;
             if (b0_hi > b0_done) {
-                hipLaunchKernelGGL((k_permute<0>), dim3((unsigned)((b0_hi - b0_done) * G.g1.num), nseg), dim3(256), ((tile_el + 1) & ~(size_t)1) * 2 + 16, ctx->stream3, G,
+                hipLaunchKernelGGL((k_permute<0>), dim3((unsigned)((b0_hi - b0_done) * G.g1.num), std::min(nseg, std::max(1, tune_int("SZ_HIP_PERM_Y", 1)))), dim3(256), ((tile_el + 1) & ~(size_t)1) * 2 + 16, ctx->stream3, G,
                                    (const uint16_t *)d_nat, d_blk, (unsigned *)ctx->col_zeros.p, segb, (unsigned *)ctx->zcnt.p, (unsigned *)ctx->zpos.p, rbl, d_hist, 0u,
                                    (int)tile_el, b0_done * G.g1.num, 0);
                 b0_done = b0_hi;
@@ -1003,10 +1003,10 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         // development (timing only): an EXTRA launch in front of the real one that stops early -- 8: after the prologue; 4: after the gather; 5: gather
         // without its loads; 6: gather without its LDS stores.  It leaves nothing behind that the real launch does not overwrite.
         if (const int pdbg = tune_int("SZ_HIP_PERM_DBG", 0)) {
-            hipLaunchKernelGGL((k_permute<0>), dim3(ncols, nseg), dim3(256), ((tile_el + 1) & ~(size_t)1) * 2 + 16, st, G, (const uint16_t *)d_nat,
+            hipLaunchKernelGGL((k_permute<0>), dim3(ncols, std::min(nseg, std::max(1, tune_int("SZ_HIP_PERM_Y", 1)))), dim3(256), ((tile_el + 1) & ~(size_t)1) * 2 + 16, st, G, (const uint16_t *)d_nat,
                                d_blk, (unsigned *)ctx->col_zeros.p, segb, (unsigned *)ctx->zcnt.p, (unsigned *)ctx->zpos.p, rbl, d_hist, 0u, (int)tile_el, 0, (pdbg & 8) ? 8 : (pdbg | 4));
         }
-        hipLaunchKernelGGL((k_permute<0>), dim3(ncols, nseg), dim3(256), ((tile_el + 1) & ~(size_t)1) * 2 + (fuse_hist ? (size_t)intervals * 4 : 0) + 16, st, G, (const uint16_t *)d_nat,
+        hipLaunchKernelGGL((k_permute<0>), dim3(ncols, std::min(nseg, std::max(1, tune_int("SZ_HIP_PERM_Y", 1)))), dim3(256), ((tile_el + 1) & ~(size_t)1) * 2 + (fuse_hist ? (size_t)intervals * 4 : 0) + 16, st, G, (const uint16_t *)d_nat,
                            d_blk, (unsigned *)ctx->col_zeros.p, segb, (unsigned *)ctx->zcnt.p, (unsigned *)ctx->zpos.p, rbl,
                            d_hist, fuse_hist ? intervals : 0u, (int)tile_el, 0, 0);
         if (fuse_hist) {
@@ -1427,7 +1427,7 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
         const int nseg = (G.g2.num + segb - 1) / segb;
         TRY(ensure(ctx, ctx->zcnt, (size_t)ncols * nseg * 4));
         TRY(ensure(ctx, ctx->zpos, (size_t)ncols * nseg * SZH_ZCAP * 4));
-        hipLaunchKernelGGL((k_permute<1>), dim3(ncols, nseg), dim3(256), tile_bytes(G, segb, 2), st, G, (const uint16_t *)d_blk, d_nat,
+        hipLaunchKernelGGL((k_permute<1>), dim3(ncols, std::min(nseg, std::max(1, tune_int("SZ_HIP_PERM_Y", nseg)))), dim3(256), tile_bytes(G, segb, 2), st, G, (const uint16_t *)d_blk, d_nat,
                            (unsigned *)ctx->col_zeros.p, segb, (unsigned *)ctx->zcnt.p, (unsigned *)ctx->zpos.p, rbl, (unsigned *)nullptr, 0u, 0, 0);
         perm_segb = segb; perm_nseg = nseg;
         HIPCHK(hipGetLastError());

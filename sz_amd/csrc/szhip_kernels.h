@@ -693,11 +693,10 @@ __global__ __launch_bounds__(256) void k_hist_u16(const uint16_t *__restrict__ c
 // k_unpred does not have to read the code array again to find them.
 #define SZH_ZCAP 128
 #define SZH_PERM_ROWS 256   /* rows of a block column whose ribbon-order constants k_permute<0> keeps in LDS */
-#define SZH_PERM_KTAB 1024  /* longest segment along dim 2 whose block-order places it keeps there */
 template <int DIR>
-__global__ __launch_bounds__(256) void k_permute(szh_geom3 G, const uint16_t *__restrict__ src, uint16_t *__restrict__ dst,
-                                                 unsigned *col_zeros, int segb, unsigned *zcnt, unsigned *zpos, szh_rb_layout rb,
-                                                 unsigned *hist, unsigned hist_bins, int tile_elems, int col0, int dbg = 0)
+__device__ __forceinline__ void permute_body(const szh_geom3 &G, const uint16_t *__restrict__ src, uint16_t *__restrict__ dst,
+                                             unsigned *col_zeros, int segb, unsigned *zcnt, unsigned *zpos, const szh_rb_layout &rb,
+                                             unsigned *hist, unsigned hist_bins, int tile_elems, int col0, int dbg, const int segi, const int nseg_all)
 {   // dbg (development, timing only): 1 = no loads in the gather, 2 = no LDS stores in the gather, 4 = no block-order side, 8 = return after the prologue
    // col0: the launch covers block columns col0 .. col0 + gridDim.x - 1 (a slice of the array along dim 0)
     // rb.on: the natural-order side (`src` for DIR 0, `dst` for DIR 1) is in the ribbon order of szh_ribbon.h
@@ -707,14 +706,13 @@ __global__ __launch_bounds__(256) void k_permute(szh_geom3 G, const uint16_t *__
     __shared__ unsigned zc_s, zp_s[SZH_ZCAP];
     __shared__ int64_t prm_base[SZH_PERM_ROWS];
     __shared__ int prm_off[SZH_PERM_ROWS];
-    __shared__ unsigned prm_ktab[SZH_PERM_KTAB];
     if (threadIdx.x == 0) zc_s = 0;
     __syncthreads();
     SZH_DYN_SMEM(smem);
     uint16_t *tile = reinterpret_cast<uint16_t *>(smem);
     // (handing XCD x a contiguous run of the (segment, column) list, so that neighbouring columns -- which share the 128-byte lines of
     //  the natural / ribbon-order side -- meet in one L2, measured 1 % slower at 512^3: tools/gpu_ab_lib.sh)
-    const int col = (int)blockIdx.x + col0, segi = blockIdx.y;
+    const int col = (int)blockIdx.x + col0;
     const int b0 = col / G.g1.num, b1 = col - b0 * G.g1.num;
     const int bkbeg = segi * segb, bkend = min(bkbeg + segb, G.g2.num);
     const int s0 = szh_blk_size(G.g0, b0), s1 = szh_blk_size(G.g1, b1);
@@ -763,7 +761,7 @@ __global__ __launch_bounds__(256) void k_permute(szh_geom3 G, const uint16_t *__
     // the block-order side below is a 16-byte LDS read and a 16-byte store per eight codes.  (Measured before, 0.295 ms in all: 0.078 for the
     // launch of 21 675 workgroups and their prologue, 0.094 the gather, 0.123 the block-order side with its walk over rows and runs.)
     const int head = (int)(base & 7);                             // elements of the first 16-byte group that belong to the previous segment
-    const bool blocked = DIR == 0 && rb.on && !do_hist && fdiv_ok && rows <= SZH_PERM_ROWS && (rb_gv & (rb_gv - 1)) == 0 && klen / 8 + 2 <= 256 && klen <= SZH_PERM_KTAB && total + 16 <= tile_elems;
+    const bool blocked = DIR == 0 && rb.on && !do_hist && fdiv_ok && rows <= SZH_PERM_ROWS && (rb_gv & (rb_gv - 1)) == 0 && klen / 8 + 2 <= 256 && total + 16 <= tile_elems;
     if (blocked) {
         // gather from ribbon order, round 4: what depends on the ROW only (tile, wavefront, lane -> where its groups start, its step
         // shift) is worked out once per row into LDS, and the threads are laid out as (row, group) with a power-of-two pitch -- the five
@@ -778,7 +776,6 @@ __global__ __launch_bounds__(256) void k_permute(szh_geom3 G, const uint16_t *__
             prm_off[r] = w * (rb.R - 1) + ln + rr;
             prm_base[r] = ((int64_t)TI * rb.nTJ + TJ) * szh_rb_tile_elems(rb) + (int64_t)(w * rb.R + rr) * rb_gv * 512 + ln * 8;
         }
-        for (int kl = threadIdx.x; kl < klen; kl += 256) { int left; const int a = kpos(kl, 0, left); prm_ktab[kl] = (unsigned)a | ((unsigned)(kl < ewid ? G.g2.early : G.g2.late) << 16); }
         __syncthreads();
         const int gl = threadIdx.x & (ngp - 1), rstep = 256 / ngp;
         if (gl < ng)
@@ -790,17 +787,16 @@ __global__ __launch_bounds__(256) void k_permute(szh_geom3 G, const uint16_t *__
                 const uint4 wv = (dbg & 1) ? make_uint4(off, tt8, k0, 1) : *reinterpret_cast<const uint4 *>(src + prm_base[r] + (int64_t)(tt8 >> lg_gv) * trip_stride + (int64_t)(tt8 & (int)(rb_gv - 1)) * 512);
                 uint16_t v[8]; __builtin_memcpy(v, &wv, 16);
                 if (dbg & 2) { if (wv.x == 0xdeadbeefu) tile[0] = 1; continue; }
-                // place of code (r, k): head + A[k - kbeg] + r * width[k - kbeg] (prm_ktab: what depends on k only, once per workgroup)
-                const int kl0 = k0 - kbeg;
-                uint16_t *const trow = tile + head;
-                if (kl0 >= 0 && kl0 + 8 <= klen) {
+                // place of the next code in the tile and codes left in its run (this row of this block): by kpos at the start of every run.
+                // (A table of the places in LDS, one look-up per code, was slower: 0.270 against 0.244 ms -- the pass is bound by its LDS operations.)
+                int pos = 0, left = 0;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { const unsigned t = prm_ktab[kl0 + e]; trow[(t & 0xffffu) + (unsigned)r * (t >> 16)] = v[e]; }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int kl = kl0 + e;
-                        if (kl >= 0 && kl < klen) { const unsigned t = prm_ktab[kl]; trow[(t & 0xffffu) + (unsigned)r * (t >> 16)] = v[e]; }
+                for (int e = 0; e < 8; ++e) {
+                    const int k = k0 + e;
+                    if (k >= kbeg && k < kend) {
+                        if (left == 0) pos = head + kpos(k - kbeg, r, left);
+                        tile[pos] = v[e];
+                        ++pos; --left;
                     }
                 }
             }
@@ -924,9 +920,22 @@ __global__ __launch_bounds__(256) void k_permute(szh_geom3 G, const uint16_t *__
     __syncthreads();
     if (do_hist) { for (unsigned b = threadIdx.x; b < hist_bins; b += 256) { const unsigned c = lh[b]; if (c) atomicAdd(&hist[b], c); } }
     const unsigned zc = zc_s;
-    const size_t slot = (size_t)col * gridDim.y + segi;
+    const size_t slot = (size_t)col * nseg_all + segi;
     if (threadIdx.x == 0) zcnt[slot] = zc;
     if (threadIdx.x < zc && threadIdx.x < SZH_ZCAP) zpos[slot * SZH_ZCAP + threadIdx.x] = zp_s[threadIdx.x];
+}
+// gridDim.y workgroups share the segments of a block column (gridDim.y = 1: one workgroup walks them all).  Round 4: with a workgroup per
+// segment, launching the 21 675 workgroups of a 512^3 array and their prologues was 0.08 of the pass's 0.3 ms.
+template <int DIR>
+__global__ __launch_bounds__(256) void k_permute(szh_geom3 G, const uint16_t *__restrict__ src, uint16_t *__restrict__ dst,
+                                                 unsigned *col_zeros, int segb, unsigned *zcnt, unsigned *zpos, szh_rb_layout rb,
+                                                 unsigned *hist, unsigned hist_bins, int tile_elems, int col0, int dbg = 0)
+{
+    const int nseg_all = (G.g2.num + segb - 1) / segb;
+    for (int segi = (int)blockIdx.y; segi < nseg_all; segi += (int)gridDim.y) {
+        permute_body<DIR>(G, src, dst, col_zeros, segb, zcnt, zpos, rb, hist, hist_bins, tile_elems, col0, dbg, segi, nseg_all);
+        __syncthreads();                                           // (the tile and the workgroup's counters are reused)
+    }
 }
 
 // ------------------------------------------------------------------ unpredictable values, in block order

@@ -18,7 +18,7 @@ print("size", size, st.ms_total)
 PY
 for D in ${DBGS:-8 4 5 6}; do
   rm -rf $O/tr
-  SZ_HIP_SLICES=1 SZ_HIP_PERM_DBG=$D timeout 60 rocprofv3 --kernel-trace -d $O/tr -o t --output-format csv -- python /tmp/one_main.py > /tmp/log.txt 2>&1
+  env $EXTRA SZ_HIP_SLICES=1 SZ_HIP_PERM_DBG=$D timeout 60 rocprofv3 --kernel-trace -d $O/tr -o t --output-format csv -- python /tmp/one_main.py > /tmp/log.txt 2>&1
   tail -1 /tmp/log.txt
   python3 - <<PY
 import csv, glob
