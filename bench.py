@@ -790,7 +790,7 @@ def main():
     ap.add_argument("--timed-only", action="store_true", help="only the headline: priming, warm-up, the timed steps, one decompression (for "
                     "rocprofv3 --stats: every launch of the sweep kernel then runs as in the timed region)")
     ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the entry on gloo + the HIP-on-CPU shim (tests only)")
-    ap.add_argument("--inflight", type=int, default=2, help="arrays in flight per GPU in the timed region (szhip_pool lanes); 1 = one blocking call after the other")
+    ap.add_argument("--inflight", type=int, default=4, help="arrays in flight per GPU in the timed region (szhip_pool lanes); 1 = one blocking call after the other")
     args = ap.parse_args()
     if args.omp_ref_child:
         return _omp_ref_child(int(args.omp_ref_child[0]), int(args.omp_ref_child[1]))

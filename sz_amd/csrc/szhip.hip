@@ -32,7 +32,7 @@ double now_ms()
 
 } // namespace
 
-struct szhip_sweep_gate { std::mutex m; hipEvent_t last = nullptr; };
+struct szhip_sweep_gate { std::mutex m; hipEvent_t last = nullptr; int lanes = 2; };
 // compress calls of this process that are inside the library right now, whatever their context: the chain / kernel overlap of an array with
 // regression blocks is only taken by a call that starts alone (see compress_impl)
 static std::atomic<int> g_compress_calls{0};
@@ -430,13 +430,14 @@ int launch_ribbon(szhip_ctx *ctx, const szh_geom3 &G, szh_qargs<T> a, hipStream_
     if (ctx->gate && tune_int("SZ_HIP_RB_POOL_ATOMIC", 1)) a.ticket_mode = 0;
     // persistent workgroups (k_ribbon): no more than one per CU, or the ticket order could wait for a workgroup that is not resident.
     // A lone context takes every CU (512^3: sweep 1.02 ms with 256 workgroups, 1.18 with 96); a lane of a pool leaves half of them to
-    // the other lanes' kernels (two arrays in flight, 40-step runs: 324 GB/s with 256, 351 - 354 with 128 or 112, 346 with 96, 326 with 64)
+    // the other lanes' kernels (two arrays in flight, 40-step runs: 324 GB/s with 256, 351 - 354 with 128 or 112, 346 with 96, 326 with 64;
+    // four in flight, round 4: 377 - 388 with 128, 391 - 395 with 96, 329 - 417 with 64: three eighths of the CUs from three lanes on)
     // (the device's own CU count, not 256: on a smaller or partitioned GPU workgroups beyond it would not be resident and every call would
     //  run into the wait bound before the atomic-ticket repetition took over)
 #ifdef SZH_SYNC_LAUNCH
     const unsigned wgs = (unsigned)tiles;      // (the CPU shim runs workgroups one after the other: a workgroup per tile, or the first would wait for tiles of the second)
 #else
-    const unsigned wgs = (unsigned)std::min<size_t>(tiles, (size_t)std::max(1, std::min(tune_int("SZ_HIP_RB_WGS", ctx->gate ? ctx->cus / 2 : ctx->cus), ctx->cus)));
+    const unsigned wgs = (unsigned)std::min<size_t>(tiles, (size_t)std::max(1, std::min(tune_int("SZ_HIP_RB_WGS", ctx->gate ? (ctx->gate->lanes <= 2 ? ctx->cus / 2 : ctx->cus * 3 / 8) : ctx->cus), ctx->cus)));
 #endif
     if (a.use_mean) hipLaunchKernelGGL((k_ribbon<T, DEC, true>), dim3(wgs), dim3((RS::W + 3 + (DEC ? 1 : 0)) * 64), 0, st, a);
     else hipLaunchKernelGGL((k_ribbon<T, DEC, false>), dim3(wgs), dim3((RS::W + 3 + (DEC ? 1 : 0)) * 64), 0, st, a);
@@ -787,7 +788,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     // slices' kernels slow every sweep in flight (measured, two lanes at 512^3: 338 GB/s without, 324 with).
     // Measured (round 4, 512^3 float, one call after the other, same box): 255 GB/s with 1 slice, 276 with 4, 251 - 275 with 8 (the slices'
     // kernels take 2 - 4 x their lone time beside the sweep and slow it by ~0.1 ms; more slices, more of that).
-    const int slices_req = tune_int("SZ_HIP_SLICES", ctx->gate ? 1 : 4);
+    const int slices_req = tune_int("SZ_HIP_SLICES", ctx->gate ? tune_int("SZ_HIP_SLICES_POOL", 2) : 4);
     const int slice_from = tune_int("SZ_HIP_SLICE_FROM", 0);          // even parts: per cent of the tile rows that the first slice covers at least
     const int slice_geom = tune_int("SZ_HIP_SLICE_GEOM", 0);
     const bool sliced = use_ribbon && slices_req > 1 && !tune_int("SZ_HIP_FUSE_HIST", 0);
@@ -3281,6 +3282,7 @@ int szhip_pool_create(szhip_pool **out, int device, int lanes)
         // (SZ_HIP_LANE_PRIO=1, development: every other lane's main stream at the highest priority, so that two lanes never share a hardware queue)
         const int rc = create_ctx(&c, device, 0, lanes > 1 && tune_int("SZ_HIP_LANE_PRIO", 0) ? (i & 1) : 0);
         if (rc != SZHIP_OK) { for (szhip_ctx *x : p->ctx) szhip_destroy(x); delete p; return rc; }
+        p->gate.lanes = lanes;
         if (lanes > 1) { c->gate = &p->gate; if (hipEventCreateWithFlags(&c->ev_gate, hipEventDisableTiming) != hipSuccess) c->gate = nullptr; }
         // (against the earlier lanes' main AND second streams: a lane's fit pass behind another lane's sweep is as bad as two sweeps in a row)
         { std::vector<hipStream_t> mains; for (szhip_ctx *x : p->ctx) { mains.push_back(x->stream); mains.push_back(x->stream2); } settle_streams(c, mains.data(), (int)mains.size(), lanes == 1); }
