@@ -1075,6 +1075,13 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     for (unsigned s = 0; s < intervals; ++s) { tab_code[s] = hf->code[s]; tab_len[s] = hf->len[s]; }
     const u64 total_bits = hf->total_bits;
     szhost_huff_free(hf);
+    // code words of up to 32 bits and a table that fits beside the window in LDS: k_encode32 (32 consecutive codes per thread) packs the
+    // payload, from the table `code << 8 | length`; anything else stays with k_encode
+    unsigned enc_maxlen = 0;
+    for (unsigned s = 0; s < intervals; ++s) enc_maxlen = std::max<unsigned>(enc_maxlen, tab_len[s]);
+    const size_t lds_e32 = (size_t)intervals * 8 + ((size_t)SZH_E32_ROUND * enc_maxlen / 32 + 4) * 4 + 16;
+    const bool enc32 = enc_maxlen >= 1 && enc_maxlen <= 32 && lds_e32 <= 60 * 1024 && tune_int("SZ_HIP_ENC32", 1);
+    if (enc32) for (unsigned s = 0; s < intervals; ++s) tab_code[s] = (tab_code[s] << 8) | tab_len[s];
     host_ms += now_ms() - h0;
 
     TRY(ensure(ctx, ctx->code_tab, (size_t)intervals * 8));
@@ -1105,6 +1112,11 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         hipLaunchKernelGGL(k_chunk_bits, dim3((unsigned)((nchunks + SZH_CB_PER - 1) / SZH_CB_PER)), dim3(256), 0, st, (const uint16_t *)d_blk, n, (const uint8_t *)ctx->len_tab.p,
                            intervals, (u64 *)ctx->chunk_bits.p);
         TRY(scan_u64(ctx, (const u64 *)ctx->chunk_bits.p, nchunks, (u64 *)ctx->chunk_off.p, sm + SM_TOTAL_BITS));
+        if (enc32) {
+            const int64_t nrounds = (n + SZH_E32_ROUND - 1) / SZH_E32_ROUND;
+            hipLaunchKernelGGL(k_encode32, dim3((unsigned)((nrounds + SZH_E32_PER - 1) / SZH_E32_PER)), dim3(256), lds_e32, st, (const uint16_t *)d_blk, n, (const u64 *)ctx->code_tab.p,
+                               intervals, (const u64 *)ctx->chunk_off.p, (u64)(hdr_len + unpred_bytes) * 8, (unsigned *)d_stream);
+        } else
         hipLaunchKernelGGL(k_encode, dim3((unsigned)((nchunks + SZH_ENC_PER - 1) / SZH_ENC_PER)), dim3(256), 0, st, (const uint16_t *)d_blk, n, (const u64 *)ctx->code_tab.p,
                            (const uint8_t *)ctx->len_tab.p, intervals, (const u64 *)ctx->chunk_off.p, (u64)(hdr_len + unpred_bytes) * 8,
                            (unsigned *)d_stream);

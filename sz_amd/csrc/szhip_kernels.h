@@ -1231,6 +1231,101 @@ __global__ __launch_bounds__(256) void k_encode(const uint16_t *__restrict__ cod
     }
 }
 
+// The same with 32 CONSECUTIVE codes per thread (round 4; the form k_omp_encode_box3 measured fastest): a workgroup walks SZH_E32_PER rounds
+// of SZH_E32_ROUND codes -- one scan and three barriers per 8192 codes instead of per 2048 -- and a thread's codes go through a 64-bit
+// accumulator: whole 32-bit words are plain LDS stores, only its first and last word are atomics.  Code words of up to 32 bits
+// (`packed[s] = code << 8 | length`, staged in LDS); longer ones or alphabets beyond the LDS budget stay with k_encode.
+// dynamic LDS: [nsym x u64][window: SZH_E32_ROUND * maxlen / 32 + 4 words].  chunk_off: bit offsets of the 2048-code chunks (k_chunk_bits + scan).
+#define SZH_E32_ROUND 8192
+#define SZH_E32_PER 4
+__global__ __launch_bounds__(256) void k_encode32(const uint16_t *__restrict__ codes, int64_t n, const u64 *__restrict__ packed, unsigned nsym,
+                                                  const u64 *__restrict__ chunk_off, u64 bit0, unsigned *out32)
+{
+    SZH_DYN_SMEM(smem);
+    __shared__ u64 sh[8];
+    u64 *ltab = reinterpret_cast<u64 *>(smem);
+    unsigned *win = reinterpret_cast<unsigned *>(smem + (size_t)nsym * 8);
+    const int tid = threadIdx.x;
+    for (unsigned i = tid; i < nsym; i += 256) ltab[i] = packed[i];
+    const int64_t nrounds = (n + SZH_E32_ROUND - 1) / SZH_E32_ROUND;
+    const int64_t r0 = (int64_t)blockIdx.x * SZH_E32_PER;
+    auto load32 = [&](int64_t r, uint4 (&v)[4]) {                  // the thread's 32 codes of round r; places past the end: 0xffff (never looked up)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t p = r * SZH_E32_ROUND + tid * 32 + k * 8;
+            if (r < nrounds && p + 8 <= n) v[k] = *reinterpret_cast<const uint4 *>(codes + p);
+            else {
+                uint16_t c[8];
+                for (int e = 0; e < 8; ++e) c[e] = (r < nrounds && p + e < n) ? codes[p + e] : (uint16_t)0xffffu;
+                __builtin_memcpy(&v[k], c, 16);
+            }
+        }
+    };
+    uint4 vn[4];
+    load32(r0, vn);
+    __syncthreads();                                               // (the table is in LDS)
+    for (int rr = 0; rr < SZH_E32_PER; ++rr) {
+        const int64_t r = r0 + rr;
+        if (r >= nrounds) break;                                   // uniform
+        uint4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = vn[k];
+        load32(r + 1 < r0 + SZH_E32_PER ? r + 1 : nrounds, vn);    // the next round's codes are on their way while this one is packed
+        const int64_t p0 = r * SZH_E32_ROUND + tid * 32;
+        unsigned s = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned wv[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const unsigned c = (e & 1) ? wv[e >> 1] >> 16 : wv[e >> 1] & 0xffffu;
+                if (p0 + k * 8 + e < n) s += (unsigned)(ltab[c] & 0xffu);
+            }
+        }
+        u64 tot;
+        const u64 ex = block_excl_scan_256((u64)s, sh, &tot);
+        const u64 gbit = bit0 + chunk_off[r * (SZH_E32_ROUND / SZH_ENC_CHUNK)];
+        const unsigned lead = (unsigned)(gbit & 31);
+        const unsigned nwords = (unsigned)((lead + tot + 31) >> 5);
+        for (unsigned w = tid; w < nwords + 1; w += 256) win[w] = 0;
+        __syncthreads();
+        if (s) {
+            const unsigned bitpos = lead + (unsigned)ex;
+            unsigned wpos = bitpos >> 5, nb = bitpos & 31u;
+            u64 acc = 0;
+            bool first = true;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned wv[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned c = (e & 1) ? wv[e >> 1] >> 16 : wv[e >> 1] & 0xffffu;
+                    if (p0 + k * 8 + e < n) {
+                        const u64 en = ltab[c];
+                        const unsigned le = (unsigned)(en & 0xffu);
+                        acc = (acc << le) | (en >> 8);
+                        nb += le;
+                        if (nb >= 32) {
+                            const unsigned word = (unsigned)(acc >> (nb - 32));
+                            if (first) { atomicOr(&win[wpos], word); first = false; } else win[wpos] = word;
+                            ++wpos; nb -= 32;
+                        }
+                    }
+                }
+            }
+            if (nb) atomicOr(&win[wpos], (unsigned)(acc << (32 - nb)));   // the last, partial word (shared with the next thread); a first word that never filled up too
+        }
+        __syncthreads();
+        const u64 w0 = gbit >> 5;
+        for (unsigned w = tid; w < nwords; w += 256) {
+            const unsigned x = __builtin_bswap32(win[w]);
+            if (w == 0 || w == nwords - 1) { if (x) atomicOr(&out32[w0 + w], x); }
+            else out32[w0 + w] = x;
+        }
+        __syncthreads();                                          // the window is read out before the next round clears it
+    }
+}
+
 // ------------------------------------------------------------------ Huffman decoding (self-synchronising)
 // The reference stream is one unbroken bit string (Huffman.c:205-308) with no index, so there are no
 // known codeword boundaries.  Every thread decodes one SUBSEQ-bit subsequence from a guessed start;
