@@ -77,6 +77,9 @@ struct szhip_ctx {
     // order AND that every XCD gets to run; if a wavefront-kernel wait ever times out the call is repeated once with the atomic ticket, which
     // assumes neither (a GPU shared with other work), and the context keeps that mode
     bool wave_timeout = false, ticket_atomic = false;
+    // the coefficient chain beside the running sweep (M-field): a sweep that gave up waiting for the coefficients (seen 5 - 6 times in 480 rounds with
+    // several arrays in flight) is answered by ONE repetition with the chain finished before the sweep starts; the context keeps that order
+    bool coef_late = false, no_chain_overlap = false;
 };
 
 namespace {
@@ -708,7 +711,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         //  rounds of tools/gpu_pool_dbg.py -- errors, not wrong streams; none in 480 rounds with the serial order.  The lanes overlap one
         //  array's chain with the other's kernels anyway.
         //  A lone context takes the overlap only when no other compress call of the process is under way as this one starts.)
-        overlap = !two_d && !ctx->gate && g_compress_calls.load() <= 1 && tune_int("SZ_HIP_CHAIN_THREADS", 1) && tune_int("SZ_HIP_CHAIN_OVERLAP", 1);
+        overlap = !two_d && !ctx->gate && !ctx->no_chain_overlap && g_compress_calls.load() <= 1 && tune_int("SZ_HIP_CHAIN_THREADS", 1) && tune_int("SZ_HIP_CHAIN_OVERLAP", 1);
         if (overlap) { TRY(probe_streams(ctx)); overlap = ctx->streams_independent == 1; }
 #endif
         TRY(ensure_pinned3(ctx, reg_count * 4 * sizeof(T) + (overlap ? ((size_t)nb + 64) * 4 * sizeof(T) + 256 : 0)));
@@ -1148,7 +1151,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     if (tp_on) { for (int i = 0; i < tp_k; ++i) fprintf(stderr, "%s %.2f | ", tp_n[i], tp_t[i]); fprintf(stderr, "\n"); }
     // after the final synchronisation: the wavefront kernel's error flag; the shuffled bit count and the device's count of zero codes
     // must match what the histogram predicted
-    if ((unsigned)h_small[SM_ERR] == 2) FAIL_PUBLISHED(SZHIP_ERR_INTERNAL, "wavefront kernel: the regression coefficients did not arrive");
+    if ((unsigned)h_small[SM_ERR] == 2) { ctx->coef_late = true; FAIL_PUBLISHED(SZHIP_ERR_INTERNAL, "wavefront kernel: the regression coefficients did not arrive"); }
     if ((unsigned)h_small[SM_ERR] != 0) { ctx->wave_timeout = true; FAIL_PUBLISHED(SZHIP_ERR_INTERNAL, "wavefront kernel: halo wait timed out"); }
     if ((total_bits > 0 && h_small[SM_TOTAL_BITS] != total_bits) || h_small[SM_TOTAL_UNPRED] != total_unpred)
         FAIL_PUBLISHED(SZHIP_ERR_INTERNAL, "entropy stage mismatch (bits %llu vs %llu, unpredictable %llu vs %llu)", (unsigned long long)h_small[SM_TOTAL_BITS],
@@ -3132,8 +3135,14 @@ int decompress_omp_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stre
 template <class F>
 static int with_ticket_fallback(szhip_ctx *ctx, F &&run)
 {
-    ctx->wave_timeout = false; ctx->hdec_unconverged = false;
+    ctx->wave_timeout = false; ctx->hdec_unconverged = false; ctx->coef_late = false;
     int rc = run();
+    if (rc == SZHIP_OK && !ctx->no_chain_overlap && tune_int("SZ_HIP_TEST_CHAIN_FALLBACK", 0)) { ctx->coef_late = true; rc = SZHIP_ERR_INTERNAL; }   // tests: exercise the repetition
+    if (rc == SZHIP_ERR_INTERNAL && ctx->coef_late && !ctx->no_chain_overlap) {           // (compression of arrays with regression blocks only)
+        hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream);
+        ctx->no_chain_overlap = true; ctx->wave_timeout = false;
+        rc = run();
+    }
     if (rc == SZHIP_ERR_INTERNAL && ctx->hdec_unconverged && !ctx->hdec_sync_rounds) {      // (decompression only)
         hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream);
         ctx->hdec_sync_rounds = true;

@@ -134,6 +134,21 @@ def test_tile_ticket_modes_on_the_cpu_shim(built, oracle, monkeypatch, mode):
     _exercise(ctypes.CDLL(sim_lib.shim_path()), oracle)
 
 
+def test_chain_fallback_on_the_cpu_shim(built, oracle, monkeypatch):
+    """a sweep that gave up waiting for the regression coefficients (here: simulated) is answered by one repetition of the call with the
+    coefficient chain finished before the sweep starts: same stream, same decoded values"""
+    import sim_lib
+    monkeypatch.setenv("SZ_HIP_TEST_CHAIN_FALLBACK", "1")
+    _exercise(ctypes.CDLL(sim_lib.shim_path()), oracle)
+
+
+@pytest.mark.gpu
+def test_chain_fallback_on_the_gpu(built, oracle, monkeypatch):
+    import sz_amd
+    monkeypatch.setenv("SZ_HIP_TEST_CHAIN_FALLBACK", "1")
+    _exercise(ctypes.CDLL(sz_amd.api.lib_path()), oracle)
+
+
 @pytest.mark.gpu
 def test_ticket_fallback_on_the_gpu(built, oracle, monkeypatch):
     import sz_amd
