@@ -580,7 +580,10 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         unsigned *d_rh = (unsigned *)ctx->hist.p, *d_fh = d_rh + max_radius;
         HIPCHK(hipMemsetAsync(d_rh, 0, (size_t)(max_radius + 8192) * 4, st));
         const int64_t nrows = szh_sample_row_limit(G, prm->sample_distance);
-        if (nrows > 0) {
+        if (!two_d && (G.g0.count <= 1 || G.g1.count <= 1)) {      // a degenerate 3-D array: the reference's walk, literally (k_sample_walk)
+            hipLaunchKernelGGL((k_sample_walk<T, true>), dim3(1), dim3(64), 0, st, G, d_in, prm->sample_distance, (double)eb, (T)smean, max_radius, d_rh, d_fh, sm + SM_WITHIN);
+            HIPCHK(hipGetLastError());
+        } else if (nrows > 0) {
             int grid = (int)std::min<int64_t>((nrows + 255) / 256, 1024);
             hipLaunchKernelGGL((k_sample<T, true>), dim3(grid), dim3(256), 0, st, G, d_in, nrows, prm->sample_distance, (double)eb,
                                (T)smean, max_radius, d_rh, d_fh, sm + SM_WITHIN);
@@ -1824,6 +1827,9 @@ int compress14_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t
             int grid = (int)std::min<int64_t>((count + 255) / 256 + 1, 1024);
             hipLaunchKernelGGL((k_sample_1d<T>), dim3(grid), dim3(256), 0, st, d_in, n, prm->sample_distance, (double)eb, max_radius, d_rh);
             HIPCHK(hipGetLastError());
+        } else if (G.ndim == 3 && (G.g0.count <= 1 || G.g1.count <= 1)) {      // a degenerate 3-D array: the reference's walk, literally
+            hipLaunchKernelGGL((k_sample_walk<T, false>), dim3(1), dim3(64), 0, st, G, d_in, prm->sample_distance, (double)eb, (T)0, max_radius, d_rh, d_fh, sm + SM_WITHIN);
+            HIPCHK(hipGetLastError());
         } else if (nrows > 0) {
             int grid = (int)std::min<int64_t>((nrows + 255) / 256, 1024);
             hipLaunchKernelGGL((k_sample<T, false>), dim3(grid), dim3(256), 0, st, G, d_in, nrows, prm->sample_distance, (double)eb, (T)0,
@@ -2745,7 +2751,10 @@ int compress_omp_impl(szhip_ctx *ctx, const void *data, int data_on_device, size
         unsigned *d_rh = (unsigned *)ctx->hist.p, *d_fh = d_rh + max_radius;
         HIPCHK(hipMemsetAsync(d_rh, 0, (size_t)(max_radius + 8192) * 4, st));
         const int64_t nrows = szh_sample_row_limit(G, prm->sample_distance);
-        if (nrows > 0) {
+        if (G.g0.count <= 1 || G.g1.count <= 1) {                   // a degenerate 3-D array: the reference's walk, literally (k_sample_walk)
+            hipLaunchKernelGGL((k_sample_walk<T, false>), dim3(1), dim3(64), 0, st, G, d_in, prm->sample_distance, (double)eb, (T)0, max_radius, d_rh, d_fh, sm + SM_WITHIN);
+            HIPCHK(hipGetLastError());
+        } else if (nrows > 0) {
             int grid = (int)std::min<int64_t>((nrows + 255) / 256, 1024);
             hipLaunchKernelGGL((k_sample<T, false>), dim3(grid), dim3(256), 0, st, G, d_in, nrows, prm->sample_distance, (double)eb, (T)0,
                                max_radius, d_rh, d_fh, sm + SM_WITHIN);

@@ -413,6 +413,38 @@ __global__ __launch_bounds__(256) void k_sample(szh_geom3 G, const T *__restrict
     if (FREQ) for (int i = threadIdx.x; i < 8192; i += 256) if (sh_f[i]) atomicAdd(&freq_hist[i], sh_f[i]);
 }
 
+// The same samples for a DEGENERATE 3-D array (an extent of 1 in dim 0 or dim 1): the reference's walk (sz_float.c:4644-4702 and the
+// optimiser of the SZ 2.1 path) does not see rows and planes, it advances ONE position through the flat array -- with r2 = 1 its row counter
+// never reaches its wrap test the way k_sample's (row, column) form assumes.  Found by tools/omp_diff_fuzz.py on the GPU in round 4 (an
+// 8 x 1 x 33 box: no samples, 65536 intervals instead of the reference's 256).  Such arrays are rare and the walk is a few hundred
+// positions per million values: one lane follows it literally.
+template <class T, bool FREQ>
+__global__ void k_sample_walk(szh_geom3 G, const T *__restrict__ data, int sd, double ebD, T mean, unsigned max_radius, unsigned *radius_hist,
+                              unsigned *freq_hist, u64 *within)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int64_t r3 = G.g2.count, r2 = G.g1.count, r23 = r2 * r3, len = G.n;
+    int64_t oc = sd - 2, n1 = 1, n2 = 1, pos = r23 + r3 + oc;
+    u64 w = 0;
+    while (pos < len) {
+        unsigned ri; int fi, we;
+        szh_sample_point<T>(data, pos, r3, r23, ebD, mean, max_radius, &ri, &fi, &we);
+        atomicAdd(&radius_hist[ri], 1u);
+        if (FREQ) atomicAdd(&freq_hist[fi], 1u);
+        w += (unsigned)we;
+        oc += sd;
+        if (oc >= r3) {
+            n2++;
+            if (n2 == r2) { n1++; n2 = 1; pos += r3; }
+            const int64_t oc2 = (n1 + n2) % sd;
+            pos += (r3 + sd - oc) + (sd - oc2);
+            oc = sd - oc2;
+            if (oc == 0) oc++;
+        } else pos += sd;
+    }
+    if (w) atomicAdd(within, w);
+}
+
 // sequential (order-preserving) sum of the values within eb of dense_pos: ONE wavefront, every lane
 // carries the same running sum; the additions happen in array order so the float rounding sequence
 // is the reference's.  Only launched when use_mean is decided.

@@ -119,6 +119,10 @@ CASES = [
     case("reg-beside-lorenzo-f32", lambda: reg_beside_lorenzo(24, 40, 32)),
     case("reg-beside-lorenzo-f64", lambda: reg_beside_lorenzo(24, 40, 32, f64)),
     case("mean-rand-f32", lambda: _rand((13, 20, 17), f32, 0), abs=1e-2),
+    # degenerate 3-D extents (round 4): the interval optimiser walks the flat array, not rows and planes (k_sample_walk)
+    case("degenerate-8x1x66-f32", lambda: s_field(8, 1, 66), abs=1e-3),
+    case("degenerate-16x1x40-f64", lambda: s_field(16, 1, 40, f64), abs=1e-3),
+    case("degenerate-9x7x1-f32", lambda: s_field(9, 7, 1), abs=1e-3),
     case("mean-rand-f64", lambda: _rand((16, 18, 21), f64, 1), abs=1e-2),
     case("mean-zeros-f32", lambda: _mean_zeros(f32), abs=1e-3),
     case("mean-zeros-f64", lambda: _mean_zeros(f64), abs=1e-3),
