@@ -379,7 +379,11 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
             pass
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": nbytes_in, "avg_kernel_ms": round(quant_avg_ms, 4)}
+                "algorithmic_bytes_per_launch": nbytes_in, "avg_kernel_ms": round(quant_avg_ms, 4),
+                # `frac` is per LAUNCH inside the timed region, where `launches_in_flight` sweeps share the GPU (each on a share of the CUs); the same
+                # kernel with the GPU to itself, from the one-call-after-the-other run of this line:
+                "launches_in_flight": inflight,
+                "alone": {"avg_kernel_ms": single_call["quant_ms"], "frac": round(nbytes_in / (single_call["quant_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if single_call["quant_ms"] > 0 else None}}
 
     # ---- arrays in flight: the same args.steps compressions with 1 / 2 / 4 lanes (outside the timed region), with the sweep kernel's own
     # time per K so that interference is visible; and every stream of the last run against the one a single blocking call gives
