@@ -358,7 +358,8 @@ int choose_segb(const szh_geom3 &G, size_t elem, size_t budget)
     size_t per_block = rows * (size_t)G.g2.early * elem;
     int segb = (int)(budget / (per_block ? per_block : 1));
     if (segb < 1) segb = 1;
-    if (segb > 32) segb = 32;
+    const int cap = std::max(1, tune_int("SZ_HIP_PERM_SEGB_MAX", 32));
+    if (segb > cap) segb = cap;
     if (segb > G.g2.num) segb = G.g2.num;
     return segb;
 }
