@@ -3149,12 +3149,12 @@ static int with_ticket_fallback(szhip_ctx *ctx, F &&run)
     int rc = run();
     if (rc == SZHIP_OK && !ctx->no_chain_overlap && tune_int("SZ_HIP_TEST_CHAIN_FALLBACK", 0)) { ctx->coef_late = true; rc = SZHIP_ERR_INTERNAL; }   // tests: exercise the repetition
     if (rc == SZHIP_ERR_INTERNAL && ctx->coef_late && !ctx->no_chain_overlap) {           // (compression of arrays with regression blocks only)
-        hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream);
+        if (ctx->stream3) hipStreamSynchronize(ctx->stream3); hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream);
         ctx->no_chain_overlap = true; ctx->wave_timeout = false;
         rc = run();
     }
     if (rc == SZHIP_ERR_INTERNAL && ctx->hdec_unconverged && !ctx->hdec_sync_rounds) {      // (decompression only)
-        hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream);
+        if (ctx->stream3) hipStreamSynchronize(ctx->stream3); hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream);
         ctx->hdec_sync_rounds = true;
         ctx->wave_timeout = false;
         rc = run();
@@ -3162,7 +3162,7 @@ static int with_ticket_fallback(szhip_ctx *ctx, F &&run)
     }
     if (rc == SZHIP_OK && !ctx->ticket_atomic && tune_int("SZ_HIP_TEST_TICKET_FALLBACK", 0)) { ctx->wave_timeout = true; rc = SZHIP_ERR_INTERNAL; }   // tests: exercise the repetition
     if (rc == SZHIP_ERR_INTERNAL && ctx->wave_timeout && !ctx->ticket_atomic) {
-        hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream);
+        if (ctx->stream3) hipStreamSynchronize(ctx->stream3); hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream);
         ctx->ticket_atomic = true;
         rc = run();
     }
@@ -3399,7 +3399,7 @@ int szhip_compress(szhip_ctx *ctx, int dtype, const void *data, int data_on_devi
     const int rc = with_ticket_fallback(ctx, [&]() { *out = out0; *out_size = cap0; return dtype == SZHIP_F32
                ? compress_impl<float>(ctx, data, data_on_device, r0, r1, r2, eb, params, meta, meta_len, out_on_device, out, out_size, stats)
                : compress_impl<double>(ctx, data, data_on_device, r0, r1, r2, eb, params, meta, meta_len, out_on_device, out, out_size, stats); });
-    if (rc != SZHIP_OK) { hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream); } // an early exit must not leave work in flight
+    if (rc != SZHIP_OK) { if (ctx->stream3) hipStreamSynchronize(ctx->stream3); hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream); } // an early exit must not leave work in flight
     return rc;
 }
 
@@ -3416,7 +3416,7 @@ int szhip_compress_sz14(szhip_ctx *ctx, int dtype, const void *data, int data_on
     const int rc = with_ticket_fallback(ctx, [&]() { *out = out0; *out_size = cap0; return dtype == SZHIP_F32
                ? compress14_impl<float>(ctx, data, data_on_device, r0, r1, r2, eb, value_range, median, params, meta, meta_len, nullptr, out_on_device, out, out_size, stats)
                : compress14_impl<double>(ctx, data, data_on_device, r0, r1, r2, eb, value_range, median, params, meta, meta_len, nullptr, out_on_device, out, out_size, stats); });
-    if (rc != SZHIP_OK) { hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream); }
+    if (rc != SZHIP_OK) { if (ctx->stream3) hipStreamSynchronize(ctx->stream3); hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream); }
     return rc;
 }
 
@@ -3429,7 +3429,7 @@ int szhip_decompress_sz14(szhip_ctx *ctx, int dtype, const unsigned char *stream
     const int rc = with_ticket_fallback(ctx, [&]() { return dtype == SZHIP_F32
                ? decompress14_impl<float>(ctx, stream, stream_on_device, stream_len, body_off, 0, r0, r1, r2, out, out_on_device, stats)
                : decompress14_impl<double>(ctx, stream, stream_on_device, stream_len, body_off, 0, r0, r1, r2, out, out_on_device, stats); });
-    if (rc != SZHIP_OK) { hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream); }
+    if (rc != SZHIP_OK) { if (ctx->stream3) hipStreamSynchronize(ctx->stream3); hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream); }
     return rc;
 }
 
@@ -3499,7 +3499,7 @@ int szhip_compress_sz14_pwr(szhip_ctx *ctx, int dtype, const void *data, int dat
     const int rc = with_ticket_fallback(ctx, [&]() { *out = out0; *out_size = cap0; return dtype == SZHIP_F32
                ? compress14_impl<float>(ctx, data, data_on_device, r0, r1, r2, eb, value_range, median, params, meta, meta_len, pwr, out_on_device, out, out_size, stats)
                : compress14_impl<double>(ctx, data, data_on_device, r0, r1, r2, eb, value_range, median, params, meta, meta_len, pwr, out_on_device, out, out_size, stats); });
-    if (rc != SZHIP_OK) { hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream); }
+    if (rc != SZHIP_OK) { if (ctx->stream3) hipStreamSynchronize(ctx->stream3); hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream); }
     return rc;
 }
 
@@ -3532,7 +3532,7 @@ int szhip_decompress_sz14_pwr(szhip_ctx *ctx, int dtype, const unsigned char *st
     const int rc = with_ticket_fallback(ctx, [&]() { return dtype == SZHIP_F32
                ? decompress14_pwr_impl<float>(ctx, stream, 0, stream_len, body_off, r0, r1, r2, signs_host, thr, msst, out, out_on_device, stats)
                : decompress14_pwr_impl<double>(ctx, stream, 0, stream_len, body_off, r0, r1, r2, signs_host, thr, msst, out, out_on_device, stats); });
-    if (rc != SZHIP_OK) { hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream); }
+    if (rc != SZHIP_OK) { if (ctx->stream3) hipStreamSynchronize(ctx->stream3); hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream); }
     return rc;
 }
 
