@@ -321,6 +321,14 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
         sync_all()
         return time.perf_counter() - t_begin, stats_all, last
 
+    # set-up, not steps: the HIP runtime stalls ONCE for ~7 ms somewhere in a process's first few hundred milliseconds of pooled submissions (all
+    # lanes at once; profiles/r04_bench_priming_runs.txt) -- priming rounds alone left it inside the timed region in 2 of 14 four-lane runs.  The pool
+    # is therefore exercised, untimed, for SZ_BENCH_REHEARSE_MS (600 ms) before the W warm-up steps; the `concurrent` object, measured seconds
+    # later in the same process, never showed the stall.
+    if not getattr(args, "dry_run", False):
+        t_reh = time.perf_counter()
+        while (time.perf_counter() - t_reh) * 1e3 < float(os.environ.get("SZ_BENCH_REHEARSE_MS", "600")):
+            run_steps(inflight, 40, False)
     run_steps(inflight, max(args.warmup, inflight), True)
     elapsed, stats_all, (size, ob) = run_steps(inflight, args.steps, True)
     quant_ms = [st.ms_quant for st in stats_all]
