@@ -557,8 +557,8 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
                  "sz14_1d_16Mi_f32_abs1e-3": {"GB/s": round(s1.numel() * 4 / t1d / 1e9, 2), "ms": round(t1d * 1e3, 3), "out_bytes": size1d}}
         del p2, s1
 
-    # ---- opt-in (--omp-boxes N): the reference's OpenMP container (szh_omp.h) on the same array, its own object; NOT part of the
-    #      default line (the path had not run on hardware when round 3 ended)
+    # ---- the reference's OpenMP container (szh_omp.h / szh_ompcol.h) on the same array, its own object in the default line since round 4
+    #      (--omp-boxes N picks the box count, --no-omp leaves it out)
     omp = None
     omp_boxes = args.omp_boxes
     if omp_boxes < 0:                                              # default: boxes of 32^3 (4096 at 512^3) when the edge allows

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Static evidence for the k_omp_* kernels while they have not run on hardware: resource usage, the order of memory accesses and
+"""Static evidence for the k_omp_* kernels, written while they had not run on hardware (they have since: round 4): resource usage, the order of memory accesses and
 waits, instruction mix per step -- read off hipcc's own output.  Writes profiles/r03_k_omp_static_isa_summary.txt.  No GPU needed."""
 import os
 import re
