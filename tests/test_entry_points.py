@@ -134,6 +134,17 @@ def test_tile_ticket_modes_on_the_cpu_shim(built, oracle, monkeypatch, mode):
     _exercise(ctypes.CDLL(sim_lib.shim_path()), oracle)
 
 
+@pytest.mark.parametrize("switch", ["SZ_HIP_ENC32=0", "SZ_HIP_SLICES=1", "SZ_HIP_SLICES=8", "SZ_HIP_PERM_Y=3", "SZ_HIP_SLICES=3;SZ_HIP_SLICE_GEOM=1"])
+def test_alternative_forms_of_the_entropy_stage_on_the_cpu_shim(built, oracle, monkeypatch, switch):
+    """round 4's switches keep the forms they replaced alive (k_encode beside k_encode32, everything after the sweep beside the slices, a workgroup per
+    segment in k_permute): every one of them gives the same streams and decoded values"""
+    import sim_lib
+    for kv in switch.split(";"):
+        k, v = kv.split("=")
+        monkeypatch.setenv(k, v)
+    _exercise(ctypes.CDLL(sim_lib.shim_path()), oracle)
+
+
 def test_chain_fallback_on_the_cpu_shim(built, oracle, monkeypatch):
     """a sweep that gave up waiting for the regression coefficients (here: simulated) is answered by one repetition of the call with the
     coefficient chain finished before the sweep starts: same stream, same decoded values"""

@@ -80,3 +80,26 @@ def test_whole_hip_layer_on_cpu_shim(oracle, c1_data):
         sz_amd.SZ_Finalize()
     finally:
         api._lib = saved
+
+
+@pytest.mark.parametrize("switch", ["SZ_HIP_SLICES=1", "SZ_HIP_SLICES=4", "SZ_HIP_SLICES=16", "SZ_HIP_SLICES=3;SZ_HIP_SLICE_GEOM=1", "SZ_HIP_SLICES=4;SZ_HIP_SLICE_FROM=60",
+                                    "SZ_HIP_ENC32=0", "SZ_HIP_PERM_Y=2"])
+def test_entropy_stage_on_finished_tile_rows_on_cpu_shim(oracle, monkeypatch, switch):
+    """round 4: the histogram and block-ordering passes run slice by slice on finished tile rows (k_ribbon publishes every tile; on the shim the sweep
+    is over when the host looks, but the slices, their bounds against the block rows and the third stream's order are the product's own).  An array
+    of five tile rows (70 planes of 16) and ragged blocks: every slicing gives the oracle's bytes; so do the forms round 4 replaced."""
+    for kv in switch.split(";"):
+        k, v = kv.split("=")
+        monkeypatch.setenv(k, v)
+    saved = api._lib
+    try:
+        api._lib = api._bind(ctypes.CDLL(sim_lib.shim_path()))
+        import os
+        assert sz_amd.SZ_Init(os.path.join(sim_lib.ROOT, "tests", "golden", "sz_speed.config")) == 0
+        for name, d, eb in (("S-70x20x45", s_field(70, 20, 45), 1e-4), ("S-f64-41x70x33", s_field(41, 70, 33, np.float64), 1e-3)):
+            ref, _ = oracle.compress(d, oracle.ABS, eb)
+            got = sz_amd.SZ_compress_args(d, sz_amd.ABS, eb)
+            assert got == ref, (name, switch)
+        sz_amd.SZ_Finalize()
+    finally:
+        api._lib = saved
