@@ -449,6 +449,42 @@ int launch_ribbon(szhip_ctx *ctx, const szh_geom3 &G, szh_qargs<T> a, hipStream_
     return SZHIP_OK;
 }
 
+// ---- the beam mapping of the sweep (szh_beam.h, round 5): 3-D arrays whose contiguous extent is a multiple of 4 values
+// does it cover this call?  (SZ_HIP_BEAM=0 sends everything to k_ribbon / k_pencil)
+template <class T> bool beam_applies(const szh_geom3 &G, const void *base, size_t reg_count)
+{
+    if (!tune_int("SZ_HIP_BEAM", 1)) return false;
+    if (G.ndim != 3 || reg_count != 0) return false;
+    if (G.g2.count < 4 || (G.g2.count & 3) != 0 || ((uintptr_t)base & 15) != 0) return false;      // 16-byte row pieces
+    const szh_bm::grid_t g = szh_bm::make_grid(G);
+    if (g.nKB > 65535 || g.nJG > 65535) return false;
+    return (double)szh_bm::kface_words<T>(G) * 8.0 < 3.0e10 && (double)szh_bm::jface_words<T>(G) * 8.0 < 3.0e10;
+}
+// granule buffers of the beams' faces + the launch; `a` carries everything that does not depend on the mapping
+template <class T, bool DEC>
+int launch_beam(szhip_ctx *ctx, const szh_geom3 &G, szh_qargs<T> a, hipStream_t st)
+{
+    const szh_bm::grid_t g = szh_bm::make_grid(G);
+    const size_t tiles = (size_t)g.nKB * g.nJG;
+    TRY(ensure(ctx, ctx->rb_down, szh_bm::kface_words<T>(G) * sizeof(u64) + 64, true));
+    TRY(ensure(ctx, ctx->rb_right, szh_bm::jface_words<T>(G) * sizeof(u64) + 64, true));
+    a.faceI = (szh_u64 *)ctx->rb_down.p; a.faceJ = (szh_u64 *)ctx->rb_right.p;
+    a.nI = g.nKB; a.nJ = g.nJG;
+    if (a.ticket_mode == 2) a.ticket_mode = 1;
+    if (ctx->gate && tune_int("SZ_HIP_RB_POOL_ATOMIC", 1)) a.ticket_mode = 0;
+#ifdef SZH_SYNC_LAUNCH
+    const unsigned wgs = (unsigned)tiles;      // (the CPU shim runs workgroups one after the other: a workgroup per tile, in ticket order)
+#else
+    // persistent workgroups in ticket order: as many as are resident at once (a tile's predecessors hold smaller tickets)
+    const int per_cu = std::max(1, tune_int("SZ_HIP_BEAM_WG_PER_CU", sizeof(T) == 4 ? 2 : 1));
+    const unsigned wgs = (unsigned)std::min<size_t>(tiles, (size_t)std::max(1, tune_int("SZ_HIP_BEAM_WGS", ctx->cus * per_cu)));
+#endif
+    if (a.use_mean) hipLaunchKernelGGL((k_beam<T, DEC, true, false>), dim3(wgs), dim3(szh_bm::WPG * 64), 0, st, a);
+    else hipLaunchKernelGGL((k_beam<T, DEC, false, false>), dim3(wgs), dim3(szh_bm::WPG * 64), 0, st, a);
+    HIPCHK(hipGetLastError());
+    return SZHIP_OK;
+}
+
 template <class T> double ord_dec(u64 e);
 template <> double ord_dec<float>(u64 e)
 {
@@ -771,7 +807,8 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
 
     // ---- predict + quantise: the wavefront kernel
     // (the ribbon mapping writes its codes in its own order, szh_ribbon.h: tiles x steps x 1024 entries, a few per cent more than n)
-    const bool use_ribbon = !overlap && ribbon_applies<T>(G, reg_count);
+    const bool use_beam = !overlap && beam_applies<T>(G, d_in, reg_count);
+    const bool use_ribbon = !use_beam && !overlap && ribbon_applies<T>(G, reg_count);
     szh_rb_layout rbl = {0, 0, 0, 0, 0, 0};
     size_t nat_elems = (size_t)n;
     if (use_ribbon) {
@@ -852,7 +889,8 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
             if (ctx->gate->last && ctx->gate->last != ctx->ev_gate) HIPCHK(hipStreamWaitEvent(st, ctx->gate->last, 0));   // the other lane's sweep first
         }
         HIPCHK(hipEventRecord(ctx->ev[2], st));
-        if (use_ribbon) { TRY((launch_ribbon<T, false>(ctx, G, a, st))); S.quant_kernel = 1; }
+        if (use_beam) { TRY((launch_beam<T, false>(ctx, G, a, st))); S.quant_kernel = 2; }
+        else if (use_ribbon) { TRY((launch_ribbon<T, false>(ctx, G, a, st))); S.quant_kernel = 1; }
         else {
         const unsigned pgrid = pencil_grid(ctx, a, ntiles);
         hipLaunchKernelGGL((k_pencil<T, false>), dim3(pgrid), dim3((TS::TPI * TS::TPJ + 2) * 64), 0, st, a);
@@ -1417,7 +1455,8 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
     // SZ_HIP_RIBBON_DEC=0: k_pencil on natural-order codes (rounds 1 - 2; still the path of arrays with regression blocks, 2-D, SZ 1.4).
     szh_rb_layout rbl = {0, 0, 0, 0, 0, 0};
     size_t nat_elems = (size_t)n;
-    int dec_ribbon_mode = ribbon_applies<T>(G, reg_count) ? tune_int("SZ_HIP_RIBBON_DEC", 2) : 0;           // 1: natural-order values through the STORE wavefront
+    const bool dec_beam = beam_applies<T>(G, out_on_device ? (const void *)out : (const void *)nullptr, reg_count);   // (the context's own buffer is aligned)
+    int dec_ribbon_mode = !dec_beam && ribbon_applies<T>(G, reg_count) ? tune_int("SZ_HIP_RIBBON_DEC", 2) : 0;           // 1: natural-order values through the STORE wavefront
     if (dec_ribbon_mode == 2 && (double)szh_rb_steps_of<T>(G.g2.count) * szh_rb_shape<T>::W * szh_rb_shape<T>::R * 64.0 * sizeof(T) >= 2.0e9)
         dec_ribbon_mode = 0;                   // (a tile's stretch of the value array is addressed with 32-bit offsets)
     const bool dec_ribbon = dec_ribbon_mode != 0;                                                            // 2: ribbon-order values + k_unribbon
@@ -1511,7 +1550,8 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
         a.trace = tune_int("SZ_HIP_TRACE", 0) ? (szh_u64 *)ctx->trace.p : nullptr;
         a.dbg = tune_int("SZ_HIP_DBG", 0); a.trace_tile = tune_int("SZ_HIP_TRACE_TILE", 1);
         HIPCHK(hipEventRecord(ctx->ev[2], st));
-        if (dec_ribbon) {
+        if (dec_beam) { TRY((launch_beam<T, true>(ctx, G, a, st))); S.quant_kernel = 2; }
+        else if (dec_ribbon) {
             a.codes_ribbon = dec_ribbon_mode == 2 ? 2 : 1;
             if (dec_ribbon_mode == 2) a.out = d_sweep;
             TRY((launch_ribbon<T, true>(ctx, G, a, st)));

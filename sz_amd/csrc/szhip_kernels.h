@@ -1922,3 +1922,4 @@ __global__ void k_probe_touch(unsigned long long *p) { *p = 1; }
 #include "szh_msst.h"
 #include "szh_omp.h"
 #include "szh_ompcol.h"
+#include "szh_beam.h"
