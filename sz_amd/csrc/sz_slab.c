@@ -84,10 +84,12 @@ unsigned char *sz_slab_compress(int dataType, void *data, size_t *outSize, int e
      * absolute bound the reference would use (computeABSErrBoundFromABS_REL etc., dataCompression.c:288-332) once, here */
     int mode = errBoundMode; double abs_eb = absErrBound;
     if (confparams_cpr == NULL && SZ_Init(NULL) != SZ_SCES) goto done;
-    const int psnr_mode = confparams_cpr->errorBoundMode == PSNR || errBoundMode == PSNR, norm_mode = !psnr_mode && (confparams_cpr->errorBoundMode == NORM || errBoundMode == NORM);
+    /* the mode is the ARGUMENT's, as in SZ_compress_args (sz.c:294-391 assigns confparams_cpr->errorBoundMode = errBoundMode before it looks
+     * at it): the configuration's own errorBoundMode -- PSNR after SZ_Init(NULL) -- must not override an explicit ABS / REL call */
+    const int psnr_mode = errBoundMode == PSNR, norm_mode = errBoundMode == NORM;
     if (norm_mode) {                                     /* conf.c:62-65 on the element count of the whole array */
         abs_eb = sqrt(3.0 / (double)(r3 * plane)) * confparams_cpr->normErr;
-        mode = ABS; confparams_cpr->errorBoundMode = ABS;
+        mode = ABS;
     }
     if (errBoundMode == REL || errBoundMode == ABS_AND_REL || errBoundMode == ABS_OR_REL || psnr_mode) {
         double lo, hi;
@@ -97,7 +99,6 @@ unsigned char *sz_slab_compress(int dataType, void *data, size_t *outSize, int e
         const double range = dataType == SZ_FLOAT ? (double)((float)hi - (float)lo) : hi - lo, rel = relBoundRatio * range;
         if (psnr_mode) {                                 /* conf.c:54-60 on the range of the whole array */
             abs_eb = range * pow(10, (confparams_cpr->psnr + 10 * log10(1 - 2.0 / 3.0 * (double)confparams_cpr->predThreshold)) / (-20));
-            confparams_cpr->errorBoundMode = ABS;
         } else if (errBoundMode == REL) abs_eb = rel;
         else if (dataType == SZ_FLOAT) {                 /* min_f / max_f narrow both operands to float (dataCompression.c:320-322) */
             const float fa = (float)absErrBound, fb = (float)rel;

@@ -111,6 +111,11 @@ template <class T> SZH_HD size_t kface_words(const szh_geom3 &G) { const grid_t 
 template <class T> SZH_HD size_t jface_words(const szh_geom3 &G) { const grid_t g = make_grid(G); return (size_t)g.nKB * g.nJG * (size_t)G.g0.count * HL * szh_gran<T>::NW; }
 
 #ifdef SZH_HIPSIM
+#define SZH_SB
+#else
+#define SZH_SB __builtin_amdgcn_sched_barrier(0)
+#endif
+#ifdef SZH_HIPSIM
 template <class V> static inline void hide(V &) {}
 #else
 __device__ __forceinline__ void hide(unsigned &v) { asm volatile("" : "+v"(v)); }
@@ -195,7 +200,7 @@ struct beam {
     const szh_qargs<T> &a;
     OC_LDS unsigned char *ring, *nring, *kring;
     OC_LDS unsigned *prog;
-    int lane, w, h, m, r0;
+    int lane, w, h, m, r0, dbg;                                    // dbg (development, timing only -- results become wrong): 1 no waits between the wavefronts, 2 / 4 / 8: no events at position 1 / 2 / 3
     bool has_prev, has_next, zero_face;                            // (uniform)
     unsigned spin_limit; bool timed_out;
     rsrc_t rs_v, rs_c, rs_k, rs_j;                                 // the array (values), the codes, the k- / j-face granules
@@ -211,6 +216,8 @@ struct beam {
     role_t rv[EV], rvs[EV], rc, rcs, rko, rki, rjo, rji;          // value rows in (out: inverse), code rows in (inverse) / out, granules
     unsigned vl[EV], cl, ko_lds, ki_lds, jo_lds, ji_lds;
     v4u gv[DV];                                                    // value rows on their way
+    v4u gx[HASREG && !DEC ? DV : 1]; unsigned gf[HASREG ? DV : 1]; // HASREG: the regression points' reconstructions of the same rows (compress), their flag bytes
+    rsrc_t rs_x, rs_f; role_t rf[EV]; unsigned fl_lds[EV];
     cpiece_t gc[UL], wqc; v4u wqv[EV];                             // inverse: code rows on their way; rows on their way out
     greg_t gk[DK], gj[DK];                                         // k-face / j-face granules on their way
     T eb, eb2, rh, caph, radf, mean; int radius; unsigned epoch;
@@ -247,6 +254,32 @@ struct beam {
         soff = 0u;
     }
     template <bool EDGE> __device__ __forceinline__ v4u load_v(int X, int ev) const { unsigned o, so; place<EDGE>(rv[ev], X, str_v, o, so); return bld16<DEC ? 0 : 2>(rs_v, o, so); }
+    template <bool EDGE> __device__ __forceinline__ v4u load_x(int X, int ev) const { unsigned o, so; place<EDGE>(rv[ev], X, str_v, o, so); return bld16<0>(rs_x, o, so); }
+    template <bool EDGE> __device__ __forceinline__ unsigned load_f(int X, int ev) const
+    {
+        unsigned o, so; place<EDGE>(rf[ev], X, str_v / (unsigned)SZ, o, so);
+#ifdef SZH_HIPSIM
+        unsigned v = 0; for (int e = 0; e < S::VPL; ++e) if (inr(rs_f, o + (unsigned)e, so, 1)) v |= (unsigned)(unsigned char)rs_f.base[o + so + (unsigned)e] << (8 * e);
+        return v;
+#else
+        return S::VPL == 4 ? (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs_f, (int)o, (int)so, 0) : (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs_f, (int)o, (int)so, 0);
+#endif
+    }
+    // a row piece goes into the ring: HASREG: the regression points' values are their reconstructions (compress; the inverse finds them in the
+    // array already), and their flag bytes go next to the values
+    __device__ __forceinline__ void put_rows(unsigned at_line, int e, v4u xv, v4u xrv, unsigned fl)
+    {
+        if (HASREG) {
+            if (!DEC) {
+                T a_[S::VPL], b_[S::VPL];
+                __builtin_memcpy(a_, &xv, 16); __builtin_memcpy(b_, &xrv, 16);
+                for (int q = 0; q < S::VPL; ++q) a_[q] = ((fl >> (8 * q)) & 0xffu) ? b_[q] : a_[q];
+                __builtin_memcpy(&xv, a_, 16);
+            }
+            if (S::VPL == 4) lds_put<unsigned>(ring, at_line + fl_lds[e], fl); else lds_put<uint16_t>(ring, at_line + fl_lds[e], (uint16_t)fl);
+        }
+        lds_put16(ring, at_line + vl[e], xv);
+    }
     template <bool EDGE> __device__ __forceinline__ cpiece_t load_c(int X) const { unsigned o, so; place<EDGE>(rc, X, str_c, o, so); return bld8<0>(rs_c, o, so); }
     template <bool EDGE> __device__ __forceinline__ greg_t load_k(int X) const { unsigned o, so; place<EDGE>(rki, X, str_k, o, so); return GIO::ld(rs_k, o, so); }
     template <bool EDGE> __device__ __forceinline__ greg_t load_j(int X) const { unsigned o, so; place<EDGE>(rji, X, str_j, o, so); return GIO::ld(rs_j, o, so); }
@@ -292,8 +325,10 @@ struct beam {
             const unsigned loX = lo(1);
             for_n<EV>([&](auto E) {
                 constexpr int e = decltype(E)::value, set = ((LL + 1) * EV + e) % DV;
-                lds_put16(ring, loX + vl[e], gv[set]);
+                put_rows(loX, e, gv[set], gx[HASREG && !DEC ? set : 0], gf[HASREG ? set : 0]);
                 gv[set] = load_v<EDGE>(it + 1 + UL, e);
+                if (HASREG && !DEC) gx[HASREG && !DEC ? set : 0] = load_x<EDGE>(it + 1 + UL, e);
+                if (HASREG) gf[HASREG ? set : 0] = load_f<EDGE>(it + 1 + UL, e);
             });
             if (zero_face) { const v4u z = {0u, 0u, 0u, 0u}; if (lane < S::HB / 16) lds_put16(ring, loX + (unsigned)lane * 16u, z); }
             if (DEC) { constexpr int set = (LL + 1) % UL; lds_put8(ring, loX + cl, gc[set]); gc[set] = load_c<EDGE>(it + 1 + UL); }
@@ -312,40 +347,79 @@ struct beam {
     __device__ __forceinline__ static T tsign(T mag, T from) { return sizeof(T) == 8 ? (T)__builtin_copysign((double)mag, (double)from) : (T)__builtin_copysignf((float)mag, (float)from); }
 
     // ---- one step: the cell the lane is at
+    // One wavefront per SIMD: a dependent VALU instruction issues ~9 cycles after the one it waits for, an independent one after 4 (tools/ubench),
+    // and hipcc's scheduler models neither: it emitted the 20 operations of the dependent chain (DPP, the 7-point sum left to right, the
+    // quantiser, the bound check) back to back and everything else around them -- 480 cycles a step.  So the step is written in the order it
+    // should issue, one chain operation and one or two independent ones per group, and the groups are pinned (SZH_SB: nothing crosses).
     template <int U, int LL, bool EDGE> __device__ __forceinline__ void step(int it)
     {
-        // what the NEXT step needs from the rings is requested now
-        const unsigned y = vaddr + (unsigned)PITCH;
-        const unsigned vnext = y >= ring_end ? y - (unsigned)RINGB : y;
         const T cur_raw = cur_next, kf = kf_next;
         const unsigned tc_in = tc_next, fl_in = fl_next;
-        cur_next = lds_get<T>(lds0, vnext);
+        const T Lraw = shr1(prev);                                       // (i, j, k-1): the left lane's previous result
+        const unsigned y = vaddr + (unsigned)PITCH;
+        SZH_SB;
+        T L = bsel(m_first, kf, Lraw);                                   // (a half's first lane: the k-face of the beam on the left)
+        const bool started = !EDGE || (unsigned)(it * LINE + U) >= tstart;      // (at the array's first lines: lanes that have not started hold zeros)
+        if (EDGE) L = started ? L : (T)0;
+        const T sw = low_to_high(prev);
+        SZH_SB;
+        const T B = dl[U], Bp = lup[U], C = Bold, Cp = Bpold;
+        // [-1] + [-s1] + [-s0] - [-s1-1] - [-s0-1] - [-s0-s1] + [-s0-s1-1], left to right (sz_float.c:7268)
+        const T s1 = L + prev;
+        const unsigned vnext = y >= ring_end ? y - (unsigned)RINGB : y;
+        SZH_SB;
+        const T s2 = s1 + B;
+        // a virtual cell: the j-face -- from the ring (lower half), from the lower half's previous result (upper half)
+        const T cur = bsel(m_vu[U], sw, cur_raw);
+        SZH_SB;
+        const T s3 = s2 - Lprev;
+        cur_next = lds_get<T>(lds0, vnext);                              // what the NEXT step needs from the rings is requested now
         if (DEC) tc_next = lds_get<uint16_t>(lds0, vnext + cdelta);
         if (HASREG) fl_next = lds_get<uint8_t>(lds0, vnext + fdelta);
+        SZH_SB;
+        const T s4 = s3 - Bp;
         {   // the k-face value of the next step's cell of lane 0 (every lane reads; only the halves' first lanes use it)
             constexpr int Un = (U + 1) % LINE, kl = (U + 1 == LINE ? LL + 1 : LL) % KRL;
             kf_next = lds_get<T>(lds0, (unsigned)(kl * LINE * 2 * SZ + Un * 2 * SZ) + kaddr_h);
         }
-        // a virtual cell: the j-face -- from the ring (lower half), from the lower half's previous result (upper half)
-        const T cur = bsel(m_vu[U], low_to_high(prev), cur_raw);
-        T L = bsel(m_first, kf, shr1(prev));
-        const bool started = !EDGE || (unsigned)(it * LINE + U) >= tstart;      // (at the array's first lines: lanes that have not started hold zeros)
-        if (EDGE) L = started ? L : (T)0;
-        const T B = dl[U], Bp = lup[U], C = Bold, Cp = Bpold;
-        // [-1] + [-s1] + [-s0] - [-s1-1] - [-s0-1] - [-s0-s1] + [-s0-s1-1], left to right (sz_float.c:7268)
-        const T pred = L + prev + B - Lprev - Bp - C + Cp;
+        SZH_SB;
+        const T s5 = s4 - C;
+        const unsigned f = vaddr + pushd;
+        SZH_SB;
+        const T pred = s5 + Cp;
+        const unsigned fa = f < nring_lo ? f + (unsigned)RINGB : f;
+        SZH_SB;
         T rec;
         if (!DEC) {
             // the quantiser of szh_rb::rb_quant (sz_float.c:7270-7287 with a shorter dependency chain, bit for bit the same results); a virtual
             // cell fails the range test (its limit is -1) and hands its value on unchanged
             const T diff = cur - pred;
-            const T hq = tabs(diff) * rh + (T)0.5;
-            const T ts = tsign(ttrunc(hq), diff);
-            const T rcn = pred + (ts * eb2 + (T)0);
-            mask_t okm = lane_mask(hq < caphU[U]) & lane_mask(!(tabs(cur - rcn) > eb));
+            const unsigned pa = bsel(m_push[U], fa, trash);
+            SZH_SB;
+            const T hq0 = tabs(diff) * rh;
+            const unsigned caddr = vaddr + cdelta;
+            SZH_SB;
+            const T hq = hq0 + (T)0.5;
+            SZH_SB;
+            const T tq = ttrunc(hq);
+            mask_t okm = lane_mask(hq < caphU[U]);
             if (HASREG) okm &= lane_mask(fl_in == 0u);
+            SZH_SB;
+            const T ts = tsign(tq, diff);
+            SZH_SB;
+            const T m1 = ts * eb2;
+            const T cf = radf + ts;
+            SZH_SB;
+            const T m2 = m1 + (T)0;
+            int code = (int)cf;
+            SZH_SB;
+            const T rcn = pred + m2;
+            SZH_SB;
+            const T err = cur - rcn;
+            SZH_SB;
+            okm &= lane_mask(!(tabs(err) > eb));
             const bool ok = in_mask(okm);
-            int code = ok ? (int)(radf + (ok ? ts : (T)0)) : 0;
+            code = ok ? code : 0;
             rec = ok ? rcn : cur;
             if (USEMEAN) {
                 if (code != 0 && code <= radius) code -= 1;                                  // sz_float.c:6944
@@ -353,23 +427,27 @@ struct beam {
                 if (HASREG) nm &= lane_mask(fl_in == 0u);
                 if (in_mask(nm)) { code = radius; rec = mean; }
             }
-            lds_put<uint16_t>(lds0, vaddr + cdelta, (uint16_t)code);
+            if (EDGE) rec = started ? rec : (T)0;
+            lds_put<uint16_t>(lds0, caddr, (uint16_t)code);
+            lds_put<T>(lds0, vaddr, rec);
+            // the last row of the upper half is the j-face of the wavefront above: into the slot of ITS virtual cell, 9 cells back in its ring
+            // (every other lane, and the workgroup's last wavefront: into the lane's write-only word)
+            lds_put<T>(lds0, pa, rec);
         } else {
             int cq = (int)tc_in;
             bool is_mean = false;
             if (USEMEAN) { is_mean = cq == radius; if (cq != 0 && cq < radius) cq += 1; }     // szd_float.c:3784
-            T r = pred + (T)(cq - radius) * eb2;                                              // = pred + 2 (c - radius) eb (szd_float.c:5786)
-            if (USEMEAN && is_mean) r = mean;
+            const T mq = (T)(cq - radius) * eb2;
             mask_t um = lane_mask(tc_in != 0u) & lane_mask(caphU[U] > (T)0);
             if (HASREG) um &= lane_mask(fl_in == 0u);
+            const unsigned pa = bsel(m_push[U], fa, trash);
+            SZH_SB;
+            T r = pred + mq;                                                                  // = pred + 2 (c - radius) eb (szd_float.c:5786)
+            if (USEMEAN && is_mean) r = mean;
             rec = in_mask(um) ? r : cur;                                                       // zero code: the pre-scattered value
-        }
-        if (EDGE) rec = started ? rec : (T)0;
-        lds_put<T>(lds0, vaddr, rec);
-        {   // the last row of the upper half is the j-face of the wavefront above: into the slot of ITS virtual cell, 9 cells back in its
-            // ring (every other lane, and the workgroup's last wavefront: into the lane's write-only word)
-            const unsigned f = vaddr + pushd, fa = f < nring_lo ? f + (unsigned)RINGB : f;
-            lds_put<T>(lds0, bsel(m_push[U], fa, trash), rec);
+            if (EDGE) rec = started ? rec : (T)0;
+            lds_put<T>(lds0, vaddr, rec);
+            lds_put<T>(lds0, pa, rec);
         }
         dl[U] = rec; lup[U] = L;
         Bold = B; Bpold = Bp;
@@ -380,12 +458,14 @@ struct beam {
     template <int LL, bool EDGE> __device__ __forceinline__ void line(int it)
     {
         // the wavefront below (in j) must be far enough ahead for the virtual cells read during this line, the one above not too far behind
+        if (!(dbg & 1)) {
         if (has_prev) wait_prog(prog + (w - 1), it + 3);
         if (has_next) wait_prog(prog + (w + 1), it - (RL - 2));
+        }
         for_n<LINE>([&](auto UU) {
             constexpr int U = decltype(UU)::value;
             wave_sync();
-            events<U, LL, EDGE>(it);
+            if (!((dbg >> U) & 1) || U == 0) events<U, LL, EDGE>(it);
             order();
             step<U, LL, EDGE>(it);
             order();
@@ -401,7 +481,7 @@ struct beam {
     __device__ __forceinline__ void run(int kb, int jg, OC_LDS unsigned char *rings, OC_LDS unsigned *prog_)
     {
         const szh_geom3 &G = a.G;
-        prog = prog_;
+        prog = prog_; dbg = a.dbg;
         r0 = G.g0.count;
         const int r1 = G.g1.count, r2 = G.g2.count;
         lane = (int)(threadIdx.x & 63u); w = uni((int)(threadIdx.x >> 6)); h = lane >> 5; m = lane & 31;
@@ -417,6 +497,8 @@ struct beam {
         const uint64_t nbytes = (uint64_t)G.n * SZ;
         rs_v = make_rsrc(DEC ? (const void *)a.out : (const void *)a.data, (unsigned)nbytes);
         rs_c = make_rsrc(a.codes, (unsigned)((uint64_t)G.n * 2));
+        rs_x = make_rsrc(HASREG && !DEC ? (const void *)a.xr : (const void *)a.codes, HASREG && !DEC ? (unsigned)nbytes : 0u);
+        rs_f = make_rsrc(HASREG ? (const void *)a.ptflags : (const void *)a.codes, HASREG ? (unsigned)G.n : 0u);
         str_v = (unsigned)(G.d0 * SZ); str_c = (unsigned)(G.d0 * 2); str_k = (unsigned)(LINE * GIO::BYTES); str_j = (unsigned)(HL * GIO::BYTES);
         {   // value rows: 64 lanes x 16 B = RPE row pieces of HB bytes: RH rows of each half
             const int r = lane / S::LPR, p = lane - r * S::LPR, vh = r / S::RH;
@@ -426,7 +508,9 @@ struct beam {
                 const bool in = j < r1 && kk < r2;
                 rv[e] = make_role(true, in ? off : 0u, vh, str_v);           // (rows outside the array: any readable place -- nobody looks at them)
                 rvs[e] = make_role(in, off, vh, str_v);
+                rf[e] = make_role(true, in ? off / (unsigned)SZ : 0u, vh, str_v / (unsigned)SZ);
                 vl[e] = (unsigned)((1 + rr) * PITCH + vh * S::HB + p * 16);
+                fl_lds[e] = (unsigned)((1 + rr) * PITCH + S::FOFF + vh * HL + p * S::VPL);
             }
         }
         {   // code rows: 64 lanes x 8 B = 8 row pieces of 64 bytes
@@ -483,10 +567,20 @@ struct beam {
         for (int e = lane; e < S::KRB / 4; e += 64) lds_put<unsigned>(kring, (unsigned)e * 4u, 0u);
         // ---- prologue: the first lines' rows are requested; line 0 goes into the ring
         {
-            v4u first[EV];
-            for_n<EV>([&](auto E) { constexpr int e = decltype(E)::value; first[e] = load_v<true>(0, e); });
-            for_n<UL>([&](auto L_) { constexpr int LL = decltype(L_)::value; for_n<EV>([&](auto E) { constexpr int e = decltype(E)::value; gv[((LL + 1) * EV + e) % DV] = load_v<true>(LL + 1, e); }); });
-            for_n<EV>([&](auto E) { constexpr int e = decltype(E)::value; lds_put16(ring, vl[e], first[e]); });
+            v4u first[EV], firstx[EV]; unsigned firstf[EV];
+            for_n<EV>([&](auto E) {
+                constexpr int e = decltype(E)::value;
+                first[e] = load_v<true>(0, e);
+                firstx[e] = (HASREG && !DEC) ? load_x<true>(0, e) : first[e];
+                firstf[e] = HASREG ? load_f<true>(0, e) : 0u;
+            });
+            for_n<UL>([&](auto L_) { constexpr int LL = decltype(L_)::value; for_n<EV>([&](auto E) {
+                constexpr int e = decltype(E)::value, set = ((LL + 1) * EV + e) % DV;
+                gv[set] = load_v<true>(LL + 1, e);
+                if (HASREG && !DEC) gx[HASREG && !DEC ? set : 0] = load_x<true>(LL + 1, e);
+                if (HASREG) gf[HASREG ? set : 0] = load_f<true>(LL + 1, e);
+            }); });
+            for_n<EV>([&](auto E) { constexpr int e = decltype(E)::value; put_rows(0u, e, first[e], firstx[e], firstf[e]); });
             if (zero_face) { const v4u z = {0u, 0u, 0u, 0u}; if (lane < S::HB / 16) lds_put16(ring, (unsigned)lane * 16u, z); }
             if (DEC) {
                 const cpiece_t c0 = load_c<true>(0);
@@ -503,7 +597,7 @@ struct beam {
         wave_sync();
         cur_next = lds_get<T>(lds0, vaddr);
         tc_next = DEC ? (unsigned)lds_get<uint16_t>(lds0, vaddr + cdelta) : 0u;
-        fl_next = 0u;
+        fl_next = HASREG ? (unsigned)lds_get<uint8_t>(lds0, vaddr + fdelta) : 0u;
         kf_next = lds_get<T>(lds0, kaddr_h);
         { const v4u z = {0u, 0u, 0u, 0u}; for (int e = 0; e < EV; ++e) wqv[e] = z; wqc.x = 0u; wqc.y = 0u; }
         // ---- the lines: every lane has left line it - LAG when lane 0 enters line it.  Blocks of UL lines; the ones in which every line any
@@ -523,6 +617,38 @@ struct beam {
     }
 };
 } // namespace szh_bm
+
+// The points of the regression blocks (sz_float.c:7153-7252; inverse szd_float.c:5786-5838): prediction a ii + b jj + c kk + d from the DECODED
+// coefficients, no neighbour involved -- a wavefront per block, all blocks at once.
+//   MODE 0  compress, before the sweep: reconstructions -> vals (the sweep's neighbours), flags -> 1
+//   MODE 1  compress, after the sweep:  codes -> codes (natural order; the sweep left whatever it computed there)
+//   MODE 2  decompress, before the sweep: values -> vals (= the output array) where the code is not zero (zero: the pre-scattered value stays), flags -> 1
+template <class T, int MODE>
+__global__ __launch_bounds__(256) void k_reg_points(szh_geom3 G, const uint8_t *__restrict__ blk_lor, const T *__restrict__ coef, int64_t cstride, const T *__restrict__ data,
+                                                    T *__restrict__ vals, uint16_t *__restrict__ codes, uint8_t *__restrict__ flags, T eb, T recip, int cap, int radius)
+{
+    const int64_t b = (int64_t)blockIdx.x * 4 + (int64_t)(threadIdx.x >> 6);
+    if (b >= G.nblocks || blk_lor[b] != 0) return;                   // (uniform per wavefront)
+    const int lane = (int)(threadIdx.x & 63u);
+    const int n12 = G.g1.num * G.g2.num, b0 = (int)(b / n12), r12 = (int)(b - (int64_t)b0 * n12), b1 = r12 / G.g2.num, b2 = r12 - b1 * G.g2.num;
+    const int i0 = szh_blk_start(G.g0, b0), j0 = szh_blk_start(G.g1, b1), k0 = szh_blk_start(G.g2, b2);
+    const int s0 = szh_blk_size(G.g0, b0), s1 = szh_blk_size(G.g1, b1), s2 = szh_blk_size(G.g2, b2), s12 = s1 * s2, np = s0 * s12;
+    const T ca = coef[b], cb = coef[cstride + b], cc = coef[2 * cstride + b], cd = coef[3 * cstride + b];
+    for (int p = lane; p < np; p += 64) {
+        const int ii = p / s12, r = p - ii * s12, jj = r / s2, kk = r - jj * s2;
+        const int64_t idx = (int64_t)(i0 + ii) * G.d0 + (int64_t)(j0 + jj) * G.d1 + (k0 + kk);
+        const T pred = ca * (T)ii + cb * (T)jj + cc * (T)kk + cd;     // sz_float.c:7165, left to right
+        if (MODE == 2) {
+            const int c = (int)codes[idx];
+            if (c != 0) vals[idx] = pred + (T)(2 * (c - radius)) * eb;   // szd_float.c:5831
+            flags[idx] = 1;
+        } else {
+            T rc;
+            const int c = szh_quant_sel<T>(data[idx], pred, eb, recip, cap, radius, &rc);   // capacity: the full interval count (sz_float.c:7170)
+            if (MODE == 0) { vals[idx] = rc; flags[idx] = 1; } else codes[idx] = (uint16_t)c;
+        }
+    }
+}
 
 // a.nI x a.nJ = the beam grid (k-beams x j-groups); a.faceI / a.faceJ = the k- / j-face granules
 template <class T, bool DEC, bool USEMEAN, bool HASREG>

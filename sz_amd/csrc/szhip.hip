@@ -61,7 +61,7 @@ struct szhip_ctx {
     hipEvent_t ev_gate = nullptr;
     unsigned long long *hdec_res = nullptr;      // pinned: {symbols the payload holds, starts still moving after round 1}, copied asynchronously
     // workspaces (grow-only)
-    DevBuf lor_bits, reg_flags, reg_rank, coef_compact, in, out, codes_nat, codes_blk, coef, blk_lor, faceI, faceJ, rb_down, rb_right, rb_vals, fast_slots, fast_units, progress, trace, order, small, hist, col_zeros, col_zeros64,
+    DevBuf lor_bits, reg_flags, reg_rank, coef_compact, in, out, codes_nat, codes_blk, coef, blk_lor, faceI, faceJ, rb_down, rb_right, rb_vals, pt_flags, fast_slots, fast_units, progress, trace, order, small, hist, col_zeros, col_zeros64,
         col_off, partial, samples, unpred, stream_buf, chunk_bits, chunk_off, code_tab, len_tab, dec_tab,
         starts, ends, counts, offs, dirty, zcnt, zpos, pwr_log, pwr_signs, pwr_small, coef_dec, msst_ptab, msst_cells, msst_rec, msst_pe;
     void *pinned = nullptr; size_t pinned_cap = 0;
@@ -454,15 +454,17 @@ int launch_ribbon(szhip_ctx *ctx, const szh_geom3 &G, szh_qargs<T> a, hipStream_
 template <class T> bool beam_applies(const szh_geom3 &G, const void *base, size_t reg_count)
 {
     if (!tune_int("SZ_HIP_BEAM", 1)) return false;
-    if (G.ndim != 3 || reg_count != 0) return false;
+    (void)reg_count;                                                                               // (regression blocks: k_reg_points beside the sweep)
+    if (G.ndim != 3) return false;
     if (G.g2.count < 4 || (G.g2.count & 3) != 0 || ((uintptr_t)base & 15) != 0) return false;      // 16-byte row pieces
+    if ((double)G.n * sizeof(T) >= 4.0e9) return false;                                            // 32-bit buffer offsets
     const szh_bm::grid_t g = szh_bm::make_grid(G);
     if (g.nKB > 65535 || g.nJG > 65535) return false;
-    return (double)szh_bm::kface_words<T>(G) * 8.0 < 3.0e10 && (double)szh_bm::jface_words<T>(G) * 8.0 < 3.0e10;
+    return (double)szh_bm::kface_words<T>(G) * 8.0 < 4.0e9 && (double)szh_bm::jface_words<T>(G) * 8.0 < 4.0e9;
 }
 // granule buffers of the beams' faces + the launch; `a` carries everything that does not depend on the mapping
 template <class T, bool DEC>
-int launch_beam(szhip_ctx *ctx, const szh_geom3 &G, szh_qargs<T> a, hipStream_t st)
+int launch_beam(szhip_ctx *ctx, const szh_geom3 &G, szh_qargs<T> a, hipStream_t st, size_t reg_count)
 {
     const szh_bm::grid_t g = szh_bm::make_grid(G);
     const size_t tiles = (size_t)g.nKB * g.nJG;
@@ -479,8 +481,37 @@ int launch_beam(szhip_ctx *ctx, const szh_geom3 &G, szh_qargs<T> a, hipStream_t 
     const int per_cu = std::max(1, tune_int("SZ_HIP_BEAM_WG_PER_CU", sizeof(T) == 4 ? 2 : 1));
     const unsigned wgs = (unsigned)std::min<size_t>(tiles, (size_t)std::max(1, tune_int("SZ_HIP_BEAM_WGS", ctx->cus * per_cu)));
 #endif
-    if (a.use_mean) hipLaunchKernelGGL((k_beam<T, DEC, true, false>), dim3(wgs), dim3(szh_bm::WPG * 64), 0, st, a);
-    else hipLaunchKernelGGL((k_beam<T, DEC, false, false>), dim3(wgs), dim3(szh_bm::WPG * 64), 0, st, a);
+    // arrays with regression blocks: their points are quantised / reconstructed by k_reg_points (no neighbour involved); the sweep takes
+    // their reconstructions as its neighbours (compress: from a.xr; the inverse: they are in the output array already) and passes them through
+    const bool hasreg = reg_count != 0;
+    if (hasreg) {
+        TRY(ensure(ctx, ctx->pt_flags, (size_t)G.n + 64));
+        HIPCHK(hipMemsetAsync(ctx->pt_flags.p, 0, (size_t)G.n, st));
+        a.ptflags = (const uint8_t *)ctx->pt_flags.p;
+        const unsigned rgrid = (unsigned)((G.nblocks + 3) / 4);
+        if (!DEC) {
+            TRY(ensure(ctx, ctx->rb_vals, (size_t)G.n * sizeof(T) + 64));
+            a.xr = (const T *)ctx->rb_vals.p;
+            hipLaunchKernelGGL((k_reg_points<T, 0>), dim3(rgrid), dim3(256), 0, st, G, a.blk_lor, a.coef, a.coef_stride, a.data, (T *)ctx->rb_vals.p, a.codes, (uint8_t *)ctx->pt_flags.p,
+                               a.eb, a.recip, a.cap, a.radius);
+        } else
+            hipLaunchKernelGGL((k_reg_points<T, 2>), dim3(rgrid), dim3(256), 0, st, G, a.blk_lor, a.coef, a.coef_stride, (const T *)nullptr, a.out, a.codes, (uint8_t *)ctx->pt_flags.p,
+                               a.eb, a.recip, a.cap, a.radius);
+        HIPCHK(hipGetLastError());
+    }
+    const dim3 grid(wgs), block(szh_bm::WPG * 64);
+    if (hasreg) {
+        if (a.use_mean) hipLaunchKernelGGL((k_beam<T, DEC, true, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_beam<T, DEC, false, true>), grid, block, 0, st, a);
+    } else {
+        if (a.use_mean) hipLaunchKernelGGL((k_beam<T, DEC, true, false>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_beam<T, DEC, false, false>), grid, block, 0, st, a);
+    }
+    if (hasreg && !DEC) {
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL((k_reg_points<T, 1>), dim3((unsigned)((G.nblocks + 3) / 4)), dim3(256), 0, st, G, a.blk_lor, a.coef, a.coef_stride, a.data, (T *)nullptr, a.codes, (uint8_t *)nullptr,
+                           a.eb, a.recip, a.cap, a.radius);
+    }
     HIPCHK(hipGetLastError());
     return SZHIP_OK;
 }
@@ -751,7 +782,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         //  rounds of tools/gpu_pool_dbg.py -- errors, not wrong streams; none in 480 rounds with the serial order.  The lanes overlap one
         //  array's chain with the other's kernels anyway.
         //  A lone context takes the overlap only when no other compress call of the process is under way as this one starts.)
-        overlap = !two_d && !ctx->gate && !ctx->no_chain_overlap && g_compress_calls.load() <= 1 && tune_int("SZ_HIP_CHAIN_THREADS", 1) && tune_int("SZ_HIP_CHAIN_OVERLAP", 1);
+        overlap = !beam_applies<T>(G, d_in, reg_count) && !two_d && !ctx->gate && !ctx->no_chain_overlap && g_compress_calls.load() <= 1 && tune_int("SZ_HIP_CHAIN_THREADS", 1) && tune_int("SZ_HIP_CHAIN_OVERLAP", 1);
         if (overlap) { TRY(probe_streams(ctx)); overlap = ctx->streams_independent == 1; }
 #endif
         TRY(ensure_pinned3(ctx, reg_count * 4 * sizeof(T) + (overlap ? ((size_t)nb + 64) * 4 * sizeof(T) + 256 : 0)));
@@ -889,7 +920,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
             if (ctx->gate->last && ctx->gate->last != ctx->ev_gate) HIPCHK(hipStreamWaitEvent(st, ctx->gate->last, 0));   // the other lane's sweep first
         }
         HIPCHK(hipEventRecord(ctx->ev[2], st));
-        if (use_beam) { TRY((launch_beam<T, false>(ctx, G, a, st))); S.quant_kernel = 2; }
+        if (use_beam) { TRY((launch_beam<T, false>(ctx, G, a, st, reg_count))); S.quant_kernel = 2; }
         else if (use_ribbon) { TRY((launch_ribbon<T, false>(ctx, G, a, st))); S.quant_kernel = 1; }
         else {
         const unsigned pgrid = pencil_grid(ctx, a, ntiles);
@@ -1550,7 +1581,7 @@ int decompress_impl(szhip_ctx *ctx, const unsigned char *stream_in, int stream_o
         a.trace = tune_int("SZ_HIP_TRACE", 0) ? (szh_u64 *)ctx->trace.p : nullptr;
         a.dbg = tune_int("SZ_HIP_DBG", 0); a.trace_tile = tune_int("SZ_HIP_TRACE_TILE", 1);
         HIPCHK(hipEventRecord(ctx->ev[2], st));
-        if (dec_beam) { TRY((launch_beam<T, true>(ctx, G, a, st))); S.quant_kernel = 2; }
+        if (dec_beam) { TRY((launch_beam<T, true>(ctx, G, a, st, reg_count))); S.quant_kernel = 2; }
         else if (dec_ribbon) {
             a.codes_ribbon = dec_ribbon_mode == 2 ? 2 : 1;
             if (dec_ribbon_mode == 2) a.out = d_sweep;
@@ -3286,7 +3317,7 @@ void szhip_destroy(szhip_ctx *ctx)
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->lor_bits, &ctx->reg_flags, &ctx->reg_rank, &ctx->coef_compact, &ctx->in, &ctx->out, &ctx->codes_nat, &ctx->codes_blk, &ctx->coef, &ctx->blk_lor, &ctx->faceI, &ctx->faceJ, &ctx->rb_down, &ctx->rb_right, &ctx->fast_slots, &ctx->fast_units, &ctx->progress, &ctx->trace,
+    DevBuf *bufs[] = {&ctx->lor_bits, &ctx->reg_flags, &ctx->reg_rank, &ctx->coef_compact, &ctx->in, &ctx->out, &ctx->codes_nat, &ctx->codes_blk, &ctx->coef, &ctx->blk_lor, &ctx->faceI, &ctx->faceJ, &ctx->rb_down, &ctx->rb_right, &ctx->rb_vals, &ctx->pt_flags, &ctx->fast_slots, &ctx->fast_units, &ctx->progress, &ctx->trace,
                       &ctx->order, &ctx->small, &ctx->hist, &ctx->col_zeros, &ctx->col_zeros64, &ctx->col_off, &ctx->partial,
                       &ctx->samples, &ctx->unpred, &ctx->stream_buf, &ctx->chunk_bits, &ctx->chunk_off, &ctx->code_tab,
                       &ctx->len_tab, &ctx->dec_tab, &ctx->starts, &ctx->ends, &ctx->counts, &ctx->offs, &ctx->dirty, &ctx->zcnt, &ctx->zpos,
