@@ -17,6 +17,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
 
 void szhost_put_u32be(unsigned char *b, uint32_t v) { b[0] = (unsigned char)(v >> 24); b[1] = (unsigned char)(v >> 16); b[2] = (unsigned char)(v >> 8); b[3] = (unsigned char)v; }
 void szhost_put_u64be(unsigned char *b, uint64_t v) { szhost_put_u32be(b, (uint32_t)(v >> 32)); szhost_put_u32be(b + 4, (uint32_t)v); }
@@ -393,11 +394,145 @@ void szhost_coeff_chain_begin(int is_double, const unsigned char *indicator, siz
     }
 }
 
-void szhost_coeff_chain_one_p(int is_double, void *coef, const unsigned char *indicator, size_t nblocks, int use_mean, int e, szhost_coeffs *out,
-                              size_t *progress)
+/* The reference's loop, literally (sz_float.c:7126-7152 / :6790-6812): ~45 cycles of dependent latency per block and coefficient (subtract,
+ * divide, add, halve, truncate, convert back, multiply, add), 3.9 ms for the 3 x 10^5 regression blocks of the 512^3 M-field.  Kept as the
+ * fall-back of single steps and as what the tests compare the fast form against. */
+void szhost_coeff_chain_one_ref(int is_double, void *coef, const unsigned char *indicator, size_t nblocks, int use_mean, int e, szhost_coeffs *out,
+                                size_t *progress)
 {
     if (is_double) { CHAIN_ONE(double, fabs, 0) }
     else { CHAIN_ONE(float, fabsf, 1) }
+}
+
+/* The same chain with most of the arithmetic taken OFF the loop-carried path (round 5).  The interval number of a step,
+ * q = (int)((|d| / prec + 1) / 2), is a monotone step function of |d| = |c_k - last_{k-1}|.  Its steps lie at T[n] = the smallest magnitude
+ * with q >= n, found once per precision with the reference's own expression (a few evaluations around (2 n - 1) prec each: tables of 32 769
+ * entries, cached); and since |c_{k-1} - last_{k-1}| <= prec after every step, |d| lies within prec of |c_k - c_{k-1}|, which is known
+ * without the chain: three candidates n0, n0 + 1, n0 + 2 chosen from the ORIGINAL coefficients cover it with a margin.  What remains on the
+ * chain is subtract, compares, a select among the candidates' pre-multiplied addends, and the add; the table look-ups of later steps run
+ * ahead of it.  A magnitude outside the candidates' range (or anything not finite) takes the reference's expression for that step.  Bit for
+ * bit the reference's codes, decoded values and verbatim coefficients (tests/test_host_logic.py compares the two forms on adversarial
+ * sequences). */
+#define CHAIN_TAB_N 32768
+typedef struct chain_tab { int is_double, variant; uint64_t prec_bits; void *thr, *pos, *neg; } chain_tab;
+#define CHAIN_TAB_SLOTS 16
+static chain_tab g_chain_tabs[CHAIN_TAB_SLOTS];
+static int g_chain_tab_count = 0;
+static pthread_mutex_t g_chain_tab_mu = PTHREAD_MUTEX_INITIALIZER;
+
+#define CHAIN_TAB_BUILD(T, NEXTAFTER, HUGE)                                                                          \
+    T *tt = (T *)malloc((CHAIN_TAB_N + 4) * sizeof(T)), *ta = (T *)malloc((CHAIN_TAB_N + 4) * sizeof(T)),            \
+      *tn = (T *)malloc((CHAIN_TAB_N + 4) * sizeof(T));                                                               \
+    if (!tt || !ta || !tn) { free(tt); free(ta); free(tn); return NULL; }                                             \
+    const T prec = (T)precd, rprec = 1 / prec;                                                                        \
+    tt[0] = 0;                                                                                                        \
+    for (int n = 0; n <= CHAIN_TAB_N + 3; n++) {                                                                      \
+        ta[n] = (T)(2 * n) * prec; tn[n] = (T)0 - ta[n];                                                              \
+        if (n == 0) continue;                                                                                         \
+        if (n > CHAIN_TAB_N) { tt[n] = HUGE; continue; }                                                              \
+        const T want = (T)(2 * n);                                                                                    \
+        T x = (T)(2 * n - 1) * prec;                                                                                  \
+        int guard = 0;                                                                                                \
+        while (x > 0 && (variant ? x * rprec + 1 : x / prec + 1) >= want && guard++ < 4096) x = NEXTAFTER(x, (T)0);   \
+        while ((variant ? x * rprec + 1 : x / prec + 1) < want && guard++ < 8192) x = NEXTAFTER(x, HUGE);             \
+        if (guard >= 4096) { free(tt); free(ta); free(tn); return NULL; }                                             \
+        tt[n] = x;                                                                                                    \
+    }                                                                                                                 \
+    t.thr = tt; t.pos = ta; t.neg = tn;
+
+static const chain_tab *chain_tab_get(int is_double, int variant, double precd)
+{
+    uint64_t bits; memcpy(&bits, &precd, 8);
+    if (!(precd > 0) || !isfinite(precd) || !isfinite(precd * 131080.0) || (is_double ? precd < 1e-290 : precd < 1e-30)) return NULL;
+    pthread_mutex_lock(&g_chain_tab_mu);
+    for (int i = 0; i < g_chain_tab_count; i++)
+        if (g_chain_tabs[i].is_double == is_double && g_chain_tabs[i].variant == variant && g_chain_tabs[i].prec_bits == bits) {
+            pthread_mutex_unlock(&g_chain_tab_mu);
+            return &g_chain_tabs[i];
+        }
+    pthread_mutex_unlock(&g_chain_tab_mu);
+    chain_tab t; t.is_double = is_double; t.variant = variant; t.prec_bits = bits; t.thr = t.pos = t.neg = NULL;
+    if (is_double) { CHAIN_TAB_BUILD(double, nextafter, HUGE_VAL) }
+    else { CHAIN_TAB_BUILD(float, nextafterf, HUGE_VALF) }
+    pthread_mutex_lock(&g_chain_tab_mu);
+    for (int i = 0; i < g_chain_tab_count; i++)                            /* another thread built the same table meanwhile */
+        if (g_chain_tabs[i].is_double == is_double && g_chain_tabs[i].variant == variant && g_chain_tabs[i].prec_bits == bits) {
+            pthread_mutex_unlock(&g_chain_tab_mu);
+            free(t.thr); free(t.pos); free(t.neg);
+            return &g_chain_tabs[i];
+        }
+    if (g_chain_tab_count == CHAIN_TAB_SLOTS) {                            /* (entries are never freed: a chain may still be reading them; a full cache stops caching) */
+        pthread_mutex_unlock(&g_chain_tab_mu);
+        free(t.thr); free(t.pos); free(t.neg);
+        return NULL;
+    }
+    g_chain_tabs[g_chain_tab_count] = t;
+    const chain_tab *r = &g_chain_tabs[g_chain_tab_count++];
+    pthread_mutex_unlock(&g_chain_tab_mu);
+    return r;
+}
+
+#define CHAIN_FAST(T, U, FABS)                                                                                       \
+    T *cf = (T *)coef + (size_t)e * nblocks;                                                                           \
+    const T prec = (T)out->prec[e], rprec = 1 / prec, prec2 = prec + prec, nlimit = (T)(2 * (CHAIN_TAB_N - 4));        \
+    const T *tt = (const T *)tab->thr, *ta = (const T *)tab->pos, *tn = (const T *)tab->neg;                           \
+    T last = 0, prevc = 0;                                                                                             \
+    T *un = (T *)out->unpred[e];                                                                                       \
+    int *codes = out->codes[e];                                                                                        \
+    size_t ci = 0, nun = 0;                                                                                            \
+    for (size_t b = 0; b < nblocks; b++) {                                                                             \
+        if (indicator[b]) continue;                                                                                    \
+        const T cur = cf[b];                                                                                           \
+        /* off the chain: the candidates from the original coefficients */                                             \
+        const T lo = FABS(cur - prevc) - prec2, ql = lo * rprec;                                                       \
+        prevc = cur;                                                                                                   \
+        int cc = 0;                                                                                                    \
+        const int fast = ql < nlimit;                            /* (false for NaN) */                                 \
+        const T qc = fast ? (ql > 0 ? ql : (T)0) : (T)0;         /* (selects, not branches: the data decide them) */   \
+        int n0 = (int)((qc + 1) * (T)0.5) - 1;                                                                         \
+        n0 = n0 < 0 ? 0 : n0;                                                                                          \
+        const T t0 = tt[n0], t1 = tt[n0 + 1], t2 = tt[n0 + 2], t3 = tt[n0 + 3];                                        \
+        U p0, p1, p2, g0, g1, g2;                                                                                      \
+        memcpy(&p0, &ta[n0], sizeof(T)); memcpy(&p1, &ta[n0 + 1], sizeof(T)); memcpy(&p2, &ta[n0 + 2], sizeof(T));     \
+        memcpy(&g0, &tn[n0], sizeof(T)); memcpy(&g1, &tn[n0 + 1], sizeof(T)); memcpy(&g2, &tn[n0 + 2], sizeof(T));     \
+        /* on the chain */                                                                                             \
+        const T diff = cur - last, ad = FABS(diff);                                                                    \
+        if (__builtin_expect(fast && ad >= t0 && ad < t3, 1)) {                                                        \
+            const int s1 = ad >= t1, s2 = ad >= t2, neg = diff < 0;                                                    \
+            const U m1 = (U)0 - (U)s1, m2 = (U)0 - (U)s2, mn = (U)0 - (U)neg;                                          \
+            const U pos = (p2 & m2) | (((p1 & m1) | (p0 & ~m1)) & ~m2), ngv = (g2 & m2) | (((g1 & m1) | (g0 & ~m1)) & ~m2); \
+            const U sel = (ngv & mn) | (pos & ~mn);                                                                    \
+            T add; memcpy(&add, &sel, sizeof(T));                                                                      \
+            const int q = n0 + s1 + s2;                                                                                \
+            cc = (neg ? -q : q) + 32768;                                                                               \
+            last = last + add;                                                                                         \
+            if (__builtin_expect(FABS(cur - last) > prec, 0)) { cc = 0; last = cur; un[nun++] = cur; }                 \
+        } else {                                                   /* the reference's expression for this step */      \
+            T itv;                                                                                                     \
+            if (!variant) itv = FABS(diff) / prec + 1; else itv = FABS(diff) * rprec + 1;                              \
+            if (itv < 65536) {                                                                                         \
+                if (diff < 0) itv = -itv;                                                                              \
+                cc = (int)(itv / 2) + 32768;                                                                           \
+                last = last + 2 * (cc - 32768) * prec;                                                                 \
+                if (FABS(cur - last) > prec) { cc = 0; last = cur; un[nun++] = cur; }                                  \
+            } else { cc = 0; last = cur; un[nun++] = cur; }                                                            \
+        }                                                                                                              \
+        codes[ci++] = cc;                                                                                              \
+        cf[b] = last;                                                                                                  \
+        if (progress && (ci & 1023) == 0) __atomic_store_n(progress, ci, __ATOMIC_RELEASE);                           \
+    }                                                                                                                  \
+    out->unpred_count[e] = nun;                                                                                        \
+    if (progress) __atomic_store_n(progress, ci, __ATOMIC_RELEASE);
+
+void szhost_coeff_chain_one_p(int is_double, void *coef, const unsigned char *indicator, size_t nblocks, int use_mean, int e, szhost_coeffs *out,
+                              size_t *progress)
+{
+    const int variant = (is_double || use_mean) ? 1 : 0;          /* 1: |diff| * (1 / prec), 0: |diff| / prec (sz_float.c:7133 against :6795, sz_double.c) */
+    const char *sw = getenv("SZ_HIP_CHAIN_FAST");
+    const chain_tab *tab = (sw && sw[0] == '0') ? NULL : chain_tab_get(is_double, variant, out->prec[e]);
+    if (!tab) { szhost_coeff_chain_one_ref(is_double, coef, indicator, nblocks, use_mean, e, out, progress); return; }
+    if (is_double) { CHAIN_FAST(double, uint64_t, fabs) }
+    else { CHAIN_FAST(float, uint32_t, fabsf) }
 }
 void szhost_coeff_chain_one(int is_double, void *coef, const unsigned char *indicator, size_t nblocks, int use_mean, int e, szhost_coeffs *out)
 {

@@ -70,6 +70,9 @@ void szhost_coeff_chain_one(int is_double, void *coef, const unsigned char *indi
 /* the same, publishing the number of regression blocks finished so far in *progress (release stores, every 1024 blocks and at the end) */
 void szhost_coeff_chain_one_p(int is_double, void *coef, const unsigned char *indicator, size_t nblocks, int use_mean, int e, szhost_coeffs *out,
                               size_t *progress);
+/* the reference's loop, literally (the fall-back and the tests' yardstick of szhost_coeff_chain_one_p, which takes the arithmetic off the chain) */
+void szhost_coeff_chain_one_ref(int is_double, void *coef, const unsigned char *indicator, size_t nblocks, int use_mean, int e, szhost_coeffs *out,
+                                size_t *progress);
 void szhost_coeffs_free(szhost_coeffs *c);
 /* inverse: codes+unpred -> decoded coefficients written into coef SoA [ncoef][nblocks] for regression blocks */
 void szhost_coeff_unchain(int is_double, void *coef, const unsigned char *indicator, size_t nblocks,

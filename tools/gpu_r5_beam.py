@@ -15,7 +15,7 @@ def small_parity():
     rng = np.random.default_rng(7)
     cases = [("S-12x8x32", s_field(12, 8, 32), 1e-4), ("S-10x40x36", s_field(10, 40, 36), 1e-4), ("S-64^3", s_field(64, 64, 64), 1e-4),
              ("N-60x36x40", (s_field(60, 36, 40) + (rng.random((60, 36, 40)) - 0.5) * 3e-4).astype(np.float32), 1e-4),
-             ("S-100x70x68", s_field(100, 70, 68), 1e-4), ("S64-41x70x36", s_field(41, 70, 36, np.float64), 1e-3), ("S-128^3", s_field(128, 128, 128), 1e-4)]
+             ("S-100x70x68", s_field(100, 70, 68), 1e-4), ("M40", m_field(40), 1e-4), ("M64", m_field(64), 1e-4), ("M36-f64", m_field(36, np.float64), 1e-3), ("S64-41x70x36", s_field(41, 70, 36, np.float64), 1e-3), ("S-128^3", s_field(128, 128, 128), 1e-4)]
     assert sz_amd.SZ_Init(os.path.join(ROOT, "tests", "golden", "sz_speed.config")) == 0
     bad = 0
     for name, d, eb in cases:
@@ -37,9 +37,9 @@ def small_parity():
     os.environ["SZ_HIP_BEAM"] = "1"
     return bad
 
-def full(edge):
+def full(edge, field="s"):
     dev = torch.device("cuda:0")
-    d = torch.from_numpy(s_field(edge, edge, edge)).to(dev)
+    d = torch.from_numpy(s_field(edge, edge, edge) if field == "s" else m_field(edge)).to(dev)
     out = torch.empty_like(d)
     meta = api.make_meta(np.float32, api.ABS, 1e-4)
     res = {}
@@ -67,7 +67,7 @@ def full(edge):
                 torch.cuda.synchronize()
                 td.append((time.time() - t0) * 1e3); tdq.append(st.ms_quant)
             err = float((out.double() - d.double()).abs().max())
-            res[beam] = {"md5": md5, "size": size, "quant_ms": sorted(tq)[len(tq) // 2], "quant_ms_min": min(tq), "call_ms": sorted(tt)[len(tt) // 2], "dec_call_ms": sorted(td)[len(td) // 2],
+            res[beam] = {"field": field, "md5": md5, "size": size, "host_ms": round(st.ms_host, 3), "reg_blocks": int(st.n_reg_blocks), "quant_ms": sorted(tq)[len(tq) // 2], "quant_ms_min": min(tq), "call_ms": sorted(tt)[len(tt) // 2], "dec_call_ms": sorted(td)[len(td) // 2],
                          "dec_quant_ms": sorted(tdq)[len(tdq) // 2], "max_err": err, "out_md5": hashlib.md5(out.cpu().numpy().tobytes()).hexdigest()}
         except Exception as e:  # noqa: BLE001
             res[beam] = {"error": str(e)[:300]}
@@ -81,4 +81,5 @@ if __name__ == "__main__":
     bad = small_parity()
     print(json.dumps({"check": "small-summary", "bad": bad}), flush=True)
     if bad == 0 or os.environ.get("R5_FORCE_FULL"):
-        full(edge)
+        for f in os.environ.get("R5_FIELDS", "s,m").split(","):
+            full(edge, f)
