@@ -35,6 +35,9 @@
 #pragma once
 // (included by szhip_kernels.h after szh_ribbon.h and szh_ompcol.h, whose helpers it uses)
 
+#ifndef SZH_DEV
+#define SZH_DEV 0
+#endif
 namespace szh_bm {
 using szh_oc::mask_t;
 using szh_oc::lane_mask;
@@ -222,6 +225,7 @@ struct beam {
     greg_t gk[DK], gj[DK];                                         // k-face / j-face granules on their way
     T eb, eb2, rh, caph, radf, mean; int radius; unsigned epoch;
     unsigned lo_it;                                                // LDS offset of wave line `it` in the ring (uniform)
+    unsigned pv_prev, pv_next;                                     // the neighbouring wavefronts' progress words as read a step ago
 
     __device__ __forceinline__ beam(const szh_qargs<T> &args) : a(args) {}
 
@@ -332,6 +336,10 @@ struct beam {
             });
             if (zero_face) { const v4u z = {0u, 0u, 0u, 0u}; if (lane < S::HB / 16) lds_put16(ring, loX + (unsigned)lane * 16u, z); }
             if (DEC) { constexpr int set = (LL + 1) % UL; lds_put8(ring, loX + cl, gc[set]); gc[set] = load_c<EDGE>(it + 1 + UL); }
+        }
+        if constexpr (U == 4) {
+            pv_prev = lds_get<unsigned>((OC_LDS unsigned char *)(prog + (has_prev ? w - 1 : w)), 0);
+            pv_next = lds_get<unsigned>((OC_LDS unsigned char *)(prog + (has_next ? w + 1 : w)), 0);
         }
         if constexpr (U == 3) {
             constexpr int set = (LL + 1) % DK, kl = (LL + 1) % KRL;
@@ -458,14 +466,15 @@ struct beam {
     template <int LL, bool EDGE> __device__ __forceinline__ void line(int it)
     {
         // the wavefront below (in j) must be far enough ahead for the virtual cells read during this line, the one above not too far behind
-        if (!(dbg & 1)) {
-        if (has_prev) wait_prog(prog + (w - 1), it + 3);
-        if (has_next) wait_prog(prog + (w + 1), it - (RL - 2));
+        // (their progress words were read during the last step of the line before: no LDS round trip here unless one of them is late)
+        if (!(SZH_DEV && (dbg & 1))) {
+        if (has_prev && uni((int)pv_prev) < it + 3) wait_prog(prog + (w - 1), it + 3);
+        if (has_next && uni((int)pv_next) < it - (RL - 2)) wait_prog(prog + (w + 1), it - (RL - 2));
         }
         for_n<LINE>([&](auto UU) {
             constexpr int U = decltype(UU)::value;
             wave_sync();
-            if (!((dbg >> U) & 1) || U == 0) events<U, LL, EDGE>(it);
+            if (!(SZH_DEV && ((dbg >> U) & 1)) || U == 0) events<U, LL, EDGE>(it);
             order();
             step<U, LL, EDGE>(it);
             order();
@@ -593,6 +602,7 @@ struct beam {
             take<true, false>(0, j0g, ring, 0u);
         }
         if (has_prev) wait_prog(prog + (w - 1), 3);
+        pv_prev = 0u; pv_next = 0u;
         order();
         wave_sync();
         cur_next = lds_get<T>(lds0, vaddr);

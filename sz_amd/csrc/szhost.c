@@ -413,6 +413,7 @@ void szhost_coeff_chain_one_ref(int is_double, void *coef, const unsigned char *
  * ahead of it.  A magnitude outside the candidates' range (or anything not finite) takes the reference's expression for that step.  Bit for
  * bit the reference's codes, decoded values and verbatim coefficients (tests/test_host_logic.py compares the two forms on adversarial
  * sequences). */
+#define COMMA ,
 #define CHAIN_TAB_N 32768
 typedef struct chain_tab { int is_double, variant; uint64_t prec_bits; void *thr, *pos, *neg; } chain_tab;
 #define CHAIN_TAB_SLOTS 16
@@ -472,7 +473,67 @@ static const chain_tab *chain_tab_get(int is_double, int variant, double precd)
     return r;
 }
 
-#define CHAIN_FAST(T, U, FABS)                                                                                       \
+
+/* The lean form of a step (most steps), in loops of their own (their register allocation is not the general loop's): when |c_k - c_{k-1}|
+ * exceeds the precision by a margin, the SIGN of c_k - last is the sign of c_k - c_{k-1}, and two candidates n, n + 1 with ONE threshold between
+ * them cover |c_k - last| (its range is one step of the interval number wide): what is left on the chain is subtract, abs, ONE compare whose
+ * result is the select mask, and the add -- all in the vector registers (SSE2 scalar forms).  n is the interval number of
+ * |c_k - c_{k-1}| - prec, by the reference's own expression (a divide, but off the chain).  Everything the selection assumes is checked by
+ * predictable branches; a step that fails a check ends the lean loop, which returns how far it came: the general form takes that step. */
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#define CHAIN_LEAN_FN(NAME, T, V, LOADS, GETS, SUBS, ADDS, ANDV, ANDNV, ORV, CMPLES, COMILT, COMIGE, COMIGT, MOVMSK, ABSMASK, FABS)     \
+static size_t NAME(const T *cf, size_t b, size_t nblocks, const unsigned char *indicator, T *plast, T *pprevc, T *cfo, int *codes,     \
+                   size_t *pci, const T *tt, const T *ta, const T *tn, T prec, int variant, size_t *progress)                          \
+{                                                                                                                                  \
+    const T rprec = 1 / prec, lim = prec * (T)1.5, pm = prec * (T)1.0001, nlimit = (T)(2 * (CHAIN_TAB_N - 4)) * prec;                   \
+    const V absmask = ABSMASK, vprec = LOADS(&prec);                                                                               \
+    V vlast = LOADS(plast);                                                                                                        \
+    T prevc = *pprevc;                                                                                                             \
+    size_t ci = *pci;                                                                                                              \
+    for (; b < nblocks; b++) {                                                                                                     \
+        if (indicator[b]) continue;                                                                                                \
+        const T cur = cf[b], Dk = cur - prevc, aD = FABS(Dk);                                                                      \
+        if (!(aD > lim && aD < nlimit)) break;                     /* (also NaN) */                                                \
+        const T lo1 = aD - pm;                                                                                                     \
+        const int n1 = (int)(((variant ? lo1 * rprec : lo1 / prec) + 1) * (T)0.5);                                                 \
+        const int neg = Dk < 0;                                                                                                    \
+        const T *sg = neg ? tn : ta;                                                                                               \
+        const V vt = LOADS(&tt[n1 + 1]), vcur = LOADS(&cf[b]);                                                                     \
+        const V vd = SUBS(vcur, vlast), vad = ANDV(vd, absmask);                                                                   \
+        const V m = CMPLES(vt, vad);                                                                                               \
+        const V vnew = ADDS(vlast, ORV(ANDV(m, LOADS(&sg[n1 + 1])), ANDNV(m, LOADS(&sg[n1]))));                                    \
+        /* what the selection assumed: the magnitude within the two candidates' range, the sign as predicted, the bound kept */     \
+        if (!(COMIGE(vad, LOADS(&tt[n1])) && COMILT(vad, LOADS(&tt[n1 + 2])))) break;                                              \
+        if (neg != (MOVMSK(vd) & 1)) break;                                                                                        \
+        if (COMIGT(ANDV(SUBS(vcur, vnew), absmask), vprec)) break;                                                                 \
+        const int q = n1 + (MOVMSK(m) & 1);                                                                                        \
+        vlast = vnew; prevc = cur;                                                                                                 \
+        codes[ci++] = (neg ? -q : q) + 32768;                                                                                      \
+        cfo[b] = GETS(vnew);                                                                                                       \
+        if (progress && (ci & 1023) == 0) __atomic_store_n(progress, ci, __ATOMIC_RELEASE);                                       \
+    }                                                                                                                              \
+    *plast = GETS(vlast); *pprevc = prevc; *pci = ci;                                                                              \
+    return b;                                                                                                                      \
+}
+CHAIN_LEAN_FN(chain_lean_f32, float, __m128, _mm_load_ss, _mm_cvtss_f32, _mm_sub_ss, _mm_add_ss, _mm_and_ps, _mm_andnot_ps, _mm_or_ps, _mm_cmple_ss,
+              _mm_comilt_ss, _mm_comige_ss, _mm_comigt_ss, _mm_movemask_ps, _mm_castsi128_ps(_mm_set_epi32(0, 0, 0, 0x7fffffff)), fabsf)
+CHAIN_LEAN_FN(chain_lean_f64, double, __m128d, _mm_load_sd, _mm_cvtsd_f64, _mm_sub_sd, _mm_add_sd, _mm_and_pd, _mm_andnot_pd, _mm_or_pd, _mm_cmple_sd,
+              _mm_comilt_sd, _mm_comige_sd, _mm_comigt_sd, _mm_movemask_pd, _mm_castsi128_pd(_mm_set_epi64x(0, 0x7fffffffffffffffll)), fabs)
+/* (data whose steps are mostly NOT lean -- coefficients that differ by about a precision -- would pay for a failed attempt at every step: after 8 in
+ *  a row that got nowhere the next 64 steps go straight to the general form) */
+#define CHAIN_LEAN_CALL(FN) { if (lean_skip > 0 || ref_steps > 0) { if (lean_skip > 0) --lean_skip; } else { const size_t b_in = b;                                      \
+        b = FN(cf, b, nblocks, indicator, &last, &prevc, cf, codes, &ci, tt, ta, tn, prec, variant, progress);                    \
+        if (b == b_in) { if (++lean_miss >= 8) { lean_miss = 0; lean_skip = 64; } } else lean_miss = 0;                           \
+        if (b >= nblocks) break; if (indicator[b]) continue; } }
+#define CHAIN_LEAN_F32 CHAIN_LEAN_CALL(chain_lean_f32)
+#define CHAIN_LEAN_F64 CHAIN_LEAN_CALL(chain_lean_f64)
+#else
+#define CHAIN_LEAN_F32
+#define CHAIN_LEAN_F64
+#endif
+
+#define CHAIN_FAST(T, U, FABS, CHAIN_LEAN_TRY, VDECL)                                                                                       \
     T *cf = (T *)coef + (size_t)e * nblocks;                                                                           \
     const T prec = (T)out->prec[e], rprec = 1 / prec, prec2 = prec + prec, nlimit = (T)(2 * (CHAIN_TAB_N - 4));        \
     const T *tt = (const T *)tab->thr, *ta = (const T *)tab->pos, *tn = (const T *)tab->neg;                           \
@@ -480,14 +541,20 @@ static const chain_tab *chain_tab_get(int is_double, int variant, double precd)
     T *un = (T *)out->unpred[e];                                                                                       \
     int *codes = out->codes[e];                                                                                        \
     size_t ci = 0, nun = 0;                                                                                            \
+    int lean_miss = 0, lean_skip = 0; (void)lean_miss; (void)lean_skip;                                               \
+    int ref_steps = 0, odd = 0, seen = 0;      /* data on which the candidates rarely hold (verbatim coefficients all over): the plain loop for a while */ \
     for (size_t b = 0; b < nblocks; b++) {                                                                             \
         if (indicator[b]) continue;                                                                                    \
+        CHAIN_LEAN_TRY                                             /* as many lean steps as come in a row; then this one in the general form */ \
         const T cur = cf[b];                                                                                           \
         /* off the chain: the candidates from the original coefficients */                                             \
-        const T lo = FABS(cur - prevc) - prec2, ql = lo * rprec;                                                       \
+        const T Dk = cur - prevc, aD = FABS(Dk);                                                                       \
+        const T lo = aD - prec2, ql = lo * rprec;                                                                      \
         prevc = cur;                                                                                                   \
         int cc = 0;                                                                                                    \
-        const int fast = ql < nlimit;                            /* (false for NaN) */                                 \
+        if (ref_steps > 0) --ref_steps;                                                                                \
+        if (++seen == 256) { if (odd > 32) ref_steps = 4096; seen = 0; odd = 0; }                                      \
+        const int fast = ql < nlimit && ref_steps == 0;          /* (false for NaN) */                                 \
         const T qc = fast ? (ql > 0 ? ql : (T)0) : (T)0;         /* (selects, not branches: the data decide them) */   \
         int n0 = (int)((qc + 1) * (T)0.5) - 1;                                                                         \
         n0 = n0 < 0 ? 0 : n0;                                                                                          \
@@ -506,8 +573,9 @@ static const chain_tab *chain_tab_get(int is_double, int variant, double precd)
             const int q = n0 + s1 + s2;                                                                                \
             cc = (neg ? -q : q) + 32768;                                                                               \
             last = last + add;                                                                                         \
-            if (__builtin_expect(FABS(cur - last) > prec, 0)) { cc = 0; last = cur; un[nun++] = cur; }                 \
+            if (__builtin_expect(FABS(cur - last) > prec, 0)) { cc = 0; last = cur; un[nun++] = cur; ++odd; }          \
         } else {                                                   /* the reference's expression for this step */      \
+            ++odd;                                                                                                     \
             T itv;                                                                                                     \
             if (!variant) itv = FABS(diff) / prec + 1; else itv = FABS(diff) * rprec + 1;                              \
             if (itv < 65536) {                                                                                         \
@@ -531,8 +599,8 @@ void szhost_coeff_chain_one_p(int is_double, void *coef, const unsigned char *in
     const char *sw = getenv("SZ_HIP_CHAIN_FAST");
     const chain_tab *tab = (sw && sw[0] == '0') ? NULL : chain_tab_get(is_double, variant, out->prec[e]);
     if (!tab) { szhost_coeff_chain_one_ref(is_double, coef, indicator, nblocks, use_mean, e, out, progress); return; }
-    if (is_double) { CHAIN_FAST(double, uint64_t, fabs) }
-    else { CHAIN_FAST(float, uint32_t, fabsf) }
+    if (is_double) { CHAIN_FAST(double, uint64_t, fabs, CHAIN_LEAN_F64, ) }
+    else { CHAIN_FAST(float, uint32_t, fabsf, CHAIN_LEAN_F32, ) }
 }
 void szhost_coeff_chain_one(int is_double, void *coef, const unsigned char *indicator, size_t nblocks, int use_mean, int e, szhost_coeffs *out)
 {

@@ -217,3 +217,55 @@ def test_slab_container_roundtrip():
     blob = slab.pack_container(np.float64, (1030, 64, 32), b, streams)
     dt, dims, bounds, got = slab.unpack_container(blob)
     assert dt == np.float64 and dims == (1030, 64, 32) and bounds == b and [bytes(g) for g in got] == streams
+
+
+class _Coeffs(ctypes.Structure):
+    _fields_ = [("reg_count", ctypes.c_size_t), ("codes", ctypes.POINTER(ctypes.c_int) * 4), ("unpred", ctypes.c_void_p * 4),
+                ("unpred_count", ctypes.c_size_t * 4), ("prec", ctypes.c_double * 4)]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("use_mean", [0, 1])
+def test_fast_coefficient_chain_equals_the_reference_loop(L, dtype, use_mean):
+    """round 5: szhost_coeff_chain_one_p keeps only subtract / compare / select / add on the loop-carried path (candidate interval numbers and their
+    exact thresholds come from the original coefficients); it must give the codes, decoded coefficients and verbatim values of the reference's
+    loop (szhost_coeff_chain_one_ref = sz_float.c:7126-7152 literally) bit for bit -- on random walks, values ON interval boundaries, jumps beyond
+    the code range, sign changes around zero, NaN / infinity."""
+    rng = np.random.default_rng(11)
+    is_double = int(dtype == np.float64)
+    eb = 1e-3 if is_double else 1e-4
+    nb = 6000
+    for kind in range(6):
+        ind = (rng.random(nb) < 0.3).astype(np.uint8) if kind % 2 else np.zeros(nb, dtype=np.uint8)
+        co = np.zeros((4, nb), dtype=dtype)
+        for e in range(4):
+            prec = 0.025 * eb / (6 if e < 3 else 1)
+            if kind == 0:
+                v = np.cumsum((rng.random(nb) - 0.5) * 40 * prec)
+            elif kind == 1:
+                v = (rng.integers(-10, 10, nb) * 2 + 1) * prec + (rng.random(nb) - 0.5) * 1e-9 * prec      # on the steps of the interval number
+            elif kind == 2:
+                v = (rng.random(nb) - 0.5) * 1e6 * prec                                                     # beyond the code range: verbatim
+            elif kind == 3:
+                v = (rng.random(nb) - 0.5) * 1.5 * prec                                                     # around zero: signs flip, codes 0 and +-1
+            elif kind == 4:
+                v = np.cumsum((rng.random(nb) - 0.5) * 6 * prec); v[::53] = np.nan; v[7::101] = np.inf
+            else:
+                v = np.cumsum(np.tile(np.arange(-3, 4), nb // 7 + 1)[:nb] * prec) + (rng.random(nb) - 0.5) * 2 * prec
+            co[e] = v.astype(dtype)
+        outs = []
+        for fn in (L.szhost_coeff_chain_one_p, L.szhost_coeff_chain_one_ref):
+            c = np.ascontiguousarray(co.copy())
+            st = _Coeffs()
+            L.szhost_coeff_chain_begin(is_double, ind.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(nb), ctypes.c_double(eb), 6, 6, 6, 4, ctypes.byref(st))
+            for e in range(4):
+                fn(is_double, c.ctypes.data_as(ctypes.c_void_p), ind.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(nb), use_mean, e, ctypes.byref(st), None)
+            rc = st.reg_count
+            codes = [np.ctypeslib.as_array(st.codes[e], shape=(rc,)).copy() for e in range(4)]
+            un = [ctypes.string_at(st.unpred[e], st.unpred_count[e] * c.itemsize) for e in range(4)]
+            outs.append((c.tobytes(), codes, un))
+            L.szhost_coeffs_free(ctypes.byref(st))
+        assert outs[0][0] == outs[1][0], (kind, "decoded coefficients")
+        for e in range(4):
+            assert np.array_equal(outs[0][1][e], outs[1][1][e]), (kind, e, "codes")
+            assert outs[0][2][e] == outs[1][2][e], (kind, e, "verbatim coefficients")
