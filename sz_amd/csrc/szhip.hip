@@ -736,6 +736,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     std::vector<unsigned char> all_reg_keep;   // "every block is a regression block" for the chain over the compacted coefficients
     std::vector<uint32_t> blk_of_rank;
     size_t chain_done[4] = {0, 0, 0, 0};       // regression blocks finished per coefficient (written by the chain threads)
+    double chain_t0[4] = {0, 0, 0, 0}, chain_t1[4] = {0, 0, 0, 0};   // (SZ_HIP_TIMING: when each chain thread started / finished its chain)
     bool overlap = false;
     T *hcoef = nullptr;   // pinned: an asynchronous copy to or from pageable memory makes the runtime pin and unpin the pages around it,
                           // which was seen to stall later calls for ~20 ms
@@ -792,6 +793,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         TP("coef on host");
         double h0 = now_ms();
         all_reg_keep.assign(reg_count, 0);
+        TP("chain begin");
         const std::vector<unsigned char> &all_reg = all_reg_keep;
         // 2-D planes are carried as {0, a, b, c}: the chain sees components 1..3
         T *const chain_in = hcoef + (two_d ? reg_count : 0);
@@ -816,7 +818,9 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
             for (int e = 0; e < ncoef; ++e) chained_f.push_back(chained[e].get_future());
             for (int e = 0; e < ncoef; ++e)
                 section_threads.emplace_back([&, e, chain_in, ind = all_reg.data()](std::promise<void> done) {
+                    chain_t0[e] = now_ms() - t_begin;
                     szhost_coeff_chain_one(is_double, chain_in, ind, reg_count, use_mean, e, &cf);
+                    chain_t1[e] = now_ms() - t_begin;
                     done.set_value();                     // the decoded coefficients of e are final: the main thread may ship them
                     make_section(e);
                 }, std::move(chained[e]));
@@ -826,6 +830,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         }
         host_ms += now_ms() - h0;
         TP("chain done");
+        if (tp_on) fprintf(stderr, "chain threads: %.2f-%.2f %.2f-%.2f %.2f-%.2f %.2f-%.2f | ", chain_t0[0], chain_t1[0], chain_t0[1], chain_t1[1], chain_t0[2], chain_t1[2], chain_t0[3], chain_t1[3]);
         if (!overlap) {
             HIPCHK(hipMemcpyAsync(ctx->coef_compact.p, hcoef, reg_count * 4 * sizeof(T), hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL((k_move_coef<T, 1>), dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, (const uint8_t *)d_lor,

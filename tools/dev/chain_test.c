@@ -45,11 +45,46 @@ int run(int is_double, size_t nb, int kind, double eb, int use_mean)
     szhost_coeffs_free(&a); szhost_coeffs_free(&r); free(ind); free(c0); free(c1);
     return bad;
 }
+int main2(void);
 int main()
 {
+#ifdef THREADS_MAIN
+    return main2();
+#endif
     int bad = 0;
     for (int d = 0; d < 2; d++) for (int kind = 0; kind < 10; kind++) for (int um = 0; um < 2; um++) bad |= run(d, 20000 + kind * 77, kind, d ? 1e-3 : 1e-4, um);
     bad |= run(0, 303450, 0, 1e-4, 0); bad |= run(0, 303450, 0, 1e-4, 0); bad |= run(1, 303450, 6, 2.9668932e-3, 0);
     printf(bad ? "FAILED\n" : "all identical\n");
     return bad;
 }
+
+/* ---- the four chains on four freshly created threads, as the product runs them (compile with -DTHREADS_MAIN) */
+#ifdef THREADS_MAIN
+#include <pthread.h>
+#include <unistd.h>
+typedef struct { int e; void *c; unsigned char *ind; size_t nb; szhost_coeffs *st; int fast; } job_t;
+static void *worker(void *p) { job_t *j = (job_t *)p; if (j->fast) szhost_coeff_chain_one_p(0, j->c, j->ind, j->nb, 0, j->e, j->st, NULL); else szhost_coeff_chain_one_ref(0, j->c, j->ind, j->nb, 0, j->e, j->st, NULL); return NULL; }
+int main2(void)
+{
+    const size_t nb = 303450; const double eb = 1e-4;
+    unsigned char *ind = calloc(nb, 1);
+    float *c0 = malloc(nb * 16);
+    double walk[4] = {0, 0, 0, 0};
+    for (int e = 0; e < 4; e++) for (size_t b = 0; b < nb; b++) { double prec = 0.025 * eb / (e < 3 ? 6 : 1); walk[e] += (rnd() - 0.5) * 40 * prec; c0[e * nb + b] = (float)walk[e]; }
+    printf("online cpus %ld\n", sysconf(_SC_NPROCESSORS_ONLN));
+    for (int rep = 0; rep < 8; rep++) {
+        const int fast = rep != 3;
+        float *c = malloc(nb * 16); memcpy(c, c0, nb * 16);
+        szhost_coeffs st; memset(&st, 0, sizeof st);
+        szhost_coeff_chain_begin(0, ind, nb, eb, 6, 6, 6, 4, &st);
+        usleep(3000);                                    /* the caller was busy elsewhere: cores asleep */
+        pthread_t th[4]; job_t j[4];
+        double t0 = now();
+        for (int e = 0; e < 4; e++) { j[e] = (job_t){e, c, ind, nb, &st, fast}; pthread_create(&th[e], NULL, worker, &j[e]); }
+        for (int e = 0; e < 4; e++) pthread_join(th[e], NULL);
+        printf("rep %d %s: 4 chains on 4 new threads %.3f ms\n", rep, fast ? "fast" : "ref ", now() - t0);
+        szhost_coeffs_free(&st); free(c);
+    }
+    return 0;
+}
+#endif
