@@ -413,6 +413,7 @@ void szhost_coeff_chain_one_ref(int is_double, void *coef, const unsigned char *
  * ahead of it.  A magnitude outside the candidates' range (or anything not finite) takes the reference's expression for that step.  Bit for
  * bit the reference's codes, decoded values and verbatim coefficients (tests/test_host_logic.py compares the two forms on adversarial
  * sequences). */
+unsigned long g_chain_generic_steps = 0;   /* (development: steps that took the general form) */
 #define COMMA ,
 #define CHAIN_TAB_N 32768
 typedef struct chain_tab { int is_double, variant; uint64_t prec_bits; void *thr, *pos, *neg; } chain_tab;
@@ -484,7 +485,7 @@ static const chain_tab *chain_tab_get(int is_double, int variant, double precd)
 #include <emmintrin.h>
 #define CHAIN_LEAN_FN(NAME, T, V, LOADS, GETS, SUBS, ADDS, ANDV, ANDNV, ORV, CMPLES, COMILT, COMIGE, COMIGT, MOVMSK, ABSMASK, FABS)     \
 static size_t NAME(const T *cf, size_t b, size_t nblocks, const unsigned char *indicator, T *plast, T *pprevc, T *cfo, int *codes,     \
-                   size_t *pci, const T *tt, const T *ta, const T *tn, T prec, int variant, size_t *progress)                          \
+                   size_t *pci, const T *tt, const T *ta, const T *tn, T prec, int variant, size_t *progress, T *un, size_t *pnun)     \
 {                                                                                                                                  \
     const T rprec = 1 / prec, lim = prec * (T)1.5, pm = prec * (T)1.0001, nlimit = (T)(2 * (CHAIN_TAB_N - 4)) * prec;                   \
     const V absmask = ABSMASK, vprec = LOADS(&prec);                                                                               \
@@ -506,11 +507,15 @@ static size_t NAME(const T *cf, size_t b, size_t nblocks, const unsigned char *i
         /* what the selection assumed: the magnitude within the two candidates' range, the sign as predicted, the bound kept */     \
         if (!(COMIGE(vad, LOADS(&tt[n1])) && COMILT(vad, LOADS(&tt[n1 + 2])))) break;                                              \
         if (neg != (MOVMSK(vd) & 1)) break;                                                                                        \
-        if (COMIGT(ANDV(SUBS(vcur, vnew), absmask), vprec)) break;                                                                 \
-        const int q = n1 + (MOVMSK(m) & 1);                                                                                        \
-        vlast = vnew; prevc = cur;                                                                                                 \
-        codes[ci++] = (neg ? -q : q) + 32768;                                                                                      \
-        cfo[b] = GETS(vnew);                                                                                                       \
+        prevc = cur;                                                                                                               \
+        if (__builtin_expect(COMIGT(ANDV(SUBS(vcur, vnew), absmask), vprec), 0)) {   /* the bound does not hold: the coefficient verbatim (sz_float.c:7143) */ \
+            vlast = vcur; codes[ci++] = 0; cfo[b] = cur; un[(*pnun)++] = cur;                                                      \
+        } else {                                                                                                                   \
+            const int q = n1 + (MOVMSK(m) & 1);                                                                                    \
+            vlast = vnew;                                                                                                          \
+            codes[ci++] = (neg ? -q : q) + 32768;                                                                                  \
+            cfo[b] = GETS(vnew);                                                                                                   \
+        }                                                                                                                          \
         if (progress && (ci & 1023) == 0) __atomic_store_n(progress, ci, __ATOMIC_RELEASE);                                       \
     }                                                                                                                              \
     *plast = GETS(vlast); *pprevc = prevc; *pci = ci;                                                                              \
@@ -523,7 +528,7 @@ CHAIN_LEAN_FN(chain_lean_f64, double, __m128d, _mm_load_sd, _mm_cvtsd_f64, _mm_s
 /* (data whose steps are mostly NOT lean -- coefficients that differ by about a precision -- would pay for a failed attempt at every step: after 8 in
  *  a row that got nowhere the next 64 steps go straight to the general form) */
 #define CHAIN_LEAN_CALL(FN) { if (lean_skip > 0 || ref_steps > 0) { if (lean_skip > 0) --lean_skip; } else { const size_t b_in = b;                                      \
-        b = FN(cf, b, nblocks, indicator, &last, &prevc, cf, codes, &ci, tt, ta, tn, prec, variant, progress);                    \
+        b = FN(cf, b, nblocks, indicator, &last, &prevc, cf, codes, &ci, tt, ta, tn, prec, variant, progress, un, &nun);                    \
         if (b == b_in) { if (++lean_miss >= 8) { lean_miss = 0; lean_skip = 64; } } else lean_miss = 0;                           \
         if (b >= nblocks) break; if (indicator[b]) continue; } }
 #define CHAIN_LEAN_F32 CHAIN_LEAN_CALL(chain_lean_f32)
@@ -542,7 +547,7 @@ CHAIN_LEAN_FN(chain_lean_f64, double, __m128d, _mm_load_sd, _mm_cvtsd_f64, _mm_s
     int *codes = out->codes[e];                                                                                        \
     size_t ci = 0, nun = 0;                                                                                            \
     int lean_miss = 0, lean_skip = 0; (void)lean_miss; (void)lean_skip;                                               \
-    int ref_steps = 0, odd = 0, seen = 0;      /* data on which the candidates rarely hold (verbatim coefficients all over): the plain loop for a while */ \
+    int ref_steps = 0, odd = 0; size_t next_eval = 1024;   /* data on which the candidates rarely hold (verbatim coefficients all over): the plain loop for a while */ \
     for (size_t b = 0; b < nblocks; b++) {                                                                             \
         if (indicator[b]) continue;                                                                                    \
         CHAIN_LEAN_TRY                                             /* as many lean steps as come in a row; then this one in the general form */ \
@@ -553,7 +558,8 @@ CHAIN_LEAN_FN(chain_lean_f64, double, __m128d, _mm_load_sd, _mm_cvtsd_f64, _mm_s
         prevc = cur;                                                                                                   \
         int cc = 0;                                                                                                    \
         if (ref_steps > 0) --ref_steps;                                                                                \
-        if (++seen == 256) { if (odd > 32) ref_steps = 4096; seen = 0; odd = 0; }                                      \
+        if (ci >= next_eval) { if (odd > 128) ref_steps = 4096; odd = 0; next_eval = ci + 1024; }   /* (of ALL steps, the lean ones included) */ \
+        ++g_chain_generic_steps;                                                                                       \
         const int fast = ql < nlimit && ref_steps == 0;          /* (false for NaN) */                                 \
         const T qc = fast ? (ql > 0 ? ql : (T)0) : (T)0;         /* (selects, not branches: the data decide them) */   \
         int n0 = (int)((qc + 1) * (T)0.5) - 1;                                                                         \
