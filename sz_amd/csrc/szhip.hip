@@ -12,6 +12,7 @@
 #include <ctime>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <future>
 #include <mutex>
 #include <thread>
@@ -37,6 +38,60 @@ struct szhip_sweep_gate { std::mutex m; hipEvent_t last = nullptr; int lanes = 2
 // regression blocks is only taken by a call that starts alone (see compress_impl)
 static std::atomic<int> g_compress_calls{0};
 struct compress_call_guard { compress_call_guard() { g_compress_calls.fetch_add(1); } ~compress_call_guard() { g_compress_calls.fetch_sub(1); } };
+// The host's coefficient chains (szhost_coeff_chain_one_p: one serial chain per coefficient) on PERSISTENT threads (round 5).  Threads created per
+// call started 0.1 ms late on cores that had been idle (measured on the GPU box: four chains of 1.0 - 1.2 ms each took 2.1 - 2.7 ms end to
+// end, and 4.9 on some runs).  A context that has met regression blocks once keeps four workers; they are woken when a compression STARTS and
+// spin -- on cores that are awake by then -- until the fit pass has delivered the coefficients (~0.4 ms), or are sent back to sleep if the array
+// has no regression block.  A job has two stages: the chain (the caller waits for it: the sweep needs the decoded coefficients), then the
+// coefficient's section of the stream header (collected where the header is assembled).
+struct szhip_chain_pool {
+    std::thread th[4];
+    std::mutex m; std::condition_variable cv;
+    std::atomic<int> phase{0};                    // 0 asleep, 1 awake (spinning for a job), 2 quit
+    std::atomic<uint64_t> seq{0};
+    std::atomic<int> stage1{0}, stage2{0};
+    int n = 0;
+    std::function<void(int)> chain, section;
+    static void pause() {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    void run(int e)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return phase.load() != 0; }); }
+            if (phase.load() == 2) return;
+            while (phase.load(std::memory_order_acquire) == 1 && seq.load(std::memory_order_acquire) == seen) pause();
+            const uint64_t s = seq.load(std::memory_order_acquire);
+            if (s != seen) {
+                seen = s;
+                if (e < n) { chain(e); stage1.fetch_add(1, std::memory_order_release); section(e); }
+                stage2.fetch_add(1, std::memory_order_release);
+            }
+        }
+    }
+    void start() { for (int e = 0; e < 4; ++e) th[e] = std::thread([this, e] { run(e); }); }
+    void arm() { { std::lock_guard<std::mutex> lk(m); if (phase.load() == 0) phase.store(1); } cv.notify_all(); }
+    void disarm() { std::lock_guard<std::mutex> lk(m); if (phase.load() == 1) phase.store(0); }
+    void submit(int ncoef, std::function<void(int)> c, std::function<void(int)> sec)
+    {
+        n = ncoef; chain = std::move(c); section = std::move(sec);
+        stage1.store(0); stage2.store(0);
+        arm();
+        seq.fetch_add(1, std::memory_order_release);
+    }
+    void wait_chains() { while (stage1.load(std::memory_order_acquire) < n) pause(); }
+    void wait_all() { while (stage2.load(std::memory_order_acquire) < 4) std::this_thread::yield(); }
+    ~szhip_chain_pool()
+    {
+        { std::lock_guard<std::mutex> lk(m); phase.store(2); }
+        cv.notify_all();
+        for (auto &t : th) if (t.joinable()) t.join();
+    }
+};
+
 struct szhip_ctx {
     int device = 0;
     int fast_stat_per_cu[2] = {0, 0}, fast_pack_per_cu[2] = {0, 0};   // resident workgroups per CU of the fast mode's persistent kernels (float, double)
@@ -80,6 +135,7 @@ struct szhip_ctx {
     // the coefficient chain beside the running sweep (M-field): a sweep that gave up waiting for the coefficients (seen 5 - 6 times in 480 rounds with
     // several arrays in flight) is answered by ONE repetition with the chain finished before the sweep starts; the context keeps that order
     bool coef_late = false, no_chain_overlap = false;
+    szhip_chain_pool *chain_pool = nullptr;      // the coefficient chains' persistent threads (created with the first array that has regression blocks)
 };
 
 namespace {
@@ -704,6 +760,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     TP("fit joined");
     const size_t reg_count = (size_t)*nreg_h;
     S.n_reg_blocks = reg_count;
+    if (reg_count == 0 && ctx->chain_pool) ctx->chain_pool->disarm();
     // the parameter bytes as they go into the stream: with SZHIP_RANGE_FROM_DATA the range field comes from the fit pass
     // (computeRangeSize_float + `max = min + valueRangeSize`, sz_float.c:2845-2849, in the data's type)
     std::vector<unsigned char> meta_own(meta, meta + meta_len);
@@ -763,10 +820,12 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         sec.resize((size_t)(q - sec.data()));
         szhost_huff_free(ch);
     };
-    struct JoinSections {   // no early return may leave the section threads running on this frame's data
-        std::vector<std::thread> &t; szhost_coeffs &c;
-        ~JoinSections() { for (auto &x : t) if (x.joinable()) x.join(); szhost_coeffs_free(&c); }
-    } join_sections{section_threads, cf};
+    bool pool_busy = false;                     // a job of this call is on the context's chain workers
+    struct JoinSections {   // no early return may leave the section threads (or the pool's workers) running on this frame's data
+        std::vector<std::thread> &t; szhost_coeffs &c; szhip_ctx *ctx; bool &busy;
+        ~JoinSections() { for (auto &x : t) if (x.joinable()) x.join(); if (busy && ctx->chain_pool) ctx->chain_pool->wait_all(); if (ctx->chain_pool) ctx->chain_pool->disarm(); szhost_coeffs_free(&c); }
+    } join_sections{section_threads, cf, ctx, pool_busy};
+    if (ctx->chain_pool) ctx->chain_pool->arm();       // (the workers wake up now and spin until the coefficients are there -- or are sent back to sleep below)
     if (reg_count > 0) {
         // only the regression blocks' coefficients travel: rank them in scan order, gather [4][reg_count], chain on the host
         // (the compact arrays are "all regression blocks" to the chain), scatter the decoded values back
@@ -812,6 +871,17 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
                     szhost_coeff_chain_one_p(is_double, chain_in, ind, reg_count, use_mean, e, &cf, &chain_done[e]);
                     make_section(e);
                 });
+        } else if (tune_int("SZ_HIP_CHAIN_THREADS", 1) && tune_int("SZ_HIP_CHAIN_POOL", 1)) {
+            if (!ctx->chain_pool) { ctx->chain_pool = new szhip_chain_pool(); ctx->chain_pool->start(); }
+            pool_busy = true;
+            ctx->chain_pool->submit(ncoef,
+                [&, chain_in, ind = all_reg.data()](int e) {
+                    chain_t0[e] = now_ms() - t_begin;
+                    szhost_coeff_chain_one(is_double, chain_in, ind, reg_count, use_mean, e, &cf);
+                    chain_t1[e] = now_ms() - t_begin;
+                },
+                [&](int e) { make_section(e); });
+            ctx->chain_pool->wait_chains();           // the decoded coefficients are final: the main thread may ship them (the sections follow on the workers)
         } else if (tune_int("SZ_HIP_CHAIN_THREADS", 1)) {
             std::vector<std::promise<void>> chained(ncoef);
             std::vector<std::future<void>> chained_f;
@@ -1120,6 +1190,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     // ---- stream header
     TP("tree built");
     for (auto &x : section_threads) if (x.joinable()) x.join();
+    if (pool_busy) { ctx->chain_pool->wait_all(); pool_busy = false; }
     TP("sections joined");
     if (section_failed) { szhost_huff_free(hf); FAIL(SZHIP_ERR_INTERNAL, "coefficient Huffman build failed"); }
     for (int e = 0; e < ncoef; ++e) coef_sections.insert(coef_sections.end(), section[e].begin(), section[e].end());
@@ -3322,6 +3393,7 @@ void szhip_destroy(szhip_ctx *ctx)
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    delete ctx->chain_pool; ctx->chain_pool = nullptr;
     DevBuf *bufs[] = {&ctx->lor_bits, &ctx->reg_flags, &ctx->reg_rank, &ctx->coef_compact, &ctx->in, &ctx->out, &ctx->codes_nat, &ctx->codes_blk, &ctx->coef, &ctx->blk_lor, &ctx->faceI, &ctx->faceJ, &ctx->rb_down, &ctx->rb_right, &ctx->rb_vals, &ctx->pt_flags, &ctx->fast_slots, &ctx->fast_units, &ctx->progress, &ctx->trace,
                       &ctx->order, &ctx->small, &ctx->hist, &ctx->col_zeros, &ctx->col_zeros64, &ctx->col_off, &ctx->partial,
                       &ctx->samples, &ctx->unpred, &ctx->stream_buf, &ctx->chunk_bits, &ctx->chunk_off, &ctx->code_tab,
