@@ -135,6 +135,7 @@ struct szhip_ctx {
     // the coefficient chain beside the running sweep (M-field): a sweep that gave up waiting for the coefficients (seen 5 - 6 times in 480 rounds with
     // several arrays in flight) is answered by ONE repetition with the chain finished before the sweep starts; the context keeps that order
     bool coef_late = false, no_chain_overlap = false;
+    std::vector<int> chain_codes; std::vector<unsigned char> chain_unpred;   // the chains' outputs, kept across calls (fresh memory page-faults under the chain: ~1 ms for the M-field's 10 MB)
     szhip_chain_pool *chain_pool = nullptr;      // the coefficient chains' persistent threads (created with the first array that has regression blocks)
 };
 
@@ -823,7 +824,15 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     bool pool_busy = false;                     // a job of this call is on the context's chain workers
     struct JoinSections {   // no early return may leave the section threads (or the pool's workers) running on this frame's data
         std::vector<std::thread> &t; szhost_coeffs &c; szhip_ctx *ctx; bool &busy;
-        ~JoinSections() { for (auto &x : t) if (x.joinable()) x.join(); if (busy && ctx->chain_pool) ctx->chain_pool->wait_all(); if (ctx->chain_pool) ctx->chain_pool->disarm(); szhost_coeffs_free(&c); }
+        bool own = false;           // the output arrays belong to the context
+        ~JoinSections()
+        {
+            for (auto &x : t) if (x.joinable()) x.join();
+            if (busy && ctx->chain_pool) ctx->chain_pool->wait_all();
+            if (ctx->chain_pool) ctx->chain_pool->disarm();
+            if (own) for (int e = 0; e < 4; ++e) { c.codes[e] = nullptr; c.unpred[e] = nullptr; }
+            szhost_coeffs_free(&c);
+        }
     } join_sections{section_threads, cf, ctx, pool_busy};
     if (ctx->chain_pool) ctx->chain_pool->arm();       // (the workers wake up now and spin until the coefficients are there -- or are sent back to sleep below)
     if (reg_count > 0) {
@@ -857,6 +866,16 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         // 2-D planes are carried as {0, a, b, c}: the chain sees components 1..3
         T *const chain_in = hcoef + (two_d ? reg_count : 0);
         szhost_coeff_chain_begin(is_double, all_reg.data(), reg_count, (double)eb, G.g0.late, G.g1.late, G.g2.late, ncoef, &cf);
+        {   // the chains write into the context's arrays (touched in earlier calls) instead of freshly allocated ones
+            if (ctx->chain_codes.size() < reg_count * 4) ctx->chain_codes.resize(reg_count * 4 + reg_count / 4);
+            if (ctx->chain_unpred.size() < reg_count * 4 * sizeof(T)) ctx->chain_unpred.resize((reg_count * 4 + reg_count / 4) * sizeof(T));
+            for (int e = 0; e < 4; ++e) {
+                free(cf.codes[e]); free(cf.unpred[e]);
+                cf.codes[e] = ctx->chain_codes.data() + (size_t)e * reg_count;
+                cf.unpred[e] = ctx->chain_unpred.data() + (size_t)e * reg_count * sizeof(T);
+            }
+            join_sections.own = true;
+        }
         // (threads also for a handful of regression blocks: a section's fixed cost -- a 131 072-state code book -- is ~0.5 ms, and
         //  four of them in line delayed the wavefront kernel of BASELINE configs[3] by 2 ms)
         if (overlap) {
