@@ -234,6 +234,7 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
     gather = slab.StreamGather() if world > 1 else None
     pending = []
     step_no = [0]
+    gather_host_s = [0.0]                          # host time inside gather.begin / gather.end (the exchange's visible cost on this rank)
 
     def one_step(src=x):
         # the whole hot path of SZ_compress_args for this call, into the stream.  The value range (computeRangeSize_float: what the
@@ -311,9 +312,11 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
                     sz_, st_ = pool.wait(tk)
                     stats_all.append(st_); last = (sz_, ob_)
                     if gather_too and world > 1:
+                        tg = time.perf_counter()
                         pending.append(gather.begin(ob_, sz_))
                         if len(pending) > 1:
                             gather.end(pending.pop(0))
+                        gather_host_s[0] += time.perf_counter() - tg
             if i < nsteps:
                 ob_ = pool_bufs[i % (k_lanes + 1)] if k_lanes + 1 <= len(pool_bufs) else pool_bufs[i % len(pool_bufs)]
                 live.append((pool.submit(srcs[i % k_lanes].data_ptr(), True, (n, n, n), np.float32, EB, meta, prm, ob_.data_ptr(), out_cap), ob_))
@@ -330,10 +333,19 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
         while (time.perf_counter() - t_reh) * 1e3 < float(os.environ.get("SZ_BENCH_REHEARSE_MS", "600")):
             run_steps(inflight, 40, False)
     run_steps(inflight, max(args.warmup, inflight), True)
+    gather_host_s[0] = 0.0
     elapsed, stats_all, (size, ob) = run_steps(inflight, args.steps, True)
+    gather_ms_per_step = gather_host_s[0] / args.steps * 1e3
     quant_ms = [st.ms_quant for st in stats_all]
     stats = stats_all[-1]
+    per_rank = None
     if world > 1:
+        # every rank's own clock and its host time in the gather, so that a flat or bent scaling curve can be read from the line
+        mine = torch.tensor([elapsed / args.steps * 1e3, gather_ms_per_step, float(np.mean(quant_ms))], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = {"ms_per_step": [round(float(t[0]), 4) for t in allr], "gather_host_ms_per_step": [round(float(t[1]), 4) for t in allr],
+                    "sweep_kernel_ms": [round(float(t[2]), 4) for t in allr]}
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -374,9 +386,10 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
     achieved = nbytes_in / (quant_avg_ms * 1e-3) / 1e9 if quant_avg_ms > 0 else 0.0     # (the CPU shim of --dry-run has no device events)
     # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside the timed process);
     # only valid for the workload it was measured on
-    kname = "k_ribbon<float,false,false>" if getattr(stats, "quant_kernel", 0) == 1 else "k_pencil<float,false>"
+    qk = getattr(stats, "quant_kernel", 0)
+    kname = "k_beam<float,false,false,false>" if qk == 2 else "k_ribbon<float,false,false>" if qk == 1 else "k_pencil<float,false>"
     traffic, traffic_src = None, None
-    for name in (("r03_pmc_traffic_ribbon.json",) if kname.startswith("k_ribbon") else ("r02_pmc_traffic_pencil.json", "r01_pmc_traffic_pencil.json")):
+    for name in (("r05_pmc_traffic_beam.json",) if qk == 2 else ("r03_pmc_traffic_ribbon.json",) if qk == 1 else ("r02_pmc_traffic_pencil.json", "r01_pmc_traffic_pencil.json")):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", name)))
             if n == EDGE:
@@ -452,7 +465,7 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
 
     # ---- the opt-in FAST mode (SZ_HIP_MODE=fast: feedback-free quantiser, own container, own oracle; never the headline value)
     fast = None
-    if world == 1 and n == EDGE and not args.no_fast:
+    if world == 1 and n == EDGE and args.fast and not args.no_fast:
         fob = out_bufs[0]
         for _ in range(2):
             ctx.compress_fast(x.data_ptr(), True, (n, n, n), np.float32, EB, 0, fob.data_ptr(), out_cap)
@@ -640,8 +653,9 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
             "config": {"workload": f"{n}x{n}x{n} float32 S-field (smooth sinusoid) per GPU, ABS 1e-4, SZ 2.1 path with adaptive Lorenzo+regression "
                                    "selection per block (on this field every block chooses Lorenzo; m_field is the mixed case), stream "
                                    "bit-identical to the reference; value-range reduction included in the step (fused into the fit pass); input and output resident in HBM; "
-                                   f"{inflight} compressions in flight per GPU, every lane on its own copy of the field (szhip_pool, one context per lane; "
-                                   "`single_call_GBps` = one blocking call after the other, `concurrent` gives 1 / 2 / 4)",
+                                   + ("one blocking compression after the other (the shape of SZ_compress_args); `concurrent` gives 1 / 2 / 4 arrays in flight (szhip_pool)" if inflight == 1 else
+                                      f"{inflight} compressions in flight per GPU, every lane on its own copy of the field (szhip_pool, one context per lane; "
+                                      "`single_call_GBps` = one blocking call after the other, `concurrent` gives 1 / 2 / 4)"),
                        "error_bound_mode": "ABS", "abs_err_bound": EB, "slabs": world, "arrays_in_flight": inflight},
             "ratio": round(nbytes_in / size, 6), "out_bytes": size, "max_abs_err": max_abs_err, "psnr": round(psnr, 6),
             "intervals": stats.intervals, "reg_blocks": stats.n_reg_blocks, "unpredictable": stats.n_unpred,
@@ -650,6 +664,7 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
             "phase_ms": {"prequant": round(stats.ms_prequant, 3), "quant": round(stats.ms_quant, 3),
                          "entropy": round(stats.ms_entropy, 3), "host_glue": round(stats.ms_host, 3), "compress_call_total": round(stats.ms_total, 3),
                          "decompress_quant": round(dst.ms_quant, 3), "decompress_total": round(dst.ms_total, 3)},
+            "per_rank": per_rank,
             "roofline": roofline, "concurrent": concurrent, "m_field": mfield, "fast_mode": fast, "other_paths": other, "omp_container": omp, "e2e": e2e, "cpu_baseline": cpu, "cpu_baseline_mt": cpu_mt}
     print(json.dumps(line))
     if world > 1:
@@ -794,7 +809,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--other-paths", action="store_true", help="(default since round 4; kept for old command lines)")
     ap.add_argument("--no-other-paths", action="store_true", help="skip the SZ 1.4 container, the 2-D array and the 1-D series (one line each)")
-    ap.add_argument("--no-fast", action="store_true", help="skip the opt-in fast-mode object")
+    ap.add_argument("--no-fast", action="store_true", help="(default since round 5; kept for old command lines)")
+    ap.add_argument("--fast", action="store_true", help="add the opt-in fast-mode object (its own container; frozen since round 3)")
     ap.add_argument("--omp-boxes", type=int, default=-1, help="boxes (thread_num) of the OpenMP-container object; default: 32^3 boxes (4096 at 512^3); 0 = skip")
     ap.add_argument("--no-omp", action="store_true", help="skip the OpenMP-container object")
     ap.add_argument("--omp-ref-child", nargs=2, default=None, help=argparse.SUPPRESS)
@@ -802,7 +818,8 @@ def main():
     ap.add_argument("--timed-only", action="store_true", help="only the headline: priming, warm-up, the timed steps, one decompression (for "
                     "rocprofv3 --stats: every launch of the sweep kernel then runs as in the timed region)")
     ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the entry on gloo + the HIP-on-CPU shim (tests only)")
-    ap.add_argument("--inflight", type=int, default=4, help="arrays in flight per GPU in the timed region (szhip_pool lanes); 1 = one blocking call after the other")
+    ap.add_argument("--inflight", type=int, default=1, help="arrays in flight per GPU in the timed region (szhip_pool lanes); 1 (the default since round 5: what a caller of "
+                    "SZ_compress_args sees) = one blocking call after the other; the `concurrent` object of the line gives 1 / 2 / 4")
     args = ap.parse_args()
     if args.omp_ref_child:
         return _omp_ref_child(int(args.omp_ref_child[0]), int(args.omp_ref_child[1]))

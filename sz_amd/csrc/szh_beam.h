@@ -38,6 +38,9 @@
 #ifndef SZH_DEV
 #define SZH_DEV 0
 #endif
+#ifndef SZH_BM_X
+#define SZH_BM_X 0     /* tools/ubench/ub_beam.hip only (timing, results wrong): 1 no face push, 2 no code write, 4 no value write, 8 no k-face read, 16 no half swap, 32 no quantiser, 64 no value read */
+#endif
 namespace szh_bm {
 using szh_oc::mask_t;
 using szh_oc::lane_mask;
@@ -212,7 +215,8 @@ struct beam {
     T dl[LINE], lup[LINE], prev, Lprev, Bold, Bpold, cur_next, kf_next;
     unsigned tc_next, fl_next, vaddr, cdelta, fdelta, kaddr_h, trash, tstart;     // (vaddr, kaddr_h, trash: byte addresses in the workgroup's LDS window `lds0`)
     OC_LDS unsigned char *lds0;
-    unsigned ring_end, pushd, nring_lo;                           // first byte behind this ring; vaddr -> the pushed face's place in the next ring; that ring's first byte
+    unsigned ring_end, nring_lo, pface;                           // first byte behind this ring; the next ring's first byte; where the lane's next face value goes (the virtual slot of its line in the next ring)
+    T face_reg;                                                    // the lane's latest last-row result (upper half): handed on once per line
     unsigned m_first, m_vu[LINE], m_push[LINE];                   // per-lane select masks: first lane of a half; virtual cell of the upper half / last row of the upper half at position U
     T caphU[LINE];                                                 // the quantiser's range test per position: half the capacity, -1 where the lane's cell is virtual
     // events: roles and LDS places
@@ -225,6 +229,7 @@ struct beam {
     greg_t gk[DK], gj[DK];                                         // k-face / j-face granules on their way
     T eb, eb2, rh, caph, radf, mean; int radius; unsigned epoch;
     unsigned lo_it;                                                // LDS offset of wave line `it` in the ring (uniform)
+    bool pface_fixed;                                              // the lane hands nothing on (its `pface` is its write-only word)
     unsigned pv_prev, pv_next;                                     // the neighbouring wavefronts' progress words as read a step ago
 
     __device__ __forceinline__ beam(const szh_qargs<T> &args) : a(args) {}
@@ -369,7 +374,7 @@ struct beam {
         T L = bsel(m_first, kf, Lraw);                                   // (a half's first lane: the k-face of the beam on the left)
         const bool started = !EDGE || (unsigned)(it * LINE + U) >= tstart;      // (at the array's first lines: lanes that have not started hold zeros)
         if (EDGE) L = started ? L : (T)0;
-        const T sw = low_to_high(prev);
+        const T sw = (SZH_BM_X & 16) ? prev : low_to_high(prev);
         SZH_SB;
         const T B = dl[U], Bp = lup[U], C = Bold, Cp = Bpold;
         // [-1] + [-s1] + [-s0] - [-s1-1] - [-s0-1] - [-s0-s1] + [-s0-s1-1], left to right (sz_float.c:7268)
@@ -381,28 +386,25 @@ struct beam {
         const T cur = bsel(m_vu[U], sw, cur_raw);
         SZH_SB;
         const T s3 = s2 - Lprev;
-        cur_next = lds_get<T>(lds0, vnext);                              // what the NEXT step needs from the rings is requested now
+        if (!(SZH_BM_X & 64)) cur_next = lds_get<T>(lds0, vnext);        // what the NEXT step needs from the rings is requested now
         if (DEC) tc_next = lds_get<uint16_t>(lds0, vnext + cdelta);
         if (HASREG) fl_next = lds_get<uint8_t>(lds0, vnext + fdelta);
         SZH_SB;
         const T s4 = s3 - Bp;
         {   // the k-face value of the next step's cell of lane 0 (every lane reads; only the halves' first lanes use it)
             constexpr int Un = (U + 1) % LINE, kl = (U + 1 == LINE ? LL + 1 : LL) % KRL;
-            kf_next = lds_get<T>(lds0, (unsigned)(kl * LINE * 2 * SZ + Un * 2 * SZ) + kaddr_h);
+            if (!(SZH_BM_X & 8)) kf_next = lds_get<T>(lds0, (unsigned)(kl * LINE * 2 * SZ + Un * 2 * SZ) + kaddr_h);
         }
         SZH_SB;
         const T s5 = s4 - C;
-        const unsigned f = vaddr + pushd;
         SZH_SB;
         const T pred = s5 + Cp;
-        const unsigned fa = f < nring_lo ? f + (unsigned)RINGB : f;
         SZH_SB;
         T rec;
         if (!DEC) {
             // the quantiser of szh_rb::rb_quant (sz_float.c:7270-7287 with a shorter dependency chain, bit for bit the same results); a virtual
             // cell fails the range test (its limit is -1) and hands its value on unchanged
             const T diff = cur - pred;
-            const unsigned pa = bsel(m_push[U], fa, trash);
             SZH_SB;
             const T hq0 = tabs(diff) * rh;
             const unsigned caddr = vaddr + cdelta;
@@ -436,11 +438,9 @@ struct beam {
                 if (in_mask(nm)) { code = radius; rec = mean; }
             }
             if (EDGE) rec = started ? rec : (T)0;
-            lds_put<uint16_t>(lds0, caddr, (uint16_t)code);
-            lds_put<T>(lds0, vaddr, rec);
-            // the last row of the upper half is the j-face of the wavefront above: into the slot of ITS virtual cell, 9 cells back in its ring
-            // (every other lane, and the workgroup's last wavefront: into the lane's write-only word)
-            lds_put<T>(lds0, pa, rec);
+            if (SZH_BM_X & 32) rec = pred + cur;
+            if (!(SZH_BM_X & 2)) lds_put<uint16_t>(lds0, caddr, (uint16_t)code);
+            if (!(SZH_BM_X & 4)) lds_put<T>(lds0, vaddr, rec);
         } else {
             int cq = (int)tc_in;
             bool is_mean = false;
@@ -448,15 +448,15 @@ struct beam {
             const T mq = (T)(cq - radius) * eb2;
             mask_t um = lane_mask(tc_in != 0u) & lane_mask(caphU[U] > (T)0);
             if (HASREG) um &= lane_mask(fl_in == 0u);
-            const unsigned pa = bsel(m_push[U], fa, trash);
             SZH_SB;
             T r = pred + mq;                                                                  // = pred + 2 (c - radius) eb (szd_float.c:5786)
             if (USEMEAN && is_mean) r = mean;
             rec = in_mask(um) ? r : cur;                                                       // zero code: the pre-scattered value
             if (EDGE) rec = started ? rec : (T)0;
             lds_put<T>(lds0, vaddr, rec);
-            lds_put<T>(lds0, pa, rec);
         }
+        // the last row of the upper half is the j-face of the wavefront above: kept where the lane made it, handed on at the end of the line
+        if (!(SZH_BM_X & 1)) face_reg = bsel(m_push[U], rec, face_reg);
         dl[U] = rec; lup[U] = L;
         Bold = B; Bpold = Bp;
         Lprev = L; prev = rec;
@@ -479,6 +479,11 @@ struct beam {
             step<U, LL, EDGE>(it);
             order();
         });
+        // the faces of this line go to the wavefront above: each lane's latest last-row result into the slot of that line's virtual cell in ITS
+        // ring (lanes of the lower half, and the workgroup's last wavefront: into their write-only word).  One write per line, not per step:
+        // the wavefront above waits for whole lines anyway (it + 3 below), so nothing arrives later than it is looked for
+        if (!(SZH_BM_X & 1)) lds_put<T>(lds0, pface, face_reg);
+        { const unsigned f = pface + (unsigned)LP; pface = pface_fixed ? pface : (f >= nring_lo + (unsigned)RINGB ? f - (unsigned)RINGB : f); }
         lds_put<unsigned>((OC_LDS unsigned char *)(prog + w), 0, (unsigned)(it + 1));
         lo_it = lo(1);
     }
@@ -555,13 +560,20 @@ struct beam {
         lds0 = rings;                                   // (the addresses below are relative to the rings' first byte; the write-only words and the k-face rings follow the rings in one array)
         const unsigned ring_lo = (unsigned)(w * RINGB);
         ring_end = ring_lo + (unsigned)RINGB; nring_lo = ring_end;
-        pushd = (unsigned)(RINGB - 9 * PITCH - S::HB);
+        {   // after wave line `it` the lane's latest finished last-row cell belongs to beam line it - 1 - ceil(m / LINE): the slot of THAT line's
+            // virtual cell in the next ring (lines before the array's first: slots nobody has looked at yet)
+            const int L0 = -1 - (m + LINE - 1) / LINE;
+            pface_fixed = !(h == 1 && has_next);
+            pface = pface_fixed ? (unsigned)(WPG * RINGB + (w * 64 + lane) * 8)
+                                : ring_end + (unsigned)((((L0 % RL) + RL) % RL) * LP + m * SZ);
+            face_reg = 0;
+        }
         vaddr = ring_lo + (unsigned)(((RS - m) % RS) * PITCH + h * S::HB + m * SZ);
         m_first = m == 0 ? 0xffffffffu : 0u;
         for (int u = 0; u < LINE; ++u) {
             const bool virt = ((u - m) % LINE + LINE) % LINE == 0, last = ((u - m) % LINE + LINE) % LINE == C1;
             m_vu[u] = (virt && h == 1) ? 0xffffffffu : 0u;
-            m_push[u] = (last && h == 1 && has_next) ? 0xffffffffu : 0u;
+            m_push[u] = (last && h == 1) ? 0xffffffffu : 0u;
             caphU[u] = virt ? (T)-1 : caph;
             hide(m_vu[u]); hide(m_push[u]); hide(caphU[u]);        // (kept in registers: hipcc otherwise rebuilds them from the lane number as scalar lane masks, ~20 SGPRs and their spills)
         }
