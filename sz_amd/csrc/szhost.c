@@ -488,6 +488,7 @@ static size_t NAME(const T *cf, size_t b, size_t nblocks, const unsigned char *i
                    size_t *pci, const T *tt, const T *ta, const T *tn, T prec, int variant, size_t *progress, T *un, size_t *pnun)     \
 {                                                                                                                                  \
     const T rprec = 1 / prec, lim = prec * (T)1.5, pm = prec * (T)1.0001, nlimit = (T)(2 * (CHAIN_TAB_N - 4)) * prec;                   \
+    const T nbeyond = (T)(2 * (CHAIN_TAB_N + 4)) * prec;                                                                           \
     const V absmask = ABSMASK, vprec = LOADS(&prec);                                                                               \
     V vlast = LOADS(plast);                                                                                                        \
     T prevc = *pprevc;                                                                                                             \
@@ -495,7 +496,38 @@ static size_t NAME(const T *cf, size_t b, size_t nblocks, const unsigned char *i
     for (; b < nblocks; b++) {                                                                                                     \
         if (indicator[b]) continue;                                                                                                \
         const T cur = cf[b], Dk = cur - prevc, aD = FABS(Dk);                                                                      \
-        if (!(aD > lim && aD < nlimit)) break;                     /* (also NaN) */                                                \
+        if (__builtin_expect(!(aD > lim && aD < nlimit), 0)) {                                                                     \
+            const V vcur0 = LOADS(&cf[b]);                                                                                         \
+            if (aD >= nbeyond && aD <= (T)3.0e38) {                                                                                \
+                /* certainly beyond the code range whatever `last` is (|c_k - last| >= |c_k - c_{k-1}| - prec): the coefficient     \
+                 * verbatim (sz_float.c:7150) -- and the chain starts afresh from it */                                             \
+                const V vd0 = SUBS(vcur0, vlast);                                                                                  \
+                if (!COMIGE(ANDV(vd0, absmask), LOADS(&tt[CHAIN_TAB_N]))) break;          /* (checked all the same) */              \
+                vlast = vcur0; prevc = cur; codes[ci++] = 0; cfo[b] = cur; un[(*pnun)++] = cur;                                    \
+                if (progress && (ci & 1023) == 0) __atomic_store_n(progress, ci, __ATOMIC_RELEASE);                               \
+                continue;                                                                                                          \
+            }                                                                                                                      \
+            if (aD <= lim) {                                                                                                       \
+                /* the coefficient barely moved: |c_k - last| < 2.5 prec, the interval number is 0 or 1 -- one threshold, the       \
+                 * addend's sign from the difference itself (still no divide on the chain) */                                       \
+                const V vd0 = SUBS(vcur0, vlast), vad0 = ANDV(vd0, absmask);                                                       \
+                const V m0 = CMPLES(LOADS(&tt[1]), vad0), mn0 = CMPLES(vad0, vad0);       /* (mn0: all ones unless NaN) */          \
+                if (!(MOVMSK(mn0) & 1) || !COMILT(vad0, LOADS(&tt[2]))) break;                                                     \
+                const V sgn0 = ANDNV(absmask, vd0);                                        /* the sign bit of the difference */      \
+                const V add0 = ANDV(m0, ORV(LOADS(&ta[1]), sgn0));                         /* +-A[1] or +0 (q = 0 adds (T)0, sz_float.c:7140) */ \
+                const V vnew0 = ADDS(vlast, add0);                                                                                 \
+                prevc = cur;                                                                                                       \
+                if (__builtin_expect(COMIGT(ANDV(SUBS(vcur0, vnew0), absmask), vprec), 0)) {                                       \
+                    vlast = vcur0; codes[ci++] = 0; cfo[b] = cur; un[(*pnun)++] = cur;                                             \
+                } else {                                                                                                           \
+                    const int q0 = MOVMSK(m0) & 1, ng0 = MOVMSK(vd0) & 1;                                                          \
+                    vlast = vnew0; codes[ci++] = (ng0 ? -q0 : q0) + 32768; cfo[b] = GETS(vnew0);                                   \
+                }                                                                                                                  \
+                if (progress && (ci & 1023) == 0) __atomic_store_n(progress, ci, __ATOMIC_RELEASE);                               \
+                continue;                                                                                                          \
+            }                                                                                                                      \
+            break;                                                     /* (NaN, infinity, the last intervals of the range) */      \
+        }                                                                                                                          \
         const T lo1 = aD - pm;                                                                                                     \
         const int n1 = (int)(((variant ? lo1 * rprec : lo1 / prec) + 1) * (T)0.5);                                                 \
         const int neg = Dk < 0;                                                                                                    \
