@@ -225,7 +225,7 @@ struct beam {
     v4u gv[DV];                                                    // value rows on their way
     v4u gx[HASREG && !DEC ? DV : 1]; unsigned gf[HASREG ? DV : 1]; // HASREG: the regression points' reconstructions of the same rows (compress), their flag bytes
     rsrc_t rs_x, rs_f; role_t rf[EV]; unsigned fl_lds[EV];
-    cpiece_t gc[UL], wqc; v4u wqv[EV];                             // inverse: code rows on their way; rows on their way out
+    cpiece_t gc[UL], wqc; v4u wqv[EV]; unsigned wfl, cfl;                             // inverse: code rows on their way; rows on their way out
     greg_t gk[DK], gj[DK];                                         // k-face / j-face granules on their way
     T eb, eb2, rh, caph, radf, mean; int radius; unsigned epoch;
     unsigned lo_it;                                                // LDS offset of wave line `it` in the ring (uniform)
@@ -319,6 +319,7 @@ struct beam {
             // finished rows (line it - LAG: every lane has left it) leave the ring: read here, stored one step later
             const unsigned loY = lo(RL - LAG);
             if (!DEC) wqc = lds_get8(ring, loY + cl);
+            if (!DEC && HASREG) wfl = lds_get<unsigned>(ring, loY + cfl);
             else for_n<EV>([&](auto E) { constexpr int e = decltype(E)::value; wqv[e] = lds_get16(ring, loY + vl[e]); });
             unsigned o, so;
             place<EDGE>(rko, it - LAG, str_k, o, so);
@@ -328,7 +329,18 @@ struct beam {
         }
         if constexpr (U == 2) {
             unsigned o, so;
-            if (!DEC) { place<EDGE>(rcs, it - LAG, str_c, o, so); bst8<0>(rs_c, o, so, wqc); }
+            if (!DEC) {
+                if (HASREG) {
+                    // the regression points of the row piece keep the codes k_reg_points gave them (the sweep passed their values through and has
+                    // zeros there): per code a 16-bit mask from its flag byte
+                    constexpr int set = LL % UL;
+                    const cpiece_t old = gc[set];
+                    const unsigned m0 = ((wfl & 0xffu) ? 0xffffu : 0u) | ((wfl & 0xff00u) ? 0xffff0000u : 0u), m1 = ((wfl & 0xff0000u) ? 0xffffu : 0u) | ((wfl & 0xff000000u) ? 0xffff0000u : 0u);
+                    wqc.x = (old.x & m0) | (wqc.x & ~m0); wqc.y = (old.y & m1) | (wqc.y & ~m1);
+                    gc[set] = load_c<true>(it - LAG + UL);
+                }
+                place<EDGE>(rcs, it - LAG, str_c, o, so); bst8<0>(rs_c, o, so, wqc);
+            }
             else for_n<EV>([&](auto E) { constexpr int e = decltype(E)::value; place<EDGE>(rvs[e], it - LAG, str_v, o, so); bst16<0>(rs_v, o, so, wqv[e]); });
             // rows that have arrived go in (line it + 1), and the register set that carried them is sent for the rows DV events further on
             const unsigned loX = lo(1);
@@ -534,6 +546,7 @@ struct beam {
             rc = make_role(true, in ? off : 0u, ch, str_c);
             rcs = make_role(in, off, ch, str_c);
             cl = (unsigned)((1 + rr) * PITCH + S::VB + ch * 64 + p * 8);
+            cfl = (unsigned)((1 + rr) * PITCH + S::FOFF + ch * HL + p * 4);
         }
         {   // k-face granules: lane e < 10: cell e % 5 of half e / 5 of a wave line; [workgroup][8 half-beams][LINE r0 cells]
             const bool en = lane < 2 * LINE;
@@ -603,6 +616,7 @@ struct beam {
             }); });
             for_n<EV>([&](auto E) { constexpr int e = decltype(E)::value; put_rows(0u, e, first[e], firstx[e], firstf[e]); });
             if (zero_face) { const v4u z = {0u, 0u, 0u, 0u}; if (lane < S::HB / 16) lds_put16(ring, (unsigned)lane * 16u, z); }
+            if (!DEC && HASREG) for_n<UL>([&](auto L_) { constexpr int LL = decltype(L_)::value; gc[LL] = load_c<true>(LL - LAG); });
             if (DEC) {
                 const cpiece_t c0 = load_c<true>(0);
                 for_n<UL>([&](auto L_) { constexpr int LL = decltype(L_)::value; gc[(LL + 1) % UL] = load_c<true>(LL + 1); });
@@ -621,10 +635,12 @@ struct beam {
         tc_next = DEC ? (unsigned)lds_get<uint16_t>(lds0, vaddr + cdelta) : 0u;
         fl_next = HASREG ? (unsigned)lds_get<uint8_t>(lds0, vaddr + fdelta) : 0u;
         kf_next = lds_get<T>(lds0, kaddr_h);
-        { const v4u z = {0u, 0u, 0u, 0u}; for (int e = 0; e < EV; ++e) wqv[e] = z; wqc.x = 0u; wqc.y = 0u; }
+        { const v4u z = {0u, 0u, 0u, 0u}; for (int e = 0; e < EV; ++e) wqv[e] = z; wqc.x = 0u; wqc.y = 0u; wfl = 0u; }
         // ---- the lines: every lane has left line it - LAG when lane 0 enters line it.  Blocks of UL lines; the ones in which every line any
         // lane asks for or stores exists take the variant without per-lane line checks
         const int NWL = r0 + 1 + LAG, nblk = (NWL + UL - 1) / UL;
+        unsigned *const pub = (!DEC && a.tile_done) ? a.tile_done + (((int64_t)kb * gr.nJG + jg) * WPG + w) : nullptr;     // (uniform)
+        constexpr int PUBB = 32 / UL;                                  // a word every 32 lines
 #pragma unroll 1
         for (int b = 0; b < nblk; ++b) {
             const int it0 = b * UL;
@@ -633,6 +649,13 @@ struct beam {
 #else
             if (it0 >= LAG + 1 && it0 <= r0 - 1 - 2 * UL) block<false>(it0); else block<true>(it0);
 #endif
+            // the host starts the entropy stage's passes over lines every wavefront has passed (szhip.hip): how many of THIS wavefront's lines have
+            // their codes in memory -- a release at system scope (this XCD's L2 is written back first), the launch's epoch beside the count
+            if (pub && ((b + 1) % PUBB == 0 || b + 1 == nblk)) {
+                int rows = b + 1 == nblk ? r0 : it0 + UL - 1 - LAG;
+                rows = rows < 0 ? 0 : (rows > r0 ? r0 : rows);
+                if (b + 1 == nblk || rows > 0) szh_rb::st_done(pub, ((epoch & 0xfffu) << 20) | (unsigned)rows);
+            }
         }
         lds_put<unsigned>((OC_LDS unsigned char *)(prog + w), 0, (unsigned)SZH_BM_INF);
         if (timed_out) st_err(a.err, 1u);
@@ -641,34 +664,41 @@ struct beam {
 } // namespace szh_bm
 
 // The points of the regression blocks (sz_float.c:7153-7252; inverse szd_float.c:5786-5838): prediction a ii + b jj + c kk + d from the DECODED
-// coefficients, no neighbour involved -- a wavefront per block, all blocks at once.
-//   MODE 0  compress, before the sweep: reconstructions -> vals (the sweep's neighbours), flags -> 1
-//   MODE 1  compress, after the sweep:  codes -> codes (natural order; the sweep left whatever it computed there)
+// coefficients, no neighbour involved -- all blocks at once.
+//   MODE 0  compress, before the sweep: reconstructions -> vals (the sweep's neighbours), flags -> 1, codes -> codes (natural order; the sweep
+//           keeps them where the flag is set when it stores a row of codes)
+//   MODE 1  (the codes alone; not used any more)
 //   MODE 2  decompress, before the sweep: values -> vals (= the output array) where the code is not zero (zero: the pre-scattered value stays), flags -> 1
 template <class T, int MODE>
 __global__ __launch_bounds__(256) void k_reg_points(szh_geom3 G, const uint8_t *__restrict__ blk_lor, const T *__restrict__ coef, int64_t cstride, const T *__restrict__ data,
                                                     T *__restrict__ vals, uint16_t *__restrict__ codes, uint8_t *__restrict__ flags, T eb, T recip, int cap, int radius)
 {
-    const int64_t b = (int64_t)blockIdx.x * 4 + (int64_t)(threadIdx.x >> 6);
-    if (b >= G.nblocks || blk_lor[b] != 0) return;                   // (uniform per wavefront)
-    const int lane = (int)(threadIdx.x & 63u);
-    const int n12 = G.g1.num * G.g2.num, b0 = (int)(b / n12), r12 = (int)(b - (int64_t)b0 * n12), b1 = r12 / G.g2.num, b2 = r12 - b1 * G.g2.num;
-    const int i0 = szh_blk_start(G.g0, b0), j0 = szh_blk_start(G.g1, b1), k0 = szh_blk_start(G.g2, b2);
-    const int s0 = szh_blk_size(G.g0, b0), s1 = szh_blk_size(G.g1, b1), s2 = szh_blk_size(G.g2, b2), s12 = s1 * s2, np = s0 * s12;
-    const T ca = coef[b], cb = coef[cstride + b], cc = coef[2 * cstride + b], cd = coef[3 * cstride + b];
-    for (int p = lane; p < np; p += 64) {
-        const int ii = p / s12, r = p - ii * s12, jj = r / s2, kk = r - jj * s2;
-        const int64_t idx = (int64_t)(i0 + ii) * G.d0 + (int64_t)(j0 + jj) * G.d1 + (k0 + kk);
-        const T pred = ca * (T)ii + cb * (T)jj + cc * (T)kk + cd;     // sz_float.c:7165, left to right
-        if (MODE == 2) {
-            const int c = (int)codes[idx];
-            if (c != 0) vals[idx] = pred + (T)(2 * (c - radius)) * eb;   // szd_float.c:5831
-            flags[idx] = 1;
-        } else {
-            T rc;
-            const int c = szh_quant_sel<T>(data[idx], pred, eb, recip, cap, radius, &rc);   // capacity: the full interval count (sz_float.c:7170)
-            if (MODE == 0) { vals[idx] = rc; flags[idx] = 1; } else codes[idx] = (uint16_t)c;
-        }
+    // a workgroup per block column (b0, b1): its threads stand side by side along the contiguous dimension, so that a row of the column's
+    // blocks is read and written as whole lines (a wavefront per block touched 24-byte pieces of 2 KB-strided rows: 0.34 ms at 512^3 against
+    // 0.1 here); a thread walks the s0 x s1 cross-section of ITS block at its position, if that block is a regression block
+    const int b0 = (int)(blockIdx.x / (unsigned)G.g1.num), b1 = (int)(blockIdx.x - (unsigned)b0 * (unsigned)G.g1.num);
+    const int i0 = szh_blk_start(G.g0, b0), j0 = szh_blk_start(G.g1, b1), s0 = szh_blk_size(G.g0, b0), s1 = szh_blk_size(G.g1, b1);
+    const int64_t bcol = ((int64_t)b0 * G.g1.num + b1) * G.g2.num;
+    for (int k = (int)threadIdx.x; k < G.g2.count; k += (int)blockDim.x) {
+        const int b2 = szh_blk_of(G.g2, k), kk = k - szh_blk_start(G.g2, b2);
+        const int64_t b = bcol + b2;
+        if (blk_lor[b] != 0) continue;
+        const T ca = coef[b], cb = coef[cstride + b], cc = coef[2 * cstride + b], cd = coef[3 * cstride + b];
+        for (int ii = 0; ii < s0; ++ii)
+            for (int jj = 0; jj < s1; ++jj) {
+                const int64_t idx = (int64_t)(i0 + ii) * G.d0 + (int64_t)(j0 + jj) * G.d1 + k;
+                const T pred = ca * (T)ii + cb * (T)jj + cc * (T)kk + cd;     // sz_float.c:7165, left to right
+                if (MODE == 2) {
+                    const int c = (int)codes[idx];
+                    if (c != 0) vals[idx] = pred + (T)(2 * (c - radius)) * eb;   // szd_float.c:5831
+                    flags[idx] = 1;
+                } else {
+                    T rc;
+                    const int c = szh_quant_sel<T>(data[idx], pred, eb, recip, cap, radius, &rc);   // capacity: the full interval count (sz_float.c:7170)
+                    if (MODE == 0) { vals[idx] = rc; flags[idx] = 1; }
+                    codes[idx] = (uint16_t)c;
+                }
+            }
     }
 }
 

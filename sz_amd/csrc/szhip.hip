@@ -545,7 +545,7 @@ int launch_beam(szhip_ctx *ctx, const szh_geom3 &G, szh_qargs<T> a, hipStream_t 
         TRY(ensure(ctx, ctx->pt_flags, (size_t)G.n + 64));
         HIPCHK(hipMemsetAsync(ctx->pt_flags.p, 0, (size_t)G.n, st));
         a.ptflags = (const uint8_t *)ctx->pt_flags.p;
-        const unsigned rgrid = (unsigned)((G.nblocks + 3) / 4);
+        const unsigned rgrid = (unsigned)(G.g0.num * G.g1.num);       // a workgroup per block column (b0, b1)
         if (!DEC) {
             TRY(ensure(ctx, ctx->rb_vals, (size_t)G.n * sizeof(T) + 64));
             a.xr = (const T *)ctx->rb_vals.p;
@@ -563,11 +563,6 @@ int launch_beam(szhip_ctx *ctx, const szh_geom3 &G, szh_qargs<T> a, hipStream_t 
     } else {
         if (a.use_mean) hipLaunchKernelGGL((k_beam<T, DEC, true, false>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((k_beam<T, DEC, false, false>), grid, block, 0, st, a);
-    }
-    if (hasreg && !DEC) {
-        HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL((k_reg_points<T, 1>), dim3((unsigned)((G.nblocks + 3) / 4)), dim3(256), 0, st, G, a.blk_lor, a.coef, a.coef_stride, a.data, (T *)nullptr, a.codes, (uint8_t *)nullptr,
-                           a.eb, a.recip, a.cap, a.radius);
     }
     HIPCHK(hipGetLastError());
     return SZHIP_OK;
@@ -960,10 +955,14 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     const int slices_req = tune_int("SZ_HIP_SLICES", ctx->gate ? tune_int("SZ_HIP_SLICES_POOL", 2) : 4);
     const int slice_from = tune_int("SZ_HIP_SLICE_FROM", 0);          // even parts: per cent of the tile rows that the first slice covers at least
     const int slice_geom = tune_int("SZ_HIP_SLICE_GEOM", 0);
-    const bool sliced = use_ribbon && slices_req > 1 && !tune_int("SZ_HIP_FUSE_HIST", 0);
+    // (round 5) the beam sweep: every wavefront publishes how many of its lines have their codes in memory (szh_beam.h, `tile_done`: a word per
+    // wavefront); a slice = the block rows whose lines every wavefront has passed
+    const bool sliced = (use_ribbon || (use_beam && tune_int("SZ_HIP_BEAM_SLICES", 1))) && slices_req > 1 && !tune_int("SZ_HIP_FUSE_HIST", 0);
     unsigned *tile_done = nullptr;
+    const szh_bm::grid_t bgrid = szh_bm::make_grid(G);
+    const size_t beam_words = (size_t)bgrid.nKB * bgrid.nJG * szh_bm::WPG;
     if (sliced) {
-        const size_t tiles = (size_t)((G.g0.count + szh_rb_shape<T>::W * szh_rb_shape<T>::R - 1) / (szh_rb_shape<T>::W * szh_rb_shape<T>::R)) * rbl.nTJ;
+        const size_t tiles = use_beam ? beam_words : (size_t)((G.g0.count + szh_rb_shape<T>::W * szh_rb_shape<T>::R - 1) / (szh_rb_shape<T>::W * szh_rb_shape<T>::R)) * rbl.nTJ;
         TRY(ensure_coherent(ctx, 512 + tiles * 4));
         tile_done = (unsigned *)((char *)ctx->coh + 512);
         if (!ctx->stream3) {
@@ -1094,7 +1093,57 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     TRY(ensure(ctx, ctx->col_zeros64, (size_t)ncols * 8));
     TRY(ensure(ctx, ctx->col_off, (size_t)ncols * 8));
     int perm_segb = 1, perm_nseg = 1;
-    if (sliced) {
+    if (sliced && use_beam) {
+        // slices of block rows (dim 0): the codes are in natural order, so a slice's codes are ONE contiguous range for the histogram, and the
+        // block-ordering pass takes the slice's block rows.  A slice starts when every wavefront of the sweep has published its lines.
+        const int NS = std::min(slices_req, G.g0.num);
+        const int segb = choose_segb(G, 2, tune_int("SZ_HIP_PERM_TILE_KB", 32) * 1024);
+        const int nseg = (G.g2.num + segb - 1) / segb;
+        TRY(ensure(ctx, ctx->zcnt, (size_t)ncols * nseg * 4));
+        TRY(ensure(ctx, ctx->zpos, (size_t)ncols * nseg * SZH_ZCAP * 4));
+        const size_t tb = tile_bytes(G, segb, 2), tile_el = (tb + 1) / 2;
+        int rshift = 0; const int use_lds = intervals <= 16384;
+        if (use_lds) { while ((intervals << (rshift + 1)) <= 16384u && rshift < 6) ++rshift; }
+        const size_t hist_lds = use_lds ? ((size_t)intervals << rshift) * 4 : 16;
+        HIPCHK(hipMemsetAsync(d_hist, 0, (size_t)intervals * 4, ctx->stream2));
+        HIPCHK(hipMemsetAsync(ctx->col_zeros.p, 0, (size_t)ncols * 4, ctx->stream3));
+        const unsigned tag = (ctx->epoch & 0xfffu) << 20;
+        bool sweep_over = false;
+        int b0_done = 0;
+        size_t first_late = 0;                                     // wavefronts below this index have been seen past the current slice's rows
+        for (int sl = 0; sl < NS; ++sl) {
+            const int b0_hi = sl == NS - 1 ? G.g0.num : std::max(b0_done, (int)((int64_t)G.g0.num * (sl + 1) / NS));
+            const int rows_need = b0_hi >= G.g0.num ? G.g0.count : szh_blk_start(G.g0, b0_hi);
+            first_late = 0;
+            unsigned spins = 0;
+            while (!sweep_over && first_late < beam_words) {
+                const unsigned wv = __atomic_load_n(&tile_done[first_late], __ATOMIC_ACQUIRE);
+                if ((wv & 0xfff00000u) == tag && (int)(wv & 0xfffffu) >= rows_need) { ++first_late; continue; }
+                if ((++spins & 127u) == 0) {
+                    const hipError_t q = hipEventQuery(ctx->ev[3]);
+                    if (q == hipSuccess) { sweep_over = true; break; }
+                    if (q != hipErrorNotReady) HIPCHK(q);
+                }
+            }
+            if (b0_hi > b0_done) {
+                const int64_t h_lo = (int64_t)szh_blk_start(G.g0, b0_done) * G.d0, h_hi = (int64_t)rows_need * G.d0;
+                const int grid = (int)std::min<int64_t>(((h_hi - h_lo) / 8 + 255) / 256 + 1, 2048);
+                hipLaunchKernelGGL(k_hist_u16, dim3(grid), dim3(256), hist_lds, ctx->stream2, (const uint16_t *)d_nat, h_hi, intervals, rshift, use_lds, d_hist, rbl,
+                                   G.g0.count, G.g1.count, G.g2.count, h_lo);
+                hipLaunchKernelGGL((k_permute<0>), dim3((unsigned)((b0_hi - b0_done) * G.g1.num), std::min(nseg, std::max(1, tune_int("SZ_HIP_PERM_Y", 1)))), dim3(256), ((tile_el + 1) & ~(size_t)1) * 2 + 16, ctx->stream3, G,
+                                   (const uint16_t *)d_nat, d_blk, (unsigned *)ctx->col_zeros.p, segb, (unsigned *)ctx->zcnt.p, (unsigned *)ctx->zpos.p, rbl, d_hist, 0u,
+                                   (int)tile_el, b0_done * G.g1.num, 0);
+                HIPCHK(hipGetLastError());
+                b0_done = b0_hi;
+            }
+        }
+        HIPCHK(hipMemcpyAsync(h_hist, d_hist, (size_t)intervals * 4, hipMemcpyDeviceToHost, ctx->stream2));
+        HIPCHK(hipEventRecord(ctx->ev_fit, ctx->stream2));
+        hipLaunchKernelGGL(k_u32_to_u64, dim3((ncols + 255) / 256), dim3(256), 0, ctx->stream3, (const unsigned *)ctx->col_zeros.p, (int64_t)ncols, (u64 *)ctx->col_zeros64.p);
+        TRY(scan_u64(ctx, (const u64 *)ctx->col_zeros64.p, ncols, (u64 *)ctx->col_off.p, sm + SM_TOTAL_UNPRED, ctx->stream3));
+        HIPCHK(hipEventRecord(ctx->ev_perm, ctx->stream3));
+        perm_segb = segb; perm_nseg = nseg;
+    } else if (sliced) {
         using RS = szh_rb_shape<T>;
         constexpr int WR = RS::W * RS::R;
         const int nTI = (G.g0.count + WR - 1) / WR, nTJ = rbl.nTJ, NS = std::min(slices_req, nTI);
