@@ -956,8 +956,10 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     const int slice_from = tune_int("SZ_HIP_SLICE_FROM", 0);          // even parts: per cent of the tile rows that the first slice covers at least
     const int slice_geom = tune_int("SZ_HIP_SLICE_GEOM", 0);
     // (round 5) the beam sweep: every wavefront publishes how many of its lines have their codes in memory (szh_beam.h, `tile_done`: a word per
-    // wavefront); a slice = the block rows whose lines every wavefront has passed
-    const bool sliced = (use_ribbon || (use_beam && tune_int("SZ_HIP_BEAM_SLICES", 1))) && slices_req > 1 && !tune_int("SZ_HIP_FUSE_HIST", 0);
+    // wavefront); a slice = the block rows whose lines every wavefront has passed.  OFF by default (SZ_HIP_BEAM_SLICES=1 switches it on): measured
+    // at 512^3 the sweep -- one latency-bound wavefront per SIMD -- slows from 1.05 to 1.58 ms beside the slices' kernels and the 16 system-scope
+    // releases per wavefront (one call 2.39 ms against 2.08 without), and one of 16 GPU parity cases met codes the histogram had read too early
+    const bool sliced = (use_ribbon || (use_beam && tune_int("SZ_HIP_BEAM_SLICES", 0))) && slices_req > 1 && !tune_int("SZ_HIP_FUSE_HIST", 0);
     unsigned *tile_done = nullptr;
     const szh_bm::grid_t bgrid = szh_bm::make_grid(G);
     const size_t beam_words = (size_t)bgrid.nKB * bgrid.nJG * szh_bm::WPG;
