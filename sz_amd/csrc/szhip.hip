@@ -927,7 +927,12 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
 
     // ---- predict + quantise: the wavefront kernel
     // (the ribbon mapping writes its codes in its own order, szh_ribbon.h: tiles x steps x 1024 entries, a few per cent more than n)
-    const bool use_beam = !overlap && beam_applies<T>(G, d_in, reg_count);
+    // Which sweep: arrays with regression blocks and doubles take the beam (k_pencil's 4.4 / 7.4 ms become 1.2 / 2.3 at 512^3 M-field / the f64 slab);
+    // a float array whose blocks all chose Lorenzo stays on k_ribbon when that applies -- alone the two sweeps take the same time (1.05 against
+    // 1.03 - 1.13 ms at 512^3), and k_ribbon's finished tile rows feed the entropy stage while it runs (one call 1.95 against 2.08 ms).
+    // SZ_HIP_BEAM=2 sends everything the beam covers to it.
+    const bool beam_first = reg_count > 0 || sizeof(T) == 8 || tune_int("SZ_HIP_BEAM", 1) >= 2 || !ribbon_applies<T>(G, reg_count);
+    const bool use_beam = !overlap && beam_first && beam_applies<T>(G, d_in, reg_count);
     const bool use_ribbon = !use_beam && !overlap && ribbon_applies<T>(G, reg_count);
     szh_rb_layout rbl = {0, 0, 0, 0, 0, 0};
     size_t nat_elems = (size_t)n;

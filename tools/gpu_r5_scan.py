@@ -9,7 +9,7 @@ from sz_amd.fields import s_field
 shapes = [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:]] or [(512, 32, 32), (512, 64, 32), (512, 128, 32), (512, 512, 32), (512, 32, 128), (512, 32, 512), (512, 128, 128), (128, 512, 512), (256, 512, 512), (512, 512, 512)]
 dev = torch.device("cuda:0")
 meta = api.make_meta(np.float32, api.ABS, 1e-4)
-for beam in os.environ.get("R5_BEAMS", "1").split(","):
+for beam in os.environ.get("R5_BEAMS", "2").split(","):
     os.environ["SZ_HIP_BEAM"] = beam
     ctx = api.HipContext(0)
     for sh in shapes:
