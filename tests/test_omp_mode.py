@@ -1,0 +1,77 @@
+"""Round 5: SZ_HIP_MODE=omp -- SZ_compress_args / SZ_decompress of this library on the reference's OpenMP container (SURVEY 8 a22 reached through the
+drop-in API, additive and off by default).  On the CPU shim of the product code (and, marked gpu, on the device):
+  * the stream SZ_compress_args returns is, byte for byte but for the mark in stream byte 19, what SZ_compress_float_3D_MDQ_openmp returns for the
+    same array, bound and box count -- i.e. what `sz_openmp -k` of an OpenMP build of the reference reads (tests/test_zz_omp_hip.py pins that entry
+    point against recorded outputs of the reference);
+  * SZ_decompress of this library recognises it and returns the array within the bound; the lossless stage wraps and unwraps it like any stream;
+  * arrays the box rule does not fit, 2-D arrays and the default mode are untouched: the SZ 2.1 stream, byte for byte the oracle's."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(sz, oracle, monkeypatch):
+    from sz_amd.fields import s_field
+    L = sz.lib()
+    L.SZ_compress_float_3D_MDQ_openmp.restype = ctypes.c_void_p
+    L.SZ_compress_float_3D_MDQ_openmp.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_float, ctypes.POINTER(ctypes.c_size_t)]
+    d = s_field(16, 32, 64)
+    # default mode: the SZ 2.1 stream
+    ref, _ = oracle.compress(d, oracle.ABS, 1e-4)
+    assert sz.SZ_compress_args(d, sz.ABS, 1e-4) == ref
+    monkeypatch.setenv("SZ_HIP_MODE", "omp")
+    monkeypatch.setenv("SZ_HIP_OMP_THREADS", "4")
+    got = sz.SZ_compress_args(d, sz.ABS, 1e-4)
+    n = ctypes.c_size_t(0)
+    p = L.SZ_compress_float_3D_MDQ_openmp(d.ctypes.data, 16, 32, 64, ctypes.c_float(1e-4), ctypes.byref(n))
+    assert p
+    direct = ctypes.string_at(p, n.value)
+    L.free(ctypes.c_void_p(p))
+    assert got[19] == 0x4F and direct[19] == 0
+    assert got[:19] + bytes([0]) + got[20:] == direct
+    assert got != ref and len(got) > 0
+    dec = sz.SZ_decompress(got, d.shape, d.dtype)
+    assert float(np.abs(dec.astype(np.float64) - d).max()) <= 1e-4
+    # REL: the bound from the range, same container
+    got_rel = sz.SZ_compress_args(d, sz.REL, 0.0, 1e-3)
+    dec = sz.SZ_decompress(got_rel, d.shape, d.dtype)
+    assert got_rel[19] == 0x4F and float(np.abs(dec.astype(np.float64) - d).max()) <= 1e-3 * float(d.max() - d.min()) * (1 + 1e-6)
+    # what the box rule does not divide, and 2-D arrays, take the ordinary path
+    odd = s_field(31, 33, 62)
+    ref_odd, _ = oracle.compress(odd, oracle.ABS, 1e-4)
+    monkeypatch.delenv("SZ_HIP_OMP_THREADS")
+    assert sz.SZ_compress_args(odd, sz.ABS, 1e-4) == ref_odd
+    flat = s_field(1, 40, 48).reshape(40, 48)
+    ref_flat, _ = oracle.compress(flat, oracle.ABS, 1e-4)
+    assert sz.SZ_compress_args(flat, sz.ABS, 1e-4) == ref_flat
+    monkeypatch.delenv("SZ_HIP_MODE")
+    assert sz.SZ_compress_args(d, sz.ABS, 1e-4) == ref
+    assert np.array_equal(sz.SZ_decompress(ref, d.shape, d.dtype).view(np.uint32), oracle.decompress(ref, d.shape, d.dtype).view(np.uint32))
+
+
+def test_omp_mode_on_the_cpu_shim(oracle, monkeypatch):
+    import sim_lib
+    import sz_amd
+    from sz_amd import api
+    saved = api._lib
+    try:
+        api._lib = api._bind(ctypes.CDLL(sim_lib.shim_path()))
+        assert sz_amd.SZ_Init(os.path.join(ROOT, "tests", "golden", "sz_speed.config")) == 0
+        _run(sz_amd, oracle, monkeypatch)
+        sz_amd.SZ_Finalize()
+    finally:
+        api._lib = saved
+
+
+@pytest.mark.gpu
+def test_omp_mode_on_the_gpu(built, oracle, monkeypatch):
+    import sz_amd
+    assert sz_amd.SZ_Init(os.path.join(ROOT, "tests", "golden", "sz_speed.config")) == 0
+    try:
+        _run(sz_amd, oracle, monkeypatch)
+    finally:
+        sz_amd.SZ_Finalize()
