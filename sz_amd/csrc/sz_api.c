@@ -631,32 +631,44 @@ int is_lossless_compressed_data(unsigned char *compressedBytes, size_t cmpSize)
     if (is_zlib_format(compressedBytes[0], compressedBytes[1])) return GZIP_COMPRESSOR;
     return -1;
 }
-/* utility.c:216-234: the first 65536 bytes of the wrapped stream (its header is all `sz -p` wants), zero-filled behind what there is.  The
- * reference inflates / decompresses INTO a 64 KiB buffer and stops; here the frame is decompressed whole and cut (same bytes). */
+/* utility.c:216-234: the first 65536 bytes of the wrapped stream (its header is all `sz -p` wants), zero-filled behind what there is.  As the
+ * reference does, the stream is inflated / decompressed INTO a 64 KiB buffer and no further (streaming entry points of the installed library,
+ * found at run time like the rest): a crafted frame that claims terabytes costs 64 KiB and the work for 64 KiB (ADVICE, round 4). */
+typedef struct { const void *src; size_t size, pos; } zstd_in_t;
+typedef struct { void *dst; size_t size, pos; } zstd_out_t;
+typedef struct { const unsigned char *next_in; unsigned avail_in; unsigned long total_in; unsigned char *next_out; unsigned avail_out; unsigned long total_out;
+                 const char *msg; void *state; void *zalloc, *zfree, *opaque; int data_type; unsigned long adler, reserved; } zlib_stream_t;   /* z_stream of zlib 1.x, LP64 */
 uint64_t sz_lossless_decompress65536bytes(int losslessCompressor, unsigned char *compressBytes, uint64_t cmpSize, unsigned char **oriData)
 {
     if (!oriData) return 0;
     *oriData = (unsigned char *)calloc(65536, 1);
     if (!*oriData || !compressBytes) return 0;
-    unsigned char *full = NULL; size_t n = 0;
     if (losslessCompressor == ZSTD_COMPRESSOR && zstd_load()) {
-        const unsigned long long fcs = g_zstd.fcs(compressBytes, cmpSize);
-        if (fcs < ((unsigned long long)1 << 40) && (full = (unsigned char *)malloc(fcs ? (size_t)fcs : 1)) != NULL) {
-            const size_t got = g_zstd.decompress(full, (size_t)fcs, compressBytes, cmpSize);
-            n = g_zstd.iserr(got) ? 0 : got;
+        void *(*create)(void) = (void *(*)(void))dlsym(g_zstd.h, "ZSTD_createDStream");
+        size_t (*freeds)(void *) = (size_t (*)(void *))dlsym(g_zstd.h, "ZSTD_freeDStream");
+        size_t (*step)(void *, zstd_out_t *, zstd_in_t *) = (size_t (*)(void *, zstd_out_t *, zstd_in_t *))dlsym(g_zstd.h, "ZSTD_decompressStream");
+        void *ds = (create && freeds && step) ? create() : NULL;
+        if (ds) {
+            zstd_in_t in = {compressBytes, (size_t)cmpSize, 0};
+            zstd_out_t out = {*oriData, 65536, 0};
+            while (in.pos < in.size && out.pos < out.size) {
+                const size_t r = step(ds, &out, &in);
+                if (g_zstd.iserr(r) || r == 0) break;              /* an error, or the frame is complete */
+            }
+            freeds(ds);
         }
     } else if (losslessCompressor == GZIP_COMPRESSOR && zlib_load()) {
-        unsigned long cap = 65536 * 4;                              /* grows until the whole stream fits or the front is out */
-        for (int tries = 0; tries < 24 && !n; ++tries, cap *= 4) {
-            free(full); full = (unsigned char *)malloc(cap);
-            if (!full) break;
-            unsigned long got = cap;
-            const int zr = g_zlib.uncompress(full, &got, compressBytes, (unsigned long)cmpSize);
-            if (zr == 0) n = got; else if (zr != -5) break;          /* Z_BUF_ERROR: a larger buffer */
+        int (*init)(zlib_stream_t *, const char *, int) = (int (*)(zlib_stream_t *, const char *, int))dlsym(g_zlib.h, "inflateInit_");
+        int (*inflate_)(zlib_stream_t *, int) = (int (*)(zlib_stream_t *, int))dlsym(g_zlib.h, "inflate");
+        int (*end)(zlib_stream_t *) = (int (*)(zlib_stream_t *))dlsym(g_zlib.h, "inflateEnd");
+        zlib_stream_t zs; memset(&zs, 0, sizeof(zs));
+        if (init && inflate_ && end && init(&zs, "1.2.11", (int)sizeof(zs)) == 0) {
+            zs.next_in = compressBytes; zs.avail_in = cmpSize > 0xffffffffu ? 0xffffffffu : (unsigned)cmpSize;
+            zs.next_out = *oriData; zs.avail_out = 65536;
+            (void)inflate_(&zs, 0 /* Z_NO_FLUSH */);               /* stops when the 64 KiB are full or the stream ends */
+            end(&zs);
         }
     } else printf("Error: Unrecognized lossless compressor\n");
-    if (full && n) memcpy(*oriData, full, n < 65536 ? n : 65536);
-    free(full);
     return 65536;
 }
 /* sz.c:768-...: print what SZ_getMetadata found */

@@ -10,6 +10,7 @@
 // names one device twice (tests), the same exchange goes through host memory behind a barrier -- same results, no xGMI.
 // The reference has no counterpart (no multi-device path); the Python twin is sz_amd/slab.py over torch.distributed.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdio>
@@ -72,6 +73,8 @@ struct shared_t {
     std::vector<double> t_compress;
     std::mutex sim_mu;                             // the CPU shim runs one launch at a time
     int gather_ok = 1; size_t gathered = 0;
+    std::vector<int> xbuf_ok;                      // per rank: its device exchange buffers exist (decided before any collective is entered)
+    int coll_failed = 0;                           // some RCCL / HIP call of the exchange returned an error: the call fails as a whole
 };
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -92,6 +95,18 @@ void worker(shared_t *S, const job_t *J, int r)
     bool alive = hipSetDevice(J->devices[r]) == hipSuccess && szhip_create(&ctx, J->devices[r]) == SZHIP_OK && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
     sz_params cpr = *J->cpr0; sz_exedata exe = *J->exe0;
     sz_slab_thread_bind(ctx, &cpr, &exe);
+    // ---- the exchange buffers of this rank, BEFORE any collective: a rank that entered a collective the others skip -- or the other way round -- hangs
+    // the whole call, so all ranks decide together (host barrier) whether the device transport is used; if any rank could not allocate, all take the
+    // host transport.  Every RCCL / HIP return of the exchange is checked; an error fails the call (S->coll_failed), it never leaves a garbage range.
+    double *d_rng = nullptr; unsigned long long *d_sizes = nullptr;
+    if (S->rccl) {
+        const bool got = alive && hipMalloc((void **)&d_rng, 4 * sizeof(double)) == hipSuccess && hipMalloc((void **)&d_sizes, ((size_t)S->ndev + 1) * 8) == hipSuccess;
+        S->xbuf_ok[r] = got ? 1 : 0;
+        S->bar.wait();
+    }
+    bool use_rccl = S->rccl;
+    if (S->rccl) for (int q = 0; q < S->ndev; ++q) if (!S->xbuf_ok[q]) use_rccl = false;
+    auto cfail = [&](bool bad) { if (bad) { std::lock_guard<std::mutex> lk(S->sim_mu); S->coll_failed = 1; } return bad; };
     // ---- the range of the whole array (range-based modes): local scan, then min / max over the devices
     int mode = J->mode; double abs_eb = J->abs_eb;
     const bool ranged = mode == REL || mode == ABS_AND_REL || mode == ABS_OR_REL;
@@ -107,25 +122,23 @@ void worker(shared_t *S, const job_t *J, int r)
             if (!have) alive = false;
         }
         if (!have) { lo = 1.0 / 0.0; hi = -1.0 / 0.0; }           // (an empty slab takes no part)
-        if (S->rccl) {
-            double *d = nullptr;
-            if (hipMalloc((void **)&d, 4 * sizeof(double)) == hipSuccess) {
-                const double v[2] = {lo, hi};
-                hipMemcpyAsync(d, v, 16, hipMemcpyHostToDevice, st);
-                S->api.AllReduce(d, d + 2, 1, NCCL_FLOAT64, NCCL_MIN, S->comms[r], st);
-                S->api.AllReduce(d + 1, d + 3, 1, NCCL_FLOAT64, NCCL_MAX, S->comms[r], st);
-                double w[2] = {lo, hi};
-                hipMemcpyAsync(w, d + 2, 16, hipMemcpyDeviceToHost, st);
-                hipStreamSynchronize(st);
-                lo = w[0]; hi = w[1];
-                hipFree(d);
-            }
+        if (use_rccl) {
+            // ONE all-reduce: min over {lo, -hi}
+            const double v[2] = {lo, -hi};
+            double wv[2] = {lo, -hi};
+            bool bad = hipMemcpyAsync(d_rng, v, 16, hipMemcpyHostToDevice, st) != hipSuccess;
+            bad = S->api.AllReduce(d_rng, d_rng + 2, 2, NCCL_FLOAT64, NCCL_MIN, S->comms[r], st) != 0 || bad;
+            bad = hipMemcpyAsync(wv, d_rng + 2, 16, hipMemcpyDeviceToHost, st) != hipSuccess || bad;
+            bad = hipStreamSynchronize(st) != hipSuccess || bad;
+            cfail(bad);
+            lo = wv[0]; hi = -wv[1];
         } else {
             S->lo[r] = lo; S->hi[r] = hi;
             S->bar.wait();
             for (int q = 0; q < S->ndev; ++q) { if (S->lo[q] < lo) lo = S->lo[q]; if (S->hi[q] > hi) hi = S->hi[q]; }
             S->bar.wait();
         }
+        if (!(lo <= hi) || lo != lo || hi != hi || lo - lo != 0 || hi - hi != 0) { cfail(true); lo = 0; hi = 0; }     // no rank saw a finite value: nothing to derive a bound from
         // getRealPrecision_float / _double on the whole array's range (dataCompression.c:288-332; the float helpers narrow both operands)
         const double range = J->dataType == SZ_FLOAT ? (double)((float)hi - (float)lo) : hi - lo, rel = J->rel * range;
         if (mode == REL) abs_eb = rel;
@@ -148,38 +161,48 @@ void worker(shared_t *S, const job_t *J, int r)
     S->t_compress[r] = now_s() - t0;
     // ---- the sub-streams on every device: sizes, then payloads (north_star's all-gather over xGMI).  Every rank takes part even when its
     // own slab failed (a collective that one rank skips hangs the others): a failed slab contributes an empty stream
-    if (S->rccl) {
-        unsigned long long *d_sizes = nullptr; unsigned char *d_all = nullptr;
+    if (use_rccl) {
+        unsigned char *d_all = nullptr;
         const unsigned long long mine = S->rc[r] == SZ_SCES ? (unsigned long long)S->bytes[r] : 0ull;
         std::vector<unsigned long long> sizes((size_t)S->ndev, 0ull);
-        if (hipMalloc((void **)&d_sizes, ((size_t)S->ndev + 1) * 8) == hipSuccess) {
-            hipMemcpyAsync(d_sizes + S->ndev, &mine, 8, hipMemcpyHostToDevice, st);
-            S->api.AllGather(d_sizes + S->ndev, d_sizes, 1, NCCL_UINT64, S->comms[r], st);
-            hipMemcpyAsync(sizes.data(), d_sizes, (size_t)S->ndev * 8, hipMemcpyDeviceToHost, st);
-            hipStreamSynchronize(st);
+        {
+            bool bad = hipMemcpyAsync(d_sizes + S->ndev, &mine, 8, hipMemcpyHostToDevice, st) != hipSuccess;
+            bad = S->api.AllGather(d_sizes + S->ndev, d_sizes, 1, NCCL_UINT64, S->comms[r], st) != 0 || bad;
+            bad = hipMemcpyAsync(sizes.data(), d_sizes, (size_t)S->ndev * 8, hipMemcpyDeviceToHost, st) != hipSuccess || bad;
+            bad = hipStreamSynchronize(st) != hipSuccess || bad;
+            if (cfail(bad)) std::fill(sizes.begin(), sizes.end(), 0ull);
         }
         size_t total = 0, my_off = 0;
         for (int q = 0; q < S->ndev; ++q) { if (q == r) my_off = total; total += (size_t)sizes[q]; }
-        if (hipMalloc((void **)&d_all, total ? total : 1) == hipSuccess) {
-            if (mine) hipMemcpyAsync(d_all + my_off, S->streams[r], (size_t)mine, hipMemcpyHostToDevice, st);
-            S->api.GroupStart();
+        // the payload buffer: again decided together (a rank without it cannot take part in the broadcasts)
+        S->xbuf_ok[r] = hipMalloc((void **)&d_all, total ? total : 1) == hipSuccess ? 1 : 0;
+        S->bar.wait();
+        bool all_have = true;
+        for (int q = 0; q < S->ndev; ++q) if (!S->xbuf_ok[q]) all_have = false;
+        if (!all_have) cfail(true);
+        else {
+            bool bad = false;
+            if (mine && sizes[r] == mine) bad = hipMemcpyAsync(d_all + my_off, S->streams[r], (size_t)mine, hipMemcpyHostToDevice, st) != hipSuccess;
+            bad = S->api.GroupStart() != 0 || bad;
             size_t off = 0;
-            for (int q = 0; q < S->ndev; ++q) { if (sizes[q]) S->api.Broadcast(d_all + off, d_all + off, (size_t)sizes[q], NCCL_UINT8, q, S->comms[r], st); off += (size_t)sizes[q]; }
-            S->api.GroupEnd();
-            hipStreamSynchronize(st);
+            for (int q = 0; q < S->ndev; ++q) { if (sizes[q]) bad = S->api.Broadcast(d_all + off, d_all + off, (size_t)sizes[q], NCCL_UINT8, q, S->comms[r], st) != 0 || bad; off += (size_t)sizes[q]; }
+            bad = S->api.GroupEnd() != 0 || bad;
+            bad = hipStreamSynchronize(st) != hipSuccess || bad;
+            cfail(bad);
             if (r == 0) S->gathered = total;
             if (J->verify_gather) {                                 // what every device now holds = the slabs' streams back to back
                 std::vector<unsigned char> back(total ? total : 1);
-                hipMemcpy(back.data(), d_all, total, hipMemcpyDeviceToHost);
+                if (hipMemcpy(back.data(), d_all, total, hipMemcpyDeviceToHost) != hipSuccess) cfail(true);
                 S->bar.wait();                                      // (all host streams are final)
                 size_t o2 = 0; bool ok = true;
                 for (int q = 0; q < S->ndev; ++q) { if (sizes[q] && memcmp(back.data() + o2, S->streams[q], (size_t)sizes[q]) != 0) ok = false; o2 += (size_t)sizes[q]; }
                 if (!ok) { std::lock_guard<std::mutex> lk(S->sim_mu); S->gather_ok = 0; }
             }
-            hipFree(d_all);
         }
-        if (d_sizes) hipFree(d_sizes);
+        if (d_all) (void)hipFree(d_all);
     }
+    if (d_rng) (void)hipFree(d_rng);
+    if (d_sizes) (void)hipFree(d_sizes);
     sz_slab_thread_bind(nullptr, nullptr, nullptr);
     if (st) hipStreamDestroy(st);
     if (ctx) szhip_destroy(ctx);
@@ -205,7 +228,7 @@ extern "C" unsigned char *sz_slab_compress_multi(int dataType, void *data, size_
     sz_slab_bounds(r3, ndev, 6, bounds.data());
     shared_t S;
     S.ndev = ndev; S.bar.n = ndev;
-    S.lo.assign(ndev, 0); S.hi.assign(ndev, 0); S.streams.assign(ndev, nullptr); S.bytes.assign(ndev, 0); S.rc.assign(ndev, SZ_NSCS); S.t_compress.assign(ndev, 0);
+    S.lo.assign(ndev, 0); S.hi.assign(ndev, 0); S.xbuf_ok.assign(ndev, 0); S.streams.assign(ndev, nullptr); S.bytes.assign(ndev, 0); S.rc.assign(ndev, SZ_NSCS); S.t_compress.assign(ndev, 0);
     const char *no = getenv("SZ_SLAB_NO_RCCL");
     if (distinct && !(no && atoi(no)) && S.api.load()) {
         S.comms.assign(ndev, nullptr);
@@ -222,7 +245,7 @@ extern "C" unsigned char *sz_slab_compress_multi(int dataType, void *data, size_
     const double t1 = now_s();
     if (S.rccl) for (ncclComm_t c : S.comms) if (c) S.api.CommDestroy(c);
     unsigned char *out = nullptr;
-    bool ok = S.gather_ok != 0;
+    bool ok = S.gather_ok != 0 && S.coll_failed == 0;
     for (int r = 0; r < ndev; ++r) if (S.rc[r] != SZ_SCES) ok = false;
     if (ok) {
         const size_t dims[3] = {r3, r2, r1};

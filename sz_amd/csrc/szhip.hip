@@ -953,8 +953,8 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     // sweep keeps the CUs busy with one workgroup each.  k_ribbon publishes every finished tile in host-coherent memory (a.tile_done);
     // this thread watches the words and launches the passes of slice after slice on two other streams.  SZ_HIP_SLICES=1: everything
     // after the sweep, as before.
-    // A lane of a pool (several arrays in flight) does not do it: the other lanes' kernels already fill the sweep's idle CUs, and the
-    // slices' kernels slow every sweep in flight (measured, two lanes at 512^3: 338 GB/s without, 324 with).
+    // A lane of a pool (several arrays in flight) takes two slices (SZ_HIP_SLICES_POOL; with the passes of the start of round 4 the lanes lost by
+    // slicing -- two lanes at 512^3: 338 GB/s without, 324 with eight slices --, with the lighter passes of its end they gain: 349 -> 356).
     // Measured (round 4, 512^3 float, one call after the other, same box): 255 GB/s with 1 slice, 276 with 4, 251 - 275 with 8 (the slices'
     // kernels take 2 - 4 x their lone time beside the sweep and slow it by ~0.1 ms; more slices, more of that).
     const int slices_req = tune_int("SZ_HIP_SLICES", ctx->gate ? tune_int("SZ_HIP_SLICES_POOL", 2) : 4);
@@ -1181,6 +1181,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
             for (int t = ti_lo * nTJ; t < ti_hi * nTJ && !sweep_over; ++t) {
                 unsigned spins = 0;
                 while (__atomic_load_n(&tile_done[t], __ATOMIC_ACQUIRE) != ep) {
+                    szhip_chain_pool::pause();                     // (the core's sibling thread gets the issue slots while this one watches a word)
                     if ((++spins & 127u) == 0) {
                         const hipError_t q = hipEventQuery(ctx->ev[3]);
                         if (q == hipSuccess) { sweep_over = true; break; }

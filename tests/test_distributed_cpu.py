@@ -205,6 +205,64 @@ def test_c_slab_container_equals_the_python_one_and_round_trips(oracle):
         api._lib = saved
 
 
+def test_c_slab_mode_comes_from_the_argument(oracle):
+    """ADVICE (round 4, high): sz_slab_compress took the error-bound mode from the stored configuration as well as from its argument, so on a
+    default-initialised library (SZ_Init(NULL): errorBoundMode = PSNR) an explicit ABS call was compressed with the PSNR-derived bound -- and a second,
+    identical call (the first had rewritten the configuration) gave other bytes.  The mode is the argument's alone now, as in SZ_compress_args
+    (sz.c:294-391).  Also the PSNR and NORM slab paths, which no test covered: bounds derived from the WHOLE array, honoured by every slab."""
+    import ctypes
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import sim_lib
+    import sz_amd
+    from sz_amd import api
+    from sz_amd.fields import s_field
+    saved = api._lib
+    try:
+        L = ctypes.CDLL(sim_lib.shim_path())
+        api._lib = api._bind(L)
+        szt = ctypes.c_size_t
+        L.SZ_Init.argtypes = [ctypes.c_char_p]
+        L.sz_slab_compress.restype = ctypes.c_void_p
+        L.sz_slab_compress.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(szt), ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, szt, szt, szt, ctypes.c_int]
+        L.sz_slab_decompress.restype = ctypes.c_void_p
+        L.sz_slab_decompress.argtypes = [ctypes.c_void_p, szt, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(szt * 3)]
+        libc = ctypes.CDLL(None); libc.free.argtypes = [ctypes.c_void_p]
+        whole = s_field(26, 21, 40)
+
+        def run(mode, absb, rel):
+            n = szt(0)
+            p = L.sz_slab_compress(0, whole.ctypes.data, ctypes.byref(n), mode, absb, rel, 0.0, *whole.shape, 2)
+            assert p
+            got = ctypes.string_at(p, n.value); libc.free(p)
+            dtc = ctypes.c_int(-1); dims = (szt * 3)()
+            q = L.sz_slab_decompress(got, len(got), ctypes.byref(dtc), ctypes.byref(dims))
+            assert q
+            back = np.ctypeslib.as_array(ctypes.cast(q, ctypes.POINTER(ctypes.c_float)), shape=(whole.size,)).copy().reshape(whole.shape)
+            libc.free(q)
+            return got, float(np.abs(back.astype(np.float64) - whole).max())
+
+        assert L.SZ_Init(None) == 0                                  # the defaults of conf.c:99-141: errorBoundMode = PSNR, psnr = 90
+        a, err_a = run(sz_amd.ABS, 1e-4, 0.0)
+        b, err_b = run(sz_amd.ABS, 1e-4, 0.0)
+        assert err_a <= 1e-4 and err_b <= 1e-4 and a == b           # the explicit bound holds on the first call, and both calls give the same bytes
+        rng = float(whole.max() - whole.min())
+        r1, err_r = run(sz_amd.REL, 0.0, 1e-3)
+        assert err_r <= 1e-3 * rng * (1 + 1e-6) and r1 != a
+        cp = api.conf_params()
+        psnr_eb = rng * 10 ** ((float(cp.psnr) + 10 * np.log10(1 - 2.0 / 3.0 * float(cp.predThreshold))) / -20)      # conf.c:54-60 on the whole array's range
+        p1, err_p = run(sz_amd.PSNR, 0.0, 0.0)
+        assert err_p <= psnr_eb * (1 + 1e-6)
+        cp.normErr = 0.05                                            # (callers of the reference poke the struct; 0 after SZ_Init(NULL))
+        norm_eb = float(np.sqrt(3.0 / whole.size) * 0.05)                                                         # conf.c:62-65 on the whole array's element count
+        n1, err_n = run(sz_amd.NORM, 0.0, 0.0)
+        assert err_n <= norm_eb * (1 + 1e-6)
+        a2, err_a2 = run(sz_amd.ABS, 1e-4, 0.0)                      # ... and an ABS call after them is the first call's stream again
+        assert a2 == a
+        sz_amd.SZ_Finalize()
+    finally:
+        api._lib = saved
+
+
 @pytest.mark.slow
 def test_bench_entry_starts_its_own_ranks_for_gpus_gt_1():
     """`python bench.py --gpus 2 ...` -- the shape of the driver's N = 1 command -- must start the two ranks itself and print ONE JSON
