@@ -165,3 +165,47 @@ def test_ticket_fallback_on_the_gpu(built, oracle, monkeypatch):
     import sz_amd
     monkeypatch.setenv("SZ_HIP_TEST_TICKET_FALLBACK", "1")
     _exercise(ctypes.CDLL(sz_amd.api.lib_path()), oracle)
+
+
+@pytest.mark.parametrize("backend", ["ZSTD_COMPRESSOR", "GZIP_COMPRESSOR"])
+def test_first_64k_of_a_wrapped_stream_is_decoded_into_a_fixed_buffer(built, oracle, tmp_path, backend):
+    """sz_lossless_decompress65536bytes (utility.c:216-234, used by `sz -p`): the front of a zstd / gzip wrapped stream, decoded INTO 64 KiB and no
+    further (a crafted frame must not be able to ask for terabytes).  On the CPU shim: the bytes are the plain stream's front (the
+    mode bits of the parameter byte aside); a frame that claims an absurd size costs nothing but the 64 KiB."""
+    import sim_lib
+    import ref_cases
+    from sz_amd.fields import s_field
+    L = ctypes.CDLL(sim_lib.shim_path())
+    L.SZ_Init.argtypes = [ctypes.c_char_p]
+    szt = ctypes.c_size_t
+    L.SZ_compress_args.restype = ctypes.c_void_p
+    L.SZ_compress_args.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(szt), ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double] + [szt] * 5
+    L.sz_lossless_decompress65536bytes.restype = ctypes.c_uint64
+    L.sz_lossless_decompress65536bytes.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p)]
+    libc = ctypes.CDLL(None); libc.free.argtypes = [ctypes.c_void_p]
+    d = (s_field(40, 48, 64) + (np.random.default_rng(1).random((40, 48, 64)) - 0.5) * 2e-3).astype(np.float32)      # a stream beyond 64 KiB
+
+    def compress(conf):
+        cfg = str(tmp_path / "c.config")
+        ref_cases.write_config(cfg, conf)
+        assert L.SZ_Init(cfg.encode()) == 0
+        n = szt(0)
+        p = L.SZ_compress_args(0, d.ctypes.data, ctypes.byref(n), 0, 1e-4, 0.0, 0.0, 0, 0, 40, 48, 64)
+        assert p
+        b = ctypes.string_at(p, n.value); libc.free(p); L.SZ_Finalize()
+        return b
+    plain = compress({"szMode": "SZ_BEST_SPEED"})
+    wrapped = compress({"szMode": "SZ_BEST_COMPRESSION", "losslessCompressor": backend})
+    assert wrapped != plain and len(plain) > 65536
+    code = 1 if backend == "ZSTD_COMPRESSOR" else 0           # defines.h: GZIP_COMPRESSOR 0, ZSTD_COMPRESSOR 1
+    out = ctypes.c_void_p()
+    buf = ctypes.create_string_buffer(wrapped, len(wrapped))
+    assert L.sz_lossless_decompress65536bytes(code, buf, len(wrapped), ctypes.byref(out)) == 65536 and out.value
+    front = ctypes.string_at(out.value, 65536); libc.free(out)
+    assert front[:4] == plain[:4] and front[5:] == plain[5:65536]
+    if backend == "ZSTD_COMPRESSOR":
+        # a frame header that claims 2^39 bytes of content: the call still returns its 64 KiB (zeros: the frame is empty behind the header)
+        crafted = bytes([0x28, 0xB5, 0x2F, 0xFD, 0xE0]) + (1 << 39).to_bytes(8, "little") + b"\x01\x00\x00"
+        out = ctypes.c_void_p()
+        assert L.sz_lossless_decompress65536bytes(1, crafted, len(crafted), ctypes.byref(out)) == 65536 and out.value
+        libc.free(out)
