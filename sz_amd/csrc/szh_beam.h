@@ -229,6 +229,7 @@ struct beam {
     greg_t gk[DK], gj[DK];                                         // k-face / j-face granules on their way
     T eb, eb2, rh, caph, radf, mean; int radius; unsigned epoch;
     unsigned lo_it;                                                // LDS offset of wave line `it` in the ring (uniform)
+    bool wt_codes;                                                 // the codes are stored write-through (the host launches passes over finished lines while the sweep runs)
     bool pface_fixed;                                              // the lane hands nothing on (its `pface` is its write-only word)
     unsigned pv_prev, pv_next;                                     // the neighbouring wavefronts' progress words as read a step ago
 
@@ -339,7 +340,8 @@ struct beam {
                     wqc.x = (old.x & m0) | (wqc.x & ~m0); wqc.y = (old.y & m1) | (wqc.y & ~m1);
                     gc[set] = load_c<true>(it - LAG + UL);
                 }
-                place<EDGE>(rcs, it - LAG, str_c, o, so); bst8<0>(rs_c, o, so, wqc);
+                place<EDGE>(rcs, it - LAG, str_c, o, so);
+                if (wt_codes) bst8<17>(rs_c, o, so, wqc); else bst8<0>(rs_c, o, so, wqc);      // (written through when the host follows this sweep's progress: see `pub` in run)
             }
             else for_n<EV>([&](auto E) { constexpr int e = decltype(E)::value; place<EDGE>(rvs[e], it - LAG, str_v, o, so); bst16<0>(rs_v, o, so, wqv[e]); });
             // rows that have arrived go in (line it + 1), and the register set that carried them is sent for the rows DV events further on
@@ -639,8 +641,9 @@ struct beam {
         // ---- the lines: every lane has left line it - LAG when lane 0 enters line it.  Blocks of UL lines; the ones in which every line any
         // lane asks for or stores exists take the variant without per-lane line checks
         const int NWL = r0 + 1 + LAG, nblk = (NWL + UL - 1) / UL;
+        wt_codes = !DEC && a.tile_done != nullptr;
         unsigned *const pub = (!DEC && a.tile_done) ? a.tile_done + (((int64_t)kb * gr.nJG + jg) * WPG + w) : nullptr;     // (uniform)
-        constexpr int PUBB = 32 / UL;                                  // a word every 32 lines
+        const int PUBB = (a.pub_lines > 0 ? a.pub_lines : 32) / UL > 0 ? (a.pub_lines > 0 ? a.pub_lines : 32) / UL : 1;     // blocks between two words (a word every 32 lines by default)
 #pragma unroll 1
         for (int b = 0; b < nblk; ++b) {
             const int it0 = b * UL;
@@ -654,7 +657,15 @@ struct beam {
             if (pub && ((b + 1) % PUBB == 0 || b + 1 == nblk)) {
                 int rows = b + 1 == nblk ? r0 : it0 + UL - 1 - LAG;
                 rows = rows < 0 ? 0 : (rows > r0 ? r0 : rows);
-                if (b + 1 == nblk || rows > 0) szh_rb::st_done(pub, ((epoch & 0xfffu) << 20) | (unsigned)rows);
+                if (b + 1 == nblk || rows > 0) {
+                    // the codes went out write-through (sc0 sc1): once this wavefront's memory counter is empty they are in memory, and the word may follow.
+                    // (A release at system scope -- which writes the XCD's L2 back -- cost ~35 us a time here with every CU storing codes: 16 words a
+                    // wavefront took the sweep from 1.05 to 1.6 ms at 512^3.)
+#ifndef SZH_HIPSIM
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                    __hip_atomic_store(pub, ((epoch & 0xfffu) << 20) | (unsigned)rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
             }
         }
         lds_put<unsigned>((OC_LDS unsigned char *)(prog + w), 0, (unsigned)SZH_BM_INF);

@@ -75,6 +75,7 @@ template <class T> struct szh_qargs {
     int wide;                 // 1: the granule rows of a tile lie within 4 GB of the tile's first row: 16-byte buffer accesses with 32-bit offsets
     int trace_tile;           // development: (TI << 16) | TJ of the tile whose left-hand hand-off is logged round by round (SZH_TRACE_LOG)
     const T *xr;              // k_beam, compress, arrays with regression blocks: the RECONSTRUCTIONS of their points (k_reg_points), natural layout
+    int pub_lines;            // k_beam with tile_done: lines between two progress words of a wavefront (a multiple of 8; 0: 32)
     const uint8_t *ptflags;   // k_beam, arrays with regression blocks: per point, 1 = the point lies in a regression block (k_reg_points; zeros elsewhere)
     int dbg;                  // development: 1 = no hand-off at all (timing only, results become WRONG), 4 = no issue priorities
     szh_u64 *trace;           // optional (development): per pencil {t_start, t_start, t_first_trip, t_end, wait spins, -, xcc, 0} + per-trip detail

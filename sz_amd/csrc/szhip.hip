@@ -961,10 +961,10 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     const int slice_from = tune_int("SZ_HIP_SLICE_FROM", 0);          // even parts: per cent of the tile rows that the first slice covers at least
     const int slice_geom = tune_int("SZ_HIP_SLICE_GEOM", 0);
     // (round 5) the beam sweep: every wavefront publishes how many of its lines have their codes in memory (szh_beam.h, `tile_done`: a word per
-    // wavefront); a slice = the block rows whose lines every wavefront has passed.  OFF by default (SZ_HIP_BEAM_SLICES=1 switches it on): measured
-    // at 512^3 the sweep -- one latency-bound wavefront per SIMD -- slows from 1.05 to 1.58 ms beside the slices' kernels and the 16 system-scope
-    // releases per wavefront (one call 2.39 ms against 2.08 without), and one of 16 GPU parity cases met codes the histogram had read too early
-    const bool sliced = (use_ribbon || (use_beam && tune_int("SZ_HIP_BEAM_SLICES", 0))) && slices_req > 1 && !tune_int("SZ_HIP_FUSE_HIST", 0);
+    // wavefront, written every SZ_HIP_BEAM_PUB lines after write-through code stores and a vmcnt(0) -- a system-scope RELEASE per word cost ~35 us
+    // each and took the sweep from 1.05 to 1.58 ms); a slice = the block rows whose lines every wavefront has passed.  Measured at 512^3, one call:
+    // S-field 2.12 ms unsliced, 1.94 - 1.96 with 3 - 6 slices; M-field 3.94 -> 3.82 (profiles/r05_beam_slices.txt).  SZ_HIP_BEAM_SLICES=0: off.
+    const bool sliced = (use_ribbon || (use_beam && tune_int("SZ_HIP_BEAM_SLICES", 1))) && slices_req > 1 && !tune_int("SZ_HIP_FUSE_HIST", 0);
     unsigned *tile_done = nullptr;
     const szh_bm::grid_t bgrid = szh_bm::make_grid(G);
     const size_t beam_words = (size_t)bgrid.nKB * bgrid.nJG * szh_bm::WPG;
@@ -983,7 +983,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
     }
     {
         szh_qargs<T> a; memset(&a, 0, sizeof(a));
-        a.tile_done = tile_done;
+        a.tile_done = tile_done; a.pub_lines = tune_int("SZ_HIP_BEAM_PUB", 32);
         a.G = G; a.data = d_in; a.out = nullptr; a.codes = d_nat; a.blk_lor = d_lor; a.coef = d_coef; a.coef_stride = nb;
         a.eb = eb; a.recip = 1 / eb; a.mean = mean; a.cap = (int)intervals; a.radius = (int)intervals / 2; a.use_mean = use_mean;
         a.faceI = (szh_u64 *)ctx->faceI.p; a.faceJ = (szh_u64 *)ctx->faceJ.p; a.epoch = ++ctx->epoch;
@@ -1118,6 +1118,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
         bool sweep_over = false;
         int b0_done = 0;
         size_t first_late = 0;                                     // wavefronts below this index have been seen past the current slice's rows
+        int64_t hist_first = 0;
         for (int sl = 0; sl < NS; ++sl) {
             const int b0_hi = sl == NS - 1 ? G.g0.num : std::max(b0_done, (int)((int64_t)G.g0.num * (sl + 1) / NS));
             const int rows_need = b0_hi >= G.g0.num ? G.g0.count : szh_blk_start(G.g0, b0_hi);
@@ -1126,6 +1127,7 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
             while (!sweep_over && first_late < beam_words) {
                 const unsigned wv = __atomic_load_n(&tile_done[first_late], __ATOMIC_ACQUIRE);
                 if ((wv & 0xfff00000u) == tag && (int)(wv & 0xfffffu) >= rows_need) { ++first_late; continue; }
+                szhip_chain_pool::pause();
                 if ((++spins & 127u) == 0) {
                     const hipError_t q = hipEventQuery(ctx->ev[3]);
                     if (q == hipSuccess) { sweep_over = true; break; }
@@ -1133,9 +1135,11 @@ int compress_impl(szhip_ctx *ctx, const void *data, int data_on_device, size_t r
                 }
             }
             if (b0_hi > b0_done) {
-                const int64_t h_lo = (int64_t)szh_blk_start(G.g0, b0_done) * G.d0, h_hi = (int64_t)rows_need * G.d0;
+                // (k_hist_u16 counts groups of eight codes: a slice of it ends on a multiple of eight below the slice's last code, the last slice takes the rest)
+                const int64_t h_lo = hist_first, h_hi = b0_hi >= G.g0.num ? (int64_t)n : ((int64_t)rows_need * G.d0) / 8 * 8;
+                hist_first = h_hi;
                 const int grid = (int)std::min<int64_t>(((h_hi - h_lo) / 8 + 255) / 256 + 1, 2048);
-                hipLaunchKernelGGL(k_hist_u16, dim3(grid), dim3(256), hist_lds, ctx->stream2, (const uint16_t *)d_nat, h_hi, intervals, rshift, use_lds, d_hist, rbl,
+                if (h_hi > h_lo) hipLaunchKernelGGL(k_hist_u16, dim3(grid), dim3(256), hist_lds, ctx->stream2, (const uint16_t *)d_nat, h_hi, intervals, rshift, use_lds, d_hist, rbl,
                                    G.g0.count, G.g1.count, G.g2.count, h_lo);
                 hipLaunchKernelGGL((k_permute<0>), dim3((unsigned)((b0_hi - b0_done) * G.g1.num), std::min(nseg, std::max(1, tune_int("SZ_HIP_PERM_Y", 1)))), dim3(256), ((tile_el + 1) & ~(size_t)1) * 2 + 16, ctx->stream3, G,
                                    (const uint16_t *)d_nat, d_blk, (unsigned *)ctx->col_zeros.p, segb, (unsigned *)ctx->zcnt.p, (unsigned *)ctx->zpos.p, rbl, d_hist, 0u,
