@@ -1484,7 +1484,8 @@ int parse_header(const unsigned char *hs, size_t avail, size_t stream_len, size_
     const int is_double = sizeof(T) == 8;
 #define PFAIL(code, ...) do { snprintf(err, errlen, __VA_ARGS__); if (hf) szhost_huff_free(hf); return (code); } while (0)
 #define NEED(k) do { const size_t end_ = (size_t)(q - hs) + (size_t)(k); if (end_ > stream_len) PFAIL(SZHIP_ERR_STREAM, "truncated stream"); \
-                     if (end_ > avail) { *need = end_; if (hf) szhost_huff_free(hf); return 1; } } while (0)
+                     if (end_ > avail) { *need = std::min(stream_len, end_ + need_more); if (hf) szhost_huff_free(hf); return 1; } } while (0)
+    size_t need_more = 0;                      // what a longer prefix should hold beyond the bytes asked for (the coefficient sections still to come)
     szhost_huff *hf = nullptr;
     const unsigned char *q = hs + body_off;
     NEED(4 + sizeof(T) + 12);
@@ -1515,7 +1516,11 @@ int parse_header(const unsigned char *hs, size_t avail, size_t stream_len, size_
     q += ind_bytes;
     H.coef.clear();
     if (H.reg_count > 0) {
+        // The four sections are LOCATED first (their lengths stand in front of them) and decoded afterwards, each on its own thread for a large
+        // array: located first, a prefix of the stream that turns out too short costs no decoding (round 4 decoded the sections again for every
+        // longer prefix it fetched: 3 x at the M-field's 3.4 MB header), and the bit-serial Huffman decode of ~300 000 codes is the long part.
         std::vector<int> ccodes[4]; int *cptr[4]; int crad[4]; double cprec[4]; const unsigned char *cun[4];
+        const unsigned char *tree_at[4], *pay_at[4]; int cnc_of[4]; size_t enc_of[4]; unsigned cu_of[4];
         for (int e = 0; e < ncoef; ++e) {
             NEED(sizeof(T) + 12);
             cprec[e] = is_double ? szhost_get_f64be(q) : (double)szhost_get_f32be(q); q += sizeof(T);
@@ -1524,32 +1529,51 @@ int parse_header(const unsigned char *hs, size_t avail, size_t stream_len, size_
             const int cnc = (int)szhost_get_u32be(q); q += 4;
             NEED(ts);
             if (cnc <= 0 || crad[e] <= 0 || crad[e] > 32768 || szhost_huff_serial_size(cnc) > ts) PFAIL(SZHIP_ERR_STREAM, "bad coefficient tree size");
-            const unsigned char *tree_at = q;
+            tree_at[e] = q; cnc_of[e] = cnc;
             q += ts;
             NEED(8);
             const uint64_t enc64 = szhost_get_u64be(q); q += 8;
             if (enc64 > (uint64_t)(stream_len - (size_t)(q - hs))) PFAIL(SZHIP_ERR_STREAM, "truncated stream");   // before any size arithmetic on it
-            const size_t enc = (size_t)enc64;
-            NEED(enc);
-            szhost_huff *ch = szhost_huff_from_bytes(4 * crad[e], tree_at, cnc);
-            if (!ch) PFAIL(SZHIP_ERR_STREAM, "bad coefficient tree");
-            ccodes[e].resize(H.reg_count);
-            if (!szhost_huff_decode_i32(ch, q, enc, H.reg_count, ccodes[e].data())) {   // bounded by the section's own length
-                szhost_huff_free(ch);
-                PFAIL(SZHIP_ERR_STREAM, "coefficient payload too short");
-            }
-            szhost_huff_free(ch);
-            cptr[e] = ccodes[e].data();
-            q += enc;
+            enc_of[e] = (size_t)enc64;
+            need_more = (size_t)(ncoef - 1 - e) * (enc_of[e] + enc_of[e] / 2 + ts + 65536) + 65536;   // (the sections are of similar size: one more fetch, not three)
+            NEED(enc_of[e]);
+            need_more = 0;
+            pay_at[e] = q;
+            q += enc_of[e];
             NEED(4);
-            const unsigned cu = szhost_get_u32be(q); q += 4;
-            NEED((size_t)cu * sizeof(T));
-            {   // every zero code takes one verbatim coefficient (szd_float.c:5809-5820): the list must hold them all
-                size_t zeros = 0;
-                for (size_t i = 0; i < H.reg_count; ++i) zeros += ccodes[e][i] == 0;
-                if (zeros > cu) PFAIL(SZHIP_ERR_STREAM, "coefficient section lists %u verbatim values, codes need %zu", cu, zeros);
-            }
-            cun[e] = q; q += (size_t)cu * sizeof(T);
+            cu_of[e] = szhost_get_u32be(q); q += 4;
+            NEED((size_t)cu_of[e] * sizeof(T));
+            cun[e] = q; q += (size_t)cu_of[e] * sizeof(T);
+        }
+        NEED(8);                                   // (the word after the sections: nothing below asks for more of the stream)
+        int sec_rc[4] = {0, 0, 0, 0};              // 1 bad tree, 2 payload too short, 3 too few verbatim values
+        size_t sec_zeros[4] = {0, 0, 0, 0};
+        auto decode_section = [&](int e) {
+            szhost_huff *ch = szhost_huff_from_bytes(4 * crad[e], tree_at[e], cnc_of[e]);
+            if (!ch) { sec_rc[e] = 1; return; }
+            ccodes[e].resize(H.reg_count);
+            const int ok = szhost_huff_decode_i32(ch, pay_at[e], enc_of[e], H.reg_count, ccodes[e].data());   // bounded by the section's own length
+            szhost_huff_free(ch);
+            if (!ok) { sec_rc[e] = 2; return; }
+            // every zero code takes one verbatim coefficient (szd_float.c:5809-5820): the list must hold them all
+            size_t zeros = 0;
+            for (size_t i = 0; i < H.reg_count; ++i) zeros += ccodes[e][i] == 0;
+            sec_zeros[e] = zeros;
+            if (zeros > cu_of[e]) sec_rc[e] = 3;
+        };
+        if (H.reg_count >= 16384) {
+            std::vector<std::thread> th;
+            for (int e = 1; e < ncoef; ++e) th.emplace_back(decode_section, e);
+            decode_section(0);
+            for (auto &t : th) t.join();
+        } else {
+            for (int e = 0; e < ncoef; ++e) decode_section(e);
+        }
+        for (int e = 0; e < ncoef; ++e) {
+            if (sec_rc[e] == 1) PFAIL(SZHIP_ERR_STREAM, "bad coefficient tree");
+            if (sec_rc[e] == 2) PFAIL(SZHIP_ERR_STREAM, "coefficient payload too short");
+            if (sec_rc[e] == 3) PFAIL(SZHIP_ERR_STREAM, "coefficient section lists %u verbatim values, codes need %zu", cu_of[e], sec_zeros[e]);
+            cptr[e] = ccodes[e].data();
         }
         // compact [4][reg_count] in scan order; the device scatters them to the blocks (k_move_coef)
         H.coef.assign(H.reg_count * 4, (T)0);

@@ -269,3 +269,48 @@ def test_fast_coefficient_chain_equals_the_reference_loop(L, dtype, use_mean):
         for e in range(4):
             assert np.array_equal(outs[0][1][e], outs[1][1][e]), (kind, e, "codes")
             assert outs[0][2][e] == outs[1][2][e], (kind, e, "verbatim coefficients")
+
+
+def test_table_decode_of_coefficient_codes_equals_the_walk(L):
+    """round 5: szhost_huff_decode_i32 looks the first 11 bits of a code up in a table and walks the rest; it must return what the bit-by-bit walk
+    of the reference's decode() (Huffman.c:314-360) returns -- the symbols that were encoded --, for short and for very long codes, and report a
+    payload that ends early instead of reading past it."""
+    rng = np.random.default_rng(5)
+    L.szhost_huff_build.restype = ctypes.c_void_p
+    L.szhost_huff_from_bytes.restype = ctypes.c_void_p
+    L.szhost_huff_tree_size.restype = ctypes.c_size_t
+    L.szhost_huff_encode_i32.restype = ctypes.c_size_t
+    for kind in range(3):
+        states = 4096
+        n = 60000
+        if kind == 0:    # a narrow peak: codes of 1 - 12 bits
+            sym = np.clip(np.rint(rng.normal(2048, 3, n)), 1, states - 1).astype(np.int32)
+        elif kind == 1:  # geometric frequencies: code lengths up to ~25 bits, far beyond the table
+            sym = np.minimum(rng.geometric(0.5, n), 30).astype(np.int32) + 100
+            sym[::997] = rng.integers(1, states, len(sym[::997]))
+        else:            # flat over 3000 symbols: every code longer than 11 bits
+            sym = rng.integers(1, 3001, n).astype(np.int32)
+        hist = np.bincount(sym, minlength=states).astype(np.uint32)
+        h = L.szhost_huff_build(states, hist.ctypes.data_as(ctypes.c_void_p), None, ctypes.c_size_t(states))
+        assert h
+        ts = L.szhost_huff_tree_size(ctypes.c_void_p(h))
+        tree = np.zeros(ts, dtype=np.uint8)
+        L.szhost_huff_tree_write(ctypes.c_void_p(h), tree.ctypes.data_as(ctypes.c_void_p))
+        pay = np.zeros(n * 8 + 64, dtype=np.uint8)
+        nbytes = L.szhost_huff_encode_i32(ctypes.c_void_p(h), sym.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(n), pay.ctypes.data_as(ctypes.c_void_p))
+        n_nodes = 2 * int((hist > 0).sum()) - 1
+        h2 = L.szhost_huff_from_bytes(states, tree.ctypes.data_as(ctypes.c_void_p), n_nodes)
+        assert h2
+        for cut in (0, 1, 9, nbytes // 2):
+            out = np.full(n, -1, dtype=np.int32)
+            ok = L.szhost_huff_decode_i32(ctypes.c_void_p(h2), pay.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(nbytes - cut), ctypes.c_size_t(n),
+                                          out.ctypes.data_as(ctypes.c_void_p))
+            if cut == 0:
+                assert ok == 1 and np.array_equal(out, sym), kind
+            elif cut > 1:
+                assert ok == 0, (kind, cut)            # (one byte less may still hold every code: the last byte is padded)
+        # a short array takes the walk alone: same symbols
+        out = np.full(100, -1, dtype=np.int32)
+        assert L.szhost_huff_decode_i32(ctypes.c_void_p(h2), pay.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(nbytes), ctypes.c_size_t(100), out.ctypes.data_as(ctypes.c_void_p)) == 1
+        assert np.array_equal(out, sym[:100])
+        L.szhost_huff_free(ctypes.c_void_p(h)); L.szhost_huff_free(ctypes.c_void_p(h2))

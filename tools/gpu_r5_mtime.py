@@ -19,3 +19,17 @@ for field in (sys.argv[2] if len(sys.argv) > 2 else "m,s").split(","):
         if it >= 3:
             print(json.dumps({"field": field, "it": it, "total_ms": round(st.ms_total, 3), "prequant": round(st.ms_prequant, 3), "quant": round(st.ms_quant, 3), "entropy": round(st.ms_entropy, 3), "host": round(st.ms_host, 3), "kernel": int(st.quant_kernel), "size": n}), flush=True)
     ctx.close()
+    # the way back: the stream stays on the device (a copy: the context's output buffer is reused), the result goes to a device array
+    if os.environ.get("R5_DEC", "1") != "0":
+        import ctypes
+        ctx = api.HipContext(0)
+        ptr, n, st = ctx.compress(d.data_ptr(), True, (edge, edge, edge), np.float32, 1e-4, meta, out_on_device=True)
+        stream = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+        out = torch.empty_like(d)
+        torch.cuda.synchronize()
+        ctypes.CDLL("libamdhip64.so").hipMemcpy(ctypes.c_void_p(stream.data_ptr()), ctypes.c_void_p(ptr), ctypes.c_size_t(n), 3)
+        for it in range(5):
+            st = ctx.decompress(stream.data_ptr(), True, n, 4 + 28 + 8, (edge, edge, edge), np.float32, out.data_ptr(), True)
+            if it >= 3:
+                print(json.dumps({"field": field, "dec_it": it, "total_ms": round(st.ms_total, 3), "entropy": round(st.ms_entropy, 3), "quant": round(st.ms_quant, 3), "host": round(st.ms_host, 3), "kernel": int(st.quant_kernel), "max_err": float((out - d).abs().max())}), flush=True)
+        ctx.close()
