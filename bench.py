@@ -286,6 +286,8 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
             copies.append(src.clone())
         return copies[:k]
 
+    step_done_s = []          # when each call of the last run_steps came back (seconds after its start): a stall inside a timed region shows here
+
     def run_steps(k_lanes, nsteps, gather_too, src=None):
         """nsteps compressions with k_lanes in flight; returns (elapsed, per-call stats, (size, buffer) of the last call)."""
         meta = sz_amd.make_meta(np.float32, err_mode=sz_amd.ABS, abs_bound=EB, vmin=0.0, vmax=0.0)
@@ -305,12 +307,14 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
         sync_all()
         t_begin = time.perf_counter()
         live, stats_all, last = [], [], None
+        del step_done_s[:]
         for i in range(nsteps + k_lanes):
             if i >= k_lanes or i >= nsteps:                 # collect the oldest call (also drains the tail)
                 if live:
                     tk, ob_ = live.pop(0)
                     sz_, st_ = pool.wait(tk)
                     stats_all.append(st_); last = (sz_, ob_)
+                    step_done_s.append(time.perf_counter() - t_begin)
                     if gather_too and world > 1:
                         tg = time.perf_counter()
                         pending.append(gather.begin(ob_, sz_))
@@ -335,6 +339,7 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
     run_steps(inflight, max(args.warmup, inflight), True)
     gather_host_s[0] = 0.0
     elapsed, stats_all, (size, ob) = run_steps(inflight, args.steps, True)
+    step_ms = [round((b - a) * 1e3, 3) for a, b in zip([0.0] + step_done_s[:-1], step_done_s)]
     gather_ms_per_step = gather_host_s[0] / args.steps * 1e3
     quant_ms = [st.ms_quant for st in stats_all]
     stats = stats_all[-1]
@@ -660,7 +665,7 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
             "ratio": round(nbytes_in / size, 6), "out_bytes": size, "max_abs_err": max_abs_err, "psnr": round(psnr, 6),
             "intervals": stats.intervals, "reg_blocks": stats.n_reg_blocks, "unpredictable": stats.n_unpred,
             "decompress_GBps": round(nbytes_in / td / 1e9, 3),
-            "single_call_GBps": single_call["GB/s"], "single_call": single_call,
+            "value_single_call": single_call["GB/s"], "single_call_GBps": single_call["GB/s"], "single_call": single_call, "step_ms": step_ms,
             "phase_ms": {"prequant": round(stats.ms_prequant, 3), "quant": round(stats.ms_quant, 3),
                          "entropy": round(stats.ms_entropy, 3), "host_glue": round(stats.ms_host, 3), "compress_call_total": round(stats.ms_total, 3),
                          "decompress_quant": round(dst.ms_quant, 3), "decompress_total": round(dst.ms_total, 3)},
