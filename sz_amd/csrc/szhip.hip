@@ -3,6 +3,7 @@
 // gfx950 only; no CPU fallback: every entry point returns an error if the HIP runtime/device is missing.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>

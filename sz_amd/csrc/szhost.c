@@ -273,41 +273,49 @@ size_t szhost_huff_encode_i32(const szhost_huff *h, const int *s, size_t n, unsi
 }
 
 /* The walk down the tree, bit by bit, of the reference's decode (Huffman decode of the coefficient codes, szd_float.c:5790-5800 ->
- * decode(), Huffman.c:314-360).  Round 5: the first 11 bits of a code are looked up in a table built by that same walk (node reached and bits
- * taken), so a common code costs one load instead of ~8 dependent ones; longer codes continue bit by bit from the table's node, and the last
- * eight bytes of the payload are decoded bit by bit throughout (the window load reads eight bytes).  Same symbols, same failure as the walk. */
+ * decode(), Huffman.c:314-360).  Round 5: the first 12 bits of a code are looked up in a table built by that same walk -- for a code of up to 12 bits
+ * the entry holds the SYMBOL and the length, so a common code costs one load off a 64-bit window that is refilled every few symbols; for a longer code it
+ * holds the node reached, and the walk goes on bit by bit from there.  The last eight bytes of the payload are decoded bit by bit throughout (the
+ * window load reads eight bytes).  Same symbols, same failure as the walk. */
 int szhost_huff_decode_i32(const szhost_huff *h, const unsigned char *in, size_t in_bytes, size_t n, int *out)
 {
     if (h->t[0]) { for (size_t i = 0; i < n; i++) out[i] = (int)h->C[0]; return 1; }
-    enum { K = 11 };
+    enum { K = 12 };
     const size_t max_bits = in_bytes * 8;
     size_t bit = 0, cnt = 0; uint32_t nd = 0;
     if (n >= 4096) {
+        /* entry: leaf within K bits: 0x80000000 | symbol << 4 | length (symbols are below 2^27: state_num is at most 131072 here and 65536 * 2 elsewhere);
+         * otherwise node << 4 | K */
         uint32_t *tab = (uint32_t *)malloc(sizeof(uint32_t) << K);
-        if (tab) {
+        if (tab && h->state_num <= (1 << 27)) {
             for (uint32_t p = 0; p < (1u << K); p++) {
                 uint32_t x = 0; int len = 0;
                 while (len < K) { x = ((p >> (K - 1 - len)) & 1) ? h->R[x] : h->L[x]; len++; if (h->t[x]) break; }
-                tab[p] = (x << 4) | (uint32_t)len;
+                tab[p] = h->t[x] ? (0x80000000u | (h->C[x] << 4) | (uint32_t)len) : ((x << 4) | (uint32_t)len);
             }
             while (cnt < n && (bit >> 3) + 8 <= in_bytes) {
                 uint64_t w; memcpy(&w, in + (bit >> 3), 8);
                 w = __builtin_bswap64(w) << (bit & 7);
-                const uint32_t e = tab[w >> (64 - K)];
-                uint32_t x = e >> 4;
-                bit += e & 15u;
-                if (!h->t[x]) {                      /* a code longer than K bits: the rest of the walk */
+                int avail = 64 - (int)(bit & 7);                 /* valid bits at the top of w */
+                while (avail >= K && cnt < n) {
+                    const uint32_t e = tab[w >> (64 - K)];
+                    const int len = (int)(e & 15u);
+                    if (e & 0x80000000u) { out[cnt++] = (int)((e >> 4) & 0x7ffffffu); w <<= len; bit += (size_t)len; avail -= len; continue; }
+                    /* a code longer than K bits: the rest of the walk, from memory */
+                    uint32_t x = e >> 4;
+                    bit += (size_t)len;
                     for (;;) {
                         if (bit >= max_bits) { free(tab); return 0; }
                         const int b = (in[bit >> 3] >> (7 - (bit & 7))) & 1; bit++;
                         x = b ? h->R[x] : h->L[x];
                         if (h->t[x]) break;
                     }
+                    out[cnt++] = (int)h->C[x];
+                    avail = 0;                                   /* refill the window at the new position */
                 }
-                out[cnt++] = (int)h->C[x];
             }
-            free(tab);
         }
+        free(tab);
     }
     while (cnt < n) {
         if (bit >= max_bits) return 0;               /* the payload ends before n symbols: corrupt stream */

@@ -2,7 +2,7 @@
 # round 5, final build: the GPU suite, the default bench line and the C4 line, the round's profile of the timed region (kernel stats + PMC passes), the same for one
 # M-field call, and one call's time line both ways for the S and the M field
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -q 2>/dev/null | grep -E "passed|failed|assert|^FAILED|^ERROR" | tail -8 > gpurun_out/r5_final_gpu_tests.txt
+timeout 1500 python -m pytest tests -m gpu -q 2>/dev/null | grep -E "passed in|failed in| passed,| failed,|^FAILED|^ERROR" | tail -8 > gpurun_out/r5_final_gpu_tests.txt
 python bench.py 2> /dev/null | grep '^{"metric"' | tail -1 > gpurun_out/r5_final_bench_default.json
 python bench.py --config c4 2> /dev/null | grep '^{"metric"' | tail -1 > gpurun_out/r5_final_bench_c4.json
 bash tools/gpu_profile_round.sh r5f > gpurun_out/r5_final_profile_round.txt 2>&1
