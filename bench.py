@@ -463,6 +463,23 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
                   "phase_ms": {"prequant": round(mst.ms_prequant, 3), "quant_incl_waits_for_the_host_chains": round(mst.ms_quant, 3),
                                "entropy": round(mst.ms_entropy, 3), "host_glue": round(mst.ms_host, 3)}}
         if not getattr(args, "dry_run", False):
+            # the sweep of this array on its own: the same call in the unfed order (chains first, then k_reg_points and the sweep back to back), whose
+            # `quant` phase is the two kernels and nothing else; PMC traffic of that order from profiles/r05_pmc_traffic_beam.json
+            os.environ["SZ_HIP_BEAM_FEED"] = "0"
+            try:
+                one_step(xm)
+                _, ust, _ = one_step(xm)
+            finally:
+                os.environ.pop("SZ_HIP_BEAM_FEED", None)
+            try:
+                btr = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_traffic_beam.json")))["traffic_bytes_per_launch"]
+            except (OSError, KeyError, ValueError):
+                btr = None
+            mfield["roofline"] = {"bound": "hbm", "kernel": "k_reg_points<float,0> + k_beam<float,false,false,true>", "unfed_call_quant_ms": round(ust.ms_quant, 4),
+                                  "achieved": round(nbytes_in / (ust.ms_quant * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(nbytes_in / (ust.ms_quant * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": btr,
+                                  "traffic_source": "profiles/r05_pmc_traffic_beam.json (k_beam alone: FETCH_SIZE x2 + WRITE_SIZE; the x2 of the guide overstates the 4- and 8-byte-per-lane reads)",
+                                  "unfed_call_ms": round(ust.ms_total, 3)}
             # two M-field arrays in flight (szhip_pool): one array's host coefficient chain beside the other's kernels
             ref_m = mob[:msize].clone()
             for km in (2,):           # (three lanes: six streams share the process's hardware queues and the coefficient DMA of one lane can queue behind another lane's waiting kernel)
