@@ -99,7 +99,7 @@ struct szhip_ctx {
     int cus = 256;                               // compute units of `device` (hipDeviceAttributeMultiprocessorCount): persistent kernels launch one workgroup per CU at most
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // the fit + selection pass runs here, concurrently with the interval optimiser's sampling and host decisions
-    hipEvent_t ev_in = nullptr, ev_fit = nullptr, ev_feed = nullptr;
+    hipEvent_t ev_in = nullptr, ev_fit = nullptr, ev_feed = nullptr, ev_sec = nullptr;
     int settle_probes = 0, settle_rejected = 0;   // settle_streams: queue probes made, streams replaced
     int side_prio = 0;               // 1: stream2 at the lowest, stream3 at the highest stream priority (create_ctx)
     hipStream_t stream3 = nullptr;   // the block-ordering pass of finished tile rows, while the sweep is still running on `stream` (created on first use)
@@ -137,7 +137,7 @@ struct szhip_ctx {
     // several arrays in flight) is answered by ONE repetition with the chain finished before the sweep starts; the context keeps that order
     bool coef_late = false, no_chain_overlap = false;
     std::vector<int> chain_codes; std::vector<unsigned char> chain_unpred;   // the chains' outputs, kept across calls (fresh memory page-faults under the chain: ~1 ms for the M-field's 10 MB)
-    std::vector<unsigned char> section_buf[4];   // the coefficient sections of the stream header as the chain threads build them
+    unsigned char *sec_pin[4] = {nullptr, nullptr, nullptr, nullptr}; size_t sec_pin_cap[4] = {0, 0, 0, 0};   // the coefficient sections of the stream header as the chain threads build them: pinned, they go to the device from where they are
     szhip_chain_pool *chain_pool = nullptr;      // the coefficient chains' persistent threads (created with the first array that has regression blocks)
 };
 
@@ -243,7 +243,8 @@ static int create_ctx(szhip_ctx **out, int device, int side_prio, int main_high 
     if (sprio && hipDeviceGetStreamPriorityRange(&plo, &phi) != hipSuccess) { plo = 0; phi = 0; }
     if ((sprio ? hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, sprio == 2 ? phi : plo) : hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking)) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fit, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_feed, hipEventDisableTiming) != hipSuccess) { delete ctx; return SZHIP_ERR_NODEVICE; }
+        hipEventCreateWithFlags(&ctx->ev_feed, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_sec, hipEventDisableTiming) != hipSuccess) { delete ctx; return SZHIP_ERR_NODEVICE; }
     *out = ctx;
     return SZHIP_OK;
 }
@@ -278,6 +279,8 @@ void szhip_destroy(szhip_ctx *ctx)
     if (ctx->ev_in) hipEventDestroy(ctx->ev_in);
     if (ctx->ev_fit) hipEventDestroy(ctx->ev_fit);
     if (ctx->ev_feed) hipEventDestroy(ctx->ev_feed);
+    if (ctx->ev_sec) hipEventDestroy(ctx->ev_sec);
+    for (int e = 0; e < 4; ++e) if (ctx->sec_pin[e]) hipHostFree(ctx->sec_pin[e]);
     if (ctx->stream2) hipStreamDestroy(ctx->stream2);
     if (ctx->stream3) hipStreamDestroy(ctx->stream3);
     if (ctx->ev_perm) hipEventDestroy(ctx->ev_perm);
