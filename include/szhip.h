@@ -103,7 +103,9 @@ int szhip_minmax(szhip_ctx *ctx, int dtype, const void *data, int data_on_device
  * `meta`/`meta_len`: the 3 version bytes + flag byte + parameter bytes the stream starts with.
  * Output: out_on_device = 0: *out is malloc'd host memory owned by the caller (free());
  *         out_on_device = 1: *out is a device pointer owned by ctx (valid until the next call);
- *         out_on_device = 2: *out is the CALLER's device buffer of capacity *out_size; the stream is copied into it.
+ *         out_on_device = 2: *out is the CALLER's device buffer of capacity *out_size; the stream is written there -- in place when the buffer is
+ *                            16-byte aligned and holds the stream plus 64 bytes of slack (bytes behind the stream, up to the capacity, may be
+ *                            zeroed), else through the context's buffer and a copy.
  */
 int szhip_compress(szhip_ctx *ctx, int dtype, const void *data, int data_on_device,
                    size_t r0, size_t r1, size_t r2, double eb, const szhip_params *params,
