@@ -54,6 +54,10 @@ typedef struct sz_slab_multi_info {
 unsigned char *sz_slab_compress_multi(int dataType, void *data, size_t *outSize, int errBoundMode, double absErrBound, double relBoundRatio,
                                       double pwrBoundRatio, size_t r3, size_t r2, size_t r1, int ndev, const int *devices, sz_slab_multi_info *info);
 
+/* sz_slab_compress_multi keeps its communicator, its per-device contexts and exchange buffers for the next call with the same device list (a communicator
+ * costs hundreds of milliseconds to make, a context its workspaces); this gives them back.  SZ_Finalize calls it.  SZ_SLAB_MULTI_CACHE=0: nothing is kept. */
+void sz_slab_multi_release(void);
+
 /* decompress every slab of a container into one malloc'd array of dims[0] x dims[1] x dims[2] values (caller frees); NULL on error */
 void *sz_slab_decompress(const unsigned char *blob, size_t len, int *dataType, size_t dims[3]);
 

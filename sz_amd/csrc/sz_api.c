@@ -146,12 +146,14 @@ int SZ_Init_Params(sz_params *params)
     return SZ_SCES;
 }
 
+void sz_slab_multi_release(void);
 void SZ_Finalize(void)
 {
     if (confparams_dec) { free(confparams_dec); confparams_dec = NULL; }
     if (confparams_cpr) { free(confparams_cpr); confparams_cpr = NULL; }
     if (exe_params) { free(exe_params); exe_params = NULL; }
     if (g_ctx) { szhip_destroy(g_ctx); g_ctx = NULL; }
+    sz_slab_multi_release();               /* (what sz_slab_compress_multi kept per device: sz_slab_multi.cpp) */
 }
 
 /* ---- dimensions ---- */

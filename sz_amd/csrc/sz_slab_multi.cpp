@@ -84,23 +84,48 @@ struct job_t {
     const sz_params *cpr0; const sz_exedata *exe0; bool verify_gather;
 };
 
-void worker(shared_t *S, const job_t *J, int r)
+// What a call needs per device and what is expensive to make -- the communicator (ncclCommInitAll: hundreds of milliseconds), the contexts (streams probed
+// for shared hardware queues, gigabytes of workspaces on first use), the exchange buffers -- is kept from call to call for the same device list (round 5).
+// sz_slab_multi_release (also called by SZ_Finalize) gives it back; SZ_SLAB_MULTI_CACHE=0: everything per call, as before.
+struct multi_cache_t {
+    std::mutex mu;                                 // one multi-device call at a time
+    std::vector<int> devs;
+    rccl_api api; bool rccl = false; std::vector<ncclComm_t> comms;
+    std::vector<szhip_ctx *> ctx; std::vector<hipStream_t> st; std::vector<double *> d_rng; std::vector<unsigned long long *> d_sizes;
+    void release()
+    {
+        for (size_t r = 0; r < devs.size(); ++r) {
+            if (hipSetDevice(devs[r]) != hipSuccess) continue;
+            if (r < d_rng.size() && d_rng[r]) (void)hipFree(d_rng[r]);
+            if (r < d_sizes.size() && d_sizes[r]) (void)hipFree(d_sizes[r]);
+            if (r < st.size() && st[r]) (void)hipStreamDestroy(st[r]);
+            if (r < ctx.size() && ctx[r]) szhip_destroy(ctx[r]);
+        }
+        if (rccl) for (ncclComm_t c : comms) if (c) api.CommDestroy(c);
+        devs.clear(); comms.clear(); ctx.clear(); st.clear(); d_rng.clear(); d_sizes.clear(); rccl = false;
+    }
+};
+multi_cache_t g_cache;
+
+void worker(shared_t *S, const job_t *J, int r, multi_cache_t *C)
 {
     const size_t esz = J->dataType == SZ_FLOAT ? 4 : 8, plane = J->r2 * J->r1;
     const size_t z0 = J->bounds[2 * r], h = J->bounds[2 * r + 1] - z0, count = h * plane;
     const unsigned char *slab = J->data + z0 * plane * esz;
     S->rc[r] = SZ_NSCS;
-    szhip_ctx *ctx = nullptr;
-    hipStream_t st = nullptr;
-    bool alive = hipSetDevice(J->devices[r]) == hipSuccess && szhip_create(&ctx, J->devices[r]) == SZHIP_OK && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+    szhip_ctx *ctx = C ? C->ctx[r] : nullptr;
+    hipStream_t st = C ? C->st[r] : nullptr;
+    bool alive = hipSetDevice(J->devices[r]) == hipSuccess && (ctx || szhip_create(&ctx, J->devices[r]) == SZHIP_OK) && (st || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess);
+    if (C) { C->ctx[r] = ctx; C->st[r] = st; }                       // (kept for the next call, whatever becomes of this one)
     sz_params cpr = *J->cpr0; sz_exedata exe = *J->exe0;
     sz_slab_thread_bind(ctx, &cpr, &exe);
     // ---- the exchange buffers of this rank, BEFORE any collective: a rank that entered a collective the others skip -- or the other way round -- hangs
     // the whole call, so all ranks decide together (host barrier) whether the device transport is used; if any rank could not allocate, all take the
     // host transport.  Every RCCL / HIP return of the exchange is checked; an error fails the call (S->coll_failed), it never leaves a garbage range.
-    double *d_rng = nullptr; unsigned long long *d_sizes = nullptr;
+    double *d_rng = C ? C->d_rng[r] : nullptr; unsigned long long *d_sizes = C ? C->d_sizes[r] : nullptr;
     if (S->rccl) {
-        const bool got = alive && hipMalloc((void **)&d_rng, 4 * sizeof(double)) == hipSuccess && hipMalloc((void **)&d_sizes, ((size_t)S->ndev + 1) * 8) == hipSuccess;
+        const bool got = alive && (d_rng || hipMalloc((void **)&d_rng, 4 * sizeof(double)) == hipSuccess) && (d_sizes || hipMalloc((void **)&d_sizes, ((size_t)S->ndev + 1) * 8) == hipSuccess);
+        if (C) { C->d_rng[r] = d_rng; C->d_sizes[r] = d_sizes; }
         S->xbuf_ok[r] = got ? 1 : 0;
         S->bar.wait();
     }
@@ -201,11 +226,13 @@ void worker(shared_t *S, const job_t *J, int r)
         }
         if (d_all) (void)hipFree(d_all);
     }
-    if (d_rng) (void)hipFree(d_rng);
-    if (d_sizes) (void)hipFree(d_sizes);
     sz_slab_thread_bind(nullptr, nullptr, nullptr);
-    if (st) hipStreamDestroy(st);
-    if (ctx) szhip_destroy(ctx);
+    if (!C) {
+        if (d_rng) (void)hipFree(d_rng);
+        if (d_sizes) (void)hipFree(d_sizes);
+        if (st) hipStreamDestroy(st);
+        if (ctx) szhip_destroy(ctx);
+    }
 }
 
 } // namespace
@@ -226,24 +253,40 @@ extern "C" unsigned char *sz_slab_compress_multi(int dataType, void *data, size_
     for (int r = 0; r < ndev; ++r) { devs[r] = devices ? devices[r] : r; for (int q = 0; q < r; ++q) if (devs[q] == devs[r]) distinct = false; }
     std::vector<size_t> bounds(2 * (size_t)ndev);
     sz_slab_bounds(r3, ndev, 6, bounds.data());
+    const char *nocache = getenv("SZ_SLAB_MULTI_CACHE");
+    multi_cache_t *const C = (nocache && atoi(nocache) == 0) ? nullptr : &g_cache;
+    std::unique_lock<std::mutex> cache_lock;
+    if (C) {
+        cache_lock = std::unique_lock<std::mutex>(C->mu);
+        if (C->devs != devs) {                     // another device list: what was kept is given back
+            C->release();
+            C->devs = devs;
+            C->ctx.assign(ndev, nullptr); C->st.assign(ndev, nullptr); C->d_rng.assign(ndev, nullptr); C->d_sizes.assign(ndev, nullptr);
+        }
+    }
     shared_t S;
     S.ndev = ndev; S.bar.n = ndev;
     S.lo.assign(ndev, 0); S.hi.assign(ndev, 0); S.xbuf_ok.assign(ndev, 0); S.streams.assign(ndev, nullptr); S.bytes.assign(ndev, 0); S.rc.assign(ndev, SZ_NSCS); S.t_compress.assign(ndev, 0);
     const char *no = getenv("SZ_SLAB_NO_RCCL");
     if (distinct && !(no && atoi(no)) && S.api.load()) {
-        S.comms.assign(ndev, nullptr);
-        S.rccl = S.api.CommInitAll(S.comms.data(), ndev, devs.data()) == 0;
-        if (!S.rccl) S.comms.clear();
+        if (C && C->rccl) { S.comms = C->comms; S.rccl = true; }      // the communicator of the last call with these devices
+        else {
+            S.comms.assign(ndev, nullptr);
+            S.rccl = S.api.CommInitAll(S.comms.data(), ndev, devs.data()) == 0;
+            if (!S.rccl) S.comms.clear();
+            else if (C) { C->api = S.api; C->comms = S.comms; C->rccl = true; }
+        }
     }
     const char *vg = getenv("SZ_SLAB_VERIFY_GATHER");
     const sz_params cpr0 = *confparams_cpr; const sz_exedata exe0 = *exe_params;
     job_t J = {dataType, errBoundMode, absErrBound, relBoundRatio, pwrBoundRatio, (const unsigned char *)data, r2, r1, bounds.data(), devs.data(), &cpr0, &exe0, vg && atoi(vg)};
     const double t0 = now_s();
     std::vector<std::thread> th;
-    for (int r = 0; r < ndev; ++r) th.emplace_back(worker, &S, &J, r);
+    for (int r = 0; r < ndev; ++r) th.emplace_back(worker, &S, &J, r, C);
     for (auto &t : th) t.join();
     const double t1 = now_s();
-    if (S.rccl) for (ncclComm_t c : S.comms) if (c) S.api.CommDestroy(c);
+    if (S.rccl && !(C && C->rccl)) for (ncclComm_t c : S.comms) if (c) S.api.CommDestroy(c);
+    if (C && S.coll_failed) C->release();          // (a communicator that failed a collective is not used again)
     unsigned char *out = nullptr;
     bool ok = S.gather_ok != 0 && S.coll_failed == 0;
     for (int r = 0; r < ndev; ++r) if (S.rc[r] != SZ_SCES) ok = false;
@@ -258,4 +301,10 @@ extern "C" unsigned char *sz_slab_compress_multi(int dataType, void *data, size_
         info->seconds_slowest_slab = m;
     }
     return out;
+}
+
+extern "C" void sz_slab_multi_release(void)
+{
+    std::lock_guard<std::mutex> lk(g_cache.mu);
+    g_cache.release();
 }

@@ -200,6 +200,17 @@ def test_c_slab_container_equals_the_python_one_and_round_trips(oracle):
             got2 = ctypes.string_at(p2, n2.value)
             libc.free(p2)
             assert got2 == want
+            # round 5: the call keeps its per-device contexts (and, with RCCL, its communicator) for the next call with the same device list; the second
+            # call runs on what the first one left, a call with the cache switched off builds everything anew: the same bytes all three times
+            for cache in ("1", "0"):
+                os.environ["SZ_SLAB_MULTI_CACHE"] = cache
+                try:
+                    n3 = szt(0)
+                    p3 = L.sz_slab_compress_multi(0 if dt == np.float32 else 1, whole.ctypes.data, ctypes.byref(n3), mode, absb, rel, 0.0, *whole.shape, world, devs, ctypes.byref(info))
+                    assert p3 and ctypes.string_at(p3, n3.value) == want, cache
+                    libc.free(p3)
+                finally:
+                    os.environ.pop("SZ_SLAB_MULTI_CACHE", None)
         sz_amd.SZ_Finalize()
     finally:
         api._lib = saved
