@@ -41,9 +41,15 @@ def test_library_exports_every_declared_symbol(L):
     # include/sz_slab.h: the slab container of the multi-GPU path for C callers
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "sz_slab.h")).read(), flags=re.S)
     sl = set(re.findall(r"\b(sz_slab_[A-Za-z0-9_]+)\s*\(", text))
-    assert len(sl) == 6
+    assert len(sl) == 7
     for n in sorted(sl):
         assert hasattr(L, n), f"{n} is declared in sz_slab.h but not exported"
+    # include/sz_omp.h (round 5): the reference's OpenMP entry points (sz/include/sz_omp.h:24-47) and the thread helpers of an OpenMP build
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "sz_omp.h")).read(), flags=re.S)
+    om = set(re.findall(r"\b(SZ_compress_[a-z]+_[123]D_MDQ_openmp|decompressDataSeries_[a-z]+_[123]D_openmp|sz_[a-z_]*thread[a-z_]*|SZ_hip_set_omp_threads)\s*\(", text))
+    assert len(om) >= 14, om
+    for n in sorted(om):
+        assert hasattr(L, n), f"{n} is declared in sz_omp.h but not exported"
 
 
 def test_hdf5_plugin_exports_every_declared_symbol(built):
