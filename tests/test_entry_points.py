@@ -220,3 +220,32 @@ def test_first_64k_of_a_wrapped_stream_is_decoded_into_a_fixed_buffer(built, ora
         out = ctypes.c_void_p()
         assert L.sz_lossless_decompress65536bytes(1, crafted, len(crafted), ctypes.byref(out)) == 65536 and out.value
         libc.free(out)
+
+
+@pytest.mark.parametrize("defer_min", ["1", "1000000000"])
+def test_coefficient_sections_decoded_beside_the_device_on_the_cpu_shim(built, oracle, monkeypatch, defer_min):
+    """round 5: in a decompression the regression coefficients' sections are only LOCATED while the header is read; their Huffman decode and chains run on their
+    own threads beside the device's decode of the type array and are joined where the coefficients are shipped (dec_header::finish).  Deferred (threshold 1) and
+    not (threshold never reached): the reference decoder's bits; a damaged stream comes back as an error or as some array, never as a crash."""
+    import sim_lib
+    import sz_amd
+    from sz_amd import api
+    from sz_amd.fields import m_field
+    monkeypatch.setenv("SZ_HIP_DEC_DEFER_MIN", defer_min)
+    saved = api._lib
+    api._lib = api._bind(ctypes.CDLL(sim_lib.shim_path()))
+    try:
+        assert sz_amd.SZ_Init(os.path.join(ROOT, "tests", "golden", "sz_speed.config")) == 0
+        for d, eb in ((m_field(36), 1e-4), (m_field(30, np.float64), 1e-3)):
+            ref, _ = oracle.compress(d, oracle.ABS, eb)
+            want = oracle.decompress(ref, d.shape, d.dtype)
+            dec = sz_amd.SZ_decompress(ref, d.shape, d.dtype)
+            assert np.array_equal(dec.view(np.uint8), want.view(np.uint8))
+            bad = bytearray(ref); bad[len(bad) // 3] ^= 0x55; bad[len(bad) // 3 + 7] ^= 0xff
+            try:
+                sz_amd.SZ_decompress(bytes(bad), d.shape, d.dtype)
+            except Exception:
+                pass
+        sz_amd.SZ_Finalize()
+    finally:
+        api._lib = saved
