@@ -241,7 +241,8 @@ struct beam {
         timed_out = true; spin_limit = 0;
         return true;
     }
-    // The regression points of the first `planes` planes (reconstructions, flags, codes: k_reg_points) are in memory.  They are made slice after slice
+    // The inputs of the first `planes` planes are in memory: compress, arrays with regression blocks -- the regression points (reconstructions, flags, codes:
+    // k_reg_points); decompress (round 5) -- the codes in natural order and the pre-scattered unpredictable values (k_permute<1>, k_unpred).  They are made slice after slice
     // of block rows on another stream while this sweep runs, as the host's coefficient chains get there (szhip_sz21.inc, "feed"); after each slice a
     // one-thread kernel stores the number of finished planes into a.reg_ready.  Read past this XCD's L2 (system scope); the slices' own stores reached
     // memory when their kernel ended, and this launch has not touched a line of those planes before (planes are whole cache lines: checked on the host).
@@ -624,7 +625,7 @@ struct beam {
         for (int e = lane; e < S::KRB / 4; e += 64) lds_put<unsigned>(kring, (unsigned)e * 4u, 0u);
         // (arrays with regression blocks whose points arrive WHILE the sweep runs -- a.reg_ready, see wait_fed: nothing of a plane is asked for before it is there)
         fed = 0; feed_late = false;
-        if (HASREG && a.reg_ready) wait_fed(UL + 2);
+        if (a.reg_ready) wait_fed(UL + 2);
         // ---- prologue: the first lines' rows are requested; line 0 goes into the ring
         {
             v4u first[EV], firstx[EV]; unsigned firstf[EV];
@@ -671,7 +672,7 @@ struct beam {
 #pragma unroll 1
         for (int b = 0; b < nblk; ++b) {
             const int it0 = b * UL;
-            if (HASREG && a.reg_ready) wait_fed(it0 + 2 * UL + 1);          // (the block's lines ask for rows up to wave line it0 + 2 UL)
+            if (a.reg_ready) wait_fed(it0 + 2 * UL + 1);          // (the block's lines ask for rows up to wave line it0 + 2 UL)
 #ifdef SZH_BM_ISA_MID_ONLY          /* (ISA inspection of the steady-state block only: wrong results) */
             block<false>(it0);
 #else

@@ -77,7 +77,7 @@ template <class T> struct szh_qargs {
     const T *xr;              // k_beam, compress, arrays with regression blocks: the RECONSTRUCTIONS of their points (k_reg_points), natural layout
     int pub_lines;            // k_beam with tile_done: lines between two progress words of a wavefront (a multiple of 8; 0: 32)
     const uint8_t *ptflags;   // k_beam, arrays with regression blocks: per point, 1 = the point lies in a regression block (k_reg_points; zeros elsewhere)
-    const unsigned *reg_ready; // k_beam, the same arrays, when k_reg_points runs in slices beside the sweep: planes whose regression points are in memory (nullptr: all, before the launch)
+    const unsigned *reg_ready; // k_beam, when its inputs are made in slices beside the sweep (compress: k_reg_points; decompress: k_permute<1> + k_unpred): planes whose inputs are in memory (nullptr: all, before the launch)
     int dbg;                  // development: 1 = no hand-off at all (timing only, results become WRONG), 4 = no issue priorities
     szh_u64 *trace;           // optional (development): per pencil {t_start, t_start, t_first_trip, t_end, wait spins, -, xcc, 0} + per-trip detail
 };

@@ -978,12 +978,14 @@ template <class T, int DIR>
 __global__ __launch_bounds__(256) void k_unpred(szh_geom3 G, const uint16_t *__restrict__ codes_blk, const unsigned *__restrict__ col_zeros,
                                                 const u64 *__restrict__ col_off, const T *data, T *unpred, T *out,
                                                 const unsigned *__restrict__ zcnt, const unsigned *__restrict__ zpos, int segb, int nseg,
-                                                szh_rb_layout rb = szh_rb_layout{0, 0, 0, 0, 0, 0})
+                                                szh_rb_layout rb = szh_rb_layout{0, 0, 0, 0, 0, 0}, int col0 = 0, u64 ucap = ~0ull)
 {   // rb.on (DIR 1 only): `out` is a value array in the ribbon order of szh_ribbon.h (szh_rb_value_index)
+    // col0: the launch covers block columns col0 .. col0 + gridDim.x - 1 (a slice along dim 0); ucap (DIR 1): entries of `unpred` -- a launch that runs before
+    // the host has compared the columns' zero counts with the stream's list (slices beside the inverse sweep) must not read behind the list
     __shared__ u64 sh[8];
     __shared__ u64 keys[SZH_ZMAX];
     __shared__ int use_list;
-    const int col = blockIdx.x;
+    const int col = (int)blockIdx.x + col0;
     const unsigned K = col_zeros[col];
     if (K == 0) return;
     const int b0 = col / G.g1.num, b1 = col - b0 * G.g1.num;
@@ -1025,7 +1027,7 @@ __global__ __launch_bounds__(256) void k_unpred(szh_geom3 G, const uint16_t *__r
             unsigned rank = 0;
             for (unsigned o = 0; o < K; ++o) rank += keys[o] < key ? 1u : 0u;
             const int64_t nat = natural((int64_t)key);
-            if (DIR == 0) unpred[run + rank] = data[nat]; else out[nat] = unpred[run + rank];
+            if (DIR == 0) unpred[run + rank] = data[nat]; else if (run + rank < ucap) out[nat] = unpred[run + rank];
         }
         return;
     }
@@ -1049,7 +1051,7 @@ __global__ __launch_bounds__(256) void k_unpred(szh_geom3 G, const uint16_t *__r
             zmask &= ~(1u << q);
             const int64_t nat = natural(e0 + q);
             if (DIR == 0) unpred[run + rank] = data[nat];
-            else out[nat] = unpred[run + rank];
+            else if (run + rank < ucap) out[nat] = unpred[run + rank];
             ++rank;
         }
         run += tot;
