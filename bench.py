@@ -10,14 +10,15 @@ predict/quantise, Huffman encode into the reference's SZ 2.1 stream -- over one 
 "S-field", ABS 1e-4) that is already resident in HBM; the stream is left in HBM.  With N ranks every rank owns one such slab of
 an (N*512)x512x512 array (weak scaling, no data-path collective) and the step ends with one all-gather of the variable-length
 sub-streams (RCCL), launched asynchronously so that it overlaps the next step's compression; every gather is completed inside
-the timed region.  Rank 0 prints ONE JSON line.  Extra objects on that line:
+the timed region.  Since round 5 the timed region is ONE BLOCKING CALL AFTER THE OTHER (`--inflight 1`: what a caller of SZ_compress_args sees;
+`value` = `value_single_call`; `step_ms` lists every step); `concurrent` gives 1 / 2 / 4 arrays in flight.  Rank 0 prints ONE JSON line.  Extra objects on that line:
   roofline     -- the predict+quantise wavefront kernel: algorithmic bytes (N*4, the array read once) / its average duration
                   measured with HIP events on the library's stream, against the 8 TB/s HBM3E peak.
-  m_field      -- BASELINE configs[2]: the same step on the 512^3 "M-field" (half of the blocks choose the regression predictor;
-                  this times the regression instantiation of the kernel and the serial host coefficient chain).
+  m_field      -- BASELINE configs[2]: the same step on the 512^3 "M-field" (half of the blocks choose the regression predictor: k_reg_points, the
+                  beam sweep fed while the host's coefficient chains run), its decompression, and the sweep's own roofline from an unfed call.
   e2e          -- SZ_compress_args / SZ_decompress from and to HOST memory (pageable), PCIe included: never the `value`.
-  cpu_baseline -- the oracle (a C restatement of the reference CPU loops, oracle/), pinned to one core, median of 3; and
-                  cpu_baseline_mt: the same code on P slabs in P processes.
+  cpu_baseline -- the unmodified reference (oracle/_ref/libSZ.so; kind "reference") pinned to one core, median of 3, with the oracle (a C restatement,
+                  oracle/) beside it as `port`; cpu_baseline_mt: the reference's own OpenMP variant on 64 threads.
 
 --config c4 (BASELINE.json configs[3]): 1024^3 float64 S-field, REL 1e-3, slab-sharded: rank r owns planes of the outer
 dimension (at N = 8: 128x1024x1024 = 1 GiB; at N = 1 the bench runs ONE such slab, it does not pretend to hold the 8 GiB
