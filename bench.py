@@ -691,6 +691,10 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
             "intervals": stats.intervals, "reg_blocks": stats.n_reg_blocks, "unpredictable": stats.n_unpred,
             "decompress_GBps": round(nbytes_in / td / 1e9, 3),
             "value_single_call": single_call["GB/s"], "single_call_GBps": single_call["GB/s"], "single_call": single_call, "step_ms": step_ms,
+            # (the HIP runtime stalls a call for 3 - 5 ms now and then -- one step in about a hundred, profiles/r05_timed_region_five_runs.txt and the step lists of
+            #  the round's lines --; `value` is the contract's K steps over their total time and carries such a step when it meets one; the median step is beside it)
+            "median_step_ms": round(float(np.median(step_ms)), 4) if step_ms else None,
+            "value_from_median_step": round(world * nbytes_in / (float(np.median(step_ms)) * 1e-3) / 1e9, 3) if step_ms else None,
             "phase_ms": {"prequant": round(stats.ms_prequant, 3), "quant": round(stats.ms_quant, 3),
                          "entropy": round(stats.ms_entropy, 3), "host_glue": round(stats.ms_host, 3), "compress_call_total": round(stats.ms_total, 3),
                          "decompress_quant": round(dst.ms_quant, 3), "decompress_total": round(dst.ms_total, 3)},
