@@ -378,6 +378,18 @@ void szhost_coeffs_free(szhost_coeffs *c)
     for (int e = 0; e < 4; e++) { free(c->codes[e]); free(c->unpred[e]); c->codes[e] = NULL; c->unpred[e] = NULL; }
 }
 
+/* A chain may start before all of its coefficients are in memory (round 5: the arrays arrive from the device in two pieces, szhost_coeff_chain_one_pa): the
+ * calling thread's g_chain_avail points at the number of blocks whose coefficients have arrived; a loop that comes to a block behind that mark waits.  One
+ * compare per step against a local copy, off the chain.  NULL: everything is there. */
+static __thread const size_t *g_chain_avail = NULL;
+#if defined(__SSE2__)
+#define CHAIN_RELAX() __builtin_ia32_pause()
+#else
+#define CHAIN_RELAX() do { } while (0)
+#endif
+#define CHAIN_AVAIL_LOCALS const size_t *const avail_p = g_chain_avail; size_t avail_c = avail_p ? 0 : (size_t)-1;
+#define CHAIN_WAIT_AVAIL(b_) do { if (__builtin_expect((b_) >= avail_c, 0)) { while ((avail_c = __atomic_load_n(avail_p, __ATOMIC_ACQUIRE)) <= (b_)) CHAIN_RELAX(); } } while (0)
+
 /* one coefficient's chain: the four (three) chains of a block sequence are independent of each other, so callers may run them on
  * different threads (szhost_coeff_chain_begin once, then szhost_coeff_chain_one per e) */
 #define CHAIN_ONE(T, FABS, DIVIDE_IN_NOMEAN)                                                              \
@@ -387,8 +399,10 @@ void szhost_coeffs_free(szhost_coeffs *c)
     T *un = (T *)out->unpred[e];                                                                           \
     int *codes = out->codes[e];                                                                            \
     size_t ci = 0, nun = 0;                                                                                \
+    CHAIN_AVAIL_LOCALS                                                                                     \
     for (size_t b = 0; b < nblocks; b++) {                                                                 \
         if (indicator[b]) continue;                                                                        \
+        CHAIN_WAIT_AVAIL(b);                                                                               \
         T cur = cf[b];                                                                                     \
         T diff = cur - last;                                                                               \
         T itv;                                                                                             \
@@ -535,8 +549,10 @@ static size_t NAME(const T *cf, size_t b, size_t nblocks, const unsigned char *i
     V vlast = LOADS(plast);                                                                                                        \
     T prevc = *pprevc;                                                                                                             \
     size_t ci = *pci;                                                                                                              \
+    CHAIN_AVAIL_LOCALS                                                                                                             \
     for (; b < nblocks; b++) {                                                                                                     \
         if (indicator[b]) continue;                                                                                                \
+        CHAIN_WAIT_AVAIL(b);                                                                                                       \
         const T cur = cf[b], Dk = cur - prevc, aD = FABS(Dk);                                                                      \
         if (__builtin_expect(!(aD > lim && aD < nlimit), 0)) {                                                                     \
             const V vcur0 = LOADS(&cf[b]);                                                                                         \
@@ -622,8 +638,10 @@ CHAIN_LEAN_FN(chain_lean_f64, double, __m128d, _mm_load_sd, _mm_cvtsd_f64, _mm_s
     size_t ci = 0, nun = 0;                                                                                            \
     int lean_miss = 0, lean_skip = 0; (void)lean_miss; (void)lean_skip;                                               \
     int ref_steps = 0, odd = 0; size_t next_eval = 1024;   /* data on which the candidates rarely hold (verbatim coefficients all over): the plain loop for a while */ \
+    CHAIN_AVAIL_LOCALS                                                                                                 \
     for (size_t b = 0; b < nblocks; b++) {                                                                             \
         if (indicator[b]) continue;                                                                                    \
+        CHAIN_WAIT_AVAIL(b);                                                                                           \
         CHAIN_LEAN_TRY                                             /* as many lean steps as come in a row; then this one in the general form */ \
         const T cur = cf[b];                                                                                           \
         /* off the chain: the candidates from the original coefficients */                                             \
@@ -681,6 +699,13 @@ void szhost_coeff_chain_one_p(int is_double, void *coef, const unsigned char *in
     if (!tab) { szhost_coeff_chain_one_ref(is_double, coef, indicator, nblocks, use_mean, e, out, progress); return; }
     if (is_double) { CHAIN_FAST(double, uint64_t, fabs, CHAIN_LEAN_F64, ) }
     else { CHAIN_FAST(float, uint32_t, fabsf, CHAIN_LEAN_F32, ) }
+}
+void szhost_coeff_chain_one_pa(int is_double, void *coef, const unsigned char *indicator, size_t nblocks, int use_mean, int e, szhost_coeffs *out,
+                               size_t *progress, const size_t *avail)
+{
+    g_chain_avail = avail;
+    szhost_coeff_chain_one_p(is_double, coef, indicator, nblocks, use_mean, e, out, progress);
+    g_chain_avail = NULL;
 }
 void szhost_coeff_chain_one(int is_double, void *coef, const unsigned char *indicator, size_t nblocks, int use_mean, int e, szhost_coeffs *out)
 {

@@ -70,6 +70,10 @@ void szhost_coeff_chain_one(int is_double, void *coef, const unsigned char *indi
 /* the same, publishing the number of regression blocks finished so far in *progress (release stores, every 1024 blocks and at the end) */
 void szhost_coeff_chain_one_p(int is_double, void *coef, const unsigned char *indicator, size_t nblocks, int use_mean, int e, szhost_coeffs *out,
                               size_t *progress);
+/* the same, started before all coefficients are in memory: *avail = blocks whose coefficients (all of the chain's array) have arrived, raised by the caller
+ * from another thread up to nblocks; the chain waits where it runs into the mark */
+void szhost_coeff_chain_one_pa(int is_double, void *coef, const unsigned char *indicator, size_t nblocks, int use_mean, int e, szhost_coeffs *out,
+                               size_t *progress, const size_t *avail);
 /* the reference's loop, literally (the fall-back and the tests' yardstick of szhost_coeff_chain_one_p, which takes the arithmetic off the chain) */
 void szhost_coeff_chain_one_ref(int is_double, void *coef, const unsigned char *indicator, size_t nblocks, int use_mean, int e, szhost_coeffs *out,
                                 size_t *progress);

@@ -76,6 +76,7 @@ def test_beam_fed_while_it_runs_equals_the_oracle(sz, oracle, name, monkeypatch)
     d, eb = _cases()[name]
     ref, _ = oracle.compress(d, oracle.ABS, eb)
     monkeypatch.setenv("SZ_HIP_FEED_MIN_REG", "1")
+    monkeypatch.setenv("SZ_HIP_CHAIN_EARLY_PIECE", "8")        # (the chains start on the first 8 coefficients of every array while the rest is on its way)
     for fed in ("1", "0", "1", "1"):
         monkeypatch.setenv("SZ_HIP_BEAM_FEED", fed)
         got = sz.SZ_compress_args(d, sz.ABS, eb)

@@ -320,3 +320,44 @@ def test_table_decode_of_coefficient_codes_equals_the_walk(L):
         assert L.szhost_huff_decode_i32(ctypes.c_void_p(h2), pay.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(nbytes), ctypes.c_size_t(100), out.ctypes.data_as(ctypes.c_void_p)) == 1
         assert np.array_equal(out, sym[:100])
         L.szhost_huff_free(ctypes.c_void_p(h)); L.szhost_huff_free(ctypes.c_void_p(h2))
+
+
+def test_chain_started_before_all_coefficients_are_there(L):
+    """round 5: szhost_coeff_chain_one_pa starts a chain while the tail of its coefficient array is still on its way (the caller raises *avail from another
+    thread); the chain waits where it runs into the mark and gives what szhost_coeff_chain_one_p gives on the complete array, bit for bit."""
+    import threading, time
+    rng = np.random.default_rng(3)
+    for dtype in (np.float32, np.float64):
+        is_double = int(dtype == np.float64)
+        eb = 1e-3 if is_double else 1e-4
+        nb = 50000
+        ind = np.zeros(nb, dtype=np.uint8)
+        co = np.zeros((4, nb), dtype=dtype)
+        for e in range(4):
+            prec = 0.025 * eb / (6 if e < 3 else 1)
+            v = np.cumsum((rng.random(nb) - 0.5) * 30 * prec); v[::977] += 1e5 * prec
+            co[e] = v.astype(dtype)
+        outs = []
+        for gated in (0, 1):
+            c = np.ascontiguousarray(co.copy())
+            if gated:
+                c[:, 20000:] = np.nan                                   # (not there yet: whatever the chain read there too early would show)
+            st = _Coeffs()
+            L.szhost_coeff_chain_begin(is_double, ind.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(nb), ctypes.c_double(eb), 6, 6, 6, 4, ctypes.byref(st))
+            avail = ctypes.c_size_t(20000 if gated else nb)
+            def late():
+                time.sleep(0.05)
+                c[:, 20000:] = co[:, 20000:]
+                avail.value = nb
+            th = threading.Thread(target=late) if gated else None
+            if th: th.start()
+            for e in range(4):
+                L.szhost_coeff_chain_one_pa(is_double, c.ctypes.data_as(ctypes.c_void_p), ind.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(nb), 0, e, ctypes.byref(st), None,
+                                            ctypes.byref(avail) if gated else None)
+            if th: th.join()
+            rc = st.reg_count
+            outs.append((c.tobytes(), [np.ctypeslib.as_array(st.codes[e], shape=(rc,)).copy() for e in range(4)]))
+            L.szhost_coeffs_free(ctypes.byref(st))
+        assert outs[0][0] == outs[1][0]
+        for e in range(4):
+            assert np.array_equal(outs[0][1][e], outs[1][1][e])
