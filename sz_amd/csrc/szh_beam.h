@@ -1,35 +1,38 @@
-// szh_beam.h -- the predict+quantise (and inverse) sweep of the SZ 2.1 path, third mapping ("beam", round 5).
+// szh_beam.h -- the predict+quantise (and inverse) sweep of the SZ 2.1 path: the "beam" mapping (round 5), rewritten lean in round 6.
 //
-// Same arithmetic as szh_pencil.h / szh_ribbon.h (7-point Lorenzo from RECONSTRUCTED neighbours, sz/src/sz_float.c:7253-7353, with the
-// mean shortcut :6914-7030; inverse sz/src/szd_float.c:3483-5866), bit for bit the same codes; the shape is k_omp_col's (szh_ompcol.h), which
-// round 4 measured at 48 % of the HBM roofline on the reference's OpenMP container, carried over to ONE dependency front over the whole array:
+// Arithmetic: 7-point Lorenzo from RECONSTRUCTED neighbours, sz/src/sz_float.c:7253-7353, with the mean shortcut :6914-7030; inverse
+// sz/src/szd_float.c:3483-5866 -- bit for bit the reference's codes and values.
 //
+// Mapping (unchanged since round 5):
 //   * a lane owns a COLUMN: one position k of the contiguous dimension, C1 = 4 consecutive rows j, ALL planes i, and walks its cells
 //     (i, j) in row-major order, one cell per step; lane m runs m steps behind lane 0.  32 such lanes are a HALF-BEAM (32 k x 4 j x r0 i),
 //     a wavefront is two half-beams side by side in j (the upper one a whole line behind), a workgroup four wavefronts side by side in j:
-//     32 k x 32 j.  No barrier inside the sweep.
-//       - (i, j, k-1) is what lane m - 1 produced one step ago: ONE DPP `wave_shr:1` per step (lane 0 of a half: the k-face of the beam on
+//     a tile of 32 k x 32 j x r0.  No barrier inside the sweep.
+//       - (i, j, k-1) is what lane m - 1 produced one step ago: ONE DPP `wave_shr:1` per step (lane 0 of a half: the k-face of the tile on
 //         its left, read from a small LDS ring);
 //       - (i, j-1, k) is the lane's own previous result; (i-1, j, k) what it produced LINE = C1 + 1 steps ago: a DELAY LINE of LINE registers
 //         indexed by the step number modulo LINE, a compile-time index in the unrolled line; the same for the left lane's values;
 //       - a line (i, :) takes LINE steps: its first is the VIRTUAL cell j = j0 - 1, whose "result" is the j-face of the half-beam below it:
 //         the upper half of a wavefront takes it from the lower half's register (v_permlane32_swap), the lower half of wavefront w + 1 finds
-//         it in its own LDS ring, where wavefront w's lanes put it the step they made it; across workgroups it travels through HBM granules.
+//         it in its own LDS ring, where wavefront w's lanes put it; across workgroups it travels through HBM granules.
 //         With that, ONE predictor expression -- the reference's 7-point sum in its order -- serves every cell;
-//   * memory: the rows of a line are read with 16 bytes per lane (8 row pieces of 128 bytes per instruction), eight such loads in flight per
-//     wavefront, and dropped into an LDS RING of RL = 9 lines of row slots indexed by the cell's step number; lane m reads ITS value of the
-//     row it is at (ds_read, conflict-free: the slot pitch is a multiple of 32 banks) one step ahead of its use and writes its code (and its
-//     reconstruction: the faces are read from there) next to it; finished rows of codes leave NATURAL order, 8 bytes per lane and line;
-//   * between workgroups: the k-face (lane 31's value of every cell) and the j-face (the last row of every line) go through HBM-side granules
-//     {launch epoch, value bits} -- 8-byte words written write-through, the data being its own flag (MI355X_MICROARCH "handoff-1to1") -- stored
-//     once per line by the wavefront itself; the consumer requests them DK lines ahead, validates the tag when it needs them and asks again
-//     (bounded) if they have not arrived.  Granule buffers hold the whole launch: no ring space to manage, nothing to clear (the tag is the epoch).
-//   * regression blocks (sz_float.c:7153-7252): their points do not depend on any neighbour -- prediction a i + b j + c k + d from the DECODED
-//     coefficients -- so a separate, fully parallel pass (k_reg_points) quantises them; this sweep only needs their RECONSTRUCTIONS as
-//     neighbours: it reads them where the other points' values are read and passes them through (HASREG: a flag byte per cell in the ring).
+//   * regression blocks (sz_float.c:7153-7252): their points do not depend on any neighbour, so a separate, fully parallel pass
+//     (k_reg_points) quantises them; this sweep only needs their RECONSTRUCTIONS as neighbours (HASREG: a flag per cell in the ring).
 //
-// Longest dependency path of a launch (512^3 float): LINE r0 = 2560 steps of one wavefront + the start-up lag of the last one: 32 + hop per
-// beam along k (15), 2 LINE + hop per wavefront along j (63) -- against 1536 steps + ~300 hops of 6 - 10 us for k_ribbon.
+// What round 6 changed -- a wavefront alone on its SIMD issues ONE instruction every ~4 cycles, whatever the instruction is, and a step's
+// dependent chain (DPP, 7-point sum, quantiser, bound check: 20 operations) takes ~150 cycles = 33 - 36 issue slots (tools/ubench/ub_step.hip:
+// the chain alone 60 ns, a lean step of 33 instructions 76 ns).  Round 5's kernel issued 84 instructions per step (43 in the step, 41 in the
+// events around it: scalar address arithmetic, ring wrap-arounds, progress words) and took 135 - 180 ns.  So:
+//   * the ring holds RL = 9 lines and the loop is unrolled over exactly those 9 lines: every LDS address of a step or an event is
+//     `lane constant + immediate`.  A lane's slot at unrolled step u is (u - m) modulo 45: two lane constants (before / after the lane's
+//     wrap) selected by one compare per step (none for u >= 32); DS address arithmetic is modulo 2^32 (tools/ubench/ub_dswrap.hip), so the
+//     "after" constant may lie below the ring;
+//   * codes take 4 bytes per lane in the ring (float: the lane's code lies a CONSTANT away from its value), packed when a row leaves;
+//   * per-stream scalar offsets advance by one add per line; the quantiser's last product is one exact v_fma (x * y + 0);
+//   * the j-face between tiles travels SKEWED -- after each wave line every lane of the last row stores its LATEST finished value (the same
+//     thing a wavefront hands to the one above it through LDS) instead of whole rows once all 32 lanes have passed: 3 lines + the memory
+//     round trip per tile hop instead of LAG + 1 + the round trip;
+//   * the lower face of the array is zeroed once (a virtual cell writes back what it read).
 //
 // Covers: 3-D arrays with r2 a multiple of 4, float / double, compress / decompress, mean shortcut, regression blocks.
 #pragma once
@@ -37,9 +40,6 @@
 
 #ifndef SZH_DEV
 #define SZH_DEV 0
-#endif
-#ifndef SZH_BM_X
-#define SZH_BM_X 0     /* tools/ubench/ub_beam.hip only (timing, results wrong): 1 no face push, 2 no code write, 4 no value write, 8 no k-face read, 16 no half swap, 32 no quantiser, 64 no value read */
 #endif
 namespace szh_bm {
 using szh_oc::mask_t;
@@ -54,23 +54,26 @@ using szh_oc::order;
 using szh_oc::wave_sync;
 typedef szh_rb::v4u v4u;
 
-constexpr int C1 = 4, LINE = C1 + 1, HL = 32, WPG = 4, RL = 9, RS = RL * LINE, KRL = 4, DK = 4;
+constexpr int C1 = 4, LINE = C1 + 1, HL = 32, WPG = 4, RL = 9, RS = RL * LINE, UL = RL, KRL = 3, DK = 3;
 constexpr int JW = 2 * C1, JG = JW * WPG;          // rows j per wavefront / per workgroup
-constexpr int LAG = 7;                              // lines after which every lane has left a line (31 steps of skew)
+constexpr int LAG = 7;                              // lines after which every lane has left a line (31 steps of skew + the upper half's line)
 #define SZH_BM_INF (1 << 30)
+static_assert(UL % KRL == 0 && UL % DK == 0 && RL >= LAG + 2, "ring geometry");
 
-template <class T, bool HASREG> struct shape {
-    static constexpr int SZ = (int)sizeof(T), VPL = 16 / SZ, LPR = HL / VPL, RPE = 64 / LPR, RH = RPE / 2, EV = C1 / RH, DV = 8, UL = DV / EV;
-    static constexpr int HB = HL * SZ, VB = 2 * HB, CB = 128, PITCH = VB + CB + (HASREG ? 128 : 0), RINGB = RS * PITCH, NW = szh_gran<T>::NW;
-    static constexpr int FOFF = VB + CB;            // flag bytes of a slot (HASREG), one per lane
+template <class T> struct shape {
+    static constexpr int SZ = (int)sizeof(T), VPL = 16 / SZ, LPR = HL / VPL, RPE = 64 / LPR, RH = RPE / 2, EV = C1 / RH;
+    static constexpr int HB = HL * SZ, VB = 2 * HB, CBW = 64 * 4, PITCH = VB + CBW, LP = LINE * PITCH, RINGB = RS * PITCH;
     static constexpr int KRB = KRL * LINE * 2 * SZ + 16; // k-face ring of a wavefront (+ a write-only word)
-    static_assert(PITCH % 128 == 0 && UL % DK == 0 && RL >= LAG + 2, "ring geometry");
+    // LDS of a workgroup: the rings | a write-only word per lane (+ slack: a lane that takes no part in an event writes there, line term included) | the k-face rings
+    // | the wavefronts' progress words |
+    static constexpr int TRASH0 = WPG * RINGB, PROG0 = TRASH0 + WPG * 64 * 8 + 256, KR0 = PROG0 + 64, LDSB = KR0 + WPG * KRB;
+    static constexpr bool CSEL = SZ != 4;           // the lane's code is NOT a constant away from its value: a second pair of lane constants
+    static_assert(PITCH % 128 == 0 && EV >= 1, "ring geometry");
 };
 
-// compile-time lane masks (both halves alike: lane = 32 h + m)
-template <int U> constexpr mask_t virt_mask() { mask_t x = 0; for (int l = 0; l < 64; ++l) if ((((l & 31) - U) % LINE + LINE) % LINE == 0) x |= 1ull << l; return x; }
-template <int U> constexpr mask_t push_mask() { mask_t x = 0; for (int l = 32; l < 64; ++l) if (((U - (l & 31)) % LINE + LINE) % LINE == C1) x |= 1ull << l; return x; }
+// compile-time lane masks (lane = 32 h + m)
 constexpr mask_t FIRSTCOL = 1ull | (1ull << 32), UPPER = 0xffffffff00000000ull;
+template <int U> constexpr mask_t virt_upper_mask() { mask_t x = 0; for (int l = 32; l < 64; ++l) if ((((l & 31) - U) % LINE + LINE) % LINE == 0) x |= 1ull << l; return x; }
 
 #ifdef SZH_HIPSIM
 struct u2_t { unsigned x, y; };
@@ -82,7 +85,7 @@ __device__ __forceinline__ void lds_put8(OC_LDS unsigned char *base, unsigned of
 
 #ifdef SZH_HIPSIM
 template <class T> static inline T shr1(T v) { return __shfl_up(v, 1, 64); }
-template <class T> static inline T low_to_high(T v) { const int l = (int)(threadIdx.x & 63); return __shfl(v, l >= 32 ? l - 32 : l, 64); }
+template <class T> static inline T low_to_high(T v, T) { const int l = (int)(threadIdx.x & 63); return __shfl(v, l >= 32 ? l - 32 : l, 64); }
 static inline int uni(int v) { return __shfl(v, 0, 64); }
 static inline void nap1() { __builtin_amdgcn_s_sleep(1); }
 #else
@@ -93,28 +96,43 @@ __device__ __forceinline__ double shr1(double v)
     const int lo = __builtin_amdgcn_mov_dpp((int)s, 0x138, 0xf, 0xf, true), hi = __builtin_amdgcn_mov_dpp((int)(s >> 32), 0x138, 0xf, 0xf, true);
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
-// lanes 32 + m receive the value of lane m (v_permlane32_swap: the upper 32 lanes of the first operand are swapped with the lower 32 of the second)
-__device__ __forceinline__ unsigned low_to_high_u(unsigned v) { const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); return r[0]; }
-__device__ __forceinline__ float low_to_high(float v) { return __uint_as_float(low_to_high_u(__float_as_uint(v))); }
-__device__ __forceinline__ double low_to_high(double v)
+// lanes 32 + m receive the value of lane m (v_permlane32_swap: lanes 32..63 of the first operand are swapped with lanes 0..31 of the second;
+// the first operand is a register whose contents nobody needs any more -- no copy of it, one of `v`)
+__device__ __forceinline__ unsigned low_to_high_u(unsigned v, unsigned junk) { const auto r = __builtin_amdgcn_permlane32_swap(junk, v, false, false); return r[0]; }
+__device__ __forceinline__ float low_to_high(float v, float junk) { return __uint_as_float(low_to_high_u(__float_as_uint(v), __float_as_uint(junk))); }
+__device__ __forceinline__ double low_to_high(double v, double junk)
 {
-    const unsigned long long s = (unsigned long long)__double_as_longlong(v);
-    const unsigned lo = low_to_high_u((unsigned)s), hi = low_to_high_u((unsigned)(s >> 32));
+    const unsigned long long s = (unsigned long long)__double_as_longlong(v), j = (unsigned long long)__double_as_longlong(junk);
+    const unsigned lo = low_to_high_u((unsigned)s, (unsigned)j), hi = low_to_high_u((unsigned)(s >> 32), (unsigned)(j >> 32));
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ void nap1() { __builtin_amdgcn_s_sleep(1); }
 #endif
+// the same in two parts, so that the copy the swap consumes is made early in a step and the swap itself sits among independent instructions (back
+// to back they need wait states: two s_nop per step).  `copy_for_swap` must be issued at least two VALU instructions before `swap_into`.
+#ifdef SZH_HIPSIM
+template <class T> static inline T copy_for_swap(T v) { return v; }
+template <class T> static inline T swap_into(T copy, T) { const int l = (int)(threadIdx.x & 63); return __shfl(copy, l >= 32 ? l - 32 : l, 64); }
+static inline bool all_lanes(bool p) { return __all(p ? 1 : 0) != 0; }
+#else
+__device__ __forceinline__ float copy_for_swap(float v) { float t; asm("v_mov_b32 %0, %1" : "=v"(t) : "v"(v)); return t; }
+__device__ __forceinline__ float swap_into(float copy, float junk) { asm("v_permlane32_swap_b32 %0, %1" : "+v"(junk), "+v"(copy)); return junk; }
+__device__ __forceinline__ double copy_for_swap(double v) { double t; asm("v_mov_b32 %L0, %L1\n\tv_mov_b32 %H0, %H1" : "=&v"(t) : "v"(v)); return t; }
+__device__ __forceinline__ double swap_into(double copy, double junk) { asm("v_permlane32_swap_b32 %L0, %L1\n\tv_permlane32_swap_b32 %H0, %H1" : "+v"(junk), "+v"(copy)); return junk; }
+__device__ __forceinline__ bool all_lanes(bool p) { return __builtin_amdgcn_ballot_w64(p) == __builtin_amdgcn_ballot_w64(true); }
+#endif
 
-__device__ __forceinline__ unsigned ld_err(const unsigned *p) { return __hip_atomic_load(const_cast<unsigned *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_err(unsigned *p, unsigned v) { atomicMax(p, v); }      // (2 = the regression points did not arrive, 1 = a face did not: the larger one stays)
 
 // geometry of a launch
 struct grid_t { int nKB, nJG; };
 SZH_HD grid_t make_grid(const szh_geom3 &G) { grid_t g; g.nKB = (G.g2.count + HL - 1) / HL; g.nJG = (G.g1.count + JG - 1) / JG; return g; }
-// granule words: k-face [workgroup][8 half-beams][LINE r0 cells][NW], j-face [workgroup][r0 lines][32 lanes][NW]
+SZH_HD int wave_lines(const szh_geom3 &G) { return ((G.g0.count + 1 + LAG + UL - 1) / UL) * UL; }       // wave lines a wavefront runs (whole unrolled blocks)
+// granule words: k-face [workgroup][8 half-beams][LINE r0 cells][NW], j-face [workgroup][wave lines][32 lanes][NW] (row X: what each lane of the
+// workgroup's last row had finished last when its wave line X ended)
 template <class T> SZH_HD size_t kface_words(const szh_geom3 &G) { const grid_t g = make_grid(G); return (size_t)g.nKB * g.nJG * 8 * LINE * (size_t)G.g0.count * szh_gran<T>::NW; }
-template <class T> SZH_HD size_t jface_words(const szh_geom3 &G) { const grid_t g = make_grid(G); return (size_t)g.nKB * g.nJG * (size_t)G.g0.count * HL * szh_gran<T>::NW; }
+template <class T> SZH_HD size_t jface_words(const szh_geom3 &G) { const grid_t g = make_grid(G); return (size_t)g.nKB * g.nJG * (size_t)wave_lines(G) * HL * szh_gran<T>::NW; }
 
 #ifdef SZH_HIPSIM
 #define SZH_SB
@@ -127,13 +145,11 @@ template <class V> static inline void hide(V &) {}
 __device__ __forceinline__ void hide(unsigned &v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void hide(float &v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void hide(double &v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void hide(mask_t &v) { asm volatile("" : "+s"(v)); }
 #endif
-// select by a per-lane constant bit mask (all ones / all zeros): v_bfi_b32, no lane mask to set up in the scalar unit
-#ifdef SZH_HIPSIM
-static inline unsigned bsel(unsigned mask, unsigned a, unsigned b) { return (a & mask) | (b & ~mask); }
-#else
-__device__ __forceinline__ unsigned bsel(unsigned mask, unsigned a, unsigned b) { unsigned r; asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b)); return r; }
-#endif
+// select by a per-lane constant bit mask (all ones / all zeros; hidden from hipcc where it is set up): v_bfi_b32, no lane mask to set up in the
+// scalar unit.  (Plain C, which hipcc turns into that instruction: behind an inline `asm` it puts an s_nop in front of the next VALU instruction.)
+__device__ __forceinline__ unsigned bsel(unsigned mask, unsigned a, unsigned b) { return (a & mask) | (b & ~mask); }
 __device__ __forceinline__ float bsel(unsigned mask, float a, float b) { return __uint_as_float(bsel(mask, __float_as_uint(a), __float_as_uint(b))); }
 __device__ __forceinline__ double bsel(unsigned mask, double a, double b)
 {
@@ -194,43 +210,51 @@ __device__ __forceinline__ role_t make_role(bool en, unsigned plain, int half, u
     role_t r; r.plain = en ? plain : SZH_BM_OOB; r.half = half; r.mid = en ? plain + (half ? 0u : stride) : SZH_BM_OOB;
     return r;
 }
+// two codes (the low halves of two ring words) in one word
+#ifdef SZH_HIPSIM
+static inline unsigned pack2(unsigned lo, unsigned hi) { return (lo & 0xffffu) | (hi << 16); }
+#else
+__device__ __forceinline__ unsigned pack2(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x05040100u); }
+#endif
 
 template <class T, bool DEC, bool USEMEAN, bool HASREG>
 struct beam {
-    typedef shape<T, HASREG> S;
+    typedef shape<T> S;
     typedef gran_io<T> GIO;
     typedef typename GIO::reg_t greg_t;
     typedef u2_t cpiece_t;
-    static constexpr int PITCH = S::PITCH, RINGB = S::RINGB, SZ = S::SZ, UL = S::UL, EV = S::EV, DV = S::DV, NW = S::NW, LP = LINE * S::PITCH;
+    static constexpr int PITCH = S::PITCH, RINGB = S::RINGB, SZ = S::SZ, EV = S::EV, NSET = UL * EV, LP = S::LP, VB = S::VB, VPL = S::VPL;
 
     const szh_qargs<T> &a;
-    OC_LDS unsigned char *ring, *nring, *kring;
+    OC_LDS unsigned char *lds0;                                    // first byte of the workgroup's rings; every LDS address below is relative to it (modulo 2^32)
     OC_LDS unsigned *prog;
-    int lane, w, h, m, r0, dbg;                                    // dbg (development, timing only -- results become wrong): 1 no waits between the wavefronts, 2 / 4 / 8: no events at position 1 / 2 / 3
-    bool has_prev, has_next, zero_face;                            // (uniform)
+    int lane, w, h, m, r0, nwl;
+    bool has_prev, has_next, kf_in, kf_out, jf_in, jf_out;         // (uniform)
     unsigned spin_limit; bool timed_out;
-    rsrc_t rs_v, rs_c, rs_k, rs_j;                                 // the array (values), the codes, the k- / j-face granules
+    rsrc_t rs_v, rs_c, rs_k, rs_j, rs_x, rs_f;                     // the array (values), the codes, the k- / j-face granules, regression points' values / flags
     unsigned str_v, str_c, str_k, str_j;                           // bytes per line of each
+    unsigned so_vl, so_xl, so_fl, so_cl, so_vs, so_cs, so_ko, so_ki, so_jo, so_ji;   // (uniform) the streams' running scalar offsets, see place()
     // per-lane state of the sweep
-    T dl[LINE], lup[LINE], prev, Lprev, Bold, Bpold, cur_next, kf_next;
-    unsigned tc_next, fl_next, vaddr, cdelta, fdelta, kaddr_h, trash, tstart;     // (vaddr, kaddr_h, trash: byte addresses in the workgroup's LDS window `lds0`)
-    OC_LDS unsigned char *lds0;
-    unsigned ring_end, nring_lo, pface;                           // first byte behind this ring; the next ring's first byte; where the lane's next face value goes (the virtual slot of its line in the next ring)
-    T face_reg;                                                    // the lane's latest last-row result (upper half): handed on once per line
-    unsigned m_first, m_vu[LINE], m_push[LINE];                   // per-lane select masks: first lane of a half; virtual cell of the upper half / last row of the upper half at position U
+    T dl[LINE], lup[LINE], prev, Lprev, Bold, Bpold, cur_next, kf_next, face_reg, sw_junk, pcopy;
+    mask_t wrapm_next;
+    unsigned tc_next, fl_next;
+    unsigned pA, pB, cA, cB, mreg, qreg;                           // the lane's slot: p? + u PITCH (A: before its wrap, u < m; B: after); its code (CSEL)
+    unsigned pc, cc;                                               // the pointers of the CURRENT step (selected a step ago)
+    unsigned pf_at[RL], ji_at[RL];                                 // face push into the next ring / j-face granules into this ring: the lane's virtual-cell slot of line-slot a - q (modulo RL), per a
+    unsigned prog_prev_at, prog_next_at; mask_t idle_k, idle_j;
+    T ko_val; unsigned prog_at, it_v;                              // the k-face value on its way out; this wavefront's progress word (LDS address), wave lines done
+    unsigned kaddr_h, trash, tstart, ring_w;
+    mask_t m_first, m_vu[LINE];                                    // lane masks (scalar registers, hidden from hipcc where they are set up: it would rebuild them at every use): first lane of a half; the upper half's lanes whose cell at position U is virtual
     T caphU[LINE];                                                 // the quantiser's range test per position: half the capacity, -1 where the lane's cell is virtual
+    mask_t upper_m;
     // events: roles and LDS places
-    role_t rv[EV], rvs[EV], rc, rcs, rko, rki, rjo, rji;          // value rows in (out: inverse), code rows in (inverse) / out, granules
-    unsigned vl[EV], cl, ko_lds, ki_lds, jo_lds, ji_lds;
-    v4u gv[DV];                                                    // value rows on their way
-    v4u gx[HASREG && !DEC ? DV : 1]; unsigned gf[HASREG ? DV : 1]; // HASREG: the regression points' reconstructions of the same rows (compress), their flag bytes
-    rsrc_t rs_x, rs_f; role_t rf[EV]; unsigned fl_lds[EV];
-    cpiece_t gc[UL], wqc; v4u wqv[EV]; unsigned wfl, cfl;                             // inverse: code rows on their way; rows on their way out
+    role_t rv[EV], rvs[EV], rc, rcs, rko, rki, rjo, rji, rf[EV];
+    unsigned vl[EV], cw[EV], cl, ko_lds, ki_lds;
+    v4u gv[NSET];                                                  // value rows on their way
+    v4u gx[HASREG && !DEC ? NSET : 1]; unsigned gf[HASREG ? NSET : 1]; // HASREG: the regression points' reconstructions of the same rows (compress), their flag bytes
+    cpiece_t gc[UL]; v4u wqc4; v4u wqv[EV];                        // code rows on their way in (inverse; HASREG compress: k_reg_points' codes); rows on their way out
     greg_t gk[DK], gj[DK];                                         // k-face / j-face granules on their way
     T eb, eb2, rh, caph, radf, mean; int radius; unsigned epoch;
-    unsigned lo_it;                                                // LDS offset of wave line `it` in the ring (uniform)
-    bool wt_codes;                                                 // the codes are stored write-through (the host launches passes over finished lines while the sweep runs)
-    bool pface_fixed;                                              // the lane hands nothing on (its `pface` is its write-only word)
     unsigned pv_prev, pv_next;                                     // the neighbouring wavefronts' progress words as read a step ago
 
     __device__ __forceinline__ beam(const szh_qargs<T> &args) : a(args) {}
@@ -242,7 +266,7 @@ struct beam {
         return true;
     }
     // The inputs of the first `planes` planes are in memory: compress, arrays with regression blocks -- the regression points (reconstructions, flags, codes:
-    // k_reg_points); decompress (round 5) -- the codes in natural order and the pre-scattered unpredictable values (k_permute<1>, k_unpred).  They are made slice after slice
+    // k_reg_points); decompress -- the codes in natural order and the pre-scattered unpredictable values (k_permute<1>, k_unpred).  They are made slice after slice
     // of block rows on another stream while this sweep runs, as the host's coefficient chains get there (szhip_sz21.inc, "feed"); after each slice a
     // one-thread kernel stores the number of finished planes into a.reg_ready.  Read past this XCD's L2 (system scope); the slices' own stores reached
     // memory when their kernel ended, and this launch has not touched a line of those planes before (planes are whole cache lines: checked on the host).
@@ -273,163 +297,209 @@ struct beam {
             nap1();
         }
     }
-    // LDS offset of the line n lines after wave line `it` (0 <= n < RL)
-    __device__ __forceinline__ unsigned lo(int n) const { const unsigned x = lo_it + (unsigned)(n * LP); return x >= (unsigned)RINGB ? x - (unsigned)RINGB : x; }
 
     // offsets of a role's access of wave line X.  Inside the array (EDGE = false: every line any lane asks for exists) the line term is the
-    // wavefront-uniform `soff` and the lane part a constant; at the array's first and last lines each lane checks its own line
-    template <bool EDGE> __device__ __forceinline__ void place(const role_t &r, int X, unsigned stride, unsigned &off, unsigned &soff) const
+    // stream's running scalar offset `so` (= (X - 1) stride, advanced by the caller) and the lane part a constant; at the array's first and last
+    // lines each lane checks its own line
+    template <bool EDGE> __device__ __forceinline__ void place(const role_t &r, int X, unsigned stride, unsigned so, unsigned &off, unsigned &soff) const
     {
-        if (!EDGE) { off = r.mid; soff = (unsigned)(X - 1) * stride; return; }
+        if (!EDGE) { off = r.mid; soff = so; return; }
         const int L = X - r.half;
         off = (r.plain != SZH_BM_OOB && (unsigned)L < (unsigned)r0) ? r.plain + (unsigned)L * stride : SZH_BM_OOB;
         soff = 0u;
     }
-    template <bool EDGE> __device__ __forceinline__ v4u load_v(int X, int ev) const { unsigned o, so; place<EDGE>(rv[ev], X, str_v, o, so); return bld16<DEC ? 0 : 2>(rs_v, o, so); }
-    template <bool EDGE> __device__ __forceinline__ v4u load_x(int X, int ev) const { unsigned o, so; place<EDGE>(rv[ev], X, str_v, o, so); return bld16<0>(rs_x, o, so); }
+    // (j-face granule rows are wave lines, not lines of the array: no half, rows 0 .. nwl - 1)
+    template <bool EDGE> __device__ __forceinline__ void place_row(const role_t &r, int X, unsigned stride, unsigned so, unsigned &off, unsigned &soff) const
+    {
+        if (!EDGE) { off = r.plain; soff = so; return; }
+        off = (r.plain != SZH_BM_OOB && (unsigned)X < (unsigned)nwl) ? r.plain + (unsigned)X * stride : SZH_BM_OOB;
+        soff = 0u;
+    }
+    template <bool EDGE> __device__ __forceinline__ v4u load_v(int X, int ev) const { unsigned o, so; place<EDGE>(rv[ev], X, str_v, so_vl, o, so); return bld16<DEC ? 0 : 2>(rs_v, o, so); }
+    template <bool EDGE> __device__ __forceinline__ v4u load_x(int X, int ev) const { unsigned o, so; place<EDGE>(rv[ev], X, str_v, so_vl, o, so); return bld16<0>(rs_x, o, so); }
     template <bool EDGE> __device__ __forceinline__ unsigned load_f(int X, int ev) const
     {
-        unsigned o, so; place<EDGE>(rf[ev], X, str_v / (unsigned)SZ, o, so);
+        unsigned o, so; place<EDGE>(rf[ev], X, str_v / (unsigned)SZ, so_fl, o, so);
 #ifdef SZH_HIPSIM
-        unsigned v = 0; for (int e = 0; e < S::VPL; ++e) if (inr(rs_f, o + (unsigned)e, so, 1)) v |= (unsigned)(unsigned char)rs_f.base[o + so + (unsigned)e] << (8 * e);
+        unsigned v = 0; for (int e = 0; e < VPL; ++e) if (inr(rs_f, o + (unsigned)e, so, 1)) v |= (unsigned)(unsigned char)rs_f.base[o + so + (unsigned)e] << (8 * e);
         return v;
 #else
-        return S::VPL == 4 ? (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs_f, (int)o, (int)so, 0) : (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs_f, (int)o, (int)so, 0);
+        return VPL == 4 ? (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs_f, (int)o, (int)so, 0) : (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs_f, (int)o, (int)so, 0);
 #endif
     }
-    // a row piece goes into the ring: HASREG: the regression points' values are their reconstructions (compress; the inverse finds them in the
-    // array already), and their flag bytes go next to the values
-    __device__ __forceinline__ void put_rows(unsigned at_line, int e, v4u xv, v4u xrv, unsigned fl)
+    template <bool EDGE> __device__ __forceinline__ cpiece_t load_c(int X) const { unsigned o, so; place<EDGE>(rc, X, str_c, so_cl, o, so); return bld8<0>(rs_c, o, so); }
+    template <bool EDGE> __device__ __forceinline__ greg_t load_k(int X) const { unsigned o, so; place<EDGE>(rki, X, str_k, so_ki, o, so); return GIO::ld(rs_k, o, so); }
+    template <bool EDGE> __device__ __forceinline__ greg_t load_j(int X) const { unsigned o, so; place_row<EDGE>(rji, X, str_j, so_ji, o, so); return GIO::ld(rs_j, o, so); }
+
+    // a row piece goes into the ring (line-slot offset `at`): HASREG: the regression points' values are their reconstructions (compress; the
+    // inverse finds them in the array already), and their flags go into the upper halves of the cells' code words
+    __device__ __forceinline__ void put_rows(unsigned at, int e, v4u xv, v4u xrv, unsigned fl)
     {
         if (HASREG) {
             if (!DEC) {
-                T a_[S::VPL], b_[S::VPL];
+                T a_[VPL], b_[VPL];
                 __builtin_memcpy(a_, &xv, 16); __builtin_memcpy(b_, &xrv, 16);
-                for (int q = 0; q < S::VPL; ++q) a_[q] = ((fl >> (8 * q)) & 0xffu) ? b_[q] : a_[q];
+                for (int q = 0; q < VPL; ++q) a_[q] = ((fl >> (8 * q)) & 0xffu) ? b_[q] : a_[q];
                 __builtin_memcpy(&xv, a_, 16);
+                // (compress: the lanes write their codes as 16-bit halves, so whole words may be written here)
+                if (VPL == 4) { v4u f4 = {(fl & 0xffu) << 16, (fl & 0xff00u) << 8, fl & 0xff0000u, (fl >> 8) & 0xff0000u}; lds_put16(lds0, ring_w + at + cw[e], f4); }
+                else { u2_t f2; f2.x = (fl & 0xffu) << 16; f2.y = (fl & 0xff00u) << 8; lds_put8(lds0, ring_w + at + cw[e], f2); }
+            } else {
+                // (inverse: the code row of the line has been written as whole words just before: the flags go into the upper halves)
+                for (int q = 0; q < VPL; ++q) lds_put<uint16_t>(lds0, ring_w + at + cw[e] + (unsigned)(4 * q + 2), (uint16_t)((fl >> (8 * q)) & 0xffu));
             }
-            if (S::VPL == 4) lds_put<unsigned>(ring, at_line + fl_lds[e], fl); else lds_put<uint16_t>(ring, at_line + fl_lds[e], (uint16_t)fl);
         }
-        lds_put16(ring, at_line + vl[e], xv);
+        lds_put16(lds0, ring_w + at + vl[e], xv);
     }
-    template <bool EDGE> __device__ __forceinline__ cpiece_t load_c(int X) const { unsigned o, so; place<EDGE>(rc, X, str_c, o, so); return bld8<0>(rs_c, o, so); }
-    template <bool EDGE> __device__ __forceinline__ greg_t load_k(int X) const { unsigned o, so; place<EDGE>(rki, X, str_k, o, so); return GIO::ld(rs_k, o, so); }
-    template <bool EDGE> __device__ __forceinline__ greg_t load_j(int X) const { unsigned o, so; place<EDGE>(rji, X, str_j, o, so); return GIO::ld(rs_j, o, so); }
-
-    // the granules of wave line X have arrived -- or are asked for again (bounded); their values go into the k-face ring / the virtual slot
-    template <bool EDGE, bool KFACE> __device__ __forceinline__ void take(int X, greg_t g, OC_LDS unsigned char *dst, unsigned at_line)
+    // (inverse) a row of codes goes into the ring: 4 codes of 16 bits -> 4 words
+    __device__ __forceinline__ void put_codes(unsigned at, cpiece_t c)
     {
-        const role_t &r = KFACE ? rki : rji;
-        // (lanes that take no part write to their write-only word: `ki_lds` / `ji_lds` is its whole offset for them)
-        const unsigned at = (r.plain != SZH_BM_OOB ? at_line : 0u) + (KFACE ? ki_lds : ji_lds);
-        const bool need = r.plain != SZH_BM_OOB && (!EDGE || (unsigned)(X - r.half) < (unsigned)r0);
-        if (__all((!need || GIO::ok(g, epoch)) ? 1 : 0) == 0) {
+        v4u c4 = {c.x & 0xffffu, c.x >> 16, c.y & 0xffffu, c.y >> 16};
+        lds_put16(lds0, ring_w + at + cl, c4);
+    }
+
+    // the granules of row X have arrived -- or are asked for again (bounded)
+    // (`idle`: the lanes that need nothing of the row)
+    template <bool KFACE> __device__ __forceinline__ greg_t arrived(int X, greg_t g, mask_t idle)
+    {
+        if ((lane_mask(GIO::ok(g, epoch)) | idle) != ~0ull) {
             unsigned spins = 0;
 #pragma unroll 1
             do {
                 if (give_up(spins)) break;
                 nap1();
                 g = KFACE ? load_k<true>(X) : load_j<true>(X);
-            } while (__all((!need || GIO::ok(g, epoch)) ? 1 : 0) == 0);
+            } while ((lane_mask(GIO::ok(g, epoch)) | idle) != ~0ull);
         }
-        lds_put<T>(dst, at, need ? GIO::val(g) : (T)0);
+        return g;
     }
+
+    static constexpr unsigned lineoff(int n) { return (unsigned)((((n % RL) + RL) % RL) * LP); }      // LDS offset of the line-slot n lines after the block's first
 
     // ---- the events of unrolled position U of wave line `it` (LL = it modulo UL, compile time)
     template <int U, int LL, bool EDGE> __device__ __forceinline__ void events(int it)
     {
         if constexpr (U == 1) {
             // finished rows (line it - LAG: every lane has left it) leave the ring: read here, stored one step later
-            const unsigned loY = lo(RL - LAG);
-            if (!DEC) wqc = lds_get8(ring, loY + cl);
-            if (!DEC && HASREG) wfl = lds_get<unsigned>(ring, loY + cfl);
-            else for_n<EV>([&](auto E) { constexpr int e = decltype(E)::value; wqv[e] = lds_get16(ring, loY + vl[e]); });
-            unsigned o, so;
-            place<EDGE>(rko, it - LAG, str_k, o, so);
-            GIO::st(rs_k, o, so, lds_get<T>(ring, loY + ko_lds), epoch);
-            place<EDGE>(rjo, it - LAG, str_j, o, so);
-            GIO::st(rs_j, o, so, lds_get<T>(ring, loY + jo_lds), epoch);
+            constexpr unsigned loY = lineoff(LL - LAG);
+            if (!DEC) wqc4 = lds_get16(lds0, ring_w + loY + cl);
+            else for_n<EV>([&](auto E) { constexpr int e = decltype(E)::value; wqv[e] = lds_get16(lds0, ring_w + loY + vl[e]); });
+            ko_val = lds_get<T>(lds0, ring_w + loY + ko_lds);
         }
         if constexpr (U == 2) {
             unsigned o, so;
+            place<EDGE>(rko, it - LAG, str_k, so_ko, o, so);
+            GIO::st(rs_k, o, so, ko_val, epoch);
+            so_ko += str_k;
             if (!DEC) {
+                cpiece_t out; out.x = pack2(wqc4.x, wqc4.y); out.y = pack2(wqc4.z, wqc4.w);
                 if (HASREG) {
                     // the regression points of the row piece keep the codes k_reg_points gave them (the sweep passed their values through and has
-                    // zeros there): per code a 16-bit mask from its flag byte
-                    constexpr int set = LL % UL;
-                    const cpiece_t old = gc[set];
-                    const unsigned m0 = ((wfl & 0xffu) ? 0xffffu : 0u) | ((wfl & 0xff00u) ? 0xffff0000u : 0u), m1 = ((wfl & 0xff0000u) ? 0xffffu : 0u) | ((wfl & 0xff000000u) ? 0xffff0000u : 0u);
-                    wqc.x = (old.x & m0) | (wqc.x & ~m0); wqc.y = (old.y & m1) | (wqc.y & ~m1);
-                    gc[set] = load_c<true>(it - LAG + UL);
+                    // zeros there): per code a 16-bit mask from the flag in the upper half of its ring word
+                    const cpiece_t old = gc[LL];
+                    const unsigned m0 = (wqc4.x > 0xffffu ? 0xffffu : 0u) | (wqc4.y > 0xffffu ? 0xffff0000u : 0u), m1 = (wqc4.z > 0xffffu ? 0xffffu : 0u) | (wqc4.w > 0xffffu ? 0xffff0000u : 0u);
+                    out.x = (old.x & m0) | (out.x & ~m0); out.y = (old.y & m1) | (out.y & ~m1);
+                    gc[LL] = load_c<true>(it - LAG + UL);
                 }
-                place<EDGE>(rcs, it - LAG, str_c, o, so);
-                if (wt_codes) bst8<17>(rs_c, o, so, wqc); else bst8<0>(rs_c, o, so, wqc);      // (written through when the host follows this sweep's progress: see `pub` in run)
+                place<EDGE>(rcs, it - LAG, str_c, so_cs, o, so);
+                bst8<17>(rs_c, o, so, out);      // (written through: the host may follow this sweep's progress, see `pub` in run; the codes are read next by other kernels, from memory either way)
+                so_cs += str_c;
+            } else {
+                for_n<EV>([&](auto E) { constexpr int e = decltype(E)::value; place<EDGE>(rvs[e], it - LAG, str_v, so_vs, o, so); bst16<0>(rs_v, o, so, wqv[e]); });
+                so_vs += str_v;
             }
-            else for_n<EV>([&](auto E) { constexpr int e = decltype(E)::value; place<EDGE>(rvs[e], it - LAG, str_v, o, so); bst16<0>(rs_v, o, so, wqv[e]); });
-            // rows that have arrived go in (line it + 1), and the register set that carried them is sent for the rows DV events further on
-            const unsigned loX = lo(1);
+            // rows that have arrived go in (line it + 1), and the register set that carried them is sent for the rows UL lines further on
+            constexpr unsigned loX = lineoff(LL + 1);
+            if (DEC) { put_codes(loX, gc[LL]); gc[LL] = load_c<EDGE>(it + 1 + UL); so_cl += str_c; wave_sync(); }      // (lock step: on the CPU shim the lanes are fibres, and the flags below go into words other lanes' code rows write whole)
             for_n<EV>([&](auto E) {
-                constexpr int e = decltype(E)::value, set = ((LL + 1) * EV + e) % DV;
+                constexpr int e = decltype(E)::value, set = LL * EV + e;
                 put_rows(loX, e, gv[set], gx[HASREG && !DEC ? set : 0], gf[HASREG ? set : 0]);
                 gv[set] = load_v<EDGE>(it + 1 + UL, e);
                 if (HASREG && !DEC) gx[HASREG && !DEC ? set : 0] = load_x<EDGE>(it + 1 + UL, e);
                 if (HASREG) gf[HASREG ? set : 0] = load_f<EDGE>(it + 1 + UL, e);
             });
-            if (zero_face) { const v4u z = {0u, 0u, 0u, 0u}; if (lane < S::HB / 16) lds_put16(ring, loX + (unsigned)lane * 16u, z); }
-            if (DEC) { constexpr int set = (LL + 1) % UL; lds_put8(ring, loX + cl, gc[set]); gc[set] = load_c<EDGE>(it + 1 + UL); }
-        }
-        if constexpr (U == 4) {
-            pv_prev = lds_get<unsigned>((OC_LDS unsigned char *)(prog + (has_prev ? w - 1 : w)), 0);
-            pv_next = lds_get<unsigned>((OC_LDS unsigned char *)(prog + (has_next ? w + 1 : w)), 0);
+            so_vl += str_v; if (HASREG) so_fl += str_v / (unsigned)SZ;
         }
         if constexpr (U == 3) {
-            constexpr int set = (LL + 1) % DK, kl = (LL + 1) % KRL;
-            take<EDGE, true>(it + 1, gk[set], kring, (unsigned)(kl * LINE * 2 * SZ));
-            gk[set] = load_k<EDGE>(it + 1 + DK);
-            take<EDGE, false>(it + 1, gj[set], ring, lo(1));
-            gj[set] = load_j<EDGE>(it + 1 + DK);
+            constexpr int set = LL % DK;
+            {   // the k-face of wave line it + 1 goes into the k-face ring
+                const bool need = rki.plain != SZH_BM_OOB && (!EDGE || (unsigned)(it + 1 - rki.half) < (unsigned)r0);
+                if (kf_in) {
+                    const greg_t g = arrived<true>(it + 1, gk[set], EDGE ? ~lane_mask(need) : idle_k);
+                    lds_put<T>(lds0, ki_lds + (unsigned)(((LL + 1) % KRL) * LINE * 2 * SZ), (!EDGE || need) ? GIO::val(g) : (T)0);
+                }
+                gk[set] = load_k<EDGE>(it + 1 + DK);
+                so_ki += str_k;
+            }
+            {   // row it + 3 of the j-face of the workgroup below: lane m's value is the virtual cell of line it + 2 - q(m)
+                constexpr int aj = (LL + 2) % RL;
+                const bool need = rji.plain != SZH_BM_OOB && (!EDGE || (unsigned)(it + 3) < (unsigned)nwl);
+                if (jf_in) {
+                    const greg_t g = arrived<false>(it + 3, gj[set], EDGE ? ~lane_mask(need) : idle_j);
+                    // (the upper half's lanes write into the upper half's part of the same slots: nobody reads a virtual cell of the upper half from the ring)
+                    lds_put<T>(lds0, ji_at[aj], (!EDGE || need) ? GIO::val(g) : (T)0);
+                }
+                gj[set] = load_j<EDGE>(it + 3 + DK);
+                so_ji += str_j;
+            }
+        }
+        if constexpr (U == 4) {
+            // (a wavefront without a neighbour reads the word that always says "far ahead")
+            pv_prev = lds_get<unsigned>(lds0, prog_prev_at);
+            pv_next = lds_get<unsigned>(lds0, prog_next_at);
         }
     }
 
     __device__ __forceinline__ static T tabs(T v) { return sizeof(T) == 8 ? (T)__builtin_fabs((double)v) : (T)__builtin_fabsf((float)v); }
     __device__ __forceinline__ static T ttrunc(T v) { return sizeof(T) == 8 ? (T)__builtin_trunc((double)v) : (T)__builtin_truncf((float)v); }
     __device__ __forceinline__ static T tsign(T mag, T from) { return sizeof(T) == 8 ? (T)__builtin_copysign((double)mag, (double)from) : (T)__builtin_copysignf((float)mag, (float)from); }
+    // x y + 0 in ONE rounding: the product rounded, and a zero product +0 whatever its sign -- what `x * y` followed by `+ 0` gives (|x| >= 1 or x = 0 here: no underflow)
+    __device__ __forceinline__ static T tmul0(T x, T y) { return sizeof(T) == 8 ? (T)__builtin_fma((double)x, (double)y, 0.0) : (T)__builtin_fmaf((float)x, (float)y, 0.0f); }
 
+    // the lanes that have not wrapped at unrolled step UN (m > UN), as a lane mask; `mreg` is hidden from hipcc block by block: it would hoist the
+    // 31 compares out of the loop as 31 lane masks in scalar registers, and spill them
+    template <int UN> __device__ __forceinline__ void next_wrap()
+    {
+        if (UN < HL - 1) wrapm_next = lane_mask(mreg > (unsigned)UN);
+    }
     // ---- one step: the cell the lane is at
     // One wavefront per SIMD: a dependent VALU instruction issues ~9 cycles after the one it waits for, an independent one after 4 (tools/ubench),
-    // and hipcc's scheduler models neither: it emitted the 20 operations of the dependent chain (DPP, the 7-point sum left to right, the
-    // quantiser, the bound check) back to back and everything else around them -- 480 cycles a step.  So the step is written in the order it
-    // should issue, one chain operation and one or two independent ones per group, and the groups are pinned (SZH_SB: nothing crosses).
+    // and hipcc's scheduler models neither.  So the step is written in the order it should issue, one chain operation and one or two independent
+    // ones per group, and the groups are pinned (SZH_SB: nothing crosses).
     template <int U, int LL, bool EDGE> __device__ __forceinline__ void step(int it)
     {
+        constexpr int u = LL * LINE + U, un = (u + 1) % RS, un2 = (u + 2) % RS;
         const T cur_raw = cur_next, kf = kf_next;
         const unsigned tc_in = tc_next, fl_in = fl_next;
+        // (the copy the swap consumes was made at the end of the step before, and the lane mask of the slot select in the middle of it: back to
+        // back with their consumers both need wait states -- three s_nop per step)
         const T Lraw = shr1(prev);                                       // (i, j, k-1): the left lane's previous result
-        const unsigned y = vaddr + (unsigned)PITCH;
+        const mask_t wrapm = wrapm_next;
         SZH_SB;
-        T L = bsel(m_first, kf, Lraw);                                   // (a half's first lane: the k-face of the beam on the left)
+        T L = in_mask(m_first) ? kf : Lraw;                              // (a half's first lane: the k-face of the tile on the left)
         const bool started = !EDGE || (unsigned)(it * LINE + U) >= tstart;      // (at the array's first lines: lanes that have not started hold zeros)
         if (EDGE) L = started ? L : (T)0;
-        const T sw = (SZH_BM_X & 16) ? prev : low_to_high(prev);
+        const T sw = low_to_high(pcopy, sw_junk);
         SZH_SB;
         const T B = dl[U], Bp = lup[U], C = Bold, Cp = Bpold;
         // [-1] + [-s1] + [-s0] - [-s1-1] - [-s0-1] - [-s0-s1] + [-s0-s1-1], left to right (sz_float.c:7268)
         const T s1 = L + prev;
-        const unsigned vnext = y >= ring_end ? y - (unsigned)RINGB : y;
         SZH_SB;
         const T s2 = s1 + B;
-        // a virtual cell: the j-face -- from the ring (lower half), from the lower half's previous result (upper half)
-        const T cur = bsel(m_vu[U], sw, cur_raw);
+        const unsigned pn = un < HL - 1 ? (in_mask(wrapm) ? pA : pB) : pB;
+        const unsigned cn = !S::CSEL ? pn : (un < HL - 1 ? (in_mask(wrapm) ? cA : cB) : cB);
         SZH_SB;
         const T s3 = s2 - Lprev;
-        if (!(SZH_BM_X & 64)) cur_next = lds_get<T>(lds0, vnext);        // what the NEXT step needs from the rings is requested now
-        if (DEC) tc_next = lds_get<uint16_t>(lds0, vnext + cdelta);
-        if (HASREG) fl_next = lds_get<uint8_t>(lds0, vnext + fdelta);
+        // a virtual cell: the j-face -- from the ring (lower half), from the lower half's previous result (upper half)
+        const T cur = in_mask(m_vu[U]) ? sw : cur_raw;
+        cur_next = lds_get<T>(lds0, pn + (unsigned)(un * PITCH));        // what the NEXT step needs from the rings is requested now
+        if (DEC) tc_next = lds_get<uint16_t>(lds0, cn + (unsigned)(un * PITCH + (S::CSEL ? 0 : VB)));
+        if (HASREG) fl_next = lds_get<uint8_t>(lds0, cn + (unsigned)(un * PITCH + (S::CSEL ? 0 : VB) + 2));
         SZH_SB;
         const T s4 = s3 - Bp;
         {   // the k-face value of the next step's cell of lane 0 (every lane reads; only the halves' first lanes use it)
             constexpr int Un = (U + 1) % LINE, kl = (U + 1 == LINE ? LL + 1 : LL) % KRL;
-            if (!(SZH_BM_X & 8)) kf_next = lds_get<T>(lds0, (unsigned)(kl * LINE * 2 * SZ + Un * 2 * SZ) + kaddr_h);
+            kf_next = lds_get<T>(lds0, (unsigned)(kl * LINE * 2 * SZ + Un * 2 * SZ) + kaddr_h);
         }
         SZH_SB;
         const T s5 = s4 - C;
@@ -438,14 +508,14 @@ struct beam {
         SZH_SB;
         T rec;
         if (!DEC) {
-            // the quantiser of szh_rb::rb_quant (sz_float.c:7270-7287 with a shorter dependency chain, bit for bit the same results); a virtual
+            // the quantiser (sz_float.c:7270-7287 with a shorter dependency chain, bit for bit the same results); a virtual
             // cell fails the range test (its limit is -1) and hands its value on unchanged
             const T diff = cur - pred;
             SZH_SB;
             const T hq0 = tabs(diff) * rh;
-            const unsigned caddr = vaddr + cdelta;
             SZH_SB;
             const T hq = hq0 + (T)0.5;
+            next_wrap<un2>();
             SZH_SB;
             const T tq = ttrunc(hq);
             mask_t okm = lane_mask(hq < caphU[U]);
@@ -453,12 +523,10 @@ struct beam {
             SZH_SB;
             const T ts = tsign(tq, diff);
             SZH_SB;
-            const T m1 = ts * eb2;
+            const T m2 = tmul0(ts, eb2);
             const T cf = radf + ts;
             SZH_SB;
-            const T m2 = m1 + (T)0;
             int code = (int)cf;
-            SZH_SB;
             const T rcn = pred + m2;
             SZH_SB;
             const T err = cur - rcn;
@@ -474,14 +542,14 @@ struct beam {
                 if (in_mask(nm)) { code = radius; rec = mean; }
             }
             if (EDGE) rec = started ? rec : (T)0;
-            if (SZH_BM_X & 32) rec = pred + cur;
-            if (!(SZH_BM_X & 2)) lds_put<uint16_t>(lds0, caddr, (uint16_t)code);
-            if (!(SZH_BM_X & 4)) lds_put<T>(lds0, vaddr, rec);
+            lds_put<uint16_t>(lds0, cc + (unsigned)(u * PITCH + (S::CSEL ? 0 : VB)), (uint16_t)code);
+            lds_put<T>(lds0, pc + (unsigned)(u * PITCH), rec);
         } else {
             int cq = (int)tc_in;
             bool is_mean = false;
             if (USEMEAN) { is_mean = cq == radius; if (cq != 0 && cq < radius) cq += 1; }     // szd_float.c:3784
             const T mq = (T)(cq - radius) * eb2;
+            next_wrap<un2>();
             mask_t um = lane_mask(tc_in != 0u) & lane_mask(caphU[U] > (T)0);
             if (HASREG) um &= lane_mask(fl_in == 0u);
             SZH_SB;
@@ -489,39 +557,47 @@ struct beam {
             if (USEMEAN && is_mean) r = mean;
             rec = in_mask(um) ? r : cur;                                                       // zero code: the pre-scattered value
             if (EDGE) rec = started ? rec : (T)0;
-            lds_put<T>(lds0, vaddr, rec);
+            lds_put<T>(lds0, pc + (unsigned)(u * PITCH), rec);
         }
         // the last row of the upper half is the j-face of the wavefront above: kept where the lane made it, handed on at the end of the line
-        if (!(SZH_BM_X & 1)) face_reg = bsel(m_push[U], rec, face_reg);
+        face_reg = in_mask(m_vu[(U + 1) % LINE]) ? rec : face_reg;      // (the upper half's lanes whose NEXT cell is virtual)
         dl[U] = rec; lup[U] = L;
         Bold = B; Bpold = Bp;
-        Lprev = L; prev = rec;
-        vaddr = vnext;
+        Lprev = L; prev = rec; sw_junk = sw;
+        pcopy = rec; hide(pcopy);                                        // (a register of its own: the swap overwrites half of it)
+        pc = pn; cc = cn;
     }
 
     template <int LL, bool EDGE> __device__ __forceinline__ void line(int it)
     {
         // the wavefront below (in j) must be far enough ahead for the virtual cells read during this line, the one above not too far behind
         // (their progress words were read during the last step of the line before: no LDS round trip here unless one of them is late)
-        if (!(SZH_DEV && (dbg & 1))) {
-        if (has_prev && uni((int)pv_prev) < it + 3) wait_prog(prog + (w - 1), it + 3);
-        if (has_next && uni((int)pv_next) < it - (RL - 2)) wait_prog(prog + (w + 1), it - (RL - 2));
-        }
+        if (uni((int)pv_prev) < it + 3) wait_prog(prog + (w - 1), it + 3);
+        if (uni((int)pv_next) < it - (RL - 2)) wait_prog(prog + (w + 1), it - (RL - 2));
         for_n<LINE>([&](auto UU) {
             constexpr int U = decltype(UU)::value;
             wave_sync();
-            if (!(SZH_DEV && ((dbg >> U) & 1)) || U == 0) events<U, LL, EDGE>(it);
+            events<U, LL, EDGE>(it);
             order();
             step<U, LL, EDGE>(it);
             order();
         });
-        // the faces of this line go to the wavefront above: each lane's latest last-row result into the slot of that line's virtual cell in ITS
-        // ring (lanes of the lower half, and the workgroup's last wavefront: into their write-only word).  One write per line, not per step:
-        // the wavefront above waits for whole lines anyway (it + 3 below), so nothing arrives later than it is looked for
-        if (!(SZH_BM_X & 1)) lds_put<T>(lds0, pface, face_reg);
-        { const unsigned f = pface + (unsigned)LP; pface = pface_fixed ? pface : (f >= nring_lo + (unsigned)RINGB ? f - (unsigned)RINGB : f); }
-        lds_put<unsigned>((OC_LDS unsigned char *)(prog + w), 0, (unsigned)(it + 1));
-        lo_it = lo(1);
+        // the faces of this line go up: each lane's latest last-row result -- the virtual cell of line it - 1 - q(m) -- into that slot of the ring
+        // of the wavefront above (one write per line, not per step: the wavefront above waits for whole lines anyway), or, from the workgroup's
+        // last wavefront, into row `it` of the j-face granules
+        {
+            constexpr int ap = (LL + RL - 1) % RL;
+            if (has_next) {
+                // (the lower half's lanes write into the upper half's part of the same slots of the next ring: nobody reads those)
+                lds_put<T>(lds0, pf_at[ap], face_reg);
+            }
+            unsigned o, so;
+            place_row<EDGE>(rjo, it, str_j, so_jo, o, so);
+            GIO::st(rs_j, o, so, face_reg, epoch);
+            so_jo += str_j;
+        }
+        it_v += 1u;
+        lds_put<unsigned>(lds0, prog_at, it_v);
     }
     template <bool EDGE> __device__ __forceinline__ void block(int it0)
     {
@@ -531,16 +607,15 @@ struct beam {
     __device__ __forceinline__ void run(int kb, int jg, OC_LDS unsigned char *rings, OC_LDS unsigned *prog_)
     {
         const szh_geom3 &G = a.G;
-        prog = prog_; dbg = a.dbg;
-        r0 = G.g0.count;
+        prog = prog_;
+        r0 = G.g0.count; nwl = wave_lines(G);
         const int r1 = G.g1.count, r2 = G.g2.count;
         lane = (int)(threadIdx.x & 63u); w = uni((int)(threadIdx.x >> 6)); h = lane >> 5; m = lane & 31;
-        ring = rings + w * RINGB; nring = rings + (w + 1 < WPG ? w + 1 : w) * RINGB; kring = rings + (WPG * RINGB + WPG * 64 * 8) + w * S::KRB;
+        lds0 = rings;
         const grid_t gr = make_grid(G);
         const int k0 = kb * HL, jw0 = jg * JG + w * JW;
         has_prev = w > 0; has_next = w + 1 < WPG;
-        const bool jf_in = w == 0 && jg > 0, jf_out = w == WPG - 1 && jg + 1 < gr.nJG, kf_in = kb > 0, kf_out = kb + 1 < gr.nKB;
-        zero_face = w == 0 && jg == 0;
+        jf_in = w == 0 && jg > 0; jf_out = w == WPG - 1 && jg + 1 < gr.nJG; kf_in = kb > 0; kf_out = kb + 1 < gr.nKB;
         spin_limit = 1u << 22; timed_out = false;
         eb = a.eb; eb2 = eb + eb; rh = a.recip * (T)0.5; caph = (T)(a.cap - 2) * (T)0.5; radf = (T)a.radius; mean = a.mean; radius = a.radius; epoch = a.epoch;
         const int64_t wg = (int64_t)kb * gr.nJG + jg;
@@ -550,28 +625,29 @@ struct beam {
         rs_x = make_rsrc(HASREG && !DEC ? (const void *)a.xr : (const void *)a.codes, HASREG && !DEC ? (unsigned)nbytes : 0u);
         rs_f = make_rsrc(HASREG ? (const void *)a.ptflags : (const void *)a.codes, HASREG ? (unsigned)G.n : 0u);
         str_v = (unsigned)(G.d0 * SZ); str_c = (unsigned)(G.d0 * 2); str_k = (unsigned)(LINE * GIO::BYTES); str_j = (unsigned)(HL * GIO::BYTES);
+        ring_w = (unsigned)(w * RINGB);
         {   // value rows: 64 lanes x 16 B = RPE row pieces of HB bytes: RH rows of each half
             const int r = lane / S::LPR, p = lane - r * S::LPR, vh = r / S::RH;
             for (int e = 0; e < EV; ++e) {
-                const int rr = r % S::RH + S::RH * e, j = jw0 + C1 * vh + rr, kk = k0 + p * S::VPL;
+                const int rr = r % S::RH + S::RH * e, j = jw0 + C1 * vh + rr, kk = k0 + p * VPL;
                 const unsigned off = (unsigned)(((int64_t)j * G.d1 + kk) * SZ);
                 const bool in = j < r1 && kk < r2;
                 rv[e] = make_role(true, in ? off : 0u, vh, str_v);           // (rows outside the array: any readable place -- nobody looks at them)
                 rvs[e] = make_role(in, off, vh, str_v);
                 rf[e] = make_role(true, in ? off / (unsigned)SZ : 0u, vh, str_v / (unsigned)SZ);
                 vl[e] = (unsigned)((1 + rr) * PITCH + vh * S::HB + p * 16);
-                fl_lds[e] = (unsigned)((1 + rr) * PITCH + S::FOFF + vh * HL + p * S::VPL);
+                cw[e] = (unsigned)((1 + rr) * PITCH + VB + (vh * HL + p * VPL) * 4);
             }
         }
-        {   // code rows: 64 lanes x 8 B = 8 row pieces of 64 bytes
+        {   // code rows: 64 lanes x 8 B (4 codes; 16 B of the ring) = 8 row pieces of 64 bytes
             const int r = lane / 8, p = lane - r * 8, rr = r % C1, ch = r / C1, j = jw0 + C1 * ch + rr, kk = k0 + 4 * p;
             const unsigned off = (unsigned)(((int64_t)j * G.d1 + kk) * 2);
             const bool in = j < r1 && kk < r2;
             rc = make_role(true, in ? off : 0u, ch, str_c);
             rcs = make_role(in, off, ch, str_c);
-            cl = (unsigned)((1 + rr) * PITCH + S::VB + ch * 64 + p * 8);
-            cfl = (unsigned)((1 + rr) * PITCH + S::FOFF + ch * HL + p * 4);
+            cl = (unsigned)((1 + rr) * PITCH + VB + (ch * HL + p * 4) * 4);
         }
+        trash = (unsigned)(S::TRASH0 + (w * 64 + lane) * 8);       // (the lane's write-only word behind the last ring)
         {   // k-face granules: lane e < 10: cell e % 5 of half e / 5 of a wave line; [workgroup][8 half-beams][LINE r0 cells]
             const bool en = lane < 2 * LINE;
             const int khh = en ? lane / LINE : 0, kuu = en ? lane % LINE : 0;
@@ -581,52 +657,56 @@ struct beam {
             rko = make_role(en && kf_out, (unsigned)((((uint64_t)(wg * 8 + 2 * w + khh)) * cells + kuu) * GIO::BYTES), khh, str_k);
             rki = make_role(en && kf_in, (unsigned)((((uint64_t)(wgl * 8 + 2 * w + khh)) * cells + kuu) * GIO::BYTES), khh, str_k);
             ko_lds = (unsigned)(kuu * PITCH + khh * S::HB + (HL - 1) * SZ);
-            ki_lds = (en && kf_in) ? (unsigned)(kuu * 2 * SZ + khh * SZ) : (unsigned)(KRL * LINE * 2 * SZ);        // (other lanes: a write-only word behind the ring)
+            // (lanes that take no part write to their write-only word; the line term of the address stays within the slack behind those words)
+            ki_lds = (en && kf_in) ? (unsigned)(S::KR0 + w * S::KRB + kuu * 2 * SZ + khh * SZ) : trash;
         }
-        {   // j-face granules: lane e < 32: column e of the row; [workgroup][r0 lines][32]; out: the upper half's last row (a line behind), in: the lower half's virtual cell
-            const bool en = lane < HL;
+        {   // j-face granules [workgroup][wave line][32]: out: the upper half's lanes, row `it`; in: the lower half's lanes, row it + 3
             const int64_t wgl = (int64_t)kb * gr.nJG + (jg > 0 ? jg - 1 : 0);
             rs_j = make_rsrc(a.faceJ, (unsigned)(jface_words<T>(G) * 8));
-            rjo = make_role(en && jf_out, (unsigned)(((uint64_t)wg * r0 * HL + (unsigned)(lane & 31)) * GIO::BYTES), 1, str_j);
-            rji = make_role(en && jf_in, (unsigned)(((uint64_t)wgl * r0 * HL + (unsigned)(lane & 31)) * GIO::BYTES), 0, str_j);
-            jo_lds = (unsigned)(C1 * PITCH + S::HB + (lane & 31) * SZ);
-            ji_lds = (en && jf_in) ? (unsigned)((lane & 31) * SZ) : (unsigned)(RINGB * (WPG - w) + (w * 64 + lane) * 8);     // (the others: their write-only slot behind the rings)
+            rjo = make_role(h == 1 && jf_out, (unsigned)(((uint64_t)wg * (unsigned)nwl * HL + (unsigned)m) * GIO::BYTES), 0, str_j);
+            rji = make_role(h == 0 && jf_in, (unsigned)(((uint64_t)wgl * (unsigned)nwl * HL + (unsigned)m) * GIO::BYTES), 0, str_j);
         }
+        idle_k = ~lane_mask(rki.plain != SZH_BM_OOB); idle_j = ~lane_mask(rji.plain != SZH_BM_OOB);
         for (int u = 0; u < LINE; ++u) { dl[u] = 0; lup[u] = 0; }
-        prev = 0; Lprev = 0; Bold = 0; Bpold = 0;
-        lds0 = rings;                                   // (the addresses below are relative to the rings' first byte; the write-only words and the k-face rings follow the rings in one array)
-        const unsigned ring_lo = (unsigned)(w * RINGB);
-        ring_end = ring_lo + (unsigned)RINGB; nring_lo = ring_end;
-        {   // after wave line `it` the lane's latest finished last-row cell belongs to beam line it - 1 - ceil(m / LINE): the slot of THAT line's
-            // virtual cell in the next ring (lines before the array's first: slots nobody has looked at yet)
-            const int L0 = -1 - (m + LINE - 1) / LINE;
-            pface_fixed = !(h == 1 && has_next);
-            pface = pface_fixed ? (unsigned)(WPG * RINGB + (w * 64 + lane) * 8)
-                                : ring_end + (unsigned)((((L0 % RL) + RL) % RL) * LP + m * SZ);
-            face_reg = 0;
-        }
-        vaddr = ring_lo + (unsigned)(((RS - m) % RS) * PITCH + h * S::HB + m * SZ);
-        m_first = m == 0 ? 0xffffffffu : 0u;
-        for (int u = 0; u < LINE; ++u) {
-            const bool virt = ((u - m) % LINE + LINE) % LINE == 0, last = ((u - m) % LINE + LINE) % LINE == C1;
-            m_vu[u] = (virt && h == 1) ? 0xffffffffu : 0u;
-            m_push[u] = (last && h == 1) ? 0xffffffffu : 0u;
-            caphU[u] = virt ? (T)-1 : caph;
-            hide(m_vu[u]); hide(m_push[u]); hide(caphU[u]);        // (kept in registers: hipcc otherwise rebuilds them from the lane number as scalar lane masks, ~20 SGPRs and their spills)
-        }
-        hide(m_first);
-        cdelta = (unsigned)(S::VB + h * 64 + m * 2) - (unsigned)(h * S::HB + m * SZ);
-        fdelta = (unsigned)(S::FOFF + lane) - (unsigned)(h * S::HB + m * SZ);
-        kaddr_h = (unsigned)(WPG * RINGB + WPG * 64 * 8 + w * S::KRB + h * SZ);
-        trash = (unsigned)(WPG * RINGB + (w * 64 + lane) * 8);       // (the lane's write-only word behind the last ring)
+        prev = 0; Lprev = 0; Bold = 0; Bpold = 0; sw_junk = 0; face_reg = 0; pcopy = 0;
+        // the lane's slot at unrolled step u is (u - m) modulo RS: pB + u PITCH from u = m on, pA + u PITCH before
+        pB = ring_w + (unsigned)(h * S::HB + m * SZ) - (unsigned)(m * PITCH); pA = pB + (unsigned)RINGB;
+        cB = ring_w + (unsigned)(VB + lane * 4) - (unsigned)(m * PITCH); cA = cB + (unsigned)RINGB;
+        mreg = (unsigned)m; qreg = (unsigned)((m + LINE - 1) / LINE);
+        // faces: after wave line `it` the lane's latest finished last-row cell belongs to beam line it - 1 - q (q = ceil(m / LINE)): the slot of THAT
+        // line's virtual cell -- in the next ring (push), or, for the granules of row X = it + 3, in this one (line it + 2 - q)
+        // (the lanes of the half that takes no part aim at the other half's part of the same slots)
+        for_n<RL>([&](auto A_) {
+            constexpr int a_ = decltype(A_)::value;
+            const unsigned ls = (unsigned)(((a_ - (int)qreg) % RL + RL) % RL) * (unsigned)LP;
+            pf_at[a_] = ring_w + (unsigned)RINGB + (unsigned)((1 - h) * S::HB + m * SZ) + ls; hide(pf_at[a_]);
+            ji_at[a_] = ring_w + (unsigned)(h * S::HB + m * SZ) + ls; hide(ji_at[a_]);
+        });
+        prog_prev_at = (unsigned)(S::PROG0 + 4 * (has_prev ? w - 1 : WPG)); hide(prog_prev_at);
+        prog_next_at = (unsigned)(S::PROG0 + 4 * (has_next ? w + 1 : WPG)); hide(prog_next_at);
+        prog_at = (unsigned)(S::PROG0 + 4 * w); hide(prog_at); it_v = 0u;
+        upper_m = UPPER;
+        m_first = FIRSTCOL; hide(m_first);
+        for_n<LINE>([&](auto UU) {
+            constexpr int u = decltype(UU)::value;
+            const bool virt = ((u - m) % LINE + LINE) % LINE == 0;
+            m_vu[u] = virt_upper_mask<u>(); hide(m_vu[u]);
+            caphU[u] = virt ? (T)-1 : caph; hide(caphU[u]);
+        });
+        kaddr_h = (unsigned)(S::KR0 + w * S::KRB + h * SZ);
         tstart = (unsigned)(m + LINE * h);
-        lo_it = 0u;
-        // the k-face ring reads zeros where nothing arrives (no beam on the left)
-        for (int e = lane; e < S::KRB / 4; e += 64) lds_put<unsigned>(kring, (unsigned)e * 4u, 0u);
+        {   // the k-face ring reads zeros where nothing arrives (no tile on the left); the virtual cells of the array's lower face read zeros (a
+            // virtual cell writes back what it read, so they stay zeros), as do those of lines the wavefront below has not pushed yet
+            OC_LDS unsigned char *kring = rings + S::KR0 + w * S::KRB;
+            for (int e = lane; e < S::KRB / 4; e += 64) lds_put<unsigned>(kring, (unsigned)e * 4u, 0u);
+            const v4u z = {0u, 0u, 0u, 0u};
+            for (int e = lane; e < RL * (S::HB / 16); e += 64) lds_put16(lds0, ring_w + (unsigned)((e / (S::HB / 16)) * LP + (e % (S::HB / 16)) * 16), z);
+        }
         // (arrays with regression blocks whose points arrive WHILE the sweep runs -- a.reg_ready, see wait_fed: nothing of a plane is asked for before it is there)
         fed = 0; feed_late = false;
         if (a.reg_ready) wait_fed(UL + 2);
         // ---- prologue: the first lines' rows are requested; line 0 goes into the ring
+        so_vl = 0u; so_xl = 0u; so_fl = 0u; so_cl = 0u; so_vs = 0u; so_cs = 0u; so_ko = 0u; so_ki = 0u; so_jo = 0u; so_ji = 0u;
         {
             v4u first[EV], firstx[EV]; unsigned firstf[EV];
             for_n<EV>([&](auto E) {
@@ -636,57 +716,78 @@ struct beam {
                 firstf[e] = HASREG ? load_f<true>(0, e) : 0u;
             });
             for_n<UL>([&](auto L_) { constexpr int LL = decltype(L_)::value; for_n<EV>([&](auto E) {
-                constexpr int e = decltype(E)::value, set = ((LL + 1) * EV + e) % DV;
+                constexpr int e = decltype(E)::value, set = LL * EV + e;
                 gv[set] = load_v<true>(LL + 1, e);
                 if (HASREG && !DEC) gx[HASREG && !DEC ? set : 0] = load_x<true>(LL + 1, e);
                 if (HASREG) gf[HASREG ? set : 0] = load_f<true>(LL + 1, e);
             }); });
-            for_n<EV>([&](auto E) { constexpr int e = decltype(E)::value; put_rows(0u, e, first[e], firstx[e], firstf[e]); });
-            if (zero_face) { const v4u z = {0u, 0u, 0u, 0u}; if (lane < S::HB / 16) lds_put16(ring, (unsigned)lane * 16u, z); }
-            if (!DEC && HASREG) for_n<UL>([&](auto L_) { constexpr int LL = decltype(L_)::value; gc[LL] = load_c<true>(LL - LAG); });
             if (DEC) {
                 const cpiece_t c0 = load_c<true>(0);
-                for_n<UL>([&](auto L_) { constexpr int LL = decltype(L_)::value; gc[(LL + 1) % UL] = load_c<true>(LL + 1); });
-                lds_put8(ring, cl, c0);
+                for_n<UL>([&](auto L_) { constexpr int LL = decltype(L_)::value; gc[LL] = load_c<true>(LL + 1); });
+                put_codes(0u, c0);
+                wave_sync();
             }
-            const greg_t k0g = load_k<true>(0), j0g = load_j<true>(0);
-            for_n<DK>([&](auto L_) { constexpr int LL = decltype(L_)::value; gk[(LL + 1) % DK] = load_k<true>(LL + 1); gj[(LL + 1) % DK] = load_j<true>(LL + 1); });
-            take<true, true>(0, k0g, kring, 0u);
-            take<true, false>(0, j0g, ring, 0u);
+            for_n<EV>([&](auto E) { constexpr int e = decltype(E)::value; put_rows(0u, e, first[e], firstx[e], firstf[e]); });
+            if (!DEC && HASREG) for_n<UL>([&](auto L_) { constexpr int LL = decltype(L_)::value; gc[LL] = load_c<true>(LL - LAG); });
+            // granules: k-face row 0 (taken now), rows 1 .. DK on their way; j-face rows 0 .. 2 (lines -q .. 1 - q: taken now, the first virtual cells
+            // are read from step 0 on), rows 3 .. 2 + DK on their way
+            const greg_t k0g = load_k<true>(0);
+            const greg_t j0g = load_j<true>(0), j1g = load_j<true>(1), j2g = load_j<true>(2);
+            for_n<DK>([&](auto L_) { constexpr int LL = decltype(L_)::value; gk[LL] = load_k<true>(LL + 1); gj[LL] = load_j<true>(LL + 3); });
+            if (kf_in) {
+                const bool need = rki.plain != SZH_BM_OOB && (unsigned)(0 - rki.half) < (unsigned)r0;
+                const greg_t g = arrived<true>(0, k0g, ~lane_mask(need));
+                lds_put<T>(lds0, ki_lds, need ? GIO::val(g) : (T)0);
+            }
+            if (jf_in) {
+                // row X carries the virtual cell of line X - 1 - q: rows 0 .. 2 hold lines that exist only for X - 1 - q >= 0
+                const greg_t jg3[3] = {j0g, j1g, j2g};
+                for (int X = 0; X < 3; ++X) {
+                    const int ln = X - 1 - (int)qreg;
+                    const bool need = rji.plain != SZH_BM_OOB && ln >= 0;
+                    const greg_t g = arrived<false>(X, jg3[X], ~lane_mask(need));
+                    if (need) lds_put<T>(lds0, ring_w + (unsigned)((ln % RL) * LP + m * SZ), GIO::val(g));
+                }
+            }
         }
+        // (EDGE blocks place every access themselves, soff = 0; the first block inside the array starts its streams where they stand then)
         if (has_prev) wait_prog(prog + (w - 1), 3);
-        pv_prev = 0u; pv_next = 0u;
+        pv_prev = (unsigned)SZH_BM_INF; pv_next = (unsigned)SZH_BM_INF;
         order();
         wave_sync();
-        cur_next = lds_get<T>(lds0, vaddr);
-        tc_next = DEC ? (unsigned)lds_get<uint16_t>(lds0, vaddr + cdelta) : 0u;
-        fl_next = HASREG ? (unsigned)lds_get<uint8_t>(lds0, vaddr + fdelta) : 0u;
+        pc = mreg > 0u ? pA : pB; cc = S::CSEL ? (mreg > 0u ? cA : cB) : pc;
+        wrapm_next = lane_mask(mreg > 1u);                                // (step 0 selects the slot of step 1)
+        cur_next = lds_get<T>(lds0, pc);
+        tc_next = DEC ? (unsigned)lds_get<uint16_t>(lds0, cc + (unsigned)(S::CSEL ? 0 : VB)) : 0u;
+        fl_next = HASREG ? (unsigned)lds_get<uint8_t>(lds0, cc + (unsigned)((S::CSEL ? 0 : VB) + 2)) : 0u;
         kf_next = lds_get<T>(lds0, kaddr_h);
-        { const v4u z = {0u, 0u, 0u, 0u}; for (int e = 0; e < EV; ++e) wqv[e] = z; wqc.x = 0u; wqc.y = 0u; wfl = 0u; }
+        { const v4u z = {0u, 0u, 0u, 0u}; for (int e = 0; e < EV; ++e) wqv[e] = z; wqc4 = z; }
         // ---- the lines: every lane has left line it - LAG when lane 0 enters line it.  Blocks of UL lines; the ones in which every line any
         // lane asks for or stores exists take the variant without per-lane line checks
-        const int NWL = r0 + 1 + LAG, nblk = (NWL + UL - 1) / UL;
-        wt_codes = !DEC && a.tile_done != nullptr;
+        const int nblk = nwl / UL;
         unsigned *const pub = (!DEC && a.tile_done) ? a.tile_done + (((int64_t)kb * gr.nJG + jg) * WPG + w) : nullptr;     // (uniform)
-        const int PUBB = (a.pub_lines > 0 ? a.pub_lines : 32) / UL > 0 ? (a.pub_lines > 0 ? a.pub_lines : 32) / UL : 1;     // blocks between two words (a word every 32 lines by default)
+        const int PUBB = (a.pub_lines > 0 ? a.pub_lines : 32) / UL > 0 ? (a.pub_lines > 0 ? a.pub_lines : 32) / UL : 1;     // blocks between two words (a word every ~32 lines by default)
 #pragma unroll 1
         for (int b = 0; b < nblk; ++b) {
             const int it0 = b * UL;
+            hide(mreg);
             if (a.reg_ready) wait_fed(it0 + 2 * UL + 1);          // (the block's lines ask for rows up to wave line it0 + 2 UL)
-#ifdef SZH_BM_ISA_MID_ONLY          /* (ISA inspection of the steady-state block only: wrong results) */
-            block<false>(it0);
-#else
-            if (it0 >= LAG + 1 && it0 <= r0 - 1 - 2 * UL) block<false>(it0); else block<true>(it0);
-#endif
+            const bool mid = it0 >= LAG + 1 && it0 + 2 * UL <= r0 - 1;
+            if (mid) {
+                // the streams' scalar offsets for this block: wave line X of a stream is at (X - 1) stride (rows of the j-face: X stride)
+                so_vl = (unsigned)(it0 + UL) * str_v; so_fl = (unsigned)(it0 + UL) * (str_v / (unsigned)SZ); so_cl = (unsigned)(it0 + UL) * str_c;
+                so_vs = (unsigned)(it0 - LAG - 1) * str_v; so_cs = (unsigned)(it0 - LAG - 1) * str_c;
+                so_ko = (unsigned)(it0 - LAG - 1) * str_k; so_ki = (unsigned)(it0 + DK) * str_k;
+                so_jo = (unsigned)it0 * str_j; so_ji = (unsigned)(it0 + 3 + DK) * str_j;
+                block<false>(it0);
+            } else block<true>(it0);
             // the host starts the entropy stage's passes over lines every wavefront has passed (szhip.hip): how many of THIS wavefront's lines have
-            // their codes in memory -- a release at system scope (this XCD's L2 is written back first), the launch's epoch beside the count
+            // their codes in memory -- the launch's epoch beside the count
             if (pub && ((b + 1) % PUBB == 0 || b + 1 == nblk)) {
                 int rows = b + 1 == nblk ? r0 : it0 + UL - 1 - LAG;
                 rows = rows < 0 ? 0 : (rows > r0 ? r0 : rows);
                 if (b + 1 == nblk || rows > 0) {
                     // the codes went out write-through (sc0 sc1): once this wavefront's memory counter is empty they are in memory, and the word may follow.
-                    // (A release at system scope -- which writes the XCD's L2 back -- cost ~35 us a time here with every CU storing codes: 16 words a
-                    // wavefront took the sweep from 1.05 to 1.6 ms at 512^3.)
 #ifndef SZH_HIPSIM
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -747,14 +848,14 @@ template <class T, bool DEC, bool USEMEAN, bool HASREG>
 __global__ __launch_bounds__(szh_bm::WPG * 64, 1) void k_beam(szh_qargs<T> a)
 {
     using namespace szh_bm;
-    typedef shape<T, HASREG> S;
-    __shared__ __attribute__((aligned(16))) unsigned char rings[WPG * S::RINGB + WPG * 64 * 8 + WPG * S::KRB];     // rings, write-only words of lanes without a face value, k-face rings
-    __shared__ unsigned prog[WPG + 2];
+    typedef shape<T> S;
+    __shared__ __attribute__((aligned(16))) unsigned char rings[S::LDSB];     // rings, write-only words of lanes without a face value, k-face rings
     __shared__ unsigned tk_s;
+    OC_LDS unsigned *const prog = (OC_LDS unsigned *)((OC_LDS unsigned char *)rings + S::PROG0);
     const unsigned ntiles = (unsigned)(a.nI * a.nJ);
     for (unsigned itile = 0;; ++itile) {
         __syncthreads();
-        if (threadIdx.x < WPG + 2) prog[threadIdx.x] = 0;
+        if (threadIdx.x < WPG + 2) prog[threadIdx.x] = threadIdx.x == WPG ? (unsigned)SZH_BM_INF : 0u;
         if (threadIdx.x == 0) {
             const unsigned t = a.ticket_mode ? blockIdx.x + itile * gridDim.x : atomicAdd(a.ticket, 1u);
             tk_s = t < ntiles ? szh_pencil_order_at(a.nI, a.nJ, t) : 0xffffffffu;
@@ -763,6 +864,6 @@ __global__ __launch_bounds__(szh_bm::WPG * 64, 1) void k_beam(szh_qargs<T> a)
         const unsigned ij = (unsigned)szh_bm::uni((int)tk_s);
         if (ij == 0xffffffffu) break;
         beam<T, DEC, USEMEAN, HASREG> s(a);
-        s.run((int)(ij >> 16), (int)(ij & 0xffffu), (OC_LDS unsigned char *)rings, (OC_LDS unsigned *)prog);
+        s.run((int)(ij >> 16), (int)(ij & 0xffffu), (OC_LDS unsigned char *)rings, prog);
     }
 }
