@@ -721,7 +721,7 @@ void *detransposeData(void *data, int dataType, size_t r5, size_t r4, size_t r3,
     return o;
 }
 
-static void omp_decompress(int dataType, void **data, size_t r1, size_t r2, size_t r3, unsigned char *comp_data);
+static void omp_decompress(int dataType, void **data, size_t r1, size_t r2, size_t r3, unsigned char *comp_data, size_t avail);
 static void *decompress_fp(int dataType, unsigned char *cmpBytes, size_t cmpSize, size_t r5, size_t r4, size_t r3, size_t r2, size_t r1)
 {
     const size_t esz = dataType == SZ_FLOAT ? 4 : 8;
@@ -807,7 +807,8 @@ static void *decompress_fp(int dataType, unsigned char *cmpBytes, size_t cmpSize
          * 4 + MetaDataByteLength bytes for both types (sz_omp.c:221, :733) */
         void *o2 = NULL;
         free(out);
-        omp_decompress(dataType, &o2, r3, r2, r1, sz + 4 + MetaDataByteLength);
+        if (szlen >= 4 + (size_t)MetaDataByteLength) omp_decompress(dataType, &o2, r3, r2, r1, sz + 4 + MetaDataByteLength, szlen - 4 - (size_t)MetaDataByteLength);
+        else printf("Error: truncated OpenMP-container stream.\n");
         if (owned) free(sz);
         return o2;
     }
@@ -1059,9 +1060,11 @@ static unsigned char *omp_compress_at(int dataType, const void *oriData, int on_
     *comp_size = n;
     return out;
 }
-/* `comp_data`: the stream behind its 4 + MetaDataByteLength leading bytes, as the reference's callers pass it (example/sz_openmp.c:580);
- * there is no length argument, so the extent is read off the stream's own tables */
-static void omp_decompress(int dataType, void **data, size_t r1, size_t r2, size_t r3, unsigned char *comp_data)
+/* `comp_data`: the stream behind its 4 + MetaDataByteLength leading bytes, as the reference's callers pass it (example/sz_openmp.c:580).
+ * `avail`: the bytes there are behind that pointer -- SZ_decompress knows (a crafted frame must not send the table walk below out of the buffer:
+ * every offset is checked against it before it is read); the reference-signature entry points have no length argument and pass SIZE_MAX:
+ * there the extent is read off the stream's own tables, as the reference does */
+static void omp_decompress(int dataType, void **data, size_t r1, size_t r2, size_t r3, unsigned char *comp_data, size_t avail)
 {
     if (!data) return;
     *data = NULL;
@@ -1070,18 +1073,34 @@ static void omp_decompress(int dataType, void **data, size_t r1, size_t r2, size
     if (!ctx) return;
     const size_t esz = dataType == SZ_FLOAT ? 4 : 8;
     const unsigned char *q = comp_data;
+    const size_t head = 4 + esz + 12;
+    if (avail < head) { printf("Error: truncated OpenMP-container stream.\n"); return; }
     const unsigned thread_num = szhost_get_u32be(q);
     const size_t tree_bytes = szhost_get_u32be(q + 4 + esz + 4);
     if (thread_num == 0 || thread_num > (1u << 30)) { printf("Error: not an OpenMP-container stream.\n"); return; }
     size_t nx, ny, nz; omp_grid((int)thread_num, &nx, &ny, &nz);
     const size_t nb = nx * ny * nz;
-    q += 4 + esz + 12 + tree_bytes;
+    /* the box grid must fit the array (a box holds at least one value) and every table must lie within the stream */
+    const size_t nvals = r1 * r2 * r3;
+    if (nb == 0 || nb > nvals) { printf("Error: OpenMP-container stream: %zu boxes for a %zu x %zu x %zu array.\n", nb, r1, r2, r3); return; }
+    size_t off = head;
+    if (tree_bytes > avail - off) { printf("Error: truncated OpenMP-container stream.\n"); return; }
+    off += tree_bytes;
+    if (nb > (avail - off) / (4 + esz)) { printf("Error: truncated OpenMP-container stream.\n"); return; }
+    q = comp_data + off;
     size_t total_un = 0;
     for (size_t b = 0; b < nb; ++b) { uint32_t c; memcpy(&c, q + b * 4, 4); total_un += c; }
-    q += nb * 4 + nb * esz + total_un * esz;
+    if (total_un > nvals) { printf("Error: OpenMP-container stream: more verbatim values than values.\n"); return; }
+    off += nb * 4 + nb * esz;
+    if (total_un > (avail - off) / esz) { printf("Error: truncated OpenMP-container stream.\n"); return; }
+    off += total_un * esz;
+    if (nb > (avail - off) / 8) { printf("Error: truncated OpenMP-container stream.\n"); return; }
+    q = comp_data + off;
     size_t pay = 0;
-    for (size_t b = 0; b < nb; ++b) { uint64_t s; memcpy(&s, q + b * 8, 8); pay += (size_t)s; }
-    const size_t total = (size_t)(q - comp_data) + nb * 8 + pay;
+    for (size_t b = 0; b < nb; ++b) { uint64_t s; memcpy(&s, q + b * 8, 8); if (s > avail || pay > avail) { pay = (size_t)-1; break; } pay += (size_t)s; }
+    off += nb * 8;
+    if (pay == (size_t)-1 || pay > avail - off) { printf("Error: truncated OpenMP-container stream.\n"); return; }
+    const size_t total = off + pay;
     void *out = malloc(r1 * r2 * r3 * esz ? r1 * r2 * r3 * esz : 1);
     if (!out) return;
     const int rc = szhip_decompress_omp(ctx, dataType == SZ_FLOAT ? SZHIP_F32 : SZHIP_F64, comp_data, 0, total, 0, r1, r2, r3, out, 0, &g_last_stats);
@@ -1093,9 +1112,9 @@ unsigned char *SZ_compress_float_3D_MDQ_openmp(float *oriData, size_t r1, size_t
 unsigned char *SZ_compress_double_3D_MDQ_openmp(double *oriData, size_t r1, size_t r2, size_t r3, double realPrecision, size_t *comp_size)
 { return omp_compress(SZ_DOUBLE, oriData, r1, r2, r3, realPrecision, comp_size); }
 void decompressDataSeries_float_3D_openmp(float **data, size_t r1, size_t r2, size_t r3, unsigned char *comp_data)
-{ omp_decompress(SZ_FLOAT, (void **)data, r1, r2, r3, comp_data); }
+{ omp_decompress(SZ_FLOAT, (void **)data, r1, r2, r3, comp_data, (size_t)-1); }
 void decompressDataSeries_double_3D_openmp(double **data, size_t r1, size_t r2, size_t r3, unsigned char *comp_data)
-{ omp_decompress(SZ_DOUBLE, (void **)data, r1, r2, r3, comp_data); }
+{ omp_decompress(SZ_DOUBLE, (void **)data, r1, r2, r3, comp_data, (size_t)-1); }
 
 /* the rest of sz/include/sz_omp.h and sz.h's thread helpers, so that callers written for an OpenMP build link unchanged:
  * sz_set_num_threads (sz_omp.c:49-53) sets the box count as omp_set_num_threads does for an OpenMP build; the 1-D / 2-D entry points

@@ -54,19 +54,25 @@ using szh_oc::order;
 using szh_oc::wave_sync;
 typedef szh_rb::v4u v4u;
 
-constexpr int C1 = 4, LINE = C1 + 1, HL = 32, WPG = 4, RL = 9, RS = RL * LINE, UL = RL, KRL = 3, DK = 3;
+#ifndef SZH_BM_DK
+#define SZH_BM_DK 1
+#endif
+constexpr int C1 = 4, LINE = C1 + 1, HL = 32, WPG = 4, RL = 9, RS = RL * LINE, UL = RL, KRL = 3, DK = SZH_BM_DK;
 constexpr int JW = 2 * C1, JG = JW * WPG;          // rows j per wavefront / per workgroup
 constexpr int LAG = 7;                              // lines after which every lane has left a line (31 steps of skew + the upper half's line)
 #define SZH_BM_INF (1 << 30)
+#ifndef SZH_BM_X
+#define SZH_BM_X 0     /* tools/ubench/ub_beam.hip only (timing, results wrong): 1 plain code stores, 2 no code stores, 4 no granule stores, 8 no progress checks, 16 no k-face read, 32 no value read, 64 no ring writes, 128 no events, 256 no swap, 512 no slot select, 1024 no face select, 2048 nothing at the end of a line, 4096 no progress reads */
+#endif
 static_assert(UL % KRL == 0 && UL % DK == 0 && RL >= LAG + 2, "ring geometry");
 
 template <class T> struct shape {
     static constexpr int SZ = (int)sizeof(T), VPL = 16 / SZ, LPR = HL / VPL, RPE = 64 / LPR, RH = RPE / 2, EV = C1 / RH;
     static constexpr int HB = HL * SZ, VB = 2 * HB, CBW = 64 * 4, PITCH = VB + CBW, LP = LINE * PITCH, RINGB = RS * PITCH;
-    static constexpr int KRB = KRL * LINE * 2 * SZ + 16; // k-face ring of a wavefront (+ a write-only word)
+    static constexpr int KHS = 8 * SZ, KLS = 2 * KHS, KRB = KRL * KLS;   // k-face ring of a wavefront: per line and half 8 slots (LINE of them used: the line's cells), read 16 bytes at a time
     // LDS of a workgroup: the rings | a write-only word per lane (+ slack: a lane that takes no part in an event writes there, line term included) | the k-face rings
     // | the wavefronts' progress words |
-    static constexpr int TRASH0 = WPG * RINGB, PROG0 = TRASH0 + WPG * 64 * 8 + 256, KR0 = PROG0 + 64, LDSB = KR0 + WPG * KRB;
+    static constexpr int TRASH0 = WPG * RINGB, PROG0 = TRASH0 + WPG * 64 * 8 + 512, KR0 = PROG0 + 64, LDSB = KR0 + WPG * KRB;
     static constexpr bool CSEL = SZ != 4;           // the lane's code is NOT a constant away from its value: a second pair of lane constants
     static_assert(PITCH % 128 == 0 && EV >= 1, "ring geometry");
 };
@@ -235,7 +241,7 @@ struct beam {
     unsigned str_v, str_c, str_k, str_j;                           // bytes per line of each
     unsigned so_vl, so_xl, so_fl, so_cl, so_vs, so_cs, so_ko, so_ki, so_jo, so_ji;   // (uniform) the streams' running scalar offsets, see place()
     // per-lane state of the sweep
-    T dl[LINE], lup[LINE], prev, Lprev, Bold, Bpold, cur_next, kf_next, face_reg, sw_junk, pcopy;
+    T dl[LINE], lup[LINE], prev, Lprev, Bold, Bpold, cur_next, kfv[LINE], kfn[LINE], face_reg, sw_junk, pcopy;
     mask_t wrapm_next;
     unsigned tc_next, fl_next;
     unsigned pA, pB, cA, cB, mreg, qreg;                           // the lane's slot: p? + u PITCH (A: before its wrap, u < m; B: after); its code (CSEL)
@@ -362,7 +368,7 @@ struct beam {
     // (`idle`: the lanes that need nothing of the row)
     template <bool KFACE> __device__ __forceinline__ greg_t arrived(int X, greg_t g, mask_t idle)
     {
-        if ((lane_mask(GIO::ok(g, epoch)) | idle) != ~0ull) {
+        if (__builtin_expect((lane_mask(GIO::ok(g, epoch)) | idle) != ~0ull, 0)) {      // (unlikely: the fast path must fall through -- a taken branch costs an instruction fetch)
             unsigned spins = 0;
 #pragma unroll 1
             do {
@@ -389,7 +395,7 @@ struct beam {
         if constexpr (U == 2) {
             unsigned o, so;
             place<EDGE>(rko, it - LAG, str_k, so_ko, o, so);
-            GIO::st(rs_k, o, so, ko_val, epoch);
+            if (!(SZH_BM_X & 4)) GIO::st(rs_k, o, so, ko_val, epoch);
             so_ko += str_k;
             if (!DEC) {
                 cpiece_t out; out.x = pack2(wqc4.x, wqc4.y); out.y = pack2(wqc4.z, wqc4.w);
@@ -402,7 +408,7 @@ struct beam {
                     gc[LL] = load_c<true>(it - LAG + UL);
                 }
                 place<EDGE>(rcs, it - LAG, str_c, so_cs, o, so);
-                bst8<17>(rs_c, o, so, out);      // (written through: the host may follow this sweep's progress, see `pub` in run; the codes are read next by other kernels, from memory either way)
+                if (SZH_BM_X & 1) bst8<0>(rs_c, o, so, out); else if (!(SZH_BM_X & 2)) bst8<17>(rs_c, o, so, out);      // (written through: the host may follow this sweep's progress, see `pub` in run; the codes are read next by other kernels, from memory either way)
                 so_cs += str_c;
             } else {
                 for_n<EV>([&](auto E) { constexpr int e = decltype(E)::value; place<EDGE>(rvs[e], it - LAG, str_v, so_vs, o, so); bst16<0>(rs_v, o, so, wqv[e]); });
@@ -420,34 +426,43 @@ struct beam {
             });
             so_vl += str_v; if (HASREG) so_fl += str_v / (unsigned)SZ;
         }
-        if constexpr (U == 3) {
-            constexpr int set = LL % DK;
-            {   // the k-face of wave line it + 1 goes into the k-face ring
-                const bool need = rki.plain != SZH_BM_OOB && (!EDGE || (unsigned)(it + 1 - rki.half) < (unsigned)r0);
-                if (kf_in) {
-                    const greg_t g = arrived<true>(it + 1, gk[set], EDGE ? ~lane_mask(need) : idle_k);
-                    lds_put<T>(lds0, ki_lds + (unsigned)(((LL + 1) % KRL) * LINE * 2 * SZ), (!EDGE || need) ? GIO::val(g) : (T)0);
-                }
-                gk[set] = load_k<EDGE>(it + 1 + DK);
-                so_ki += str_k;
-            }
-            {   // row it + 3 of the j-face of the workgroup below: lane m's value is the virtual cell of line it + 2 - q(m)
-                constexpr int aj = (LL + 2) % RL;
-                const bool need = rji.plain != SZH_BM_OOB && (!EDGE || (unsigned)(it + 3) < (unsigned)nwl);
-                if (jf_in) {
-                    const greg_t g = arrived<false>(it + 3, gj[set], EDGE ? ~lane_mask(need) : idle_j);
-                    // (the upper half's lanes write into the upper half's part of the same slots: nobody reads a virtual cell of the upper half from the ring)
-                    lds_put<T>(lds0, ji_at[aj], (!EDGE || need) ? GIO::val(g) : (T)0);
-                }
-                gj[set] = load_j<EDGE>(it + 3 + DK);
-                so_ji += str_j;
-            }
-        }
-        if constexpr (U == 4) {
+        if constexpr (U == 2) {
             // (a wavefront without a neighbour reads the word that always says "far ahead")
             pv_prev = lds_get<unsigned>(lds0, prog_prev_at);
             pv_next = lds_get<unsigned>(lds0, prog_next_at);
         }
+        if constexpr (U == 3) {
+            // Everything the NEXT wave line needs from others, tested in ONE branch (a conditional branch, taken or not, costs a wavefront alone on its
+            // SIMD the better part of a step: it has to wait for the compare behind it): the k-face granules of wave line it + 1 and the j-face
+            // granules of row it + 3 (lane m's value is the virtual cell of line it + 2 - q(m)) have arrived; the wavefront below (in j) is far enough
+            // ahead for the virtual cells read from line it + 1 on (it has finished wave line it + 3), the one above not too far behind.  All of
+            // that is the usual case; otherwise `late` sorts it out.
+            constexpr int set = LL % DK, aj = (LL + 2) % RL;
+            const bool need_k = rki.plain != SZH_BM_OOB && (!EDGE || (unsigned)(it + 1 - rki.half) < (unsigned)r0);
+            const bool need_j = rji.plain != SZH_BM_OOB && (!EDGE || (unsigned)(it + 3) < (unsigned)nwl);
+            const mask_t idk = EDGE ? ~lane_mask(need_k) : idle_k, idj = EDGE ? ~lane_mask(need_j) : idle_j;
+            greg_t g_k = gk[set], g_j = gj[set];
+            if (!(SZH_BM_X & 65536)) {
+                const mask_t both = (lane_mask(GIO::ok(g_k, epoch)) | idk) & (lane_mask(GIO::ok(g_j, epoch)) | idj);
+                const int pvp = uni((int)pv_prev), pvn = uni((int)pv_next);
+                const unsigned behind = (unsigned)((pvp - (it + 4)) | (pvn - (it - (RL - 3)))) >> 31;      // (a sign bit: one of them is short)
+                if (__builtin_expect((unsigned)(both != ~0ull) | ((SZH_BM_X & 8) ? 0u : behind), 0)) {
+                    g_k = arrived<true>(it + 1, g_k, idk);
+                    g_j = arrived<false>(it + 3, g_j, idj);
+                    if (!(SZH_BM_X & 8)) {
+                        if (pvp < it + 4) wait_prog(prog + (w - 1), it + 4);
+                        if (pvn < it - (RL - 3)) wait_prog(prog + (w + 1), it - (RL - 3));
+                    }
+                }
+                // (lanes and wavefronts that take no part write to their write-only words)
+                lds_put<T>(lds0, ki_lds + (unsigned)(((LL + 1) % KRL) * S::KLS), (!EDGE || need_k) ? GIO::val(g_k) : (T)0);
+                // (the upper half's lanes write into the upper half's part of the same slots: nobody reads a virtual cell of the upper half from the ring)
+                lds_put<T>(lds0, ji_at[aj], (!EDGE || need_j) ? GIO::val(g_j) : (T)0);
+            }
+            if (!(SZH_BM_X & 131072)) { gk[set] = load_k<EDGE>(it + 1 + DK); gj[set] = load_j<EDGE>(it + 3 + DK); }
+            so_ki += str_k; so_ji += str_j;
+        }
+        if constexpr (U == 4) read_kface<(LL + 1) % KRL>();      // (the k-face values of the next line's cells: one read per line, not one per step)
     }
 
     __device__ __forceinline__ static T tabs(T v) { return sizeof(T) == 8 ? (T)__builtin_fabs((double)v) : (T)__builtin_fabsf((float)v); }
@@ -456,11 +471,22 @@ struct beam {
     // x y + 0 in ONE rounding: the product rounded, and a zero product +0 whatever its sign -- what `x * y` followed by `+ 0` gives (|x| >= 1 or x = 0 here: no underflow)
     __device__ __forceinline__ static T tmul0(T x, T y) { return sizeof(T) == 8 ? (T)__builtin_fma((double)x, (double)y, 0.0) : (T)__builtin_fmaf((float)x, (float)y, 0.0f); }
 
+    // the k-face values of a whole line (cell U of the lane's half at kfv[U]): every lane reads, only the halves' first lanes use them
+    template <int KL> __device__ __forceinline__ void read_kface()
+    {
+        if (SZH_BM_X & 16) return;
+        const unsigned at = kaddr_h + (unsigned)(KL * S::KLS);
+        if (SZ == 4) {
+            const v4u q = lds_get16(lds0, at);
+            kfn[0] = __uint_as_float(q.x); kfn[1] = __uint_as_float(q.y); kfn[2] = __uint_as_float(q.z); kfn[3] = __uint_as_float(q.w);
+            kfn[4] = lds_get<T>(lds0, at + 16u);
+        } else for_n<LINE>([&](auto UU) { constexpr int u_ = decltype(UU)::value; kfn[u_] = lds_get<T>(lds0, at + (unsigned)(u_ * SZ)); });
+    }
     // the lanes that have not wrapped at unrolled step UN (m > UN), as a lane mask; `mreg` is hidden from hipcc block by block: it would hoist the
     // 31 compares out of the loop as 31 lane masks in scalar registers, and spill them
     template <int UN> __device__ __forceinline__ void next_wrap()
     {
-        if (UN < HL - 1) wrapm_next = lane_mask(mreg > (unsigned)UN);
+        if (UN < HL - 1 && !(SZH_BM_X & 512)) wrapm_next = lane_mask(mreg > (unsigned)UN);
     }
     // ---- one step: the cell the lane is at
     // One wavefront per SIMD: a dependent VALU instruction issues ~9 cycles after the one it waits for, an independent one after 4 (tools/ubench),
@@ -469,38 +495,34 @@ struct beam {
     template <int U, int LL, bool EDGE> __device__ __forceinline__ void step(int it)
     {
         constexpr int u = LL * LINE + U, un = (u + 1) % RS, un2 = (u + 2) % RS;
-        const T cur_raw = cur_next, kf = kf_next;
+        const T cur_raw = cur_next, kf = kfv[U];
         const unsigned tc_in = tc_next, fl_in = fl_next;
         // (the copy the swap consumes was made at the end of the step before, and the lane mask of the slot select in the middle of it: back to
         // back with their consumers both need wait states -- three s_nop per step)
         const T Lraw = shr1(prev);                                       // (i, j, k-1): the left lane's previous result
         const mask_t wrapm = wrapm_next;
+        const unsigned pn = (un < HL - 1 && !(SZH_BM_X & 512)) ? (in_mask(wrapm) ? pA : pB) : pB;
+        const unsigned cn = !S::CSEL ? pn : (un < HL - 1 ? (in_mask(wrapm) ? cA : cB) : cB);
         SZH_SB;
         T L = in_mask(m_first) ? kf : Lraw;                              // (a half's first lane: the k-face of the tile on the left)
         const bool started = !EDGE || (unsigned)(it * LINE + U) >= tstart;      // (at the array's first lines: lanes that have not started hold zeros)
         if (EDGE) L = started ? L : (T)0;
-        const T sw = low_to_high(pcopy, sw_junk);
+        const T sw = (SZH_BM_X & 256) ? sw_junk : low_to_high(pcopy, sw_junk);
         SZH_SB;
         const T B = dl[U], Bp = lup[U], C = Bold, Cp = Bpold;
         // [-1] + [-s1] + [-s0] - [-s1-1] - [-s0-1] - [-s0-s1] + [-s0-s1-1], left to right (sz_float.c:7268)
         const T s1 = L + prev;
+        if (!(SZH_BM_X & 32)) cur_next = lds_get<T>(lds0, pn + (unsigned)(un * PITCH));        // what the NEXT step needs from the rings is requested now
+        if (DEC) tc_next = lds_get<uint16_t>(lds0, cn + (unsigned)(un * PITCH + (S::CSEL ? 0 : VB)));
+        if (HASREG) fl_next = lds_get<uint8_t>(lds0, cn + (unsigned)(un * PITCH + (S::CSEL ? 0 : VB) + 2));
         SZH_SB;
         const T s2 = s1 + B;
-        const unsigned pn = un < HL - 1 ? (in_mask(wrapm) ? pA : pB) : pB;
-        const unsigned cn = !S::CSEL ? pn : (un < HL - 1 ? (in_mask(wrapm) ? cA : cB) : cB);
         SZH_SB;
         const T s3 = s2 - Lprev;
         // a virtual cell: the j-face -- from the ring (lower half), from the lower half's previous result (upper half)
         const T cur = in_mask(m_vu[U]) ? sw : cur_raw;
-        cur_next = lds_get<T>(lds0, pn + (unsigned)(un * PITCH));        // what the NEXT step needs from the rings is requested now
-        if (DEC) tc_next = lds_get<uint16_t>(lds0, cn + (unsigned)(un * PITCH + (S::CSEL ? 0 : VB)));
-        if (HASREG) fl_next = lds_get<uint8_t>(lds0, cn + (unsigned)(un * PITCH + (S::CSEL ? 0 : VB) + 2));
         SZH_SB;
         const T s4 = s3 - Bp;
-        {   // the k-face value of the next step's cell of lane 0 (every lane reads; only the halves' first lanes use it)
-            constexpr int Un = (U + 1) % LINE, kl = (U + 1 == LINE ? LL + 1 : LL) % KRL;
-            kf_next = lds_get<T>(lds0, (unsigned)(kl * LINE * 2 * SZ + Un * 2 * SZ) + kaddr_h);
-        }
         SZH_SB;
         const T s5 = s4 - C;
         SZH_SB;
@@ -542,8 +564,10 @@ struct beam {
                 if (in_mask(nm)) { code = radius; rec = mean; }
             }
             if (EDGE) rec = started ? rec : (T)0;
+            if (!(SZH_BM_X & 64)) {
             lds_put<uint16_t>(lds0, cc + (unsigned)(u * PITCH + (S::CSEL ? 0 : VB)), (uint16_t)code);
             lds_put<T>(lds0, pc + (unsigned)(u * PITCH), rec);
+            } else if (code == 12345) lds_put<T>(lds0, pc, rec);
         } else {
             int cq = (int)tc_in;
             bool is_mean = false;
@@ -560,7 +584,7 @@ struct beam {
             lds_put<T>(lds0, pc + (unsigned)(u * PITCH), rec);
         }
         // the last row of the upper half is the j-face of the wavefront above: kept where the lane made it, handed on at the end of the line
-        face_reg = in_mask(m_vu[(U + 1) % LINE]) ? rec : face_reg;      // (the upper half's lanes whose NEXT cell is virtual)
+        if (!(SZH_BM_X & 1024)) face_reg = in_mask(m_vu[(U + 1) % LINE]) ? rec : face_reg;      // (the upper half's lanes whose NEXT cell is virtual)
         dl[U] = rec; lup[U] = L;
         Bold = B; Bpold = Bp;
         Lprev = L; prev = rec; sw_junk = sw;
@@ -572,12 +596,11 @@ struct beam {
     {
         // the wavefront below (in j) must be far enough ahead for the virtual cells read during this line, the one above not too far behind
         // (their progress words were read during the last step of the line before: no LDS round trip here unless one of them is late)
-        if (uni((int)pv_prev) < it + 3) wait_prog(prog + (w - 1), it + 3);
-        if (uni((int)pv_next) < it - (RL - 2)) wait_prog(prog + (w + 1), it - (RL - 2));
+        for_n<LINE>([&](auto UU) { constexpr int u_ = decltype(UU)::value; kfv[u_] = kfn[u_]; });
         for_n<LINE>([&](auto UU) {
             constexpr int U = decltype(UU)::value;
             wave_sync();
-            events<U, LL, EDGE>(it);
+            if (!(SZH_BM_X & 128) && !((SZH_BM_X >> (12 + U)) & 1)) events<U, LL, EDGE>(it);      /* (8192 / 16384 / 32768: no events at position 1 / 2 / 3) */
             order();
             step<U, LL, EDGE>(it);
             order();
@@ -585,19 +608,18 @@ struct beam {
         // the faces of this line go up: each lane's latest last-row result -- the virtual cell of line it - 1 - q(m) -- into that slot of the ring
         // of the wavefront above (one write per line, not per step: the wavefront above waits for whole lines anyway), or, from the workgroup's
         // last wavefront, into row `it` of the j-face granules
-        {
+        if (!(SZH_BM_X & 2048)) {
             constexpr int ap = (LL + RL - 1) % RL;
-            if (has_next) {
-                // (the lower half's lanes write into the upper half's part of the same slots of the next ring: nobody reads those)
-                lds_put<T>(lds0, pf_at[ap], face_reg);
-            }
+            // (the lower half's lanes write into the upper half's part of the same slots of the next ring: nobody reads those; the workgroup's
+            // last wavefront: into the lanes' write-only words)
+            lds_put<T>(lds0, pf_at[ap], face_reg);
             unsigned o, so;
             place_row<EDGE>(rjo, it, str_j, so_jo, o, so);
-            GIO::st(rs_j, o, so, face_reg, epoch);
+            if (!(SZH_BM_X & 4)) GIO::st(rs_j, o, so, face_reg, epoch);
             so_jo += str_j;
         }
         it_v += 1u;
-        lds_put<unsigned>(lds0, prog_at, it_v);
+        if (!(SZH_BM_X & 2048)) lds_put<unsigned>(lds0, prog_at, it_v);
     }
     template <bool EDGE> __device__ __forceinline__ void block(int it0)
     {
@@ -658,7 +680,7 @@ struct beam {
             rki = make_role(en && kf_in, (unsigned)((((uint64_t)(wgl * 8 + 2 * w + khh)) * cells + kuu) * GIO::BYTES), khh, str_k);
             ko_lds = (unsigned)(kuu * PITCH + khh * S::HB + (HL - 1) * SZ);
             // (lanes that take no part write to their write-only word; the line term of the address stays within the slack behind those words)
-            ki_lds = (en && kf_in) ? (unsigned)(S::KR0 + w * S::KRB + kuu * 2 * SZ + khh * SZ) : trash;
+            ki_lds = (en && kf_in) ? (unsigned)(S::KR0 + w * S::KRB + khh * S::KHS + kuu * SZ) : trash;
         }
         {   // j-face granules [workgroup][wave line][32]: out: the upper half's lanes, row `it`; in: the lower half's lanes, row it + 3
             const int64_t wgl = (int64_t)kb * gr.nJG + (jg > 0 ? jg - 1 : 0);
@@ -679,8 +701,8 @@ struct beam {
         for_n<RL>([&](auto A_) {
             constexpr int a_ = decltype(A_)::value;
             const unsigned ls = (unsigned)(((a_ - (int)qreg) % RL + RL) % RL) * (unsigned)LP;
-            pf_at[a_] = ring_w + (unsigned)RINGB + (unsigned)((1 - h) * S::HB + m * SZ) + ls; hide(pf_at[a_]);
-            ji_at[a_] = ring_w + (unsigned)(h * S::HB + m * SZ) + ls; hide(ji_at[a_]);
+            pf_at[a_] = has_next ? ring_w + (unsigned)RINGB + (unsigned)((1 - h) * S::HB + m * SZ) + ls : trash; hide(pf_at[a_]);
+            ji_at[a_] = jf_in ? ring_w + (unsigned)(h * S::HB + m * SZ) + ls : trash; hide(ji_at[a_]);
         });
         prog_prev_at = (unsigned)(S::PROG0 + 4 * (has_prev ? w - 1 : WPG)); hide(prog_prev_at);
         prog_next_at = (unsigned)(S::PROG0 + 4 * (has_next ? w + 1 : WPG)); hide(prog_next_at);
@@ -693,7 +715,7 @@ struct beam {
             m_vu[u] = virt_upper_mask<u>(); hide(m_vu[u]);
             caphU[u] = virt ? (T)-1 : caph; hide(caphU[u]);
         });
-        kaddr_h = (unsigned)(S::KR0 + w * S::KRB + h * SZ);
+        kaddr_h = (unsigned)(S::KR0 + w * S::KRB + h * S::KHS); hide(kaddr_h);
         tstart = (unsigned)(m + LINE * h);
         {   // the k-face ring reads zeros where nothing arrives (no tile on the left); the virtual cells of the array's lower face read zeros (a
             // virtual cell writes back what it read, so they stay zeros), as do those of lines the wavefront below has not pushed yet
@@ -760,7 +782,7 @@ struct beam {
         cur_next = lds_get<T>(lds0, pc);
         tc_next = DEC ? (unsigned)lds_get<uint16_t>(lds0, cc + (unsigned)(S::CSEL ? 0 : VB)) : 0u;
         fl_next = HASREG ? (unsigned)lds_get<uint8_t>(lds0, cc + (unsigned)((S::CSEL ? 0 : VB) + 2)) : 0u;
-        kf_next = lds_get<T>(lds0, kaddr_h);
+        for_n<LINE>([&](auto UU) { constexpr int u_ = decltype(UU)::value; kfn[u_] = 0; }); read_kface<0>();
         { const v4u z = {0u, 0u, 0u, 0u}; for (int e = 0; e < EV; ++e) wqv[e] = z; wqc4 = z; }
         // ---- the lines: every lane has left line it - LAG when lane 0 enters line it.  Blocks of UL lines; the ones in which every line any
         // lane asks for or stores exists take the variant without per-lane line checks

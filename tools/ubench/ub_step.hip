@@ -19,6 +19,9 @@
 #ifndef FMA
 #define FMA 0
 #endif
+#ifndef UNR
+#define UNR 1        /* lines per loop trip (straight-line code of UNR x 5 steps) */
+#endif
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 #define SB __builtin_amdgcn_sched_barrier(0)
 #define LDS __attribute__((address_space(3)))
@@ -46,9 +49,10 @@ __global__ __launch_bounds__(NTHR, VAR == 4 ? 2 : 1) void k_step(float *io, int 
     unsigned dummy[16]; for (int i = 0; i < 16; ++i) dummy[i] = lane + i;
     unsigned sd = (unsigned)nlines;
 #pragma unroll 1
-    for (int it = 0; it < nlines; ++it) {
+    for (int it = 0; it < nlines; it += UNR) {
 #pragma unroll
-        for (int U = 0; U < LINE; ++U) {
+        for (int UU = 0; UU < LINE * UNR; ++UU) {
+            const int U = UU % LINE;
             const float cur = cur_next;
             const float Lraw = shr1(prev);
             SB;
@@ -133,6 +137,6 @@ int main(int argc, char **argv)
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         if (ms < best) best = ms;
     }
-    printf("VAR=%d EXTRA=%d FMA=%d: %d lines x 5 steps, %d WGs of %d: %.4f ms = %.1f ns per step\n", VAR, EXTRA, FMA, nlines, nwg, NTHR, best, best * 1e6 / (nlines * 5.0));
+    printf("VAR=%d EXTRA=%d FMA=%d UNR=%d: %d lines x 5 steps, %d WGs of %d: %.4f ms = %.1f ns per step\n", VAR, EXTRA, FMA, UNR, nlines, nwg, NTHR, best, best * 1e6 / (nlines * 5.0));
     return 0;
 }
