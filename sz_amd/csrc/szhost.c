@@ -469,7 +469,7 @@ void szhost_coeff_chain_one_ref(int is_double, void *coef, const unsigned char *
  * ahead of it.  A magnitude outside the candidates' range (or anything not finite) takes the reference's expression for that step.  Bit for
  * bit the reference's codes, decoded values and verbatim coefficients (tests/test_host_logic.py compares the two forms on adversarial
  * sequences). */
-unsigned long g_chain_generic_steps = 0;   /* (development: steps that took the general form) */
+__thread unsigned long g_chain_generic_steps = 0;   /* (development: steps of THIS thread's chains that took the general form) */
 #define COMMA ,
 #define CHAIN_TAB_N 32768
 typedef struct chain_tab { int is_double, variant; uint64_t prec_bits; void *thr, *pos, *neg; } chain_tab;
@@ -498,8 +498,14 @@ static pthread_mutex_t g_chain_tab_mu = PTHREAD_MUTEX_INITIALIZER;
     }                                                                                                                 \
     t.thr = tt; t.pos = ta; t.neg = tn;
 
-static const chain_tab *chain_tab_get(int is_double, int variant, double precd)
+/* `*owned` = 1: the table is the caller's (the cache is full: entries are never evicted, a chain may still be reading them), to be released with
+ * chain_tab_release after the chain.  `steps`: the length of the chain the table is wanted for -- building one costs ~1.7 ms, which a short chain
+ * never earns back (3.6 against 11.7 ns a step): below CHAIN_TAB_MIN_STEPS a table is used only if it is there already */
+#define CHAIN_TAB_MIN_STEPS 150000
+static void chain_tab_release(const chain_tab *t) { if (t) { free(t->thr); free(t->pos); free(t->neg); free((void *)t); } }
+static const chain_tab *chain_tab_get(int is_double, int variant, double precd, size_t steps, int *owned)
 {
+    *owned = 0;
     uint64_t bits; memcpy(&bits, &precd, 8);
     if (!(precd > 0) || !isfinite(precd) || !isfinite(precd * 131080.0) || (is_double ? precd < 1e-290 : precd < 1e-30)) return NULL;
     pthread_mutex_lock(&g_chain_tab_mu);
@@ -509,6 +515,7 @@ static const chain_tab *chain_tab_get(int is_double, int variant, double precd)
             return &g_chain_tabs[i];
         }
     pthread_mutex_unlock(&g_chain_tab_mu);
+    { const char *mn = getenv("SZ_HIP_CHAIN_TAB_MIN"); if (steps < (mn ? (size_t)atol(mn) : (size_t)CHAIN_TAB_MIN_STEPS)) return NULL; }      /* (tests set 0: the fast form on short chains) */
     chain_tab t; t.is_double = is_double; t.variant = variant; t.prec_bits = bits; t.thr = t.pos = t.neg = NULL;
     if (is_double) { CHAIN_TAB_BUILD(double, nextafter, HUGE_VAL) }
     else { CHAIN_TAB_BUILD(float, nextafterf, HUGE_VALF) }
@@ -519,10 +526,12 @@ static const chain_tab *chain_tab_get(int is_double, int variant, double precd)
             free(t.thr); free(t.pos); free(t.neg);
             return &g_chain_tabs[i];
         }
-    if (g_chain_tab_count == CHAIN_TAB_SLOTS) {                            /* (entries are never freed: a chain may still be reading them; a full cache stops caching) */
+    if (g_chain_tab_count == CHAIN_TAB_SLOTS) {                            /* (a full cache stops caching: the table just built serves this chain and goes) */
         pthread_mutex_unlock(&g_chain_tab_mu);
-        free(t.thr); free(t.pos); free(t.neg);
-        return NULL;
+        chain_tab *mine = (chain_tab *)malloc(sizeof(chain_tab));
+        if (!mine) { free(t.thr); free(t.pos); free(t.neg); return NULL; }
+        *mine = t; *owned = 1;
+        return mine;
     }
     g_chain_tabs[g_chain_tab_count] = t;
     const chain_tab *r = &g_chain_tabs[g_chain_tab_count++];
@@ -695,10 +704,14 @@ void szhost_coeff_chain_one_p(int is_double, void *coef, const unsigned char *in
 {
     const int variant = (is_double || use_mean) ? 1 : 0;          /* 1: |diff| * (1 / prec), 0: |diff| / prec (sz_float.c:7133 against :6795, sz_double.c) */
     const char *sw = getenv("SZ_HIP_CHAIN_FAST");
-    const chain_tab *tab = (sw && sw[0] == '0') ? NULL : chain_tab_get(is_double, variant, out->prec[e]);
+    int owned = 0;
+    size_t steps = 0;
+    for (size_t b = 0; b < nblocks; b++) steps += indicator[b] == 0;      /* the chain's length: the regression blocks */
+    const chain_tab *tab = (sw && sw[0] == '0') ? NULL : chain_tab_get(is_double, variant, out->prec[e], steps, &owned);
     if (!tab) { szhost_coeff_chain_one_ref(is_double, coef, indicator, nblocks, use_mean, e, out, progress); return; }
     if (is_double) { CHAIN_FAST(double, uint64_t, fabs, CHAIN_LEAN_F64, ) }
     else { CHAIN_FAST(float, uint32_t, fabsf, CHAIN_LEAN_F32, ) }
+    if (owned) chain_tab_release(tab);
 }
 void szhost_coeff_chain_one_pa(int is_double, void *coef, const unsigned char *indicator, size_t nblocks, int use_mean, int e, szhost_coeffs *out,
                                size_t *progress, const size_t *avail)

@@ -232,11 +232,13 @@ class _Coeffs(ctypes.Structure):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("use_mean", [0, 1])
-def test_fast_coefficient_chain_equals_the_reference_loop(L, dtype, use_mean):
-    """round 5: szhost_coeff_chain_one_p keeps only subtract / compare / select / add on the loop-carried path (candidate interval numbers and their
+def test_fast_coefficient_chain_equals_the_reference_loop(L, dtype, use_mean, monkeypatch):
+    """(SZ_HIP_CHAIN_TAB_MIN=0: the threshold-table form on these short chains too -- by default a chain shorter than 150 000 steps takes the
+    reference's loop unless its table is cached already, round 6.)  round 5: szhost_coeff_chain_one_p keeps only subtract / compare / select / add on the loop-carried path (candidate interval numbers and their
     exact thresholds come from the original coefficients); it must give the codes, decoded coefficients and verbatim values of the reference's
     loop (szhost_coeff_chain_one_ref = sz_float.c:7126-7152 literally) bit for bit -- on random walks, values ON interval boundaries, jumps beyond
     the code range, sign changes around zero, NaN / infinity."""
+    monkeypatch.setenv("SZ_HIP_CHAIN_TAB_MIN", "0")
     rng = np.random.default_rng(11)
     is_double = int(dtype == np.float64)
     eb = 1e-3 if is_double else 1e-4
@@ -322,10 +324,11 @@ def test_table_decode_of_coefficient_codes_equals_the_walk(L):
         L.szhost_huff_free(ctypes.c_void_p(h)); L.szhost_huff_free(ctypes.c_void_p(h2))
 
 
-def test_chain_started_before_all_coefficients_are_there(L):
+def test_chain_started_before_all_coefficients_are_there(L, monkeypatch):
     """round 5: szhost_coeff_chain_one_pa starts a chain while the tail of its coefficient array is still on its way (the caller raises *avail from another
     thread); the chain waits where it runs into the mark and gives what szhost_coeff_chain_one_p gives on the complete array, bit for bit."""
     import threading, time
+    monkeypatch.setenv("SZ_HIP_CHAIN_TAB_MIN", "0")
     rng = np.random.default_rng(3)
     for dtype in (np.float32, np.float64):
         is_double = int(dtype == np.float64)
@@ -361,3 +364,39 @@ def test_chain_started_before_all_coefficients_are_there(L):
         assert outs[0][0] == outs[1][0]
         for e in range(4):
             assert np.array_equal(outs[0][1][e], outs[1][1][e])
+
+
+def test_chain_table_cache_full_and_short_chains(L, monkeypatch):
+    """round 6 (ADVICE): (a) once the 16 slots of the threshold-table cache are taken, a chain with a new precision still runs in the fast form on a
+    table of its own -- same results as the reference's loop -- instead of building a table, throwing it away and walking the slow loop; (b) a short
+    chain does not build a table at all (it costs more than it saves) and gives the same results."""
+    rng = np.random.default_rng(23)
+    nb = 4000
+    ind = np.zeros(nb, dtype=np.uint8)
+    L.szhost_coeff_chain_begin.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_Coeffs)]
+    for fn in (L.szhost_coeff_chain_one_p, L.szhost_coeff_chain_one_ref):
+        fn.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_Coeffs), ctypes.c_void_p]
+    L.szhost_coeffs_free.argtypes = [ctypes.POINTER(_Coeffs)]
+
+    def run(fn, co, eb):
+        c = _Coeffs()
+        work = co.copy()
+        L.szhost_coeff_chain_begin(0, ind.ctypes.data, nb, eb, 6, 6, 6, 4, ctypes.byref(c))
+        for e in range(4):
+            fn(0, work.ctypes.data, ind.ctypes.data, nb, 0, e, ctypes.byref(c), None)
+        out = (work.copy(), [np.ctypeslib.as_array(c.codes[e], shape=(nb,)).copy() for e in range(4)], [int(c.unpred_count[e]) for e in range(4)])
+        L.szhost_coeffs_free(ctypes.byref(c))
+        return out
+
+    for minsteps in ("0", None):                      # 0: every chain builds / finds a table (24 precisions x 4 > 16 slots); default: none of these short chains does
+        if minsteps is None:
+            monkeypatch.delenv("SZ_HIP_CHAIN_TAB_MIN", raising=False)
+        else:
+            monkeypatch.setenv("SZ_HIP_CHAIN_TAB_MIN", minsteps)
+        for k in range(24):
+            eb = 1e-4 * (1.0 + 0.37 * k)
+            co = np.cumsum((rng.random((4, nb)) - 0.5) * 30 * 0.025 * eb, axis=1).astype(np.float32)
+            a, b = run(L.szhost_coeff_chain_one_p, co, eb), run(L.szhost_coeff_chain_one_ref, co, eb)
+            assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and a[2] == b[2], (minsteps, k)
+            for e in range(4):
+                assert np.array_equal(a[1][e], b[1][e]), (minsteps, k, e)
