@@ -66,7 +66,8 @@ typedef struct szhip_stats {
     uint64_t quant_kernel_launches; /* launches of the wavefront kernel (1 per call) */
     double vmin, vmax;      /* the array's range when SZHIP_RANGE_FROM_DATA was set (else 0) */
     int chain_overlapped;   /* 1: the regression-coefficient chain ran next to the wavefront kernel */
-    int quant_kernel;       /* which mapping of the wavefront kernel ran: 0 = k_pencil (8x8 pencils), 1 = k_ribbon (szh_ribbon.h); fast mode: 2 = two-pass form */
+    int quant_kernel;       /* which mapping of the wavefront kernel ran: 0 = k_pencil (8x8 pencils), 1 = k_ribbon (szh_ribbon.h), 2 = k_beam (szh_beam.h); fast mode: 2 = two-pass form */
+    int packing;            /* (round 6) 1: the Huffman packing read the sweep's natural-order codes segment by segment (szh_segenc.h); 0: block-ordered copy first */
 } szhip_stats;
 
 int  szhip_create(szhip_ctx **ctx, int device);

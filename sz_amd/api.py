@@ -47,7 +47,7 @@ class szhip_stats(ctypes.Structure):  # include/szhip.h
                 ("ms_entropy", ctypes.c_double), ("ms_host", ctypes.c_double),
                 ("n_elements", ctypes.c_uint64), ("n_blocks", ctypes.c_uint64), ("n_reg_blocks", ctypes.c_uint64),
                 ("n_unpred", ctypes.c_uint64), ("intervals", ctypes.c_uint), ("use_mean", ctypes.c_int),
-                ("out_bytes", ctypes.c_uint64), ("quant_kernel_launches", ctypes.c_uint64), ("vmin", ctypes.c_double), ("vmax", ctypes.c_double), ("chain_overlapped", ctypes.c_int), ("quant_kernel", ctypes.c_int)]
+                ("out_bytes", ctypes.c_uint64), ("quant_kernel_launches", ctypes.c_uint64), ("vmin", ctypes.c_double), ("vmax", ctypes.c_double), ("chain_overlapped", ctypes.c_int), ("quant_kernel", ctypes.c_int), ("packing", ctypes.c_int)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

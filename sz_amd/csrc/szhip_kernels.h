@@ -2071,3 +2071,4 @@ __global__ void k_probe_touch(unsigned long long *p) { *p = 1; }
 #include "szh_omp.h"
 #include "szh_ompcol.h"
 #include "szh_beam.h"
+#include "szh_segenc.h"
