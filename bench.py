@@ -17,6 +17,7 @@ the timed region.  Since round 5 the timed region is ONE BLOCKING CALL AFTER THE
   m_field      -- BASELINE configs[2]: the same step on the 512^3 "M-field" (half of the blocks choose the regression predictor: k_reg_points, the
                   beam sweep fed while the host's coefficient chains run), its decompression, and the sweep's own roofline from an unfed call.
   e2e          -- SZ_compress_args / SZ_decompress from and to HOST memory (pageable), PCIe included: never the `value`.
+  e2e_default  -- the same two calls under the reference's SHIPPED mode (szMode = SZ_BEST_COMPRESSION: the zstd stage), beside the unmodified reference doing the same.
   cpu_baseline -- the unmodified reference (oracle/_ref/libSZ.so; kind "reference") pinned to one core, median of 3, with the oracle (a C restatement,
                   oracle/) beside it as `port`; cpu_baseline_mt: the reference's own OpenMP variant on 64 threads.
 
@@ -673,6 +674,78 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
                        "pinned buffers by four host threads + the stream back, and the reverse into a freshly malloc'd array (transparent huge pages requested for it); median of 3",
                "stream_identical_to_device_path": bool(s2len == size)}
 
+    # ---- the same two calls under the mode the reference SHIPS (example/sz.config: szMode = SZ_BEST_COMPRESSION, the zstd stage behind the SZ stream, conf.c:114,
+    #      utility.c:174-214), and the unmodified reference doing the same on one core: what a caller who changes nothing gets
+    e2e_default = None
+    if world == 1 and n == EDGE and not args.timed_only:
+        import hashlib
+        cfg_def = os.path.join(ROOT, "tests", "golden", "sz_default.config")
+        assert sz_amd.SZ_Init(cfg_def) == 0
+        L = sz_amd.lib()
+        dims = (0, 0, n, n, n)
+        tcs, tds, wrapped = [], [], None
+        for _ in range(3):
+            nn2 = ctypes.c_size_t(0)
+            t1 = time.perf_counter()
+            p2 = L.SZ_compress_args(0, host.ctypes.data, ctypes.byref(nn2), sz_amd.ABS, EB, 0.0, 0.0, *dims)
+            tcs.append(time.perf_counter() - t1)
+            if not p2:
+                raise RuntimeError("SZ_compress_args (default mode) failed")
+            if wrapped is None:
+                wrapped = ctypes.string_at(p2, nn2.value)
+            L.free(p2)
+        sbuf = ctypes.create_string_buffer(wrapped, len(wrapped))
+        dec_md5 = None
+        L.SZ_decompress.restype = ctypes.c_void_p
+        for _ in range(3):
+            t1 = time.perf_counter()
+            q2 = L.SZ_decompress(0, sbuf, len(wrapped), *dims)
+            tds.append(time.perf_counter() - t1)
+            if not q2:
+                raise RuntimeError("SZ_decompress (default mode) failed")
+            if dec_md5 is None:
+                dec_md5 = hashlib.md5(ctypes.string_at(q2, host.nbytes)).hexdigest()
+            L.free(q2)
+        sz_amd.SZ_Finalize()
+        e2e_default = {"compress_GBps": round(nbytes_in / float(np.median(tcs)) / 1e9, 2), "decompress_GBps": round(nbytes_in / float(np.median(tds)) / 1e9, 2),
+                       "compress_ms": round(float(np.median(tcs)) * 1e3, 1), "decompress_ms": round(float(np.median(tds)) * 1e3, 1), "wrapped_bytes": len(wrapped),
+                       "what": "SZ_compress_args / SZ_decompress on a pageable host array under tests/golden/sz_default.config (szMode = SZ_BEST_COMPRESSION, zstd level 3): the GPU "
+                               "path + PCIe + the zstd stage on host threads (the stream in pieces, a frame each, the frames one behind the other: any ZSTD_decompress reads them as one "
+                               "stream); median of 3"}
+        # the unmodified reference: the same call (one pass: ~2.5 s), and ITS decoder on this library's wrapped stream
+        so = os.path.join(ROOT, "oracle", "_ref", "libSZ.so")
+        if os.path.exists(so) and not args.no_cpu_baseline:
+            R = ctypes.CDLL(so)
+            szt = ctypes.c_size_t
+            R.SZ_Init.argtypes = [ctypes.c_char_p]
+            R.SZ_compress_args.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(szt), ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double] + [szt] * 5
+            R.SZ_compress_args.restype = ctypes.c_void_p
+            R.SZ_decompress.argtypes = [ctypes.c_int, ctypes.c_void_p, szt] + [szt] * 5
+            R.SZ_decompress.restype = ctypes.c_void_p
+            libc = ctypes.CDLL(None); libc.free.argtypes = [ctypes.c_void_p]
+            if R.SZ_Init(cfg_def.encode()) == 0:
+                m = szt(0)
+                t1 = time.perf_counter()
+                rp = R.SZ_compress_args(0, host.ctypes.data, ctypes.byref(m), 0, EB, 0.0, 0.0, *dims)
+                tr = time.perf_counter() - t1
+                ref_wrapped = ctypes.string_at(rp, m.value)
+                libc.free(rp)
+                t1 = time.perf_counter()
+                rq = R.SZ_decompress(0, sbuf, len(wrapped), *dims)          # the stock decoder reads the GPU library's wrapped stream
+                trd = time.perf_counter() - t1
+                ref_dec_md5 = hashlib.md5(ctypes.string_at(rq, host.nbytes)).hexdigest() if rq else None
+                if rq:
+                    libc.free(rq)
+                rbuf = ctypes.create_string_buffer(ref_wrapped, len(ref_wrapped))
+                q3 = L.SZ_decompress(0, rbuf, len(ref_wrapped), *dims)      # and this library the reference's
+                back_md5 = hashlib.md5(ctypes.string_at(q3, host.nbytes)).hexdigest() if q3 else None
+                if q3:
+                    L.free(q3)
+                R.SZ_Finalize()
+                e2e_default["reference"] = {"compress_GBps": round(nbytes_in / tr / 1e9, 4), "decompress_GBps": round(nbytes_in / trd / 1e9, 4), "cores": 1, "wrapped_bytes": len(ref_wrapped),
+                                            "what": "oracle/_ref/libSZ.so (the unmodified reference) on the same array and configuration, one pass each way; its decompression is of THIS library's wrapped stream"}
+                e2e_default["decoded_md5_equal"] = bool(dec_md5 is not None and dec_md5 == ref_dec_md5 == back_md5)
+
     cpu, cpu_mt = (None, None)
     if not args.no_cpu_baseline and world == 1:
         cpu, cpu_mt = cpu_baselines(host, n, size)
@@ -699,7 +772,7 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
                          "entropy": round(stats.ms_entropy, 3), "host_glue": round(stats.ms_host, 3), "compress_call_total": round(stats.ms_total, 3),
                          "decompress_quant": round(dst.ms_quant, 3), "decompress_total": round(dst.ms_total, 3)},
             "per_rank": per_rank,
-            "roofline": roofline, "concurrent": concurrent, "m_field": mfield, "fast_mode": fast, "other_paths": other, "omp_container": omp, "e2e": e2e, "cpu_baseline": cpu, "cpu_baseline_mt": cpu_mt}
+            "roofline": roofline, "concurrent": concurrent, "m_field": mfield, "fast_mode": fast, "other_paths": other, "omp_container": omp, "e2e": e2e, "e2e_default": e2e_default, "cpu_baseline": cpu, "cpu_baseline_mt": cpu_mt}
     print(json.dumps(line))
     if world > 1:
         dist.barrier(); dist.destroy_process_group()

@@ -17,6 +17,8 @@
 #include <sys/mman.h>
 #include <string.h>
 #include <time.h>
+#include <unistd.h>
+#include <pthread.h>
 #include "sz.h"
 #include "szhip.h"
 #include "szhost.h"
@@ -81,7 +83,8 @@ typedef size_t (*zstd_compress_fn)(void *, size_t, const void *, size_t, int);
 typedef size_t (*zstd_decompress_fn)(void *, size_t, const void *, size_t);
 typedef unsigned long long (*zstd_fcs_fn)(const void *, size_t);
 typedef unsigned (*zstd_iserr_fn)(size_t);
-static struct { int tried; void *h; zstd_compress_fn compress; zstd_decompress_fn decompress; zstd_fcs_fn fcs; zstd_iserr_fn iserr; } g_zstd;
+typedef size_t (*zstd_framesize_fn)(const void *, size_t);
+static struct { int tried; void *h; zstd_compress_fn compress; zstd_decompress_fn decompress; zstd_fcs_fn fcs; zstd_iserr_fn iserr; zstd_framesize_fn frame_size; } g_zstd;
 
 static int zstd_load(void)
 {
@@ -95,7 +98,99 @@ static int zstd_load(void)
     g_zstd.fcs = (zstd_fcs_fn)dlsym(g_zstd.h, "ZSTD_getFrameContentSize");
     g_zstd.iserr = (zstd_iserr_fn)dlsym(g_zstd.h, "ZSTD_isError");
     if (!g_zstd.compress || !g_zstd.decompress || !g_zstd.fcs || !g_zstd.iserr) { dlclose(g_zstd.h); g_zstd.h = NULL; return 0; }
+    g_zstd.frame_size = (zstd_framesize_fn)dlsym(g_zstd.h, "ZSTD_findFrameCompressedSize");      /* (optional: frames decoded side by side) */
     return 1;
+}
+/* sz_lossless_compress with ZSTD_COMPRESSOR (utility.c:174-195: ONE ZSTD_compress call over the whole stream, on the calling thread -- at 512^3 that call is fifty
+ * times the GPU's part of SZ_compress_args under the shipped szMode, SZ_BEST_COMPRESSION).  Streams of more than a few megabytes are cut into pieces, each piece
+ * compressed by a host thread of its own into a frame of its own, the frames written one behind the other: ZSTD_decompress -- the stock sz_lossless_decompress's,
+ * utility.c:207, zstd 1.3.5 -- reads "some number of frames" as one stream, ZSTD_getFrameContentSize answers for the first.  (The library's own worker threads,
+ * ZSTD_c_nbWorkers, would give ONE frame, but the system's libzstd.so.1 of this image is built without them: the parameter is refused.)
+ * SZ_HIP_ZSTD_WORKERS sets the number of pieces (0 / 1: the reference's single call). */
+typedef struct { const unsigned char *src; size_t n; int level; unsigned char *out; size_t cap, got; int err; } zstd_piece;
+static void *zstd_piece_run(void *arg)
+{
+    zstd_piece *p = (zstd_piece *)arg;
+    p->out = (unsigned char *)malloc(p->cap);
+    if (!p->out) { p->err = 1; return NULL; }
+    p->got = g_zstd.compress(p->out, p->cap, p->src, p->n, p->level);
+    p->err = g_zstd.iserr(p->got) ? 1 : 0;
+    return NULL;
+}
+typedef struct { unsigned char *dst; const unsigned char *src; size_t n; } copy_piece;
+static void *copy_piece_run(void *arg) { copy_piece *c = (copy_piece *)arg; memcpy(c->dst, c->src, c->n); return NULL; }
+/* returns a malloc'd buffer holding the wrapped stream (*out_size bytes), NULL on failure */
+static unsigned char *zstd_compress_stream(const unsigned char *src, size_t n, int level, size_t *out_size)
+{
+    int pieces = 1;
+    const char *e = getenv("SZ_HIP_ZSTD_WORKERS");
+    if (e) pieces = atoi(e);
+    else if (n >= ((size_t)8 << 20)) {
+        long nc = sysconf(_SC_NPROCESSORS_ONLN);
+        pieces = nc > 32 ? 32 : (int)nc;
+        if ((size_t)pieces > n / ((size_t)1 << 20)) pieces = (int)(n / ((size_t)1 << 20));
+    }
+    if (pieces > 64) pieces = 64;
+    if (pieces < 2 || n < 2) {
+        size_t est = n < 100 ? 200 : (size_t)(n * 1.2);
+        unsigned char *z = (unsigned char *)malloc(est);
+        if (!z) return NULL;
+        size_t zs = g_zstd.compress(z, est, src, n, level);
+        if (g_zstd.iserr(zs)) { free(z); return NULL; }
+        *out_size = zs;
+        return z;
+    }
+    zstd_piece P[64]; pthread_t th[64]; int started[64];
+    const size_t per = (n + (size_t)pieces - 1) / (size_t)pieces;
+    int np = 0;
+    for (size_t off = 0; off < n; off += per, ++np) {
+        P[np].src = src + off; P[np].n = n - off < per ? n - off : per; P[np].level = level;
+        P[np].cap = P[np].n + P[np].n / 128 + 1024;            /* (>= ZSTD_compressBound: n + n / 256 + a small constant) */
+        P[np].out = NULL; P[np].got = 0; P[np].err = 0;
+    }
+    for (int i = 0; i < np; i++) started[i] = pthread_create(&th[i], NULL, zstd_piece_run, &P[i]) == 0;
+    for (int i = 0; i < np; i++) { if (started[i]) pthread_join(th[i], NULL); else zstd_piece_run(&P[i]); }
+    size_t total = 0; int bad = 0;
+    for (int i = 0; i < np; i++) { bad |= P[i].err; total += P[i].got; }
+    unsigned char *z = bad ? NULL : (unsigned char *)malloc(total ? total : 1);
+    if (z) {
+        copy_piece C[64]; size_t at = 0;
+        for (int i = 0; i < np; i++) { C[i].dst = z + at; C[i].src = P[i].out; C[i].n = P[i].got; at += P[i].got; }
+        for (int i = 0; i < np; i++) started[i] = pthread_create(&th[i], NULL, copy_piece_run, &C[i]) == 0;
+        for (int i = 0; i < np; i++) { if (started[i]) pthread_join(th[i], NULL); else copy_piece_run(&C[i]); }
+        *out_size = total;
+    }
+    for (int i = 0; i < np; i++) free(P[i].out);
+    return z;
+}
+
+/* the way back: a stream of several frames (zstd_compress_stream's, or anybody's) is decoded frame by frame on threads of their own when every frame says how long
+ * its content is; anything else goes to ONE ZSTD_decompress call, as in the reference (utility.c:207).  Returns what ZSTD_decompress would (ZSTD_isError-testable). */
+typedef struct { unsigned char *dst; size_t cap; const unsigned char *src; size_t n; size_t got; } unzstd_piece;
+static void *unzstd_piece_run(void *arg) { unzstd_piece *p = (unzstd_piece *)arg; p->got = g_zstd.decompress(p->dst, p->cap, p->src, p->n); return NULL; }
+static size_t zstd_decompress_stream(unsigned char *dst, size_t cap, const unsigned char *src, size_t n)
+{
+    unzstd_piece P[64]; int np = 0;
+    const char *e = getenv("SZ_HIP_ZSTD_WORKERS");
+    if (g_zstd.frame_size && !(e && atoi(e) <= 1)) {
+        size_t at = 0, out = 0;
+        while (at < n && np < 64) {
+            const size_t fs = g_zstd.frame_size(src + at, n - at);
+            if (g_zstd.iserr(fs) || fs == 0 || fs > n - at) { np = 0; break; }
+            const unsigned long long cs = g_zstd.fcs(src + at, fs);
+            if (cs == (unsigned long long)-1 || cs == (unsigned long long)-2 || cs > cap - out) { np = 0; break; }
+            P[np].dst = dst + out; P[np].cap = (size_t)cs; P[np].src = src + at; P[np].n = fs; P[np].got = 0; ++np;
+            at += fs; out += (size_t)cs;
+        }
+        if (at != n) np = 0;
+    }
+    if (np < 2) return g_zstd.decompress(dst, cap, src, n);
+    pthread_t th[64]; int started[64];
+    for (int i = 0; i < np; i++) started[i] = pthread_create(&th[i], NULL, unzstd_piece_run, &P[i]) == 0;
+    for (int i = 0; i < np; i++) { if (started[i]) pthread_join(th[i], NULL); else unzstd_piece_run(&P[i]); }
+    size_t total = 0;
+    for (int i = 0; i < np; i++) { if (g_zstd.iserr(P[i].got) || P[i].got != P[i].cap) return g_zstd.iserr(P[i].got) ? P[i].got : (size_t)-1; total += P[i].got; }
+    return total;
 }
 
 /* ---- zlib (GZIP_COMPRESSOR; callZlib.c:205-253 deflates with deflateInit(level), :496-527 inflates) through the system library ---- */
@@ -300,11 +395,9 @@ static int finish_lossless(unsigned char *tmp, size_t tmpSize, unsigned char **n
          * change what szMode promises (and the reference's default is SZ_BEST_COMPRESSION, conf.c:114) */
         if (confparams_cpr->losslessCompressor == ZSTD_COMPRESSOR) {
             if (!zstd_load()) { printf("Error: szMode asks for the zstd back end but libzstd.so.1 cannot be loaded (use SZ_BEST_SPEED or GZIP_COMPRESSOR).\n"); free(tmp); return SZ_NSCS; }
-            size_t est = tmpSize < 100 ? 200 : (size_t)(tmpSize * 1.2);
-            unsigned char *z = (unsigned char *)malloc(est);
-            if (!z) { free(tmp); return SZ_NSCS; }
-            size_t zs = g_zstd.compress(z, est, tmp, tmpSize, confparams_cpr->gzipMode);
-            if (g_zstd.iserr(zs)) { printf("Error: ZSTD_compress failed.\n"); free(z); free(tmp); return SZ_NSCS; }
+            size_t zs = 0;
+            unsigned char *z = zstd_compress_stream(tmp, tmpSize, confparams_cpr->gzipMode, &zs);
+            if (!z) { printf("Error: ZSTD_compress failed.\n"); free(tmp); return SZ_NSCS; }
             free(tmp); *newByteData = z; *outSize = zs;
         } else if (confparams_cpr->losslessCompressor == GZIP_COMPRESSOR) {
             if (!zlib_load()) { printf("Error: szMode asks for the gzip back end but libz.so.1 cannot be loaded (use SZ_BEST_SPEED).\n"); free(tmp); return SZ_NSCS; }
@@ -751,7 +844,7 @@ static void *decompress_fp(int dataType, unsigned char *cmpBytes, size_t cmpSize
                 }
                 unsigned char *buf = (unsigned char *)malloc(target);
                 if (!buf) { printf("Error: out of memory.\n"); return NULL; }
-                size_t got = g_zstd.decompress(buf, target, cmpBytes, cmpSize);
+                size_t got = zstd_decompress_stream(buf, target, cmpBytes, cmpSize);
                 if (g_zstd.iserr(got)) { printf("Error: ZSTD_decompress failed.\n"); free(buf); return NULL; }
                 sz = buf; szlen = got; owned = 1;
             } else {

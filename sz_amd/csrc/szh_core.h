@@ -170,6 +170,22 @@ SZH_HD unsigned szh_radius_index(double rq, unsigned max_radius)
     return rq >= (double)max_radius ? max_radius - 1 : (unsigned)rq;
 }
 
+// the bin of a sampled value in the optimiser's histogram around the mean (sz_float.c:6466-6476)
+template <class T>
+SZH_HD int szh_freq_index(T x, T mean, double ebD)
+{
+    const T mean_diff = x - mean;
+    const double fq = (double)mean_diff / ebD;
+    // (ptrdiff_t)fq: outside the int64 range (or NaN) the x86 conversion of the reference yields
+    // INT64_MIN, which lands in bin 0 after the clamp below
+    int64_t fi;
+    if (!(fq < 9.2233720368547758e18 && fq >= -9.2233720368547758e18)) fi = -(((int64_t)1) << 62);
+    else fi = (int64_t)fq;
+    if (!(mean_diff > 0)) fi -= 1;
+    fi += 4096;
+    return fi <= 0 ? 0 : (fi >= 8192 ? 8191 : (int)fi);
+}
+
 template <class T>
 SZH_HD void szh_sample_point(const T *data, int64_t pos, int64_t r2, int64_t r12, double ebD, T mean,
                              unsigned max_radius, unsigned *radius_index, int *freq_index, int *within_eb)
@@ -182,16 +198,7 @@ SZH_HD void szh_sample_point(const T *data, int64_t pos, int64_t r2, int64_t r12
     double rq = ((double)pred_err / ebD + 1) / 2;
     const unsigned ri = szh_radius_index(rq, max_radius);
     *radius_index = ri;
-    const T mean_diff = *d - mean;
-    const double fq = (double)mean_diff / ebD;
-    // (ptrdiff_t)fq: outside the int64 range (or NaN) the x86 conversion of the reference yields
-    // INT64_MIN, which lands in bin 0 after the clamp below
-    int64_t fi;
-    if (!(fq < 9.2233720368547758e18 && fq >= -9.2233720368547758e18)) fi = -(((int64_t)1) << 62);
-    else fi = (int64_t)fq;
-    if (!(mean_diff > 0)) fi -= 1;
-    fi += 4096;
-    *freq_index = fi <= 0 ? 0 : (fi >= 8192 ? 8191 : (int)fi);
+    *freq_index = szh_freq_index<T>(*d, mean, ebD);
 }
 
 // number of logical sample rows the sequential walk of the reference visits before its first

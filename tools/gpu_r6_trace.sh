@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; field=${1:-s}; tag=${2:-trace}
 rm -rf $R/gpurun_out/tr_$tag
-rocprofv3 --kernel-trace -d $R/gpurun_out/tr_$tag -o t --output-format csv -- python $R/tools/gpu_r5_mtime.py 512 $field > $R/gpurun_out/r6_${tag}_log.txt 2>&1
+rocprofv3 --kernel-trace -d $R/gpurun_out/tr_$tag -o t --output-format csv -- ${TRACE_CMD:-python $R/tools/gpu_r5_mtime.py 512 $field} > $R/gpurun_out/r6_${tag}_log.txt 2>&1
 f=$(find $R/gpurun_out/tr_$tag -name "*kernel_trace.csv" | head -1)
 python3 - "$f" > $R/gpurun_out/r6_${tag}_timeline.txt <<'PY'
 import csv, sys
@@ -26,7 +26,7 @@ def show(c, title):
         print("%8.3f %8.3f %7.3f  q%-3s %s grid %s wg %s" % (s / 1e6, e / 1e6, (e - s) / 1e6, r.get("Queue_Id", "?"), r["Kernel_Name"][:60], r.get("Grid_Size", "?"), r.get("Workgroup_Size", "?")))
 big = [c for c in calls if len(c) >= 8]
 names = lambda c: " ".join(r["Kernel_Name"] for r in c)
-comp = [c for c in big if "k_fit_select" in names(c)]
+comp = [c for c in big if "k_fit" in names(c)]
 dec = [c for c in big if "k_hdec_write" in names(c)]
 if comp: show(comp[-1], "last compress call")
 if dec: show(dec[-1], "last decompress call")
