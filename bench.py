@@ -396,7 +396,7 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
     qk = getattr(stats, "quant_kernel", 0)
     kname = "k_beam<float,false,false,false>" if qk == 2 else "k_ribbon<float,false,false>" if qk == 1 else "k_pencil<float,false>"
     traffic, traffic_src = None, None
-    for name in (("r05_pmc_traffic_beam.json",) if qk == 2 else ("r05_pmc_traffic_ribbon.json", "r03_pmc_traffic_ribbon.json") if qk == 1 else ("r02_pmc_traffic_pencil.json", "r01_pmc_traffic_pencil.json")):
+    for name in (("r06_pmc_traffic_beam_sfield.json",) if qk == 2 else ("r05_pmc_traffic_ribbon.json", "r03_pmc_traffic_ribbon.json") if qk == 1 else ("r02_pmc_traffic_pencil.json", "r01_pmc_traffic_pencil.json")):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", name)))
             if n == EDGE:
@@ -466,7 +466,7 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
                                "entropy": round(mst.ms_entropy, 3), "host_glue": round(mst.ms_host, 3)}}
         if not getattr(args, "dry_run", False):
             # the sweep of this array on its own: the same call in the unfed order (chains first, then k_reg_points and the sweep back to back), whose
-            # `quant` phase is the two kernels and nothing else; PMC traffic of that order from profiles/r05_pmc_traffic_beam.json
+            # `quant` phase is the two kernels and nothing else; PMC traffic of that order from profiles/r06_pmc_traffic_beam_mfield.json
             os.environ["SZ_HIP_BEAM_FEED"] = "0"
             try:
                 one_step(xm)
@@ -474,13 +474,13 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
             finally:
                 os.environ.pop("SZ_HIP_BEAM_FEED", None)
             try:
-                btr = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_traffic_beam.json")))["traffic_bytes_per_launch"]
+                btr = json.load(open(os.path.join(ROOT, "profiles", "r06_pmc_traffic_beam_mfield.json")))["traffic_bytes_per_launch"]
             except (OSError, KeyError, ValueError):
                 btr = None
             mfield["roofline"] = {"bound": "hbm", "kernel": "k_reg_points<float,0> + k_beam<float,false,false,true>", "unfed_call_quant_ms": round(ust.ms_quant, 4),
                                   "achieved": round(nbytes_in / (ust.ms_quant * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(nbytes_in / (ust.ms_quant * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": btr,
-                                  "traffic_source": "profiles/r05_pmc_traffic_beam.json (k_beam alone: FETCH_SIZE x2 + WRITE_SIZE; the x2 of the guide overstates the 4- and 8-byte-per-lane reads)",
+                                  "traffic_source": "profiles/r06_pmc_traffic_beam_mfield.json (k_beam alone: FETCH_SIZE x2 + WRITE_SIZE; the x2 of the guide overstates the 4- and 8-byte-per-lane reads)",
                                   "unfed_call_ms": round(ust.ms_total, 3)}
             # two M-field arrays in flight (szhip_pool): one array's host coefficient chain beside the other's kernels
             ref_m = mob[:msize].clone()

@@ -136,7 +136,6 @@ struct szhip_ctx {
     // the coefficient chain beside the running sweep (M-field): a sweep that gave up waiting for the coefficients (seen 5 - 6 times in 480 rounds with
     // several arrays in flight) is answered by ONE repetition with the chain finished before the sweep starts; the context keeps that order
     bool coef_late = false, no_chain_overlap = false;
-    bool enc_lb_failed = false, no_enc_lb = false;     // the one-pass Huffman packing gave up once (k_encode32_lb): this context packs in three passes from then on
     std::vector<int> chain_codes; std::vector<unsigned char> chain_unpred;   // the chains' outputs, kept across calls (fresh memory page-faults under the chain: ~1 ms for the M-field's 10 MB)
     unsigned char *sec_pin[4] = {nullptr, nullptr, nullptr, nullptr}; size_t sec_pin_cap[4] = {0, 0, 0, 0};   // the coefficient sections of the stream header as the chain threads build them: pinned, they go to the device from where they are
     szhip_chain_pool *chain_pool = nullptr;      // the coefficient chains' persistent threads (created with the first array that has regression blocks)
@@ -159,14 +158,8 @@ namespace {
 template <class F>
 static int with_ticket_fallback(szhip_ctx *ctx, F &&run)
 {
-    ctx->wave_timeout = false; ctx->hdec_unconverged = false; ctx->coef_late = false; ctx->enc_lb_failed = false;
+    ctx->wave_timeout = false; ctx->hdec_unconverged = false; ctx->coef_late = false;
     int rc = run();
-    if (rc == SZHIP_OK && !ctx->no_enc_lb && tune_int("SZ_HIP_TEST_ENC_LB_FALLBACK", 0)) { ctx->enc_lb_failed = true; rc = SZHIP_ERR_INTERNAL; }   // tests: exercise the repetition
-    if (rc == SZHIP_ERR_INTERNAL && ctx->enc_lb_failed && !ctx->no_enc_lb) {               // (compression: the one-pass packing)
-        if (ctx->stream3) hipStreamSynchronize(ctx->stream3); hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream);
-        ctx->no_enc_lb = true; ctx->wave_timeout = false; ctx->coef_late = false;
-        rc = run();
-    }
     if (rc == SZHIP_OK && !ctx->no_chain_overlap && tune_int("SZ_HIP_TEST_CHAIN_FALLBACK", 0)) { ctx->coef_late = true; rc = SZHIP_ERR_INTERNAL; }   // tests: exercise the repetition
     if (rc == SZHIP_ERR_INTERNAL && ctx->coef_late && !ctx->no_chain_overlap) {           // (compression of arrays with regression blocks only)
         if (ctx->stream3) hipStreamSynchronize(ctx->stream3); hipStreamSynchronize(ctx->stream2); hipStreamSynchronize(ctx->stream);

@@ -1378,152 +1378,6 @@ __global__ __launch_bounds__(256) void k_encode32(const uint16_t *__restrict__ c
     }
 }
 
-// k_encode32 without the passes in front of it (round 5): k_chunk_bits read the 2 N bytes of codes once only to learn where every chunk's bits start, and
-// three scan launches turned the counts into offsets.  Here a workgroup keeps its SZH_E32_PER rounds of codes in registers (128 codes a thread), sums their code
-// lengths, and gets the bit offset of its first round from its predecessors by a DECOUPLED LOOK-BACK (Merrill & Garland's single-pass scan): it publishes
-// its own total (`A`), reads the descriptors of the workgroups before it -- 64 at a time, one per lane of its first wavefront --, adds totals until it meets a
-// workgroup that has published an inclusive prefix (`P`), and publishes its own.  Workgroups take their index from an atomic ticket, so every predecessor is
-// running or done; descriptors are single 64-bit words (two flag bits on top) moved with agent-scope atomics -- the per-XCD L2s are not coherent.  Waits are
-// bounded: a workgroup that gives up raises *err (3) and the host repeats the call with the three-pass form.  desc[0 .. nwg) and *ticket zeroed by the host.
-#define SZH_LB_A (1ull << 62)
-#define SZH_LB_P (2ull << 62)
-#define SZH_LB_VAL ((1ull << 62) - 1)
-__global__ __launch_bounds__(256) void k_encode32_lb(const uint16_t *__restrict__ codes, int64_t n, const u64 *__restrict__ packed, unsigned nsym,
-                                                     u64 *desc, unsigned *ticket, u64 bit0, unsigned *out32, u64 *total_bits_out, unsigned *err)
-{
-    SZH_DYN_SMEM(smem);
-    __shared__ u64 sh[8];
-    __shared__ u64 prefix_s;
-    __shared__ unsigned wg_s;
-    u64 *ltab = reinterpret_cast<u64 *>(smem);
-    unsigned *win = reinterpret_cast<unsigned *>(smem + (size_t)nsym * 8);
-    const int tid = threadIdx.x;
-    for (unsigned i = tid; i < nsym; i += 256) ltab[i] = packed[i];
-    if (tid == 0) wg_s = atomicAdd(ticket, 1u);
-    __syncthreads();
-    const int64_t b = (int64_t)wg_s;
-    const int64_t nrounds = (n + SZH_E32_ROUND - 1) / SZH_E32_ROUND;
-    const int64_t nwg = (nrounds + SZH_E32_PER - 1) / SZH_E32_PER;
-    if (b >= nwg) return;                                          // (uniform)
-    const int64_t r0 = b * SZH_E32_PER;
-    // ---- the workgroup's codes, and how many bits each thread's 32 codes of a round take
-    uint4 v[SZH_E32_PER][4];
-    unsigned s[SZH_E32_PER];
-#pragma unroll
-    for (int rr = 0; rr < SZH_E32_PER; ++rr) {
-        const int64_t r = r0 + rr;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int64_t p = r * SZH_E32_ROUND + tid * 32 + k * 8;
-            if (r < nrounds && p + 8 <= n) v[rr][k] = *reinterpret_cast<const uint4 *>(codes + p);
-            else {
-                uint16_t c[8];
-                for (int e = 0; e < 8; ++e) c[e] = (r < nrounds && p + e < n) ? codes[p + e] : (uint16_t)0xffffu;
-                __builtin_memcpy(&v[rr][k], c, 16);
-            }
-        }
-    }
-    u64 ex[SZH_E32_PER], tot[SZH_E32_PER], T = 0;
-#pragma unroll
-    for (int rr = 0; rr < SZH_E32_PER; ++rr) {
-        const int64_t p0 = (r0 + rr) * SZH_E32_ROUND + tid * 32;
-        unsigned a = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned wv[4] = {v[rr][k].x, v[rr][k].y, v[rr][k].z, v[rr][k].w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const unsigned c = (e & 1) ? wv[e >> 1] >> 16 : wv[e >> 1] & 0xffffu;
-                if (p0 + k * 8 + e < n) a += (unsigned)(ltab[c] & 0xffu);
-            }
-        }
-        s[rr] = a;
-        ex[rr] = block_excl_scan_256((u64)a, sh, &tot[rr]);
-        T += tot[rr];
-    }
-    // ---- where the workgroup's bits start: the look-back (first wavefront)
-    if (tid < 64) {
-        u64 prefix = 0;
-        if (b == 0) { if (tid == 0) __hip_atomic_store(&desc[0], SZH_LB_P | T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-        else {
-            if (tid == 0) __hip_atomic_store(&desc[b], SZH_LB_A | T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            bool bad = false;
-            for (int64_t j = b - 1; j >= 0; j -= 64) {
-                const int64_t mine = j - tid;                      // lane 0: the nearest predecessor of this window
-                u64 d = SZH_LB_P;                                  // (in front of workgroup 0: an inclusive prefix of nothing)
-                unsigned spins = 0;
-                for (;;) {
-                    if (mine >= 0) d = __hip_atomic_load(&desc[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (__all((d >> 62) != 0)) break;
-                    if (++spins > (1u << 20)) { bad = true; break; }
-#ifndef SZH_HIPSIM
-                    __builtin_amdgcn_s_sleep(2);
-#endif
-                }
-                if (bad) break;
-                // the nearest lane that holds a prefix ends the walk; the totals of the lanes in front of it count
-                const u64 pmask = __ballot((d >> 62) == 2);
-                const int stop = pmask ? __builtin_ctzll(pmask) : 64;
-                u64 part = tid <= stop ? (d & SZH_LB_VAL) : 0;
-                for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-                prefix += part;
-                if (pmask) break;
-            }
-            if (bad) { if (tid == 0) atomicMax(err, 3u); prefix = 0; }
-            if (tid == 0) __hip_atomic_store(&desc[b], SZH_LB_P | ((prefix + T) & SZH_LB_VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (tid == 0) { prefix_s = prefix; if (b == nwg - 1) *total_bits_out = prefix + T; }
-    }
-    __syncthreads();
-    u64 gbit = bit0 + prefix_s;
-    // ---- pack, round by round (as k_encode32)
-#pragma unroll
-    for (int rr = 0; rr < SZH_E32_PER; ++rr) {
-        const int64_t r = r0 + rr;
-        if (r >= nrounds) break;                                   // uniform
-        const int64_t p0 = r * SZH_E32_ROUND + tid * 32;
-        const unsigned lead = (unsigned)(gbit & 31);
-        const unsigned nwords = (unsigned)((lead + tot[rr] + 31) >> 5);
-        for (unsigned w = tid; w < nwords + 1; w += 256) win[w] = 0;
-        __syncthreads();
-        if (s[rr]) {
-            const unsigned bitpos = lead + (unsigned)ex[rr];
-            unsigned wpos = bitpos >> 5, nb = bitpos & 31u;
-            u64 acc = 0;
-            bool first = true;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const unsigned wv[4] = {v[rr][k].x, v[rr][k].y, v[rr][k].z, v[rr][k].w};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const unsigned c = (e & 1) ? wv[e >> 1] >> 16 : wv[e >> 1] & 0xffffu;
-                    if (p0 + k * 8 + e < n) {
-                        const u64 en = ltab[c];
-                        const unsigned le = (unsigned)(en & 0xffu);
-                        acc = (acc << le) | (en >> 8);
-                        nb += le;
-                        if (nb >= 32) {
-                            const unsigned word = (unsigned)(acc >> (nb - 32));
-                            if (first) { atomicOr(&win[wpos], word); first = false; } else win[wpos] = word;
-                            ++wpos; nb -= 32;
-                        }
-                    }
-                }
-            }
-            if (nb) atomicOr(&win[wpos], (unsigned)(acc << (32 - nb)));
-        }
-        __syncthreads();
-        const u64 w0 = gbit >> 5;
-        for (unsigned w = tid; w < nwords; w += 256) {
-            const unsigned x = __builtin_bswap32(win[w]);
-            if (w == 0 || w == nwords - 1) { if (x) atomicOr(&out32[w0 + w], x); }
-            else out32[w0 + w] = x;
-        }
-        __syncthreads();                                          // the window is read out before the next round clears it
-        gbit += tot[rr];
-    }
-}
-
 // ------------------------------------------------------------------ Huffman decoding (self-synchronising)
 // The reference stream is one unbroken bit string (Huffman.c:205-308) with no index, so there are no
 // known codeword boundaries.  Every thread decodes one SUBSEQ-bit subsequence from a guessed start;

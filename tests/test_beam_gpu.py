@@ -88,22 +88,6 @@ def test_beam_fed_while_it_runs_equals_the_oracle(sz, oracle, name, monkeypatch)
             assert int(st.chain_overlapped) == 2, "the fed order must be the one that ran"
 
 
-@pytest.mark.parametrize("name", ["long-in-i", "f64", "mean", "S128"])
-def test_inverse_beam_fed_while_it_runs_equals_the_oracle(sz, oracle, name, monkeypatch):
-    """round 5, an alternative form that is off by default (slower: DESIGN section 5): the inverse sweep launched right behind the Huffman decode and fed the codes in
-    natural order and the unpredictable values slice by slice (k_permute<1>, k_unpred on the second stream).  The reference decoder's bits, twice over."""
-    d, eb = _cases()[name]
-    ref, _ = oracle.compress(d, oracle.ABS, eb)
-    want = oracle.decompress(ref, d.shape, d.dtype)
-    monkeypatch.setenv("SZ_HIP_DEC_FEED", "1"); monkeypatch.setenv("SZ_HIP_DEC_FEED_MIN", "1")
-    for slices in ("8", "3"):
-        monkeypatch.setenv("SZ_HIP_DEC_FEED_SLICES", slices)
-        dec = sz.SZ_decompress(ref, d.shape, d.dtype)
-        assert np.array_equal(dec.view(np.uint8), want.view(np.uint8)), (name, slices)
-        if d.shape[1] * d.shape[2] % 128 == 0:
-            assert int(sz.SZ_hip_last_stats().chain_overlapped) == 3, "the fed order must be the one that ran"
-
-
 def test_m_field_512_full_size(sz):
     """BASELINE configs[2] at full size against the recorded output of the unmodified reference."""
     from sz_amd.fields import m_field
