@@ -394,9 +394,9 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
     # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside the timed process);
     # only valid for the workload it was measured on
     qk = getattr(stats, "quant_kernel", 0)
-    kname = "k_beam<float,false,false,false>" if qk == 2 else "k_ribbon<float,false,false>" if qk == 1 else "k_pencil<float,false>"
+    kname = "k_beam<float,false,false,false>" if qk == 2 else "k_pencil<float,false>"
     traffic, traffic_src = None, None
-    for name in (("r06_pmc_traffic_beam_sfield.json",) if qk == 2 else ("r05_pmc_traffic_ribbon.json", "r03_pmc_traffic_ribbon.json") if qk == 1 else ("r02_pmc_traffic_pencil.json", "r01_pmc_traffic_pencil.json")):
+    for name in (("r06_pmc_traffic_beam_sfield.json",) if qk == 2 else ("r02_pmc_traffic_pencil.json", "r01_pmc_traffic_pencil.json")):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", name)))
             if n == EDGE:

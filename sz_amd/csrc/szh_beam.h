@@ -52,7 +52,7 @@ using szh_oc::lds_get16;
 using szh_oc::lds_put16;
 using szh_oc::order;
 using szh_oc::wave_sync;
-typedef szh_rb::v4u v4u;
+typedef szh_io::v4u v4u;
 
 #ifndef SZH_BM_DK
 #define SZH_BM_DK 1
@@ -168,8 +168,8 @@ __device__ __forceinline__ double bsel(unsigned mask, double a, double b)
 // then counts the accesses in flight exactly: with accesses under a branch its `s_waitcnt vmcnt` fell to 0 once per line -- a memory round
 // trip every five steps).  `soff` is wavefront-uniform; the range check is against offset + soff.  AUX: 0 plain, 2 non-temporal, 17 = sc0 sc1
 // (granules: written through, read past this XCD's copies)
-typedef szh_rb::rsrc_t rsrc_t;
-using szh_rb::make_rsrc;
+typedef szh_io::rsrc_t rsrc_t;
+using szh_io::make_rsrc;
 #define SZH_BM_OOB 0xffffffffu
 #ifdef SZH_HIPSIM
 static inline bool inr(rsrc_t rs, unsigned off, unsigned soff, unsigned bytes) { return (uint64_t)off + soff + bytes <= rs.n; }

@@ -245,7 +245,7 @@ template <class T> __device__ __forceinline__ int32_t szg_prequant(T x, T recip,
 // offset and reads 0 (= the value whose pre-quantised form is 0, what the halo outside the array has to be), so there is no branch
 // around a load and any row alignment goes as 16-byte vectors.  Planes too large for 32-bit offsets inside a tile (9 planes >= 2 GB)
 // take plain loads at commit time instead (szg_big).
-template <class T> struct szg_regs { szh_rb::v4u w[(SZG_ROWS * (SZF_TK / (16 / (int)sizeof(T))) + 255) / 256]; T hx; };
+template <class T> struct szg_regs { szh_io::v4u w[(SZG_ROWS * (SZF_TK / (16 / (int)sizeof(T))) + 255) / 256]; T hx; };
 __host__ __device__ __forceinline__ bool szg_big(const szg_geom &g, size_t esz) { return (uint64_t)(SZG_TI + 1) * (uint64_t)g.r1 * (uint64_t)g.r2 * esz >= 0x7ff00000ull; }
 template <class T>
 __device__ __forceinline__ void szg_tile_load(const szg_geom &g, const T *__restrict__ data, int i0, int j0, int k0, szg_regs<T> &R)
@@ -255,7 +255,7 @@ __device__ __forceinline__ void szg_tile_load(const szg_geom &g, const T *__rest
     const int ib = i0 > 0 ? i0 - 1 : 0;
     const int64_t base_el = (int64_t)ib * g.r1 * g.r2;
     const uint64_t span = (uint64_t)((int64_t)g.r0 * g.r1 * g.r2 - base_el) * sizeof(T);
-    const szh_rb::rsrc_t rs = szh_rb::make_rsrc(data + base_el, span > 0x7ffffff0ull ? 0x7ffffff0u : (unsigned)span);
+    const szh_io::rsrc_t rs = szh_io::make_rsrc(data + base_el, span > 0x7ffffff0ull ? 0x7ffffff0u : (unsigned)span);
     R.hx = (T)0;
     {
         const int row = threadIdx.x;
@@ -271,7 +271,7 @@ __device__ __forceinline__ void szg_tile_load(const szg_geom &g, const T *__rest
         const int gi = i0 + ih - 1, gj = j0 + jh - 1;
         const bool ok = v < NVEC && gi >= 0 && gj >= 0 && gi < g.r0 && gj < g.r1 && k0 + c < g.r2;
         const unsigned off = (unsigned)(((gi - ib) * g.r1 + gj) * g.r2 + k0 + c) * (unsigned)sizeof(T);
-        R.w[b] = szh_rb::bload16(rs, ok ? off : 0xffffffffu);
+        R.w[b] = szh_io::bload16(rs, ok ? off : 0xffffffffu);
     }
 }
 template <class T>

@@ -34,7 +34,7 @@ static inline void wave_sync() { (void)__all(1); }        // (the lanes of the C
 #define OC_LDS __attribute__((address_space(3)))
 __device__ __forceinline__ void wave_sync() {}
 #endif
-typedef szh_rb::v4u v4u;
+typedef szh_io::v4u v4u;
 
 template <class E> __device__ __forceinline__ E lds_get(OC_LDS unsigned char *base, unsigned off) { return *(volatile OC_LDS E *)(base + off); }
 template <class E> __device__ __forceinline__ void lds_put(OC_LDS unsigned char *base, unsigned off, E v) { *(volatile OC_LDS E *)(base + off) = v; }
@@ -83,7 +83,7 @@ static inline bool in_mask(mask_t m) { return (m >> (threadIdx.x & 63u)) & 1ull;
 __device__ __forceinline__ mask_t lane_mask(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ bool in_mask(mask_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 #endif
-// lane l receives v of lane l - 1, lane 0 receives +0 (DPP wave_shr:1 with bound_ctrl: no `old` operand to set up, unlike szh_rb::shr1)
+// lane l receives v of lane l - 1, lane 0 receives +0 (DPP wave_shr:1 with bound_ctrl: no `old` operand to set up, unlike szh_io::shr1)
 #ifdef SZH_HIPSIM
 template <class T> static inline T shr1z(T v) { const T s = __shfl_up(v, 1, 64); return (threadIdx.x & 63) == 0 ? (T)0 : s; }
 #else

@@ -53,7 +53,7 @@ template <class T> struct szh_qargs {
     int no_reg;               // 1: the caller knows that no block is a regression block (the per-pencil scan of blk_lor in front of the sweep is skipped)
     int ticket_mode;          // 0: atomic ticket + order table; 1: blockIdx.x as the ticket (+ table); 2: blockIdx.x and the tile computed (szh_pencil_order_at)
     int persist;              // k_pencil: persistent workgroups draw tile after tile from the ticket counter (gridDim.x < number of tiles)
-    int codes_ribbon;         // k_ribbon, inverse: `codes` is in ribbon order (szh_ribbon.h; k_permute<1> wrote it that way) instead of natural order
+    int codes_ribbon;         // (unused since round 6: the ribbon mapping is gone)
     unsigned *err;            // set to 1 if a halo wait timed out
     const szh_u64 *coef_progress; // compress, optional: number of blocks (scan order) whose decoded coefficients have arrived in `coef`;
                               // the host's coefficient chain runs NEXT TO this kernel and ships them as it goes (nullptr: all there)

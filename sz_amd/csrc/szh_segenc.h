@@ -449,3 +449,123 @@ __global__ __launch_bounds__(256) void k_col_encode(szh_geom3 G, const uint16_t 
         s = sn;
     }
 }
+
+// ------------------------------------------------------------------ the way back (round 6): block-ordered codes -> natural order, unpredictable values into the array
+// Until round 6: k_permute<1> (0.35 ms at 512^3), three scan launches and k_unpred<1> (0.08 ms) between the Huffman decode and the inverse sweep.
+// k_col_zeros: the zero codes of every block column (its codes are one contiguous range of the block-ordered array).
+__global__ __launch_bounds__(256) void k_col_zeros(szh_geom3 G, const uint16_t *__restrict__ blk, unsigned *__restrict__ col_zeros)
+{
+    __shared__ unsigned red[4];
+    const szh_se::col_t c = szh_se::make_col(G, (int)blockIdx.x);
+    const int64_t base = szh_code_base01(G, c.b0, c.b1), len = (int64_t)c.rows * G.g2.count;
+    const int head = (int)(base & 7);
+    const int64_t ngroups = (head + len + 7) / 8;
+    unsigned z = 0;
+    for (int64_t g = threadIdx.x; g < ngroups; g += 256) {
+        const uint4 w = *reinterpret_cast<const uint4 *>(blk + (base - head) + g * 8);       // (the array has slack behind its last code)
+        const unsigned wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int64_t at = g * 8 + e - head;
+            const unsigned cd = (e & 1) ? wv[e >> 1] >> 16 : wv[e >> 1] & 0xffffu;
+            z += (at >= 0 && at < len && cd == 0u) ? 1u : 0u;
+        }
+    }
+    z = wave_sum_u32(z);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = z;
+    __syncthreads();
+    if (threadIdx.x == 0) col_zeros[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+// k_col_unpack: a workgroup per block column, the column in the segments of `segs`: a segment's block-ordered codes into LDS as they lie (one contiguous range, 16-byte
+// loads); every thread walks its share of them for zero codes, whose values -- the next ones of the stream's list, col_zoff says where the column's begin; never beyond
+// `ucap` entries -- go to their places in `out` (szd_float.c:3784: the pre-scattered values the inverse sweep finds); then the segment's rows leave in natural order,
+// 16 bytes at a time, gathered from LDS.
+template <class T>
+__global__ __launch_bounds__(256) void k_col_unpack(szh_geom3 G, const uint16_t *__restrict__ blk, uint16_t *__restrict__ nat, const szh_se::seg_t *__restrict__ segs, int nseg, int vw,
+                                                    const u64 *__restrict__ col_zoff, const T *__restrict__ unpred, u64 ucap, T *__restrict__ out)
+{
+    using namespace szh_se;
+    SZH_DYN_SMEM(smem);
+    __shared__ u64 sh[8];
+    __shared__ unsigned rowbase[128];
+    uint16_t *L = reinterpret_cast<uint16_t *>(smem);
+    const int tid = (int)threadIdx.x;
+    const col_t c = make_col(G, (int)blockIdx.x);
+    if (tid < c.rows) { const int i = tid / c.s1, j = tid - i * c.s1; rowbase[tid] = (unsigned)((int64_t)(c.o0 + i) * G.d0 + (int64_t)(c.o1 + j) * G.d1); }
+    const int64_t col_base = szh_code_base01(G, c.b0, c.b1);
+    u64 zeros_done = col_zoff[blockIdx.x];
+    for (int segi = 0; segi < nseg; ++segi) {
+        const seg_t s = segs[segi];
+        const int klen = s.kend - s.kbeg, total = c.rows * klen;
+        const int64_t start = col_base + (int64_t)c.rows * s.kbeg;
+        const int head = (int)(start & 7), ngroups = (head + total + 7) / 8;
+        __syncthreads();                                             // (the segment before has left the buffer; the row offsets are there)
+        for (int g = tid; g < ngroups; g += 256) *reinterpret_cast<uint4 *>(L + g * 8) = *reinterpret_cast<const uint4 *>(blk + (start - head) + (int64_t)g * 8);
+        __syncthreads();
+        const uint16_t *B = L + head;                                // the segment's codes in block order: [block][row][kk]
+        const int esz = c.rows * s.E, lsz = c.rows * s.L, eregion = s.nE * esz;
+        // the unpredictable values: a thread's share = `per` consecutive codes
+        {
+            const int per = (total + 255) / 256, e0 = tid * per, e1 = e0 + per < total ? e0 + per : total;
+            unsigned z = 0;
+            for (int e = e0; e < e1; ++e) z += B[e] == 0 ? 1u : 0u;
+            u64 tot;
+            u64 rank = zeros_done + block_excl_scan_256((u64)z, sh, &tot);
+            if (z) {
+                for (int e = e0; e < e1; ++e) {
+                    if (B[e] != 0) continue;
+                    int bl, rem, s2, koff;
+                    if (e < eregion) { bl = e / esz; rem = e - bl * esz; s2 = s.E; koff = bl * s.E; }
+                    else { const int e2 = e - eregion; bl = e2 / lsz; rem = e2 - bl * lsz; s2 = s.L; koff = s.nE * s.E + bl * s.L; }
+                    const int row = rem / s2, kk = rem - row * s2;
+                    if (rank < ucap) out[(size_t)rowbase[row] + (unsigned)(s.kbeg + koff + kk)] = unpred[rank];
+                    ++rank;
+                }
+            }
+            zeros_done += tot;
+        }
+        // natural order out: vector cv of row r (a power-of-two pitch for the vector index); the vector's codes are read run after run: where the first one
+        // lies is worked out once, the step from a run's end to the same row of the next block is (rows - 1) s2 (+ r (s2' - s2) where the block width changes)
+        const int lg = s.lg_nvec, mask = (1 << lg) - 1;
+        const unsigned m_E = magic_of((unsigned)s.E), m_L = magic_of((unsigned)s.L);
+        const int edge_k = s.nE * s.E;
+        for (int x = tid; (x >> lg) < c.rows; x += 256) {
+            const int r = x >> lg, cv = x & mask;
+            if (cv >= s.nvec) continue;
+            const int k0 = s.ka + cv * vw;                             // the vector's first k; its codes that lie in [kbeg, kend) are this segment's
+            const int kl = k0 - s.kbeg;                                // (may be negative in a row's first vector)
+            const int e_lo = kl < 0 ? -kl : 0, e_hi = klen - kl < vw ? klen - kl : vw;
+            uint16_t v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0;
+            if (e_lo < e_hi) {
+                const int q = kl + e_lo;
+                int bl, kk, s2;
+                if (q < edge_k) { bl = (int)div_by((unsigned)q, (unsigned)s.E, m_E); kk = q - bl * s.E; s2 = s.E; }
+                else { const int q2 = q - edge_k; const int b2 = (int)div_by((unsigned)q2, (unsigned)s.L, m_L); kk = q2 - b2 * s.L; bl = s.nE + b2; s2 = s.L; }
+                int idx = (bl < s.nE ? bl * esz : eregion + (bl - s.nE) * lsz) + r * s2 + kk, left = s2 - kk;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (e >= e_lo && e < e_hi) {
+                        v[e] = B[idx];
+                        ++idx;
+                        if (--left == 0) {
+                            ++bl;
+                            const int s2n = bl < s.nE ? s.E : s.L;
+                            idx += (c.rows - 1) * s2 + r * (s2n - s2);
+                            s2 = s2n; left = s2;
+                        }
+                    }
+                }
+            }
+            uint16_t *dst = nat + (size_t)rowbase[r] + (unsigned)k0;
+            if (kl >= 0 && kl + vw <= klen) {
+                if (vw == 8) { uint4 w; __builtin_memcpy(&w, v, 16); *reinterpret_cast<uint4 *>(dst) = w; }
+                else if (vw == 4) { uint2 w; __builtin_memcpy(&w, v, 8); *reinterpret_cast<uint2 *>(dst) = w; }
+                else dst[0] = v[0];
+            } else {
+                for (int e = 0; e < vw; ++e) if (kl + e >= 0 && kl + e < klen) dst[e] = v[e];      // (a vector that straddles two segments: each writes its own codes)
+            }
+        }
+    }
+}

@@ -19,7 +19,7 @@
 #include <hip/hip_runtime.h>
 #include "szh_core.h"
 #include "szh_pencil.h"
-#include "szh_ribbon.h"
+#include "szh_bufio.h"
 
 typedef unsigned long long u64;
 
@@ -660,11 +660,9 @@ __global__ __launch_bounds__(256) void k_chain_seg_1d(const T *__restrict__ data
 
 // ------------------------------------------------------------------ code histogram (order independent)
 // LDS-privatised with R replicas per bin to spread same-symbol atomics over banks.
-// rb.on: `codes` is in the ribbon order of szh_ribbon.h (n = its length, padding included): a group of 8 codes is 8 consecutive k of
-// one row; positions outside the array are skipped by geometry (r0, r1, r2 = the array's extents)
-// first: the pass covers elements [first, n) (a multiple of 8; the histogram of a slice of the ribbon order, taken while the sweep is running)
+// first: the pass covers elements [first, n) (a multiple of 8; the histogram of a slice of the code array, taken while the sweep is running)
 __global__ __launch_bounds__(256) void k_hist_u16(const uint16_t *__restrict__ codes, int64_t n, unsigned nbins, int rshift,
-                                                  int use_lds, unsigned *hist, szh_rb_layout rb, int r0, int r1, int r2, int64_t first)
+                                                  int use_lds, unsigned *hist, int64_t first)
 {
     SZH_DYN_SMEM(smem);
     unsigned *sh = reinterpret_cast<unsigned *>(smem);
@@ -677,10 +675,6 @@ __global__ __launch_bounds__(256) void k_hist_u16(const uint16_t *__restrict__ c
     const int64_t nvec = n / 8;
     const uint4 *v4 = reinterpret_cast<const uint4 *>(codes);
     const int64_t stride = (int64_t)gridDim.x * 256;
-    auto is_p2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
-    auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
-    const bool pow2 = rb.on && is_p2(rb.U / 8) && is_p2(rb.R) && is_p2(rb.W) && (nvec >> 6) < (int64_t)0xffffffffll;
-    const int lg_gv = pow2 ? lg(rb.U / 8) : 0, lg_R = pow2 ? lg(rb.R) : 0, lg_W = pow2 ? lg(rb.W) : 0;
     for (int64_t i = first / 8 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += 4 * stride) {     // four loads in flight per thread
         uint4 v[4];
 #pragma unroll
@@ -689,36 +683,15 @@ __global__ __launch_bounds__(256) void k_hist_u16(const uint16_t *__restrict__ c
         for (int u = 0; u < 4; ++u) {
             if (i + u * stride >= nvec) break;
             const unsigned wv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-            int klo = 0, khi = 8;                                 // which of the group's 8 codes count
-            if (rb.on) {
-                // group g of the ribbon order: [tile][trip][w][r][v][lane] -> k of its first code, row and column of the array
-                // (32-bit arithmetic: five 64-bit divisions per group were more than half of this pass, 0.16 ms against 0.07 for natural-order
-                //  codes; U / 8, R and W are powers of two in every shape of szh_rb_shape, `pow2` says so)
-                const int64_t g64 = i + u * stride;
-                const int ln = (int)(g64 & 63);
-                unsigned g = (unsigned)(g64 >> 6);
-                const unsigned gv = (unsigned)rb.U / 8;
-                int vv, rr, w;
-                if (pow2) { vv = (int)(g & (gv - 1)); g >>= lg_gv; rr = (int)(g & ((unsigned)rb.R - 1)); g >>= lg_R; w = (int)(g & ((unsigned)rb.W - 1)); g >>= lg_W; }
-                else { vv = (int)(g % gv); g /= gv; rr = (int)(g % (unsigned)rb.R); g /= (unsigned)rb.R; w = (int)(g % (unsigned)rb.W); g /= (unsigned)rb.W; }
-                const unsigned ntr = (unsigned)(rb.NT / rb.U);
-                const unsigned g1 = g / ntr; const int trip = (int)(g - g1 * ntr);
-                const unsigned g2 = g1 / (unsigned)rb.nTJ; const int TJ = (int)(g1 - g2 * (unsigned)rb.nTJ), TI = (int)g2;
-                const int row = (TI * rb.W + w) * rb.R + rr, col = TJ * 64 + ln;
-                const int k0 = trip * rb.U + vv * 8 - w * (rb.R - 1) - ln - rr;
-                if (row >= r0 || col >= r1) khi = 0;
-                else { klo = k0 < 0 ? -k0 : 0; khi = r2 - k0 < 8 ? r2 - k0 : 8; }
-            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const unsigned c0 = wv[q] & 0xffffu, c1 = wv[q] >> 16;
-                const bool t0 = 2 * q >= klo && 2 * q < khi, t1 = 2 * q + 1 >= klo && 2 * q + 1 < khi;
-                if (use_lds) { if (t0) atomicAdd(&sh[(c0 << rshift) + rep], 1u); if (t1) atomicAdd(&sh[(c1 << rshift) + rep], 1u); }
-                else { if (t0) atomicAdd(&hist[c0], 1u); if (t1) atomicAdd(&hist[c1], 1u); }
+                if (use_lds) { atomicAdd(&sh[(c0 << rshift) + rep], 1u); atomicAdd(&sh[(c1 << rshift) + rep], 1u); }
+                else { atomicAdd(&hist[c0], 1u); atomicAdd(&hist[c1], 1u); }
             }
         }
     }
-    if (blockIdx.x == 0 && !rb.on) {
+    if (blockIdx.x == 0) {
         for (int64_t i = nvec * 8 + threadIdx.x; i < n; i += 256) {
             const unsigned c = codes[i];
             if (use_lds) atomicAdd(&sh[(c << rshift) + rep], 1u); else atomicAdd(&hist[c], 1u);
@@ -742,20 +715,16 @@ __global__ __launch_bounds__(256) void k_hist_u16(const uint16_t *__restrict__ c
 // It also notes WHERE the zero codes are (segment-local block-order index, up to SZH_ZCAP per workgroup, unordered), so that
 // k_unpred does not have to read the code array again to find them.
 #define SZH_ZCAP 128
-#define SZH_PERM_ROWS 256   /* rows of a block column whose ribbon-order constants k_permute<0> keeps in LDS */
 template <int DIR>
 __device__ __forceinline__ void permute_body(const szh_geom3 &G, const uint16_t *__restrict__ src, uint16_t *__restrict__ dst,
-                                             unsigned *col_zeros, int segb, unsigned *zcnt, unsigned *zpos, const szh_rb_layout &rb,
+                                             unsigned *col_zeros, int segb, unsigned *zcnt, unsigned *zpos,
                                              unsigned *hist, unsigned hist_bins, int tile_elems, int col0, int dbg, const int segi, const int nseg_all)
 {   // dbg (development, timing only): 1 = no loads in the gather, 2 = no LDS stores in the gather, 4 = no block-order side, 8 = return after the prologue
    // col0: the launch covers block columns col0 .. col0 + gridDim.x - 1 (a slice of the array along dim 0)
-    // rb.on: the natural-order side (`src` for DIR 0, `dst` for DIR 1) is in the ribbon order of szh_ribbon.h
     // hist (DIR 0 only, hist_bins > 0): the code histogram of Huffman.c:165-174 is taken here, while the codes sit in LDS anyway (one
     // pass over the code array less): per workgroup in LDS behind the tile, the peak symbol (radius = hist_bins / 2, most of a smooth
     // field) counted by ballot instead of by atomics, non-empty bins added to the global histogram at the end
     __shared__ unsigned zc_s, zp_s[SZH_ZCAP];
-    __shared__ int64_t prm_base[SZH_PERM_ROWS];
-    __shared__ int prm_off[SZH_PERM_ROWS];
     if (threadIdx.x == 0) zc_s = 0;
     __syncthreads();
     SZH_DYN_SMEM(smem);
@@ -805,69 +774,8 @@ __device__ __forceinline__ void permute_body(const szh_geom3 &G, const uint16_t 
     const unsigned peak = hist_bins / 2;
     unsigned peak_cnt = 0;
     if (do_hist) { for (unsigned b = threadIdx.x; b < hist_bins; b += 256) lh[b] = 0; }
-    const unsigned rb_gv = rb.on ? (unsigned)rb.U / 8 : 1u;
-    // round 4: the fast form of DIR 0 from ribbon order keeps the tile in BLOCK ORDER (element e of the segment at tile[head + e]), so the
-    // per-element work -- which block, which place in it -- is done once, where the gather scatters its 2-byte pieces into LDS anyway, and
-    // the block-order side below is a 16-byte LDS read and a 16-byte store per eight codes.  (Measured before, 0.295 ms in all: 0.078 for the
-    // launch of 21 675 workgroups and their prologue, 0.094 the gather, 0.123 the block-order side with its walk over rows and runs.)
     const int head = (int)(base & 7);                             // elements of the first 16-byte group that belong to the previous segment
-    const bool blocked = DIR == 0 && rb.on && !do_hist && fdiv_ok && rows <= SZH_PERM_ROWS && (rb_gv & (rb_gv - 1)) == 0 && klen / 8 + 2 <= 256 && total + 16 <= tile_elems;
-    if (blocked) {
-        // gather from ribbon order, round 4: what depends on the ROW only (tile, wavefront, lane -> where its groups start, its step
-        // shift) is worked out once per row into LDS, and the threads are laid out as (row, group) with a power-of-two pitch -- the five
-        // divisions per 16-byte group of the form below were most of this pass's instructions (0.33 ms, 45 instructions per code)
-        const int ng = klen / 8 + 2, WR = rb.W * rb.R;
-        int ngp = 1; while (ngp < ng) ngp <<= 1;
-        int lg_gv = 0; while ((1u << lg_gv) < rb_gv) ++lg_gv;
-        const int64_t trip_stride = (int64_t)rb.W * rb.R * rb_gv * 512;
-        for (int r = threadIdx.x; r < rows; r += 256) {
-            const int i = o0 + r / s1, j = o1 + r % s1;
-            const int TI = i / WR, q = i - TI * WR, w = q / rb.R, rr = q - w * rb.R, TJ = j >> 6, ln = j & 63;
-            prm_off[r] = w * (rb.R - 1) + ln + rr;
-            prm_base[r] = ((int64_t)TI * rb.nTJ + TJ) * szh_rb_tile_elems(rb) + (int64_t)(w * rb.R + rr) * rb_gv * 512 + ln * 8;
-        }
-        __syncthreads();
-        const int gl = threadIdx.x & (ngp - 1), rstep = 256 / ngp;
-        if (gl < ng)
-            for (int r = threadIdx.x / ngp; r < rows; r += rstep) {
-                const int off = prm_off[r];
-                const int tt8 = ((kbeg + off) >> 3) + gl;
-                const int k0 = tt8 * 8 - off;
-                if (k0 >= kend) continue;
-                const uint4 wv = (dbg & 1) ? make_uint4(off, tt8, k0, 1) : *reinterpret_cast<const uint4 *>(src + prm_base[r] + (int64_t)(tt8 >> lg_gv) * trip_stride + (int64_t)(tt8 & (int)(rb_gv - 1)) * 512);
-                uint16_t v[8]; __builtin_memcpy(v, &wv, 16);
-                if (dbg & 2) { if (wv.x == 0xdeadbeefu) tile[0] = 1; continue; }
-                // place of the next code in the tile and codes left in its run (this row of this block): by kpos at the start of every run.
-                // (A table of the places in LDS, one look-up per code, was slower: 0.270 against 0.244 ms -- the pass is bound by its LDS operations.)
-                int pos = 0, left = 0;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int k = k0 + e;
-                    if (k >= kbeg && k < kend) {
-                        if (left == 0) pos = head + kpos(k - kbeg, r, left);
-                        tile[pos] = v[e];
-                        ++pos; --left;
-                    }
-                }
-            }
-        __syncthreads();
-    } else if (DIR == 0 && rb.on) {
-        // (the general form: one thread per (row, group), everything by division)
-        const int ng = klen / 8 + 2, WR = rb.W * rb.R;
-        for (int p = threadIdx.x; p < rows * ng; p += 256) {
-            const int r = p / ng, gl = p - r * ng;
-            const int i = o0 + r / s1, j = o1 + r % s1;
-            const int TI = i / WR, q = i - TI * WR, w = q / rb.R, rr = q - w * rb.R, TJ = j >> 6, ln = j & 63;
-            const int off = w * (rb.R - 1) + ln + rr;                       // shifted step of k = 0
-            const int tt8 = ((kbeg + off) >> 3) + gl;                        // group number along the sweep
-            const int k0 = tt8 * 8 - off;
-            if (k0 >= kend) continue;
-            const uint4 wv = *reinterpret_cast<const uint4 *>(src + szh_rb_group_index(rb, (int64_t)TI * rb.nTJ + TJ, w, rr, tt8 * 8) + ln * 8);
-            uint16_t v[8]; __builtin_memcpy(v, &wv, 16);
-            for (int e = 0; e < 8; ++e) { const int k = k0 + e; if (k >= kbeg && k < kend) tile[r * kp + kshift + (k - kbeg)] = v[e]; }
-        }
-        __syncthreads();
-    } else if (DIR == 0) {
+    if (DIR == 0) {
         for (int r = wid; r < rows; r += 4) {
             const int i = r / s1, j = r - i * s1;
             const uint16_t *srow = src + (int64_t)(o0 + i) * G.d0 + (int64_t)(o1 + j) * G.d1 + ka;
@@ -877,25 +785,7 @@ __device__ __forceinline__ void permute_body(const szh_geom3 &G, const uint16_t 
         __syncthreads();
     }
     // block-order side: the segment is one contiguous range [base, base + total); 16-byte groups by absolute address
-    if (blocked && !(dbg & 4)) {
-        const int ngroups = (head + total + 7) / 8;
-        for (int g = threadIdx.x; g < ngroups; g += 256) {
-            const int e0 = g * 8 - head;                           // may be negative in the first group
-            const int elo = e0 < 0 ? 0 : e0, ehi = e0 + 8 > total ? total : e0 + 8;
-            const uint4 w = *reinterpret_cast<const uint4 *>(tile + g * 8);
-            uint16_t v[8]; __builtin_memcpy(v, &w, 16);
-#pragma unroll
-            for (int q8 = 0; q8 < 8; ++q8) {
-                const int e = e0 + q8;
-                if (e >= elo && e < ehi && v[q8] == 0) { ++zeros; const unsigned q = atomicAdd(&zc_s, 1u); if (q < SZH_ZCAP) zp_s[q] = (unsigned)e; }
-            }
-            if (ehi - elo == 8) *reinterpret_cast<uint4 *>(dst + base + e0) = w;
-            else {
-#pragma unroll
-                for (int q8 = 0; q8 < 8; ++q8) { const int e = e0 + q8; if (e >= elo && e < ehi) dst[base + e] = v[q8]; }
-            }
-        }
-    } else if (!(dbg & 4)) {
+    if (!(dbg & 4)) {
         const int ngroups = (head + total + 7) / 8;
         for (int g = threadIdx.x; g < ngroups; g += 256) {
             const int e0 = g * 8 - head;                           // may be negative in the first group
@@ -920,34 +810,7 @@ __device__ __forceinline__ void permute_body(const szh_geom3 &G, const uint16_t 
             }
         }
     }
-    if (DIR == 1 && rb.on) {
-        // into ribbon order (the inverse sweep of szh_ribbon.h reads its codes the way the forward sweep writes them): one thread per
-        // (row, group of 8 consecutive k); a group that straddles the segment is completed by the neighbouring workgroup, so its
-        // part goes out as 2-byte stores
-        __syncthreads();
-        const int ng = klen / 8 + 2, WR = rb.W * rb.R;
-        for (int p = threadIdx.x; p < rows * ng; p += 256) {
-            const int r = p / ng, gl = p - r * ng;
-            const int i = o0 + r / s1, j = o1 + r % s1;
-            const int TI = i / WR, q = i - TI * WR, w = q / rb.R, rr = q - w * rb.R, TJ = j >> 6, ln = j & 63;
-            const int off = w * (rb.R - 1) + ln + rr;                       // shifted step of k = 0
-            const int tt8 = ((kbeg + off) >> 3) + gl;                        // group number along the sweep
-            const int k0 = tt8 * 8 - off;
-            if (k0 >= kend) continue;
-            uint16_t *d = dst + szh_rb_group_index(rb, (int64_t)TI * rb.nTJ + TJ, w, rr, tt8 * 8) + ln * 8;
-            if (k0 >= kbeg && k0 + 8 <= kend) {
-                uint16_t v[8];
-                for (int e = 0; e < 8; ++e) v[e] = tile[r * kp + kshift + (k0 + e - kbeg)];
-                uint4 wv; __builtin_memcpy(&wv, v, 16);
-                *reinterpret_cast<uint4 *>(d) = wv;
-            } else {
-#ifndef SZH_HIPSIM
-#pragma clang loop vectorize(disable) unroll(disable)
-#endif
-                for (int e = 0; e < 8; ++e) { const int k = k0 + e; if (k >= kbeg && k < kend) d[e] = tile[r * kp + kshift + (k - kbeg)]; }
-            }
-        }
-    } else if (DIR == 1) {
+    if (DIR == 1) {
         __syncthreads();
         for (int r = wid; r < rows; r += 4) {
             const int i = r / s1, j = r - i * s1;
@@ -978,12 +841,12 @@ __device__ __forceinline__ void permute_body(const szh_geom3 &G, const uint16_t 
 // segment, launching the 21 675 workgroups of a 512^3 array and their prologues was 0.08 of the pass's 0.3 ms.
 template <int DIR>
 __global__ __launch_bounds__(256) void k_permute(szh_geom3 G, const uint16_t *__restrict__ src, uint16_t *__restrict__ dst,
-                                                 unsigned *col_zeros, int segb, unsigned *zcnt, unsigned *zpos, szh_rb_layout rb,
+                                                 unsigned *col_zeros, int segb, unsigned *zcnt, unsigned *zpos,
                                                  unsigned *hist, unsigned hist_bins, int tile_elems, int col0, int dbg = 0)
 {
     const int nseg_all = (G.g2.num + segb - 1) / segb;
     for (int segi = (int)blockIdx.y; segi < nseg_all; segi += (int)gridDim.y) {
-        permute_body<DIR>(G, src, dst, col_zeros, segb, zcnt, zpos, rb, hist, hist_bins, tile_elems, col0, dbg, segi, nseg_all);
+        permute_body<DIR>(G, src, dst, col_zeros, segb, zcnt, zpos, hist, hist_bins, tile_elems, col0, dbg, segi, nseg_all);
         __syncthreads();                                           // (the tile and the workgroup's counters are reused)
     }
 }
@@ -996,8 +859,8 @@ template <class T, int DIR>
 __global__ __launch_bounds__(256) void k_unpred(szh_geom3 G, const uint16_t *__restrict__ codes_blk, const unsigned *__restrict__ col_zeros,
                                                 const u64 *__restrict__ col_off, const T *data, T *unpred, T *out,
                                                 const unsigned *__restrict__ zcnt, const unsigned *__restrict__ zpos, int segb, int nseg,
-                                                szh_rb_layout rb = szh_rb_layout{0, 0, 0, 0, 0, 0}, int col0 = 0, u64 ucap = ~0ull)
-{   // rb.on (DIR 1 only): `out` is a value array in the ribbon order of szh_ribbon.h (szh_rb_value_index)
+                                                int col0 = 0, u64 ucap = ~0ull)
+{
     // col0: the launch covers block columns col0 .. col0 + gridDim.x - 1 (a slice along dim 0); ucap (DIR 1): entries of `unpred` -- a launch that runs before
     // the host has compared the columns' zero counts with the stream's list (slices beside the inverse sweep) must not read behind the list
     __shared__ u64 sh[8];
@@ -1021,7 +884,6 @@ __global__ __launch_bounds__(256) void k_unpred(szh_geom3 G, const uint16_t *__r
         else { const int64_t e2 = e - eregion; const int64_t bl = e2 / lsz; rem = e2 - bl * lsz; s2 = G.g2.late; o2 = G.g2.split * G.g2.early + (int)bl * G.g2.late; }
         const int row = (int)(rem / s2), kk = (int)(rem - (int64_t)row * s2);
         const int ii = row / s1, jj = row - ii * s1;
-        if (DIR == 1 && rb.on) return szh_rb_value_index(rb, 16 / (int)sizeof(T), o0 + ii, o1 + jj, o2 + kk);
         return (int64_t)(o0 + ii) * G.d0 + (int64_t)(o1 + jj) * G.d1 + o2 + kk;
     };
     // the positions k_permute noted, if every segment's note is complete: order them (they are few) and move the values
@@ -1510,7 +1372,7 @@ __device__ __forceinline__ unsigned hdec_run_lut(const SZH_LDS unsigned *l, unsi
         const unsigned idx = win >> (32 - SZH_LUT_BITS);
         unsigned w;
         if (WRITE) {
-            const szh_rb::v4u e = reinterpret_cast<const SZH_LDS szh_rb::v4u *>(lut)[idx];
+            const szh_io::v4u e = reinterpret_cast<const SZH_LDS szh_io::v4u *>(lut)[idx];
             w = e.w;
             if (w & 15u) put((u64)e.x | ((u64)e.y << 32), w & 15u);
         } else w = reinterpret_cast<const SZH_LDS unsigned *>(lut)[idx];
@@ -1693,59 +1555,6 @@ __global__ __launch_bounds__(256) void k_hdec_write(szh_hdec_args a, const u64 *
     unsigned endl;
     hdec_run_lut<true>(S.l, total, ltab, a.table, lut, run ? (unsigned)((int64_t)st_g - S.bit0) : 0u, run ? (unsigned)((int64_t)limit_g - S.bit0) : 0u, &endl, out, o, oend, run);
 }
-// ------------------------------------------------------------------ ribbon-order values -> the array (inverse, mode 2)
-// The inverse sweep of szh_ribbon.h leaves its results in ribbon order (coalesced stores); this pass writes them where they belong.
-// A wavefront takes one (tile, wavefront w, row r) and SZH_UR_STEPS steps of it: 64 lanes x SZH_UR_STEPS values = 64 row pieces of
-// SZH_UR_STEPS * sizeof(T) contiguous bytes.  It reads them as the sweep wrote them (64 lanes x 16 bytes per load), turns the block
-// in LDS and writes every row piece with neighbouring lanes (SZH_UR_STEPS / g lanes per row: 256-byte runs for float).
-#ifndef SZH_UR_STEPS
-#define SZH_UR_STEPS 64
-#endif
-template <class T>
-__global__ __launch_bounds__(256) void k_unribbon(szh_geom3 G, szh_rb_layout rb, const T *__restrict__ xr, T *__restrict__ out)
-{
-    constexpr int g = 16 / (int)sizeof(T), NV = SZH_UR_STEPS / g, PITCH = SZH_UR_STEPS + g;      // (+ g: rows start in different banks)
-    static_assert(64 % NV == 0 && (szh_rb_shape<T>::W * szh_rb_shape<T>::R) % 4 == 0, "a wavefront writes whole rows; a workgroup takes four (w, r) pairs");
-    __shared__ __attribute__((aligned(16))) T tile[4][64 * PITCH];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int WR = rb.W * rb.R, nchunk = (rb.NT + SZH_UR_STEPS - 1) / SZH_UR_STEPS;
-    // blockIdx.x -> (tile, group of 4 (w, r) pairs, chunk of steps)
-    const int64_t b = blockIdx.x;
-    const int chunk = (int)(b % nchunk); const int64_t b1 = b / nchunk;
-    const int grp = (int)(b1 % (WR / 4)); const int64_t tile_id = b1 / (WR / 4);
-    const int TI = (int)(tile_id / rb.nTJ), TJ = (int)(tile_id - (int64_t)TI * rb.nTJ);
-    const int q = grp * 4 + wv, w = q / rb.R, r = q - w * rb.R;
-    const int i = TI * WR + q;
-    const int tt0 = chunk * SZH_UR_STEPS;
-    T *const tb = tile[wv];
-    // read: vector v of the chunk = steps tt0 + g v ..; in the ribbon array vector (trip, vv) of (w, r) is 64 lanes x 16 bytes
-    const int64_t tbase = tile_id * szh_rb_tile_elems(rb);
-#pragma unroll 4
-    for (int v = 0; v < NV; ++v) {
-        const int tt = tt0 + v * g;
-        if (tt >= rb.NT) break;
-        const int trip = tt / rb.U, vv = (tt - trip * rb.U) / g;
-        const uint4 val = *reinterpret_cast<const uint4 *>(xr + tbase + (((((int64_t)trip * rb.W + w) * rb.R + r) * (rb.U / g) + vv) * 64 + lane) * g);
-        *reinterpret_cast<uint4 *>(tb + lane * PITCH + v * g) = val;
-    }
-    __syncthreads();
-    if (i >= G.g0.count) return;
-    // write: NV lanes per row; row ln holds positions k = tt - sh - ln - r
-    const int sh = w * (rb.R - 1), seg = lane % NV, rl = lane / NV;
-    for (int rr = 0; rr < 64; rr += 64 / NV) {
-        const int ln = rr + rl, j = TJ * 64 + ln;
-        if (j >= G.g1.count) continue;
-        const int k = tt0 + seg * g - sh - ln - r;
-        const uint4 val = *reinterpret_cast<const uint4 *>(tb + ln * PITCH + seg * g);
-        T *dst = out + (int64_t)i * G.d0 + (int64_t)j * G.d1 + k;
-        if (k >= 0 && k + g <= G.g2.count && tt0 + seg * g + g <= rb.NT) __builtin_memcpy(dst, &val, 16);      // (4- / 8-byte aligned: one 16-byte store on gfx950)
-        else {
-            T tmp[g]; __builtin_memcpy(tmp, &val, 16);
-            for (int e = 0; e < g; ++e) if (k + e >= 0 && k + e < G.g2.count && tt0 + seg * g + e < rb.NT) dst[e] = tmp[e];
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void k_fill_u16(uint16_t *p, int64_t n, uint16_t v)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;

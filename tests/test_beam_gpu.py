@@ -4,7 +4,7 @@ and through HBM granules), ragged extents in every dimension, a last k-beam with
 regression blocks (their points quantised by k_reg_points, passed through by the sweep), regression next to Lorenzo blocks at the array's
 faces.  (b) BASELINE configs[2] at FULL size -- the 512^3 M-field -- against what the unmodified reference gave for it
 (tests/golden/anchors.json, recorded by tools/record_reference_m512.py): stream length, md5, regression blocks, decoded md5, PSNR to 6 d.p.,
-the bound.  (c) The same streams with the beam switched off (k_ribbon / k_pencil): one switch, identical bytes."""
+the bound.  (c) The same streams with the beam switched off (k_pencil): one switch, identical bytes."""
 import hashlib
 import json
 import os

@@ -1,5 +1,5 @@
 """Round 6: the packing passes that read the sweep's natural-order codes (sz_amd/csrc/szh_segenc.h: per-column histograms, k_col_bits / k_col_bits_h, k_col_scan,
-k_col_encode), the fit pass from LDS tiles (szh_fittile.h) and the two other orders of the interval optimiser's passes -- every form must give the oracle's stream,
+k_col_encode; on the way back k_col_zeros, k_col_unpack), the fit pass from LDS tiles (szh_fittile.h) and the two other orders of the interval optimiser's passes -- every form must give the oracle's stream,
 byte for byte (the oracle: oracle/, pinned against the reference's recorded outputs; sz_float.c:7064-7359, Huffman.c:205-308, sz_float.c:6598-6633, :7083-7123)."""
 import ctypes
 import os
@@ -22,7 +22,7 @@ def _cases():
             ("s50x47x52", s_field(50, 47, 52)),                                                  # every dimension with early and late blocks
             ("noisy", (s_field(30, 36, 40) + 0.01 * rng.standard_normal((30, 36, 40))).astype(np.float32)),      # 1024 intervals: beyond the per-column histograms
             ("f64", s_field(24, 30, 36, np.float64)),
-            ("s20x20x45", s_field(20, 20, 45)),                                                  # rows that are no multiple of four values: the other sweeps
+            ("s20x20x45", s_field(20, 20, 45)),                                                  # rows that are no multiple of four values: k_pencil
             ("s7x9x12", s_field(7, 9, 12)),                                                      # single blocks of 7 and 9: the general forms
             ("spiky", np.where(rng.random((24, 24, 64)) < 0.02, 100.0, s_field(24, 24, 64)).astype(np.float32)),  # 65536 / 16384 intervals: the block-ordered copy after all
             ("m30x41x56", np.ascontiguousarray(m_field(56)[:30, :41, :])),
@@ -30,7 +30,8 @@ def _cases():
 
 
 SWITCHES = ["", "SZ_HIP_SEGENC=0", "SZ_HIP_SEGHIST=0", "SZ_HIP_SEG_SCAN1=0", "SZ_HIP_SEG_SEGB=3", "SZ_HIP_SEG_TILE_KB=4", "SZ_HIP_SEGENC=2", "SZ_HIP_FIT_TILE=1",
-            "SZ_HIP_MEAN_FIRST=1", "SZ_HIP_MEAN_FIRST=1;SZ_HIP_SAMPLE_EARLY=1", "SZ_HIP_SAMPLE_EARLY=1"]
+            "SZ_HIP_MEAN_FIRST=1", "SZ_HIP_MEAN_FIRST=1;SZ_HIP_SAMPLE_EARLY=1", "SZ_HIP_SAMPLE_EARLY=1",
+            "SZ_HIP_COL_UNPACK=0", "SZ_HIP_UNPACK_TILE_KB=4"]
 
 
 def _run(monkeypatch, switch, few=False):
@@ -53,6 +54,8 @@ def _run(monkeypatch, switch, few=False):
                 seen.add(int(st.packing))
                 assert got == ref, (switch, name, eb, len(got), len(ref), int(st.packing), int(st.quant_kernel))
                 dec = sz_amd.SZ_decompress(got, d.shape, d.dtype)
+                want = O.decompress(ref, d.shape, d.dtype)
+                assert np.array_equal(dec.view(np.uint8), want.view(np.uint8)), (switch, name, eb, "decoded values differ from the reference decoder's")
                 assert float(np.abs(dec.astype(np.float64) - d).max()) <= eb
         return seen
     finally:
@@ -75,7 +78,7 @@ def test_packing_from_natural_order_codes_on_the_cpu_shim(shim, monkeypatch, swi
     if switch == "SZ_HIP_SEGENC=0":
         assert seen == {0}
     else:
-        assert seen == {0, 1}          # (the large alphabets and the ribbon sweep's arrays still take the block-ordered copy)
+        assert seen == {0, 1}          # (the large alphabets still take the block-ordered copy)
 
 
 @pytest.mark.gpu

@@ -186,12 +186,12 @@ def test_huffman_decoder_blocks_long_codes_and_repair_rounds_on_cpu_shim(oracle,
         api._lib = saved
 
 
-def _ribbon_inverse_cases():
+def _ragged_inverse_cases():
     return [("S-33x70x50", s_field(33, 70, 50), 1e-4), ("S-f64-20x65x40", s_field(20, 65, 40, np.float64), 1e-6), ("S-17x130x38", s_field(17, 130, 38), 1e-3)]
 
 
-def test_opt_in_ribbon_inverse_on_cpu_shim(oracle, built):
-    """SZ_HIP_RIBBON_DEC=1: the inverse sweep on k_ribbon (ribbon-order codes from k_permute<1>, results transposed through LDS) must
+def test_inverse_of_arrays_the_beam_does_not_take_on_cpu_shim(oracle, built):
+    """rows that are no multiple of four values: the inverse sweep runs k_pencil (until round 5: the ribbon mapping); it must
     decode the oracle's streams bit for bit -- ragged tiles in every dimension, float and double."""
     import sim_lib
     import sz_amd
@@ -200,31 +200,29 @@ def test_opt_in_ribbon_inverse_on_cpu_shim(oracle, built):
     try:
         api._lib = api._bind(ctypes.CDLL(sim_lib.shim_path()))
         assert sz_amd.SZ_Init(os.path.join(ROOT, "tests", "golden", "sz_speed.config")) == 0
-        for mode in ("1", "2"):           # 1: results through the STORE wavefront; 2: ribbon-order value array + k_unribbon
-            os.environ["SZ_HIP_RIBBON_DEC"] = mode
-            for name, d, eb in _ribbon_inverse_cases():
+        for mode in ("-",):
+            for name, d, eb in _ragged_inverse_cases():
                 ref_stream, _ = oracle.compress(d, oracle.ABS, eb)
                 got = sz_amd.SZ_decompress(ref_stream, d.shape, d.dtype)
                 iv = np.uint32 if d.dtype == np.float32 else np.uint64
                 assert np.array_equal(got.view(iv), oracle.decompress(ref_stream, d.shape, d.dtype).view(iv)), (name, mode)
         sz_amd.SZ_Finalize()
     finally:
-        os.environ.pop("SZ_HIP_RIBBON_DEC", None)
+        pass
         api._lib = saved
 
 
 @pytest.mark.gpu
-def test_opt_in_ribbon_inverse_on_gpu(oracle, built):
+def test_inverse_of_arrays_the_beam_does_not_take_on_gpu(oracle, built):
     import sz_amd
     try:
         assert sz_amd.SZ_Init(os.path.join(ROOT, "tests", "golden", "sz_speed.config")) == 0
-        for mode in ("1", "2"):
-            os.environ["SZ_HIP_RIBBON_DEC"] = mode
-            for name, d, eb in _ribbon_inverse_cases() + [("S-100x200x300", s_field(100, 200, 300), 1e-4)]:
+        for mode in ("-",):
+            for name, d, eb in _ragged_inverse_cases() + [("S-100x200x300", s_field(100, 200, 300), 1e-4)]:
                 ref_stream, _ = oracle.compress(d, oracle.ABS, eb)
                 got = sz_amd.SZ_decompress(ref_stream, d.shape, d.dtype)
                 iv = np.uint32 if d.dtype == np.float32 else np.uint64
                 assert np.array_equal(got.view(iv), oracle.decompress(ref_stream, d.shape, d.dtype).view(iv)), (name, mode)
         sz_amd.SZ_Finalize()
     finally:
-        os.environ.pop("SZ_HIP_RIBBON_DEC", None)
+        pass
