@@ -38,7 +38,38 @@ struct szhip_sweep_gate { std::mutex m; hipEvent_t last = nullptr; int lanes = 2
 // compress calls of this process that are inside the library right now, whatever their context: the chain / kernel overlap of an array with
 // regression blocks is only taken by a call that starts alone (see compress_impl)
 static std::atomic<int> g_compress_calls{0};
-struct compress_call_guard { compress_call_guard() { g_compress_calls.fetch_add(1); } ~compress_call_guard() { g_compress_calls.fetch_sub(1); } };
+// (round 6) A sweep that is FED while the host's chains run (arrays with regression blocks, a call that starts alone) must not be joined half-way by another lone context's
+// call: its slices' kernels then wait behind the other call's sweep, the fed sweep runs into its bounded waits, and the call is repeated -- streams stayed right in 20 000
+// calls of two and four contexts on threads, but single calls took up to 5.7 s (profiles/r06_multi_context_stress_before_the_fed_call_guard.txt).  So: the fed call raises
+// g_fed_active for its duration, and a compress call that starts meanwhile waits at its door (a few milliseconds at most); a call that meets another one inside the library
+// notes the time, and for a while after such a meeting nobody feeds (several contexts at work overlap their calls anyway).  Sequentially consistent: either the fed call sees
+// the newcomer's count (and does not feed), or the newcomer sees the flag (and waits).
+static std::atomic<int> g_fed_active{0};
+static std::atomic<long long> g_last_meeting_us{-(1ll << 60)};
+static long long mono_us() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (long long)ts.tv_sec * 1000000ll + ts.tv_nsec / 1000; }
+struct compress_call_guard {
+    compress_call_guard()
+    {
+        if (g_compress_calls.fetch_add(1) > 0) g_last_meeting_us.store(mono_us());
+        const long long t0 = mono_us();
+        while (g_fed_active.load() != 0 && mono_us() - t0 < 200000) std::this_thread::yield();       // (bounded: 0.2 s, far beyond a fed call)
+    }
+    ~compress_call_guard() { g_compress_calls.fetch_sub(1); }
+};
+// the fed call's side: raise the flag, then look again whether the call is still alone
+struct fed_call_guard {
+    bool on = false;
+    bool try_raise()
+    {
+        if (mono_us() - g_last_meeting_us.load() < 100000) return false;       // (another context was at work within the last 0.1 s)
+        int expected = 0;
+        if (!g_fed_active.compare_exchange_strong(expected, 1)) return false;
+        if (g_compress_calls.load() > 1) { g_fed_active.store(0); return false; }
+        on = true;
+        return true;
+    }
+    ~fed_call_guard() { if (on) g_fed_active.store(0); }
+};
 // The host's coefficient chains (szhost_coeff_chain_one_p: one serial chain per coefficient) on PERSISTENT threads (round 5).  Threads created per
 // call started 0.1 ms late on cores that had been idle (measured on the GPU box: four chains of 1.0 - 1.2 ms each took 2.1 - 2.7 ms end to
 // end, and 4.9 on some runs).  A context that has met regression blocks once keeps four workers; they are woken when a compression STARTS and
