@@ -134,7 +134,7 @@ struct szhip_ctx {
     int settle_probes = 0, settle_rejected = 0;   // settle_streams: queue probes made, streams replaced
     int side_prio = 0;               // 1: stream2 at the lowest, stream3 at the highest stream priority (create_ctx)
     hipStream_t stream3 = nullptr;   // the block-ordering pass of finished tile rows, while the sweep is still running on `stream` (created on first use)
-    hipEvent_t ev_perm = nullptr, ev_mean = nullptr;
+    hipEvent_t ev_perm = nullptr;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     char err[512] = {0};
     unsigned epoch = 0;
@@ -149,7 +149,7 @@ struct szhip_ctx {
     unsigned long long *hdec_res = nullptr;      // pinned: {symbols the payload holds, starts still moving after round 1}, copied asynchronously
     // workspaces (grow-only)
     DevBuf lor_bits, reg_flags, reg_rank, coef_compact, in, out, codes_nat, codes_blk, coef, blk_lor, faceI, faceJ, rb_down, rb_right, rb_vals, pt_flags, feed_word, fast_slots, fast_units, progress, trace, order, small, hist, col_zeros, col_zeros64,
-        seg_bits, seg_zeros, seg_bitoff, seg_zoff, seg_hist, seg_tab, keep_vals, keep_cnt, col_off, partial, samples, unpred, stream_buf, chunk_bits, chunk_off, code_tab, len_tab, dec_tab,
+        seg_bits, seg_zeros, seg_bitoff, seg_zoff, seg_hist, seg_tab, col_off, partial, samples, unpred, stream_buf, chunk_bits, chunk_off, code_tab, len_tab, dec_tab,
         starts, ends, counts, offs, dirty, zcnt, zpos, pwr_log, pwr_signs, pwr_small, coef_dec, msst_ptab, msst_cells, msst_rec, msst_pe;
     void *pinned = nullptr; size_t pinned_cap = 0;
     void *pinned2 = nullptr; size_t pinned2_cap = 0;   // target of the second stream's copies (indicator bits, regression-block count)
@@ -294,7 +294,7 @@ void szhip_destroy(szhip_ctx *ctx)
     hipStreamSynchronize(ctx->stream);
     delete ctx->chain_pool; ctx->chain_pool = nullptr;
     DevBuf *bufs[] = {&ctx->lor_bits, &ctx->reg_flags, &ctx->reg_rank, &ctx->coef_compact, &ctx->in, &ctx->out, &ctx->codes_nat, &ctx->codes_blk, &ctx->coef, &ctx->blk_lor, &ctx->faceI, &ctx->faceJ, &ctx->rb_down, &ctx->rb_right, &ctx->rb_vals, &ctx->pt_flags, &ctx->feed_word, &ctx->fast_slots, &ctx->fast_units, &ctx->progress, &ctx->trace,
-                      &ctx->order, &ctx->small, &ctx->hist, &ctx->col_zeros, &ctx->col_zeros64, &ctx->seg_bits, &ctx->seg_zeros, &ctx->seg_bitoff, &ctx->seg_zoff, &ctx->seg_hist, &ctx->seg_tab, &ctx->keep_vals, &ctx->keep_cnt, &ctx->col_off, &ctx->partial,
+                      &ctx->order, &ctx->small, &ctx->hist, &ctx->col_zeros, &ctx->col_zeros64, &ctx->seg_bits, &ctx->seg_zeros, &ctx->seg_bitoff, &ctx->seg_zoff, &ctx->seg_hist, &ctx->seg_tab, &ctx->col_off, &ctx->partial,
                       &ctx->samples, &ctx->unpred, &ctx->stream_buf, &ctx->chunk_bits, &ctx->chunk_off, &ctx->code_tab,
                       &ctx->len_tab, &ctx->dec_tab, &ctx->starts, &ctx->ends, &ctx->counts, &ctx->offs, &ctx->dirty, &ctx->zcnt, &ctx->zpos,
                       &ctx->pwr_log, &ctx->pwr_signs, &ctx->pwr_small, &ctx->coef_dec, &ctx->msst_ptab, &ctx->msst_cells, &ctx->msst_rec, &ctx->msst_pe};
@@ -315,7 +315,6 @@ void szhip_destroy(szhip_ctx *ctx)
     if (ctx->stream2) hipStreamDestroy(ctx->stream2);
     if (ctx->stream3) hipStreamDestroy(ctx->stream3);
     if (ctx->ev_perm) hipEventDestroy(ctx->ev_perm);
-    if (ctx->ev_mean) hipEventDestroy(ctx->ev_mean);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }

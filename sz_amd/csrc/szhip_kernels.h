@@ -378,11 +378,9 @@ __global__ __launch_bounds__(256) void k_gather_mean(const T *__restrict__ data,
 // FREQ = false: only the radius histogram is wanted (the SZ 1.4 optimiser and the OpenMP container's, sz_float.c:4644) -- 16 KB of LDS
 // instead of 48.  (Round 4 tried one thread per SAMPLE instead of per row: slower -- 0.23 ms against 0.10-0.16 -- the pass is bound by
 // the 64-byte sectors its scattered reads touch, ~0.35 GB at 512^3, not by the five dependent rounds of a row.)
-// keep != nullptr (round 6): the histogram around the mean is NOT taken here -- the mean is still on its way to the host and back when this pass starts --; the sampled
-// values themselves are kept, `nmax` places per row and their number in keep_cnt, for k_freq_hist to bin once the mean is known
 template <class T, bool FREQ>
 __global__ __launch_bounds__(256) void k_sample(szh_geom3 G, const T *__restrict__ data, int64_t nrows, int sd, double ebD, T mean,
-                                                unsigned max_radius, unsigned *radius_hist, unsigned *freq_hist, u64 *within, T *keep = nullptr, uint8_t *keep_cnt = nullptr, int nmax = 0)
+                                                unsigned max_radius, unsigned *radius_hist, unsigned *freq_hist, u64 *within)
 {
     __shared__ unsigned sh_r[SZH_LDS_RADIUS_BINS];
     __shared__ unsigned sh_f[FREQ ? 8192 : 1];
@@ -396,7 +394,6 @@ __global__ __launch_bounds__(256) void k_sample(szh_geom3 G, const T *__restrict
         const int64_t n1 = two_d ? 0 : ridx / rpp + 1, n2 = two_d ? ridx + 1 : ridx - (n1 - 1) * rpp + 1;
         const int64_t c0 = two_d ? szh_sample_col0_2d(n2, sd) : sd - ((n1 + n2) % sd);
         const int64_t origin = n1 * G.d0 + n2 * r2;
-        if (FREQ && keep) keep_cnt[ridx] = 0;
         for (int64_t m = 0;; ++m) {
             const int64_t col = c0 + m * sd;
             if (m > 0 && col >= r2) break;
@@ -405,8 +402,7 @@ __global__ __launch_bounds__(256) void k_sample(szh_geom3 G, const T *__restrict
             unsigned ri; int fi, we;
             szh_sample_point<T>(data, pos, r2, two_d ? 0 : G.d0, ebD, mean, max_radius, &ri, &fi, &we);
             if (ri < SZH_LDS_RADIUS_BINS) atomicAdd(&sh_r[ri], 1u); else atomicAdd(&radius_hist[ri], 1u);
-            if (FREQ && !keep) atomicAdd(&sh_f[fi], 1u);
-            if (FREQ && keep && m < nmax) { keep[ridx * nmax + m] = data[pos]; keep_cnt[ridx] = (uint8_t)(m + 1); }
+            if (FREQ) atomicAdd(&sh_f[fi], 1u);
             w += (unsigned)we;
         }
     }
@@ -414,23 +410,8 @@ __global__ __launch_bounds__(256) void k_sample(szh_geom3 G, const T *__restrict
     if ((threadIdx.x & 63) == 0 && w) atomicAdd(within, (u64)w);
     __syncthreads();
     for (int i = threadIdx.x; i < SZH_LDS_RADIUS_BINS; i += 256) if (sh_r[i]) atomicAdd(&radius_hist[i], sh_r[i]);
-    if (FREQ && !keep) for (int i = threadIdx.x; i < 8192; i += 256) if (sh_f[i]) atomicAdd(&freq_hist[i], sh_f[i]);
+    if (FREQ) for (int i = threadIdx.x; i < 8192; i += 256) if (sh_f[i]) atomicAdd(&freq_hist[i], sh_f[i]);
 }
-// the optimiser's histogram around the mean, from the sampled values k_sample kept
-template <class T>
-__global__ __launch_bounds__(256) void k_freq_hist(const T *__restrict__ keep, const uint8_t *__restrict__ keep_cnt, int64_t nrows, int nmax, double ebD, T mean, unsigned *freq_hist)
-{
-    __shared__ unsigned sh_f[8192];
-    for (int i = threadIdx.x; i < 8192; i += 256) sh_f[i] = 0;
-    __syncthreads();
-    for (int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x; x < nrows * nmax; x += (int64_t)gridDim.x * 256) {
-        const int64_t ridx = x / nmax; const int m = (int)(x - ridx * nmax);
-        if (m < (int)keep_cnt[ridx]) atomicAdd(&sh_f[szh_freq_index<T>(keep[x], mean, ebD)], 1u);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 8192; i += 256) if (sh_f[i]) atomicAdd(&freq_hist[i], sh_f[i]);
-}
-
 // The same samples for a DEGENERATE 3-D array (an extent of 1 in dim 0 or dim 1): the reference's walk (sz_float.c:4644-4702 and the
 // optimiser of the SZ 2.1 path) does not see rows and planes, it advances ONE position through the flat array -- with r2 = 1 its row counter
 // never reaches its wrap test the way k_sample's (row, column) form assumes.  Found by tools/omp_diff_fuzz.py on the GPU in round 4 (an

@@ -1,5 +1,5 @@
 """Round 6: the packing passes that read the sweep's natural-order codes (sz_amd/csrc/szh_segenc.h: per-column histograms, k_col_bits / k_col_bits_h, k_col_scan,
-k_col_encode; on the way back k_col_zeros, k_col_unpack), the fit pass from LDS tiles (szh_fittile.h) and the two other orders of the interval optimiser's passes -- every form must give the oracle's stream,
+k_col_encode; on the way back k_col_zeros, k_col_unpack), the fit pass from LDS tiles (szh_fittile.h) -- every form must give the oracle's stream,
 byte for byte (the oracle: oracle/, pinned against the reference's recorded outputs; sz_float.c:7064-7359, Huffman.c:205-308, sz_float.c:6598-6633, :7083-7123)."""
 import ctypes
 import os
@@ -30,7 +30,6 @@ def _cases():
 
 
 SWITCHES = ["", "SZ_HIP_SEGENC=0", "SZ_HIP_SEGHIST=0", "SZ_HIP_SEG_SCAN1=0", "SZ_HIP_SEG_SEGB=3", "SZ_HIP_SEG_TILE_KB=4", "SZ_HIP_SEGENC=2", "SZ_HIP_FIT_TILE=1",
-            "SZ_HIP_MEAN_FIRST=1", "SZ_HIP_MEAN_FIRST=1;SZ_HIP_SAMPLE_EARLY=1", "SZ_HIP_SAMPLE_EARLY=1",
             "SZ_HIP_COL_UNPACK=0", "SZ_HIP_UNPACK_TILE_KB=4"]
 
 
