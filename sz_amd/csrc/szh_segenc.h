@@ -223,8 +223,8 @@ __global__ __launch_bounds__(256) void k_col_bounds(const u64 *__restrict__ col_
     out32[at >> 5] = 0u;
     if (e == nent) out32[(at >> 5) + 1] = 0u;
 }
-// both scans and the boundary words in ONE launch of one workgroup (up to 2^14 columns, sixteen per thread in registers: six launches of the general scan less)
-#define SZH_COL_SCAN_PER 16
+// both scans and the boundary words in ONE launch of one workgroup (up to 2^13 columns, eight per thread in registers -- sixteen spilled under the 1024-thread register bound --: six launches of the general scan less)
+#define SZH_COL_SCAN_PER 8
 __global__ __launch_bounds__(1024) void k_col_scan(const u64 *__restrict__ col_bits, const u64 *__restrict__ col_zeros, int nent, u64 *__restrict__ col_bitoff, u64 *__restrict__ col_zoff,
                                                    u64 *total_bits, u64 *total_zeros, u64 bit0, unsigned *out32)
 {
