@@ -494,70 +494,6 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
                     "stream_identical_to_single_call": bool(lsz == msize and torch.equal(lob[:lsz], ref_m))}
         del xm, mdec
 
-    # ---- the opt-in FAST mode (SZ_HIP_MODE=fast: feedback-free quantiser, own container, own oracle; never the headline value)
-    fast = None
-    if world == 1 and n == EDGE and args.fast and not args.no_fast:
-        fob = out_bufs[0]
-        for _ in range(2):
-            ctx.compress_fast(x.data_ptr(), True, (n, n, n), np.float32, EB, 0, fob.data_ptr(), out_cap)
-        _sync(torch); tf = time.perf_counter()
-        fq = []
-        for _ in range(args.steps):
-            _, fsize, fst = ctx.compress_fast(x.data_ptr(), True, (n, n, n), np.float32, EB, 0, fob.data_ptr(), out_cap)
-            fq.append(fst.ms_quant)
-        _sync(torch); tf = (time.perf_counter() - tf) / args.steps
-        fdst = ctx.decompress_fast(fob.data_ptr(), True, fsize, (n, n, n), np.float32, dec.data_ptr(), True)
-        ferr = float((dec - x).abs().max().item())
-        _sync(torch); tfd = time.perf_counter()
-        for _ in range(3):
-            ctx.decompress_fast(fob.data_ptr(), True, fsize, (n, n, n), np.float32, dec.data_ptr(), True)
-        _sync(torch); tfd = (time.perf_counter() - tfd) / 3
-        fq_ms = float(np.mean(fq))
-        two_pass = getattr(fst, "quant_kernel", 0) == 2
-        # the other form of the front end (SZ_HIP_FAST2: 0 = code array, 1 = two passes over the input, szh_fast.h): same stream, its own times
-        other_form = None
-        if not args.dry_run:
-            import hashlib
-            h_default = hashlib.sha256(fob[:fsize].cpu().numpy().tobytes()).hexdigest()
-            prev = os.environ.get("SZ_HIP_FAST2")
-            os.environ["SZ_HIP_FAST2"] = "0" if two_pass else "1"
-            try:
-                for _ in range(2):
-                    ctx.compress_fast(x.data_ptr(), True, (n, n, n), np.float32, EB, 0, fob.data_ptr(), out_cap)
-                _sync(torch); t2 = time.perf_counter()
-                q2, e2 = [], []
-                for _ in range(args.steps):
-                    _, fsize2, fst2 = ctx.compress_fast(x.data_ptr(), True, (n, n, n), np.float32, EB, 0, fob.data_ptr(), out_cap)
-                    q2.append(fst2.ms_quant); e2.append(fst2.ms_entropy)
-                _sync(torch); t2 = (time.perf_counter() - t2) / args.steps
-                q2m = float(np.mean(q2))
-                other_form = {"form": "two passes over the input (k_fast_stat: statistics; k_fast_pack: per-unit slots; k_fast_compact), no code array"
-                                      if fst2.quant_kernel == 2 else "code array (k_fast_quant writes 2 N bytes of codes; histogram, chunk bits, k_encode)",
-                              "ms": round(t2 * 1e3, 3), "GB/s": round(nbytes_in / t2 / 1e9, 2), "phase_ms": {"quant": round(q2m, 3), "entropy": round(float(np.mean(e2)), 3)},
-                              "quant_kernel": "k_fast_stat<float>" if fst2.quant_kernel == 2 else "k_fast_quant<float>",
-                              "quant_kernel_frac_of_hbm_peak_on_N_sizeof_T": round(nbytes_in / (q2m * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                              "stream_identical_to_default_form": bool(fsize2 == fsize and hashlib.sha256(fob[:fsize2].cpu().numpy().tobytes()).hexdigest() == h_default)}
-            finally:
-                if prev is None: os.environ.pop("SZ_HIP_FAST2", None)
-                else: os.environ["SZ_HIP_FAST2"] = prev
-        # the predict+quantise kernel is priced on N * sizeof(T) bytes READ.  Two-pass form (szh_fast.h): k_fast_stat reads the
-        # array once and writes no code array; the code-array form (SZ_HIP_FAST2=0) also writes 2 N bytes of codes (reported separately)
-        falg = nbytes_in
-        fast = {"mode": "SZ_HIP_MODE=fast (szhip_compress_fast): q = rint(x/2eb), integer Lorenzo on q, same Huffman stage; container 'SZHF', "
-                        "not readable by stock SZ; checked against oracle/szo_fast.c"
-                        + ("; two passes over the input (statistics, then packing into per-unit slots + bit-exact compaction), no code array" if two_pass else ""),
-                "GB/s": round(nbytes_in / tf / 1e9, 2), "ms": round(tf * 1e3, 3), "decompress_GBps": round(nbytes_in / tfd / 1e9, 2),
-                "out_bytes": int(fsize), "ratio": round(nbytes_in / fsize, 4), "ratio_vs_exact": round(size / fsize, 4), "max_abs_err": ferr,
-                "side_list_entries": int(fst.n_unpred),
-                "phase_ms": {"quant": round(fst.ms_quant, 3), "entropy": round(fst.ms_entropy, 3), "host_glue": round(fst.ms_host, 3),
-                             "compress_call_total": round(fst.ms_total, 3), "decompress_entropy": round(fdst.ms_entropy, 3),
-                             "decompress_scans": round(fdst.ms_quant, 3), "decompress_total": round(fdst.ms_total, 3)},
-                "roofline": {"bound": "hbm", "kernel": "k_fast_stat<float>" if two_pass else "k_fast_quant<float>", "achieved": round(falg / (fq_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": round(falg / (fq_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
-                             "algorithmic_bytes_per_launch": falg, "avg_kernel_ms": round(fq_ms, 4),
-                             "note": "algorithmic bytes = N * sizeof(T) read (SURVEY 8d)" + ("" if two_pass else "; this form also writes 2 N bytes of codes")},
-                "other_form": other_form}
-
     # ---- the other paths of the same library, one line each (optional; outside the timed region; single GPU only): the SZ 1.4 container
     #      (withLinearRegression = NO) on the same array, a 2-D array through the SZ 2.1 path, a 1-D series
     other = None
@@ -772,7 +708,7 @@ def run_headline(args, torch, dist, world, rank, local_rank, dev):
                          "entropy": round(stats.ms_entropy, 3), "host_glue": round(stats.ms_host, 3), "compress_call_total": round(stats.ms_total, 3),
                          "decompress_quant": round(dst.ms_quant, 3), "decompress_total": round(dst.ms_total, 3)},
             "per_rank": per_rank,
-            "roofline": roofline, "concurrent": concurrent, "m_field": mfield, "fast_mode": fast, "other_paths": other, "omp_container": omp, "e2e": e2e, "e2e_default": e2e_default, "cpu_baseline": cpu, "cpu_baseline_mt": cpu_mt}
+            "roofline": roofline, "concurrent": concurrent, "m_field": mfield, "other_paths": other, "omp_container": omp, "e2e": e2e, "e2e_default": e2e_default, "cpu_baseline": cpu, "cpu_baseline_mt": cpu_mt}
     print(json.dumps(line))
     if world > 1:
         dist.barrier(); dist.destroy_process_group()
@@ -916,8 +852,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--other-paths", action="store_true", help="(default since round 4; kept for old command lines)")
     ap.add_argument("--no-other-paths", action="store_true", help="skip the SZ 1.4 container, the 2-D array and the 1-D series (one line each)")
-    ap.add_argument("--no-fast", action="store_true", help="(default since round 5; kept for old command lines)")
-    ap.add_argument("--fast", action="store_true", help="add the opt-in fast-mode object (its own container; frozen since round 3)")
     ap.add_argument("--omp-boxes", type=int, default=-1, help="boxes (thread_num) of the OpenMP-container object; default: 32^3 boxes (4096 at 512^3); 0 = skip")
     ap.add_argument("--no-omp", action="store_true", help="skip the OpenMP-container object")
     ap.add_argument("--omp-ref-child", nargs=2, default=None, help=argparse.SUPPRESS)
@@ -949,14 +883,14 @@ def main():
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))
     if args.timed_only:
-        args.no_cpu_baseline = args.no_fast = args.no_m_field = True
+        args.no_cpu_baseline = args.no_m_field = True
     if args.dry_run:
         # CPU rehearsal of the multi-rank entry (tests/test_distributed_cpu.py): gloo + the product's code on the HIP-on-CPU shim, tiny
         # arrays, no GPU.  Nothing it prints is a measurement.
         if not os.environ.get("SZ_AMD_LIB"):
             raise SystemExit("--dry-run needs SZ_AMD_LIB = tests/sim/libszhip_sim.so")
         dev = torch.device("cpu")
-        args.no_cpu_baseline = args.no_fast = args.no_m_field = True
+        args.no_cpu_baseline = args.no_m_field = True
         args.inflight = 1                      # (the shim executes one launch at a time)
         if world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -66,7 +66,7 @@ typedef struct szhip_stats {
     uint64_t quant_kernel_launches; /* launches of the wavefront kernel (1 per call) */
     double vmin, vmax;      /* the array's range when SZHIP_RANGE_FROM_DATA was set (else 0) */
     int chain_overlapped;   /* 1: the regression-coefficient chain ran next to the wavefront kernel */
-    int quant_kernel;       /* which mapping of the wavefront kernel ran: 0 = k_pencil (8x8 pencils), 1 = k_ribbon (szh_ribbon.h), 2 = k_beam (szh_beam.h); fast mode: 2 = two-pass form */
+    int quant_kernel;       /* which mapping of the wavefront kernel ran: 0 = k_pencil (8x8 pencils), 2 = k_beam (szh_beam.h) */
     int packing;            /* (round 6) 1: the Huffman packing read the sweep's natural-order codes segment by segment (szh_segenc.h); 0: block-ordered copy first */
 } szhip_stats;
 
@@ -214,23 +214,6 @@ int szhip_sz14_pwr_locate(int dtype, const unsigned char *stream, size_t stream_
 int szhip_decompress_sz14_pwr(szhip_ctx *ctx, int dtype, const unsigned char *stream, int stream_on_device, size_t stream_len,
                               size_t body_off, size_t r0, size_t r1, size_t r2, const unsigned char *signs_host, void *out,
                               int out_on_device, szhip_stats *stats);
-
-/*
- * FAST mode (opt-in; SZ_HIP_MODE=fast through the SZ_* API): values pre-quantised to integers (q = rint(x / 2eb), verified per point), then
- * a 7-point Lorenzo difference on q over the whole array in integer arithmetic -- no reconstruction feedback, every point independent,
- * so predict + quantise is a streaming kernel.  The precedent for trading the reference's codes for parallelism is its own OpenMP
- * variant (block-local Lorenzo: SZ_compress_float_3D_MDQ_RA_block, sz/src/sz_float.c:4704-5012; sz/src/sz_omp.c:63-358).  The absolute
- * bound `eb` always holds; codes and ratio differ slightly from the exact path (no regression predictor), and the stream is this
- * library's own container (magic "SZHF"), which a stock SZ reader rejects at its version check.  Inverse: three prefix sums.
- * 1-D / 2-D arrays: leading extents 1.  `intervals`: code alphabet (even, 4 .. 65536; 0 = 1024).  Output conventions as for
- * szhip_compress.  DESIGN.md section 4e.
- */
-int szhip_compress_fast(szhip_ctx *ctx, int dtype, const void *data, int data_on_device, size_t r0, size_t r1, size_t r2, double eb,
-                        unsigned intervals, int out_on_device, unsigned char **out, size_t *out_size, szhip_stats *stats);
-int szhip_decompress_fast(szhip_ctx *ctx, int dtype, const unsigned char *stream, int stream_on_device, size_t stream_len,
-                          size_t r0, size_t r1, size_t r2, void *out, int out_on_device, szhip_stats *stats);
-/* 1 if the bytes start a fast-mode container */
-int szhip_is_fast_stream(const unsigned char *stream, size_t stream_len);
 
 /* test/diagnostic hook: copy the first `bytes` bytes of an internal device workspace of the LAST call to host.
  * which: 0 coef (T SoA[4][nblocks]) 1 blk_lor (u8) 2 codes in natural order (u16) 3 codes in block order (u16)

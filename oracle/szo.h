@@ -18,8 +18,7 @@
  * by tests/test_ref_recorded.py (stream length + md5, decoded md5); plus the survey's
  * own scalar anchors (tests/test_oracle_pins.py).  In the build container the oracle was also run against the
  * reference library itself on random inputs and configurations (tools/ref_diff_fuzz.py: 4 100 cases, streams and decoded
- * arrays identical).  Not pinned: szo_fast.c, which
- * restates this repository's own opt-in fast mode and has no reference counterpart.
+ * arrays identical).
  */
 #ifndef SZO_H
 #define SZO_H
@@ -117,9 +116,6 @@ size_t    szo_huff_encode(const szo_huff *h, const int *s, size_t n, unsigned ch
 void      szo_huff_decode(const szo_huff *h, const unsigned char *in, size_t n, int *out);
 void      szo_huff_free(szo_huff *h);
 
-/* ---- the product's own FAST mode restated as sequential loops (szo_fast.c); `r0` slowest, extents >= 1 ---- */
-unsigned char *szo_fast_compress(int data_type, const void *data, size_t r0, size_t r1, size_t r2, double eb, unsigned intervals, size_t *out_size);
-void *szo_fast_decompress(int data_type, const unsigned char *bytes, size_t len, size_t r0, size_t r1, size_t r2);
 
 /* quality metrics with the formulas of example/sz.c:558-620 */
 void szo_metrics_f32(const float *a, const float *b, size_t n, double *max_abs_err, double *psnr, double *nrmse);

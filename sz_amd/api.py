@@ -129,12 +129,6 @@ def _bind(L):
     L.szhip_decompress_sz14.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, sz, sz, sz, sz, sz,
                                         ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(szhip_stats)]
     L.szhip_decompress_sz14.restype = ctypes.c_int
-    L.szhip_compress_fast.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, sz, sz, sz, ctypes.c_double, ctypes.c_uint, ctypes.c_int,
-                                      ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(sz), ctypes.POINTER(szhip_stats)]
-    L.szhip_compress_fast.restype = ctypes.c_int
-    L.szhip_decompress_fast.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, sz, sz, sz, sz, ctypes.c_void_p, ctypes.c_int,
-                                        ctypes.POINTER(szhip_stats)]
-    L.szhip_decompress_fast.restype = ctypes.c_int
     L.szhip_debug_fetch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, sz]; L.szhip_debug_fetch.restype = ctypes.c_int
     if hasattr(L, "szhip_compress_omp"):
         L.szhip_compress_omp.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, sz, sz, sz, ctypes.c_double, ctypes.c_int,
@@ -341,30 +335,6 @@ class HipContext:
         b = ctypes.string_at(out.value, n.value)
         lib().free(out)
         return b, n.value, st
-
-    def compress_fast(self, ptr, on_device, shape3, dtype, eb, intervals=0, out_ptr=None, out_cap=0):
-        """FAST mode (szhip_compress_fast).  Returns (bytes, size, stats), or (None, size, stats) when the stream went into the
-        caller's device buffer `out_ptr`."""
-        out = ctypes.c_void_p(out_ptr)
-        n = ctypes.c_size_t(out_cap)
-        st = szhip_stats()
-        rc = lib().szhip_compress_fast(self._h, 0 if np.dtype(dtype) == np.float32 else 1, ptr, int(on_device), shape3[0], shape3[1], shape3[2],
-                                       eb, intervals, 2 if out_ptr else 0, ctypes.byref(out), ctypes.byref(n), ctypes.byref(st))
-        if rc:
-            self._err(rc, "szhip_compress_fast")
-        if out_ptr:
-            return None, n.value, st
-        b = ctypes.string_at(out.value, n.value)
-        lib().free(out)
-        return b, n.value, st
-
-    def decompress_fast(self, stream_ptr, stream_on_device, stream_len, shape3, dtype, out_ptr, out_on_device):
-        st = szhip_stats()
-        rc = lib().szhip_decompress_fast(self._h, 0 if np.dtype(dtype) == np.float32 else 1, stream_ptr, int(stream_on_device), stream_len,
-                                         shape3[0], shape3[1], shape3[2], out_ptr, int(out_on_device), ctypes.byref(st))
-        if rc:
-            self._err(rc, "szhip_decompress_fast")
-        return st
 
     def compress_omp(self, ptr, on_device, shape3, dtype, eb, thread_num, meta, params=None, out_on_device=False):
         """The reference's OpenMP container (szhip_compress_omp; sz/src/sz_omp.c:63-358).  Returns (bytes | device pointer int, size, stats)."""

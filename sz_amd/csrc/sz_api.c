@@ -443,8 +443,7 @@ static int compress_fp(int dataType, int withRegression, unsigned char **newByte
      * own fit pass, which reads the array anyway (SZHIP_RANGE_FROM_DATA), instead of a separate pass over the input. */
     const int dim_in = computeDimension(r5, r4, r3, r2, r1);
     const char *hip_mode = getenv("SZ_HIP_MODE");
-    const int fuse_range = errBoundMode == ABS && withRegression != SZ_NO_REGRESSION && dim_in >= 2 && dim_in <= 4 && !confparams_cpr->randomAccess
-                           && !(hip_mode && strcmp(hip_mode, "fast") == 0) && absErr_Bound > 0;
+    const int fuse_range = errBoundMode == ABS && withRegression != SZ_NO_REGRESSION && dim_in >= 2 && dim_in <= 4 && !confparams_cpr->randomAccess && absErr_Bound > 0;
     double vmin = 0, vmax = 0;
     double valueRangeSize = 0;
     if (!fuse_range) {
@@ -573,20 +572,6 @@ static int compress_fp(int dataType, int withRegression, unsigned char **newByte
         printf("Error: the MI355X build covers 2-D/3-D/4-D float/double arrays with withLinearRegression=YES and 1-D/2-D/3-D arrays with "
                "withLinearRegression=NO; this call (dim=%d, withRegression=%d, randomAccess=%d) is not covered yet.\n", dim, withRegression, confparams_cpr->randomAccess);
         return SZ_NSCS;
-    }
-    /* opt-in FAST mode (SZ_HIP_MODE=fast): the feedback-free quantiser and this library's own container (include/szhip.h).  Off by
-     * default; the bound still holds, the stream is NOT a reference stream (a stock reader rejects it at its version check). */
-    {
-        const char *mode = getenv("SZ_HIP_MODE");
-        if (mode && strcmp(mode, "fast") == 0) {
-            unsigned char *ftmp = NULL; size_t fsize = 0;
-            const size_t f0 = dim >= 3 ? (dim == 4 ? r4 * r3 : r3) : 1, f1 = dim >= 2 ? r2 : 1;
-            int frc = szhip_compress_fast(ctx, dataType == SZ_FLOAT ? SZHIP_F32 : SZHIP_F64, d_in, 1, f0, f1, r1, realPrecision,
-                                          exe_params->optQuantMode == 1 ? 0u : (unsigned)exe_params->intvCapacity, 0, &ftmp, &fsize, &g_last_stats);
-            if (frc != SZHIP_OK) { printf("Error: szhip_compress_fast failed (%d): %s\n", frc, szhip_last_error(ctx)); return SZ_NSCS; }
-            *newByteData = ftmp; *outSize = fsize;
-            return status;
-        }
     }
     /* opt-in (SZ_HIP_MODE=omp, round 5): 3-D arrays whose extents the box rule divides go out in the reference's OpenMP container (sz_omp.c:63-358: boxes
      * of the array quantised independently, one code book) instead of the SZ 2.1 stream -- no dependency front across the array, ~800 GB/s instead of
@@ -857,16 +842,6 @@ static void *decompress_fp(int dataType, unsigned char *cmpBytes, size_t cmpSize
                 sz = buf; szlen = (size_t)got; owned = 1;
             }
         }
-    }
-    if (szhip_is_fast_stream(cmpBytes, cmpSize)) {            /* this library's own FAST-mode container */
-        szhip_ctx *fctx = get_ctx();
-        const int fdim = computeDimension(r5, r4, r3, r2, r1);
-        const size_t f0 = fdim >= 3 ? (fdim == 4 ? r4 * r3 : r3) : 1, f1 = fdim >= 2 ? r2 : 1;
-        void *fo = malloc(dataLength * esz + 1);
-        if (!fo) { printf("Error: out of memory (%zu bytes for the decompressed array)\n", dataLength * esz); return NULL; }
-        int frc = fctx ? szhip_decompress_fast(fctx, dataType == SZ_FLOAT ? SZHIP_F32 : SZHIP_F64, cmpBytes, 0, cmpSize, f0, f1, r1, fo, 0, &g_last_stats) : SZHIP_ERR_NODEVICE;
-        if (frc != SZHIP_OK) { printf("Error: szhip_decompress_fast failed (%d): %s\n", frc, fctx ? szhip_last_error(fctx) : "no device"); free(fo); return NULL; }
-        return fo;
     }
     if (dataLength <= MIN_NUM_OF_ELEMENTS) { /* raw copy written by SZ_skip_compress */
         void *o = malloc(dataLength * esz != 0 ? dataLength * esz : 1);

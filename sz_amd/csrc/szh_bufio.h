@@ -1,4 +1,4 @@
-// szh_bufio.h -- raw-buffer, LDS and cross-lane helpers shared by the sweep kernels (szh_beam.h, szh_ompcol.h, szh_fast.h): 16-byte buffer loads / stores with
+// szh_bufio.h -- raw-buffer, LDS and cross-lane helpers shared by the sweep kernels (szh_beam.h, szh_ompcol.h): 16-byte buffer loads / stores with
 // out-of-range offsets that read zeros / store nothing, write-through granule stores, LDS accesses that stay 32-bit offsets, the CPU shim's stand-ins.
 // (Until round 6 the head of szh_ribbon.h, the hyperplane "ribbon" mapping of the sweep -- rounds 3 - 5, 1.13 ms at 512^3 float --, which the lean beam of
 // round 6 replaced; arrays the beam does not take run k_pencil.)

@@ -126,7 +126,6 @@ struct szhip_chain_pool {
 
 struct szhip_ctx {
     int device = 0;
-    int fast_stat_per_cu[2] = {0, 0}, fast_pack_per_cu[2] = {0, 0};   // resident workgroups per CU of the fast mode's persistent kernels (float, double)
     int cus = 256;                               // compute units of `device` (hipDeviceAttributeMultiprocessorCount): persistent kernels launch one workgroup per CU at most
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // the fit + selection pass runs here, concurrently with the interval optimiser's sampling and host decisions
@@ -148,7 +147,7 @@ struct szhip_ctx {
     hipEvent_t ev_gate = nullptr;
     unsigned long long *hdec_res = nullptr;      // pinned: {symbols the payload holds, starts still moving after round 1}, copied asynchronously
     // workspaces (grow-only)
-    DevBuf lor_bits, reg_flags, reg_rank, coef_compact, in, out, codes_nat, codes_blk, coef, blk_lor, faceI, faceJ, rb_down, rb_right, rb_vals, pt_flags, feed_word, fast_slots, fast_units, progress, trace, order, small, hist, col_zeros, col_zeros64,
+    DevBuf lor_bits, reg_flags, reg_rank, coef_compact, in, out, codes_nat, codes_blk, coef, blk_lor, faceI, faceJ, rb_down, rb_right, rb_vals, pt_flags, feed_word, progress, trace, order, small, hist, col_zeros, col_zeros64,
         seg_bits, seg_zeros, seg_bitoff, seg_zoff, seg_hist, seg_tab, col_off, partial, samples, unpred, stream_buf, chunk_bits, chunk_off, code_tab, len_tab, dec_tab,
         starts, ends, counts, offs, dirty, zcnt, zpos, pwr_log, pwr_signs, pwr_small, coef_dec, msst_ptab, msst_cells, msst_rec, msst_pe;
     void *pinned = nullptr; size_t pinned_cap = 0;
@@ -180,7 +179,6 @@ namespace {
 #include "szhip_sz21.inc"    // SZ 2.1: the hot path (SZ_compress_args / SZ_decompress of float and double arrays)
 #include "szhip_sz14.inc"    // SZ 1.4 container, MSST19
 #include "szhip_pwr.inc"     // point-wise relative bounds
-#include "szhip_fast.inc"    // opt-in fast container
 #include "szhip_omp.inc"     // the reference's OpenMP container
 
 } // namespace
@@ -216,32 +214,6 @@ static int with_ticket_fallback(szhip_ctx *ctx, F &&run)
 
 extern "C" {
 
-int szhip_is_fast_stream(const unsigned char *stream, size_t stream_len) { return stream && stream_len >= SZF_HDR_FIXED && memcmp(stream, "SZHF", 4) == 0; }
-
-int szhip_compress_fast(szhip_ctx *ctx, int dtype, const void *data, int data_on_device, size_t r0, size_t r1, size_t r2, double eb,
-                        unsigned intervals, int out_on_device, unsigned char **out, size_t *out_size, szhip_stats *stats)
-{
-    if (!ctx || !data || !out || !out_size || !(eb > 0)) return SZHIP_ERR_ARG;
-    if (intervals == 0) intervals = 1024;
-    if (r0 < 1 || r1 < 1 || r2 < 1 || r0 > 0x7fffffff || r1 > 0x7fffffff || r2 > 0x7fffffff || intervals < 4 || intervals > 65536 || (intervals & 1)) return SZHIP_ERR_ARG;
-    if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
-    const int rc = dtype == SZHIP_F32 ? compress_fast_impl<float>(ctx, data, data_on_device, r0, r1, r2, eb, intervals, out_on_device, out, out_size, stats)
-                                      : compress_fast_impl<double>(ctx, data, data_on_device, r0, r1, r2, eb, intervals, out_on_device, out, out_size, stats);
-    if (rc != SZHIP_OK) hipStreamSynchronize(ctx->stream);
-    return rc;
-}
-
-int szhip_decompress_fast(szhip_ctx *ctx, int dtype, const unsigned char *stream, int stream_on_device, size_t stream_len,
-                          size_t r0, size_t r1, size_t r2, void *out, int out_on_device, szhip_stats *stats)
-{
-    if (!ctx || !stream || !out || r0 < 1 || r1 < 1 || r2 < 1) return SZHIP_ERR_ARG;
-    if (hipSetDevice(ctx->device) != hipSuccess) return SZHIP_ERR_NODEVICE;
-    const int rc = with_ticket_fallback(ctx, [&]() { return dtype == SZHIP_F32
-                       ? decompress_fast_impl<float>(ctx, stream, stream_on_device, stream_len, r0, r1, r2, out, out_on_device, stats)
-                       : decompress_fast_impl<double>(ctx, stream, stream_on_device, stream_len, r0, r1, r2, out, out_on_device, stats); });    // (for the Huffman decoder's repetition)
-    if (rc != SZHIP_OK) hipStreamSynchronize(ctx->stream);
-    return rc;
-}
 
 // side_prio: the second / third stream at the lowest / highest priority the device offers.  HIP maps the streams of one priority onto a few
 // hardware queues, and whether two streams of a context share one is the luck of what else the process has created (measured, round 4, one call
@@ -293,7 +265,7 @@ void szhip_destroy(szhip_ctx *ctx)
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     delete ctx->chain_pool; ctx->chain_pool = nullptr;
-    DevBuf *bufs[] = {&ctx->lor_bits, &ctx->reg_flags, &ctx->reg_rank, &ctx->coef_compact, &ctx->in, &ctx->out, &ctx->codes_nat, &ctx->codes_blk, &ctx->coef, &ctx->blk_lor, &ctx->faceI, &ctx->faceJ, &ctx->rb_down, &ctx->rb_right, &ctx->rb_vals, &ctx->pt_flags, &ctx->feed_word, &ctx->fast_slots, &ctx->fast_units, &ctx->progress, &ctx->trace,
+    DevBuf *bufs[] = {&ctx->lor_bits, &ctx->reg_flags, &ctx->reg_rank, &ctx->coef_compact, &ctx->in, &ctx->out, &ctx->codes_nat, &ctx->codes_blk, &ctx->coef, &ctx->blk_lor, &ctx->faceI, &ctx->faceJ, &ctx->rb_down, &ctx->rb_right, &ctx->rb_vals, &ctx->pt_flags, &ctx->feed_word, &ctx->progress, &ctx->trace,
                       &ctx->order, &ctx->small, &ctx->hist, &ctx->col_zeros, &ctx->col_zeros64, &ctx->seg_bits, &ctx->seg_zeros, &ctx->seg_bitoff, &ctx->seg_zoff, &ctx->seg_hist, &ctx->seg_tab, &ctx->col_off, &ctx->partial,
                       &ctx->samples, &ctx->unpred, &ctx->stream_buf, &ctx->chunk_bits, &ctx->chunk_off, &ctx->code_tab,
                       &ctx->len_tab, &ctx->dec_tab, &ctx->starts, &ctx->ends, &ctx->counts, &ctx->offs, &ctx->dirty, &ctx->zcnt, &ctx->zpos,

@@ -1715,7 +1715,6 @@ __global__ __launch_bounds__(256) void k_exact_build(const uint8_t *__restrict__
     list[i] = IM::to(u) + median;
 }
 
-// ------------------------------------------------------------------ the opt-in fast mode (feedback-free; own container)
 // One-time probe of a context (szhip.hip: streams_independent): spins on a host-coherent word until the host sets it or ~4 ms pass
 __global__ void k_probe_wait(const unsigned long long *flag, unsigned long long *saw)
 {
@@ -1727,7 +1726,6 @@ __global__ void k_probe_wait(const unsigned long long *flag, unsigned long long 
 
 __global__ void k_probe_touch(unsigned long long *p) { *p = 1; }
 
-#include "szh_fast.h"
 #include "szh_pwr.h"
 #include "szh_msst.h"
 #include "szh_omp.h"

@@ -53,10 +53,6 @@ def lib():
                                         ctypes.c_double] + [ctypes.c_size_t] * 5 + [ctypes.c_void_p]
         L.szo_decompress.restype = ctypes.c_void_p
         L.szo_decompress.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t] + [ctypes.c_size_t] * 5
-        L.szo_fast_compress.restype = ctypes.POINTER(ctypes.c_ubyte)
-        L.szo_fast_compress.argtypes = [ctypes.c_int, ctypes.c_void_p] + [ctypes.c_size_t] * 3 + [ctypes.c_double, ctypes.c_uint, ctypes.POINTER(ctypes.c_size_t)]
-        L.szo_fast_decompress.restype = ctypes.c_void_p
-        L.szo_fast_decompress.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t] + [ctypes.c_size_t] * 3
         L.szo_omp_compress.restype = ctypes.POINTER(ctypes.c_ubyte)
         L.szo_omp_compress.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p] + [ctypes.c_size_t] * 3 + [ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
         L.szo_omp_decompress.restype = ctypes.c_void_p
@@ -156,29 +152,6 @@ def metrics(ori, dec):
 def _dims3(shape):
     d = [1] * (3 - len(shape)) + list(shape)
     return d[0], d[1], d[2]
-
-
-def fast_compress(data, eb, intervals=0):
-    """The product's FAST mode restated (oracle/szo_fast.c)."""
-    L = lib()
-    data = np.ascontiguousarray(data)
-    n = ctypes.c_size_t(0)
-    out = L.szo_fast_compress(SZ_FLOAT if data.dtype == np.float32 else SZ_DOUBLE, data.ctypes.data, *_dims3(data.shape), eb, intervals, ctypes.byref(n))
-    b = bytes(out[:n.value])
-    L.free(out)
-    return b
-
-
-def fast_decompress(stream, shape, dtype):
-    L = lib()
-    buf = ctypes.create_string_buffer(stream, len(stream))
-    r = L.szo_fast_decompress(SZ_FLOAT if np.dtype(dtype) == np.float32 else SZ_DOUBLE, buf, len(stream), *_dims3(shape))
-    if not r:
-        raise RuntimeError("oracle fast decompress failed")
-    n = int(np.prod(shape))
-    a = np.ctypeslib.as_array(ctypes.cast(r, ctypes.POINTER(np.ctypeslib.as_ctypes_type(np.dtype(dtype)))), shape=(n,)).copy()
-    L.free(r)
-    return a.reshape(shape)
 
 
 def omp_compress(data, eb, threads, meta, params=None):

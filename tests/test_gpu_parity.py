@@ -537,10 +537,10 @@ def test_differential_fuzz_sz14_against_the_oracle(built):
     assert tail and tail[-1].startswith("fuzz: 300 cases, 0 failures"), "\n".join(tail[-10:]) + out.stderr[-2000:]
 
 
-def test_fuzz_pw_rel_and_fast_mode(built):
-    """random differential cases for two paths added in round 2: point-wise relative bounds (log-domain form; the MSST19 form has tests/test_msst19.py) and the opt-in fast mode"""
+def test_fuzz_pw_rel(built):
+    """random differential cases for a path added in round 2: point-wise relative bounds (log-domain form; the MSST19 form has tests/test_msst19.py)"""
     import subprocess
-    for args in (("300", "41", "pwr"), ("300", "43", "fast")):
+    for args in (("300", "41", "pwr"),):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_fuzz.py"), *args], capture_output=True, text=True, timeout=600)
         tail = [ln for ln in out.stdout.splitlines() if ln.startswith("fuzz:") or ln.startswith("FAIL")]
         assert tail and tail[-1].startswith("fuzz: 300 cases, 0 failures"), "\n".join(tail[-10:]) + out.stderr[-2000:]
