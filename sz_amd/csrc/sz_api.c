@@ -1083,7 +1083,10 @@ static int omp_pick_threads(size_t r1, size_t r2, size_t r3)
 {
     int t = g_omp_threads;
     if (t <= 0) { const char *e = getenv("SZ_HIP_OMP_THREADS"); if (e) t = atoi(e); }
-    if (t > 0) return t;
+    if (t > 0) {      /* a forced box count: only if its grid divides the array (else SZ_compress_args returned NULL instead of taking the ordinary path) */
+        size_t nx, ny, nz; omp_grid(t, &nx, &ny, &nz);
+        return (nx <= r1 && ny <= r2 && nz <= r3 && r1 % nx == 0 && r2 % ny == 0 && r3 % nz == 0) ? t : 0;
+    }
     for (int o = 0; o <= 30; ++o) {
         size_t nx, ny, nz; omp_grid(1 << o, &nx, &ny, &nz);
         if (nx > r1 || ny > r2 || nz > r3) break;

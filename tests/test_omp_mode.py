@@ -43,8 +43,15 @@ def _run(sz, oracle, monkeypatch):
     # what the box rule does not divide, and 2-D arrays, take the ordinary path
     odd = s_field(31, 33, 62)
     ref_odd, _ = oracle.compress(odd, oracle.ABS, 1e-4)
+    monkeypatch.setenv("SZ_HIP_OMP_THREADS", "8")          # (round 6, ADVICE: a FORCED box count whose grid does not divide the array must not make the call fail)
+    assert sz.SZ_compress_args(odd, sz.ABS, 1e-4) == ref_odd
     monkeypatch.delenv("SZ_HIP_OMP_THREADS")
     assert sz.SZ_compress_args(odd, sz.ABS, 1e-4) == ref_odd
+    # float64 through the same switch (ADVICE: untested so far)
+    d64 = s_field(16, 32, 64, np.float64)
+    got64 = sz.SZ_compress_args(d64, sz.ABS, 1e-6)
+    dec64 = sz.SZ_decompress(got64, d64.shape, d64.dtype)
+    assert got64[19] == 0x4F and float(np.abs(dec64 - d64).max()) <= 1e-6
     flat = s_field(1, 40, 48).reshape(40, 48)
     ref_flat, _ = oracle.compress(flat, oracle.ABS, 1e-4)
     assert sz.SZ_compress_args(flat, sz.ABS, 1e-4) == ref_flat
