@@ -57,6 +57,18 @@ typedef szh_io::v4u v4u;
 #ifndef SZH_BM_DK
 #define SZH_BM_DK 1
 #endif
+#ifndef SZH_BM_PD64
+#define SZH_BM_PD64 3      /* lines a double sweep over an array with regression blocks asks ahead, see beam::PD */
+#endif
+#ifndef SZH_BM_PD64N
+#define SZH_BM_PD64N 9     /* ... a double sweep over an array without */
+#endif
+#ifndef SZH_BM_PD32
+#define SZH_BM_PD32 9      /* ... a float sweep, with regression blocks */
+#endif
+#ifndef SZH_BM_PD32N
+#define SZH_BM_PD32N 9     /* ... and without */
+#endif
 constexpr int C1 = 4, LINE = C1 + 1, HL = 32, WPG = 4, RL = 9, RS = RL * LINE, UL = RL, KRL = 3, DK = SZH_BM_DK;
 constexpr int JW = 2 * C1, JG = JW * WPG;          // rows j per wavefront / per workgroup
 constexpr int LAG = 7;                              // lines after which every lane has left a line (31 steps of skew + the upper half's line)
@@ -229,7 +241,13 @@ struct beam {
     typedef gran_io<T> GIO;
     typedef typename GIO::reg_t greg_t;
     typedef u2_t cpiece_t;
-    static constexpr int PITCH = S::PITCH, RINGB = S::RINGB, SZ = S::SZ, EV = S::EV, NSET = UL * EV, LP = S::LP, VB = S::VB, VPL = S::VPL;
+    static constexpr int PITCH = S::PITCH, RINGB = S::RINGB, SZ = S::SZ, EV = S::EV, LP = S::LP, VB = S::VB, VPL = S::VPL;
+
+    // rows are asked for PD lines before they go into the ring (one register set per line in flight).  UL lines (45 steps) everywhere but in the
+    // double sweep over arrays with regression blocks: three streams of 16-byte pieces, two pieces a line -- 9 lines of them are 180 registers, and the
+    // kernel spilled 174 (round 6's C4 slab: 2.9 ms against round 5's 2.4); 3 lines (15 steps of a double sweep: ~3 us) are 60
+    static constexpr int PD = SZ == 8 ? (HASREG ? SZH_BM_PD64 : SZH_BM_PD64N) : (HASREG ? SZH_BM_PD32 : SZH_BM_PD32N), NSET = PD * EV;
+    static_assert(UL % PD == 0, "register sets are named by the unrolled line");
 
     const szh_qargs<T> &a;
     OC_LDS unsigned char *lds0;                                    // first byte of the workgroup's rings; every LDS address below is relative to it (modulo 2^32)
@@ -258,7 +276,7 @@ struct beam {
     unsigned vl[EV], cw[EV], cl, ko_lds, ki_lds;
     v4u gv[NSET];                                                  // value rows on their way
     v4u gx[HASREG && !DEC ? NSET : 1]; unsigned gf[HASREG ? NSET : 1]; // HASREG: the regression points' reconstructions of the same rows (compress), their flag bytes
-    cpiece_t gc[UL]; v4u wqc4; v4u wqv[EV];                        // code rows on their way in (inverse; HASREG compress: k_reg_points' codes); rows on their way out
+    cpiece_t gc[PD]; v4u wqc4; v4u wqv[EV];                        // code rows on their way in (inverse; HASREG compress: k_reg_points' codes); rows on their way out
     greg_t gk[DK], gj[DK];                                         // k-face / j-face granules on their way
     T eb, eb2, rh, caph, radf, mean; int radius; unsigned epoch;
     unsigned pv_prev, pv_next;                                     // the neighbouring wavefronts' progress words as read a step ago
@@ -402,10 +420,10 @@ struct beam {
                 if (HASREG) {
                     // the regression points of the row piece keep the codes k_reg_points gave them (the sweep passed their values through and has
                     // zeros there): per code a 16-bit mask from the flag in the upper half of its ring word
-                    const cpiece_t old = gc[LL];
+                    const cpiece_t old = gc[LL % PD];
                     const unsigned m0 = (wqc4.x > 0xffffu ? 0xffffu : 0u) | (wqc4.y > 0xffffu ? 0xffff0000u : 0u), m1 = (wqc4.z > 0xffffu ? 0xffffu : 0u) | (wqc4.w > 0xffffu ? 0xffff0000u : 0u);
                     out.x = (old.x & m0) | (out.x & ~m0); out.y = (old.y & m1) | (out.y & ~m1);
-                    gc[LL] = load_c<true>(it - LAG + UL);
+                    gc[LL % PD] = load_c<true>(it - LAG + PD);
                 }
                 place<EDGE>(rcs, it - LAG, str_c, so_cs, o, so);
                 if (SZH_BM_X & 1) bst8<0>(rs_c, o, so, out); else if (!(SZH_BM_X & 2)) bst8<17>(rs_c, o, so, out);      // (written through: the host may follow this sweep's progress, see `pub` in run; the codes are read next by other kernels, from memory either way)
@@ -416,13 +434,13 @@ struct beam {
             }
             // rows that have arrived go in (line it + 1), and the register set that carried them is sent for the rows UL lines further on
             constexpr unsigned loX = lineoff(LL + 1);
-            if (DEC) { put_codes(loX, gc[LL]); gc[LL] = load_c<EDGE>(it + 1 + UL); so_cl += str_c; wave_sync(); }      // (lock step: on the CPU shim the lanes are fibres, and the flags below go into words other lanes' code rows write whole)
+            if (DEC) { put_codes(loX, gc[LL % PD]); gc[LL % PD] = load_c<EDGE>(it + 1 + PD); so_cl += str_c; wave_sync(); }      // (lock step: on the CPU shim the lanes are fibres, and the flags below go into words other lanes' code rows write whole)
             for_n<EV>([&](auto E) {
-                constexpr int e = decltype(E)::value, set = LL * EV + e;
+                constexpr int e = decltype(E)::value, set = (LL % PD) * EV + e;
                 put_rows(loX, e, gv[set], gx[HASREG && !DEC ? set : 0], gf[HASREG ? set : 0]);
-                gv[set] = load_v<EDGE>(it + 1 + UL, e);
-                if (HASREG && !DEC) gx[HASREG && !DEC ? set : 0] = load_x<EDGE>(it + 1 + UL, e);
-                if (HASREG) gf[HASREG ? set : 0] = load_f<EDGE>(it + 1 + UL, e);
+                gv[set] = load_v<EDGE>(it + 1 + PD, e);
+                if (HASREG && !DEC) gx[HASREG && !DEC ? set : 0] = load_x<EDGE>(it + 1 + PD, e);
+                if (HASREG) gf[HASREG ? set : 0] = load_f<EDGE>(it + 1 + PD, e);
             });
             so_vl += str_v; if (HASREG) so_fl += str_v / (unsigned)SZ;
         }
@@ -737,7 +755,7 @@ struct beam {
                 firstx[e] = (HASREG && !DEC) ? load_x<true>(0, e) : first[e];
                 firstf[e] = HASREG ? load_f<true>(0, e) : 0u;
             });
-            for_n<UL>([&](auto L_) { constexpr int LL = decltype(L_)::value; for_n<EV>([&](auto E) {
+            for_n<PD>([&](auto L_) { constexpr int LL = decltype(L_)::value; for_n<EV>([&](auto E) {
                 constexpr int e = decltype(E)::value, set = LL * EV + e;
                 gv[set] = load_v<true>(LL + 1, e);
                 if (HASREG && !DEC) gx[HASREG && !DEC ? set : 0] = load_x<true>(LL + 1, e);
@@ -745,12 +763,12 @@ struct beam {
             }); });
             if (DEC) {
                 const cpiece_t c0 = load_c<true>(0);
-                for_n<UL>([&](auto L_) { constexpr int LL = decltype(L_)::value; gc[LL] = load_c<true>(LL + 1); });
+                for_n<PD>([&](auto L_) { constexpr int LL = decltype(L_)::value; gc[LL] = load_c<true>(LL + 1); });
                 put_codes(0u, c0);
                 wave_sync();
             }
             for_n<EV>([&](auto E) { constexpr int e = decltype(E)::value; put_rows(0u, e, first[e], firstx[e], firstf[e]); });
-            if (!DEC && HASREG) for_n<UL>([&](auto L_) { constexpr int LL = decltype(L_)::value; gc[LL] = load_c<true>(LL - LAG); });
+            if (!DEC && HASREG) for_n<PD>([&](auto L_) { constexpr int LL = decltype(L_)::value; gc[LL] = load_c<true>(LL - LAG); });
             // granules: k-face row 0 (taken now), rows 1 .. DK on their way; j-face rows 0 .. 2 (lines -q .. 1 - q: taken now, the first virtual cells
             // are read from step 0 on), rows 3 .. 2 + DK on their way
             const greg_t k0g = load_k<true>(0);
@@ -797,7 +815,7 @@ struct beam {
             const bool mid = it0 >= LAG + 1 && it0 + 2 * UL <= r0 - 1;
             if (mid) {
                 // the streams' scalar offsets for this block: wave line X of a stream is at (X - 1) stride (rows of the j-face: X stride)
-                so_vl = (unsigned)(it0 + UL) * str_v; so_fl = (unsigned)(it0 + UL) * (str_v / (unsigned)SZ); so_cl = (unsigned)(it0 + UL) * str_c;
+                so_vl = (unsigned)(it0 + PD) * str_v; so_fl = (unsigned)(it0 + PD) * (str_v / (unsigned)SZ); so_cl = (unsigned)(it0 + PD) * str_c;
                 so_vs = (unsigned)(it0 - LAG - 1) * str_v; so_cs = (unsigned)(it0 - LAG - 1) * str_c;
                 so_ko = (unsigned)(it0 - LAG - 1) * str_k; so_ki = (unsigned)(it0 + DK) * str_k;
                 so_jo = (unsigned)it0 * str_j; so_ji = (unsigned)(it0 + 3 + DK) * str_j;
