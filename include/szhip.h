@@ -93,6 +93,12 @@ const char *szhip_last_error(szhip_ctx *ctx);
  * szhip_compress can both run on it (data_on_device = 1) without a second PCIe transfer */
 int szhip_stage_input(szhip_ctx *ctx, const void *host_data, size_t bytes, void **device_ptr);
 
+/*
+ * Device pointers and ordering (all calls below): a call runs on the context's own NON-BLOCKING streams and returns when its results are complete.
+ * What it reads from device memory must be complete when the call is made: synchronise the stream that produces it first -- the null stream's
+ * implicit ordering does not reach non-blocking streams, and a device-to-device hipMemcpy may return to the host before the copy has finished
+ * (profiles/r06_device_input_ordering.txt: a tool that decoded a stream right behind such a copy read a stream whose end had not arrived).
+ */
 /* min / max of n values (device or host pointer) */
 int szhip_minmax(szhip_ctx *ctx, int dtype, const void *data, int data_on_device, size_t n, double *vmin, double *vmax);
 

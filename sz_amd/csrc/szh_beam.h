@@ -57,17 +57,8 @@ typedef szh_io::v4u v4u;
 #ifndef SZH_BM_DK
 #define SZH_BM_DK 1
 #endif
-#ifndef SZH_BM_PD64
-#define SZH_BM_PD64 3      /* lines a double sweep over an array with regression blocks asks ahead, see beam::PD */
-#endif
-#ifndef SZH_BM_PD64N
-#define SZH_BM_PD64N 9     /* ... a double sweep over an array without */
-#endif
-#ifndef SZH_BM_PD32
-#define SZH_BM_PD32 9      /* ... a float sweep, with regression blocks */
-#endif
-#ifndef SZH_BM_PD32N
-#define SZH_BM_PD32N 9     /* ... and without */
+#ifndef SZH_BM_PD
+#define SZH_BM_PD 3        /* lines a wavefront asks for its rows ahead, see beam::PD (a divisor of UL) */
 #endif
 constexpr int C1 = 4, LINE = C1 + 1, HL = 32, WPG = 4, RL = 9, RS = RL * LINE, UL = RL, KRL = 3, DK = SZH_BM_DK;
 constexpr int JW = 2 * C1, JG = JW * WPG;          // rows j per wavefront / per workgroup
@@ -243,10 +234,11 @@ struct beam {
     typedef u2_t cpiece_t;
     static constexpr int PITCH = S::PITCH, RINGB = S::RINGB, SZ = S::SZ, EV = S::EV, LP = S::LP, VB = S::VB, VPL = S::VPL;
 
-    // rows are asked for PD lines before they go into the ring (one register set per line in flight).  UL lines (45 steps) everywhere but in the
-    // double sweep over arrays with regression blocks: three streams of 16-byte pieces, two pieces a line -- 9 lines of them are 180 registers, and the
-    // kernel spilled 174 (round 6's C4 slab: 2.9 ms against round 5's 2.4); 3 lines (15 steps of a double sweep: ~3 us) are 60
-    static constexpr int PD = SZ == 8 ? (HASREG ? SZH_BM_PD64 : SZH_BM_PD64N) : (HASREG ? SZH_BM_PD32 : SZH_BM_PD32N), NSET = PD * EV;
+    // rows are asked for PD lines before they go into the ring (one register set per line in flight).  PD = UL = 9 lines (45 steps) until late in round 6: in
+    // the double sweep over arrays with regression blocks -- three streams of 16-byte pieces, two pieces a line -- 180 registers, and that kernel spilled 174
+    // (the C4 slab: 2.90 ms against round 5's 2.41).  3 lines (15 steps: 2 - 3 us) cover the memory's latency as well: that kernel 1.39 ms, and every other
+    // form a little faster too, its lanes moving fewer values between the two register files (profiles/r06_sweep_prefetch_distance.txt)
+    static constexpr int PD = SZH_BM_PD, NSET = PD * EV;
     static_assert(UL % PD == 0, "register sets are named by the unrolled line");
 
     const szh_qargs<T> &a;

@@ -88,3 +88,33 @@ def test_inverse_of_arrays_the_beam_does_not_take_on_gpu(oracle, built):
         sz_amd.SZ_Finalize()
     finally:
         pass
+
+
+@pytest.mark.gpu
+def test_decompression_ignores_what_the_output_array_and_the_bytes_behind_the_stream_held(oracle, built):
+    """The inverse sweep reads the output array (the unpredictable values are scattered into it first) and the decoder reads whole words up to the
+    stream's end: neither what the array held before the call nor the bytes behind the stream may show in the result (bit for bit the oracle's values)."""
+    import torch
+    from sz_amd import api
+    dev = torch.device("cuda:0")
+    ctx = api.HipContext(0)
+    try:
+        for name, d, eb in (("S-96", s_field(96, 96, 96), 1e-4), ("M-72", m_field(72), 1e-4), ("S-f64-41x70x36", s_field(41, 70, 36, np.float64), 1e-3)):
+            stream, _ = oracle.compress(d, oracle.ABS, eb)
+            want = torch.from_numpy(oracle.decompress(stream, d.shape, d.dtype)).to(dev)
+            body_off = 4 + (28 if d.dtype == np.float32 else 36) + 8
+            other = torch.from_numpy(np.ascontiguousarray(d[::-1])).to(dev)
+            it = torch.int32 if d.dtype == np.float32 else torch.int64
+            fills = {"zeros": lambda o: o.zero_(), "0xff bytes": lambda o: o.view(torch.uint8).fill_(255), "the field upside down": lambda o: o.copy_(other),
+                     "random bits": lambda o: o.view(torch.int32).random_(-2 ** 31, 2 ** 31 - 1)}
+            for tail in ("zeros", "random"):
+                s = torch.zeros(len(stream) + 4096, dtype=torch.uint8, device=dev)
+                s[:len(stream)] = torch.frombuffer(bytearray(stream), dtype=torch.uint8).to(dev)
+                if tail == "random": s[len(stream):] = torch.randint(0, 256, (4096,), dtype=torch.uint8, device=dev)
+                for fname, f in fills.items():
+                    out = torch.empty_like(want); f(out)
+                    torch.cuda.synchronize()
+                    ctx.decompress(s.data_ptr(), True, len(stream), body_off, d.shape, d.dtype, out.data_ptr(), True)
+                    assert torch.equal(out.view(it), want.view(it)), (name, tail, fname)
+    finally:
+        ctx.close()

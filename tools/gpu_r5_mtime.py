@@ -28,10 +28,13 @@ for field in (sys.argv[2] if len(sys.argv) > 2 else "m,s").split(","):
         out = torch.empty_like(d)
         torch.cuda.synchronize()
         ctypes.CDLL("libamdhip64.so").hipMemcpy(ctypes.c_void_p(stream.data_ptr()), ctypes.c_void_p(ptr), ctypes.c_size_t(n), 3)
+        ctypes.CDLL("libamdhip64.so").hipDeviceSynchronize()     # (a device-to-device hipMemcpy may return before the copy is done, and the context's streams do not wait for the null stream: include/szhip.h)
         for it in range(5):
             if it == 3: os.environ["SZ_HIP_TIMING"] = "1"
             else: os.environ.pop("SZ_HIP_TIMING", None)
-            st = ctx.decompress(stream.data_ptr(), True, n, 4 + 28 + 8, (edge, edge, edge), np.float32, out.data_ptr(), True)
+            try: st = ctx.decompress(stream.data_ptr(), True, n, 4 + 28 + 8, (edge, edge, edge), np.float32, out.data_ptr(), True)
+            except Exception as ex:
+                print("DEC FAILED field", field, "dec_it", it, str(ex)[-90:], flush=True); continue
             if it >= 3:
                 print(json.dumps({"field": field, "dec_it": it, "total_ms": round(st.ms_total, 3), "entropy": round(st.ms_entropy, 3), "quant": round(st.ms_quant, 3), "host": round(st.ms_host, 3), "kernel": int(st.quant_kernel), "max_err": float((out - d).abs().max())}), flush=True)
         ctx.close()

@@ -42,6 +42,7 @@ def run(threads, calls, edge=512):
                 mis += 1
                 continue
             ctypes.CDLL("libamdhip64.so").hipMemcpy(ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(p), ctypes.c_size_t(n), 3)
+            ctypes.CDLL("libamdhip64.so").hipStreamSynchronize(None)      # (a device-to-device hipMemcpy may return before the copy is done; cmp_s does not wait for the null stream)
             with torch.cuda.stream(cmp_s):
                 same = bool(torch.equal(out[:n], ref))
             mis += not same
