@@ -252,6 +252,28 @@ __global__ __launch_bounds__(1024) void k_col_scan(const u64 *__restrict__ col_b
     if (tid == 0) { *total_bits = totb; *total_zeros = totz; out32[(bit0 + totb) >> 5] = 0u; out32[((bit0 + totb) >> 5) + 1] = 0u; }
 }
 
+// (the way back) the columns' zero counts (k_col_zeros) -> where each column's unpredictable values begin in the stream's list, and their number: one launch of one workgroup
+// (up to 2^13 columns) in place of a widening pass and the general scan's three
+__global__ __launch_bounds__(1024) void k_col_zscan(const unsigned *__restrict__ col_zeros, int nent, u64 *__restrict__ col_zoff, u64 *total_zeros)
+{
+    __shared__ u64 shz[16];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lo = tid * SZH_COL_SCAN_PER;
+    u64 vz[SZH_COL_SCAN_PER], z = 0;
+#pragma unroll
+    for (int q = 0; q < SZH_COL_SCAN_PER; ++q) { vz[q] = lo + q < nent ? (u64)col_zeros[lo + q] : 0ull; z += vz[q]; }
+    u64 iz = z;
+    for (int o = 1; o < 64; o <<= 1) { const u64 tz = __shfl_up(iz, o, 64); if (lane >= o) iz += tz; }
+    if (lane == 63) shz[wid] = iz;
+    __syncthreads();
+    u64 basez = 0, totz = 0;
+    for (int w = 0; w < 16; ++w) { if (w < wid) basez += shz[w]; totz += shz[w]; }
+    u64 rz = basez + iz - z;
+#pragma unroll
+    for (int q = 0; q < SZH_COL_SCAN_PER; ++q) { if (lo + q < nent) col_zoff[lo + q] = rz; rz += vz[q]; }
+    if (tid == 0) *total_zeros = totz;
+}
+
 // dynamic LDS: [(nsym + 1) x u64 table][a segment's rows][16 bytes: a run of the null symbol][window]
 // table entry of symbol s: low word = code length (bit 16 set for symbol 0: the zero codes are counted in the same sum), high word = the code; entry nsym (the null
 // symbol: places of a thread's share that hold no code) = 0

@@ -742,12 +742,6 @@ __device__ __forceinline__ void permute_body(const szh_geom3 &G, const uint16_t 
         if (e < eregion) { const int bl = qdiv(e, esz, m_esz); const int rem = e - bl * esz; s2 = G.g2.early; koff = bl * s2; row = qdiv(rem, s2, m_e2); kk = rem - row * s2; }
         else { const int e2 = e - eregion; const int bl = qdiv(e2, lsz, m_lsz); const int rem = e2 - bl * lsz; s2 = G.g2.late; koff = nE * G.g2.early + bl * s2; row = qdiv(rem, s2, m_l2); kk = rem - row * s2; }
     };
-    // place of (row r, k = kbeg + kl) in the segment's block order, and how many codes of its run (this row of this block) start there
-    const int ewid = nE * G.g2.early;
-    auto kpos = [&](int kl, int r, int &left) -> int {
-        if (kl < ewid) { const int bl = qdiv(kl, G.g2.early, m_e2), kk = kl - bl * G.g2.early; left = G.g2.early - kk; return bl * esz + r * G.g2.early + kk; }
-        const int kl2 = kl - ewid, bl = qdiv(kl2, G.g2.late, m_l2), kk = kl2 - bl * G.g2.late; left = G.g2.late - kk; return eregion + bl * lsz + r * G.g2.late + kk;
-    };
     if (dbg & 8) return;
     unsigned zeros = 0;
     unsigned *const lh = reinterpret_cast<unsigned *>(tile + ((tile_elems + 1) & ~1));

@@ -30,7 +30,7 @@ def _cases():
 
 
 SWITCHES = ["", "SZ_HIP_SEGENC=0", "SZ_HIP_SEGHIST=0", "SZ_HIP_SEG_SCAN1=0", "SZ_HIP_SEG_SEGB=3", "SZ_HIP_SEG_TILE_KB=4", "SZ_HIP_SEGENC=2", "SZ_HIP_FIT_TILE=1",
-            "SZ_HIP_COL_UNPACK=0", "SZ_HIP_UNPACK_TILE_KB=4"]
+            "SZ_HIP_COL_UNPACK=0", "SZ_HIP_UNPACK_TILE_KB=4", "SZ_HIP_DEC_CHECKS_LAST=0"]
 
 
 def _run(monkeypatch, switch, few=False):

@@ -134,7 +134,7 @@ def test_tile_ticket_modes_on_the_cpu_shim(built, oracle, monkeypatch, mode):
     _exercise(ctypes.CDLL(sim_lib.shim_path()), oracle)
 
 
-@pytest.mark.parametrize("switch", ["SZ_HIP_ENC32=0", "SZ_HIP_SEGENC=0;SZ_HIP_ENC32=0", "SZ_HIP_OUT_IN_PLACE=0", "SZ_HIP_SLICES=1", "SZ_HIP_SLICES=8", "SZ_HIP_PERM_Y=3", "SZ_HIP_SLICES=3;SZ_HIP_SLICE_GEOM=1"])
+@pytest.mark.parametrize("switch", ["SZ_HIP_ENC32=0", "SZ_HIP_SEGENC=0;SZ_HIP_ENC32=0", "SZ_HIP_OUT_IN_PLACE=0", "SZ_HIP_SLICES=1", "SZ_HIP_SLICES=8", "SZ_HIP_PERM_Y=3", "SZ_HIP_SLICES=3"])
 def test_alternative_forms_of_the_entropy_stage_on_the_cpu_shim(built, oracle, monkeypatch, switch):
     """round 4's switches keep the forms they replaced alive (k_encode beside k_encode32, everything after the sweep beside the slices, a workgroup per
     segment in k_permute), round 5's too (the one-pass look-back packing, off by default, also with the repetition of a call whose look-back gave

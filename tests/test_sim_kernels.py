@@ -82,7 +82,7 @@ def test_whole_hip_layer_on_cpu_shim(oracle, c1_data):
         api._lib = saved
 
 
-@pytest.mark.parametrize("switch", ["SZ_HIP_SLICES=1", "SZ_HIP_SLICES=4", "SZ_HIP_SLICES=16", "SZ_HIP_SLICES=3;SZ_HIP_SLICE_GEOM=1", "SZ_HIP_SLICES=4;SZ_HIP_SLICE_FROM=60",
+@pytest.mark.parametrize("switch", ["SZ_HIP_SLICES=1", "SZ_HIP_SLICES=4", "SZ_HIP_SLICES=16", "SZ_HIP_SLICES=3",
                                     "SZ_HIP_ENC32=0", "SZ_HIP_PERM_Y=2"])
 def test_entropy_stage_on_finished_tile_rows_on_cpu_shim(oracle, monkeypatch, switch):
     """round 4: the histogram and block-ordering passes run slice by slice on finished tile rows (k_ribbon publishes every tile; on the shim the sweep
