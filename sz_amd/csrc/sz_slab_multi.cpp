@@ -74,6 +74,7 @@ struct shared_t {
     std::mutex sim_mu;                             // the CPU shim runs one launch at a time
     int gather_ok = 1; size_t gathered = 0;
     std::vector<int> xbuf_ok;                      // per rank: its device exchange buffers exist (decided before any collective is entered)
+    std::vector<int> pbuf_ok;                      // per rank: its payload buffer exists (the second decision of a call: words of its own, so that a rank still reading the first one never sees it)
     int coll_failed = 0;                           // some RCCL / HIP call of the exchange returned an error: the call fails as a whole
 };
 
@@ -200,10 +201,10 @@ void worker(shared_t *S, const job_t *J, int r, multi_cache_t *C)
         size_t total = 0, my_off = 0;
         for (int q = 0; q < S->ndev; ++q) { if (q == r) my_off = total; total += (size_t)sizes[q]; }
         // the payload buffer: again decided together (a rank without it cannot take part in the broadcasts)
-        S->xbuf_ok[r] = hipMalloc((void **)&d_all, total ? total : 1) == hipSuccess ? 1 : 0;
+        S->pbuf_ok[r] = hipMalloc((void **)&d_all, total ? total : 1) == hipSuccess ? 1 : 0;
         S->bar.wait();
         bool all_have = true;
-        for (int q = 0; q < S->ndev; ++q) if (!S->xbuf_ok[q]) all_have = false;
+        for (int q = 0; q < S->ndev; ++q) if (!S->pbuf_ok[q]) all_have = false;
         if (!all_have) cfail(true);
         else {
             bool bad = false;
@@ -266,7 +267,7 @@ extern "C" unsigned char *sz_slab_compress_multi(int dataType, void *data, size_
     }
     shared_t S;
     S.ndev = ndev; S.bar.n = ndev;
-    S.lo.assign(ndev, 0); S.hi.assign(ndev, 0); S.xbuf_ok.assign(ndev, 0); S.streams.assign(ndev, nullptr); S.bytes.assign(ndev, 0); S.rc.assign(ndev, SZ_NSCS); S.t_compress.assign(ndev, 0);
+    S.lo.assign(ndev, 0); S.hi.assign(ndev, 0); S.xbuf_ok.assign(ndev, 0); S.pbuf_ok.assign(ndev, 0); S.streams.assign(ndev, nullptr); S.bytes.assign(ndev, 0); S.rc.assign(ndev, SZ_NSCS); S.t_compress.assign(ndev, 0);
     const char *no = getenv("SZ_SLAB_NO_RCCL");
     if (distinct && !(no && atoi(no)) && S.api.load()) {
         if (C && C->rccl) { S.comms = C->comms; S.rccl = true; }      // the communicator of the last call with these devices
