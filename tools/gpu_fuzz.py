@@ -29,9 +29,13 @@ for c in range(ncases):
     dt = np.float32 if rng.random() < 0.6 else np.float64
     shape = tuple(int(x) for x in rng.integers(2, 72, size=3))
     if rng.random() < 0.2: shape = (shape[0], shape[1], int(rng.integers(60, 200)))
-    two_d = rng.random() < 0.3     # a 2-D array: generated as one plane of the 3-D field
+    big = int(os.environ.get("FUZZ_MAXDIM", "0"))      # larger 3-D arrays (many tiles of the sweep, many segments of the packing passes): every case 3-D, rows a multiple of 4 values two times in three
+    if big:
+        shape = tuple(int(x) for x in rng.integers(20, big, size=3))
+        if rng.random() < 0.67: shape = (shape[0], shape[1], (shape[2] + 3) // 4 * 4)
+    two_d = rng.random() < 0.3 and not big     # a 2-D array: generated as one plane of the 3-D field
     if two_d: shape = (1, int(rng.integers(2, 150)), int(rng.integers(2, 300)))
-    one_d = rng.random() < 0.15    # a 1-D array: one row of the field
+    one_d = rng.random() < 0.15 and not big    # a 1-D array: one row of the field
     if one_d: two_d = False; shape = (1, 1, int(rng.integers(2, 20000)))
     if shape[0] * shape[1] * shape[2] <= 20: continue
     kind = int(rng.integers(0, 8))
